@@ -1,0 +1,132 @@
+/*
+ * sassy_hip.h -- additive C-ABI of libsassy_hip.so (everything the reference exposes only
+ * through its Rust API, plus the device-resident entry points the benchmark and the multi-GPU
+ * driver need).  Plain pointers and sizes only; no torch / C++ types.
+ *
+ * Conventions: functions returning int return 0 on success and a negative code on error;
+ * sassy_hip_last_error() then holds a message (thread-local).  Nothing here falls back to a CPU
+ * implementation: without a usable HIP device the search calls fail with SASSY_HIP_ENODEVICE.
+ */
+#ifndef SASSY_HIP_H
+#define SASSY_HIP_H
+
+#include "sassy.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SASSY_HIP_EINVAL (-1)    /* bad argument (null pointer, invalid pattern, ...) */
+#define SASSY_HIP_ENODEVICE (-2) /* no usable HIP device / HIP runtime error */
+#define SASSY_HIP_EUNSUPPORTED (-3)
+#define SASSY_HIP_ENOMEM (-4)
+
+/* search flags */
+#define SASSY_HIP_ALL_MINIMA 1u     /* Searcher::search_all (src/search.rs:685-700) */
+#define SASSY_HIP_WITHOUT_TRACE 2u  /* Searcher::without_trace (src/search.rs:448-451,1464-1475) */
+#define SASSY_HIP_TEXT_ON_DEVICE 4u /* `text` is a device pointer (e.g. a torch tensor's data_ptr) */
+
+/* Full match record = reference Match (src/search.rs:35-62).  cigar is the SAM text the
+ * reference's Cigar::to_string gives ("3=1X"), stored in the result's string pool.
+ * without_trace: text_start = pattern_start = UINT64_MAX and an empty cigar, as the reference. */
+typedef struct sassy_hip_Match {
+  uint64_t pattern_idx;
+  uint64_t text_idx;
+  uint64_t text_start;
+  uint64_t text_end;
+  uint64_t pattern_start;
+  uint64_t pattern_end;
+  int32_t cost;
+  uint8_t strand; /* 0 = Fwd, 1 = Rc */
+  uint8_t pad_[3];
+  uint32_t cigar_off; /* offset of the NUL-terminated cigar string in the pool */
+  uint32_t cigar_len;
+} sassy_hip_Match;
+
+typedef struct sassy_hip_Result sassy_hip_Result;       /* opaque, owns matches + cigar pool */
+typedef struct sassy_hip_Encoded sassy_hip_Encoded;     /* opaque EncodedPatterns */
+
+/* Per-call statistics of the last search on a searcher (for bench.py's roofline object). */
+typedef struct sassy_hip_Stats {
+  double scan_ms;        /* HIP-event time of the scan kernel launch(es), all strands */
+  double trace_ms;       /* HIP-event time of candidate gathering / traceback kernels */
+  double total_ms;       /* host wall time of the whole call */
+  uint64_t text_bytes;   /* algorithmic bytes scanned (text_len per strand) */
+  uint64_t scan_launches;
+  uint64_t candidates;   /* (end_pos, cost) records produced by the scan */
+  uint64_t cond_resolved;/* candidates whose plateau-entry direction needed the chunk-state chain */
+  uint64_t chunks;       /* lane chunks the text was cut into */
+  uint64_t blocks;       /* 64-byte text blocks visited incl. warm-up */
+  uint64_t word_rows;    /* DP word-rows computed (0 unless the kernel was built with counters) */
+  uint32_t blocks_per_chunk;
+  uint32_t warmup_blocks;
+  uint32_t grid;
+  uint32_t pad_;
+} sassy_hip_Stats;
+
+const char *sassy_hip_last_error(void);
+const char *sassy_hip_version(void);
+int sassy_hip_device_count(void); /* number of visible HIP devices, 0 if none / no runtime */
+
+/* Mirrors Searcher::new(rc, alpha) (src/search.rs:486-503) without aborting: NULL on error. */
+sassy_SearcherType *sassy_hip_searcher_new(const char *alphabet, bool rc, float alpha);
+/* Use an existing HIP stream (hipStream_t) for all work of this searcher; NULL = own stream. */
+int sassy_hip_set_stream(sassy_SearcherType *s, void *hip_stream);
+int sassy_hip_get_stats(const sassy_SearcherType *s, sassy_hip_Stats *out);
+
+/* Searcher::search / search_all with full Match records (src/search.rs:510-525, 685-700). */
+int sassy_hip_search(sassy_SearcherType *s, const uint8_t *pattern, size_t pattern_len,
+                     const uint8_t *text, size_t text_len, size_t k, uint32_t flags,
+                     sassy_hip_Result **out);
+
+/* One shard of a larger text that lives on this device (multi-GPU).
+ * d_text points at the first byte of the halo; the shard owns global end positions whose
+ * 64-byte block lies in [global_offset, global_offset + shard_len); halo_len bytes precede it
+ * (halo_len = 0 for the first shard, otherwise >= sassy_hip_required_halo(m, k); halo_len,
+ * global_offset and -- except for the last shard -- shard_len are multiples of 64).
+ * total_len is the length of the whole text (the end-of-text rule is applied by the shard that
+ * contains it).  Matches carry global coordinates.  Forward strand only. */
+int sassy_hip_search_shard(sassy_SearcherType *s, const uint8_t *pattern, size_t pattern_len,
+                           const uint8_t *d_text, uint64_t halo_len, uint64_t shard_len,
+                           uint64_t global_offset, uint64_t total_len, size_t k, uint32_t flags,
+                           sassy_hip_Result **out);
+uint64_t sassy_hip_required_halo(size_t pattern_len, size_t k);
+
+size_t sassy_hip_result_len(const sassy_hip_Result *r);
+const sassy_hip_Match *sassy_hip_result_matches(const sassy_hip_Result *r);
+const char *sassy_hip_result_cigars(const sassy_hip_Result *r); /* string pool */
+/* Shard bookkeeping for the cross-shard plateau rule (see DESIGN.md "seams"):
+ * entry_state: 0 = the shard's first report did not depend on the previous shard,
+ *              1 = it did (the record with SASSY flag is still in the result, marked below);
+ * exit_state:  0 = decreasing FALSE, 1 = decreasing TRUE, 2 = PASS (undetermined, inherit). */
+int sassy_hip_result_exit_state(const sassy_hip_Result *r);
+int64_t sassy_hip_result_conditional_index(const sassy_hip_Result *r); /* -1 if none */
+void sassy_hip_result_free(sassy_hip_Result *r);
+
+/* Searcher::encode_patterns / search_encoded_patterns (src/search.rs:404-423):
+ * npat patterns of equal length plen (<= 64) stored back to back. */
+sassy_hip_Encoded *sassy_hip_encode_patterns(sassy_SearcherType *s, const uint8_t *patterns,
+                                             size_t npat, size_t plen);
+void sassy_hip_encoded_free(sassy_hip_Encoded *e);
+int sassy_hip_search_encoded(sassy_SearcherType *s, const sassy_hip_Encoded *e,
+                             const uint8_t *text, size_t text_len, size_t k, uint32_t flags,
+                             sassy_hip_Result **out);
+
+/* Synthetic inputs generated in place on the device; same function as
+ * oracle/sassy_oracle.c:orc_generate_dna / orc_plant_window, checked byte for byte in tests. */
+int sassy_hip_generate_dna(uint8_t *d_text, uint64_t n, uint64_t seed, uint64_t first,
+                           void *hip_stream);
+int sassy_hip_plant(uint8_t *d_text, uint64_t n, uint64_t first, uint64_t total_n, uint64_t seed,
+                    const uint8_t *pattern, size_t pattern_len, size_t k, uint64_t stride,
+                    void *hip_stream, uint64_t *planted);
+
+/* Plain device memory helpers so that non-torch callers (C, tests) can use the device paths. */
+void *sassy_hip_malloc(size_t bytes);
+void sassy_hip_free(void *d_ptr);
+int sassy_hip_memcpy_h2d(void *d_dst, const void *h_src, size_t bytes);
+int sassy_hip_memcpy_d2h(void *h_dst, const void *d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SASSY_HIP_H */

@@ -1,0 +1,379 @@
+"""sassy_amd -- MI355X-native drop-in for sassy's bit-parallel search path.
+
+The product is ``sassy_amd/lib/libsassy_hip.so`` (hand-written HIP for gfx950 behind the C-ABI of
+``include/sassy.h`` / ``include/sassy_hip.h``).  This package is the thin Python host mirror of
+the reference's Python / Rust searcher interface for that path:
+
+    reference (src/python.rs:26-220)            here
+    sassy.Searcher(alphabet, rc, alpha)     ->  sassy_amd.Searcher(alphabet, rc, alpha)
+    .search(pattern, text, k)               ->  .search(pattern, text, k)
+    .search_all(pattern, text, k)           ->  .search_all(pattern, text, k)
+    Searcher::encode_patterns / search_encoded_patterns (src/search.rs:404-423)
+                                            ->  .encode_patterns(...) / .search_encoded_patterns(...)
+    Match getters pattern_idx, text_start, text_end, pattern_start, pattern_end, cost,
+    strand ('+'/'-'), cigar                 ->  the same attribute names
+
+There is no CPU implementation in here: without the compiled library or without a HIP device
+every search raises ``SassyHipError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "lib", "libsassy_hip.so")
+
+ALL_MINIMA = 1
+WITHOUT_TRACE = 2
+TEXT_ON_DEVICE = 4
+UINT64_MAX = (1 << 64) - 1
+
+
+class SassyHipError(RuntimeError):
+    pass
+
+
+class CMatch(C.Structure):
+    """include/sassy.h: sassy_Match (40 bytes, align 8)."""
+    _fields_ = [
+        ("text_start", C.c_size_t),
+        ("text_end", C.c_size_t),
+        ("pattern_start", C.c_size_t),
+        ("pattern_end", C.c_size_t),
+        ("cost", C.c_int32),
+        ("strand", C.c_uint8),
+    ]
+
+
+class _HipMatch(C.Structure):
+    _fields_ = [
+        ("pattern_idx", C.c_uint64),
+        ("text_idx", C.c_uint64),
+        ("text_start", C.c_uint64),
+        ("text_end", C.c_uint64),
+        ("pattern_start", C.c_uint64),
+        ("pattern_end", C.c_uint64),
+        ("cost", C.c_int32),
+        ("strand", C.c_uint8),
+        ("pad_", C.c_uint8 * 3),
+        ("cigar_off", C.c_uint32),
+        ("cigar_len", C.c_uint32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("scan_ms", C.c_double),
+        ("trace_ms", C.c_double),
+        ("total_ms", C.c_double),
+        ("text_bytes", C.c_uint64),
+        ("scan_launches", C.c_uint64),
+        ("candidates", C.c_uint64),
+        ("cond_resolved", C.c_uint64),
+        ("chunks", C.c_uint64),
+        ("blocks", C.c_uint64),
+        ("word_rows", C.c_uint64),
+        ("blocks_per_chunk", C.c_uint32),
+        ("warmup_blocks", C.c_uint32),
+        ("grid", C.c_uint32),
+        ("pad_", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_ if f != "pad_"}
+
+
+# every symbol include/sassy.h and include/sassy_hip.h declare
+EXPORTED_SYMBOLS = [
+    "sassy_searcher", "sassy_searcher_free", "search", "sassy_matches_free",
+    "sassy_hip_last_error", "sassy_hip_version", "sassy_hip_device_count",
+    "sassy_hip_searcher_new", "sassy_hip_set_stream", "sassy_hip_get_stats",
+    "sassy_hip_search", "sassy_hip_search_shard", "sassy_hip_required_halo",
+    "sassy_hip_result_len", "sassy_hip_result_matches", "sassy_hip_result_cigars",
+    "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
+    "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
+    "sassy_hip_generate_dna", "sassy_hip_plant",
+    "sassy_hip_malloc", "sassy_hip_free", "sassy_hip_memcpy_h2d", "sassy_hip_memcpy_d2h",
+]
+
+_lib = None
+
+
+def library_path() -> str:
+    return _SO
+
+
+def lib():
+    """The loaded C-ABI library.  Fails loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise SassyHipError(
+            f"{_SO} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc, gfx950).  There is no pure-Python / CPU fallback for the search path.")
+    L = C.CDLL(_SO)
+    vp, u8p, sz = C.c_void_p, C.c_char_p, C.c_size_t
+    L.sassy_hip_last_error.restype = C.c_char_p
+    L.sassy_hip_version.restype = C.c_char_p
+    L.sassy_hip_device_count.restype = C.c_int
+    L.sassy_hip_searcher_new.restype = vp
+    L.sassy_hip_searcher_new.argtypes = [C.c_char_p, C.c_bool, C.c_float]
+    L.sassy_searcher.restype = vp
+    L.sassy_searcher.argtypes = [C.c_char_p, C.c_bool, C.c_float]
+    L.sassy_searcher_free.restype = None
+    L.sassy_searcher_free.argtypes = [vp]
+    L.search.restype = sz
+    L.search.argtypes = [vp, u8p, sz, u8p, sz, sz, C.POINTER(C.POINTER(CMatch))]
+    L.sassy_matches_free.restype = None
+    L.sassy_matches_free.argtypes = [C.POINTER(CMatch), sz]
+    L.sassy_hip_set_stream.restype = C.c_int
+    L.sassy_hip_set_stream.argtypes = [vp, vp]
+    L.sassy_hip_get_stats.restype = C.c_int
+    L.sassy_hip_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.sassy_hip_enable_counters.restype = C.c_int
+    L.sassy_hip_enable_counters.argtypes = [vp, C.c_int]
+    L.sassy_hip_search.restype = C.c_int
+    L.sassy_hip_search.argtypes = [vp, u8p, sz, vp, sz, sz, C.c_uint32, C.POINTER(vp)]
+    L.sassy_hip_search_shard.restype = C.c_int
+    L.sassy_hip_search_shard.argtypes = [vp, u8p, sz, vp, C.c_uint64, C.c_uint64, C.c_uint64,
+                                         C.c_uint64, sz, C.c_uint32, C.POINTER(vp)]
+    L.sassy_hip_required_halo.restype = C.c_uint64
+    L.sassy_hip_required_halo.argtypes = [sz, sz]
+    L.sassy_hip_result_len.restype = sz
+    L.sassy_hip_result_len.argtypes = [vp]
+    L.sassy_hip_result_matches.restype = C.POINTER(_HipMatch)
+    L.sassy_hip_result_matches.argtypes = [vp]
+    L.sassy_hip_result_cigars.restype = vp
+    L.sassy_hip_result_cigars.argtypes = [vp]
+    L.sassy_hip_result_exit_state.restype = C.c_int
+    L.sassy_hip_result_exit_state.argtypes = [vp]
+    L.sassy_hip_result_conditional_index.restype = C.c_int64
+    L.sassy_hip_result_conditional_index.argtypes = [vp]
+    L.sassy_hip_result_free.restype = None
+    L.sassy_hip_result_free.argtypes = [vp]
+    L.sassy_hip_encode_patterns.restype = vp
+    L.sassy_hip_encode_patterns.argtypes = [vp, u8p, sz, sz]
+    L.sassy_hip_encoded_free.restype = None
+    L.sassy_hip_encoded_free.argtypes = [vp]
+    L.sassy_hip_search_encoded.restype = C.c_int
+    L.sassy_hip_search_encoded.argtypes = [vp, vp, vp, sz, sz, C.c_uint32, C.POINTER(vp)]
+    L.sassy_hip_generate_dna.restype = C.c_int
+    L.sassy_hip_generate_dna.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+    L.sassy_hip_plant.restype = C.c_int
+    L.sassy_hip_plant.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, u8p, sz, sz,
+                                  C.c_uint64, vp, C.POINTER(C.c_uint64)]
+    L.sassy_hip_malloc.restype = vp
+    L.sassy_hip_malloc.argtypes = [sz]
+    L.sassy_hip_free.restype = None
+    L.sassy_hip_free.argtypes = [vp]
+    L.sassy_hip_memcpy_h2d.restype = C.c_int
+    L.sassy_hip_memcpy_h2d.argtypes = [vp, vp, sz]
+    L.sassy_hip_memcpy_d2h.restype = C.c_int
+    L.sassy_hip_memcpy_d2h.argtypes = [vp, vp, sz]
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise SassyHipError(f"libsassy_hip error {rc}: {lib().sassy_hip_last_error().decode()}")
+
+
+def device_count() -> int:
+    return lib().sassy_hip_device_count()
+
+
+@dataclass(frozen=True)
+class Match:
+    """Reference Match (src/search.rs:35-62) with the Python getters' conventions
+    (src/python.rs:157-203): strand is '+' or '-', cigar is the SAM string."""
+    pattern_idx: int
+    text_start: int
+    text_end: int
+    pattern_start: int
+    pattern_end: int
+    cost: int
+    strand: str
+    cigar: str
+    text_idx: int = 0
+
+    def sort_key(self):
+        return (self.pattern_idx, self.text_start, self.text_end, self.cost, self.strand, self.cigar)
+
+
+class Result:
+    """Matches of one call plus the shard bookkeeping (see include/sassy_hip.h)."""
+
+    def __init__(self, handle):
+        L = lib()
+        try:
+            n = L.sassy_hip_result_len(handle)
+            ms = L.sassy_hip_result_matches(handle)
+            pool = L.sassy_hip_result_cigars(handle)
+            self.matches: List[Match] = []
+            for i in range(n):
+                m = ms[i]
+                cig = C.string_at(pool + m.cigar_off, m.cigar_len).decode() if m.cigar_len else ""
+                self.matches.append(Match(m.pattern_idx, m.text_start, m.text_end, m.pattern_start,
+                                          m.pattern_end, m.cost, "-" if m.strand else "+", cig,
+                                          m.text_idx))
+            self.exit_state = L.sassy_hip_result_exit_state(handle)
+            self.conditional_index = L.sassy_hip_result_conditional_index(handle)
+        finally:
+            L.sassy_hip_result_free(handle)
+
+
+def _ptr_len(text):
+    """(address, length, keepalive, on_device) for bytes / numpy uint8 / torch uint8 tensors."""
+    if isinstance(text, (bytes, bytearray)):
+        b = bytes(text)
+        return C.cast(C.c_char_p(b), C.c_void_p).value or 0, len(b), b, False
+    if hasattr(text, "data_ptr"):  # torch tensor
+        if text.dtype.itemsize != 1 or not text.is_contiguous():
+            raise SassyHipError("text tensor must be contiguous uint8")
+        return text.data_ptr(), text.numel(), text, text.is_cuda
+    if hasattr(text, "ctypes"):  # numpy
+        import numpy as np
+        a = np.ascontiguousarray(text, dtype=np.uint8)
+        return a.ctypes.data, a.size, a, False
+    raise TypeError("text must be bytes, a numpy uint8 array or a torch uint8 tensor")
+
+
+class EncodedPatterns:
+    """Reference EncodedPatterns (src/pattern_tiling/general.rs:132-150), opaque."""
+
+    def __init__(self, handle, n, plen):
+        self._h, self.n_patterns, self.pattern_len = handle, n, plen
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sassy_hip_encoded_free(self._h)
+            self._h = None
+
+
+class Searcher:
+    """Mirror of sassy.Searcher (src/python.rs:26-64) / Searcher::<P>::new (src/search.rs:486-503).
+
+    Note the reference's Python default rc=True; ``new_fwd``-style searchers pass rc=False."""
+
+    def __init__(self, alphabet: str, rc: bool = True, alpha: Optional[float] = None):
+        L = lib()
+        a = float("nan") if alpha is None else float(alpha)
+        self._h = L.sassy_hip_searcher_new(alphabet.encode(), bool(rc), a)
+        if not self._h:
+            raise SassyHipError(L.sassy_hip_last_error().decode())
+        self.alphabet, self.rc = alphabet.lower(), bool(rc)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().sassy_searcher_free(self._h)
+            self._h = None
+
+    # --- reference API ---
+    def search(self, pattern: bytes, text, k: int) -> List[Match]:
+        return self._search(pattern, text, k, 0).matches
+
+    def search_all(self, pattern: bytes, text, k: int) -> List[Match]:
+        return self._search(pattern, text, k, ALL_MINIMA).matches
+
+    def search_without_trace(self, pattern: bytes, text, k: int) -> List[Match]:
+        return self._search(pattern, text, k, WITHOUT_TRACE).matches
+
+    def encode_patterns(self, patterns: Sequence[bytes]) -> EncodedPatterns:
+        patterns = [bytes(p) for p in patterns]
+        if not patterns:
+            raise SassyHipError("No queries provided")
+        plen = len(patterns[0])
+        if any(len(p) != plen for p in patterns):
+            raise SassyHipError("All pattern must have the same length")
+        h = lib().sassy_hip_encode_patterns(self._h, b"".join(patterns), len(patterns), plen)
+        if not h:
+            raise SassyHipError(lib().sassy_hip_last_error().decode())
+        return EncodedPatterns(h, len(patterns), plen)
+
+    def search_encoded_patterns(self, encoded: EncodedPatterns, text, k: int,
+                                all_minima: bool = False) -> List[Match]:
+        addr, n, keep, on_dev = _ptr_len(text)
+        out = C.c_void_p()
+        flags = (ALL_MINIMA if all_minima else 0) | (TEXT_ON_DEVICE if on_dev else 0)
+        _check(lib().sassy_hip_search_encoded(self._h, encoded._h, addr, n, k, flags, C.byref(out)))
+        return Result(out).matches
+
+    # --- device-resident / multi-GPU entry points ---
+    def search_shard(self, pattern: bytes, d_text_ptr: int, halo_len: int, shard_len: int,
+                     global_offset: int, total_len: int, k: int, flags: int = 0) -> Result:
+        out = C.c_void_p()
+        pattern = bytes(pattern)
+        _check(lib().sassy_hip_search_shard(self._h, pattern, len(pattern), d_text_ptr, halo_len,
+                                            shard_len, global_offset, total_len, k, flags,
+                                            C.byref(out)))
+        return Result(out)
+
+    def set_stream(self, hip_stream_handle: int):
+        _check(lib().sassy_hip_set_stream(self._h, hip_stream_handle or None))
+
+    def enable_counters(self, on: bool = True):
+        _check(lib().sassy_hip_enable_counters(self._h, int(on)))
+
+    def stats(self) -> dict:
+        st = Stats()
+        _check(lib().sassy_hip_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def _search(self, pattern: bytes, text, k: int, flags: int) -> Result:
+        pattern = bytes(pattern)
+        addr, n, keep, on_dev = _ptr_len(text)
+        if on_dev:
+            flags |= TEXT_ON_DEVICE
+        out = C.c_void_p()
+        _check(lib().sassy_hip_search(self._h, pattern, len(pattern), addr, n, k, flags, C.byref(out)))
+        return Result(out)
+
+
+def required_halo(pattern_len: int, k: int) -> int:
+    return lib().sassy_hip_required_halo(pattern_len, k)
+
+
+def generate_dna(d_ptr: int, n: int, seed: int, first: int = 0, stream: int = 0):
+    """Fill device memory [d_ptr, d_ptr+n) with the synthetic ACGT text."""
+    _check(lib().sassy_hip_generate_dna(d_ptr, n, seed, first, stream or None))
+
+
+def plant(d_ptr: int, n: int, first: int, total_n: int, seed: int, pattern: bytes, k: int,
+          stride: int = 1 << 20, stream: int = 0) -> int:
+    cnt = C.c_uint64()
+    pattern = bytes(pattern)
+    _check(lib().sassy_hip_plant(d_ptr, n, first, total_n, seed, pattern, len(pattern), k, stride,
+                                 stream or None, C.byref(cnt)))
+    return cnt.value
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes for callers without torch (tests, C-style use)."""
+
+    def __init__(self, nbytes: int):
+        self.nbytes = nbytes
+        self.ptr = lib().sassy_hip_malloc(nbytes)
+        if not self.ptr:
+            raise SassyHipError(lib().sassy_hip_last_error().decode())
+
+    def upload(self, data: bytes, offset: int = 0):
+        _check(lib().sassy_hip_memcpy_h2d(self.ptr + offset, data, len(data)))
+
+    def download(self, nbytes: Optional[int] = None, offset: int = 0) -> bytes:
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        buf = C.create_string_buffer(nbytes)
+        _check(lib().sassy_hip_memcpy_d2h(buf, self.ptr + offset, nbytes))
+        return buf.raw
+
+    def free(self):
+        if self.ptr:
+            lib().sassy_hip_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        self.free()

@@ -1,0 +1,132 @@
+// aux_kernels.hip -- small device helpers around the scan kernel: synthetic text generator,
+// plant scatter, text reversal for the reverse-complement strand, window gather for traceback.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace sassy_hip {
+
+// ---------------------------------------------------------------- synthetic text
+// byte i = "ACGT"[(h(seed, i>>5) >> (2*(i&31))) & 3], h = splitmix64(seed*0x9E3779B97F4A7C15 + (i>>5)).
+// The CPU twin used by the tests is oracle/sassy_oracle.c:orc_generate_dna.
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+// One thread per 32-character hash block (32 output bytes, written as two 16-byte stores when the
+// destination is aligned and fully inside the buffer).
+__global__ __launch_bounds__(256) void generate_dna_kernel(uint8_t* out, uint64_t n, uint64_t seed,
+                                                           uint64_t first) {
+  const uint64_t nb = (first + n + 31) / 32 - first / 32;  // hash blocks touched
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nb; t += stride) {
+    const uint64_t hb = first / 32 + t;
+    const uint64_t h = splitmix64(seed * 0x9E3779B97F4A7C15ull + hb);
+    // 32 chars; char c of the block: "ACGT"[(h >> 2c) & 3].  'A'=0x41 'C'=0x43 'G'=0x47 'T'=0x54
+    uint32_t w[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      uint32_t v = 0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const uint32_t code = (uint32_t)(h >> (2 * (4 * q + b))) & 3u;
+        const uint32_t ch = (0x54474341u >> (8 * code)) & 0xFFu;
+        v |= ch << (8 * b);
+      }
+      w[q] = v;
+    }
+    const uint64_t g0 = hb * 32;  // global index of the block's first char
+    if (g0 >= first && g0 + 32 <= first + n && (((uintptr_t)(out + (g0 - first))) & 15) == 0) {
+      uint4* dst = reinterpret_cast<uint4*>(out + (g0 - first));
+      dst[0] = make_uint4(w[0], w[1], w[2], w[3]);
+      dst[1] = make_uint4(w[4], w[5], w[6], w[7]);
+    } else {
+      for (int c = 0; c < 32; ++c) {
+        const uint64_t g = g0 + c;
+        if (g >= first && g < first + n) out[g - first] = (uint8_t)((w[c >> 2] >> (8 * (c & 3))) & 0xFFu);
+      }
+    }
+  }
+}
+
+// text[pos[i] - first] = val[i] for the planted bytes that fall into [first, first + n)
+__global__ void scatter_bytes_kernel(uint8_t* text, uint64_t n, uint64_t first, const uint64_t* pos,
+                                     const uint8_t* val, uint64_t count) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint64_t p = pos[i];
+  if (p >= first && p < first + n) text[p - first] = val[i];
+}
+
+// out[i] = in[n-1-i]   (the reference searches complement(pattern) against the reversed text for
+// the Rc strand, reference: src/search.rs:813-858).  16 output bytes per thread.
+__global__ __launch_bounds__(256) void reverse_kernel(const uint8_t* in, uint8_t* out, uint64_t n) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+  const uint64_t nv = (n + 15) / 16;
+  for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nv; t += stride) {
+    const uint64_t o0 = t * 16;
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const uint64_t o = o0 + q;
+      const uint32_t ch = o < n ? in[n - 1 - o] : 0u;
+      w[q >> 2] |= ch << (8 * (q & 3));
+    }
+    if (o0 + 16 <= n) {
+      *reinterpret_cast<uint4*>(out + o0) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+      for (int q = 0; q < 16 && o0 + q < n; ++q) out[o0 + q] = (uint8_t)((w[q >> 2] >> (8 * (q & 3))) & 0xFFu);
+    }
+  }
+}
+
+// Copy the traceback window of every candidate into a compact buffer:
+// out[c*wlen + i] = text[start[c] + i] for i < len[c].
+__global__ void gather_windows_kernel(const uint8_t* text, const uint64_t* start, const uint32_t* len,
+                                      uint32_t wlen, uint32_t count, uint8_t* out) {
+  const uint32_t c = blockIdx.x;
+  if (c >= count) return;
+  const uint64_t s = start[c];
+  const uint32_t l = len[c];
+  for (uint32_t i = threadIdx.x; i < l; i += blockDim.x) out[(uint64_t)c * wlen + i] = text[s + i];
+}
+
+// ------------------------------------------------------------------ launchers
+hipError_t launch_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first,
+                               hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const uint64_t nb = (first + n + 31) / 32 - first / 32;
+  uint64_t blocks = (nb + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(generate_dna_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_text, n, seed, first);
+  return hipGetLastError();
+}
+
+hipError_t launch_scatter_bytes(uint8_t* d_text, uint64_t n, uint64_t first, const uint64_t* d_pos,
+                                const uint8_t* d_val, uint64_t count, hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(scatter_bytes_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, stream,
+                     d_text, n, first, d_pos, d_val, count);
+  return hipGetLastError();
+}
+
+hipError_t launch_reverse(const uint8_t* d_in, uint8_t* d_out, uint64_t n, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  uint64_t blocks = ((n + 15) / 16 + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(reverse_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_in, d_out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_windows(const uint8_t* d_text, const uint64_t* d_start, const uint32_t* d_len,
+                                 uint32_t wlen, uint32_t count, uint8_t* d_out, hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_windows_kernel, dim3(count), dim3(64), 0, stream, d_text, d_start, d_len,
+                     wlen, count, d_out);
+  return hipGetLastError();
+}
+
+}  // namespace sassy_hip

@@ -1,0 +1,57 @@
+// common.h -- structs shared by the host side and the HIP kernels of libsassy_hip.so.
+#pragma once
+#include <cstdint>
+
+namespace sassy_hip {
+
+enum Profile : uint32_t { PROFILE_ASCII = 0, PROFILE_DNA = 1, PROFILE_IUPAC = 2 };
+
+constexpr int kWave = 64;              // gfx950 wavefront
+constexpr int kWavesPerGroup = 4;      // 256-thread workgroups, every wave works alone
+constexpr int kTileBytes = 64 * 128;   // text tile of one wave: 64 lane chunks x 2 blocks x 64 B
+constexpr int kMaxSlots = 32;          // profile slots (distinct pattern letters) per search
+constexpr int kGroupHeaderBytes = 64;  // IUPAC letter -> base-set table at the start of LDS
+
+// candidate flags
+constexpr uint32_t kCandCond = 1u;     // report depends on the plateau-entry direction left of the chunk
+// chunk exit states
+constexpr uint8_t kStateDecFalse = 0, kStateDecTrue = 1, kStatePass = 2;
+
+// scan flags
+constexpr uint32_t kScanAllMinima = 1u;  // report every end position with cost <= k
+constexpr uint32_t kScanTextStart = 2u;  // buffer byte 0 is the true start of the text (column 0)
+constexpr uint32_t kScanTextEnd = 4u;    // buffer end is the true end of the text
+
+// One (end position, cost) report of the scan kernel.  16 bytes.
+struct Candidate {
+  uint64_t pos;   // global end position (exclusive end of the match in the text)
+  int32_t cost;
+  uint32_t flags;
+};
+
+struct ScanParams {
+  const uint8_t* text;        // device: first byte of the buffer (halo first, 16-byte aligned)
+  uint64_t text_len;          // bytes in the buffer
+  uint64_t n_blocks;          // ceil(text_len / 64)
+  uint64_t first_owned_block; // halo_len / 64
+  uint64_t global_offset;     // global position of text[0]
+  uint64_t n_chunks;          // lane chunks covering [first_owned_block, n_blocks)
+  uint32_t bpl;               // owned blocks per lane chunk
+  uint32_t wb;                // warm-up blocks in front of every chunk: 64*wb >= m+k+1
+  uint32_t m, k;
+  uint32_t nwords;            // ceil(m / 32): 32 pattern rows per carry word
+  uint32_t nslots;
+  uint32_t flags;
+  uint32_t profile;           // Profile enum
+  uint32_t lds_per_wave;      // bytes
+  uint32_t cand_cap;
+  uint32_t n_iter;            // iterations of the block loop
+  const uint32_t* row_off;    // device, m entries: byte offset of the row's slot mask = slot*512
+  Candidate* cand;            // device, cand_cap entries
+  uint32_t* cand_count;       // device counter (keeps counting past cand_cap)
+  uint8_t* chunk_state;       // device, n_chunks entries
+  unsigned long long* counters; // optional device counters [0]=word rows, [1]=blocks; may be null
+  uint8_t slot_val[kMaxSlots]; // per slot: Dna 2-bit code, Iupac base-set nibble, Ascii byte
+};
+
+}  // namespace sassy_hip

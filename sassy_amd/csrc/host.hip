@@ -1,0 +1,917 @@
+// host.hip -- host side of libsassy_hip.so: the Searcher (mirror of the reference's
+// Searcher<P>, reference: src/search.rs:227-937) and the C-ABI of include/sassy.h + sassy_hip.h.
+//
+// Division of labour: the HIP kernels find every reported (end position, cost); the host sorts
+// the (rare) records, resolves the plateau-entry chain across lane chunks, and turns each record
+// into a Match with the reference's traceback rules.  There is no CPU scan path: if the device
+// is unusable every search entry point fails (additive API) or aborts (drop-in API).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sassy_hip.h"
+#include "common.h"
+#include "profiles.h"
+
+namespace sassy_hip {
+
+// kernel launchers (scan_kernel.hip is compiled once per profile; aux_kernels.hip)
+hipError_t launch_scan_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
+hipError_t launch_scan_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
+hipError_t launch_scan_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
+hipError_t launch_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first, hipStream_t stream);
+hipError_t launch_scatter_bytes(uint8_t* d_text, uint64_t n, uint64_t first, const uint64_t* d_pos,
+                                const uint8_t* d_val, uint64_t count, hipStream_t stream);
+hipError_t launch_reverse(const uint8_t* d_in, uint8_t* d_out, uint64_t n, hipStream_t stream);
+hipError_t launch_gather_windows(const uint8_t* d_text, const uint64_t* d_start, const uint32_t* d_len,
+                                 uint32_t wlen, uint32_t count, uint8_t* d_out, hipStream_t stream);
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+static int hip_fail(hipError_t e, const char* what) {
+  return fail(SASSY_HIP_ENODEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                   \
+  do {                                                  \
+    hipError_t e_ = (expr);                             \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr);   \
+  } while (0)
+
+// A growable device buffer.
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t cap = 0;  // elements
+  int reserve(size_t n) {
+    if (n <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = n + n / 8 + 64;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p), want * sizeof(T));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc");
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+struct MatchRec {
+  uint64_t pattern_idx = 0, text_idx = 0;
+  uint64_t text_start = 0, text_end = 0, pattern_start = 0, pattern_end = 0;
+  int32_t cost = 0;
+  uint8_t strand = 0;
+  std::string cigar;  // SAM text, e.g. "3=1X"
+};
+
+}  // namespace sassy_hip
+
+using namespace sassy_hip;
+
+struct sassy_hip_Result {
+  std::vector<sassy_hip_Match> matches;
+  std::string pool;
+  int exit_state = kStateDecTrue;
+  int64_t conditional_index = -1;
+};
+
+struct sassy_hip_Encoded {
+  Profile profile;
+  bool rc;
+  size_t plen;
+  std::vector<std::vector<uint8_t>> patterns;  // originals, then (if rc) their reverse complements
+  size_t n_original;
+};
+
+// The searcher.  Mirrors the configuration surface of the reference's Searcher<P>
+// (rc, alpha; reference: src/search.rs:227-256, 486-503) and caches device buffers the way the
+// reference caches its host buffers.
+struct sassy_SearcherType {
+  Profile profile = PROFILE_DNA;
+  bool rc = false;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  bool device_ready = false;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
+  DevBuf<uint8_t> d_text, d_rev, d_state, d_win, d_pbytes;
+  DevBuf<uint32_t> d_rowoff, d_count, d_wlen;
+  DevBuf<Candidate> d_cand;
+  DevBuf<uint64_t> d_wstart, d_ppos;
+  DevBuf<unsigned long long> d_counters;
+  bool want_counters = false;
+  sassy_hip_Stats stats{};
+
+  ~sassy_SearcherType() {
+    d_text.release(); d_rev.release(); d_state.release(); d_win.release(); d_pbytes.release();
+    d_rowoff.release(); d_count.release(); d_wlen.release(); d_cand.release();
+    d_wstart.release(); d_ppos.release(); d_counters.release();
+    if (ev_a) (void)hipEventDestroy(ev_a);
+    if (ev_b) (void)hipEventDestroy(ev_b);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+
+  int ensure_device() {
+    if (device_ready) return 0;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+      return fail(SASSY_HIP_ENODEVICE,
+                  "no usable HIP device (libsassy_hip has no CPU fallback; the scan runs on gfx950 only)");
+    if (!stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      own_stream = true;
+    }
+    HIP_TRY(hipEventCreate(&ev_a));
+    HIP_TRY(hipEventCreate(&ev_b));
+    device_ready = true;
+    return 0;
+  }
+};
+
+namespace sassy_hip {
+
+// ------------------------------------------------------------------ traceback (host)
+// Window w = text[o .. min(e, n)), o = max(0, e - (m+k)) (reference: src/search.rs:1477-1478);
+// local matrix L[j][0] = j, L[0][i] = 0 (reference: src/trace.rs:80-103); greedy walk from
+// (m, e-o) preferring '=', 'X', 'D', 'I' (reference: src/trace.rs:337-365).  The walk only ever
+// visits cells of optimal alignments, all of which lie on diagonals [0, 2k] of the window, so a
+// band of those diagonals (+1 on each side, values saturated at k+1) reproduces the full-matrix
+// walk exactly (DESIGN.md "traceback").
+struct TraceOut {
+  uint64_t text_start = 0;
+  int32_t cost = 0;
+  std::string ops;  // one char per alignment column, pattern direction
+  bool ok = false;
+};
+
+static TraceOut trace_window(Profile pr, const uint8_t* pat, size_t m, const uint8_t* win, size_t wl,
+                             uint64_t o, int k) {
+  TraceOut out;
+  // band: cell (j, i) with d = i - j + shift, shift chosen so that the end cell (m, wl) sits at
+  // d = k+1 when wl = m+k; the window may be shorter near the start of the text.
+  const long dend = (long)wl - (long)m;          // diagonal of the end cell
+  const long dlo = dend - (long)k - 1, dhi = dend + (long)k + 1;
+  const size_t bw = (size_t)(dhi - dlo + 1);
+  const int inf = k + 1;
+  std::vector<uint16_t> L((m + 1) * bw, (uint16_t)inf);
+  auto at = [&](size_t j, long i) -> int {
+    if (i < 0 || i > (long)wl) return inf;
+    const long d = i - (long)j;
+    if (d < dlo || d > dhi) return inf;
+    return L[j * bw + (size_t)(d - dlo)];
+  };
+  auto set = [&](size_t j, long i, int v) { L[j * bw + (size_t)(i - (long)j - dlo)] = (uint16_t)v; };
+  for (size_t j = 0; j <= m; ++j) {
+    const long ilo = std::max<long>(0, (long)j + dlo), ihi = std::min<long>((long)wl, (long)j + dhi);
+    for (long i = ilo; i <= ihi; ++i) {
+      int v;
+      if (j == 0) v = 0;
+      else if (i == 0) v = (int)std::min<size_t>(j, (size_t)inf);
+      else {
+        v = at(j - 1, i - 1) + (scan_eq(pr, pat[j - 1], win[i - 1]) ? 0 : 1);
+        v = std::min(v, at(j, i - 1) + 1);
+        v = std::min(v, at(j - 1, i) + 1);
+        v = std::min(v, inf);
+      }
+      set(j, i, v);
+    }
+  }
+  size_t j = m;
+  long i = (long)wl;
+  int g = at(j, i);
+  out.cost = g;
+  if (g > k) return out;  // cannot happen for a position the scan reported
+  std::string ops;
+  while (j > 0) {
+    if (i > 0 && at(j - 1, i - 1) == g && trace_is_match(pr, pat[j - 1], win[i - 1])) {
+      ops.push_back('='); --j; --i; continue;
+    }
+    g -= 1;
+    if (g < 0) return out;
+    if (i > 0 && at(j - 1, i - 1) == g) { ops.push_back('X'); --j; --i; continue; }
+    if (i > 0 && at(j, i - 1) == g) { ops.push_back('D'); --i; continue; }
+    if (at(j - 1, i) == g) { ops.push_back('I'); --j; continue; }
+    return out;  // reference: panic "Trace failed! No ancestor found" (src/trace.rs:384-387)
+  }
+  if (g != 0) return out;
+  std::reverse(ops.begin(), ops.end());
+  out.ops = std::move(ops);
+  out.text_start = o + (uint64_t)i;
+  out.ok = true;
+  return out;
+}
+
+// pa_types::Cigar::to_string: run-length encoded "<count><op>" (SURVEY 8c).
+static std::string rle(const std::string& ops) {
+  std::string s;
+  size_t i = 0;
+  while (i < ops.size()) {
+    size_t j = i;
+    while (j < ops.size() && ops[j] == ops[i]) ++j;
+    s += std::to_string(j - i);
+    s.push_back(ops[i]);
+    i = j;
+  }
+  return s;
+}
+
+// ------------------------------------------------------------------ scan driver
+struct ShardView {
+  const uint8_t* d_text;   // device buffer (halo first)
+  uint64_t text_len;       // bytes in the buffer
+  uint64_t halo_len;       // bytes before the first owned block
+  uint64_t global_offset;  // global position of d_text[0]
+  bool text_start;         // buffer byte 0 is column 0 of the whole text
+  bool text_end;           // buffer end is the end of the whole text
+};
+
+struct ScanOut {
+  std::vector<Candidate> cands;  // sorted by pos, unconditional (COND resolved) ...
+  int64_t conditional_index = -1; // ... except this one, which depends on the previous shard
+  int exit_state = kStateDecTrue;
+  uint64_t cond_seen = 0;
+};
+
+static uint32_t warmup_blocks(uint32_t m, uint32_t k) { return (m + k + 1 + 63) / 64; }
+
+// Runs the scan kernel over one buffer and returns the resolved reports.
+static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPlan& plan, uint32_t k,
+                    bool all_minima, ScanOut& out) {
+  out = ScanOut();
+  const uint64_t n_blocks = (sh.text_len + 63) / 64;
+  const uint64_t first_owned = sh.halo_len / 64;
+  if (n_blocks <= first_owned) return 0;  // nothing owned (empty text)
+  const uint64_t owned = n_blocks - first_owned;
+
+  ScanParams P{};
+  P.text = sh.d_text;
+  P.text_len = sh.text_len;
+  P.n_blocks = n_blocks;
+  P.first_owned_block = first_owned;
+  P.global_offset = sh.global_offset;
+  P.m = plan.m;
+  P.k = k;
+  P.nwords = plan.nwords;
+  P.nslots = plan.nslots;
+  P.profile = (uint32_t)S->profile;
+  P.wb = warmup_blocks(plan.m, k);
+  // Chunk geometry: enough lanes to fill 256 CUs several times over, chunks long enough that the
+  // warm-up blocks stay a few percent of the work.
+  const uint64_t target_lanes = 256ull * 12 * 64 * 2;
+  uint64_t bpl = (owned + target_lanes - 1) / target_lanes;
+  const uint64_t min_bpl = std::max<uint64_t>(8, 6ull * P.wb);
+  if (bpl < min_bpl) bpl = min_bpl;
+  if (bpl > 0xFFFFFFFFull / 2) return fail(SASSY_HIP_EUNSUPPORTED, "text too large for one launch");
+  P.bpl = (uint32_t)bpl;
+  P.n_chunks = (owned + bpl - 1) / bpl;
+  P.n_iter = P.wb + 1 + P.bpl;
+  P.flags = (all_minima ? kScanAllMinima : 0u) | (sh.text_start ? kScanTextStart : 0u) |
+            (sh.text_end ? kScanTextEnd : 0u);
+  const uint32_t bucket = plan.nslots <= 4 ? 4 : plan.nslots <= 8 ? 8 : 16;
+  P.lds_per_wave = (uint32_t)kTileBytes + bucket * 512u + (plan.nwords > 1 ? plan.nwords * 512u : 0u);
+  const size_t smem = kGroupHeaderBytes + (size_t)kWavesPerGroup * P.lds_per_wave;
+  if (smem > 160 * 1024) return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
+  for (int s = 0; s < kMaxSlots; ++s) P.slot_val[s] = plan.slot_val[s];
+  const uint64_t groups = (P.n_chunks + 255) / 256;
+  if (groups > 0x7FFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "grid too large");
+  const uint32_t grid = (uint32_t)groups;
+
+  if (int rc = S->d_rowoff.reserve(plan.row_off.size())) return rc;
+  HIP_TRY(hipMemcpyAsync(S->d_rowoff.p, plan.row_off.data(), plan.row_off.size() * sizeof(uint32_t),
+                         hipMemcpyHostToDevice, S->stream));
+  if (int rc = S->d_state.reserve(P.n_chunks)) return rc;
+  if (int rc = S->d_count.reserve(4)) return rc;
+  if (S->d_cand.cap == 0)
+    if (int rc = S->d_cand.reserve(1u << 16)) return rc;
+  if (S->want_counters) {
+    if (int rc = S->d_counters.reserve(2)) return rc;
+    HIP_TRY(hipMemsetAsync(S->d_counters.p, 0, 2 * sizeof(unsigned long long), S->stream));
+  }
+  P.row_off = S->d_rowoff.p;
+  P.chunk_state = S->d_state.p;
+  P.cand_count = S->d_count.p;
+  P.counters = S->want_counters ? S->d_counters.p : nullptr;
+
+  uint32_t count = 0;
+  for (int attempt = 0; attempt < 3; ++attempt) {
+    P.cand = S->d_cand.p;
+    P.cand_cap = (uint32_t)std::min<size_t>(S->d_cand.cap, 0xFFFFFFFFu);
+    HIP_TRY(hipMemsetAsync(S->d_count.p, 0, sizeof(uint32_t), S->stream));
+    HIP_TRY(hipEventRecord(S->ev_a, S->stream));
+    hipError_t le;
+    switch (S->profile) {
+      case PROFILE_DNA: le = launch_scan_dna(P, grid, smem, S->stream); break;
+      case PROFILE_IUPAC: le = launch_scan_iupac(P, grid, smem, S->stream); break;
+      default: le = launch_scan_ascii(P, grid, smem, S->stream); break;
+    }
+    if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
+    HIP_TRY(hipEventRecord(S->ev_b, S->stream));
+    HIP_TRY(hipMemcpyAsync(&count, S->d_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream));
+    HIP_TRY(hipStreamSynchronize(S->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_b));
+    S->stats.scan_ms += ms;
+    S->stats.scan_launches += 1;
+    if (count <= P.cand_cap) break;
+    // more reports than the buffer holds (dense matches): grow and run again
+    if (int rc = S->d_cand.reserve((size_t)count + 1024)) return rc;
+  }
+  if (count > (uint32_t)std::min<size_t>(S->d_cand.cap, 0xFFFFFFFFu))
+    return fail(SASSY_HIP_ENOMEM, "candidate buffer overflow");
+  S->stats.chunks = P.n_chunks;
+  S->stats.blocks_per_chunk = P.bpl;
+  S->stats.warmup_blocks = P.wb;
+  S->stats.grid = grid;
+  S->stats.text_bytes += sh.text_len - sh.halo_len;
+  if (S->want_counters) {
+    unsigned long long c[2] = {0, 0};
+    HIP_TRY(hipMemcpy(c, S->d_counters.p, sizeof c, hipMemcpyDeviceToHost));
+    S->stats.word_rows += c[0];
+    S->stats.blocks += c[1];
+  }
+
+  out.cands.resize(count);
+  if (count)
+    HIP_TRY(hipMemcpy(out.cands.data(), S->d_cand.p, (size_t)count * sizeof(Candidate), hipMemcpyDeviceToHost));
+  std::sort(out.cands.begin(), out.cands.end(),
+            [](const Candidate& a, const Candidate& b) { return a.pos < b.pos; });
+  S->stats.candidates += count;
+
+  // ---- seams: reports that depend on how a plateau was entered left of their chunk ----
+  bool any_cond = false;
+  for (const Candidate& c : out.cands) any_cond |= (c.flags & kCandCond) != 0;
+  std::vector<uint8_t> state;
+  const bool need_state = any_cond || !sh.text_end;  // non-final shards publish their exit state
+  if (need_state) {
+    state.resize(P.n_chunks);
+    HIP_TRY(hipMemcpy(state.data(), S->d_state.p, P.n_chunks, hipMemcpyDeviceToHost));
+  }
+  if (any_cond) {
+    std::vector<Candidate> kept;
+    kept.reserve(out.cands.size());
+    const uint64_t end_global = sh.global_offset + sh.text_len;
+    for (const Candidate& c : out.cands) {
+      if (!(c.flags & kCandCond)) { kept.push_back(c); continue; }
+      out.cond_seen++;
+      uint64_t local = c.pos - sh.global_offset;
+      uint64_t blk = local / 64;
+      if (c.pos == end_global && blk >= n_blocks) blk = n_blocks - 1;  // end-of-text report
+      uint64_t chunk = (blk - first_owned) / bpl;
+      if (chunk >= P.n_chunks) chunk = P.n_chunks - 1;
+      // direction in which the plateau was entered = exit state of the nearest chunk to the
+      // left that determined it
+      int64_t q = (int64_t)chunk - 1;
+      while (q >= 0 && state[(size_t)q] == kStatePass) --q;
+      if (q >= 0) {
+        if (state[(size_t)q] == kStateDecTrue) { Candidate cc = c; cc.flags &= ~kCandCond; kept.push_back(cc); }
+      } else if (sh.text_start) {
+        Candidate cc = c; cc.flags &= ~kCandCond; kept.push_back(cc);  // entered at column 0: decreasing
+      } else {
+        out.conditional_index = (int64_t)kept.size();  // only the previous shard knows
+        kept.push_back(c);
+      }
+    }
+    out.cands.swap(kept);
+  }
+  if (need_state) {
+    int64_t q = (int64_t)P.n_chunks - 1;
+    while (q >= 0 && state[(size_t)q] == kStatePass) --q;
+    out.exit_state = q >= 0 ? state[(size_t)q] : (sh.text_start ? kStateDecTrue : kStatePass);
+  }
+  S->stats.cond_resolved += out.cond_seen;
+  return 0;
+}
+
+// Turn reports into matches.  `host_text` (may be null) is the forward text on the host when the
+// caller has it; otherwise the windows are gathered from the device buffer.  For the Rc strand
+// the buffer holds the reversed text and `reversed_host` says host_text must be read backwards.
+static int trace_reports(sassy_SearcherType* S, const ShardView& sh, const uint8_t* host_text,
+                         bool reversed_host, uint64_t total_len, const PatternPlan& plan,
+                         const uint8_t* pat, uint32_t k, bool without_trace,
+                         const std::vector<Candidate>& cands, std::vector<MatchRec>& out) {
+  const size_t m = plan.m;
+  const uint64_t fill = (uint64_t)m + k;
+  const size_t cnt = cands.size();
+  if (cnt == 0) return 0;
+  if (without_trace) {
+    for (const Candidate& c : cands) {
+      MatchRec r;  // reference: src/search.rs:1464-1475
+      r.text_start = UINT64_MAX;
+      r.text_end = std::min<uint64_t>(c.pos, total_len);
+      r.pattern_start = UINT64_MAX;
+      r.pattern_end = m;
+      r.cost = c.cost;
+      out.push_back(std::move(r));
+    }
+    return 0;
+  }
+  std::vector<uint8_t> windows;
+  const uint32_t wlen = (uint32_t)fill;
+  std::vector<uint64_t> o(cnt);
+  std::vector<uint32_t> wl(cnt);
+  for (size_t i = 0; i < cnt; ++i) {
+    const uint64_t e = cands[i].pos;
+    o[i] = e > fill ? e - fill : 0;
+    const uint64_t we = std::min<uint64_t>(e, total_len);
+    wl[i] = (uint32_t)(we - o[i]);
+  }
+  if (!host_text) {
+    std::vector<uint64_t> lstart(cnt);
+    for (size_t i = 0; i < cnt; ++i) {
+      if (o[i] < sh.global_offset)
+        return fail(SASSY_HIP_EINVAL, "traceback window reaches left of the shard's halo");
+      lstart[i] = o[i] - sh.global_offset;
+    }
+    if (int rc = S->d_wstart.reserve(cnt)) return rc;
+    if (int rc = S->d_wlen.reserve(cnt)) return rc;
+    if (int rc = S->d_win.reserve(cnt * (size_t)wlen)) return rc;
+    HIP_TRY(hipEventRecord(S->ev_a, S->stream));
+    HIP_TRY(hipMemcpyAsync(S->d_wstart.p, lstart.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, S->stream));
+    HIP_TRY(hipMemcpyAsync(S->d_wlen.p, wl.data(), cnt * sizeof(uint32_t), hipMemcpyHostToDevice, S->stream));
+    hipError_t le = launch_gather_windows(sh.d_text, S->d_wstart.p, S->d_wlen.p, wlen, (uint32_t)cnt, S->d_win.p, S->stream);
+    if (le != hipSuccess) return hip_fail(le, "gather kernel launch");
+    windows.resize(cnt * (size_t)wlen);
+    HIP_TRY(hipMemcpyAsync(windows.data(), S->d_win.p, windows.size(), hipMemcpyDeviceToHost, S->stream));
+    HIP_TRY(hipEventRecord(S->ev_b, S->stream));
+    HIP_TRY(hipStreamSynchronize(S->stream));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_b));
+    S->stats.trace_ms += ms;
+  }
+  std::vector<uint8_t> tmp(wlen ? wlen : 1);
+  for (size_t i = 0; i < cnt; ++i) {
+    const uint8_t* w;
+    if (host_text) {
+      if (reversed_host) {  // window [o, o+wl) of reverse(text) = reverse of text[n-o-wl, n-o)
+        for (uint32_t q = 0; q < wl[i]; ++q) tmp[q] = host_text[total_len - 1 - (o[i] + q)];
+        w = tmp.data();
+      } else {
+        w = host_text + o[i];
+      }
+    } else {
+      w = windows.data() + i * (size_t)wlen;
+    }
+    TraceOut t = trace_window(S->profile, pat, m, w, wl[i], o[i], (int)k);
+    if (!t.ok || t.cost > cands[i].cost)
+      return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
+    MatchRec r;
+    r.text_start = t.text_start;
+    r.text_end = o[i] + wl[i];
+    r.pattern_start = 0;
+    r.pattern_end = m;
+    r.cost = t.cost;
+    r.cigar = rle(t.ops);
+    out.push_back(std::move(r));
+  }
+  return 0;
+}
+
+static void finish_result(const std::vector<MatchRec>& recs, sassy_hip_Result* R) {
+  R->matches.reserve(recs.size());
+  for (const MatchRec& r : recs) {
+    sassy_hip_Match m{};
+    m.pattern_idx = r.pattern_idx;
+    m.text_idx = r.text_idx;
+    m.text_start = r.text_start;
+    m.text_end = r.text_end;
+    m.pattern_start = r.pattern_start;
+    m.pattern_end = r.pattern_end;
+    m.cost = r.cost;
+    m.strand = r.strand;
+    m.cigar_off = (uint32_t)R->pool.size();
+    m.cigar_len = (uint32_t)r.cigar.size();
+    R->pool.append(r.cigar);
+    R->pool.push_back('\0');
+    R->matches.push_back(m);
+  }
+}
+
+static double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// Searcher::search / search_all on one text (reference: src/search.rs:510-525, 685-700, 787-881).
+// `text` is a host pointer unless TEXT_ON_DEVICE.
+static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t plen, const uint8_t* text,
+                       size_t tlen, size_t k, uint32_t flags, uint64_t pattern_idx, bool fwd_strand,
+                       bool rc_strand, std::vector<MatchRec>& recs) {
+  PatternPlan plan;
+  std::string err;
+  if (!make_plan(S->profile, pattern, plen, plan, err)) return fail(SASSY_HIP_EINVAL, err);
+  if (k > 0x7FFFFFFFu) return fail(SASSY_HIP_EINVAL, "k too large");
+  if (int rc = S->ensure_device()) return rc;
+  const bool on_dev = (flags & SASSY_HIP_TEXT_ON_DEVICE) != 0;
+  const bool all = (flags & SASSY_HIP_ALL_MINIMA) != 0;
+  const bool wo = (flags & SASSY_HIP_WITHOUT_TRACE) != 0;
+  if (tlen == 0) return 0;  // reference: no reports for an empty text (src/search.rs:1314-1316)
+
+  const uint8_t* d_fwd = text;
+  if (!on_dev) {
+    if (int rc = S->d_text.reserve(tlen + 64)) return rc;
+    HIP_TRY(hipMemcpyAsync(S->d_text.p, text, tlen, hipMemcpyHostToDevice, S->stream));
+    d_fwd = S->d_text.p;
+  } else if (((uintptr_t)text & 15) != 0) {
+    return fail(SASSY_HIP_EINVAL, "device text pointer must be 16-byte aligned");
+  }
+  const uint8_t* host_text = on_dev ? nullptr : text;
+
+  if (fwd_strand) {
+    ShardView sh{d_fwd, tlen, 0, 0, true, true};
+    ScanOut so;
+    if (int rc = run_scan(S, sh, plan, (uint32_t)k, all, so)) return rc;
+    const size_t first = recs.size();
+    if (int rc = trace_reports(S, sh, host_text, false, tlen, plan, pattern, (uint32_t)k, wo, so.cands, recs)) return rc;
+    for (size_t i = first; i < recs.size(); ++i) recs[i].pattern_idx = pattern_idx;
+  }
+  if (rc_strand) {
+    // complement(pattern) against reverse(text), coordinates mapped back
+    // (reference: src/search.rs:813-878)
+    std::vector<uint8_t> cp(plen);
+    for (size_t i = 0; i < plen; ++i) cp[i] = complement_char(S->profile, pattern[i]);
+    PatternPlan cplan;
+    if (!make_plan(S->profile, cp.data(), plen, cplan, err)) return fail(SASSY_HIP_EINVAL, err);
+    if (int rc = S->d_rev.reserve(tlen + 64)) return rc;
+    hipError_t le = launch_reverse(d_fwd, S->d_rev.p, tlen, S->stream);
+    if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
+    ShardView sh{S->d_rev.p, tlen, 0, 0, true, true};
+    ScanOut so;
+    if (int rc = run_scan(S, sh, cplan, (uint32_t)k, all, so)) return rc;
+    const size_t first = recs.size();
+    if (int rc = trace_reports(S, sh, host_text, true, tlen, cplan, cp.data(), (uint32_t)k, wo, so.cands, recs)) return rc;
+    for (size_t i = first; i < recs.size(); ++i) {
+      MatchRec& r = recs[i];
+      const uint64_t rs = r.text_start, re = r.text_end;
+      r.strand = 1;
+      r.pattern_idx = pattern_idx;
+      r.text_start = tlen - re;
+      r.text_end = wo ? UINT64_MAX : tlen - rs;  // reference: src/search.rs:868-873
+    }
+  }
+  return 0;
+}
+
+static void reset_stats(sassy_SearcherType* S) { S->stats = sassy_hip_Stats{}; }
+
+}  // namespace sassy_hip
+
+// ======================================================================== C-ABI
+extern "C" {
+
+const char* sassy_hip_last_error(void) { return g_err.c_str(); }
+const char* sassy_hip_version(void) { return "sassy-hip 0.1 (gfx950)"; }
+
+int sassy_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+static bool parse_alphabet(const char* alphabet, Profile& pr) {
+  std::string a(alphabet ? alphabet : "");
+  for (char& c : a) c = (char)tolower((unsigned char)c);
+  if (a == "dna") pr = PROFILE_DNA;
+  else if (a == "iupac") pr = PROFILE_IUPAC;
+  else if (a == "ascii") pr = PROFILE_ASCII;
+  else return false;
+  return true;
+}
+
+sassy_SearcherType* sassy_hip_searcher_new(const char* alphabet, bool rc, float alpha) {
+  if (!alphabet) { fail(SASSY_HIP_EINVAL, "Alphabet pointer must not be null"); return nullptr; }
+  Profile pr;
+  if (!parse_alphabet(alphabet, pr)) {
+    fail(SASSY_HIP_EINVAL, std::string("Unsupported alphabet: ") + alphabet);
+    return nullptr;
+  }
+  if (!std::isnan(alpha)) {
+    fail(SASSY_HIP_EUNSUPPORTED, "overhang (alpha) is not built yet; pass NAN");
+    return nullptr;
+  }
+  if (rc && pr == PROFILE_ASCII) {
+    // the reference panics at the first rc search (Profile::complement is unimplemented for Ascii)
+    fail(SASSY_HIP_EUNSUPPORTED, "reverse complement is not defined for the ascii alphabet");
+    return nullptr;
+  }
+  sassy_SearcherType* s = new sassy_SearcherType();
+  s->profile = pr;
+  s->rc = rc;
+  return s;
+}
+
+[[noreturn]] static void die(const char* msg) {
+  std::fprintf(stderr, "sassy (hip): %s\n", msg);
+  std::abort();
+}
+
+sassy_SearcherType* sassy_searcher(const char* alphabet, bool rc, float alpha) {
+  sassy_SearcherType* s = sassy_hip_searcher_new(alphabet, rc, alpha);
+  if (!s) die(g_err.c_str());  // the reference panics (src/c.rs:57,66)
+  return s;
+}
+
+void sassy_searcher_free(sassy_SearcherType* ptr) {
+  if (!ptr) die("Pointer to SearcherType must not be null");  // src/c.rs:75-77
+  delete ptr;
+}
+
+int sassy_hip_set_stream(sassy_SearcherType* s, void* hip_stream) {
+  if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
+  if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+  s->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  s->own_stream = false;
+  if (!hip_stream && s->device_ready) {
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    s->own_stream = true;
+  }
+  return 0;
+}
+
+int sassy_hip_get_stats(const sassy_SearcherType* s, sassy_hip_Stats* out) {
+  if (!s || !out) return fail(SASSY_HIP_EINVAL, "null argument");
+  *out = s->stats;
+  return 0;
+}
+
+int sassy_hip_enable_counters(sassy_SearcherType* s, int on) {
+  if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
+  s->want_counters = on != 0;
+  return 0;
+}
+
+int sassy_hip_search(sassy_SearcherType* s, const uint8_t* pattern, size_t pattern_len,
+                     const uint8_t* text, size_t text_len, size_t k, uint32_t flags,
+                     sassy_hip_Result** out) {
+  if (!s || !pattern || (!text && text_len) || !out) return fail(SASSY_HIP_EINVAL, "Pointers in search() must not be null");
+  const double t0 = now_ms();
+  reset_stats(s);
+  std::vector<MatchRec> recs;
+  if (int rc = search_text(s, pattern, pattern_len, text, text_len, k, flags, 0, true, s->rc, recs)) return rc;
+  sassy_hip_Result* R = new sassy_hip_Result();
+  finish_result(recs, R);
+  s->stats.total_ms = now_ms() - t0;
+  *out = R;
+  return 0;
+}
+
+uint64_t sassy_hip_required_halo(size_t pattern_len, size_t k) {
+  // warm-up blocks + the traceback window, rounded up to whole 128-byte lines
+  const uint64_t wb = warmup_blocks((uint32_t)pattern_len, (uint32_t)k);
+  uint64_t h = std::max<uint64_t>(64 * (wb + 1), pattern_len + k);
+  return (h + 127) / 128 * 128;
+}
+
+int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t pattern_len,
+                           const uint8_t* d_text, uint64_t halo_len, uint64_t shard_len,
+                           uint64_t global_offset, uint64_t total_len, size_t k, uint32_t flags,
+                           sassy_hip_Result** out) {
+  if (!s || !pattern || !d_text || !out) return fail(SASSY_HIP_EINVAL, "null argument");
+  if (halo_len % 64 || global_offset % 64) return fail(SASSY_HIP_EINVAL, "halo_len and global_offset must be multiples of 64");
+  if (global_offset < halo_len) return fail(SASSY_HIP_EINVAL, "halo reaches left of the text start");
+  if (global_offset + shard_len > total_len) return fail(SASSY_HIP_EINVAL, "shard exceeds the text");
+  const bool is_first = global_offset == 0, is_last = global_offset + shard_len == total_len;
+  if (!is_last && shard_len % 64) return fail(SASSY_HIP_EINVAL, "inner shard lengths must be multiples of 64");
+  if (!is_first && halo_len < sassy_hip_required_halo(pattern_len, k)) return fail(SASSY_HIP_EINVAL, "halo too short");
+  if (((uintptr_t)d_text & 15) != 0) return fail(SASSY_HIP_EINVAL, "device text pointer must be 16-byte aligned");
+  const double t0 = now_ms();
+  reset_stats(s);
+  PatternPlan plan;
+  std::string err;
+  if (!make_plan(s->profile, pattern, pattern_len, plan, err)) return fail(SASSY_HIP_EINVAL, err);
+  if (int rc = s->ensure_device()) return rc;
+  sassy_hip_Result* R = new sassy_hip_Result();
+  if (shard_len > 0) {
+    ShardView sh{d_text, halo_len + shard_len, halo_len, global_offset - halo_len,
+                 is_first && halo_len == 0, is_last};
+    ScanOut so;
+    if (int rc = run_scan(s, sh, plan, (uint32_t)k, (flags & SASSY_HIP_ALL_MINIMA) != 0, so)) { delete R; return rc; }
+    std::vector<MatchRec> recs;
+    if (int rc = trace_reports(s, sh, nullptr, false, total_len, plan, pattern, (uint32_t)k,
+                               (flags & SASSY_HIP_WITHOUT_TRACE) != 0, so.cands, recs)) { delete R; return rc; }
+    finish_result(recs, R);
+    R->exit_state = so.exit_state;
+    R->conditional_index = so.conditional_index;
+  }
+  s->stats.total_ms = now_ms() - t0;
+  *out = R;
+  return 0;
+}
+
+size_t sassy_hip_result_len(const sassy_hip_Result* r) { return r ? r->matches.size() : 0; }
+const sassy_hip_Match* sassy_hip_result_matches(const sassy_hip_Result* r) { return r ? r->matches.data() : nullptr; }
+const char* sassy_hip_result_cigars(const sassy_hip_Result* r) { return r ? r->pool.c_str() : nullptr; }
+int sassy_hip_result_exit_state(const sassy_hip_Result* r) { return r ? r->exit_state : -1; }
+int64_t sassy_hip_result_conditional_index(const sassy_hip_Result* r) { return r ? r->conditional_index : -1; }
+void sassy_hip_result_free(sassy_hip_Result* r) { delete r; }
+
+// ---- drop-in `search` (reference: c/sassy.h:52-58, src/c.rs:89-122) ----
+uintptr_t search(sassy_SearcherType* searcher, const uint8_t* pattern, uintptr_t pattern_len,
+                 const uint8_t* text, uintptr_t text_len, uintptr_t k, sassy_Match** out_matches) {
+  if (!searcher || !pattern || !text || !out_matches) die("Pointers in search() must not be null");
+  sassy_hip_Result* R = nullptr;
+  if (sassy_hip_search(searcher, pattern, pattern_len, text, text_len, k, 0, &R) != 0) die(g_err.c_str());
+  const size_t n = R->matches.size();
+  // never null, also for zero matches (the reference hands out a dangling non-null pointer and
+  // sassy_matches_free asserts non-null: src/c.rs:112-127)
+  sassy_Match* arr = static_cast<sassy_Match*>(std::malloc(std::max<size_t>(1, n) * sizeof(sassy_Match)));
+  if (!arr) die("out of memory");
+  for (size_t i = 0; i < n; ++i) {
+    const sassy_hip_Match& m = R->matches[i];
+    arr[i].text_start = (uintptr_t)m.text_start;
+    arr[i].text_end = (uintptr_t)m.text_end;
+    arr[i].pattern_start = (uintptr_t)m.pattern_start;
+    arr[i].pattern_end = (uintptr_t)m.pattern_end;
+    arr[i].cost = m.cost;
+    arr[i].strand = m.strand;
+  }
+  sassy_hip_result_free(R);
+  *out_matches = arr;
+  return n;
+}
+
+void sassy_matches_free(sassy_Match* ptr, uintptr_t len) {
+  (void)len;
+  if (!ptr) die("Pointer to matches must not be null");  // src/c.rs:127
+  std::free(ptr);
+}
+
+// ---- encoded patterns (reference: src/search.rs:404-423) ----
+sassy_hip_Encoded* sassy_hip_encode_patterns(sassy_SearcherType* s, const uint8_t* patterns,
+                                             size_t npat, size_t plen) {
+  if (!s || !patterns) { fail(SASSY_HIP_EINVAL, "null argument"); return nullptr; }
+  if (npat == 0) { fail(SASSY_HIP_EINVAL, "No queries provided"); return nullptr; }  // general.rs:250-252
+  if (plen == 0 || plen > 64) {  // tqueries.rs:60-65, general.rs:285-291
+    fail(SASSY_HIP_EINVAL, "Invalid pattern length (must be 1..=64)");
+    return nullptr;
+  }
+  sassy_hip_Encoded* e = new sassy_hip_Encoded();
+  e->profile = s->profile;
+  e->rc = s->rc;
+  e->plen = plen;
+  e->n_original = npat;
+  for (size_t p = 0; p < npat; ++p) e->patterns.emplace_back(patterns + p * plen, patterns + (p + 1) * plen);
+  if (s->rc) {  // RC of every pattern appended as patterns P..2P (tqueries.rs:74-80)
+    for (size_t p = 0; p < npat; ++p) {
+      std::vector<uint8_t> r(plen);
+      for (size_t i = 0; i < plen; ++i) r[i] = complement_char(PROFILE_IUPAC, patterns[p * plen + plen - 1 - i]);
+      e->patterns.push_back(std::move(r));
+    }
+  }
+  return e;
+}
+void sassy_hip_encoded_free(sassy_hip_Encoded* e) { delete e; }
+
+int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* text,
+                             size_t text_len, size_t k, uint32_t flags, sassy_hip_Result** out) {
+  if (!s || !e || (!text && text_len) || !out) return fail(SASSY_HIP_EINVAL, "null argument");
+  const double t0 = now_ms();
+  reset_stats(s);
+  if (int rc = s->ensure_device()) return rc;
+  std::vector<MatchRec> recs;
+  // One forward scan per (rc-expanded) pattern over the device-resident text: the text goes to
+  // the device once, every pattern reuses it.
+  const uint8_t* d_text = text;
+  uint32_t f = flags;
+  if (!(flags & SASSY_HIP_TEXT_ON_DEVICE) && text_len) {
+    if (int rc = s->d_text.reserve(text_len + 64)) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_text.p, text, text_len, hipMemcpyHostToDevice, s->stream));
+  }
+  const uint8_t* tptr = (flags & SASSY_HIP_TEXT_ON_DEVICE) ? d_text : s->d_text.p;
+  f |= SASSY_HIP_TEXT_ON_DEVICE;  // search_text must not upload the text again per pattern
+  for (size_t p = 0; p < e->patterns.size(); ++p) {
+    const size_t first = recs.size();
+    if (int rc = search_text(s, e->patterns[p].data(), e->plen, tptr, text_len, k, f,
+                             p % e->n_original, true, false, recs)) return rc;
+    for (size_t i = first; i < recs.size(); ++i) recs[i].strand = p >= e->n_original ? 1 : 0;
+  }
+  // The reference's order is an artefact of its range bookkeeping; its own differential test
+  // sorts by this key before comparing (pattern_tiling/search.rs:748-757).
+  std::sort(recs.begin(), recs.end(), [](const MatchRec& a, const MatchRec& b) {
+    if (a.pattern_idx != b.pattern_idx) return a.pattern_idx < b.pattern_idx;
+    if (a.text_start != b.text_start) return a.text_start < b.text_start;
+    if (a.text_end != b.text_end) return a.text_end < b.text_end;
+    if (a.cost != b.cost) return a.cost < b.cost;
+    if (a.strand != b.strand) return a.strand < b.strand;
+    return a.cigar < b.cigar;
+  });
+  sassy_hip_Result* R = new sassy_hip_Result();
+  finish_result(recs, R);
+  s->stats.total_ms = now_ms() - t0;
+  *out = R;
+  return 0;
+}
+
+// ---- synthetic inputs ----
+int sassy_hip_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first, void* hip_stream) {
+  if (!d_text && n) return fail(SASSY_HIP_EINVAL, "null argument");
+  hipError_t e = launch_generate_dna(d_text, n, seed, first, reinterpret_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "generate kernel launch");
+  HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream)));
+  return 0;
+}
+
+static inline uint64_t splitmix64_host(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+static inline uint64_t hash_host(uint64_t seed, uint64_t idx) { return splitmix64_host(seed * 0x9E3779B97F4A7C15ull + idx); }
+
+// Plant q = the pattern with (q mod (k+1)) edits drawn from the counter-based hash:
+// r = hash(seed ^ "plant", 64*q + t); type = r % 3 (0 sub, 1 ins, 2 del); pos = (r >> 8) % len;
+// base = (r >> 40) & 3.  The CPU twin used by the tests is oracle/sassy_oracle.c:orc_make_plant.
+static std::vector<uint8_t> make_plant(uint64_t seed, uint64_t q, const uint8_t* pat, size_t m, int edits) {
+  static const char acgt[4] = {'A', 'C', 'G', 'T'};
+  std::vector<uint8_t> s(pat, pat + m);
+  for (int t = 0; t < edits; ++t) {
+    const uint64_t r = hash_host(seed ^ 0x706c616e74ull, 64 * q + (uint64_t)t);
+    const int type = (int)(r % 3);
+    const size_t pos = (size_t)((r >> 8) % s.size());
+    const int b = (int)((r >> 40) & 3);
+    if (type == 0) {
+      int idx = 0;
+      for (int a = 0; a < 4; ++a)
+        if (s[pos] == (uint8_t)acgt[a]) idx = a;
+      s[pos] = (uint8_t)acgt[(idx + 1 + (b % 3)) & 3];
+    } else if (type == 1) {
+      s.insert(s.begin() + (long)pos, (uint8_t)acgt[b]);
+    } else if (s.size() > 1) {
+      s.erase(s.begin() + (long)pos);
+    }
+  }
+  return s;
+}
+
+int sassy_hip_plant(uint8_t* d_text, uint64_t n, uint64_t first, uint64_t total_n, uint64_t seed,
+                    const uint8_t* pattern, size_t pattern_len, size_t k, uint64_t stride,
+                    void* hip_stream, uint64_t* planted) {
+  if (!d_text || !pattern || stride == 0) return fail(SASSY_HIP_EINVAL, "bad argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+  std::vector<uint64_t> pos;
+  std::vector<uint8_t> val;
+  uint64_t cnt = 0;
+  for (uint64_t q = 0;; ++q) {
+    const uint64_t p = q * stride + stride / 2;
+    if (p + pattern_len + k > total_n) break;
+    if (p >= first + n) break;
+    std::vector<uint8_t> s = make_plant(seed, q, pattern, pattern_len, (int)(q % (k + 1)));
+    if (p + s.size() <= first) continue;
+    for (size_t i = 0; i < s.size(); ++i) {
+      const uint64_t g = p + i;
+      if (g >= first && g < first + n) { pos.push_back(g); val.push_back(s[i]); }
+    }
+    cnt++;
+  }
+  if (planted) *planted = cnt;
+  if (pos.empty()) return 0;
+  uint64_t* d_pos = nullptr;
+  uint8_t* d_val = nullptr;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&d_pos), pos.size() * sizeof(uint64_t)));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_val), val.size());
+  if (e != hipSuccess) { (void)hipFree(d_pos); return hip_fail(e, "hipMalloc"); }
+  int rc = 0;
+  do {
+    if ((e = hipMemcpyAsync(d_pos, pos.data(), pos.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st)) != hipSuccess) break;
+    if ((e = hipMemcpyAsync(d_val, val.data(), val.size(), hipMemcpyHostToDevice, st)) != hipSuccess) break;
+    if ((e = launch_scatter_bytes(d_text, n, first, d_pos, d_val, pos.size(), st)) != hipSuccess) break;
+    e = hipStreamSynchronize(st);
+  } while (0);
+  if (e != hipSuccess) rc = hip_fail(e, "plant");
+  (void)hipFree(d_pos);
+  (void)hipFree(d_val);
+  return rc;
+}
+
+// ---- plain device memory helpers ----
+void* sassy_hip_malloc(size_t bytes) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+  if (e != hipSuccess) { hip_fail(e, "hipMalloc"); return nullptr; }
+  return p;
+}
+void sassy_hip_free(void* d_ptr) { if (d_ptr) (void)hipFree(d_ptr); }
+int sassy_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes) {
+  HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+  return 0;
+}
+int sassy_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes) {
+  HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+}  // extern "C"

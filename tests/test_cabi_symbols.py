@@ -1,0 +1,107 @@
+"""CPU-only: the C-ABI library builds, loads and exports every symbol include/*.h declares;
+the host logic that needs no device behaves; and without a device the search path FAILS LOUDLY
+instead of falling back to anything."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def sassy():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    g.build()
+    import sassy_amd
+    return sassy_amd
+
+
+def declared_symbols():
+    syms = set()
+    for h in ("sassy.h", "sassy_hip.h"):
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\(", src):
+            name = m.group(1)
+            if name.startswith("sassy_") or name == "search":
+                syms.add(name)
+    return syms
+
+
+def test_every_declared_symbol_is_exported(sassy):
+    L = sassy.lib()
+    decl = declared_symbols()
+    assert {"sassy_searcher", "sassy_searcher_free", "search", "sassy_matches_free"} <= decl
+    assert len(decl) >= 25
+    for name in decl:
+        assert hasattr(L, name), name
+    assert set(sassy.EXPORTED_SYMBOLS) >= decl
+
+
+def test_match_struct_layout(sassy):
+    # reference c/sassy.h:11-21: repr(C), 40 bytes, align 8
+    assert C.sizeof(sassy.CMatch) == 40
+    assert sassy.CMatch.cost.offset == 32 and sassy.CMatch.strand.offset == 36
+
+
+def test_searcher_constructor_errors(sassy):
+    with pytest.raises(sassy.SassyHipError, match="Unsupported alphabet"):
+        sassy.Searcher("protein")
+    with pytest.raises(sassy.SassyHipError, match="overhang"):
+        sassy.Searcher("iupac", rc=False, alpha=0.5)
+    with pytest.raises(sassy.SassyHipError):
+        sassy.Searcher("ascii", rc=True)
+    for a in ("dna", "DNA", "Iupac", "ascii"):
+        sassy.Searcher(a, rc=False)
+
+
+def test_required_halo(sassy):
+    assert sassy.required_halo(32, 3) % 128 == 0
+    assert sassy.required_halo(32, 3) >= 64 * 2
+    assert sassy.required_halo(200, 20) >= 64 * 4 + 64
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful on a box without a GPU")
+def test_no_device_fails_loudly(sassy):
+    assert sassy.device_count() == 0
+    s = sassy.Searcher("dna", rc=False)
+    with pytest.raises(sassy.SassyHipError, match="no usable HIP device"):
+        s.search(b"ACGT", b"ACGTACGT", 0)
+    e = s.encode_patterns([b"ACGT"])
+    with pytest.raises(sassy.SassyHipError, match="no usable HIP device"):
+        s.search_encoded_patterns(e, b"ACGTACGT", 0)
+    # invalid IUPAC pattern is rejected before any device work (reference panics: iupac.rs:19-24)
+    with pytest.raises(sassy.SassyHipError, match="not valid IUPAC"):
+        sassy.Searcher("iupac", rc=False).search(b"AC1T", b"ACGT", 0)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful on a box without a GPU")
+def test_drop_in_search_aborts_without_device(sassy):
+    """The drop-in `search` mirrors the reference's panic: message + abort, never a fake result."""
+    code = (
+        "import ctypes as C, sassy_amd\n"
+        "L = sassy_amd.lib()\n"
+        "s = L.sassy_searcher(b'dna', False, float('nan'))\n"
+        "out = C.POINTER(sassy_amd.CMatch)()\n"
+        "L.search(s, b'ACGT', 4, b'ACGTACGT', 8, 0, C.byref(out))\n"
+        "print('returned')\n"
+    )
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+    assert p.returncode != 0
+    assert "returned" not in p.stdout
+    assert "no usable HIP device" in p.stderr
+
+
+def test_product_does_not_touch_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use oracle/."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "sassy_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in src and "liboracle" not in src, f
+                assert "orc_" not in src.replace("orc_generate_dna", "").replace("orc_make_plant", "").replace("orc_plant_window", ""), f

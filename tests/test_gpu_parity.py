@@ -1,0 +1,364 @@
+"""GPU parity tests: the HIP path (through the C-ABI of libsassy_hip.so) against the CPU oracle
+and the reference's known-answer tests.  Bit-exact: integer / byte / index work only.
+
+Run on the MI355X box with `pytest -m gpu`."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import build_text, cigar_path
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sassy():
+    import sassy_amd
+    assert sassy_amd.device_count() > 0, "no HIP device: the GPU tests must not silently skip"
+    return sassy_amd
+
+
+def key(m):
+    return (m.pattern_idx, m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost,
+            m.strand, m.cigar)
+
+
+def assert_same(got, want, ctx=None):
+    g, w = [key(m) for m in got], [key(m) for m in want]
+    assert g == w, (ctx, g[:5], w[:5], len(g), len(w))
+
+
+def rand_seq(rng, n, alphabet=b"ACGT"):
+    return bytes(rng.choice(alphabet) for _ in range(n))
+
+
+def mutate(rng, s, edits):
+    s = bytearray(s)
+    for _ in range(edits):
+        t, p = rng.randrange(3), rng.randrange(len(s))
+        if t == 0:
+            s[p] = rng.choice(b"ACGT")
+        elif t == 1:
+            s.insert(p, rng.choice(b"ACGT"))
+        elif len(s) > 1:
+            del s[p]
+    return bytes(s)
+
+
+# ------------------------------------------------------------------ reference KATs via HIP
+def test_reference_kats_through_hip(sassy, kats):
+    for e in kats["search"]:
+        s = sassy.Searcher(e["profile"], rc=e["rc"])
+        text = build_text(e)
+        pat = e["pattern"].encode()
+        ms = s.search_all(pat, text, e["k"]) if e["mode"] == "search_all" else s.search(pat, text, e["k"])
+        if "expect_len" in e:
+            assert len(ms) == e["expect_len"], (e["id"], ms)
+        for m, exp in zip(ms, e.get("expect", [])):
+            for f, v in exp.items():
+                assert getattr(m, f) == v, (e["id"], f, m)
+        if "expect_first" in e:
+            for f, v in e["expect_first"].items():
+                if f == "path":
+                    assert cigar_path(ms[0]) == [tuple(x) for x in v]
+                else:
+                    assert getattr(ms[0], f) == v, (e["id"], f, ms[0])
+        if "expect_text_ends" in e:
+            assert [m.text_end for m in ms] == e["expect_text_ends"]
+        # and the oracle agrees field by field, cigar included
+        want = oracle.search(e["profile"], pat, text, e["k"], rc=e["rc"], all_minima=(e["mode"] == "search_all"))
+        assert_same(ms, want, e["id"])
+
+
+def test_encoded_kats_through_hip(sassy, kats):
+    for e in kats["encoded"]:
+        s = sassy.Searcher(e["profile"], rc=e["rc"])
+        enc = s.encode_patterns([p.encode() for p in e["patterns"]])
+        ms = s.search_encoded_patterns(enc, e["text"].encode(), e["k"], all_minima=e.get("all", False))
+        assert len(ms) == e["expect_len"], (e["id"], ms)
+        if "expect_text_starts_in_order" in e:
+            assert [m.text_start for m in ms] == e["expect_text_starts_in_order"]
+        for pidx, exp in e.get("expect_by_pattern", {}).items():
+            m = [x for x in ms if x.pattern_idx == int(pidx)][0]
+            for f, v in exp.items():
+                assert getattr(m, f) == v
+        want = oracle.search_encoded(e["profile"], [p.encode() for p in e["patterns"]],
+                                     e["text"].encode(), e["k"], rc=e["rc"], all_minima=e.get("all", False))
+        assert_same(ms, want, e["id"])
+
+
+def test_not_rev_invariant_through_hip(sassy, kats):
+    e = kats["not_rev_invariant"]
+    s = sassy.Searcher(e["profile"], rc=False)
+    p, t = e["pattern"].encode(), e["text"].encode()
+    assert len(s.search(p, t, e["k"])) != len(s.search(p[::-1], t[::-1], e["k"]))
+
+
+def test_drop_in_c_abi_call_sequence(sassy):
+    """The exact call sequence of the reference's c/example.c:14-29 against the drop-in symbols."""
+    L = sassy.lib()
+    s = L.sassy_searcher(b"dna", True, float("nan"))
+    pat = b"AAGGGGA"
+    text = b"CCCCCCCCCAAGGGGACCCCCAAGGCGACCCCCCCCC"
+    out = C.POINTER(sassy.CMatch)()
+    n = L.search(s, pat, len(pat), text, len(text), 1, C.byref(out))
+    got = [(out[i].text_start, out[i].text_end, out[i].pattern_start, out[i].pattern_end,
+            out[i].cost, out[i].strand) for i in range(n)]
+    L.sassy_matches_free(out, n)
+    want = oracle.search("dna", pat, text, 1, rc=True)
+    assert got == [(m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost,
+                    1 if m.strand == "-" else 0) for m in want]
+    assert got[:2] == [(9, 16, 0, 7, 0, 0), (21, 28, 0, 7, 1, 0)]
+    # zero matches: still a non-null pointer that sassy_matches_free accepts (src/c.rs:112-127)
+    n0 = L.search(s, b"TTTTTTTT", 8, b"CCCCCCCCCCCCCCCC", 16, 0, C.byref(out))
+    assert n0 == 0 and bool(out)
+    L.sassy_matches_free(out, 0)
+    L.sassy_searcher_free(s)
+
+
+# ------------------------------------------------------------------ differential fuzz vs oracle
+@pytest.mark.parametrize("profile", ["dna", "iupac"])
+def test_fuzz_small_texts(sassy, profile):
+    rng = random.Random(42 if profile == "dna" else 43)
+    fwd = sassy.Searcher(profile, rc=False)
+    both = sassy.Searcher(profile, rc=True)
+    for it in range(400):
+        m = rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 23, 31, 32, 33, 40, 63, 64, 65, 100, 130])
+        k = min(rng.choice([0, 0, 1, 2, 3, 3, 5, 8]), m - 1) if m > 1 else 0
+        n = rng.choice([0, 1, 2, 31, 63, 64, 65, 100, 127, 128, 129, 200, 500, 511, 512, 513, 1500, 4000])
+        pal = b"ACGT" if profile == "dna" else b"ACGTNRYSWKMBDHV"
+        pat = rand_seq(rng, m, pal if rng.random() < 0.3 else b"ACGT")
+        text = bytearray(rand_seq(rng, n, b"ACGT" if rng.random() < 0.7 else (b"ACGTNacgtn" if profile == "iupac" else b"ACGTacgt")))
+        for _ in range(rng.randrange(5)):
+            if n > m + 8:
+                at = rng.randrange(0, n - m - 6)
+                ins = mutate(rng, bytes(c if c in b"ACGT" else 65 for c in pat), rng.randrange(k + 2))
+                text[at:at + len(ins)] = ins
+        text = bytes(text[:n])
+        rc = rng.random() < 0.4
+        allm = rng.random() < 0.25
+        s = both if rc else fwd
+        got = s.search_all(pat, text, k) if allm else s.search(pat, text, k)
+        want = oracle.search(profile, pat, text, k, rc=rc, all_minima=allm)
+        assert_same(got, want, (it, profile, m, k, n, rc, allm, pat, text))
+
+
+def test_low_complexity_and_seams(sassy):
+    """Plateaus that straddle many lane chunks: poly-A, periodic text, long constant-cost runs.
+    The oracle is the un-chunked definition; the HIP path must agree exactly (this exercises the
+    conditional reports and the chunk exit-state chain)."""
+    s = sassy.Searcher("dna", rc=False)
+    cases = []
+    cases.append((b"A" * 20, b"A" * 5000, 3))
+    cases.append((b"A" * 20, b"A" * 92 + (b"C" + b"A" * 19) * 43 + b"G" * 51, 3))   # SURVEY A.5 shape
+    cases.append((b"A" * 20, b"G" * 700 + b"A" * 3000 + b"G" * 900, 2))
+    cases.append((b"A" * 20, b"A" * 3000 + b"C" + b"A" * 3000, 3))
+    cases.append((b"ACAC" * 6, b"AC" * 4000, 2))
+    cases.append((b"ACGT" * 8, (b"ACGT" * 8 + b"T") * 300, 3))
+    cases.append((b"A" * 10, (b"A" * 9 + b"C") * 700, 1))
+    cases.append((b"A" * 40, b"A" * 64 * 40, 5))
+    rng = random.Random(5)
+    for _ in range(60):
+        per = rng.randrange(1, 12)
+        unit = rand_seq(rng, per, b"AC")
+        n = rng.randrange(600, 9000)
+        text = bytearray((unit * (n // per + 1))[:n])
+        for _ in range(rng.randrange(4)):
+            text[rng.randrange(n)] = rng.choice(b"ACGT")
+        m = rng.randrange(6, 45)
+        pat = (unit * (m // per + 1))[:m]
+        cases.append((pat, bytes(text), rng.randrange(0, 4)))
+    for i, (pat, text, k) in enumerate(cases):
+        k = min(k, len(pat) - 1)
+        got = s.search(pat, text, k)
+        want = oracle.search("dna", pat, text, k)
+        assert_same(got, want, (i, pat, k, len(text)))
+        got = s.search_all(pat, text[:1500], k)
+        want = oracle.search("dna", pat, text[:1500], k, all_minima=True)
+        assert_same(got, want, (i, "all"))
+    assert s.stats()["cond_resolved"] >= 0
+
+
+def test_long_pattern_iupac_config3_shape(sassy):
+    """BASELINE config 3 shape at oracle-checkable size: |pattern|=200 with IUPAC letters, k=20."""
+    rng = random.Random(44)
+    pat = bytearray(oracle.generate_dna(44, 0, 200).tobytes())
+    pat[50], pat[100], pat[150], pat[199] = ord("N"), ord("R"), ord("Y"), ord("W")
+    pat = bytes(pat)
+    n = 200_000
+    text = oracle.generate_dna(42, 0, n)
+    plain = bytes(c if c in b"ACGT" else 65 for c in pat)
+    for q in range(12):
+        ins = mutate(rng, plain, q * 2)
+        at = 5000 + q * 15000
+        text[at:at + len(ins)] = np.frombuffer(ins, dtype=np.uint8)
+    tb = text.tobytes()
+    s = sassy.Searcher("iupac", rc=False)
+    got = s.search(pat, tb, 20)
+    want = oracle.search("iupac", pat, tb, 20)
+    assert len(want) >= 10
+    assert_same(got, want)
+
+
+def test_config1_shape_1mib(sassy):
+    """BASELINE config 1: 'ATCG'x8, k=3, 1 MiB random ACGT (+ plants), Dna, forward only."""
+    pat = b"ATCG" * 8
+    n = 1 << 20
+    text = oracle.generate_dna(42, 0, n)
+    oracle.plant_window(42, n, 0, text, pat, 3, stride=1 << 14)
+    tb = text.tobytes()
+    s = sassy.Searcher("dna", rc=False)
+    got = s.search(pat, tb, 3)
+    want = oracle.search("dna", pat, tb, 3)
+    assert len(want) >= 64
+    assert_same(got, want)
+    # the reference-shaped CPU port reports the same end positions
+    ends, _ = oracle.refstyle_ends("dna", pat, tb, 3)
+    assert [(m.text_end, m.cost) for m in got] == ends
+    # rc searcher on the same text
+    got = sassy.Searcher("dna", rc=True).search(pat, tb, 3)
+    assert_same(got, oracle.search("dna", pat, tb, 3, rc=True))
+
+
+def test_without_trace(sassy):
+    s = sassy.Searcher("dna", rc=True)
+    pat, text = b"ATCGATCG", b"GGGGATCGATCGTTTT"
+    full = s.search(pat, text, 1)
+    wt = s.search_without_trace(pat, text, 1)
+    assert len(wt) == len(full) == 3
+    U = sassy.UINT64_MAX
+    # reference: src/search.rs:1464-1475 (fwd) and :868-873 (rc: text_end = usize::MAX)
+    assert (wt[0].text_start, wt[0].text_end, wt[0].pattern_start, wt[0].cost, wt[0].cigar) == (U, 12, U, 0, "")
+    assert wt[1].strand == "-" and wt[1].text_end == U and wt[1].cost == full[1].cost
+
+
+def test_ascii_profile(sassy):
+    s = sassy.Searcher("ascii", rc=False)
+    text = b"the quick brown fox jumps over the lazy dog, The Quick Brown Fox" * 20
+    for pat, k in [(b"quick", 0), (b"quick", 1), (b"brwn fox", 2), (b"Quick", 0)]:
+        assert_same(s.search(pat, text, k), oracle.search("ascii", pat, text, k), (pat, k))
+
+
+# ------------------------------------------------------------------ device-resident text
+def test_device_generator_matches_cpu_twin(sassy):
+    n = 1 << 20
+    buf = sassy.DeviceBuffer(n + 256)
+    for first in (0, 12345, 1 << 32):
+        sassy.generate_dna(buf.ptr, n, 42, first)
+        assert buf.download(n) == oracle.generate_dna(42, first, n).tobytes()
+    pat = bytes(oracle.generate_dna(43, 0, 32))
+    sassy.generate_dna(buf.ptr, n, 42, 0)
+    planted = sassy.plant(buf.ptr, n, 0, n, 42, pat, 3, stride=1 << 14)
+    want = oracle.generate_dna(42, 0, n)
+    assert oracle.plant_window(42, n, 0, want, pat, 3, stride=1 << 14) == planted == 64
+    assert buf.download(n) == want.tobytes()
+
+
+def test_device_resident_search_and_shards(sassy):
+    """Text generated on the device, searched in place; then the same text searched as 3 shards
+    with halos (the multi-GPU decomposition): union of shard results == whole."""
+    pat = bytes(oracle.generate_dna(43, 0, 32))
+    n = (1 << 22) + 1000  # not a multiple of 64
+    buf = sassy.DeviceBuffer(n + 256)
+    sassy.generate_dna(buf.ptr, n, 42, 0)
+    sassy.plant(buf.ptr, n, 0, n, 42, pat, 3, stride=1 << 16)
+    host = buf.download(n)
+    want = oracle.search("dna", pat, host, 3)
+    assert len(want) >= 60
+    s = sassy.Searcher("dna", rc=False)
+    got = s._search(pat, _DevText(buf.ptr, n), 3, sassy.TEXT_ON_DEVICE).matches
+    assert_same(got, want)
+    halo = sassy.required_halo(len(pat), 3)
+    bounds = [0, 1 << 20, (1 << 21) + 64 * 777, n]
+    allm = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        h = 0 if a == 0 else halo
+        r = s.search_shard(pat, buf.ptr + a - h, h, b - a, a, n, 3)
+        assert r.conditional_index == -1
+        allm += r.matches
+    assert_same(allm, want)
+
+
+class _DevText:
+    """Minimal stand-in for a CUDA tensor: data_ptr/numel/is_cuda (torch is not needed here)."""
+
+    def __init__(self, ptr, n):
+        self._p, self._n = ptr, n
+        self.is_cuda = True
+
+        class _DT:
+            itemsize = 1
+        self.dtype = _DT()
+
+    def data_ptr(self):
+        return self._p
+
+    def numel(self):
+        return self._n
+
+    def is_contiguous(self):
+        return True
+
+
+def test_shard_seam_plateau_chain(sassy):
+    """A constant-cost plateau that runs across shard borders: each shard reports its exit state
+    and flags the report that depends on the previous shard (conditional_index); resolving the
+    chain on the host reproduces the un-sharded answer."""
+    pat = b"A" * 20
+    text = b"G" * 1000 + b"A" * 90 + b"C" + b"A" * 20000 + b"G" * 3000
+    n = len(text)
+    buf = sassy.DeviceBuffer(n + 256)
+    buf.upload(text)
+    s = sassy.Searcher("dna", rc=False)
+    want = oracle.search("dna", pat, text, 3)
+    halo = sassy.required_halo(len(pat), 3)
+    bounds = [0, 64 * 40, 64 * 100, 64 * 200, n]
+    prev_state = 1  # decreasing = TRUE at column 0
+    allm = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        h = 0 if a == 0 else halo
+        r = s.search_shard(pat, buf.ptr + a - h, h, b - a, a, n, 3)
+        ms = list(r.matches)
+        if r.conditional_index >= 0 and prev_state != 1:
+            del ms[r.conditional_index]
+        allm += ms
+        if r.exit_state != 2:
+            prev_state = r.exit_state
+    assert_same(allm, want)
+
+
+# ------------------------------------------------------------------ full-size properties
+def test_full_size_3gb_properties(sassy):
+    """BASELINE config 2 at full size (3 GB, |P|=32, k=3, Dna): no CPU oracle can run this, so
+    check size-independent properties: every plant is found once, at its planted position,
+    with cost <= its edit count, and a 2 MiB slice of the same device text agrees bit-exactly
+    with the oracle."""
+    n = 3_000_000_000
+    pat = bytes(oracle.generate_dna(43, 0, 32))
+    try:
+        buf = sassy.DeviceBuffer(n + 4096)
+    except sassy.SassyHipError:
+        pytest.skip("cannot allocate 3 GB on this device")
+    sassy.generate_dna(buf.ptr, n, 42, 0)
+    planted = sassy.plant(buf.ptr, n, 0, n, 42, pat, 3, stride=1 << 20)
+    assert planted == n // (1 << 20)
+    s = sassy.Searcher("dna", rc=False)
+    got = s._search(pat, _DevText(buf.ptr, n), 3, sassy.TEXT_ON_DEVICE).matches
+    assert len(got) == planted
+    for q, m in enumerate(got):
+        assert abs(m.text_start - (q * (1 << 20) + (1 << 19))) <= 3, (q, m)
+        assert m.cost <= q % 4
+        assert 29 <= m.text_end - m.text_start <= 35
+    assert [m.text_end for m in got] == sorted(m.text_end for m in got)
+    off = 1_500_000_000 - 4096
+    sl = buf.download(1 << 21, off)
+    want = oracle.search("dna", pat, sl, 3)
+    sub = [m for m in got if off + 64 <= m.text_start and m.text_end <= off + (1 << 21)]
+    assert [(m.text_start - off, m.text_end - off, m.cost, m.cigar) for m in sub] == \
+           [(m.text_start, m.text_end, m.cost, m.cigar) for m in want if m.text_start >= 64]
+    st = s.stats()
+    assert st["scan_launches"] == 1 and st["text_bytes"] == n
+    buf.free()
