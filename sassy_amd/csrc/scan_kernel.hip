@@ -186,20 +186,21 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
   return (dec ? kStDec : 0u) | (amb ? kStAmb : 0u);
 }
 
-// 16 text bytes that straddle or lie past the end of the buffer (cold path).
+// 16 text bytes that straddle or lie past the end of the buffer (cold path): bytes past the end
+// read as 'X' (reference: src/search.rs:202-207).
 __device__ __noinline__ uint4 load_tail16(const uint8_t* text, uint64_t off, uint64_t text_len) {
-  uint32_t wd[4] = {0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u};  // 'X'
+  uint64_t lo = 0x5858585858585858ull, hi = 0x5858585858585858ull;
+  if (off < text_len) {
+    const uint32_t valid = (uint32_t)min((uint64_t)16, text_len - off);
 #pragma unroll 1
-  for (int q = 0; q < 16; ++q) {
-    if (off + q < text_len) {
-      const uint32_t sh = 8u * (q & 3);
-      const uint32_t ch = text[off + q];
-      const int wi = q >> 2;
-      const uint32_t nv = (wd[wi == 0 ? 0 : wi == 1 ? 1 : wi == 2 ? 2 : 3] & ~(0xFFu << sh)) | (ch << sh);
-      if (wi == 0) wd[0] = nv; else if (wi == 1) wd[1] = nv; else if (wi == 2) wd[2] = nv; else wd[3] = nv;
+    for (uint32_t q = 0; q < valid; ++q) {
+      const uint64_t ch = text[off + q];
+      const uint32_t sh = 8u * (q & 7u);
+      if (q < 8) lo = (lo & ~(0xFFull << sh)) | (ch << sh);
+      else hi = (hi & ~(0xFFull << sh)) | (ch << sh);
     }
   }
-  return make_uint4(wd[0], wd[1], wd[2], wd[3]);
+  return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 
 template <int PROFILE>
