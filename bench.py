@@ -1,0 +1,263 @@
+#!/usr/bin/env python
+"""bench.py -- the headline measurement of the search path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], the one the metric is quoted on; configs[4] for N > 1):
+Searcher::<Dna>::new_fwd().search(pattern, text, k) with |pattern| = 32 (seeded random 32-mer),
+k = 3, on 3 GB of synthetic random-ACGT text PER GPU that is already resident in HBM when the
+timed region starts (generated on the device; one planted near-match per MiB so that
+"matches/sec" means something).  A "step" is one full search of the resident shard: scan kernel,
+report resolution, traceback, Match records (with cigars) on the host -- and, for N > 1, the
+RCCL gather of all ranks' match lists to rank 0 and the cross-shard merge.  Weak scaling: the
+per-GPU text is fixed, total text = N x 3 GB.
+
+One JSON line on stdout (rank 0).  `roofline` is for the dominant kernel (scan_kernel):
+algorithmic bytes per launch = text bytes scanned (every text byte is read from HBM exactly once,
+SURVEY 8d) divided by the kernel's duration measured with HIP events on the searcher's stream
+inside the timed steps.  `cpu_baseline` (N = 1 only) times the reference-shaped CPU port
+(oracle/sassy_refstyle.c, kind "port": the reference is Rust and cannot be built here) on the
+host cores of the same box over the same text.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+METRIC = "GB text/sec (+ matches/sec) |P|=32 k=3 DNA, 1/2/4/8 MI355X vs CPU"
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def cpu_baseline(host_text, pat, k, profile, gpu_ends, passes):
+    """Reference-shaped CPU port on all host cores over the same text (see module docstring)."""
+    import threading
+
+    import numpy as np
+
+    import oracle
+
+    n = host_text.size
+    m = len(pat)
+    cores = os.cpu_count() or 1
+    T = max(1, min(cores, 256))
+    ov = -(-(m + k + 1) // 64) * 64
+    per = -(-n // T)
+    per = -(-per // 64) * 64
+    shards = []
+    for t in range(T):
+        a, b = t * per, min((t + 1) * per, n)
+        if a >= b:
+            break
+        shards.append((a, b, max(0, a - ov)))
+    results = [None] * len(shards)
+
+    def work(i):
+        a, b, s = shards[i]
+        ends, _ = oracle.refstyle_ends(profile, pat, host_text[s:b], k)
+        results[i] = [(p + s, c) for p, c in ends if (p + s > a or a == 0) and p + s <= b]
+
+    oracle.lib()  # build / load outside the timed region
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        th = [threading.Thread(target=work, args=(i,)) for i in range(len(shards))]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+    dt = time.perf_counter() - t0
+    ends = [e for r in results for e in r]
+    # single thread, one search call, on a 2^28-byte slice (comparable to the reference's
+    # published 1.2-2.1 GB/s per thread)
+    sl = host_text[: min(n, 1 << 28)]
+    t1 = time.perf_counter()
+    oracle.refstyle_ends(profile, pat, sl, k)
+    st = time.perf_counter() - t1
+    return {
+        "value": round(n * passes / dt / 1e9, 3),
+        "unit": "GB/s",
+        "cores": len(shards),
+        "kind": "port",
+        "sample": f"{passes} passes over the full {n} byte text of this run, split into {len(shards)} "
+                  f"shards with {ov} bytes overlap, one thread each "
+                  f"(oracle/sassy_refstyle.c, gcc -O3 -mavx2 -mbmi2, 4x u64 lanes)",
+        "single_thread_gbps": round(sl.size / st / 1e9, 3),
+        "cpu_seconds": round(dt * len(shards), 2),
+        "host_cpus": cores,
+        "ends_equal_gpu": ends == gpu_ends,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--text-bytes", type=int, default=3_000_000_000, help="text bytes per GPU")
+    ap.add_argument("--pattern-len", type=int, default=32)
+    ap.add_argument("--k", type=int, default=3)
+    ap.add_argument("--profile", default="dna")
+    ap.add_argument("--plant-stride", type=int, default=1 << 20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-passes", type=int, default=4)
+    args = ap.parse_args()
+
+    import torch
+
+    import sassy_amd
+    from sassy_amd import multigpu
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+
+    # ---------------------------------------------------------------- workload
+    n_per = args.text_bytes // 64 * 64
+    total = n_per * world
+    m, k = args.pattern_len, args.k
+    seed_text, seed_pat = 42, 43
+    # the pattern: seeded random ACGT m-mer -- a tiny host-side use of the same
+    # counter-based generator; computed with numpy to keep the oracle out of the product path
+    pat = bytes(_dna_bytes(seed_pat, 0, m))
+    if args.profile == "iupac" and m >= 200:
+        p = bytearray(pat)
+        p[50], p[100], p[150], p[199] = ord("N"), ord("R"), ord("Y"), ord("W")
+        pat = bytes(p)
+    halo = 0 if rank == 0 else sassy_amd.required_halo(m, k)
+    a = rank * n_per
+    buf = torch.empty(halo + n_per + 4096, dtype=torch.uint8, device=device)
+    sassy_amd.generate_dna(buf.data_ptr(), halo + n_per, seed_text, a - halo)
+    planted = sassy_amd.plant(buf.data_ptr(), halo + n_per, a - halo, total, seed_text,
+                              bytes(c if c in b"ACGT" else 65 for c in pat), k, args.plant_stride)
+    torch.cuda.synchronize()
+    searcher = sassy_amd.Searcher(args.profile, rc=False)
+
+    def step():
+        r = searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
+        local = multigpu.ShardResult(r.matches, r.exit_state, r.conditional_index)
+        if world == 1:
+            return multigpu.merge_shard_results([local]), searcher.stats()
+        shards = multigpu.gather_shard_results(local, torch, dist, device, sassy_amd.Match)
+        merged = multigpu.merge_shard_results(shards) if rank == 0 else None
+        return merged, searcher.stats()
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    scan_ms, trace_ms, matches = 0.0, 0.0, None
+    for _ in range(args.steps):
+        matches, st = step()
+        scan_ms += st["scan_ms"]
+        trace_ms += st["trace_ms"]
+    sync()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed, scan_ms / max(1, args.steps)], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed, scan_avg_ms = float(el[0]), float(el[1])
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total * args.steps / elapsed / 1e9
+    achieved = n_per / (scan_avg_ms / 1e3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("scan_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": METRIC,
+        "value": round(value, 3),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"BASELINE config {'2' if world == 1 else '5'}: Searcher::<{args.profile.capitalize()}>::new_fwd()"
+                         f".search, |pattern|={m} (seeded random), k={k}, {n_per} B random-ACGT text per GPU "
+                         f"resident in HBM, one planted near-match per {args.plant_stride} B; step = scan + "
+                         f"traceback + Match records on host" + (" + RCCL gather to rank 0" if world > 1 else "")),
+            "text_bytes_per_gpu": n_per,
+            "total_text_bytes": total,
+            "pattern_len": m,
+            "k": k,
+            "profile": args.profile,
+            "parallelism": f"text sharded x{world}, one process per GPU",
+        },
+        "matches": len(matches),
+        "matches_per_s": round(len(matches) * args.steps / elapsed, 1),
+        "planted_rank0": planted,
+        "scan_kernel_ms": round(scan_avg_ms, 4),
+        "trace_ms_per_step": round(trace_ms / args.steps, 4),
+        "roofline": {
+            "bound": "hbm",
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4),
+            "traffic": traffic,
+            "kernel": "scan_kernel",
+            "algorithmic_bytes_per_launch": n_per,
+        },
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        host = buf[:n_per].cpu().numpy()
+        gpu_ends = [(mm.text_end, mm.cost) for mm in matches]
+        out["cpu_baseline"] = cpu_baseline(host, pat, k, args.profile, gpu_ends, args.cpu_passes)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _dna_bytes(seed, first, n):
+    """The synthetic-text function of SURVEY 8(d) in numpy (pattern generation only)."""
+    import numpy as np
+    idx = np.arange(first, first + n, dtype=np.uint64)
+    blk = idx >> np.uint64(5)
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + blk
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        x = x ^ (x >> np.uint64(31))
+    code = (x >> (np.uint64(2) * (idx & np.uint64(31)))) & np.uint64(3)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[code.astype(np.int64)]
+
+
+if __name__ == "__main__":
+    main()
