@@ -8,9 +8,9 @@ enum Profile : uint32_t { PROFILE_ASCII = 0, PROFILE_DNA = 1, PROFILE_IUPAC = 2 
 
 constexpr int kWave = 64;              // gfx950 wavefront
 constexpr int kWavesPerGroup = 4;      // 256-thread workgroups, every wave works alone
-constexpr int kTileBytes = 64 * 128;   // text tile of one wave: 64 lane chunks x 2 blocks x 64 B
-constexpr int kMaxSlots = 32;          // profile slots (distinct pattern letters) per search
-constexpr int kGroupHeaderBytes = 64;  // IUPAC letter -> base-set table at the start of LDS
+constexpr int kTileBytes = 64 * 128;   // text tile of one wave: 64 lane chunks x 2 blocks x 64 B,
+                                       // 16-byte slots XOR-swizzled by (owner>>1)&7
+constexpr int kMaxSlots = 16;          // profile slots (distinct pattern letters) per search
 
 // candidate flags
 constexpr uint32_t kCandCond = 1u;     // report depends on the plateau-entry direction left of the chunk
@@ -46,7 +46,8 @@ struct ScanParams {
   uint32_t lds_per_wave;      // bytes
   uint32_t cand_cap;
   uint32_t n_iter;            // iterations of the block loop
-  const uint32_t* row_off;    // device, m entries: byte offset of the row's slot mask = slot*512
+  const uint32_t* row_tab;    // device, 8*nwords words: one byte per pattern row = 2 * its profile
+                              // slot (row r of word w: byte r&3 of row_tab[8w + (r>>2)])
   Candidate* cand;            // device, cand_cap entries
   uint32_t* cand_count;       // device counter (keeps counting past cand_cap)
   uint8_t* chunk_state;       // device, n_chunks entries

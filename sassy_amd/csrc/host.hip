@@ -275,6 +275,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   uint64_t bpl = (owned + target_lanes - 1) / target_lanes;
   const uint64_t min_bpl = std::max<uint64_t>(8, 6ull * P.wb);
   if (bpl < min_bpl) bpl = min_bpl;
+  bpl += bpl & 1;  // even: a staged pair of blocks is then always one aligned 128-byte line
   if (bpl > 0xFFFFFFFFull / 2) return fail(SASSY_HIP_EUNSUPPORTED, "text too large for one launch");
   P.bpl = (uint32_t)bpl;
   P.n_chunks = (owned + bpl - 1) / bpl;
@@ -282,16 +283,16 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   P.flags = (all_minima ? kScanAllMinima : 0u) | (sh.text_start ? kScanTextStart : 0u) |
             (sh.text_end ? kScanTextEnd : 0u);
   const uint32_t bucket = plan.nslots <= 4 ? 4 : plan.nslots <= 8 ? 8 : 16;
-  P.lds_per_wave = (uint32_t)kTileBytes + bucket * 512u + (plan.nwords > 1 ? plan.nwords * 512u : 0u);
-  const size_t smem = kGroupHeaderBytes + (size_t)kWavesPerGroup * P.lds_per_wave;
+  P.lds_per_wave = (uint32_t)kTileBytes + bucket * 512u + plan.nwords * 512u;
+  const size_t smem = (size_t)kWavesPerGroup * P.lds_per_wave;
   if (smem > 160 * 1024) return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
   for (int s = 0; s < kMaxSlots; ++s) P.slot_val[s] = plan.slot_val[s];
   const uint64_t groups = (P.n_chunks + 255) / 256;
   if (groups > 0x7FFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "grid too large");
   const uint32_t grid = (uint32_t)groups;
 
-  if (int rc = S->d_rowoff.reserve(plan.row_off.size())) return rc;
-  HIP_TRY(hipMemcpyAsync(S->d_rowoff.p, plan.row_off.data(), plan.row_off.size() * sizeof(uint32_t),
+  if (int rc = S->d_rowoff.reserve(plan.row_tab.size())) return rc;
+  HIP_TRY(hipMemcpyAsync(S->d_rowoff.p, plan.row_tab.data(), plan.row_tab.size() * sizeof(uint32_t),
                          hipMemcpyHostToDevice, S->stream));
   if (int rc = S->d_state.reserve(P.n_chunks)) return rc;
   if (int rc = S->d_count.reserve(4)) return rc;
@@ -301,7 +302,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     if (int rc = S->d_counters.reserve(2)) return rc;
     HIP_TRY(hipMemsetAsync(S->d_counters.p, 0, 2 * sizeof(unsigned long long), S->stream));
   }
-  P.row_off = S->d_rowoff.p;
+  P.row_tab = S->d_rowoff.p;
   P.chunk_state = S->d_state.p;
   P.cand_count = S->d_count.p;
   P.counters = S->want_counters ? S->d_counters.p : nullptr;

@@ -80,7 +80,8 @@ struct PatternPlan {
   uint32_t nslots = 0;
   uint32_t nwords = 0;               // ceil(m / 32)
   uint8_t slot_val[kMaxSlots] = {};  // Dna: 2-bit code; Iupac: base-set nibble; Ascii: byte
-  std::vector<uint32_t> row_off;     // per row: slot * 512 (LDS byte offset), padded to 32*nwords
+  std::vector<uint32_t> row_tab;     // one byte per row = 2 * its profile slot, 4 rows per word,
+                                     // 8 words per 32 rows (padded with slot 0)
 };
 
 // Profile::encode_pattern (dna.rs:19-23, iupac.rs:18-36, ascii.rs:18-29).
@@ -90,12 +91,13 @@ inline bool make_plan(Profile pr, const uint8_t* pat, size_t m, PatternPlan& pla
   if (m > (1u << 20)) { err = "pattern longer than 2^20 is not supported"; return false; }
   plan.m = (uint32_t)m;
   plan.nwords = (uint32_t)((m + 31) / 32);
-  plan.row_off.assign((size_t)plan.nwords * 32, 0u);
+  plan.row_tab.assign((size_t)plan.nwords * 8, 0u);
+  auto set_row = [&](size_t j, uint32_t slot) { plan.row_tab[j >> 2] |= (2u * slot) << (8 * (j & 3)); };
   std::vector<uint8_t> letters;
   if (pr == PROFILE_DNA) {
     plan.nslots = 4;
     for (int s = 0; s < 4; ++s) plan.slot_val[s] = (uint8_t)s;
-    for (size_t j = 0; j < m; ++j) plan.row_off[j] = (uint32_t)((pat[j] >> 1) & 3) * 512u;
+    for (size_t j = 0; j < m; ++j) set_row(j, (uint32_t)((pat[j] >> 1) & 3));
     return true;
   }
   if (pr == PROFILE_IUPAC) {
@@ -110,7 +112,7 @@ inline bool make_plan(Profile pr, const uint8_t* pat, size_t m, PatternPlan& pla
     size_t s = 0;
     while (s < letters.size() && letters[s] != c) ++s;
     if (s == letters.size()) letters.push_back(c);
-    plan.row_off[j] = (uint32_t)s * 512u;
+    if (s < 16) set_row(j, (uint32_t)s);
   }
   if (letters.size() > 16) {
     // Iupac: the reference's profile holds 16 masks and asserts (iupac.rs:69); Ascii: 256 in the

@@ -13,12 +13,16 @@
 //     blocks never leave the lane: 32 rows are packed into one 32-bit register pair (more rows:
 //     one LDS slot pair per 32 rows).
 //   * text reaches the lanes through an LDS tile: 8 coalesced 16 B/lane loads fetch 128 B
-//     (one full cache line, 2 blocks) for each of the 64 lane chunks of a wave.
-//   * the per-block equality masks ("profile") are built wave-cooperatively: all 64 lanes read
-//     one byte of a block from the tile, one v_cmp per profile slot yields the 64-bit mask in an
-//     SGPR pair (the ballot), v_writelane drops it into the owner lane's register; masks then
-//     live in LDS so that a pattern row fetches its Eq word with one conflict-free ds_read_b64
-//     at a wave-uniform slot offset.
+//     (one full cache line = 2 blocks) for each of the 64 lane chunks of a wave; the 16-byte
+//     slots of a tile row are XOR-swizzled so that every lane then reads its own 64 bytes back
+//     with four conflict-free ds_read_b128.
+//   * the per-block equality masks ("profile", reference: Profile::encode_ref) are built by every
+//     lane for its own block, all 64 lanes in parallel: bit b of the 4 bytes of a dword is
+//     isolated with one v_and and gathered into a nibble with one v_dot4_u32_u8 (weights 1,2,4,8
+//     / 16..128), giving the 64-bit bit-plane of that text bit; the slot masks are boolean
+//     functions of the planes (Dna: 2 planes; Iupac: 5 planes through a bit-sliced letter->base-set
+//     table; Ascii: 8 planes).  Masks go to LDS so that a pattern row fetches its Eq word with
+//     one conflict-free ds_read_b64 at a wave-uniform slot offset.
 //   * a block whose last row has no cell <= k (the normal case on random text) costs one cheap
 //     popcount bound; only blocks that may hold a match run the exact 64-step minima scan and
 //     append (end position, cost) records through an atomic counter.
@@ -37,25 +41,13 @@ namespace sassy_hip {
 __device__ __forceinline__ uint32_t lo32(uint64_t x) { return (uint32_t)x; }
 __device__ __forceinline__ uint32_t hi32(uint64_t x) { return (uint32_t)(x >> 32); }
 
-// v_writelane_b32: drop a wave-uniform (SGPR) value into one lane of a VGPR.  clang has no builtin
-// for it.  gfx9 VALU instructions may read only one SGPR (constant bus limit 1), so the lane
-// select travels in M0 (which does not count) and the data in an SGPR.  M0 is written by scalar
-// code, one wait state before its first VALU reader; four 64-bit masks go per statement.
-__device__ __forceinline__ void writelane_x8(uint32_t (&v)[8], const uint32_t (&sv)[8], int L) {
-  asm volatile(
-      "s_mov_b32 m0, %16\n\t"
-      "s_nop 0\n\t"
-      "v_writelane_b32 %0, %8, m0\n\t"
-      "v_writelane_b32 %1, %9, m0\n\t"
-      "v_writelane_b32 %2, %10, m0\n\t"
-      "v_writelane_b32 %3, %11, m0\n\t"
-      "v_writelane_b32 %4, %12, m0\n\t"
-      "v_writelane_b32 %5, %13, m0\n\t"
-      "v_writelane_b32 %6, %14, m0\n\t"
-      "v_writelane_b32 %7, %15, m0"
-      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7])
-      : "s"(sv[0]), "s"(sv[1]), "s"(sv[2]), "s"(sv[3]), "s"(sv[4]), "s"(sv[5]), "s"(sv[6]), "s"(sv[7]),
-        "s"(L));  // M0 is reserved (not allocated) on gfx9, so it needs no clobber entry
+// v_bitop3_b32 with an explicit truth table: result bit = TT[(a << 2) | (b << 1) | c].
+template <int TT>
+__device__ __forceinline__ uint32_t bitop3(uint32_t a, uint32_t b, uint32_t c) {
+  return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+}
+__device__ __forceinline__ uint32_t mux(uint32_t s, uint32_t x0, uint32_t x1) {  // s ? x1 : x0
+  return bitop3<0xAC>(s, x0, x1);
 }
 
 // One 64-column word of horizontal deltas (+1 mask, -1 mask), kept as explicit 32-bit halves so
@@ -92,8 +84,8 @@ __device__ __forceinline__ void dp_row(DpWord& V, uint2 eq, uint32_t hp0, uint32
 // Lower bound on the minimum of the 65 cells of a row: cell b = ds + P_b - M_b with P_b / M_b the
 // number of +1 / -1 deltas among the first b columns.  Inside byte q of the word every cell is
 // >= ds + P_{8q} - M_{8q+8}.  Returns true when some cell MAY be <= k (never false for a live row).
-__device__ __forceinline__ bool row_maybe_live(int ds, uint64_t vp, uint64_t vm, int k) {
-  const uint32_t pl = lo32(vp), ph = hi32(vp), ml = lo32(vm), mh = hi32(vm);
+__device__ __forceinline__ bool row_maybe_live(int ds, const DpWord& V, int k) {
+  const uint32_t pl = V.vpl, ph = V.vph, ml = V.vml, mh = V.vmh;
   const int P8 = __popc(pl & 0xFFu), P16 = __popc(pl & 0xFFFFu), P24 = __popc(pl & 0xFFFFFFu);
   const int P32 = __popc(pl);
   const int P40 = P32 + __popc(ph & 0xFFu), P48 = P32 + __popc(ph & 0xFFFFu);
@@ -144,8 +136,8 @@ __device__ __forceinline__ void emit(const EmitCtx& P, uint64_t gpos, int cost, 
 //   emitted) or is warm-up (state only); x0: first local column whose <=k values are exact
 //   (-1: all); last_warm: this is the block right before the chunk's first owned block.
 __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64_t vm, int ds,
-                                        uint64_t b, bool owned, bool last_warm, int64_t x0,
-                                        uint32_t state) {
+                                            uint64_t b, bool owned, bool last_warm, int64_t x0,
+                                            uint32_t state) {
   bool dec = (state & kStDec) != 0, amb = (state & kStAmb) != 0;
   const int k = (int)P.k;
   const bool all = (P.flags & kScanAllMinima) != 0;
@@ -203,106 +195,193 @@ __device__ __noinline__ uint4 load_tail16(const uint8_t* text, uint64_t off, uin
   return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 
-template <int PROFILE>
-__device__ __forceinline__ uint32_t text_xform(uint32_t c, const unsigned char* nibtab) {
-  if (PROFILE == PROFILE_DNA) return (c >> 1) & 3u;   // reference: src/profiles/dna.rs:100-102
-  if (PROFILE == PROFILE_IUPAC) return nibtab[c & 31u];  // reference: src/profiles/iupac.rs:281-330
-  return c;
-}
-template <int PROFILE>
-__device__ __forceinline__ bool slot_test(uint32_t t, uint32_t sv) {
-  if (PROFILE == PROFILE_IUPAC) return (t & sv) != 0;  // base sets intersect (iupac.rs:104-126)
-  return t == sv;                                      // Dna code / Ascii byte equality
+// ------------------------------------------------------------------ the profile, lane-parallel
+// Bit-plane BIT of the lane's 64 text bytes: bit c of the result = bit BIT of byte c.
+// Per dword: v_and isolates the bit of its 4 bytes, v_dot4_u32_u8 with weights 1,2,4,8 (even
+// dword of a pair) / 16,32,64,128 (odd dword) gathers them; 8 chars land in bits BIT..BIT+7.
+template <int BIT>
+__device__ __forceinline__ uint2 bit_plane(const uint32_t (&x)[16]) {
+  constexpr uint32_t kSel = 0x01010101u << BIT;
+  uint32_t v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t a = __builtin_amdgcn_udot4(x[2 * i] & kSel, 0x08040201u, 0u, false);
+    v[i] = __builtin_amdgcn_udot4(x[2 * i + 1] & kSel, 0x80402010u, a, false);
+  }
+  uint2 r;
+  r.x = (v[0] >> BIT) | (v[1] << (8 - BIT)) | (v[2] << (16 - BIT)) | (v[3] << (24 - BIT));
+  r.y = (v[4] >> BIT) | (v[5] << (8 - BIT)) | (v[6] << (16 - BIT)) | (v[7] << (24 - BIT));
+  return r;
 }
 
-// Masks of the 64 blocks of a wave, one block per step: lane i reads byte i of block L from the
-// tile, one compare per slot gives the 64-bit equality mask as a wave-uniform value, which is
-// written into lane L (the block's owner).  All NS slots are always built (the host pads unused
-// slots with a value that never matches) so the body is branch-free.
+// IUPAC letter (c & 31) -> low nibble of its base set; non-letters act as N (15), X = 0
+// (reference: src/profiles/iupac.rs:281-330).  A=1 C=2 T=4 G=8.
+__host__ __device__ constexpr int iupac_nib(int i) {
+  return i == 1 ? 1 : i == 3 ? 2 : i == 20 ? 4 : i == 21 ? 4 : i == 7 ? 8 : i == 14 ? 15
+       : i == 18 ? 9 : i == 25 ? 6 : i == 19 ? 10 : i == 23 ? 5 : i == 11 ? 12 : i == 13 ? 3
+       : i == 2 ? 14 : i == 4 ? 13 : i == 8 ? 7 : i == 22 ? 11 : i == 24 ? 0 : 15;
+}
+// Truth table (index = b2*4 + b1*2 + b0) of output bit O of the nibble table for letters
+// 8*HI .. 8*HI+7.
+template <int O, int HI>
+struct IupacTT {
+  static constexpr int value() {
+    int tt = 0;
+    for (int i = 0; i < 8; ++i) tt |= ((iupac_nib(HI * 8 + i) >> O) & 1) << i;
+    return tt;
+  }
+};
+// Bit-sliced table lookup: base-set bit O of all 32 text chars of a half word, from the five
+// letter-index planes b0..b4: Shannon expansion on b4, b3 over four 3-input functions.
+template <int O>
+__device__ __forceinline__ uint32_t iupac_base_plane(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3,
+                                                     uint32_t b4) {
+  const uint32_t g0 = bitop3<IupacTT<O, 0>::value()>(b2, b1, b0);
+  const uint32_t g1 = bitop3<IupacTT<O, 1>::value()>(b2, b1, b0);
+  const uint32_t g2 = bitop3<IupacTT<O, 2>::value()>(b2, b1, b0);
+  const uint32_t g3 = bitop3<IupacTT<O, 3>::value()>(b2, b1, b0);
+  return mux(b4, mux(b3, g0, g1), mux(b3, g2, g3));
+}
+
+// Slot masks of one block from the lane's 64 text bytes.  m[s] = mask of slot s (lo, hi).
 template <int PROFILE, int NS>
-__device__ __forceinline__ void build_masks(const ScanParams& P, const unsigned char* src,
-                                            const unsigned char* nibtab, uint32_t (&msk)[NS / 4][8]) {
-  static_assert(NS % 4 == 0, "slots are handled in groups of four");
-  uint32_t sv[NS];
+__device__ __forceinline__ void build_masks(const uint32_t (&x)[16], const ScanParams& P, uint2 (&m)[NS]) {
+  if constexpr (PROFILE == PROFILE_DNA) {
+    // code = (c >> 1) & 3: A=0 C=1 T=2 G=3 (reference: src/profiles/dna.rs:19-40)
+    const uint2 p1 = bit_plane<1>(x), p2 = bit_plane<2>(x);
+    m[0] = make_uint2(~(p1.x | p2.x), ~(p1.y | p2.y));
+    m[1] = make_uint2(p1.x & ~p2.x, p1.y & ~p2.y);
+    m[2] = make_uint2(~p1.x & p2.x, ~p1.y & p2.y);
+    m[3] = make_uint2(p1.x & p2.x, p1.y & p2.y);
+  } else if constexpr (PROFILE == PROFILE_IUPAC) {
+    // mask[slot] = (base set of the text letter) intersects (base set of the slot's pattern
+    // letter) (reference: src/profiles/iupac.rs:68-128)
+    const uint2 b0 = bit_plane<0>(x), b1 = bit_plane<1>(x), b2 = bit_plane<2>(x), b3 = bit_plane<3>(x),
+                b4 = bit_plane<4>(x);
+    uint2 base[4];
+    base[0] = make_uint2(iupac_base_plane<0>(b0.x, b1.x, b2.x, b3.x, b4.x), iupac_base_plane<0>(b0.y, b1.y, b2.y, b3.y, b4.y));
+    base[1] = make_uint2(iupac_base_plane<1>(b0.x, b1.x, b2.x, b3.x, b4.x), iupac_base_plane<1>(b0.y, b1.y, b2.y, b3.y, b4.y));
+    base[2] = make_uint2(iupac_base_plane<2>(b0.x, b1.x, b2.x, b3.x, b4.x), iupac_base_plane<2>(b0.y, b1.y, b2.y, b3.y, b4.y));
+    base[3] = make_uint2(iupac_base_plane<3>(b0.x, b1.x, b2.x, b3.x, b4.x), iupac_base_plane<3>(b0.y, b1.y, b2.y, b3.y, b4.y));
 #pragma unroll
-  for (int s = 0; s < NS; ++s)  // unused slots: Iupac empty set (0) / a value no byte equals
-    sv[s] = (s < (int)P.nslots) ? (uint32_t)P.slot_val[s] : (PROFILE == PROFILE_IUPAC ? 0u : 0x100u);
-#pragma unroll 4
-  for (int L = 0; L < 64; ++L) {
-    const uint32_t c = src[L * 128];
-    const uint32_t t = text_xform<PROFILE>(c, nibtab);
+    for (int s = 0; s < NS; ++s) {
+      const uint32_t sv = P.slot_val[s];  // wave-uniform; unused slots hold 0 -> empty mask
+      uint2 r = make_uint2(0u, 0u);
 #pragma unroll
-    for (int g = 0; g < NS / 4; ++g) {
-      uint32_t bal[8];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint64_t b64 = __ballot(slot_test<PROFILE>(t, sv[g * 4 + q]));
-        bal[2 * q] = lo32(b64);
-        bal[2 * q + 1] = hi32(b64);
+      for (int o = 0; o < 4; ++o) {
+        const uint32_t sel = ((sv >> o) & 1u) ? 0xFFFFFFFFu : 0u;
+        r.x |= base[o].x & sel;
+        r.y |= base[o].y & sel;
       }
-      writelane_x8(msk[g], bal, L);
+      m[s] = r;
+    }
+  } else {
+    // Ascii: byte equality with the slot's pattern byte (reference: src/profiles/ascii.rs:75-90)
+    uint2 pl[8];
+    pl[0] = bit_plane<0>(x); pl[1] = bit_plane<1>(x); pl[2] = bit_plane<2>(x); pl[3] = bit_plane<3>(x);
+    pl[4] = bit_plane<4>(x); pl[5] = bit_plane<5>(x); pl[6] = bit_plane<6>(x); pl[7] = bit_plane<7>(x);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const uint32_t sv = P.slot_val[s];
+      uint2 r = (s < (int)P.nslots) ? make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu) : make_uint2(0u, 0u);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const uint32_t inv = ((sv >> b) & 1u) ? 0u : 0xFFFFFFFFu;  // XNOR with the slot's bit
+        r.x &= pl[b].x ^ inv;
+        r.y &= pl[b].y ^ inv;
+      }
+      m[s] = r;
     }
   }
 }
 
-// first block a chunk touches: its first owned block minus the warm-up, clipped at the buffer
-// start, rounded down to an even block so that a staged pair of blocks is one 128-byte line.
-__device__ __forceinline__ uint64_t chunk_blk0(const ScanParams& P, uint64_t chunk) {
-  const uint64_t start = P.first_owned_block + chunk * (uint64_t)P.bpl;
-  const uint64_t b0 = start > P.wb ? start - P.wb : 0;
-  return b0 & ~1ull;
+// first block a chunk touches: its first owned block minus `back` = the warm-up plus the parity
+// that makes it even (a staged pair of blocks is then one aligned 128-byte line; bpl is even),
+// clipped at the buffer start (only the very first chunk of a text clips).
+__device__ __forceinline__ uint64_t chunk_blk0(uint64_t first_owned, uint32_t bpl, uint32_t back, uint64_t chunk) {
+  const uint64_t start = first_owned + chunk * (uint64_t)bpl;
+  return start > back ? start - back : 0;
+}
+
+typedef const uint32_t __attribute__((address_space(4)))* const_u32_ptr;  // scalar (s_load) reads
+
+// Row -> LDS offset of its slot mask, from the packed row table: one byte per row holding
+// slot*2, so that (byte << 8) = slot * 512.  Scalar extraction (s_bfe) + one VALU add.
+__device__ __forceinline__ uint32_t row_mask_off(const uint32_t (&pk)[8], int r) {
+  return ((pk[r >> 2] >> (8 * (r & 3))) & 0xFFu) << 8;
+}
+
+// The rows of one 32-row word.  pk_in holds the profile slot of each row (one byte per row).
+__device__ __forceinline__ void dp_word(DpWord& V, const unsigned char* my_masks, uint32_t ohp, uint32_t ohm,
+                                        const uint32_t (&pk_in)[8], uint32_t rows, uint32_t& nhp_out,
+                                        uint32_t& nhm_out) {
+  // Opaque copies: keeps the 32 per-row offsets from being hoisted out of the block loop as 32
+  // live scalars (SGPR spills cost VALU v_readlane ops); re-deriving them is one s_bfe each.
+  uint32_t pk[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    pk[i] = pk_in[i];
+    asm volatile("" : "+s"(pk[i]));
+  }
+  uint32_t nhp = 0, nhm = 0, done = 0;
+  uint2 eqn[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) eqn[u] = *reinterpret_cast<const uint2*>(my_masks + row_mask_off(pk, u));
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    if (4u * g + 4u <= rows) {
+      uint2 eqc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) eqc[u] = eqn[u];
+      if (g < 7) {  // prefetch the next group's Eq words while this group computes
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          eqn[u] = *reinterpret_cast<const uint2*>(my_masks + row_mask_off(pk, 4 * g + 4 + u));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        dp_row(V, eqc[u], (ohp >> (31 - (4 * g + u))) & 1u, (ohm >> (31 - (4 * g + u))) & 1u, nhp, nhm);
+      done = 4u * g + 4u;
+    }
+  }
+  // up to three leftover rows when the word's row count is not a multiple of 4: they all lie in
+  // table word done/4
+  if (done < rows) {
+    const uint32_t q = done >> 2;
+    const uint32_t pw = q == 0 ? pk[0] : q == 1 ? pk[1] : q == 2 ? pk[2] : q == 3 ? pk[3]
+                      : q == 4 ? pk[4] : q == 5 ? pk[5] : q == 6 ? pk[6] : pk[7];
+    for (uint32_t r = done; r < rows; ++r) {
+      const uint2 eq = *reinterpret_cast<const uint2*>(my_masks + (((pw >> (8 * (r & 3))) & 0xFFu) << 8));
+      dp_row(V, eq, (ohp >> (31 - r)) & 1u, (ohm >> (31 - r)) & 1u, nhp, nhm);
+    }
+  }
+  if (rows < 32) { nhp <<= (32 - rows); nhm <<= (32 - rows); }
+  nhp_out = nhp;
+  nhm_out = nhm;
 }
 
 template <int PROFILE, int NS>
 __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  unsigned char* nibtab = smem;  // 32 bytes used
-  unsigned char* wbase = smem + kGroupHeaderBytes + (size_t)wave * P.lds_per_wave;
-  unsigned char* tile = wbase;
-  unsigned char* mask_bytes = wbase + kTileBytes;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  unsigned char* wbase = smem + (size_t)wave * P.lds_per_wave;
+  unsigned char* tile = wbase;                                                    // 8 KiB
+  unsigned char* mask_bytes = wbase + kTileBytes;                                 // [NS][64] u64
   uint32_t* carry = reinterpret_cast<uint32_t*>(wbase + kTileBytes + NS * 512);  // [word][hp|hm][lane]
-
-  if (PROFILE == PROFILE_IUPAC) {
-    // letter index (c & 31) -> low nibble of the IUPAC base set; non-letters act as N (=15), X = 0
-    if (threadIdx.x < 32) {
-      const unsigned t = threadIdx.x;
-      unsigned v = 15;
-      switch (t) {
-        case 1: v = 1; break;    // A
-        case 3: v = 2; break;    // C
-        case 20: v = 4; break;   // T
-        case 21: v = 4; break;   // U
-        case 7: v = 8; break;    // G
-        case 14: v = 15; break;  // N
-        case 18: v = 9; break;   // R = A|G
-        case 25: v = 6; break;   // Y = C|T
-        case 19: v = 10; break;  // S = G|C
-        case 23: v = 5; break;   // W = A|T
-        case 11: v = 12; break;  // K = G|T
-        case 13: v = 3; break;   // M = A|C
-        case 2: v = 14; break;   // B = C|G|T
-        case 4: v = 13; break;   // D = A|G|T
-        case 8: v = 7; break;    // H = A|C|T
-        case 22: v = 11; break;  // V = A|C|G
-        case 24: v = 0; break;   // X
-        default: break;
-      }
-      nibtab[t] = (unsigned char)v;
-    }
-    __syncthreads();
-  }
 
   const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * kWavesPerGroup + wave) * kWave;
   if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
   const uint64_t chunk = wave_chunk0 + lane;
 
-  const uint64_t own_lo = P.first_owned_block + chunk * (uint64_t)P.bpl;
-  uint64_t own_hi = own_lo + P.bpl;
+  const uint32_t bpl = P.bpl;
+  const uint64_t first_owned = P.first_owned_block;
+  const uint32_t back = P.wb + (uint32_t)((first_owned + P.wb) & 1u);  // warm-up + evenness (bpl is even)
+  const uint64_t own_lo = first_owned + chunk * (uint64_t)bpl;
+  uint64_t own_hi = own_lo + bpl;
   if (own_hi > P.n_blocks) own_hi = P.n_blocks;
   const bool has_chunk = chunk < P.n_chunks && own_lo < P.n_blocks;
-  const uint64_t blk0 = chunk_blk0(P, chunk);
+  const uint64_t blk0 = chunk_blk0(first_owned, bpl, back, chunk);
   // The chunk's fresh start is the true DP boundary only at column 0 of the whole text.
   const bool exact_start = (blk0 == 0) && (P.flags & kScanTextStart);
   const int64_t x0 = exact_start ? -1 : (int64_t)(blk0 * 64 + P.m + P.k);
@@ -312,16 +391,39 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   const uint32_t nwords = P.nwords;
   const uint32_t last_rows = m - 32 * (nwords - 1);
   const uint32_t last_word_init = last_rows == 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> last_rows);
+  const_u32_ptr row_tab = (const_u32_ptr)(P.row_tab);
+  uint32_t pkw0[8];  // row table of word 0, resident in scalar registers
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pkw0[i] = row_tab[i];
 
   // per-row carries between horizontally adjacent blocks, 32 rows per word, row r of a word at
-  // bit 31-r.  Fresh start: every vertical delta on the left edge is +1 (D[j][start] = j).
-  uint32_t c_hp = nwords == 1 ? last_word_init : 0xFFFFFFFFu, c_hm = 0;  // word 0 in registers
-  if (nwords > 1) {
-    for (uint32_t w = 0; w < nwords; ++w) {
-      carry[(w * 2 + 0) * 64 + lane] = (w == nwords - 1) ? last_word_init : 0xFFFFFFFFu;
-      carry[(w * 2 + 1) * 64 + lane] = 0;
-    }
+  // bit 31-r, one LDS slot pair per word and lane.  Fresh start: every vertical delta on the left
+  // edge is +1 (D[j][start] = j).
+  for (uint32_t w = 0; w < nwords; ++w) {
+    carry[(w * 2 + 0) * 64 + lane] = (w == nwords - 1) ? last_word_init : 0xFFFFFFFFu;
+    carry[(w * 2 + 1) * 64 + lane] = 0;
   }
+
+  // ---- staging geometry: instruction i of a stage loads, for tile row `owner`, the 16-byte
+  // chunk that belongs into slot (lane & 7) of that row; slot = chunk ^ ((owner >> 1) & 7).
+  const uint64_t wave_blk0 = chunk_blk0(first_owned, bpl, back, wave_chunk0);
+  const uint8_t* text_base = P.text + wave_blk0 * 64;
+  uint32_t soff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t owner = (uint32_t)i * 8u + (lane >> 3);
+    const uint32_t slot = lane & 7u;
+    const uint32_t j = slot ^ ((owner >> 1) & 7u);
+    soff[i] = (uint32_t)((chunk_blk0(first_owned, bpl, back, wave_chunk0 + owner) - wave_blk0) * 64) + j * 16u;
+  }
+  // wave-uniform: can every staged byte of this wave be read without a bounds check?
+  const uint64_t wave_last = chunk_blk0(first_owned, bpl, back, wave_chunk0 + 63) + P.n_iter + 2;
+  const bool interior = wave_last * 64 <= P.text_len;
+  // reading side: the lane's own row, logical chunks 4*sub + c
+  const uint32_t fsw = (lane >> 1) & 7u;
+  uint32_t rc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rc[c] = lane * 128u + (((uint32_t)c ^ (fsw & 3u)) << 4);
 
   uint32_t st = kStDec;  // dec = true, amb = false
   EmitCtx ctx;
@@ -334,105 +436,78 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   ctx.flags = P.flags;
 
   unsigned long long cnt_rows = 0, cnt_blocks = 0;
+  const unsigned char* my_masks = mask_bytes + lane * 8;
 
   for (uint32_t it = 0; it < P.n_iter; ++it) {
     const uint32_t sub = it & 1u;
     if (sub == 0) {
       // ---- stage 2 blocks (128 B) for each of the 64 lane chunks: 8 x (64 lanes x 16 B) ----
+      if (interior) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const uint32_t owner = (uint32_t)i * 8u + ((uint32_t)lane >> 3);
-        const uint32_t part = (uint32_t)lane & 7u;
-        const uint64_t ob = chunk_blk0(P, wave_chunk0 + owner) + it;
-        const uint64_t off = ob * 64 + part * 16;
-        uint4 v;
-        if (off + 16 <= P.text_len) {
-          v = *reinterpret_cast<const uint4*>(P.text + off);
-        } else {
-          // tail of the text: bytes past the end read as 'X' (reference: src/search.rs:202-207)
-          v = load_tail16(P.text, off, P.text_len);
+        for (int i = 0; i < 8; ++i) {
+          const uint4 v = *reinterpret_cast<const uint4*>(text_base + (uint64_t)it * 64 + soff[i]);
+          *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
         }
-        *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+      } else {
+#pragma unroll 1
+        for (int i = 0; i < 8; ++i) {
+          const uint32_t so = i == 0 ? soff[0] : i == 1 ? soff[1] : i == 2 ? soff[2] : i == 3 ? soff[3]
+                            : i == 4 ? soff[4] : i == 5 ? soff[5] : i == 6 ? soff[6] : soff[7];
+          const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + so;
+          uint4 v;
+          if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
+          else v = load_tail16(P.text, off, P.text_len);
+          *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+        }
       }
     }
 
-    // ---- profile: one 64-bit equality mask per slot for each lane's block ----
-    uint32_t msk[NS / 4][8];  // [slot group][slot-in-group * 2 + (lo|hi)]
+    // ---- the lane's own 64 text bytes -> profile masks -> LDS ----
+    {
+      const uint32_t hs = ((sub << 2) ^ (fsw & 4u)) << 4;  // slot bit 2 selects the block of the pair
+      uint32_t x[16];
 #pragma unroll
-    for (int g = 0; g < NS / 4; ++g)
+      for (int c = 0; c < 4; ++c) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + rc[c] + hs);
+        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+      }
+      uint2 msk[NS];
+      build_masks<PROFILE, NS>(x, P, msk);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) msk[g][q] = 0;
-    build_masks<PROFILE, NS>(P, tile + sub * 64 + lane, nibtab, msk);
-#pragma unroll
-    for (int s = 0; s < NS; ++s)
-      *reinterpret_cast<uint2*>(mask_bytes + s * 512 + lane * 8) =
-          make_uint2(msk[s / 4][(s % 4) * 2], msk[s / 4][(s % 4) * 2 + 1]);
+      for (int s = 0; s < NS; ++s)
+        *reinterpret_cast<uint2*>(mask_bytes + s * 512 + lane * 8) = msk[s];
+    }
 
     // ---- the DP rows of this block ----
     DpWord V;
     V.vpl = V.vph = V.vml = V.vmh = 0;  // row 0 of the matrix is all 0: horizontal deltas 0
     int ds = 0;                         // cost at the block's left edge in the last row
-    const unsigned char* my_masks = mask_bytes + lane * 8;
     for (uint32_t w = 0; w < nwords; ++w) {
-      uint32_t ohp, ohm;
-      if (nwords == 1) {
-        ohp = c_hp; ohm = c_hm;
-      } else {
-        ohp = carry[(w * 2 + 0) * 64 + lane];
-        ohm = carry[(w * 2 + 1) * 64 + lane];
-      }
+      const uint32_t ohp = carry[(w * 2 + 0) * 64 + lane];
+      const uint32_t ohm = carry[(w * 2 + 1) * 64 + lane];
       ds += __popc(ohp) - __popc(ohm);
       const uint32_t rows = (w == nwords - 1) ? last_rows : 32u;
-      // Row -> LDS offset of its slot mask.  Constant address space: wave-uniform reads become
-      // scalar loads, and for m <= 32 they are loop invariant (hoisted out of the block loop).
-      typedef const uint32_t __attribute__((address_space(4)))* const_u32_ptr;
-      const_u32_ptr ro = (const_u32_ptr)(P.row_off) + 32 * w;
-      uint32_t roff[32];
+      uint32_t pkw[8];
+      if (w == 0) {
 #pragma unroll
-      for (int r = 0; r < 32; ++r) roff[r] = ro[r];  // the table is padded to 32*nwords entries
-      uint32_t nhp = 0, nhm = 0;
-      uint32_t done = 0;
-      uint2 eqn[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) eqn[u] = *reinterpret_cast<const uint2*>(my_masks + roff[u]);
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        if (4u * g + 4u <= rows) {
-          uint2 eqc[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) eqc[u] = eqn[u];
-          if (g < 7) {  // prefetch the next group's Eq words while this group computes
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-              eqn[u] = *reinterpret_cast<const uint2*>(my_masks + roff[4 * g + 4 + u]);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            dp_row(V, eqc[u], (ohp >> (31 - (4 * g + u))) & 1u, (ohm >> (31 - (4 * g + u))) & 1u, nhp, nhm);
-          done = 4u * g + 4u;
-        }
-      }
-      // up to three leftover rows when m is not a multiple of 4
-      for (uint32_t r = done; r < rows; ++r) {
-        const uint2 eq = *reinterpret_cast<const uint2*>(my_masks + ro[r]);
-        dp_row(V, eq, (ohp >> (31 - r)) & 1u, (ohm >> (31 - r)) & 1u, nhp, nhm);
-      }
-      if (rows < 32) { nhp <<= (32 - rows); nhm <<= (32 - rows); }
-      if (nwords == 1) {
-        c_hp = nhp; c_hm = nhm;
+        for (int i = 0; i < 8; ++i) pkw[i] = pkw0[i];
       } else {
-        carry[(w * 2 + 0) * 64 + lane] = nhp;
-        carry[(w * 2 + 1) * 64 + lane] = nhm;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pkw[i] = row_tab[8 * w + i];
       }
+      uint32_t nhp, nhm;
+      dp_word(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm);
+      carry[(w * 2 + 0) * 64 + lane] = nhp;
+      carry[(w * 2 + 1) * 64 + lane] = nhm;
     }
-    const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
 
     // ---- last row of the block: anything <= k ? ----
     const uint64_t b = blk0 + it;
     const bool active = has_chunk && b < own_hi;
     if (active) {
       if (P.counters) { cnt_rows += m; cnt_blocks += 1; }
-      if (row_maybe_live(ds, vp, vm, k)) {
+      if (row_maybe_live(ds, V, k)) {
+        const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
         st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
       } else {
         st = kStDec;  // dec = true: a later <=k run can only be entered by a decrease; amb = false
@@ -440,7 +515,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
     }
   }
 
-  if (chunk < P.n_chunks) P.chunk_state[chunk] = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
+  if (chunk < P.n_chunks)
+    P.chunk_state[chunk] = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
   if (P.counters) {
     atomicAdd(&P.counters[0], cnt_rows);
     atomicAdd(&P.counters[1], cnt_blocks);
