@@ -150,11 +150,13 @@ def main():
     searcher = sassy_amd.Searcher(args.profile, rc=False)
 
     def step():
+        # one full search of the resident shard; Match records arrive on the host as one packed
+        # array (include/sassy_hip.h: sassy_hip_Match + cigar pool), for N > 1 gathered to rank 0
         r = searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
-        local = multigpu.ShardResult(r.matches, r.exit_state, r.conditional_index)
+        local = multigpu.pack_result(r)
         if world == 1:
             return multigpu.merge_shard_results([local]), searcher.stats()
-        shards = multigpu.gather_shard_results(local, torch, dist, device, sassy_amd.Match)
+        shards = multigpu.gather_shard_results(local, torch, dist, device)
         merged = multigpu.merge_shard_results(shards) if rank == 0 else None
         return merged, searcher.stats()
 
@@ -237,7 +239,7 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         host = buf[:n_per].cpu().numpy()
-        gpu_ends = [(mm.text_end, mm.cost) for mm in matches]
+        gpu_ends = [(int(r[2]), int(r[5])) for r in matches]
         out["cpu_baseline"] = cpu_baseline(host, pat, k, args.profile, gpu_ends, args.cpu_passes)
     print(json.dumps(out), flush=True)
     if dist is not None:

@@ -73,6 +73,8 @@ sassy_SearcherType *sassy_hip_searcher_new(const char *alphabet, bool rc, float 
 /* Use an existing HIP stream (hipStream_t) for all work of this searcher; NULL = own stream. */
 int sassy_hip_set_stream(sassy_SearcherType *s, void *hip_stream);
 int sassy_hip_get_stats(const sassy_SearcherType *s, sassy_hip_Stats *out);
+/* Count DP word-rows / blocks in the scan kernel (stats.word_rows, stats.blocks); off by default. */
+int sassy_hip_enable_counters(sassy_SearcherType *s, int on);
 
 /* Searcher::search / search_all with full Match records (src/search.rs:510-525, 685-700). */
 int sassy_hip_search(sassy_SearcherType *s, const uint8_t *pattern, size_t pattern_len,
@@ -95,6 +97,7 @@ uint64_t sassy_hip_required_halo(size_t pattern_len, size_t k);
 size_t sassy_hip_result_len(const sassy_hip_Result *r);
 const sassy_hip_Match *sassy_hip_result_matches(const sassy_hip_Result *r);
 const char *sassy_hip_result_cigars(const sassy_hip_Result *r); /* string pool */
+size_t sassy_hip_result_cigars_len(const sassy_hip_Result *r);   /* bytes in the pool */
 /* Shard bookkeeping for the cross-shard plateau rule (see DESIGN.md "seams"):
  * entry_state: 0 = the shard's first report did not depend on the previous shard,
  *              1 = it did (the record with SASSY flag is still in the result, marked below);

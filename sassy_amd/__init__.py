@@ -93,6 +93,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_searcher_new", "sassy_hip_set_stream", "sassy_hip_get_stats",
     "sassy_hip_search", "sassy_hip_search_shard", "sassy_hip_required_halo",
     "sassy_hip_result_len", "sassy_hip_result_matches", "sassy_hip_result_cigars",
+    "sassy_hip_result_cigars_len", "sassy_hip_enable_counters",
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
     "sassy_hip_generate_dna", "sassy_hip_plant",
@@ -149,6 +150,8 @@ def lib():
     L.sassy_hip_result_matches.argtypes = [vp]
     L.sassy_hip_result_cigars.restype = vp
     L.sassy_hip_result_cigars.argtypes = [vp]
+    L.sassy_hip_result_cigars_len.restype = sz
+    L.sassy_hip_result_cigars_len.argtypes = [vp]
     L.sassy_hip_result_exit_state.restype = C.c_int
     L.sassy_hip_result_exit_state.argtypes = [vp]
     L.sassy_hip_result_conditional_index.restype = C.c_int64
@@ -205,26 +208,56 @@ class Match:
         return (self.pattern_idx, self.text_start, self.text_end, self.cost, self.strand, self.cigar)
 
 
+def match_dtype():
+    """numpy view of include/sassy_hip.h: sassy_hip_Match (64 bytes)."""
+    import numpy as np
+    return np.dtype([("pattern_idx", "<u8"), ("text_idx", "<u8"), ("text_start", "<u8"),
+                     ("text_end", "<u8"), ("pattern_start", "<u8"), ("pattern_end", "<u8"),
+                     ("cost", "<i4"), ("strand", "u1"), ("pad_", "u1", (3,)),
+                     ("cigar_off", "<u4"), ("cigar_len", "<u4")])
+
+
 class Result:
-    """Matches of one call plus the shard bookkeeping (see include/sassy_hip.h)."""
+    """Matches of one call plus the shard bookkeeping (see include/sassy_hip.h).
+
+    ``array`` is the C match array copied once into a numpy structured array (match_dtype) and
+    ``pool`` the cigar string pool; ``matches`` materialises reference-style Match objects on
+    first use (a Python object per match is far slower than the search itself)."""
 
     def __init__(self, handle):
+        import numpy as np
         L = lib()
         try:
             n = L.sassy_hip_result_len(handle)
-            ms = L.sassy_hip_result_matches(handle)
+            ptr = L.sassy_hip_result_matches(handle)
+            raw = C.string_at(ptr, n * 64) if n else b""
+            self.array = np.frombuffer(raw, dtype=match_dtype())
+            plen = L.sassy_hip_result_cigars_len(handle)
             pool = L.sassy_hip_result_cigars(handle)
-            self.matches: List[Match] = []
-            for i in range(n):
-                m = ms[i]
-                cig = C.string_at(pool + m.cigar_off, m.cigar_len).decode() if m.cigar_len else ""
-                self.matches.append(Match(m.pattern_idx, m.text_start, m.text_end, m.pattern_start,
-                                          m.pattern_end, m.cost, "-" if m.strand else "+", cig,
-                                          m.text_idx))
+            self.pool = C.string_at(pool, plen) if plen else b""
             self.exit_state = L.sassy_hip_result_exit_state(handle)
             self.conditional_index = L.sassy_hip_result_conditional_index(handle)
+            self._matches = None
         finally:
             L.sassy_hip_result_free(handle)
+
+    def __len__(self):
+        return len(self.array)
+
+    @property
+    def matches(self) -> List["Match"]:
+        if self._matches is None:
+            self._matches = matches_from_array(self.array, self.pool)
+        return self._matches
+
+
+def matches_from_array(array, pool: bytes) -> List["Match"]:
+    out = []
+    for r in array.tolist():
+        (pidx, tidx, ts, te, ps, pe, cost, strand, _pad, coff, clen) = r
+        out.append(Match(pidx, ts, te, ps, pe, cost, "-" if strand else "+",
+                         pool[coff:coff + clen].decode() if clen else "", tidx))
+    return out
 
 
 def _ptr_len(text):

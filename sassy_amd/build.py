@@ -27,6 +27,7 @@ UNITS = [
     ("scan_kernel.hip", "scan_dna.o", ["-DSASSY_SCAN_PROFILE=1"]),
     ("scan_kernel.hip", "scan_iupac.o", ["-DSASSY_SCAN_PROFILE=2"]),
     ("aux_kernels.hip", "aux_kernels.o", []),
+    ("trace_kernel.hip", "trace_kernel.o", []),
     ("host.hip", "host.o", []),
 ]
 HEADERS = ["common.h", "profiles.h", os.path.join("..", "..", "include", "sassy.h"),

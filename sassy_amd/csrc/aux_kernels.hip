@@ -1,5 +1,5 @@
 // aux_kernels.hip -- small device helpers around the scan kernel: synthetic text generator,
-// plant scatter, text reversal for the reverse-complement strand, window gather for traceback.
+// plant scatter, text reversal for the reverse-complement strand.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -83,17 +83,6 @@ __global__ __launch_bounds__(256) void reverse_kernel(const uint8_t* in, uint8_t
   }
 }
 
-// Copy the traceback window of every candidate into a compact buffer:
-// out[c*wlen + i] = text[start[c] + i] for i < len[c].
-__global__ void gather_windows_kernel(const uint8_t* text, const uint64_t* start, const uint32_t* len,
-                                      uint32_t wlen, uint32_t count, uint8_t* out) {
-  const uint32_t c = blockIdx.x;
-  if (c >= count) return;
-  const uint64_t s = start[c];
-  const uint32_t l = len[c];
-  for (uint32_t i = threadIdx.x; i < l; i += blockDim.x) out[(uint64_t)c * wlen + i] = text[s + i];
-}
-
 // ------------------------------------------------------------------ launchers
 hipError_t launch_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first,
                                hipStream_t stream) {
@@ -118,14 +107,6 @@ hipError_t launch_reverse(const uint8_t* d_in, uint8_t* d_out, uint64_t n, hipSt
   uint64_t blocks = ((n + 15) / 16 + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(reverse_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_in, d_out, n);
-  return hipGetLastError();
-}
-
-hipError_t launch_gather_windows(const uint8_t* d_text, const uint64_t* d_start, const uint32_t* d_len,
-                                 uint32_t wlen, uint32_t count, uint8_t* d_out, hipStream_t stream) {
-  if (count == 0) return hipSuccess;
-  hipLaunchKernelGGL(gather_windows_kernel, dim3(count), dim3(64), 0, stream, d_text, d_start, d_len,
-                     wlen, count, d_out);
   return hipGetLastError();
 }
 

@@ -46,6 +46,7 @@ struct ScanParams {
   uint32_t lds_per_wave;      // bytes
   uint32_t cand_cap;
   uint32_t n_iter;            // iterations of the block loop
+  uint32_t stage_blocks;      // 1 or 2: text blocks per lane chunk fetched per staging step
   const uint32_t* row_tab;    // device, 8*nwords words: one byte per pattern row = 2 * its profile
                               // slot (row r of word w: byte r&3 of row_tab[8w + (r>>2)])
   Candidate* cand;            // device, cand_cap entries
@@ -53,6 +54,33 @@ struct ScanParams {
   uint8_t* chunk_state;       // device, n_chunks entries
   unsigned long long* counters; // optional device counters [0]=word rows, [1]=blocks; may be null
   uint8_t slot_val[kMaxSlots]; // per slot: Dna 2-bit code, Iupac base-set nibble, Ascii byte
+};
+
+// One traced report (device traceback kernel output).  32 bytes.
+struct TraceRec {
+  uint64_t text_start;
+  uint64_t text_end;
+  int32_t cost;
+  uint32_t nops;  // alignment columns written to the ops buffer (end -> start order)
+  uint32_t ok;    // 0: no ancestor found / cost mismatch (the reference would panic)
+  uint32_t cand;  // index of the candidate this record belongs to
+};
+
+struct TraceParams {
+  const uint8_t* text;      // device buffer the candidates refer to
+  uint64_t global_offset;   // global position of text[0]
+  uint64_t total_len;       // length of the whole text (window end is clipped to it)
+  const Candidate* cand;
+  const uint32_t* cand_count;
+  uint32_t cand_cap;
+  uint32_t m, k;
+  uint32_t profile;
+  const uint8_t* pattern;   // device copy of the (strand-specific) pattern
+  uint8_t* scratch;         // nthreads * scratch_stride bytes
+  uint32_t scratch_stride;  // bytes per thread: (m+1) * (2k+3) * sizeof(cell)
+  TraceRec* out;            // cand_cap records
+  uint8_t* out_ops;         // cand_cap * ops_stride bytes
+  uint32_t ops_stride;      // >= m + k + 1
 };
 
 }  // namespace sassy_hip

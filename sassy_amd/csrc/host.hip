@@ -30,8 +30,7 @@ hipError_t launch_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint6
 hipError_t launch_scatter_bytes(uint8_t* d_text, uint64_t n, uint64_t first, const uint64_t* d_pos,
                                 const uint8_t* d_val, uint64_t count, hipStream_t stream);
 hipError_t launch_reverse(const uint8_t* d_in, uint8_t* d_out, uint64_t n, hipStream_t stream);
-hipError_t launch_gather_windows(const uint8_t* d_text, const uint64_t* d_start, const uint32_t* d_len,
-                                 uint32_t wlen, uint32_t count, uint8_t* d_out, hipStream_t stream);
+hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stream);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -106,21 +105,22 @@ struct sassy_SearcherType {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   bool device_ready = false;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr;
-  DevBuf<uint8_t> d_text, d_rev, d_state, d_win, d_pbytes;
-  DevBuf<uint32_t> d_rowoff, d_count, d_wlen;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+  DevBuf<uint8_t> d_text, d_rev, d_state, d_pattern, d_scratch, d_ops;
+  DevBuf<uint32_t> d_rowoff, d_count;
   DevBuf<Candidate> d_cand;
-  DevBuf<uint64_t> d_wstart, d_ppos;
+  DevBuf<TraceRec> d_trace;
   DevBuf<unsigned long long> d_counters;
   bool want_counters = false;
   sassy_hip_Stats stats{};
 
   ~sassy_SearcherType() {
-    d_text.release(); d_rev.release(); d_state.release(); d_win.release(); d_pbytes.release();
-    d_rowoff.release(); d_count.release(); d_wlen.release(); d_cand.release();
-    d_wstart.release(); d_ppos.release(); d_counters.release();
+    d_text.release(); d_rev.release(); d_state.release(); d_pattern.release(); d_scratch.release();
+    d_ops.release(); d_rowoff.release(); d_count.release(); d_cand.release(); d_trace.release();
+    d_counters.release();
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
+    if (ev_c) (void)hipEventDestroy(ev_c);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
 
@@ -137,6 +137,7 @@ struct sassy_SearcherType {
     }
     HIP_TRY(hipEventCreate(&ev_a));
     HIP_TRY(hipEventCreate(&ev_b));
+    HIP_TRY(hipEventCreate(&ev_c));
     device_ready = true;
     return 0;
   }
@@ -144,86 +145,16 @@ struct sassy_SearcherType {
 
 namespace sassy_hip {
 
-// ------------------------------------------------------------------ traceback (host)
-// Window w = text[o .. min(e, n)), o = max(0, e - (m+k)) (reference: src/search.rs:1477-1478);
-// local matrix L[j][0] = j, L[0][i] = 0 (reference: src/trace.rs:80-103); greedy walk from
-// (m, e-o) preferring '=', 'X', 'D', 'I' (reference: src/trace.rs:337-365).  The walk only ever
-// visits cells of optimal alignments, all of which lie on diagonals [0, 2k] of the window, so a
-// band of those diagonals (+1 on each side, values saturated at k+1) reproduces the full-matrix
-// walk exactly (DESIGN.md "traceback").
-struct TraceOut {
-  uint64_t text_start = 0;
-  int32_t cost = 0;
-  std::string ops;  // one char per alignment column, pattern direction
-  bool ok = false;
-};
-
-static TraceOut trace_window(Profile pr, const uint8_t* pat, size_t m, const uint8_t* win, size_t wl,
-                             uint64_t o, int k) {
-  TraceOut out;
-  // band: cell (j, i) with d = i - j + shift, shift chosen so that the end cell (m, wl) sits at
-  // d = k+1 when wl = m+k; the window may be shorter near the start of the text.
-  const long dend = (long)wl - (long)m;          // diagonal of the end cell
-  const long dlo = dend - (long)k - 1, dhi = dend + (long)k + 1;
-  const size_t bw = (size_t)(dhi - dlo + 1);
-  const int inf = k + 1;
-  std::vector<uint16_t> L((m + 1) * bw, (uint16_t)inf);
-  auto at = [&](size_t j, long i) -> int {
-    if (i < 0 || i > (long)wl) return inf;
-    const long d = i - (long)j;
-    if (d < dlo || d > dhi) return inf;
-    return L[j * bw + (size_t)(d - dlo)];
-  };
-  auto set = [&](size_t j, long i, int v) { L[j * bw + (size_t)(i - (long)j - dlo)] = (uint16_t)v; };
-  for (size_t j = 0; j <= m; ++j) {
-    const long ilo = std::max<long>(0, (long)j + dlo), ihi = std::min<long>((long)wl, (long)j + dhi);
-    for (long i = ilo; i <= ihi; ++i) {
-      int v;
-      if (j == 0) v = 0;
-      else if (i == 0) v = (int)std::min<size_t>(j, (size_t)inf);
-      else {
-        v = at(j - 1, i - 1) + (scan_eq(pr, pat[j - 1], win[i - 1]) ? 0 : 1);
-        v = std::min(v, at(j, i - 1) + 1);
-        v = std::min(v, at(j - 1, i) + 1);
-        v = std::min(v, inf);
-      }
-      set(j, i, v);
-    }
-  }
-  size_t j = m;
-  long i = (long)wl;
-  int g = at(j, i);
-  out.cost = g;
-  if (g > k) return out;  // cannot happen for a position the scan reported
-  std::string ops;
-  while (j > 0) {
-    if (i > 0 && at(j - 1, i - 1) == g && trace_is_match(pr, pat[j - 1], win[i - 1])) {
-      ops.push_back('='); --j; --i; continue;
-    }
-    g -= 1;
-    if (g < 0) return out;
-    if (i > 0 && at(j - 1, i - 1) == g) { ops.push_back('X'); --j; --i; continue; }
-    if (i > 0 && at(j, i - 1) == g) { ops.push_back('D'); --i; continue; }
-    if (at(j - 1, i) == g) { ops.push_back('I'); --j; continue; }
-    return out;  // reference: panic "Trace failed! No ancestor found" (src/trace.rs:384-387)
-  }
-  if (g != 0) return out;
-  std::reverse(ops.begin(), ops.end());
-  out.ops = std::move(ops);
-  out.text_start = o + (uint64_t)i;
-  out.ok = true;
-  return out;
-}
-
-// pa_types::Cigar::to_string: run-length encoded "<count><op>" (SURVEY 8c).
-static std::string rle(const std::string& ops) {
+// pa_types::Cigar::to_string: run-length encoded "<count><op>" (SURVEY 8c).  `ops` holds one
+// char per alignment column in end -> start order (as the device traceback writes them).
+static std::string rle_reversed(const uint8_t* ops, size_t n) {
   std::string s;
-  size_t i = 0;
-  while (i < ops.size()) {
+  size_t i = n;
+  while (i > 0) {
     size_t j = i;
-    while (j < ops.size() && ops[j] == ops[i]) ++j;
-    s += std::to_string(j - i);
-    s.push_back(ops[i]);
+    while (j > 0 && ops[j - 1] == ops[i - 1]) --j;
+    s += std::to_string(i - j);
+    s.push_back((char)ops[i - 1]);
     i = j;
   }
   return s;
@@ -244,13 +175,18 @@ struct ScanOut {
   int64_t conditional_index = -1; // ... except this one, which depends on the previous shard
   int exit_state = kStateDecTrue;
   uint64_t cond_seen = 0;
+  // device traceback results, indexed by the candidate's slot in the device buffer
+  std::vector<uint32_t> slot;    // cands[i] was device candidate slot[i]
+  std::vector<TraceRec> recs;    // by device slot
+  std::vector<uint8_t> ops;      // by device slot, ops_stride bytes each
+  uint32_t ops_stride = 0;
 };
 
 static uint32_t warmup_blocks(uint32_t m, uint32_t k) { return (m + k + 1 + 63) / 64; }
 
 // Runs the scan kernel over one buffer and returns the resolved reports.
 static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPlan& plan, uint32_t k,
-                    bool all_minima, ScanOut& out) {
+                    bool all_minima, const uint8_t* pat, bool do_trace, uint64_t total_len, ScanOut& out) {
   out = ScanOut();
   const uint64_t n_blocks = (sh.text_len + 63) / 64;
   const uint64_t first_owned = sh.halo_len / 64;
@@ -271,7 +207,8 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   P.wb = warmup_blocks(plan.m, k);
   // Chunk geometry: enough lanes to fill 256 CUs several times over, chunks long enough that the
   // warm-up blocks stay a few percent of the work.
-  const uint64_t target_lanes = 256ull * 12 * 64 * 2;
+  static const int env_wpc = getenv("SASSY_HIP_WAVES_PER_CU") ? atoi(getenv("SASSY_HIP_WAVES_PER_CU")) : 0;
+  const uint64_t target_lanes = 256ull * (env_wpc > 0 ? env_wpc : 12) * 64 * 2;
   uint64_t bpl = (owned + target_lanes - 1) / target_lanes;
   const uint64_t min_bpl = std::max<uint64_t>(8, 6ull * P.wb);
   if (bpl < min_bpl) bpl = min_bpl;
@@ -283,7 +220,9 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   P.flags = (all_minima ? kScanAllMinima : 0u) | (sh.text_start ? kScanTextStart : 0u) |
             (sh.text_end ? kScanTextEnd : 0u);
   const uint32_t bucket = plan.nslots <= 4 ? 4 : plan.nslots <= 8 ? 8 : 16;
-  P.lds_per_wave = (uint32_t)kTileBytes + bucket * 512u + plan.nwords * 512u;
+  static const int env_sb = getenv("SASSY_HIP_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_STAGE_BLOCKS")) : 0;
+  P.stage_blocks = env_sb == 1 || env_sb == 2 ? (uint32_t)env_sb : 2u;
+  P.lds_per_wave = 4096u * P.stage_blocks + bucket * 512u + plan.nwords * 512u;
   const size_t smem = (size_t)kWavesPerGroup * P.lds_per_wave;
   if (smem > 160 * 1024) return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
   for (int s = 0; s < kMaxSlots; ++s) P.slot_val[s] = plan.slot_val[s];
@@ -307,10 +246,43 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   P.cand_count = S->d_count.p;
   P.counters = S->want_counters ? S->d_counters.p : nullptr;
 
+  // device traceback (K3) runs right behind the scan on the same stream: one host sync per strand
+  TraceParams T{};
+  uint32_t trace_blocks = 0;
+  if (do_trace) {
+    const uint64_t cell = (k + 1 <= 255) ? 1 : 2;
+    const uint64_t stride = ((uint64_t)(plan.m + 1) * (2ull * k + 3) * cell + 15) / 16 * 16;
+    if (stride > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "pattern/k too large for the traceback band");
+    uint64_t nthreads = (256ull << 20) / stride;
+    nthreads = std::max<uint64_t>(64, std::min<uint64_t>(16384, nthreads)) / 64 * 64;
+    trace_blocks = (uint32_t)(nthreads / 64);
+    if (int rc = S->d_scratch.reserve(nthreads * stride)) return rc;
+    if (int rc = S->d_pattern.reserve(plan.m)) return rc;
+    HIP_TRY(hipMemcpyAsync(S->d_pattern.p, pat, plan.m, hipMemcpyHostToDevice, S->stream));
+    T.text = sh.d_text;
+    T.global_offset = sh.global_offset;
+    T.total_len = total_len;
+    T.cand_count = S->d_count.p;
+    T.m = plan.m;
+    T.k = k;
+    T.profile = (uint32_t)S->profile;
+    T.pattern = S->d_pattern.p;
+    T.scratch = S->d_scratch.p;
+    T.scratch_stride = (uint32_t)stride;
+    T.ops_stride = (plan.m + k + 1 + 15) / 16 * 16;
+  }
   uint32_t count = 0;
   for (int attempt = 0; attempt < 3; ++attempt) {
     P.cand = S->d_cand.p;
     P.cand_cap = (uint32_t)std::min<size_t>(S->d_cand.cap, 0xFFFFFFFFu);
+    if (do_trace) {
+      if (int rc = S->d_trace.reserve(P.cand_cap)) return rc;
+      if (int rc = S->d_ops.reserve((size_t)P.cand_cap * T.ops_stride)) return rc;
+      T.cand = S->d_cand.p;
+      T.cand_cap = P.cand_cap;
+      T.out = S->d_trace.p;
+      T.out_ops = S->d_ops.p;
+    }
     HIP_TRY(hipMemsetAsync(S->d_count.p, 0, sizeof(uint32_t), S->stream));
     HIP_TRY(hipEventRecord(S->ev_a, S->stream));
     hipError_t le;
@@ -321,12 +293,21 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     }
     if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
     HIP_TRY(hipEventRecord(S->ev_b, S->stream));
+    if (do_trace) {
+      le = launch_trace(T, trace_blocks, S->stream);
+      if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
+      HIP_TRY(hipEventRecord(S->ev_c, S->stream));
+    }
     HIP_TRY(hipMemcpyAsync(&count, S->d_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream));
     HIP_TRY(hipStreamSynchronize(S->stream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_b));
     S->stats.scan_ms += ms;
     S->stats.scan_launches += 1;
+    if (do_trace) {
+      HIP_TRY(hipEventElapsedTime(&ms, S->ev_b, S->ev_c));
+      S->stats.trace_ms += ms;
+    }
     if (count <= P.cand_cap) break;
     // more reports than the buffer holds (dense matches): grow and run again
     if (int rc = S->d_cand.reserve((size_t)count + 1024)) return rc;
@@ -345,11 +326,24 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     S->stats.blocks += c[1];
   }
 
+  std::vector<Candidate> raw(count);
+  if (count) {
+    HIP_TRY(hipMemcpy(raw.data(), S->d_cand.p, (size_t)count * sizeof(Candidate), hipMemcpyDeviceToHost));
+    if (do_trace) {
+      out.recs.resize(count);
+      out.ops_stride = T.ops_stride;
+      out.ops.resize((size_t)count * T.ops_stride);
+      HIP_TRY(hipMemcpy(out.recs.data(), S->d_trace.p, (size_t)count * sizeof(TraceRec), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(out.ops.data(), S->d_ops.p, out.ops.size(), hipMemcpyDeviceToHost));
+    }
+  }
+  // the atomic append leaves the reports in arbitrary order: sort by end position
+  std::vector<uint32_t> order(count);
+  for (uint32_t i = 0; i < count; ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return raw[a].pos < raw[b].pos; });
   out.cands.resize(count);
-  if (count)
-    HIP_TRY(hipMemcpy(out.cands.data(), S->d_cand.p, (size_t)count * sizeof(Candidate), hipMemcpyDeviceToHost));
-  std::sort(out.cands.begin(), out.cands.end(),
-            [](const Candidate& a, const Candidate& b) { return a.pos < b.pos; });
+  out.slot.resize(count);
+  for (uint32_t i = 0; i < count; ++i) { out.cands[i] = raw[order[i]]; out.slot[i] = order[i]; }
   S->stats.candidates += count;
 
   // ---- seams: reports that depend on how a plateau was entered left of their chunk ----
@@ -363,10 +357,14 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   }
   if (any_cond) {
     std::vector<Candidate> kept;
+    std::vector<uint32_t> kept_slot;
     kept.reserve(out.cands.size());
+    kept_slot.reserve(out.cands.size());
     const uint64_t end_global = sh.global_offset + sh.text_len;
-    for (const Candidate& c : out.cands) {
-      if (!(c.flags & kCandCond)) { kept.push_back(c); continue; }
+    for (size_t ci = 0; ci < out.cands.size(); ++ci) {
+      const Candidate& c = out.cands[ci];
+      const uint32_t cslot = out.slot[ci];
+      if (!(c.flags & kCandCond)) { kept.push_back(c); kept_slot.push_back(cslot); continue; }
       out.cond_seen++;
       uint64_t local = c.pos - sh.global_offset;
       uint64_t blk = local / 64;
@@ -378,15 +376,17 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       int64_t q = (int64_t)chunk - 1;
       while (q >= 0 && state[(size_t)q] == kStatePass) --q;
       if (q >= 0) {
-        if (state[(size_t)q] == kStateDecTrue) { Candidate cc = c; cc.flags &= ~kCandCond; kept.push_back(cc); }
+        if (state[(size_t)q] == kStateDecTrue) { Candidate cc = c; cc.flags &= ~kCandCond; kept.push_back(cc); kept_slot.push_back(cslot); }
       } else if (sh.text_start) {
-        Candidate cc = c; cc.flags &= ~kCandCond; kept.push_back(cc);  // entered at column 0: decreasing
+        Candidate cc = c; cc.flags &= ~kCandCond; kept.push_back(cc); kept_slot.push_back(cslot);  // column 0: decreasing
       } else {
         out.conditional_index = (int64_t)kept.size();  // only the previous shard knows
         kept.push_back(c);
+        kept_slot.push_back(cslot);
       }
     }
     out.cands.swap(kept);
+    out.slot.swap(kept_slot);
   }
   if (need_state) {
     int64_t q = (int64_t)P.n_chunks - 1;
@@ -397,85 +397,31 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   return 0;
 }
 
-// Turn reports into matches.  `host_text` (may be null) is the forward text on the host when the
-// caller has it; otherwise the windows are gathered from the device buffer.  For the Rc strand
-// the buffer holds the reversed text and `reversed_host` says host_text must be read backwards.
-static int trace_reports(sassy_SearcherType* S, const ShardView& sh, const uint8_t* host_text,
-                         bool reversed_host, uint64_t total_len, const PatternPlan& plan,
-                         const uint8_t* pat, uint32_t k, bool without_trace,
-                         const std::vector<Candidate>& cands, std::vector<MatchRec>& out) {
+// Turn the resolved reports + their device traceback records into matches.
+static int trace_reports(const ScanOut& so, uint64_t total_len, const PatternPlan& plan, bool without_trace,
+                         std::vector<MatchRec>& out) {
   const size_t m = plan.m;
-  const uint64_t fill = (uint64_t)m + k;
-  const size_t cnt = cands.size();
-  if (cnt == 0) return 0;
-  if (without_trace) {
-    for (const Candidate& c : cands) {
-      MatchRec r;  // reference: src/search.rs:1464-1475
+  for (size_t i = 0; i < so.cands.size(); ++i) {
+    const Candidate& c = so.cands[i];
+    MatchRec r;
+    if (without_trace) {  // reference: src/search.rs:1464-1475
       r.text_start = UINT64_MAX;
       r.text_end = std::min<uint64_t>(c.pos, total_len);
       r.pattern_start = UINT64_MAX;
       r.pattern_end = m;
       r.cost = c.cost;
-      out.push_back(std::move(r));
-    }
-    return 0;
-  }
-  std::vector<uint8_t> windows;
-  const uint32_t wlen = (uint32_t)fill;
-  std::vector<uint64_t> o(cnt);
-  std::vector<uint32_t> wl(cnt);
-  for (size_t i = 0; i < cnt; ++i) {
-    const uint64_t e = cands[i].pos;
-    o[i] = e > fill ? e - fill : 0;
-    const uint64_t we = std::min<uint64_t>(e, total_len);
-    wl[i] = (uint32_t)(we - o[i]);
-  }
-  if (!host_text) {
-    std::vector<uint64_t> lstart(cnt);
-    for (size_t i = 0; i < cnt; ++i) {
-      if (o[i] < sh.global_offset)
-        return fail(SASSY_HIP_EINVAL, "traceback window reaches left of the shard's halo");
-      lstart[i] = o[i] - sh.global_offset;
-    }
-    if (int rc = S->d_wstart.reserve(cnt)) return rc;
-    if (int rc = S->d_wlen.reserve(cnt)) return rc;
-    if (int rc = S->d_win.reserve(cnt * (size_t)wlen)) return rc;
-    HIP_TRY(hipEventRecord(S->ev_a, S->stream));
-    HIP_TRY(hipMemcpyAsync(S->d_wstart.p, lstart.data(), cnt * sizeof(uint64_t), hipMemcpyHostToDevice, S->stream));
-    HIP_TRY(hipMemcpyAsync(S->d_wlen.p, wl.data(), cnt * sizeof(uint32_t), hipMemcpyHostToDevice, S->stream));
-    hipError_t le = launch_gather_windows(sh.d_text, S->d_wstart.p, S->d_wlen.p, wlen, (uint32_t)cnt, S->d_win.p, S->stream);
-    if (le != hipSuccess) return hip_fail(le, "gather kernel launch");
-    windows.resize(cnt * (size_t)wlen);
-    HIP_TRY(hipMemcpyAsync(windows.data(), S->d_win.p, windows.size(), hipMemcpyDeviceToHost, S->stream));
-    HIP_TRY(hipEventRecord(S->ev_b, S->stream));
-    HIP_TRY(hipStreamSynchronize(S->stream));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_b));
-    S->stats.trace_ms += ms;
-  }
-  std::vector<uint8_t> tmp(wlen ? wlen : 1);
-  for (size_t i = 0; i < cnt; ++i) {
-    const uint8_t* w;
-    if (host_text) {
-      if (reversed_host) {  // window [o, o+wl) of reverse(text) = reverse of text[n-o-wl, n-o)
-        for (uint32_t q = 0; q < wl[i]; ++q) tmp[q] = host_text[total_len - 1 - (o[i] + q)];
-        w = tmp.data();
-      } else {
-        w = host_text + o[i];
-      }
     } else {
-      w = windows.data() + i * (size_t)wlen;
+      const TraceRec& t = so.recs[so.slot[i]];
+      // the reference asserts both (src/search.rs:1672-1685) and panics in get_trace otherwise
+      if (!t.ok || t.cost > c.cost)
+        return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
+      r.text_start = t.text_start;
+      r.text_end = t.text_end;
+      r.pattern_start = 0;
+      r.pattern_end = m;
+      r.cost = t.cost;
+      r.cigar = rle_reversed(so.ops.data() + (size_t)so.slot[i] * so.ops_stride, t.nops);
     }
-    TraceOut t = trace_window(S->profile, pat, m, w, wl[i], o[i], (int)k);
-    if (!t.ok || t.cost > cands[i].cost)
-      return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
-    MatchRec r;
-    r.text_start = t.text_start;
-    r.text_end = o[i] + wl[i];
-    r.pattern_start = 0;
-    r.pattern_end = m;
-    r.cost = t.cost;
-    r.cigar = rle(t.ops);
     out.push_back(std::move(r));
   }
   return 0;
@@ -529,14 +475,13 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
   } else if (((uintptr_t)text & 15) != 0) {
     return fail(SASSY_HIP_EINVAL, "device text pointer must be 16-byte aligned");
   }
-  const uint8_t* host_text = on_dev ? nullptr : text;
 
   if (fwd_strand) {
     ShardView sh{d_fwd, tlen, 0, 0, true, true};
     ScanOut so;
-    if (int rc = run_scan(S, sh, plan, (uint32_t)k, all, so)) return rc;
+    if (int rc = run_scan(S, sh, plan, (uint32_t)k, all, pattern, !wo, tlen, so)) return rc;
     const size_t first = recs.size();
-    if (int rc = trace_reports(S, sh, host_text, false, tlen, plan, pattern, (uint32_t)k, wo, so.cands, recs)) return rc;
+    if (int rc = trace_reports(so, tlen, plan, wo, recs)) return rc;
     for (size_t i = first; i < recs.size(); ++i) recs[i].pattern_idx = pattern_idx;
   }
   if (rc_strand) {
@@ -551,9 +496,9 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
     if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
     ShardView sh{S->d_rev.p, tlen, 0, 0, true, true};
     ScanOut so;
-    if (int rc = run_scan(S, sh, cplan, (uint32_t)k, all, so)) return rc;
+    if (int rc = run_scan(S, sh, cplan, (uint32_t)k, all, cp.data(), !wo, tlen, so)) return rc;
     const size_t first = recs.size();
-    if (int rc = trace_reports(S, sh, host_text, true, tlen, cplan, cp.data(), (uint32_t)k, wo, so.cands, recs)) return rc;
+    if (int rc = trace_reports(so, tlen, cplan, wo, recs)) return rc;
     for (size_t i = first; i < recs.size(); ++i) {
       MatchRec& r = recs[i];
       const uint64_t rs = r.text_start, re = r.text_end;
@@ -699,10 +644,11 @@ int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t
     ShardView sh{d_text, halo_len + shard_len, halo_len, global_offset - halo_len,
                  is_first && halo_len == 0, is_last};
     ScanOut so;
-    if (int rc = run_scan(s, sh, plan, (uint32_t)k, (flags & SASSY_HIP_ALL_MINIMA) != 0, so)) { delete R; return rc; }
+    const bool wo = (flags & SASSY_HIP_WITHOUT_TRACE) != 0;
+    if (int rc = run_scan(s, sh, plan, (uint32_t)k, (flags & SASSY_HIP_ALL_MINIMA) != 0, pattern, !wo,
+                          total_len, so)) { delete R; return rc; }
     std::vector<MatchRec> recs;
-    if (int rc = trace_reports(s, sh, nullptr, false, total_len, plan, pattern, (uint32_t)k,
-                               (flags & SASSY_HIP_WITHOUT_TRACE) != 0, so.cands, recs)) { delete R; return rc; }
+    if (int rc = trace_reports(so, total_len, plan, wo, recs)) { delete R; return rc; }
     finish_result(recs, R);
     R->exit_state = so.exit_state;
     R->conditional_index = so.conditional_index;
@@ -715,6 +661,7 @@ int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t
 size_t sassy_hip_result_len(const sassy_hip_Result* r) { return r ? r->matches.size() : 0; }
 const sassy_hip_Match* sassy_hip_result_matches(const sassy_hip_Result* r) { return r ? r->matches.data() : nullptr; }
 const char* sassy_hip_result_cigars(const sassy_hip_Result* r) { return r ? r->pool.c_str() : nullptr; }
+size_t sassy_hip_result_cigars_len(const sassy_hip_Result* r) { return r ? r->pool.size() : 0; }
 int sassy_hip_result_exit_state(const sassy_hip_Result* r) { return r ? r->exit_state : -1; }
 int64_t sassy_hip_result_conditional_index(const sassy_hip_Result* r) { return r ? r->conditional_index : -1; }
 void sassy_hip_result_free(sassy_hip_Result* r) { delete r; }

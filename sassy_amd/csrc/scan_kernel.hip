@@ -360,15 +360,22 @@ __device__ __forceinline__ void dp_word(DpWord& V, const unsigned char* my_masks
   nhm_out = nhm;
 }
 
-template <int PROFILE, int NS>
+// SB = text blocks per lane chunk fetched by one staging step: 2 = one full 128-byte line per
+// chunk (8 KiB tile), 1 = half lines (4 KiB tile, more waves fit in the LDS).
+template <int PROFILE, int NS, int SB>
 __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr uint32_t kRowBytes = 64u * SB;          // tile row = the staged bytes of one lane chunk
+  constexpr uint32_t kSlots = 4u * SB;              // 16-byte slots per row
+  constexpr uint32_t kOwnersPerInstr = 64u / kSlots;  // tile rows filled by one 64-lane load
+  constexpr int kStageInstr = 4 * SB;
+  constexpr uint32_t kTile = 64u * kRowBytes;
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = threadIdx.x >> 6;
   unsigned char* wbase = smem + (size_t)wave * P.lds_per_wave;
-  unsigned char* tile = wbase;                                                    // 8 KiB
-  unsigned char* mask_bytes = wbase + kTileBytes;                                 // [NS][64] u64
-  uint32_t* carry = reinterpret_cast<uint32_t*>(wbase + kTileBytes + NS * 512);  // [word][hp|hm][lane]
+  unsigned char* tile = wbase;
+  unsigned char* mask_bytes = wbase + kTile;                                 // [NS][64] u64
+  uint32_t* carry = reinterpret_cast<uint32_t*>(wbase + kTile + NS * 512);  // [word][hp|hm][lane]
 
   const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * kWavesPerGroup + wave) * kWave;
   if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
@@ -405,25 +412,27 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   }
 
   // ---- staging geometry: instruction i of a stage loads, for tile row `owner`, the 16-byte
-  // chunk that belongs into slot (lane & 7) of that row; slot = chunk ^ ((owner >> 1) & 7).
+  // chunk that belongs into slot (lane % kSlots) of that row.  Slots are XOR-swizzled so that the
+  // owners' ds_read_b128 of their own rows are bank-conflict free:
+  //   SB = 2: slot = chunk ^ ((owner >> 1) & 7);  SB = 1: slot = chunk ^ ((owner >> 2) & 3).
   const uint64_t wave_blk0 = chunk_blk0(first_owned, bpl, back, wave_chunk0);
   const uint8_t* text_base = P.text + wave_blk0 * 64;
-  uint32_t soff[8];
+  uint32_t soff[kStageInstr];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const uint32_t owner = (uint32_t)i * 8u + (lane >> 3);
-    const uint32_t slot = lane & 7u;
-    const uint32_t j = slot ^ ((owner >> 1) & 7u);
+  for (int i = 0; i < kStageInstr; ++i) {
+    const uint32_t owner = (uint32_t)i * kOwnersPerInstr + lane / kSlots;
+    const uint32_t slot = lane % kSlots;
+    const uint32_t j = slot ^ (SB == 2 ? ((owner >> 1) & 7u) : ((owner >> 2) & 3u));
     soff[i] = (uint32_t)((chunk_blk0(first_owned, bpl, back, wave_chunk0 + owner) - wave_blk0) * 64) + j * 16u;
   }
   // wave-uniform: can every staged byte of this wave be read without a bounds check?
   const uint64_t wave_last = chunk_blk0(first_owned, bpl, back, wave_chunk0 + 63) + P.n_iter + 2;
   const bool interior = wave_last * 64 <= P.text_len;
   // reading side: the lane's own row, logical chunks 4*sub + c
-  const uint32_t fsw = (lane >> 1) & 7u;
+  const uint32_t fsw = SB == 2 ? ((lane >> 1) & 7u) : ((lane >> 2) & 3u);
   uint32_t rc[4];
 #pragma unroll
-  for (int c = 0; c < 4; ++c) rc[c] = lane * 128u + (((uint32_t)c ^ (fsw & 3u)) << 4);
+  for (int c = 0; c < 4; ++c) rc[c] = lane * kRowBytes + (((uint32_t)c ^ (fsw & 3u)) << 4);
 
   uint32_t st = kStDec;  // dec = true, amb = false
   EmitCtx ctx;
@@ -439,21 +448,19 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   const unsigned char* my_masks = mask_bytes + lane * 8;
 
   for (uint32_t it = 0; it < P.n_iter; ++it) {
-    const uint32_t sub = it & 1u;
+    const uint32_t sub = SB == 2 ? (it & 1u) : 0u;
     if (sub == 0) {
-      // ---- stage 2 blocks (128 B) for each of the 64 lane chunks: 8 x (64 lanes x 16 B) ----
+      // ---- stage SB blocks for each of the 64 lane chunks: kStageInstr x (64 lanes x 16 B) ----
       if (interior) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < kStageInstr; ++i) {
           const uint4 v = *reinterpret_cast<const uint4*>(text_base + (uint64_t)it * 64 + soff[i]);
           *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
         }
       } else {
-#pragma unroll 1
-        for (int i = 0; i < 8; ++i) {
-          const uint32_t so = i == 0 ? soff[0] : i == 1 ? soff[1] : i == 2 ? soff[2] : i == 3 ? soff[3]
-                            : i == 4 ? soff[4] : i == 5 ? soff[5] : i == 6 ? soff[6] : soff[7];
-          const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + so;
+#pragma unroll
+        for (int i = 0; i < kStageInstr; ++i) {
+          const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
           uint4 v;
           if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
           else v = load_tail16(P.text, off, P.text_len);
@@ -464,7 +471,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
 
     // ---- the lane's own 64 text bytes -> profile masks -> LDS ----
     {
-      const uint32_t hs = ((sub << 2) ^ (fsw & 4u)) << 4;  // slot bit 2 selects the block of the pair
+      const uint32_t hs = SB == 2 ? (((sub << 2) ^ (fsw & 4u)) << 4) : 0u;  // slot bit 2 = block of the pair
       uint32_t x[16];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -524,17 +531,22 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
 }
 
 // ------------------------------------------------------------------ launcher
-template <int PROFILE, int NS>
-static hipError_t launch_one(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+template <int PROFILE, int NS, int SB>
+static hipError_t launch_sb(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
   static bool attr_set = false;  // LDS beyond the 64 KiB default needs an explicit opt-in
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<PROFILE, NS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<PROFILE, NS, SB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((scan_kernel<PROFILE, NS>), dim3(grid), dim3(256), smem, stream, P);
+  hipLaunchKernelGGL((scan_kernel<PROFILE, NS, SB>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
+}
+template <int PROFILE, int NS>
+static hipError_t launch_one(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  return P.stage_blocks == 1 ? launch_sb<PROFILE, NS, 1>(P, grid, smem, stream)
+                             : launch_sb<PROFILE, NS, 2>(P, grid, smem, stream);
 }
 
 #ifndef SASSY_SCAN_PROFILE

@@ -12,15 +12,19 @@ is latency-bound, never link-bound.
 Cross-shard exactness: a <=k plateau that runs across a shard border is resolved exactly like
 across lane chunks inside one GPU -- every shard reports its exit state (decreasing TRUE / FALSE /
 PASS) and marks the one report that depends on its left neighbour; rank 0 walks the chain.
+
+Records travel as numpy / torch arrays (one row per match), never as Python objects.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import numpy as np
+
 STATE_FALSE, STATE_TRUE, STATE_PASS = 0, 1, 2
-_CIGAR_BYTES = 40
-_COLS = 7 + _CIGAR_BYTES // 8  # int64 columns per packed match
+CIGAR_BYTES = 40
+COLS = 7 + CIGAR_BYTES // 8  # int64 columns per packed match
 
 
 def shard_bounds(total_len: int, world: int) -> List[Tuple[int, int]]:
@@ -37,47 +41,55 @@ def shard_bounds(total_len: int, world: int) -> List[Tuple[int, int]]:
 
 @dataclass
 class ShardResult:
-    matches: list            # sassy_amd.Match (global coordinates)
+    """rows: int64 array [n, COLS] = pattern_idx, text_start, text_end, pattern_start,
+    pattern_end, cost, strand, then CIGAR_BYTES bytes of NUL-padded cigar text."""
+    rows: np.ndarray
     exit_state: int          # STATE_*
-    conditional_index: int   # index into matches of the report that depends on the left shard, or -1
+    conditional_index: int   # row of the report that depends on the left shard, or -1
+
+    def __len__(self):
+        return int(self.rows.shape[0])
 
 
-def merge_shard_results(shards: Sequence[ShardResult]) -> list:
-    """Concatenate shard results in text order, dropping conditional reports whose plateau was
-    entered by an increase (decreasing = FALSE arriving from the left)."""
-    out = []
-    incoming = STATE_TRUE  # column 0 of the text: decreasing = true (src/search.rs:1055)
-    for sh in shards:
-        ms = list(sh.matches)
-        if sh.conditional_index >= 0 and incoming != STATE_TRUE:
-            del ms[sh.conditional_index]
-        out.extend(ms)
-        if sh.exit_state != STATE_PASS:
-            incoming = sh.exit_state
-    return out
+def pack_result(result) -> ShardResult:
+    """sassy_amd.Result -> ShardResult (vectorised; no per-match Python work)."""
+    a = result.array
+    n = len(a)
+    rows = np.zeros((n, COLS), dtype=np.int64)
+    if n:
+        for col, f in enumerate(("pattern_idx", "text_start", "text_end", "pattern_start", "pattern_end")):
+            rows[:, col] = a[f].view(np.int64) if a[f].dtype == np.uint64 else a[f]
+        rows[:, 5] = a["cost"]
+        rows[:, 6] = a["strand"]
+        clen = a["cigar_len"].astype(np.int64)
+        if int(clen.max(initial=0)) > CIGAR_BYTES:
+            raise ValueError("cigar longer than the fixed gather field")
+        pool = np.frombuffer(result.pool, dtype=np.uint8) if result.pool else np.zeros(1, np.uint8)
+        idx = a["cigar_off"].astype(np.int64)[:, None] + np.arange(CIGAR_BYTES, dtype=np.int64)[None, :]
+        keep = np.arange(CIGAR_BYTES, dtype=np.int64)[None, :] < clen[:, None]
+        cig = np.where(keep, pool[np.minimum(idx, len(pool) - 1)], 0).astype(np.uint8)
+        rows[:, 7:] = cig.view(np.int64)
+    return ShardResult(rows, result.exit_state, result.conditional_index)
 
 
-def pack_matches(matches, torch, device):
-    """[count, _COLS] int64 tensor: idx, start, end, pstart, pend, cost, strand, cigar bytes."""
-    import numpy as np
-    arr = np.zeros((len(matches), _COLS), dtype=np.int64)
+def rows_from_matches(matches) -> np.ndarray:
+    """Match objects -> packed rows (tests / small inputs)."""
+    rows = np.zeros((len(matches), COLS), dtype=np.int64)
     for i, m in enumerate(matches):
         cig = m.cigar.encode()
-        if len(cig) > _CIGAR_BYTES:
+        if len(cig) > CIGAR_BYTES:
             raise ValueError("cigar longer than the fixed gather field")
-        row = arr[i]
-        row[0], row[1], row[2], row[3], row[4] = m.pattern_idx, _s64(m.text_start), _s64(m.text_end), \
+        r = rows[i]
+        r[0], r[1], r[2], r[3], r[4] = m.pattern_idx, _s64(m.text_start), _s64(m.text_end), \
             _s64(m.pattern_start), _s64(m.pattern_end)
-        row[5], row[6] = m.cost, 1 if m.strand == "-" else 0
-        row[7:].view(np.uint8)[: len(cig)] = np.frombuffer(cig, dtype=np.uint8)
-    return torch.from_numpy(arr).to(device)
+        r[5], r[6] = m.cost, 1 if m.strand == "-" else 0
+        r[7:].view(np.uint8)[: len(cig)] = np.frombuffer(cig, dtype=np.uint8)
+    return rows
 
 
-def unpack_matches(t, Match):
-    import numpy as np
-    arr = t.cpu().numpy()
+def matches_from_rows(rows: np.ndarray, Match) -> list:
     out = []
-    for row in arr:
+    for row in rows:
         cig = bytes(row[7:].view(np.uint8)).rstrip(b"\0").decode()
         out.append(Match(int(row[0]), _u64(row[1]), _u64(row[2]), _u64(row[3]), _u64(row[4]),
                          int(row[5]), "-" if row[6] else "+", cig))
@@ -93,28 +105,42 @@ def _u64(v) -> int:
     return v + (1 << 64) if v < 0 else v
 
 
-def gather_shard_results(local: ShardResult, torch, dist, device, Match) -> Optional[List[ShardResult]]:
+def merge_shard_results(shards: Sequence[ShardResult]) -> np.ndarray:
+    """Concatenate shard rows in text order, dropping conditional reports whose plateau was
+    entered by an increase (decreasing = FALSE arriving from the left)."""
+    parts = []
+    incoming = STATE_TRUE  # column 0 of the text: decreasing = true (src/search.rs:1055)
+    for sh in shards:
+        rows = sh.rows
+        if sh.conditional_index >= 0 and incoming != STATE_TRUE:
+            rows = np.delete(rows, sh.conditional_index, axis=0)
+        parts.append(rows)
+        if sh.exit_state != STATE_PASS:
+            incoming = sh.exit_state
+    return np.concatenate(parts, axis=0) if parts else np.zeros((0, COLS), dtype=np.int64)
+
+
+def gather_shard_results(local: ShardResult, torch, dist, device) -> Optional[List[ShardResult]]:
     """The one exchange of the path: all ranks' match lists to rank 0.
     Two collectives: all_gather of the 3-word headers (count, exit state, conditional index),
     then gather of the records padded to the largest count."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    head = torch.tensor([len(local.matches), local.exit_state, local.conditional_index],
+    head = torch.tensor([len(local), local.exit_state, local.conditional_index],
                         dtype=torch.int64, device=device)
     heads = [torch.empty_like(head) for _ in range(world)]
     dist.all_gather(heads, head)
-    counts = [int(h[0]) for h in heads]
+    heads = torch.stack(heads).cpu().tolist()
+    counts = [h[0] for h in heads]
     maxc = max(counts)
     if maxc == 0:
         if rank != 0:
             return None
-        return [ShardResult([], int(h[1]), int(h[2])) for h in heads]
-    mine = pack_matches(local.matches, torch, device)
-    if mine.shape[0] < maxc:
-        pad = torch.zeros((maxc - mine.shape[0], _COLS), dtype=torch.int64, device=device)
-        mine = torch.cat([mine, pad], dim=0)
+        return [ShardResult(np.zeros((0, COLS), np.int64), h[1], h[2]) for h in heads]
+    padded = np.zeros((maxc, COLS), dtype=np.int64)
+    padded[: len(local)] = local.rows
+    mine = torch.from_numpy(padded).to(device)
     bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
     dist.gather(mine, gather_list=bufs, dst=0)
     if rank != 0:
         return None
-    return [ShardResult(unpack_matches(bufs[r][: counts[r]], Match), int(heads[r][1]), int(heads[r][2]))
-            for r in range(world)]
+    return [ShardResult(bufs[r][: counts[r]].cpu().numpy(), heads[r][1], heads[r][2]) for r in range(world)]

@@ -27,18 +27,23 @@ def test_shard_bounds():
 
 
 def test_merge_chain():
-    S = multigpu.ShardResult
+    def S(ms, state, cond):
+        return multigpu.ShardResult(multigpu.rows_from_matches(ms), state, cond)
+
+    def merged(shards):
+        return multigpu.matches_from_rows(multigpu.merge_shard_results(shards), Match)
+
     T, F, P = multigpu.STATE_TRUE, multigpu.STATE_FALSE, multigpu.STATE_PASS
     # no conditionals: plain concatenation
-    assert multigpu.merge_shard_results([S([M(1, 5)], T, -1), S([M(70, 74)], T, -1)]) == [M(1, 5), M(70, 74)]
+    assert merged([S([M(1, 5)], T, -1), S([M(70, 74)], T, -1)]) == [M(1, 5), M(70, 74)]
     # conditional report survives when the chain delivers TRUE through PASS shards
     sh = [S([M(1, 5)], T, -1), S([], P, -1), S([M(200, 204), M(300, 304)], F, 0), S([M(400, 404)], T, 0)]
-    assert multigpu.merge_shard_results(sh) == [M(1, 5), M(200, 204), M(300, 304)]
+    assert merged(sh) == [M(1, 5), M(200, 204), M(300, 304)]
     # ... and is dropped when the plateau was entered by an increase
     sh = [S([M(1, 5)], F, -1), S([], P, -1), S([M(200, 204), M(300, 304)], T, 0)]
-    assert multigpu.merge_shard_results(sh) == [M(1, 5), M(300, 304)]
+    assert merged(sh) == [M(1, 5), M(300, 304)]
     # first shard: column 0 counts as decreasing
-    assert multigpu.merge_shard_results([S([M(1, 5)], P, 0)]) == [M(1, 5)]
+    assert merged([S([M(1, 5)], P, 0)]) == [M(1, 5)]
 
 
 def _worker(rank, world, port, q):
@@ -51,25 +56,30 @@ def _worker(rank, world, port, q):
         dev = torch.device("cpu")
         big = (1 << 64) - 1
         if rank == 0:
-            local = multigpu.ShardResult([M(3, 7, 1, "+", "3=1X"), M(90, 95, 2, "-", "2=1I2=1D")], multigpu.STATE_FALSE, -1)
+            mine = [M(3, 7, 1, "+", "3=1X"), M(90, 95, 2, "-", "2=1I2=1D")]
+            local = multigpu.ShardResult(multigpu.rows_from_matches(mine), multigpu.STATE_FALSE, -1)
         else:
-            local = multigpu.ShardResult([M(3_000_000_100, 3_000_000_132, 3, "+", "10=1X10=1X10="),
-                                          Match(0, big, 3_000_000_500, big, 32, 0, "+", ""),
-                                          M(3_000_000_900, 3_000_000_932)], multigpu.STATE_TRUE, 0)
-        got = multigpu.gather_shard_results(local, torch, dist, dev, Match)
+            mine = [M(3_000_000_100, 3_000_000_132, 3, "+", "10=1X10=1X10="),
+                    Match(0, big, 3_000_000_500, big, 32, 0, "+", ""),
+                    M(3_000_000_900, 3_000_000_932)]
+            local = multigpu.ShardResult(multigpu.rows_from_matches(mine), multigpu.STATE_TRUE, 0)
+        got = multigpu.gather_shard_results(local, torch, dist, dev)
         if rank == 0:
             assert len(got) == 2
-            assert got[0].matches == local.matches and got[0].exit_state == multigpu.STATE_FALSE
-            assert got[1].conditional_index == 0 and len(got[1].matches) == 3
-            assert got[1].matches[1].text_start == big and got[1].matches[0].cigar == "10=1X10=1X10="
-            merged = multigpu.merge_shard_results(got)
+            ms0 = multigpu.matches_from_rows(got[0].rows, Match)
+            ms1 = multigpu.matches_from_rows(got[1].rows, Match)
+            assert ms0 == mine and got[0].exit_state == multigpu.STATE_FALSE
+            assert got[1].conditional_index == 0 and len(ms1) == 3
+            assert ms1[1].text_start == big and ms1[0].cigar == "10=1X10=1X10="
+            merged = multigpu.matches_from_rows(multigpu.merge_shard_results(got), Match)
             assert [m.text_start for m in merged] == [3, 90, big, 3_000_000_900]
         else:
             assert got is None
         # empty everywhere
-        got = multigpu.gather_shard_results(multigpu.ShardResult([], multigpu.STATE_PASS, -1), torch, dist, dev, Match)
+        empty = multigpu.ShardResult(multigpu.rows_from_matches([]), multigpu.STATE_PASS, -1)
+        got = multigpu.gather_shard_results(empty, torch, dist, dev)
         if rank == 0:
-            assert [len(g.matches) for g in got] == [0, 0]
+            assert [len(g) for g in got] == [0, 0]
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
