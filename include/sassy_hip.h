@@ -61,6 +61,10 @@ typedef struct sassy_hip_Stats {
   uint32_t blocks_per_chunk;
   uint32_t warmup_blocks;
   uint32_t grid;
+  uint32_t filtered;     /* 1: prefilter -> chunk list -> DP on the listed chunks; 0: DP over every block */
+  double filter_ms;      /* HIP-event time of the prefilter kernel (part of scan_ms) */
+  uint64_t hit_blocks;   /* text blocks in which an exact pattern piece ends */
+  uint32_t piece_len;    /* rows per pattern piece (k+1 pieces), 0 when unfiltered */
   uint32_t pad_;
 } sassy_hip_Stats;
 

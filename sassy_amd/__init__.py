@@ -79,6 +79,10 @@ class Stats(C.Structure):
         ("blocks_per_chunk", C.c_uint32),
         ("warmup_blocks", C.c_uint32),
         ("grid", C.c_uint32),
+        ("filtered", C.c_uint32),
+        ("filter_ms", C.c_double),
+        ("hit_blocks", C.c_uint64),
+        ("piece_len", C.c_uint32),
         ("pad_", C.c_uint32),
     ]
 

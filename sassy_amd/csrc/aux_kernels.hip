@@ -83,6 +83,73 @@ __global__ __launch_bounds__(256) void reverse_kernel(const uint8_t* in, uint8_t
   }
 }
 
+// ---------------------------------------------------------------- K0b: hit bitmap -> chunk list
+// A hit in block h (an exact piece occurrence ends there) means: cells <= k are possible in
+// blocks [h, h+L]; the DP needs `wb` warm-up blocks in front.  A' = union of [h-wb, h+L] over all
+// hits.  Every maximal run of A' becomes one chunk (long runs are cut at absolute multiples of
+// `maxlen` blocks); a chunk whose left neighbour block is outside A' is flagged kDescClearBefore
+// (its left edge holds no cell <= k, so the report rule starts exactly with decreasing = true).
+struct BuildParams {
+  const unsigned long long* hit;
+  uint64_t n_words;
+  uint64_t n_blocks;
+  uint64_t first_owned;
+  uint32_t wb, L, maxlen;
+  ChunkDesc* desc;
+  uint32_t* desc_count;
+  uint32_t desc_cap;
+};
+
+__device__ __forceinline__ unsigned long long dilated_word(const BuildParams& P, long long w) {
+  if (w < 0 || (uint64_t)w >= P.n_words) return 0ull;
+  const unsigned long long cur = P.hit[w];
+  const unsigned long long prev = w > 0 ? P.hit[w - 1] : 0ull;
+  const unsigned long long next = (uint64_t)(w + 1) < P.n_words ? P.hit[w + 1] : 0ull;
+  unsigned long long a = cur;
+  for (uint32_t d = 1; d <= P.L; ++d) a |= (cur << d) | (prev >> (64 - d));    // h -> h + d
+  for (uint32_t d = 1; d <= P.wb; ++d) a |= (cur >> d) | (next << (64 - d));   // h -> h - d (warm-up)
+  // blocks past the end of the buffer do not exist
+  const uint64_t base = (uint64_t)w * 64;
+  if (base + 64 > P.n_blocks) a &= (P.n_blocks > base) ? (~0ull >> (64 - (P.n_blocks - base))) : 0ull;
+  return a;
+}
+__device__ __forceinline__ bool dilated_bit(const BuildParams& P, uint64_t blk) {
+  return (dilated_word(P, (long long)(blk >> 6)) >> (blk & 63)) & 1ull;
+}
+
+__global__ __launch_bounds__(256) void build_chunks_kernel(const BuildParams P) {
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= P.n_words) return;
+  const unsigned long long A = dilated_word(P, (long long)w);
+  if (A == 0) return;
+  const unsigned long long prev_top = w > 0 ? (dilated_word(P, (long long)w - 1) >> 63) : 0ull;
+  unsigned long long align = 0;
+  for (int i = 0; i < 64; ++i)
+    if (((w * 64 + i) % P.maxlen) == 0) align |= 1ull << i;
+  unsigned long long own = ~0ull;  // only blocks >= first_owned are owned (the halo is warm-up)
+  if (w * 64 < P.first_owned) own = (P.first_owned - w * 64 >= 64) ? 0ull : (~0ull << (P.first_owned - w * 64));
+  unsigned long long first_bit = 0;  // the first owned block starts a chunk if it is in A'
+  if (P.first_owned >= w * 64 && P.first_owned < w * 64 + 64) first_bit = 1ull << (P.first_owned - w * 64);
+  unsigned long long starts = A & own & (~((A << 1) | prev_top) | align | first_bit);
+  while (starts) {
+    const int i = __ffsll((long long)starts) - 1;
+    starts &= starts - 1;
+    const uint64_t lo = w * 64 + (uint64_t)i;
+    const bool left_in = i > 0 ? ((A >> (i - 1)) & 1ull) : (prev_top != 0);
+    uint64_t j = lo + 1;
+    while (j < P.n_blocks && (j % P.maxlen) != 0 && dilated_bit(P, j)) ++j;
+    const uint32_t idx = atomicAdd(P.desc_count, 1u);
+    if (idx < P.desc_cap) {
+      ChunkDesc d;
+      d.own_lo = (uint32_t)lo;
+      d.own_hi = (uint32_t)j;
+      d.flags = left_in ? 0u : kDescClearBefore;
+      d.pad_ = 0;
+      P.desc[idx] = d;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ launchers
 hipError_t launch_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first,
                                hipStream_t stream) {
@@ -107,6 +174,18 @@ hipError_t launch_reverse(const uint8_t* d_in, uint8_t* d_out, uint64_t n, hipSt
   uint64_t blocks = ((n + 15) / 16 + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(reverse_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_in, d_out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_build_chunks(const unsigned long long* d_hit, uint64_t n_words, uint64_t n_blocks,
+                               uint64_t first_owned, uint32_t wb, uint32_t L, uint32_t maxlen,
+                               ChunkDesc* d_desc, uint32_t* d_desc_count, uint32_t desc_cap,
+                               hipStream_t stream) {
+  if (n_words == 0) return hipSuccess;
+  BuildParams P;
+  P.hit = d_hit; P.n_words = n_words; P.n_blocks = n_blocks; P.first_owned = first_owned;
+  P.wb = wb; P.L = L; P.maxlen = maxlen; P.desc = d_desc; P.desc_count = d_desc_count; P.desc_cap = desc_cap;
+  hipLaunchKernelGGL(build_chunks_kernel, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, stream, P);
   return hipGetLastError();
 }
 

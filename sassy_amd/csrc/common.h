@@ -17,6 +17,17 @@ constexpr uint32_t kCandCond = 1u;     // report depends on the plateau-entry di
 // chunk exit states
 constexpr uint8_t kStateDecFalse = 0, kStateDecTrue = 1, kStatePass = 2;
 
+// chunk descriptor flags (list mode)
+constexpr uint32_t kDescClearBefore = 1u;  // the block left of own_lo holds no cell <= k
+
+// A chunk of consecutive text blocks handed to one lane of the list-mode DP kernel.  16 bytes.
+struct ChunkDesc {
+  uint32_t own_lo;   // first owned block (buffer-relative; texts up to 2^32 blocks = 256 GiB)
+  uint32_t own_hi;   // one past the last owned block
+  uint32_t flags;    // kDesc*
+  uint32_t pad_;
+};
+
 // scan flags
 constexpr uint32_t kScanAllMinima = 1u;  // report every end position with cost <= k
 constexpr uint32_t kScanTextStart = 2u;  // buffer byte 0 is the true start of the text (column 0)
@@ -53,6 +64,14 @@ struct ScanParams {
   uint32_t* cand_count;       // device counter (keeps counting past cand_cap)
   uint8_t* chunk_state;       // device, n_chunks entries
   unsigned long long* counters; // optional device counters [0]=word rows, [1]=blocks; may be null
+  // ---- prefilter (K0) / list mode (K1-list) ----
+  uint32_t n_pieces;          // k+1 pattern pieces of piece_len rows each (rows 0 .. n_pieces*piece_len)
+  uint32_t piece_len;
+  unsigned long long* hit_bitmap;  // one bit per text block: an exact piece occurrence ends in it
+  unsigned long long* hit_count;   // device counter of hit blocks
+  const ChunkDesc* desc;      // list mode: chunk descriptors
+  const uint32_t* desc_count; // list mode: number of descriptors (device)
+  uint32_t desc_cap;
   uint8_t slot_val[kMaxSlots]; // per slot: Dna 2-bit code, Iupac base-set nibble, Ascii byte
 };
 

@@ -26,6 +26,16 @@ namespace sassy_hip {
 hipError_t launch_scan_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_scan_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_scan_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
+hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
+hipError_t launch_filter_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
+hipError_t launch_filter_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
+hipError_t launch_list_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
+hipError_t launch_list_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
+hipError_t launch_list_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
+hipError_t launch_build_chunks(const unsigned long long* d_hit, uint64_t n_words, uint64_t n_blocks,
+                               uint64_t first_owned, uint32_t wb, uint32_t L, uint32_t maxlen,
+                               ChunkDesc* d_desc, uint32_t* d_desc_count, uint32_t desc_cap,
+                               hipStream_t stream);
 hipError_t launch_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first, hipStream_t stream);
 hipError_t launch_scatter_bytes(uint8_t* d_text, uint64_t n, uint64_t first, const uint64_t* d_pos,
                                 const uint8_t* d_val, uint64_t count, hipStream_t stream);
@@ -105,19 +115,21 @@ struct sassy_SearcherType {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   bool device_ready = false;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_f = nullptr;
   DevBuf<uint8_t> d_text, d_rev, d_state, d_pattern, d_scratch, d_ops;
   DevBuf<uint32_t> d_rowoff, d_count;
   DevBuf<Candidate> d_cand;
   DevBuf<TraceRec> d_trace;
-  DevBuf<unsigned long long> d_counters;
+  DevBuf<ChunkDesc> d_desc;
+  DevBuf<unsigned long long> d_counters, d_bitmap;
   bool want_counters = false;
   sassy_hip_Stats stats{};
 
   ~sassy_SearcherType() {
     d_text.release(); d_rev.release(); d_state.release(); d_pattern.release(); d_scratch.release();
     d_ops.release(); d_rowoff.release(); d_count.release(); d_cand.release(); d_trace.release();
-    d_counters.release();
+    d_counters.release(); d_desc.release(); d_bitmap.release();
+    if (ev_f) (void)hipEventDestroy(ev_f);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
     if (ev_c) (void)hipEventDestroy(ev_c);
@@ -138,6 +150,7 @@ struct sassy_SearcherType {
     HIP_TRY(hipEventCreate(&ev_a));
     HIP_TRY(hipEventCreate(&ev_b));
     HIP_TRY(hipEventCreate(&ev_c));
+    HIP_TRY(hipEventCreate(&ev_f));
     device_ready = true;
     return 0;
   }
@@ -184,13 +197,70 @@ struct ScanOut {
 
 static uint32_t warmup_blocks(uint32_t m, uint32_t k) { return (m + k + 1 + 63) / 64; }
 
-// Runs the scan kernel over one buffer and returns the resolved reports.
+// Prefilter geometry: k+1 disjoint pattern pieces of q rows.  Enabled when the pieces are long
+// enough to be selective (expected hit blocks on random DNA: 64*(k+1)/4^q of all blocks).
+static uint32_t filter_piece_len(const PatternPlan& plan, uint32_t k) {
+  static const int env = getenv("SASSY_HIP_PREFILTER") ? atoi(getenv("SASSY_HIP_PREFILTER")) : -1;
+  if (env == 0) return 0;
+  const uint64_t pieces = (uint64_t)k + 1;
+  uint64_t q = plan.m / pieces;
+  if (q > 12) q = 12;
+  if (pieces * q > 255) return 0;            // the term table holds 256 piece rows
+  if (q < (env == 1 ? 2u : 7u)) return 0;    // too unselective: stream the full DP instead
+  return (uint32_t)q;
+}
+
+static hipError_t launch_scan_any(Profile pr, const ScanParams& P, uint32_t grid, size_t smem, hipStream_t st) {
+  switch (pr) {
+    case PROFILE_DNA: return launch_scan_dna(P, grid, smem, st);
+    case PROFILE_IUPAC: return launch_scan_iupac(P, grid, smem, st);
+    default: return launch_scan_ascii(P, grid, smem, st);
+  }
+}
+static hipError_t launch_filter_any(Profile pr, const ScanParams& P, uint32_t grid, size_t smem, hipStream_t st) {
+  switch (pr) {
+    case PROFILE_DNA: return launch_filter_dna(P, grid, smem, st);
+    case PROFILE_IUPAC: return launch_filter_iupac(P, grid, smem, st);
+    default: return launch_filter_ascii(P, grid, smem, st);
+  }
+}
+static hipError_t launch_list_any(Profile pr, const ScanParams& P, uint32_t grid, size_t smem, hipStream_t st) {
+  switch (pr) {
+    case PROFILE_DNA: return launch_list_dna(P, grid, smem, st);
+    case PROFILE_IUPAC: return launch_list_iupac(P, grid, smem, st);
+    default: return launch_list_ascii(P, grid, smem, st);
+  }
+}
+
+// Chunk geometry of a streaming kernel: enough lanes to fill 256 CUs several times over, chunks
+// long enough that the extra blocks in front of each chunk stay a few percent of the work.
+static int stream_geometry(ScanParams& P, uint64_t owned, uint32_t extra_front, uint32_t* grid) {
+  static const int env_wpc = getenv("SASSY_HIP_WAVES_PER_CU") ? atoi(getenv("SASSY_HIP_WAVES_PER_CU")) : 0;
+  const uint64_t target_lanes = 256ull * (env_wpc > 0 ? env_wpc : 16) * 64 * 2;
+  uint64_t bpl = (owned + target_lanes - 1) / target_lanes;
+  const uint64_t min_bpl = std::max<uint64_t>(8, 6ull * extra_front);
+  if (bpl < min_bpl) bpl = min_bpl;
+  bpl += bpl & 1;  // even: a staged pair of blocks is then always one aligned 128-byte line
+  if (bpl > 0xFFFFFFFFull / 2) return fail(SASSY_HIP_EUNSUPPORTED, "text too large for one launch");
+  P.bpl = (uint32_t)bpl;
+  P.n_chunks = (owned + bpl - 1) / bpl;
+  P.n_iter = extra_front + 1 + P.bpl;
+  const uint64_t groups = (P.n_chunks + 255) / 256;
+  if (groups > 0x7FFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "grid too large");
+  *grid = (uint32_t)groups;
+  return 0;
+}
+
+// Runs the scan over one buffer and returns the resolved reports (+ device traceback records).
+// Two exact paths: the streaming DP over every block, or -- when the pattern splits into k+1
+// selective pieces -- prefilter (K0) -> chunk list (K0b) -> DP over the listed chunks (K1-list).
 static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPlan& plan, uint32_t k,
                     bool all_minima, const uint8_t* pat, bool do_trace, uint64_t total_len, ScanOut& out) {
   out = ScanOut();
   const uint64_t n_blocks = (sh.text_len + 63) / 64;
   const uint64_t first_owned = sh.halo_len / 64;
   if (n_blocks <= first_owned) return 0;  // nothing owned (empty text)
+  if (n_blocks > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "text longer than 2^38 bytes per buffer");
   const uint64_t owned = n_blocks - first_owned;
 
   ScanParams P{};
@@ -205,44 +275,24 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   P.nslots = plan.nslots;
   P.profile = (uint32_t)S->profile;
   P.wb = warmup_blocks(plan.m, k);
-  // Chunk geometry: enough lanes to fill 256 CUs several times over, chunks long enough that the
-  // warm-up blocks stay a few percent of the work.
-  static const int env_wpc = getenv("SASSY_HIP_WAVES_PER_CU") ? atoi(getenv("SASSY_HIP_WAVES_PER_CU")) : 0;
-  const uint64_t target_lanes = 256ull * (env_wpc > 0 ? env_wpc : 12) * 64 * 2;
-  uint64_t bpl = (owned + target_lanes - 1) / target_lanes;
-  const uint64_t min_bpl = std::max<uint64_t>(8, 6ull * P.wb);
-  if (bpl < min_bpl) bpl = min_bpl;
-  bpl += bpl & 1;  // even: a staged pair of blocks is then always one aligned 128-byte line
-  if (bpl > 0xFFFFFFFFull / 2) return fail(SASSY_HIP_EUNSUPPORTED, "text too large for one launch");
-  P.bpl = (uint32_t)bpl;
-  P.n_chunks = (owned + bpl - 1) / bpl;
-  P.n_iter = P.wb + 1 + P.bpl;
   P.flags = (all_minima ? kScanAllMinima : 0u) | (sh.text_start ? kScanTextStart : 0u) |
             (sh.text_end ? kScanTextEnd : 0u);
   const uint32_t bucket = plan.nslots <= 4 ? 4 : plan.nslots <= 8 ? 8 : 16;
   static const int env_sb = getenv("SASSY_HIP_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_STAGE_BLOCKS")) : 0;
-  P.stage_blocks = env_sb == 1 || env_sb == 2 ? (uint32_t)env_sb : 2u;
-  P.lds_per_wave = 4096u * P.stage_blocks + bucket * 512u + plan.nwords * 512u;
-  const size_t smem = (size_t)kWavesPerGroup * P.lds_per_wave;
-  if (smem > 160 * 1024) return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
+  P.stage_blocks = env_sb == 1 || env_sb == 2 ? (uint32_t)env_sb : 1u;
   for (int s = 0; s < kMaxSlots; ++s) P.slot_val[s] = plan.slot_val[s];
-  const uint64_t groups = (P.n_chunks + 255) / 256;
-  if (groups > 0x7FFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "grid too large");
-  const uint32_t grid = (uint32_t)groups;
+  const uint32_t q = filter_piece_len(plan, k);
+  const bool filtered = q > 0;
 
   if (int rc = S->d_rowoff.reserve(plan.row_tab.size())) return rc;
   HIP_TRY(hipMemcpyAsync(S->d_rowoff.p, plan.row_tab.data(), plan.row_tab.size() * sizeof(uint32_t),
                          hipMemcpyHostToDevice, S->stream));
-  if (int rc = S->d_state.reserve(P.n_chunks)) return rc;
-  if (int rc = S->d_count.reserve(4)) return rc;
+  if (int rc = S->d_count.reserve(16)) return rc;   // [0] candidates, [1] descriptors
   if (S->d_cand.cap == 0)
     if (int rc = S->d_cand.reserve(1u << 16)) return rc;
-  if (S->want_counters) {
-    if (int rc = S->d_counters.reserve(2)) return rc;
-    HIP_TRY(hipMemsetAsync(S->d_counters.p, 0, 2 * sizeof(unsigned long long), S->stream));
-  }
+  if (int rc = S->d_counters.reserve(4)) return rc;   // [0] word rows [1] blocks [2] hit blocks
+  HIP_TRY(hipMemsetAsync(S->d_counters.p, 0, 4 * sizeof(unsigned long long), S->stream));
   P.row_tab = S->d_rowoff.p;
-  P.chunk_state = S->d_state.p;
   P.cand_count = S->d_count.p;
   P.counters = S->want_counters ? S->d_counters.p : nullptr;
 
@@ -271,8 +321,45 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     T.scratch_stride = (uint32_t)stride;
     T.ops_stride = (plan.m + k + 1 + 15) / 16 * 16;
   }
-  uint32_t count = 0;
-  for (int attempt = 0; attempt < 3; ++attempt) {
+
+  // ---- geometry of the streaming kernel (full DP, or the prefilter) ----
+  uint32_t grid = 0;
+  ScanParams F = P;           // prefilter launch
+  uint32_t fgrid = 0;
+  const uint32_t maxlen = 128;  // list mode: longest chunk in blocks (long runs are cut)
+  uint64_t n_words = 0;
+  if (!filtered) {
+    if (int rc = stream_geometry(P, owned, P.wb, &grid)) return rc;
+    P.lds_per_wave = 4096u * P.stage_blocks + bucket * 512u + plan.nwords * 512u;
+    if ((size_t)kWavesPerGroup * P.lds_per_wave > 160 * 1024)
+      return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
+    if (int rc = S->d_state.reserve(P.n_chunks)) return rc;
+    P.chunk_state = S->d_state.p;
+  } else {
+    // K0 also looks at the last halo blocks: a piece that ends there can belong to a match that
+    // ends in the first owned blocks, and K0b must know whether the block left of the first
+    // owned one is affected.
+    const uint64_t look = std::min<uint64_t>(first_owned, (uint64_t)P.wb + 2);
+    F.first_owned_block = first_owned - look;
+    F.n_pieces = k + 1;
+    F.piece_len = q;
+    if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, 1, &fgrid)) return rc;
+    F.lds_per_wave = 4096u * F.stage_blocks + 2u * bucket * 512u;
+    n_words = (n_blocks + 63) / 64;
+    if (int rc = S->d_bitmap.reserve(n_words + 2)) return rc;
+    F.hit_bitmap = S->d_bitmap.p;
+    F.hit_count = S->d_counters.p + 2;
+    HIP_TRY(hipMemsetAsync(S->d_bitmap.p, 0, (n_words + 2) * sizeof(unsigned long long), S->stream));
+    if (S->d_desc.cap == 0)
+      if (int rc = S->d_desc.reserve(1u << 18)) return rc;
+    P.lds_per_wave = bucket * 512u + plan.nwords * 512u;
+    if ((size_t)kWavesPerGroup * P.lds_per_wave > 160 * 1024)
+      return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
+  }
+
+  uint32_t counts[2] = {0, 0};
+  uint32_t desc_cap = 0;
+  for (int attempt = 0; attempt < 4; ++attempt) {
     P.cand = S->d_cand.p;
     P.cand_cap = (uint32_t)std::min<size_t>(S->d_cand.cap, 0xFFFFFFFFu);
     if (do_trace) {
@@ -283,47 +370,79 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       T.out = S->d_trace.p;
       T.out_ops = S->d_ops.p;
     }
-    HIP_TRY(hipMemsetAsync(S->d_count.p, 0, sizeof(uint32_t), S->stream));
+    HIP_TRY(hipMemsetAsync(S->d_count.p, 0, 2 * sizeof(uint32_t), S->stream));
     HIP_TRY(hipEventRecord(S->ev_a, S->stream));
     hipError_t le;
-    switch (S->profile) {
-      case PROFILE_DNA: le = launch_scan_dna(P, grid, smem, S->stream); break;
-      case PROFILE_IUPAC: le = launch_scan_iupac(P, grid, smem, S->stream); break;
-      default: le = launch_scan_ascii(P, grid, smem, S->stream); break;
+    if (!filtered) {
+      le = launch_scan_any(S->profile, P, grid, (size_t)kWavesPerGroup * P.lds_per_wave, S->stream);
+      if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
+    } else {
+      if (attempt == 0) {  // the hit bitmap does not depend on buffer sizes: build it once
+        le = launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, S->stream);
+        if (le != hipSuccess) return hip_fail(le, "filter kernel launch");
+      }
+      HIP_TRY(hipEventRecord(S->ev_f, S->stream));
+      desc_cap = (uint32_t)std::min<size_t>(S->d_desc.cap, 0x7FFFFFFFu);
+      if (int rc = S->d_state.reserve(desc_cap)) return rc;
+      P.chunk_state = S->d_state.p;
+      le = launch_build_chunks(S->d_bitmap.p, n_words, n_blocks, first_owned, P.wb, P.wb, maxlen, S->d_desc.p,
+                               S->d_count.p + 1, desc_cap, S->stream);
+      if (le != hipSuccess) return hip_fail(le, "chunk builder launch");
+      P.desc = S->d_desc.p;
+      P.desc_count = S->d_count.p + 1;
+      P.desc_cap = desc_cap;
+      // the descriptor count lives on the device: launch for the capacity, idle waves exit at once
+      const uint32_t lgrid = (desc_cap + 255) / 256;
+      le = launch_list_any(S->profile, P, lgrid, (size_t)kWavesPerGroup * P.lds_per_wave, S->stream);
+      if (le != hipSuccess) return hip_fail(le, "list kernel launch");
     }
-    if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
     HIP_TRY(hipEventRecord(S->ev_b, S->stream));
     if (do_trace) {
       le = launch_trace(T, trace_blocks, S->stream);
       if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
       HIP_TRY(hipEventRecord(S->ev_c, S->stream));
     }
-    HIP_TRY(hipMemcpyAsync(&count, S->d_count.p, sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream));
+    HIP_TRY(hipMemcpyAsync(counts, S->d_count.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream));
     HIP_TRY(hipStreamSynchronize(S->stream));
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_b));
     S->stats.scan_ms += ms;
     S->stats.scan_launches += 1;
+    if (filtered && attempt == 0) {
+      HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_f));
+      S->stats.filter_ms += ms;
+    }
     if (do_trace) {
       HIP_TRY(hipEventElapsedTime(&ms, S->ev_b, S->ev_c));
       S->stats.trace_ms += ms;
     }
-    if (count <= P.cand_cap) break;
-    // more reports than the buffer holds (dense matches): grow and run again
-    if (int rc = S->d_cand.reserve((size_t)count + 1024)) return rc;
+    bool again = false;
+    if (filtered && counts[1] > desc_cap) {  // more chunks than descriptors fit: grow, rebuild
+      if (int rc = S->d_desc.reserve((size_t)counts[1] + 1024)) return rc;
+      again = true;
+    }
+    if (counts[0] > P.cand_cap) {  // more reports than the buffer holds (dense matches)
+      if (int rc = S->d_cand.reserve((size_t)counts[0] + 1024)) return rc;
+      again = true;
+    }
+    if (!again) break;
+    if (attempt == 3) return fail(SASSY_HIP_ENOMEM, "candidate / descriptor buffer overflow");
   }
-  if (count > (uint32_t)std::min<size_t>(S->d_cand.cap, 0xFFFFFFFFu))
-    return fail(SASSY_HIP_ENOMEM, "candidate buffer overflow");
-  S->stats.chunks = P.n_chunks;
-  S->stats.blocks_per_chunk = P.bpl;
+  const uint32_t count = counts[0];
+  const uint32_t n_desc = filtered ? counts[1] : 0;
+  S->stats.chunks = filtered ? n_desc : P.n_chunks;
+  S->stats.blocks_per_chunk = filtered ? F.bpl : P.bpl;
   S->stats.warmup_blocks = P.wb;
-  S->stats.grid = grid;
+  S->stats.grid = filtered ? fgrid : grid;
   S->stats.text_bytes += sh.text_len - sh.halo_len;
-  if (S->want_counters) {
-    unsigned long long c[2] = {0, 0};
+  S->stats.filtered = filtered ? 1 : 0;
+  S->stats.piece_len = q;
+  {
+    unsigned long long c[4] = {0, 0, 0, 0};
     HIP_TRY(hipMemcpy(c, S->d_counters.p, sizeof c, hipMemcpyDeviceToHost));
     S->stats.word_rows += c[0];
     S->stats.blocks += c[1];
+    S->stats.hit_blocks += c[2];
   }
 
   std::vector<Candidate> raw(count);
@@ -349,12 +468,47 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   // ---- seams: reports that depend on how a plateau was entered left of their chunk ----
   bool any_cond = false;
   for (const Candidate& c : out.cands) any_cond |= (c.flags & kCandCond) != 0;
-  std::vector<uint8_t> state;
   const bool need_state = any_cond || !sh.text_end;  // non-final shards publish their exit state
+  // chunk table in text order: [own_lo, own_hi), exit state, "its left edge is known to be > k"
+  struct ChunkInfo { uint64_t lo, hi; uint8_t state; bool clear_before; };
+  std::vector<ChunkInfo> chunks;
   if (need_state) {
-    state.resize(P.n_chunks);
-    HIP_TRY(hipMemcpy(state.data(), S->d_state.p, P.n_chunks, hipMemcpyDeviceToHost));
+    if (!filtered) {
+      std::vector<uint8_t> state(P.n_chunks);
+      HIP_TRY(hipMemcpy(state.data(), S->d_state.p, P.n_chunks, hipMemcpyDeviceToHost));
+      chunks.resize(P.n_chunks);
+      for (uint64_t c = 0; c < P.n_chunks; ++c) {
+        const uint64_t lo = first_owned + c * P.bpl;
+        chunks[c] = ChunkInfo{lo, std::min<uint64_t>(lo + P.bpl, n_blocks), state[c], false};
+      }
+    } else if (n_desc) {
+      std::vector<ChunkDesc> desc(n_desc);
+      std::vector<uint8_t> state(n_desc);
+      HIP_TRY(hipMemcpy(desc.data(), S->d_desc.p, (size_t)n_desc * sizeof(ChunkDesc), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(state.data(), S->d_state.p, n_desc, hipMemcpyDeviceToHost));
+      chunks.resize(n_desc);
+      for (uint32_t c = 0; c < n_desc; ++c)
+        chunks[c] = ChunkInfo{desc[c].own_lo, desc[c].own_hi, state[c], (desc[c].flags & kDescClearBefore) != 0};
+      std::sort(chunks.begin(), chunks.end(), [](const ChunkInfo& a, const ChunkInfo& b) { return a.lo < b.lo; });
+    }
   }
+  // decreasing-state arriving at the left edge of chunk ci: kStateDecTrue/False, or kStatePass
+  // when only the previous shard knows
+  auto incoming = [&](size_t ci) -> int {
+    for (;;) {
+      const ChunkInfo& c = chunks[ci];
+      if (c.clear_before) return kStateDecTrue;
+      if (ci == 0 || chunks[ci - 1].hi != c.lo) {
+        // nothing of this buffer lies directly left of it: text start, a skipped (all > k)
+        // block, or the previous shard
+        if (c.lo == first_owned && !(sh.text_start && first_owned == 0) && first_owned > 0) return kStatePass;
+        if (c.lo == 0 && !sh.text_start) return kStatePass;
+        return kStateDecTrue;
+      }
+      if (chunks[ci - 1].state != kStatePass) return chunks[ci - 1].state;
+      --ci;
+    }
+  };
   if (any_cond) {
     std::vector<Candidate> kept;
     std::vector<uint32_t> kept_slot;
@@ -366,32 +520,34 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       const uint32_t cslot = out.slot[ci];
       if (!(c.flags & kCandCond)) { kept.push_back(c); kept_slot.push_back(cslot); continue; }
       out.cond_seen++;
-      uint64_t local = c.pos - sh.global_offset;
-      uint64_t blk = local / 64;
+      uint64_t blk = (c.pos - sh.global_offset) / 64;
       if (c.pos == end_global && blk >= n_blocks) blk = n_blocks - 1;  // end-of-text report
-      uint64_t chunk = (blk - first_owned) / bpl;
-      if (chunk >= P.n_chunks) chunk = P.n_chunks - 1;
-      // direction in which the plateau was entered = exit state of the nearest chunk to the
-      // left that determined it
-      int64_t q = (int64_t)chunk - 1;
-      while (q >= 0 && state[(size_t)q] == kStatePass) --q;
-      if (q >= 0) {
-        if (state[(size_t)q] == kStateDecTrue) { Candidate cc = c; cc.flags &= ~kCandCond; kept.push_back(cc); kept_slot.push_back(cslot); }
-      } else if (sh.text_start) {
-        Candidate cc = c; cc.flags &= ~kCandCond; kept.push_back(cc); kept_slot.push_back(cslot);  // column 0: decreasing
-      } else {
+      // the chunk that owns the block in which this report was decided
+      size_t lo = 0, hi = chunks.size();
+      while (lo + 1 < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (chunks[mid].lo <= blk) lo = mid; else hi = mid;
+      }
+      const int inc = chunks.empty() ? kStateDecTrue : incoming(lo);
+      Candidate cc = c;
+      if (inc == kStateDecTrue) { cc.flags &= ~kCandCond; kept.push_back(cc); kept_slot.push_back(cslot); }
+      else if (inc == kStatePass) {
         out.conditional_index = (int64_t)kept.size();  // only the previous shard knows
         kept.push_back(c);
         kept_slot.push_back(cslot);
-      }
+      }  // kStateDecFalse: the plateau was entered by an increase -> not a report
     }
     out.cands.swap(kept);
     out.slot.swap(kept_slot);
   }
   if (need_state) {
-    int64_t q = (int64_t)P.n_chunks - 1;
-    while (q >= 0 && state[(size_t)q] == kStatePass) --q;
-    out.exit_state = q >= 0 ? state[(size_t)q] : (sh.text_start ? kStateDecTrue : kStatePass);
+    // exit state = decreasing-state after the last owned block
+    out.exit_state = kStateDecTrue;
+    if (!chunks.empty() && chunks.back().hi == n_blocks) {
+      size_t ci = chunks.size() - 1;
+      if (chunks[ci].state != kStatePass) out.exit_state = chunks[ci].state;
+      else out.exit_state = incoming(ci);
+    }
   }
   S->stats.cond_resolved += out.cond_seen;
   return 0;
@@ -616,8 +772,9 @@ int sassy_hip_search(sassy_SearcherType* s, const uint8_t* pattern, size_t patte
 
 uint64_t sassy_hip_required_halo(size_t pattern_len, size_t k) {
   // warm-up blocks + the traceback window, rounded up to whole 128-byte lines
+  // warm-up blocks, the blocks the prefilter looks back into, and the traceback window
   const uint64_t wb = warmup_blocks((uint32_t)pattern_len, (uint32_t)k);
-  uint64_t h = std::max<uint64_t>(64 * (wb + 1), pattern_len + k);
+  uint64_t h = std::max<uint64_t>(64 * (wb + 4), pattern_len + k);
   return (h + 127) / 128 * 128;
 }
 

@@ -530,6 +530,255 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   }
 }
 
+// ====================================================================== K0: the prefilter
+// Pigeonhole: cut the first n_pieces * piece_len pattern rows into n_pieces = k+1 disjoint pieces;
+// an alignment with <= k edits leaves at least one piece untouched, so every cell <= k in the
+// last DP row at column c implies an EXACT occurrence of some piece ending at a text position
+// e in [c - (m+k), c].  This kernel streams over the text exactly like the DP kernel (same
+// staging, same lane-parallel profile), but per block it only evaluates, for every piece, the
+// bit-parallel exact-match word  E_p = AND_j (mask[slot(p,j)] << (piece_len-1-j))  with the bits
+// shifted in from the previous block's masks, and records the blocks in which some piece ends.
+// Blocks far from every recorded block cannot hold a cell <= k and never see the DP.
+// (The piece test uses the same slot masks as the scan, so it is exact for every profile.)
+template <int PROFILE, int NS, int SB>
+__global__ __launch_bounds__(256) void filter_kernel(const ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr uint32_t kRowBytes = 64u * SB;
+  constexpr uint32_t kSlots = 4u * SB;
+  constexpr uint32_t kOwnersPerInstr = 64u / kSlots;
+  constexpr int kStageInstr = 4 * SB;
+  constexpr uint32_t kTile = 64u * kRowBytes;
+  constexpr uint32_t kTermTabBytes = 1024;  // LDS offset of the slot mask of every piece row
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  uint32_t* term_off = reinterpret_cast<uint32_t*>(smem);
+  unsigned char* wbase = smem + kTermTabBytes + (size_t)wave * P.lds_per_wave;
+  unsigned char* tile = wbase;
+  unsigned char* mask_bytes = wbase + kTile;  // two buffers of [NS][64] u64: this block / previous block
+
+  const uint32_t n_terms = P.n_pieces * P.piece_len;
+  {
+    const_u32_ptr row_tab = (const_u32_ptr)(P.row_tab);
+    for (uint32_t t = threadIdx.x; t < n_terms; t += blockDim.x)
+      term_off[t] = ((row_tab[t >> 2] >> (8 * (t & 3))) & 0xFFu) << 8;
+  }
+  // previous-block masks of a chunk that starts at the buffer start: nothing matches before it
+#pragma unroll
+  for (int s = 0; s < 2 * NS; ++s) *reinterpret_cast<uint2*>(mask_bytes + s * 512 + lane * 8) = make_uint2(0u, 0u);
+  __syncthreads();
+
+  const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * kWavesPerGroup + wave) * kWave;
+  if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
+  const uint64_t chunk = wave_chunk0 + lane;
+  const uint32_t bpl = P.bpl;
+  const uint64_t first_owned = P.first_owned_block;
+  const uint32_t back = 1u + (uint32_t)((first_owned + 1u) & 1u);  // previous block + evenness
+  const uint64_t own_lo = first_owned + chunk * (uint64_t)bpl;
+  uint64_t own_hi = own_lo + bpl;
+  if (own_hi > P.n_blocks) own_hi = P.n_blocks;
+  const bool has_chunk = chunk < P.n_chunks && own_lo < P.n_blocks;
+  const uint64_t blk0 = chunk_blk0(first_owned, bpl, back, chunk);
+
+  const uint64_t wave_blk0 = chunk_blk0(first_owned, bpl, back, wave_chunk0);
+  const uint8_t* text_base = P.text + wave_blk0 * 64;
+  uint32_t soff[kStageInstr];
+#pragma unroll
+  for (int i = 0; i < kStageInstr; ++i) {
+    const uint32_t owner = (uint32_t)i * kOwnersPerInstr + lane / kSlots;
+    const uint32_t slot = lane % kSlots;
+    const uint32_t j = slot ^ (SB == 2 ? ((owner >> 1) & 7u) : ((owner >> 2) & 3u));
+    soff[i] = (uint32_t)((chunk_blk0(first_owned, bpl, back, wave_chunk0 + owner) - wave_blk0) * 64) + j * 16u;
+  }
+  const uint64_t wave_last = chunk_blk0(first_owned, bpl, back, wave_chunk0 + 63) + P.n_iter + 2;
+  const bool interior = wave_last * 64 <= P.text_len;
+  const uint32_t fsw = SB == 2 ? ((lane >> 1) & 7u) : ((lane >> 2) & 3u);
+  uint32_t rc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rc[c] = lane * kRowBytes + (((uint32_t)c ^ (fsw & 3u)) << 4);
+
+  const uint32_t q = P.piece_len;
+  unsigned long long nhits = 0;
+
+  for (uint32_t it = 0; it < P.n_iter; ++it) {
+    const uint32_t sub = SB == 2 ? (it & 1u) : 0u;
+    if (sub == 0) {
+      if (interior) {
+#pragma unroll
+        for (int i = 0; i < kStageInstr; ++i) {
+          const uint4 v = *reinterpret_cast<const uint4*>(text_base + (uint64_t)it * 64 + soff[i]);
+          *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < kStageInstr; ++i) {
+          const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
+          uint4 v;
+          if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
+          else v = load_tail16(P.text, off, P.text_len);
+          *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+        }
+      }
+    }
+    unsigned char* cur = mask_bytes + (it & 1u) * (NS * 512);
+    const unsigned char* prv = mask_bytes + ((it & 1u) ^ 1u) * (NS * 512);
+    {
+      const uint32_t hs = SB == 2 ? (((sub << 2) ^ (fsw & 4u)) << 4) : 0u;
+      uint32_t x[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + rc[c] + hs);
+        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+      }
+      uint2 msk[NS];
+      build_masks<PROFILE, NS>(x, P, msk);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<uint2*>(cur + s * 512 + lane * 8) = msk[s];
+    }
+    // ---- exact piece occurrences that end inside this block ----
+    uint32_t hl = 0, hh = 0;
+    const unsigned char* curl = cur + lane * 8;
+    const unsigned char* prvl = prv + lane * 8;
+    uint32_t t = 0;
+    for (uint32_t p = 0; p < P.n_pieces; ++p) {
+      uint32_t sl = 0xFFFFFFFFu, sh = 0xFFFFFFFFu;
+      for (uint32_t j = 0; j + 1 < q; ++j, ++t) {
+        const uint32_t off = term_off[t];
+        const uint2 c = *reinterpret_cast<const uint2*>(curl + off);
+        const uint2 pv = *reinterpret_cast<const uint2*>(prvl + off);
+        const uint32_t sr = 32u - (q - 1u - j);  // shift left by q-1-j as a funnel shift right
+        sl &= __builtin_amdgcn_alignbit(c.x, pv.y, sr);
+        sh &= __builtin_amdgcn_alignbit(c.y, c.x, sr);
+      }
+      const uint2 c = *reinterpret_cast<const uint2*>(curl + term_off[t]);  // last row of the piece: no shift
+      ++t;
+      hl |= sl & c.x;
+      hh |= sh & c.y;
+    }
+    const uint64_t b = blk0 + it;
+    const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
+    if (evaluate && (hl | hh) != 0) {
+      atomicOr(&P.hit_bitmap[b >> 6], 1ull << (b & 63));
+      nhits += 1;
+    }
+  }
+  if (nhits) atomicAdd(P.hit_count, nhits);
+}
+
+// ====================================================================== K1-list: DP over a chunk list
+// Same DP, same report rule, same seam bookkeeping as scan_kernel, but every lane takes its chunk
+// (first block, end block, flags) from a descriptor list built from the prefilter's hit bitmap.
+// The chunks are few and short, so each lane simply reads its own 64 bytes per block.
+template <int PROFILE, int NS>
+__global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  unsigned char* wbase = smem + (size_t)wave * P.lds_per_wave;
+  unsigned char* mask_bytes = wbase;                                        // [NS][64] u64
+  uint32_t* carry = reinterpret_cast<uint32_t*>(wbase + NS * 512);          // [word][hp|hm][lane]
+
+  uint32_t n_desc = *P.desc_count;
+  if (n_desc > P.desc_cap) n_desc = P.desc_cap;
+  const uint32_t wave_first = (blockIdx.x * kWavesPerGroup + wave) * kWave;
+  if (wave_first >= n_desc) return;  // wave-uniform
+  const uint32_t di = wave_first + lane;
+  const bool has_chunk = di < n_desc;
+  ChunkDesc d;
+  d.own_lo = d.own_hi = d.flags = d.pad_ = 0;
+  if (has_chunk) d = P.desc[di];
+  const uint64_t own_lo = d.own_lo, own_hi = d.own_hi;
+  const bool clear_before = (d.flags & kDescClearBefore) != 0;
+  // a chunk whose left neighbour block holds no cell <= k starts fresh at its own first block;
+  // a continuation chunk (split of a long run) needs the warm-up blocks in front of it
+  uint64_t blk0 = own_lo;
+  if (!clear_before) blk0 = own_lo > P.wb ? own_lo - P.wb : 0;
+  const bool exact_start = clear_before || (blk0 == 0 && (P.flags & kScanTextStart));
+  const int64_t x0 = exact_start ? -1 : (int64_t)(blk0 * 64 + P.m + P.k);
+  const uint32_t my_iters = has_chunk ? (uint32_t)(own_hi - blk0) : 0u;
+
+  const int k = (int)P.k;
+  const uint32_t m = P.m;
+  const uint32_t nwords = P.nwords;
+  const uint32_t last_rows = m - 32 * (nwords - 1);
+  const uint32_t last_word_init = last_rows == 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> last_rows);
+  const_u32_ptr row_tab = (const_u32_ptr)(P.row_tab);
+  uint32_t pkw0[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pkw0[i] = row_tab[i];
+  for (uint32_t w = 0; w < nwords; ++w) {
+    carry[(w * 2 + 0) * 64 + lane] = (w == nwords - 1) ? last_word_init : 0xFFFFFFFFu;
+    carry[(w * 2 + 1) * 64 + lane] = 0;
+  }
+  uint32_t st = kStDec;
+  EmitCtx ctx;
+  ctx.cand = P.cand;
+  ctx.cand_count = P.cand_count;
+  ctx.text_len = P.text_len;
+  ctx.global_offset = P.global_offset;
+  ctx.cand_cap = P.cand_cap;
+  ctx.k = P.k;
+  ctx.flags = P.flags;
+  unsigned long long cnt_rows = 0, cnt_blocks = 0;
+  const unsigned char* my_masks = mask_bytes + lane * 8;
+
+  for (uint32_t it = 0; __any(it < my_iters); ++it) {
+    const bool active = it < my_iters;
+    const uint64_t b = blk0 + it;
+    uint32_t x[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint64_t off = b * 64 + (uint64_t)c * 16;
+      uint4 v = make_uint4(0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u);
+      if (active) {
+        if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
+        else v = load_tail16(P.text, off, P.text_len);
+      }
+      x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+    }
+    {
+      uint2 msk[NS];
+      build_masks<PROFILE, NS>(x, P, msk);
+#pragma unroll
+      for (int s = 0; s < NS; ++s) *reinterpret_cast<uint2*>(mask_bytes + s * 512 + lane * 8) = msk[s];
+    }
+    DpWord V;
+    V.vpl = V.vph = V.vml = V.vmh = 0;
+    int ds = 0;
+    for (uint32_t w = 0; w < nwords; ++w) {
+      const uint32_t ohp = carry[(w * 2 + 0) * 64 + lane];
+      const uint32_t ohm = carry[(w * 2 + 1) * 64 + lane];
+      ds += __popc(ohp) - __popc(ohm);
+      const uint32_t rows = (w == nwords - 1) ? last_rows : 32u;
+      uint32_t pkw[8];
+      if (w == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pkw[i] = pkw0[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pkw[i] = row_tab[8 * w + i];
+      }
+      uint32_t nhp, nhm;
+      dp_word(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm);
+      carry[(w * 2 + 0) * 64 + lane] = nhp;
+      carry[(w * 2 + 1) * 64 + lane] = nhm;
+    }
+    if (active) {
+      if (P.counters) { cnt_rows += m; cnt_blocks += 1; }
+      if (row_maybe_live(ds, V, k)) {
+        const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
+        st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
+      } else {
+        st = kStDec;
+      }
+    }
+  }
+  if (has_chunk) P.chunk_state[di] = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
+  if (P.counters) {
+    atomicAdd(&P.counters[0], cnt_rows);
+    atomicAdd(&P.counters[1], cnt_blocks);
+  }
+}
+
 // ------------------------------------------------------------------ launcher
 template <int PROFILE, int NS, int SB>
 static hipError_t launch_sb(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
@@ -549,6 +798,36 @@ static hipError_t launch_one(const ScanParams& P, uint32_t grid, size_t smem, hi
                              : launch_sb<PROFILE, NS, 2>(P, grid, smem, stream);
 }
 
+template <int PROFILE, int NS, int SB>
+static hipError_t launch_filter_sb(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_kernel<PROFILE, NS, SB>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((filter_kernel<PROFILE, NS, SB>), dim3(grid), dim3(256), smem, stream, P);
+  return hipGetLastError();
+}
+template <int PROFILE, int NS>
+static hipError_t launch_filter_one(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  return P.stage_blocks == 1 ? launch_filter_sb<PROFILE, NS, 1>(P, grid, smem, stream)
+                             : launch_filter_sb<PROFILE, NS, 2>(P, grid, smem, stream);
+}
+template <int PROFILE, int NS>
+static hipError_t launch_list_one(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&list_kernel<PROFILE, NS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((list_kernel<PROFILE, NS>), dim3(grid), dim3(256), smem, stream, P);
+  return hipGetLastError();
+}
+
 #ifndef SASSY_SCAN_PROFILE
 #error "compile with -DSASSY_SCAN_PROFILE=<0|1|2> (one translation unit per profile)"
 #endif
@@ -557,6 +836,12 @@ static hipError_t launch_one(const ScanParams& P, uint32_t grid, size_t smem, hi
 // Dna always has exactly the four slots A, C, T, G.
 hipError_t launch_scan_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
   return launch_one<PROFILE_DNA, 4>(P, grid, smem, stream);
+}
+hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  return launch_filter_one<PROFILE_DNA, 4>(P, grid, smem, stream);
+}
+hipError_t launch_list_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  return launch_list_one<PROFILE_DNA, 4>(P, grid, smem, stream);
 }
 #else
 #if SASSY_SCAN_PROFILE == 2
@@ -569,6 +854,30 @@ hipError_t launch_scan_ascii(const ScanParams& P, uint32_t grid, size_t smem, hi
   if (P.nslots <= 4) return launch_one<PR, 4>(P, grid, smem, stream);
   if (P.nslots <= 8) return launch_one<PR, 8>(P, grid, smem, stream);
   if (P.nslots <= 16) return launch_one<PR, 16>(P, grid, smem, stream);
+  return hipErrorInvalidValue;
+}
+#if SASSY_SCAN_PROFILE == 2
+hipError_t launch_filter_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  constexpr int PR2 = PROFILE_IUPAC;
+#else
+hipError_t launch_filter_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  constexpr int PR2 = PROFILE_ASCII;
+#endif
+  if (P.nslots <= 4) return launch_filter_one<PR2, 4>(P, grid, smem, stream);
+  if (P.nslots <= 8) return launch_filter_one<PR2, 8>(P, grid, smem, stream);
+  if (P.nslots <= 16) return launch_filter_one<PR2, 16>(P, grid, smem, stream);
+  return hipErrorInvalidValue;
+}
+#if SASSY_SCAN_PROFILE == 2
+hipError_t launch_list_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  constexpr int PR3 = PROFILE_IUPAC;
+#else
+hipError_t launch_list_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  constexpr int PR3 = PROFILE_ASCII;
+#endif
+  if (P.nslots <= 4) return launch_list_one<PR3, 4>(P, grid, smem, stream);
+  if (P.nslots <= 8) return launch_list_one<PR3, 8>(P, grid, smem, stream);
+  if (P.nslots <= 16) return launch_list_one<PR3, 16>(P, grid, smem, stream);
   return hipErrorInvalidValue;
 }
 #endif
