@@ -118,27 +118,68 @@ __device__ __forceinline__ bool dilated_bit(const BuildParams& P, uint64_t blk) 
 }
 
 __global__ __launch_bounds__(256) void build_chunks_kernel(const BuildParams P) {
+  __shared__ uint32_t wave_sum[4];
+  __shared__ uint32_t group_base;
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= P.n_words) return;
-  const unsigned long long A = dilated_word(P, (long long)w);
-  if (A == 0) return;
-  const unsigned long long prev_top = w > 0 ? (dilated_word(P, (long long)w - 1) >> 63) : 0ull;
-  unsigned long long align = 0;
-  for (int i = 0; i < 64; ++i)
-    if (((w * 64 + i) % P.maxlen) == 0) align |= 1ull << i;
-  unsigned long long own = ~0ull;  // only blocks >= first_owned are owned (the halo is warm-up)
-  if (w * 64 < P.first_owned) own = (P.first_owned - w * 64 >= 64) ? 0ull : (~0ull << (P.first_owned - w * 64));
-  unsigned long long first_bit = 0;  // the first owned block starts a chunk if it is in A'
-  if (P.first_owned >= w * 64 && P.first_owned < w * 64 + 64) first_bit = 1ull << (P.first_owned - w * 64);
-  unsigned long long starts = A & own & (~((A << 1) | prev_top) | align | first_bit);
+  unsigned long long A = 0, prev_top = 0, starts = 0;
+  if (w < P.n_words) {
+    A = dilated_word(P, (long long)w);
+    if (A) {
+      prev_top = w > 0 ? (dilated_word(P, (long long)w - 1) >> 63) : 0ull;
+      // maxlen is a power of two >= 64: a cut can only fall on bit 0 of a word
+      const unsigned long long align = ((w * 64) & (uint64_t)(P.maxlen - 1)) == 0 ? 1ull : 0ull;
+      unsigned long long own = ~0ull;  // only blocks >= first_owned are owned (the halo is warm-up)
+      if (w * 64 < P.first_owned) own = (P.first_owned - w * 64 >= 64) ? 0ull : (~0ull << (P.first_owned - w * 64));
+      unsigned long long first_bit = 0;  // the first owned block starts a chunk if it is in A'
+      if (P.first_owned >= w * 64 && P.first_owned < w * 64 + 64) first_bit = 1ull << (P.first_owned - w * 64);
+      starts = A & own & (~((A << 1) | prev_top) | align | first_bit);
+    }
+  }
+  // one atomic per workgroup: exclusive scan of the per-thread chunk counts
+  const uint32_t mine = (uint32_t)__popcll(starts);
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d);
+    if (lane >= (uint32_t)d) incl += up;
+  }
+  if (lane == 63) wave_sum[wv] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    group_base = total ? atomicAdd(P.desc_count, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t idx = group_base + (incl - mine);
+  for (uint32_t v = 0; v < wv; ++v) idx += wave_sum[v];
+
   while (starts) {
     const int i = __ffsll((long long)starts) - 1;
     starts &= starts - 1;
     const uint64_t lo = w * 64 + (uint64_t)i;
     const bool left_in = i > 0 ? ((A >> (i - 1)) & 1ull) : (prev_top != 0);
+    // end of the chunk: first block after lo that is outside A', or the next cut
     uint64_t j = lo + 1;
-    while (j < P.n_blocks && (j % P.maxlen) != 0 && dilated_bit(P, j)) ++j;
-    const uint32_t idx = atomicAdd(P.desc_count, 1u);
+    {
+      unsigned long long rest = (i < 63) ? (A >> (i + 1)) : 0ull;       // A' bits of blocks lo+1 ..
+      int avail = 63 - i;                                               // .. still inside this word
+      uint64_t ww = w;
+      for (;;) {
+        // consecutive A' blocks at the bottom of `rest` (bits past `avail` are zero or ignored)
+        const unsigned long long inv = ~rest;
+        int run = inv ? (__ffsll((long long)inv) - 1) : 64;
+        if (run > avail) run = avail;
+        j += (uint64_t)run;
+        if (run < avail) break;                       // hit a block outside A'
+        ++ww;
+        if (ww * 64 >= P.n_blocks) break;             // end of the buffer
+        if (((ww * 64) & (uint64_t)(P.maxlen - 1)) == 0) break;  // cut at a multiple of maxlen
+        rest = dilated_word(P, (long long)ww);
+        avail = 64;
+      }
+      if (j > P.n_blocks) j = P.n_blocks;
+    }
     if (idx < P.desc_cap) {
       ChunkDesc d;
       d.own_lo = (uint32_t)lo;
@@ -147,6 +188,7 @@ __global__ __launch_bounds__(256) void build_chunks_kernel(const BuildParams P) 
       d.pad_ = 0;
       P.desc[idx] = d;
     }
+    ++idx;
   }
 }
 

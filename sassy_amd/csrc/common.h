@@ -67,6 +67,12 @@ struct ScanParams {
   // ---- prefilter (K0) / list mode (K1-list) ----
   uint32_t n_pieces;          // k+1 pattern pieces of piece_len rows each (rows 0 .. n_pieces*piece_len)
   uint32_t piece_len;
+  // fast path (k+1 <= 8): slot*2 of row j of pieces 4g..4g+3, one byte per piece, for the shifted
+  // rows j < piece_len-1 (piece_tab) and for the last, unshifted row (piece_last); missing pieces
+  // repeat piece 0
+  uint32_t piece_groups;      // 0: generic path (table in LDS), 1 or 2: fast path
+  uint32_t piece_tab[2][12];
+  uint32_t piece_last[2];
   unsigned long long* hit_bitmap;  // one bit per text block: an exact piece occurrence ends in it
   unsigned long long* hit_count;   // device counter of hit blocks
   const ChunkDesc* desc;      // list mode: chunk descriptors

@@ -124,11 +124,26 @@ struct sassy_SearcherType {
   DevBuf<unsigned long long> d_counters, d_bitmap;
   bool want_counters = false;
   sassy_hip_Stats stats{};
+  // pinned host staging area: counts, counters and the first kSpec reports of a call arrive with
+  // one batch of async copies in front of the single stream synchronisation
+  unsigned char* h_pin = nullptr;
+  size_t h_pin_cap = 0;
+  int reserve_pinned(size_t bytes) {
+    if (bytes <= h_pin_cap) return 0;
+    if (h_pin) (void)hipHostFree(h_pin);
+    h_pin = nullptr;
+    h_pin_cap = 0;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h_pin), bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+    h_pin_cap = bytes;
+    return 0;
+  }
 
   ~sassy_SearcherType() {
     d_text.release(); d_rev.release(); d_state.release(); d_pattern.release(); d_scratch.release();
     d_ops.release(); d_rowoff.release(); d_count.release(); d_cand.release(); d_trace.release();
     d_counters.release(); d_desc.release(); d_bitmap.release();
+    if (h_pin) (void)hipHostFree(h_pin);
     if (ev_f) (void)hipEventDestroy(ev_f);
     if (ev_a) (void)hipEventDestroy(ev_a);
     if (ev_b) (void)hipEventDestroy(ev_b);
@@ -343,6 +358,22 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     F.first_owned_block = first_owned - look;
     F.n_pieces = k + 1;
     F.piece_len = q;
+    F.piece_groups = F.n_pieces <= 4 ? 1u : F.n_pieces <= 8 ? 2u : 0u;
+    if (F.piece_groups) {
+      auto row_byte = [&](uint32_t r) { return (plan.row_tab[r >> 2] >> (8 * (r & 3))) & 0xFFu; };
+      for (uint32_t g = 0; g < F.piece_groups; ++g) {
+        for (uint32_t j = 0; j < 12; ++j) F.piece_tab[g][j] = 0;
+        F.piece_last[g] = 0;
+        for (uint32_t pp = 0; pp < 4; ++pp) {
+          uint32_t piece = 4 * g + pp;
+          if (piece >= F.n_pieces) piece = 0;  // a repeated piece changes nothing
+          for (uint32_t j = 0; j + 1 < q; ++j) F.piece_tab[g][j] |= row_byte(piece * q + j) << (8 * pp);
+          F.piece_last[g] |= row_byte(piece * q + q - 1) << (8 * pp);
+        }
+      }
+    }
+    static const int env_fsb = getenv("SASSY_HIP_FILTER_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_FILTER_STAGE_BLOCKS")) : 0;
+    F.stage_blocks = env_fsb == 1 || env_fsb == 2 ? (uint32_t)env_fsb : 2u;
     if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, 1, &fgrid)) return rc;
     F.lds_per_wave = 4096u * F.stage_blocks + 2u * bucket * 512u;
     n_words = (n_blocks + 63) / 64;
@@ -357,6 +388,12 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
   }
 
+  constexpr uint32_t kSpec = 4096;               // reports fetched speculatively with the counts
+  constexpr size_t kPinCounts = 0, kPinCounters = 64;
+  const size_t pin_cands = 128;
+  const size_t pin_recs = pin_cands + (size_t)kSpec * sizeof(Candidate);
+  const size_t pin_ops = pin_recs + (size_t)kSpec * sizeof(TraceRec);
+  if (int rc = S->reserve_pinned(pin_ops + (size_t)kSpec * (do_trace ? T.ops_stride : 0) + 64)) return rc;
   uint32_t counts[2] = {0, 0};
   uint32_t desc_cap = 0;
   for (int attempt = 0; attempt < 4; ++attempt) {
@@ -402,8 +439,20 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
       HIP_TRY(hipEventRecord(S->ev_c, S->stream));
     }
-    HIP_TRY(hipMemcpyAsync(counts, S->d_count.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream));
+    // one batch of async copies into pinned memory, then the only synchronisation of the call
+    {
+      unsigned char* hp = S->h_pin;
+      HIP_TRY(hipMemcpyAsync(hp + kPinCounts, S->d_count.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream));
+      HIP_TRY(hipMemcpyAsync(hp + kPinCounters, S->d_counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, S->stream));
+      const uint32_t spec = std::min<uint32_t>(kSpec, P.cand_cap);
+      HIP_TRY(hipMemcpyAsync(hp + pin_cands, S->d_cand.p, (size_t)spec * sizeof(Candidate), hipMemcpyDeviceToHost, S->stream));
+      if (do_trace) {
+        HIP_TRY(hipMemcpyAsync(hp + pin_recs, S->d_trace.p, (size_t)spec * sizeof(TraceRec), hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipMemcpyAsync(hp + pin_ops, S->d_ops.p, (size_t)spec * T.ops_stride, hipMemcpyDeviceToHost, S->stream));
+      }
+    }
     HIP_TRY(hipStreamSynchronize(S->stream));
+    memcpy(counts, S->h_pin + kPinCounts, sizeof counts);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_b));
     S->stats.scan_ms += ms;
@@ -438,8 +487,8 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   S->stats.filtered = filtered ? 1 : 0;
   S->stats.piece_len = q;
   {
-    unsigned long long c[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpy(c, S->d_counters.p, sizeof c, hipMemcpyDeviceToHost));
+    unsigned long long c[4];
+    memcpy(c, S->h_pin + kPinCounters, sizeof c);
     S->stats.word_rows += c[0];
     S->stats.blocks += c[1];
     S->stats.hit_blocks += c[2];
@@ -447,13 +496,21 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
 
   std::vector<Candidate> raw(count);
   if (count) {
-    HIP_TRY(hipMemcpy(raw.data(), S->d_cand.p, (size_t)count * sizeof(Candidate), hipMemcpyDeviceToHost));
+    const uint32_t have = std::min<uint32_t>(count, kSpec);
+    memcpy(raw.data(), S->h_pin + pin_cands, (size_t)have * sizeof(Candidate));
+    if (count > have)
+      HIP_TRY(hipMemcpy(raw.data() + have, S->d_cand.p + have, (size_t)(count - have) * sizeof(Candidate), hipMemcpyDeviceToHost));
     if (do_trace) {
       out.recs.resize(count);
       out.ops_stride = T.ops_stride;
       out.ops.resize((size_t)count * T.ops_stride);
-      HIP_TRY(hipMemcpy(out.recs.data(), S->d_trace.p, (size_t)count * sizeof(TraceRec), hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(out.ops.data(), S->d_ops.p, out.ops.size(), hipMemcpyDeviceToHost));
+      memcpy(out.recs.data(), S->h_pin + pin_recs, (size_t)have * sizeof(TraceRec));
+      memcpy(out.ops.data(), S->h_pin + pin_ops, (size_t)have * T.ops_stride);
+      if (count > have) {
+        HIP_TRY(hipMemcpy(out.recs.data() + have, S->d_trace.p + have, (size_t)(count - have) * sizeof(TraceRec), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out.ops.data() + (size_t)have * T.ops_stride, S->d_ops.p + (size_t)have * T.ops_stride,
+                          (size_t)(count - have) * T.ops_stride, hipMemcpyDeviceToHost));
+      }
     }
   }
   // the atomic append leaves the reports in arbitrary order: sort by end position

@@ -540,7 +540,9 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
 // shifted in from the previous block's masks, and records the blocks in which some piece ends.
 // Blocks far from every recorded block cannot hold a cell <= k and never see the DP.
 // (The piece test uses the same slot masks as the scan, so it is exact for every profile.)
-template <int PROFILE, int NS, int SB>
+// NPG: 0 = any number of pieces (row table in LDS), 1 / 2 = up to 4 / 8 pieces with the row table
+// in scalar registers and all pieces advanced side by side (independent chains hide LDS latency).
+template <int PROFILE, int NS, int SB, int NPG>
 __global__ __launch_bounds__(256) void filter_kernel(const ScanParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr uint32_t kRowBytes = 64u * SB;
@@ -638,21 +640,55 @@ __global__ __launch_bounds__(256) void filter_kernel(const ScanParams P) {
     uint32_t hl = 0, hh = 0;
     const unsigned char* curl = cur + lane * 8;
     const unsigned char* prvl = prv + lane * 8;
-    uint32_t t = 0;
-    for (uint32_t p = 0; p < P.n_pieces; ++p) {
-      uint32_t sl = 0xFFFFFFFFu, sh = 0xFFFFFFFFu;
-      for (uint32_t j = 0; j + 1 < q; ++j, ++t) {
-        const uint32_t off = term_off[t];
-        const uint2 c = *reinterpret_cast<const uint2*>(curl + off);
-        const uint2 pv = *reinterpret_cast<const uint2*>(prvl + off);
-        const uint32_t sr = 32u - (q - 1u - j);  // shift left by q-1-j as a funnel shift right
-        sl &= __builtin_amdgcn_alignbit(c.x, pv.y, sr);
-        sh &= __builtin_amdgcn_alignbit(c.y, c.x, sr);
+    if constexpr (NPG > 0) {
+      uint32_t sl[4 * NPG], sh[4 * NPG];
+#pragma unroll
+      for (int i = 0; i < 4 * NPG; ++i) { sl[i] = 0xFFFFFFFFu; sh[i] = 0xFFFFFFFFu; }
+#pragma unroll
+      for (int j = 0; j < 11; ++j) {
+        if ((uint32_t)j + 1u < q) {                      // wave-uniform
+          const uint32_t sr = 32u - (q - 1u - (uint32_t)j);  // shift left by q-1-j as a funnel shift right
+#pragma unroll
+          for (int g = 0; g < NPG; ++g) {
+            const uint32_t w = P.piece_tab[g][j];
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+              const uint32_t off = ((w >> (8 * pp)) & 0xFFu) << 8;
+              const uint2 c = *reinterpret_cast<const uint2*>(curl + off);
+              const uint2 pv = *reinterpret_cast<const uint2*>(prvl + off);
+              sl[4 * g + pp] &= __builtin_amdgcn_alignbit(c.x, pv.y, sr);
+              sh[4 * g + pp] &= __builtin_amdgcn_alignbit(c.y, c.x, sr);
+            }
+          }
+        }
       }
-      const uint2 c = *reinterpret_cast<const uint2*>(curl + term_off[t]);  // last row of the piece: no shift
-      ++t;
-      hl |= sl & c.x;
-      hh |= sh & c.y;
+#pragma unroll
+      for (int g = 0; g < NPG; ++g) {
+        const uint32_t w = P.piece_last[g];
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+          const uint2 c = *reinterpret_cast<const uint2*>(curl + (((w >> (8 * pp)) & 0xFFu) << 8));
+          hl |= sl[4 * g + pp] & c.x;
+          hh |= sh[4 * g + pp] & c.y;
+        }
+      }
+    } else {
+      uint32_t t = 0;
+      for (uint32_t p = 0; p < P.n_pieces; ++p) {
+        uint32_t sl = 0xFFFFFFFFu, sh = 0xFFFFFFFFu;
+        for (uint32_t j = 0; j + 1 < q; ++j, ++t) {
+          const uint32_t off = term_off[t];
+          const uint2 c = *reinterpret_cast<const uint2*>(curl + off);
+          const uint2 pv = *reinterpret_cast<const uint2*>(prvl + off);
+          const uint32_t sr = 32u - (q - 1u - j);
+          sl &= __builtin_amdgcn_alignbit(c.x, pv.y, sr);
+          sh &= __builtin_amdgcn_alignbit(c.y, c.x, sr);
+        }
+        const uint2 c = *reinterpret_cast<const uint2*>(curl + term_off[t]);  // last row of the piece: no shift
+        ++t;
+        hl |= sl & c.x;
+        hh |= sh & c.y;
+      }
     }
     const uint64_t b = blk0 + it;
     const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
@@ -661,7 +697,10 @@ __global__ __launch_bounds__(256) void filter_kernel(const ScanParams P) {
       nhits += 1;
     }
   }
-  if (nhits) atomicAdd(P.hit_count, nhits);
+  // one atomic per wave
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) nhits += __shfl_xor(nhits, d);
+  if (lane == 0 && nhits) atomicAdd(P.hit_count, nhits);
 }
 
 // ====================================================================== K1-list: DP over a chunk list
@@ -798,17 +837,23 @@ static hipError_t launch_one(const ScanParams& P, uint32_t grid, size_t smem, hi
                              : launch_sb<PROFILE, NS, 2>(P, grid, smem, stream);
 }
 
-template <int PROFILE, int NS, int SB>
-static hipError_t launch_filter_sb(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+template <int PROFILE, int NS, int SB, int NPG>
+static hipError_t launch_filter_npg(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_kernel<PROFILE, NS, SB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_kernel<PROFILE, NS, SB, NPG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((filter_kernel<PROFILE, NS, SB>), dim3(grid), dim3(256), smem, stream, P);
+  hipLaunchKernelGGL((filter_kernel<PROFILE, NS, SB, NPG>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
+}
+template <int PROFILE, int NS, int SB>
+static hipError_t launch_filter_sb(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  if (P.piece_groups == 1) return launch_filter_npg<PROFILE, NS, SB, 1>(P, grid, smem, stream);
+  if (P.piece_groups == 2) return launch_filter_npg<PROFILE, NS, SB, 2>(P, grid, smem, stream);
+  return launch_filter_npg<PROFILE, NS, SB, 0>(P, grid, smem, stream);
 }
 template <int PROFILE, int NS>
 static hipError_t launch_filter_one(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {

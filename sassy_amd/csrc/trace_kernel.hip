@@ -32,8 +32,11 @@ __device__ __forceinline__ bool d_is_match(uint32_t pr, uint32_t p, uint32_t t) 
   return p == t;
 }
 
-template <typename Cell>
+// IN_LDS: the band of every thread of the block fits into LDS (64 * scratch_stride bytes of dynamic
+// shared memory) -- the usual case; otherwise it lives in a global scratch slice.
+template <typename Cell, bool IN_LDS>
 __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char trace_smem[];
   const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t nthreads = gridDim.x * blockDim.x;
   uint32_t count = *P.cand_count;
@@ -41,7 +44,8 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
   const long m = (long)P.m, k = (long)P.k;
   const long bw = 2 * k + 3;
   const int inf = (int)k + 1;
-  Cell* L = reinterpret_cast<Cell*>(P.scratch + (uint64_t)tid * P.scratch_stride);
+  Cell* L = IN_LDS ? reinterpret_cast<Cell*>(trace_smem + (size_t)threadIdx.x * P.scratch_stride)
+                   : reinterpret_cast<Cell*>(P.scratch + (uint64_t)tid * P.scratch_stride);
 
   for (uint32_t c = tid; c < count; c += nthreads) {
     const uint64_t e = P.cand[c].pos;                 // global end position
@@ -110,10 +114,15 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
 }
 
 hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stream) {
-  if (P.k + 1 <= 255)
-    hipLaunchKernelGGL(trace_kernel<uint8_t>, dim3(nblocks), dim3(64), 0, stream, P);
-  else
-    hipLaunchKernelGGL(trace_kernel<uint16_t>, dim3(nblocks), dim3(64), 0, stream, P);
+  const size_t lds = (size_t)64 * P.scratch_stride;
+  const bool in_lds = lds <= 64 * 1024;
+  if (P.k + 1 <= 255) {
+    if (in_lds) hipLaunchKernelGGL((trace_kernel<uint8_t, true>), dim3(nblocks), dim3(64), lds, stream, P);
+    else hipLaunchKernelGGL((trace_kernel<uint8_t, false>), dim3(nblocks), dim3(64), 0, stream, P);
+  } else {
+    if (in_lds) hipLaunchKernelGGL((trace_kernel<uint16_t, true>), dim3(nblocks), dim3(64), lds, stream, P);
+    else hipLaunchKernelGGL((trace_kernel<uint16_t, false>), dim3(nblocks), dim3(64), 0, stream, P);
+  }
   return hipGetLastError();
 }
 

@@ -21,13 +21,15 @@ for f in find("*kernel_stats.csv"):
             print(f"{name:60s} calls={row.get('Calls')} avg_ns={row.get('AverageNs')} "
                   f"min_ns={row.get('MinNs')} max_ns={row.get('MaxNs')} pct={row.get('Percentage')}")
 
-print("== PMC (average per dispatch of kernels whose name contains 'scan_kernel') ==")
+print("== PMC (average per dispatch, kernels scan_kernel / filter_kernel / list_kernel) ==")
 for f in find("*counter_collection.csv"):
     acc = defaultdict(list)
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            if "scan_kernel" not in row.get("Kernel_Name", ""):
+            kn = row.get("Kernel_Name", "")
+            short = next((x for x in ("scan_kernel", "filter_kernel", "list_kernel") if x in kn), None)
+            if short is None:
                 continue
-            acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-    for k, v in sorted(acc.items()):
-        print(f"{os.path.basename(os.path.dirname(os.path.dirname(f)))}: {k} avg={sum(v) / len(v):.6g} n={len(v)}")
+            acc[(short, row["Counter_Name"])].append(float(row["Counter_Value"]))
+    for (kn, k), v in sorted(acc.items()):
+        print(f"{kn}: {k} avg={sum(v) / len(v):.6g} n={len(v)}")
