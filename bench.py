@@ -153,9 +153,10 @@ def main():
         # one full search of the resident shard; Match records arrive on the host as one packed
         # array (include/sassy_hip.h: sassy_hip_Match + cigar pool), for N > 1 gathered to rank 0
         r = searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
-        local = multigpu.pack_result(r)
         if world == 1:
-            return multigpu.merge_shard_results([local]), searcher.stats()
+            # the records are already on the host in their final form (r.array + r.pool)
+            return r, searcher.stats()
+        local = multigpu.pack_result(r)
         shards = multigpu.gather_shard_results(local, torch, dist, device)
         merged = multigpu.merge_shard_results(shards) if rank == 0 else None
         return merged, searcher.stats()
@@ -169,12 +170,17 @@ def main():
         step()
     sync()
     t0 = time.perf_counter()
-    scan_ms, trace_ms, filter_ms, matches, st = 0.0, 0.0, 0.0, None, None
+    scan_ms, trace_ms, filter_ms, call_ms, matches, st = 0.0, 0.0, 0.0, 0.0, None, None
+    host = [0.0, 0.0, 0.0]
     for _ in range(args.steps):
         matches, st = step()
+        host[0] += st["host_enqueue_ms"]
+        host[1] += st["host_wait_ms"]
+        host[2] += st["host_post_ms"]
         scan_ms += st["scan_ms"]
         trace_ms += st["trace_ms"]
         filter_ms += st["filter_ms"]
+        call_ms += st["total_ms"]
     sync()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed, scan_ms / max(1, args.steps), filter_ms / max(1, args.steps)],
@@ -236,6 +242,9 @@ def main():
         "prefilter": {"enabled": filtered, "piece_len": st["piece_len"], "hit_blocks": st["hit_blocks"],
                       "chunks": st["chunks"]},
         "trace_ms_per_step": round(trace_ms / args.steps, 4),
+        "host_ms_per_step": {"enqueue": round(host[0] / args.steps, 4), "wait": round(host[1] / args.steps, 4),
+                             "post": round(host[2] / args.steps, 4)},
+        "c_abi_call_ms_per_step": round(call_ms / args.steps, 4),
         "roofline": {
             "bound": "hbm",
             "achieved": round(achieved, 1),
@@ -249,7 +258,7 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         host = buf[:n_per].cpu().numpy()
-        gpu_ends = [(int(r[2]), int(r[5])) for r in matches]
+        gpu_ends = [(int(e), int(c)) for e, c in zip(matches.array["text_end"], matches.array["cost"])]
         out["cpu_baseline"] = cpu_baseline(host, pat, k, args.profile, gpu_ends, args.cpu_passes)
     print(json.dumps(out), flush=True)
     if dist is not None:

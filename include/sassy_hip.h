@@ -66,6 +66,9 @@ typedef struct sassy_hip_Stats {
   uint64_t hit_blocks;   /* text blocks in which an exact pattern piece ends */
   uint32_t piece_len;    /* rows per pattern piece (k+1 pieces), 0 when unfiltered */
   uint32_t pad_;
+  double host_enqueue_ms; /* host wall time spent queueing work on the stream */
+  double host_wait_ms;    /* host wall time blocked in the stream synchronisation */
+  double host_post_ms;    /* host wall time after it: sort, seams, cigar strings, result records */
 } sassy_hip_Stats;
 
 const char *sassy_hip_last_error(void);

@@ -84,6 +84,9 @@ class Stats(C.Structure):
         ("hit_blocks", C.c_uint64),
         ("piece_len", C.c_uint32),
         ("pad_", C.c_uint32),
+        ("host_enqueue_ms", C.c_double),
+        ("host_wait_ms", C.c_double),
+        ("host_post_ms", C.c_double),
     ]
 
     def as_dict(self):

@@ -116,8 +116,12 @@ struct sassy_SearcherType {
   bool own_stream = false;
   bool device_ready = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_f = nullptr;
-  DevBuf<uint8_t> d_text, d_rev, d_state, d_pattern, d_scratch, d_ops;
-  DevBuf<uint32_t> d_rowoff, d_count;
+  DevBuf<uint8_t> d_text, d_rev, d_state, d_pattern, d_scratch, d_ops, d_ctl;
+  DevBuf<uint32_t> d_rowoff;
+  // what d_rowoff / d_pattern currently hold (uploads are skipped when the pattern repeats)
+  std::vector<uint8_t> up_pattern;
+  std::vector<uint32_t> up_rowtab;
+  int up_profile = -1;
   DevBuf<Candidate> d_cand;
   DevBuf<TraceRec> d_trace;
   DevBuf<ChunkDesc> d_desc;
@@ -141,7 +145,7 @@ struct sassy_SearcherType {
 
   ~sassy_SearcherType() {
     d_text.release(); d_rev.release(); d_state.release(); d_pattern.release(); d_scratch.release();
-    d_ops.release(); d_rowoff.release(); d_count.release(); d_cand.release(); d_trace.release();
+    d_ops.release(); d_rowoff.release(); d_ctl.release(); d_cand.release(); d_trace.release();
     d_counters.release(); d_desc.release(); d_bitmap.release();
     if (h_pin) (void)hipHostFree(h_pin);
     if (ev_f) (void)hipEventDestroy(ev_f);
@@ -175,13 +179,37 @@ namespace sassy_hip {
 
 // pa_types::Cigar::to_string: run-length encoded "<count><op>" (SURVEY 8c).  `ops` holds one
 // char per alignment column in end -> start order (as the device traceback writes them).
+static double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// SASSY_HIP_DEBUG_TIMING=1: print host-side phase marks of every call to stderr
+struct PhaseMarks {
+  bool on = getenv("SASSY_HIP_DEBUG_TIMING") != nullptr;
+  double last = 0;
+  void start() { if (on) last = now_ms(); }
+  void mark(const char* what) {
+    if (!on) return;
+    const double t = now_ms();
+    fprintf(stderr, "[sassy-hip] %-18s %8.1f us\n", what, (t - last) * 1e3);
+    last = t;
+  }
+};
+static PhaseMarks g_marks;
+
 static std::string rle_reversed(const uint8_t* ops, size_t n) {
   std::string s;
+  s.reserve(24);
   size_t i = n;
   while (i > 0) {
     size_t j = i;
     while (j > 0 && ops[j - 1] == ops[i - 1]) --j;
-    s += std::to_string(i - j);
+    size_t run = i - j;
+    char digits[24];
+    int nd = 0;
+    do { digits[nd++] = (char)('0' + run % 10); run /= 10; } while (run);
+    while (nd) s.push_back(digits[--nd]);
     s.push_back((char)ops[i - 1]);
     i = j;
   }
@@ -271,6 +299,7 @@ static int stream_geometry(ScanParams& P, uint64_t owned, uint32_t extra_front, 
 // selective pieces -- prefilter (K0) -> chunk list (K0b) -> DP over the listed chunks (K1-list).
 static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPlan& plan, uint32_t k,
                     bool all_minima, const uint8_t* pat, bool do_trace, uint64_t total_len, ScanOut& out) {
+  const double t_enter = now_ms();
   out = ScanOut();
   const uint64_t n_blocks = (sh.text_len + 63) / 64;
   const uint64_t first_owned = sh.halo_len / 64;
@@ -299,17 +328,32 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   const uint32_t q = filter_piece_len(plan, k);
   const bool filtered = q > 0;
 
+  // pattern-dependent device data is uploaded only when the pattern changed since the last call
   if (int rc = S->d_rowoff.reserve(plan.row_tab.size())) return rc;
-  HIP_TRY(hipMemcpyAsync(S->d_rowoff.p, plan.row_tab.data(), plan.row_tab.size() * sizeof(uint32_t),
-                         hipMemcpyHostToDevice, S->stream));
-  if (int rc = S->d_count.reserve(16)) return rc;   // [0] candidates, [1] descriptors
+  if (int rc = S->d_pattern.reserve(plan.m)) return rc;
+  {
+    const bool same = S->up_profile == (int)S->profile && S->up_pattern.size() == plan.m &&
+                      memcmp(S->up_pattern.data(), pat, plan.m) == 0 && S->up_rowtab == plan.row_tab;
+    if (!same) {
+      S->up_pattern.assign(pat, pat + plan.m);
+      S->up_rowtab = plan.row_tab;
+      S->up_profile = (int)S->profile;
+      // the sources must stay valid until the copies ran: use the searcher-owned copies
+      HIP_TRY(hipMemcpyAsync(S->d_rowoff.p, S->up_rowtab.data(), S->up_rowtab.size() * sizeof(uint32_t),
+                             hipMemcpyHostToDevice, S->stream));
+      HIP_TRY(hipMemcpyAsync(S->d_pattern.p, S->up_pattern.data(), plan.m, hipMemcpyHostToDevice, S->stream));
+    }
+  }
+  // control block: [0] candidates, [1] descriptors (u32) | +16 B: counters [0] word rows
+  // [1] blocks [2] hit blocks (u64): one memset, one copy back
+  if (int rc = S->d_ctl.reserve(64)) return rc;
   if (S->d_cand.cap == 0)
     if (int rc = S->d_cand.reserve(1u << 16)) return rc;
-  if (int rc = S->d_counters.reserve(4)) return rc;   // [0] word rows [1] blocks [2] hit blocks
-  HIP_TRY(hipMemsetAsync(S->d_counters.p, 0, 4 * sizeof(unsigned long long), S->stream));
+  uint32_t* d_counts = reinterpret_cast<uint32_t*>(S->d_ctl.p);
+  unsigned long long* d_counters = reinterpret_cast<unsigned long long*>(S->d_ctl.p + 16);
   P.row_tab = S->d_rowoff.p;
-  P.cand_count = S->d_count.p;
-  P.counters = S->want_counters ? S->d_counters.p : nullptr;
+  P.cand_count = d_counts;
+  P.counters = S->want_counters ? d_counters : nullptr;
 
   // device traceback (K3) runs right behind the scan on the same stream: one host sync per strand
   TraceParams T{};
@@ -322,12 +366,10 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     nthreads = std::max<uint64_t>(64, std::min<uint64_t>(16384, nthreads)) / 64 * 64;
     trace_blocks = (uint32_t)(nthreads / 64);
     if (int rc = S->d_scratch.reserve(nthreads * stride)) return rc;
-    if (int rc = S->d_pattern.reserve(plan.m)) return rc;
-    HIP_TRY(hipMemcpyAsync(S->d_pattern.p, pat, plan.m, hipMemcpyHostToDevice, S->stream));
     T.text = sh.d_text;
     T.global_offset = sh.global_offset;
     T.total_len = total_len;
-    T.cand_count = S->d_count.p;
+    T.cand_count = d_counts;
     T.m = plan.m;
     T.k = k;
     T.profile = (uint32_t)S->profile;
@@ -379,7 +421,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     n_words = (n_blocks + 63) / 64;
     if (int rc = S->d_bitmap.reserve(n_words + 2)) return rc;
     F.hit_bitmap = S->d_bitmap.p;
-    F.hit_count = S->d_counters.p + 2;
+    F.hit_count = d_counters + 2;
     HIP_TRY(hipMemsetAsync(S->d_bitmap.p, 0, (n_words + 2) * sizeof(unsigned long long), S->stream));
     if (S->d_desc.cap == 0)
       if (int rc = S->d_desc.reserve(1u << 18)) return rc;
@@ -388,8 +430,9 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
   }
 
+  double t_mark = t_enter;
   constexpr uint32_t kSpec = 4096;               // reports fetched speculatively with the counts
-  constexpr size_t kPinCounts = 0, kPinCounters = 64;
+  constexpr size_t kPinCounts = 0, kPinCounters = 16;
   const size_t pin_cands = 128;
   const size_t pin_recs = pin_cands + (size_t)kSpec * sizeof(Candidate);
   const size_t pin_ops = pin_recs + (size_t)kSpec * sizeof(TraceRec);
@@ -407,7 +450,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       T.out = S->d_trace.p;
       T.out_ops = S->d_ops.p;
     }
-    HIP_TRY(hipMemsetAsync(S->d_count.p, 0, 2 * sizeof(uint32_t), S->stream));
+    HIP_TRY(hipMemsetAsync(S->d_ctl.p, 0, attempt == 0 ? 64 : 16, S->stream));
     HIP_TRY(hipEventRecord(S->ev_a, S->stream));
     hipError_t le;
     if (!filtered) {
@@ -423,10 +466,10 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       if (int rc = S->d_state.reserve(desc_cap)) return rc;
       P.chunk_state = S->d_state.p;
       le = launch_build_chunks(S->d_bitmap.p, n_words, n_blocks, first_owned, P.wb, P.wb, maxlen, S->d_desc.p,
-                               S->d_count.p + 1, desc_cap, S->stream);
+                               d_counts + 1, desc_cap, S->stream);
       if (le != hipSuccess) return hip_fail(le, "chunk builder launch");
       P.desc = S->d_desc.p;
-      P.desc_count = S->d_count.p + 1;
+      P.desc_count = d_counts + 1;
       P.desc_cap = desc_cap;
       // the descriptor count lives on the device: launch for the capacity, idle waves exit at once
       const uint32_t lgrid = (desc_cap + 255) / 256;
@@ -442,8 +485,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     // one batch of async copies into pinned memory, then the only synchronisation of the call
     {
       unsigned char* hp = S->h_pin;
-      HIP_TRY(hipMemcpyAsync(hp + kPinCounts, S->d_count.p, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream));
-      HIP_TRY(hipMemcpyAsync(hp + kPinCounters, S->d_counters.p, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, S->stream));
+      HIP_TRY(hipMemcpyAsync(hp + kPinCounts, S->d_ctl.p, 64, hipMemcpyDeviceToHost, S->stream));
       const uint32_t spec = std::min<uint32_t>(kSpec, P.cand_cap);
       HIP_TRY(hipMemcpyAsync(hp + pin_cands, S->d_cand.p, (size_t)spec * sizeof(Candidate), hipMemcpyDeviceToHost, S->stream));
       if (do_trace) {
@@ -451,7 +493,13 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
         HIP_TRY(hipMemcpyAsync(hp + pin_ops, S->d_ops.p, (size_t)spec * T.ops_stride, hipMemcpyDeviceToHost, S->stream));
       }
     }
+    const double t_sync0 = now_ms();
     HIP_TRY(hipStreamSynchronize(S->stream));
+    const double t_sync1 = now_ms();
+    S->stats.host_enqueue_ms += t_sync0 - t_mark;
+    S->stats.host_wait_ms += t_sync1 - t_sync0;
+    t_mark = t_sync1;
+    g_marks.start();
     memcpy(counts, S->h_pin + kPinCounts, sizeof counts);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_b));
@@ -465,6 +513,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       HIP_TRY(hipEventElapsedTime(&ms, S->ev_b, S->ev_c));
       S->stats.trace_ms += ms;
     }
+    g_marks.mark("event times");
     bool again = false;
     if (filtered && counts[1] > desc_cap) {  // more chunks than descriptors fit: grow, rebuild
       if (int rc = S->d_desc.reserve((size_t)counts[1] + 1024)) return rc;
@@ -513,6 +562,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       }
     }
   }
+  g_marks.mark("copy out");
   // the atomic append leaves the reports in arbitrary order: sort by end position
   std::vector<uint32_t> order(count);
   for (uint32_t i = 0; i < count; ++i) order[i] = i;
@@ -521,6 +571,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   out.slot.resize(count);
   for (uint32_t i = 0; i < count; ++i) { out.cands[i] = raw[order[i]]; out.slot[i] = order[i]; }
   S->stats.candidates += count;
+  g_marks.mark("sort");
 
   // ---- seams: reports that depend on how a plateau was entered left of their chunk ----
   bool any_cond = false;
@@ -607,6 +658,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     }
   }
   S->stats.cond_resolved += out.cond_seen;
+  g_marks.mark("seams");
   return 0;
 }
 
@@ -658,11 +710,6 @@ static void finish_result(const std::vector<MatchRec>& recs, sassy_hip_Result* R
     R->pool.push_back('\0');
     R->matches.push_back(m);
   }
-}
-
-static double now_ms() {
-  using namespace std::chrono;
-  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
 // Searcher::search / search_all on one text (reference: src/search.rs:510-525, 685-700, 787-881).
@@ -823,6 +870,7 @@ int sassy_hip_search(sassy_SearcherType* s, const uint8_t* pattern, size_t patte
   sassy_hip_Result* R = new sassy_hip_Result();
   finish_result(recs, R);
   s->stats.total_ms = now_ms() - t0;
+  s->stats.host_post_ms = s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms;
   *out = R;
   return 0;
 }
@@ -863,11 +911,14 @@ int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t
                           total_len, so)) { delete R; return rc; }
     std::vector<MatchRec> recs;
     if (int rc = trace_reports(so, total_len, plan, wo, recs)) { delete R; return rc; }
+    g_marks.mark("trace_reports");
     finish_result(recs, R);
+    g_marks.mark("finish_result");
     R->exit_state = so.exit_state;
     R->conditional_index = so.conditional_index;
   }
   s->stats.total_ms = now_ms() - t0;
+  s->stats.host_post_ms = s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms;
   *out = R;
   return 0;
 }
@@ -973,6 +1024,7 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
   sassy_hip_Result* R = new sassy_hip_Result();
   finish_result(recs, R);
   s->stats.total_ms = now_ms() - t0;
+  s->stats.host_post_ms = s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms;
   *out = R;
   return 0;
 }
