@@ -206,7 +206,11 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("scan_kernel_hbm_bytes_per_launch")
+            # measured by tools/prof.sh (rocprofv3 PMC, separate passes) for this same workload;
+            # only valid for the text size it was taken at
+            t = json.load(open(tpath))
+            if t.get("text_bytes_per_gpu") == n_per:
+                traffic = t.get("kernels", {}).get(dom_name, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
     out = {
