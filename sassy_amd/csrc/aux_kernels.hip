@@ -192,7 +192,64 @@ __global__ __launch_bounds__(256) void build_chunks_kernel(const BuildParams P) 
   }
 }
 
+// ------------------------------------------------------------------ report ranking
+// The scan kernels append reports with an atomic counter, i.e. in arbitrary order; the result
+// order is by end position (reference: matches of one strand come out by increasing end,
+// src/search.rs:1180-1199).  Reports are few (thousands): every report counts the reports that
+// precede it.  The count^2 comparisons are spread over the chip as (256 reports) x (256 others)
+// tiles, one workgroup per tile, partial ranks added with one atomic per report and tile; a
+// second pass moves every report to its rank.  Above kRankLimit the host sorts instead.
+__global__ __launch_bounds__(256) void rank_count_kernel(const Candidate* __restrict__ cand,
+                                                         const uint32_t* __restrict__ count_p, uint32_t cap,
+                                                         uint32_t* __restrict__ rank) {
+  __shared__ uint64_t tile[256];
+  uint32_t count = *count_p;
+  if (count > cap) count = cap;
+  if (count > kRankLimit) return;
+  const uint32_t nb = (count + 255) / 256;
+  const uint32_t npairs = nb * nb;
+  for (uint32_t p = blockIdx.x; p < npairs; p += gridDim.x) {
+    const uint32_t cb = p / nb, sb = p - cb * nb;
+    const uint32_t c = cb * 256 + threadIdx.x;
+    const uint64_t mine = c < count ? cand[c].pos : ~0ull;
+    const uint32_t x0 = sb * 256;
+    __syncthreads();
+    tile[threadIdx.x] = x0 + threadIdx.x < count ? cand[x0 + threadIdx.x].pos : ~0ull;
+    __syncthreads();
+    uint32_t r = 0;
+    // every lane reads the same LDS word (broadcast); the ~0 padding never precedes a report
+#pragma unroll 8
+    for (uint32_t x = 0; x < 256; ++x) {
+      const uint64_t q = tile[x];
+      r += (q < mine || (q == mine && x0 + x < c)) ? 1u : 0u;
+    }
+    if (c < count && r) atomicAdd(&rank[c], r);
+  }
+}
+
+__global__ __launch_bounds__(256) void rank_scatter_kernel(const Candidate* __restrict__ cand,
+                                                           const uint32_t* __restrict__ count_p, uint32_t cap,
+                                                           const uint32_t* __restrict__ rank,
+                                                           Candidate* __restrict__ sorted) {
+  uint32_t count = *count_p;
+  if (count > cap) count = cap;
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= count) return;
+  sorted[count > kRankLimit ? c : rank[c]] = cand[c];
+}
+
 // ------------------------------------------------------------------ launchers
+// d_rank: cap zeroed counters (zeroed by the caller together with its control block).
+hipError_t launch_rank(const Candidate* d_cand, const uint32_t* d_count, uint32_t cap, uint32_t* d_rank,
+                       Candidate* d_sorted, hipStream_t stream) {
+  if (cap == 0) return hipSuccess;
+  // the count lives on the device: fixed grid, surplus workgroups exit at once
+  hipLaunchKernelGGL(rank_count_kernel, dim3(1024), dim3(256), 0, stream, d_cand, d_count, cap, d_rank);
+  hipLaunchKernelGGL(rank_scatter_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, d_cand, d_count, cap,
+                     d_rank, d_sorted);
+  return hipGetLastError();
+}
+
 hipError_t launch_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first,
                                hipStream_t stream) {
   if (n == 0) return hipSuccess;

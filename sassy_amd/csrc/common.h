@@ -81,31 +81,41 @@ struct ScanParams {
   uint8_t slot_val[kMaxSlots]; // per slot: Dna 2-bit code, Iupac base-set nibble, Ascii byte
 };
 
-// One traced report (device traceback kernel output).  32 bytes.
-struct TraceRec {
-  uint64_t text_start;
-  uint64_t text_end;
+// A finished match record as the trace kernel writes it; same layout as sassy_hip_Match
+// (include/sassy_hip.h).  64 bytes.
+struct MatchOut {
+  uint64_t pattern_idx, text_idx;
+  uint64_t text_start, text_end, pattern_start, pattern_end;
   int32_t cost;
-  uint32_t nops;  // alignment columns written to the ops buffer (end -> start order)
-  uint32_t ok;    // 0: no ancestor found / cost mismatch (the reference would panic)
-  uint32_t cand;  // index of the candidate this record belongs to
+  uint8_t strand;
+  uint8_t pad_[3];
+  uint32_t cigar_off;  // = record index * str_stride: the string slots double as the cigar pool
+  uint32_t cigar_len;
 };
+
+// Reports are ranked (sorted by end position) on the device up to this many; beyond it the host sorts.
+constexpr uint32_t kRankLimit = 32768;
+// The trace kernel keeps its 64 per-thread slices (+ the pattern) in LDS up to this many bytes.
+constexpr uint32_t kTraceLdsLimit = 128 * 1024;
 
 struct TraceParams {
   const uint8_t* text;      // device buffer the candidates refer to
   uint64_t global_offset;   // global position of text[0]
   uint64_t total_len;       // length of the whole text (window end is clipped to it)
-  const Candidate* cand;
+  const Candidate* cand;    // reports in output order (ranked by rank_kernel)
   const uint32_t* cand_count;
   uint32_t cand_cap;
   uint32_t m, k;
   uint32_t profile;
   const uint8_t* pattern;   // device copy of the (strand-specific) pattern
-  uint8_t* scratch;         // nthreads * scratch_stride bytes
-  uint32_t scratch_stride;  // bytes per thread: (m+1) * (2k+3) * sizeof(cell)
-  TraceRec* out;            // cand_cap records
-  uint8_t* out_ops;         // cand_cap * ops_stride bytes
-  uint32_t ops_stride;      // >= m + k + 1
+  uint8_t* scratch;         // nthreads * scratch_stride bytes (used when the slices do not fit LDS)
+  uint32_t scratch_stride;  // bytes per thread: band | window | ops
+  uint32_t band_bytes;      // (m+1) * (2k+3) * sizeof(cell), rounded up to 4
+  uint32_t win_bytes;       // m+k rounded up to 4
+  MatchOut* out;            // cand_cap records
+  uint8_t* out_str;         // cand_cap * str_stride bytes: NUL-terminated cigar text per record
+  uint32_t str_stride;      // >= 2*(m+k+1) + 2
+  uint32_t* fail_count;     // device counter: reports whose traceback found no ancestor
 };
 
 }  // namespace sassy_hip

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -41,6 +42,8 @@ hipError_t launch_scatter_bytes(uint8_t* d_text, uint64_t n, uint64_t first, con
                                 const uint8_t* d_val, uint64_t count, hipStream_t stream);
 hipError_t launch_reverse(const uint8_t* d_in, uint8_t* d_out, uint64_t n, hipStream_t stream);
 hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stream);
+hipError_t launch_rank(const Candidate* d_cand, const uint32_t* d_count, uint32_t cap, uint32_t* d_rank,
+                       Candidate* d_sorted, hipStream_t stream);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -79,14 +82,6 @@ struct DevBuf {
   }
 };
 
-struct MatchRec {
-  uint64_t pattern_idx = 0, text_idx = 0;
-  uint64_t text_start = 0, text_end = 0, pattern_start = 0, pattern_end = 0;
-  int32_t cost = 0;
-  uint8_t strand = 0;
-  std::string cigar;  // SAM text, e.g. "3=1X"
-};
-
 }  // namespace sassy_hip
 
 using namespace sassy_hip;
@@ -116,14 +111,14 @@ struct sassy_SearcherType {
   bool own_stream = false;
   bool device_ready = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_f = nullptr;
-  DevBuf<uint8_t> d_text, d_rev, d_state, d_pattern, d_scratch, d_ops, d_ctl;
+  DevBuf<uint8_t> d_text, d_rev, d_state, d_pattern, d_scratch, d_str, d_ctl;
   DevBuf<uint32_t> d_rowoff;
   // what d_rowoff / d_pattern currently hold (uploads are skipped when the pattern repeats)
   std::vector<uint8_t> up_pattern;
   std::vector<uint32_t> up_rowtab;
   int up_profile = -1;
-  DevBuf<Candidate> d_cand;
-  DevBuf<TraceRec> d_trace;
+  DevBuf<Candidate> d_cand, d_sorted;
+  DevBuf<MatchOut> d_trace;
   DevBuf<ChunkDesc> d_desc;
   DevBuf<unsigned long long> d_counters, d_bitmap;
   bool want_counters = false;
@@ -145,7 +140,8 @@ struct sassy_SearcherType {
 
   ~sassy_SearcherType() {
     d_text.release(); d_rev.release(); d_state.release(); d_pattern.release(); d_scratch.release();
-    d_ops.release(); d_rowoff.release(); d_ctl.release(); d_cand.release(); d_trace.release();
+    d_str.release(); d_rowoff.release(); d_ctl.release(); d_cand.release(); d_sorted.release();
+    d_trace.release();
     d_counters.release(); d_desc.release(); d_bitmap.release();
     if (h_pin) (void)hipHostFree(h_pin);
     if (ev_f) (void)hipEventDestroy(ev_f);
@@ -198,24 +194,6 @@ struct PhaseMarks {
 };
 static PhaseMarks g_marks;
 
-static std::string rle_reversed(const uint8_t* ops, size_t n) {
-  std::string s;
-  s.reserve(24);
-  size_t i = n;
-  while (i > 0) {
-    size_t j = i;
-    while (j > 0 && ops[j - 1] == ops[i - 1]) --j;
-    size_t run = i - j;
-    char digits[24];
-    int nd = 0;
-    do { digits[nd++] = (char)('0' + run % 10); run /= 10; } while (run);
-    while (nd) s.push_back(digits[--nd]);
-    s.push_back((char)ops[i - 1]);
-    i = j;
-  }
-  return s;
-}
-
 // ------------------------------------------------------------------ scan driver
 struct ShardView {
   const uint8_t* d_text;   // device buffer (halo first)
@@ -231,12 +209,12 @@ struct ScanOut {
   int64_t conditional_index = -1; // ... except this one, which depends on the previous shard
   int exit_state = kStateDecTrue;
   uint64_t cond_seen = 0;
-  // device traceback results, indexed by the candidate's slot in the device buffer
-  std::vector<uint32_t> slot;    // cands[i] was device candidate slot[i]
-  std::vector<TraceRec> recs;    // by device slot
-  std::vector<uint8_t> ops;      // by device slot, ops_stride bytes each
-  uint32_t ops_stride = 0;
+  // device traceback results (empty without trace): one finished record per candidate, in the
+  // same order, whose cigar_off points into `pool`
+  std::vector<sassy_hip_Match> matches;
+  std::string pool;
 };
+static_assert(sizeof(MatchOut) == sizeof(sassy_hip_Match) && sizeof(MatchOut) == 64, "record layout");
 
 static uint32_t warmup_blocks(uint32_t m, uint32_t k) { return (m + k + 1 + 63) / 64; }
 
@@ -360,12 +338,19 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   uint32_t trace_blocks = 0;
   if (do_trace) {
     const uint64_t cell = (k + 1 <= 255) ? 1 : 2;
-    const uint64_t stride = ((uint64_t)(plan.m + 1) * (2ull * k + 3) * cell + 15) / 16 * 16;
+    const uint64_t band = ((uint64_t)(plan.m + 1) * (2ull * k + 3) * cell + 3) / 4 * 4;
+    const uint64_t win = ((uint64_t)plan.m + k + 15 + 15) / 16 * 16;  // whole 16-byte chunks
+    const uint64_t opsb = ((uint64_t)plan.m + k + 1 + 3) / 4 * 4;
+    uint64_t stride = band + win + opsb;
+    if ((stride / 4) % 2 == 0) stride += 4;  // odd number of LDS words: conflict-free slices
     if (stride > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "pattern/k too large for the traceback band");
     uint64_t nthreads = (256ull << 20) / stride;
     nthreads = std::max<uint64_t>(64, std::min<uint64_t>(16384, nthreads)) / 64 * 64;
     trace_blocks = (uint32_t)(nthreads / 64);
-    if (int rc = S->d_scratch.reserve(nthreads * stride)) return rc;
+    if (64 * stride + (plan.m + 15) / 16 * 16 > kTraceLdsLimit)  // slices in global memory
+      if (int rc = S->d_scratch.reserve(nthreads * stride)) return rc;
+    T.band_bytes = (uint32_t)band;
+    T.win_bytes = (uint32_t)win;
     T.text = sh.d_text;
     T.global_offset = sh.global_offset;
     T.total_len = total_len;
@@ -376,7 +361,8 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     T.pattern = S->d_pattern.p;
     T.scratch = S->d_scratch.p;
     T.scratch_stride = (uint32_t)stride;
-    T.ops_stride = (plan.m + k + 1 + 15) / 16 * 16;
+    T.str_stride = (2 * (plan.m + k + 1) + 2 + 15) / 16 * 16;
+    T.fail_count = d_counts + 2;
   }
 
   // ---- geometry of the streaming kernel (full DP, or the prefilter) ----
@@ -435,22 +421,36 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   constexpr size_t kPinCounts = 0, kPinCounters = 16;
   const size_t pin_cands = 128;
   const size_t pin_recs = pin_cands + (size_t)kSpec * sizeof(Candidate);
-  const size_t pin_ops = pin_recs + (size_t)kSpec * sizeof(TraceRec);
-  if (int rc = S->reserve_pinned(pin_ops + (size_t)kSpec * (do_trace ? T.ops_stride : 0) + 64)) return rc;
-  uint32_t counts[2] = {0, 0};
+  const size_t pin_ops = pin_recs + (size_t)kSpec * sizeof(MatchOut);
+  if (int rc = S->reserve_pinned(pin_ops + (size_t)kSpec * (do_trace ? T.str_stride : 0) + 64)) return rc;
+  uint32_t counts[3] = {0, 0, 0};  // reports, chunk descriptors, failed tracebacks
   uint32_t desc_cap = 0;
   for (int attempt = 0; attempt < 4; ++attempt) {
     P.cand = S->d_cand.p;
     P.cand_cap = (uint32_t)std::min<size_t>(S->d_cand.cap, 0xFFFFFFFFu);
+    if (int rc = S->d_sorted.reserve(P.cand_cap)) return rc;
     if (do_trace) {
+      if ((uint64_t)P.cand_cap * T.str_stride > 0xFFFFFFFFull)
+        return fail(SASSY_HIP_EUNSUPPORTED, "too many reports for one cigar pool (> 4 GiB of cigar text)");
       if (int rc = S->d_trace.reserve(P.cand_cap)) return rc;
-      if (int rc = S->d_ops.reserve((size_t)P.cand_cap * T.ops_stride)) return rc;
-      T.cand = S->d_cand.p;
+      if (int rc = S->d_str.reserve((size_t)P.cand_cap * T.str_stride)) return rc;
+      T.cand = S->d_sorted.p;
       T.cand_cap = P.cand_cap;
       T.out = S->d_trace.p;
-      T.out_ops = S->d_ops.p;
+      T.out_str = S->d_str.p;
     }
-    HIP_TRY(hipMemsetAsync(S->d_ctl.p, 0, attempt == 0 ? 64 : 16, S->stream));
+    // the control block and the rank counters of the reports (capped: beyond kRankLimit reports
+    // the host sorts) are zeroed together
+    const size_t n_rank = std::min<size_t>(P.cand_cap, kRankLimit);
+    if (int rc = S->d_ctl.reserve(64 + 4 * n_rank)) return rc;
+    d_counts = reinterpret_cast<uint32_t*>(S->d_ctl.p);
+    d_counters = reinterpret_cast<unsigned long long*>(S->d_ctl.p + 16);
+    P.cand_count = d_counts;
+    P.counters = S->want_counters ? d_counters : nullptr;
+    T.cand_count = d_counts;
+    T.fail_count = d_counts + 2;
+    F.hit_count = d_counters + 2;
+    HIP_TRY(hipMemsetAsync(S->d_ctl.p, 0, 64 + 4 * n_rank, S->stream));
     HIP_TRY(hipEventRecord(S->ev_a, S->stream));
     hipError_t le;
     if (!filtered) {
@@ -477,6 +477,10 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       if (le != hipSuccess) return hip_fail(le, "list kernel launch");
     }
     HIP_TRY(hipEventRecord(S->ev_b, S->stream));
+    // reports into result order (by end position), then their traceback
+    le = launch_rank(S->d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(S->d_ctl.p + 64),
+                     S->d_sorted.p, S->stream);
+    if (le != hipSuccess) return hip_fail(le, "rank kernel launch");
     if (do_trace) {
       le = launch_trace(T, trace_blocks, S->stream);
       if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
@@ -487,10 +491,10 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       unsigned char* hp = S->h_pin;
       HIP_TRY(hipMemcpyAsync(hp + kPinCounts, S->d_ctl.p, 64, hipMemcpyDeviceToHost, S->stream));
       const uint32_t spec = std::min<uint32_t>(kSpec, P.cand_cap);
-      HIP_TRY(hipMemcpyAsync(hp + pin_cands, S->d_cand.p, (size_t)spec * sizeof(Candidate), hipMemcpyDeviceToHost, S->stream));
+      HIP_TRY(hipMemcpyAsync(hp + pin_cands, S->d_sorted.p, (size_t)spec * sizeof(Candidate), hipMemcpyDeviceToHost, S->stream));
       if (do_trace) {
-        HIP_TRY(hipMemcpyAsync(hp + pin_recs, S->d_trace.p, (size_t)spec * sizeof(TraceRec), hipMemcpyDeviceToHost, S->stream));
-        HIP_TRY(hipMemcpyAsync(hp + pin_ops, S->d_ops.p, (size_t)spec * T.ops_stride, hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipMemcpyAsync(hp + pin_recs, S->d_trace.p, (size_t)spec * sizeof(MatchOut), hipMemcpyDeviceToHost, S->stream));
+        HIP_TRY(hipMemcpyAsync(hp + pin_ops, S->d_str.p, (size_t)spec * T.str_stride, hipMemcpyDeviceToHost, S->stream));
       }
     }
     const double t_sync0 = now_ms();
@@ -543,33 +547,42 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     S->stats.hit_blocks += c[2];
   }
 
-  std::vector<Candidate> raw(count);
+  if (do_trace && counts[2] != 0)
+    // the reference asserts both conditions (src/search.rs:1672-1685) and panics in get_trace
+    return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
+  out.cands.resize(count);
   if (count) {
     const uint32_t have = std::min<uint32_t>(count, kSpec);
-    memcpy(raw.data(), S->h_pin + pin_cands, (size_t)have * sizeof(Candidate));
+    memcpy(out.cands.data(), S->h_pin + pin_cands, (size_t)have * sizeof(Candidate));
     if (count > have)
-      HIP_TRY(hipMemcpy(raw.data() + have, S->d_cand.p + have, (size_t)(count - have) * sizeof(Candidate), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(out.cands.data() + have, S->d_sorted.p + have, (size_t)(count - have) * sizeof(Candidate), hipMemcpyDeviceToHost));
     if (do_trace) {
-      out.recs.resize(count);
-      out.ops_stride = T.ops_stride;
-      out.ops.resize((size_t)count * T.ops_stride);
-      memcpy(out.recs.data(), S->h_pin + pin_recs, (size_t)have * sizeof(TraceRec));
-      memcpy(out.ops.data(), S->h_pin + pin_ops, (size_t)have * T.ops_stride);
+      out.matches.resize(count);
+      out.pool.resize((size_t)count * T.str_stride);
+      memcpy(out.matches.data(), S->h_pin + pin_recs, (size_t)have * sizeof(MatchOut));
+      memcpy(&out.pool[0], S->h_pin + pin_ops, (size_t)have * T.str_stride);
       if (count > have) {
-        HIP_TRY(hipMemcpy(out.recs.data() + have, S->d_trace.p + have, (size_t)(count - have) * sizeof(TraceRec), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(out.ops.data() + (size_t)have * T.ops_stride, S->d_ops.p + (size_t)have * T.ops_stride,
-                          (size_t)(count - have) * T.ops_stride, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(out.matches.data() + have, S->d_trace.p + have, (size_t)(count - have) * sizeof(MatchOut), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&out.pool[0] + (size_t)have * T.str_stride, S->d_str.p + (size_t)have * T.str_stride,
+                          (size_t)(count - have) * T.str_stride, hipMemcpyDeviceToHost));
       }
     }
   }
   g_marks.mark("copy out");
-  // the atomic append leaves the reports in arbitrary order: sort by end position
-  std::vector<uint32_t> order(count);
-  for (uint32_t i = 0; i < count; ++i) order[i] = i;
-  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return raw[a].pos < raw[b].pos; });
-  out.cands.resize(count);
-  out.slot.resize(count);
-  for (uint32_t i = 0; i < count; ++i) { out.cands[i] = raw[order[i]]; out.slot[i] = order[i]; }
+  if (count > kRankLimit) {
+    // too many reports for the device ranking pass: they arrived in append order, sort here
+    std::vector<uint32_t> order(count);
+    for (uint32_t i = 0; i < count; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return out.cands[x].pos < out.cands[y].pos; });
+    std::vector<Candidate> sc(count);
+    for (uint32_t i = 0; i < count; ++i) sc[i] = out.cands[order[i]];
+    out.cands.swap(sc);
+    if (do_trace) {
+      std::vector<sassy_hip_Match> sm(count);
+      for (uint32_t i = 0; i < count; ++i) sm[i] = out.matches[order[i]];
+      out.matches.swap(sm);
+    }
+  }
   S->stats.candidates += count;
   g_marks.mark("sort");
 
@@ -619,14 +632,17 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   };
   if (any_cond) {
     std::vector<Candidate> kept;
-    std::vector<uint32_t> kept_slot;
+    std::vector<sassy_hip_Match> kept_m;
     kept.reserve(out.cands.size());
-    kept_slot.reserve(out.cands.size());
+    if (do_trace) kept_m.reserve(out.cands.size());
+    auto keep = [&](const Candidate& c, size_t ci) {
+      kept.push_back(c);
+      if (do_trace) kept_m.push_back(out.matches[ci]);
+    };
     const uint64_t end_global = sh.global_offset + sh.text_len;
     for (size_t ci = 0; ci < out.cands.size(); ++ci) {
       const Candidate& c = out.cands[ci];
-      const uint32_t cslot = out.slot[ci];
-      if (!(c.flags & kCandCond)) { kept.push_back(c); kept_slot.push_back(cslot); continue; }
+      if (!(c.flags & kCandCond)) { keep(c, ci); continue; }
       out.cond_seen++;
       uint64_t blk = (c.pos - sh.global_offset) / 64;
       if (c.pos == end_global && blk >= n_blocks) blk = n_blocks - 1;  // end-of-text report
@@ -638,15 +654,14 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       }
       const int inc = chunks.empty() ? kStateDecTrue : incoming(lo);
       Candidate cc = c;
-      if (inc == kStateDecTrue) { cc.flags &= ~kCandCond; kept.push_back(cc); kept_slot.push_back(cslot); }
+      if (inc == kStateDecTrue) { cc.flags &= ~kCandCond; keep(cc, ci); }
       else if (inc == kStatePass) {
         out.conditional_index = (int64_t)kept.size();  // only the previous shard knows
-        kept.push_back(c);
-        kept_slot.push_back(cslot);
+        keep(c, ci);
       }  // kStateDecFalse: the plateau was entered by an increase -> not a report
     }
     out.cands.swap(kept);
-    out.slot.swap(kept_slot);
+    if (do_trace) out.matches.swap(kept_m);
   }
   if (need_state) {
     // exit state = decreasing-state after the last owned block
@@ -662,61 +677,56 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   return 0;
 }
 
-// Turn the resolved reports + their device traceback records into matches.
-static int trace_reports(const ScanOut& so, uint64_t total_len, const PatternPlan& plan, bool without_trace,
-                         std::vector<MatchRec>& out) {
-  const size_t m = plan.m;
-  for (size_t i = 0; i < so.cands.size(); ++i) {
-    const Candidate& c = so.cands[i];
-    MatchRec r;
-    if (without_trace) {  // reference: src/search.rs:1464-1475
+// Append the matches of one scan to a result: the device already produced finished records and
+// cigar text (trace_kernel.hip); only the pool offsets are rebased.  Returns the index of the
+// first appended match.
+static int append_matches(ScanOut& so, uint64_t total_len, const PatternPlan& plan, bool without_trace,
+                          uint64_t pattern_idx, sassy_hip_Result* R, size_t& first) {
+  first = R->matches.size();
+  if (without_trace) {  // reference: src/search.rs:1464-1475
+    R->matches.reserve(first + so.cands.size());
+    for (const Candidate& c : so.cands) {
+      sassy_hip_Match r{};
+      r.pattern_idx = pattern_idx;
       r.text_start = UINT64_MAX;
       r.text_end = std::min<uint64_t>(c.pos, total_len);
       r.pattern_start = UINT64_MAX;
-      r.pattern_end = m;
+      r.pattern_end = plan.m;
       r.cost = c.cost;
-    } else {
-      const TraceRec& t = so.recs[so.slot[i]];
-      // the reference asserts both (src/search.rs:1672-1685) and panics in get_trace otherwise
-      if (!t.ok || t.cost > c.cost)
-        return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
-      r.text_start = t.text_start;
-      r.text_end = t.text_end;
-      r.pattern_start = 0;
-      r.pattern_end = m;
-      r.cost = t.cost;
-      r.cigar = rle_reversed(so.ops.data() + (size_t)so.slot[i] * so.ops_stride, t.nops);
+      r.cigar_off = (uint32_t)R->pool.size();  // empty string: points at a NUL
+      r.cigar_len = 0;
+      R->matches.push_back(r);
     }
-    out.push_back(std::move(r));
+    if (R->pool.empty()) R->pool.push_back('\0');
+    for (size_t i = first; i < R->matches.size(); ++i) R->matches[i].cigar_off = 0;
+    return 0;
+  }
+  if (first == 0 && R->pool.empty()) {  // the common single-scan case: adopt the buffers
+    R->matches.swap(so.matches);
+    R->pool.swap(so.pool);
+    if (pattern_idx)
+      for (sassy_hip_Match& r : R->matches) r.pattern_idx = pattern_idx;
+    if (R->pool.empty()) R->pool.push_back('\0');
+    return 0;
+  }
+  const size_t base = R->pool.size();
+  if (base + so.pool.size() > 0xFFFFFFFFull)
+    return fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB");
+  R->pool.append(so.pool);
+  R->matches.reserve(first + so.matches.size());
+  for (sassy_hip_Match r : so.matches) {
+    r.pattern_idx = pattern_idx;
+    r.cigar_off = (uint32_t)(r.cigar_off + base);
+    R->matches.push_back(r);
   }
   return 0;
-}
-
-static void finish_result(const std::vector<MatchRec>& recs, sassy_hip_Result* R) {
-  R->matches.reserve(recs.size());
-  for (const MatchRec& r : recs) {
-    sassy_hip_Match m{};
-    m.pattern_idx = r.pattern_idx;
-    m.text_idx = r.text_idx;
-    m.text_start = r.text_start;
-    m.text_end = r.text_end;
-    m.pattern_start = r.pattern_start;
-    m.pattern_end = r.pattern_end;
-    m.cost = r.cost;
-    m.strand = r.strand;
-    m.cigar_off = (uint32_t)R->pool.size();
-    m.cigar_len = (uint32_t)r.cigar.size();
-    R->pool.append(r.cigar);
-    R->pool.push_back('\0');
-    R->matches.push_back(m);
-  }
 }
 
 // Searcher::search / search_all on one text (reference: src/search.rs:510-525, 685-700, 787-881).
 // `text` is a host pointer unless TEXT_ON_DEVICE.
 static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t plen, const uint8_t* text,
                        size_t tlen, size_t k, uint32_t flags, uint64_t pattern_idx, bool fwd_strand,
-                       bool rc_strand, std::vector<MatchRec>& recs) {
+                       bool rc_strand, sassy_hip_Result* R) {
   PatternPlan plan;
   std::string err;
   if (!make_plan(S->profile, pattern, plen, plan, err)) return fail(SASSY_HIP_EINVAL, err);
@@ -740,9 +750,8 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
     ShardView sh{d_fwd, tlen, 0, 0, true, true};
     ScanOut so;
     if (int rc = run_scan(S, sh, plan, (uint32_t)k, all, pattern, !wo, tlen, so)) return rc;
-    const size_t first = recs.size();
-    if (int rc = trace_reports(so, tlen, plan, wo, recs)) return rc;
-    for (size_t i = first; i < recs.size(); ++i) recs[i].pattern_idx = pattern_idx;
+    size_t first = 0;
+    if (int rc = append_matches(so, tlen, plan, wo, pattern_idx, R, first)) return rc;
   }
   if (rc_strand) {
     // complement(pattern) against reverse(text), coordinates mapped back
@@ -757,13 +766,12 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
     ShardView sh{S->d_rev.p, tlen, 0, 0, true, true};
     ScanOut so;
     if (int rc = run_scan(S, sh, cplan, (uint32_t)k, all, cp.data(), !wo, tlen, so)) return rc;
-    const size_t first = recs.size();
-    if (int rc = trace_reports(so, tlen, cplan, wo, recs)) return rc;
-    for (size_t i = first; i < recs.size(); ++i) {
-      MatchRec& r = recs[i];
+    size_t first = 0;
+    if (int rc = append_matches(so, tlen, cplan, wo, pattern_idx, R, first)) return rc;
+    for (size_t i = first; i < R->matches.size(); ++i) {
+      sassy_hip_Match& r = R->matches[i];
       const uint64_t rs = r.text_start, re = r.text_end;
       r.strand = 1;
-      r.pattern_idx = pattern_idx;
       r.text_start = tlen - re;
       r.text_end = wo ? UINT64_MAX : tlen - rs;  // reference: src/search.rs:868-873
     }
@@ -865,10 +873,9 @@ int sassy_hip_search(sassy_SearcherType* s, const uint8_t* pattern, size_t patte
   if (!s || !pattern || (!text && text_len) || !out) return fail(SASSY_HIP_EINVAL, "Pointers in search() must not be null");
   const double t0 = now_ms();
   reset_stats(s);
-  std::vector<MatchRec> recs;
-  if (int rc = search_text(s, pattern, pattern_len, text, text_len, k, flags, 0, true, s->rc, recs)) return rc;
   sassy_hip_Result* R = new sassy_hip_Result();
-  finish_result(recs, R);
+  if (int rc = search_text(s, pattern, pattern_len, text, text_len, k, flags, 0, true, s->rc, R)) { delete R; return rc; }
+  if (R->pool.empty()) R->pool.push_back('\0');
   s->stats.total_ms = now_ms() - t0;
   s->stats.host_post_ms = s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms;
   *out = R;
@@ -909,11 +916,9 @@ int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t
     const bool wo = (flags & SASSY_HIP_WITHOUT_TRACE) != 0;
     if (int rc = run_scan(s, sh, plan, (uint32_t)k, (flags & SASSY_HIP_ALL_MINIMA) != 0, pattern, !wo,
                           total_len, so)) { delete R; return rc; }
-    std::vector<MatchRec> recs;
-    if (int rc = trace_reports(so, total_len, plan, wo, recs)) { delete R; return rc; }
-    g_marks.mark("trace_reports");
-    finish_result(recs, R);
-    g_marks.mark("finish_result");
+    size_t first = 0;
+    if (int rc = append_matches(so, total_len, plan, wo, 0, R, first)) { delete R; return rc; }
+    g_marks.mark("append_matches");
     R->exit_state = so.exit_state;
     R->conditional_index = so.conditional_index;
   }
@@ -994,7 +999,8 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
   const double t0 = now_ms();
   reset_stats(s);
   if (int rc = s->ensure_device()) return rc;
-  std::vector<MatchRec> recs;
+  sassy_hip_Result* R = new sassy_hip_Result();
+  std::unique_ptr<sassy_hip_Result> guard(R);
   // One forward scan per (rc-expanded) pattern over the device-resident text: the text goes to
   // the device once, every pattern reuses it.
   const uint8_t* d_text = text;
@@ -1006,23 +1012,24 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
   const uint8_t* tptr = (flags & SASSY_HIP_TEXT_ON_DEVICE) ? d_text : s->d_text.p;
   f |= SASSY_HIP_TEXT_ON_DEVICE;  // search_text must not upload the text again per pattern
   for (size_t p = 0; p < e->patterns.size(); ++p) {
-    const size_t first = recs.size();
+    const size_t first = R->matches.size();
     if (int rc = search_text(s, e->patterns[p].data(), e->plen, tptr, text_len, k, f,
-                             p % e->n_original, true, false, recs)) return rc;
-    for (size_t i = first; i < recs.size(); ++i) recs[i].strand = p >= e->n_original ? 1 : 0;
+                             p % e->n_original, true, false, R)) return rc;
+    for (size_t i = first; i < R->matches.size(); ++i) R->matches[i].strand = p >= e->n_original ? 1 : 0;
   }
   // The reference's order is an artefact of its range bookkeeping; its own differential test
   // sorts by this key before comparing (pattern_tiling/search.rs:748-757).
-  std::sort(recs.begin(), recs.end(), [](const MatchRec& a, const MatchRec& b) {
+  if (R->pool.empty()) R->pool.push_back('\0');
+  const char* pool = R->pool.c_str();
+  std::sort(R->matches.begin(), R->matches.end(), [pool](const sassy_hip_Match& a, const sassy_hip_Match& b) {
     if (a.pattern_idx != b.pattern_idx) return a.pattern_idx < b.pattern_idx;
     if (a.text_start != b.text_start) return a.text_start < b.text_start;
     if (a.text_end != b.text_end) return a.text_end < b.text_end;
     if (a.cost != b.cost) return a.cost < b.cost;
     if (a.strand != b.strand) return a.strand < b.strand;
-    return a.cigar < b.cigar;
+    return strcmp(pool + a.cigar_off, pool + b.cigar_off) < 0;
   });
-  sassy_hip_Result* R = new sassy_hip_Result();
-  finish_result(recs, R);
+  guard.release();
   s->stats.total_ms = now_ms() - t0;
   s->stats.host_post_ms = s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms;
   *out = R;

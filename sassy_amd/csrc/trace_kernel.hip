@@ -6,122 +6,293 @@
 // '=', then 'X', 'D', 'I').  Only the diagonals a <=k alignment can touch are computed: every
 // cell the walk visits lies on an optimal alignment ending in (m, e), hence on window diagonals
 // [dend-k, dend+k]; one more diagonal on each side covers the neighbours the walk compares, and
-// values are saturated at k+1 (DESIGN.md "traceback").  The band lives in a per-thread slice of
-// a global scratch buffer; reports are rare, so this kernel is microseconds.
+// values are saturated at k+1 (DESIGN.md "traceback").
+//
+// Band coordinates: cell (j, i) of the window matrix is stored at row j, column b = i - j - dlo
+// (0 <= b < 2k+3).  Its neighbours are (j-1, i-1) -> same b, (j, i-1) -> b-1, (j-1, i) -> b+1.
+// Cells outside the window store k+1, so no position checks are needed when reading.
+//
+// Per-thread slice = band | window bytes | ops (end -> start), in LDS when 64 slices fit, else in
+// a global scratch buffer.  Reports are few (thousands), so the kernel is a latency chain, not a
+// throughput problem: the window arrives with a handful of independent 16-byte loads, and for
+// small k the band row and the text bytes under it stay in registers while the band is filled
+// (LDS only records the rows for the walk).  The thread finishes its record completely:
+// run-length encoded cigar text (pa-types' Cigar::to_string form, reference src/search.rs:75-98)
+// and a sassy_hip_Match-layout row, so the host only copies.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
 
 namespace sassy_hip {
 
-__device__ __forceinline__ uint32_t d_iupac_code(uint32_t c) {
-  // letter (5 low bits) -> base set, 255 = not a letter (reference: src/profiles/iupac.rs:281-317)
-  const uint32_t i = c & 31u;
-  return i == 1 ? 1 : i == 3 ? 2 : i == 20 ? 4 : i == 21 ? 4 : i == 7 ? 8 : i == 14 ? 15
-       : i == 18 ? 9 : i == 25 ? 6 : i == 19 ? 10 : i == 23 ? 5 : i == 11 ? 12 : i == 13 ? 3
-       : i == 2 ? 14 : i == 4 ? 13 : i == 8 ? 7 : i == 22 ? 11 : i == 24 ? 0 : 255;
+// Letter (5 low bits of the byte) -> IUPAC base set, 255 = not a letter
+// (reference: src/profiles/iupac.rs:281-317).
+__constant__ uint8_t kIupacCode[32] = {
+    255, 1, 14, 2, 13, 255, 255, 8, 7, 255, 255, 12, 255, 3, 15, 255,
+    255, 255, 9, 10, 4, 4, 11, 5, 0, 6, 255, 255, 255, 255, 255, 255};
+
+// Characters are compared through one formula for all profiles, so that the fill and walk loops
+// stay small (the kernel runs once per call on a few dozen waves: instruction fetch of cold code
+// is a visible part of its time).  Stored byte s(c): Dna / Ascii the raw byte, Iupac its base
+// set.  With X = iupac ? p & t : p ^ t:
+//   scan equality   (profile eq of the scan)        : ((X & emask) != 0) == iupac
+//   display match   (Profile::is_match, '=' vs 'X') : ((X & mmask) != 0) == iupac
+// Dna: emask 6 ((c>>1)&3 codes, src/profiles/dna.rs:19-60), mmask 0xDF (case-insensitive byte);
+// Iupac: emask 15 (non-letters = 255 act as N in the scan), mmask 255; Ascii: both 255.
+struct CharRule {
+  uint32_t iupac, emask, mmask;
+};
+__device__ __forceinline__ CharRule char_rule(uint32_t profile) {
+  CharRule r;
+  r.iupac = profile == PROFILE_IUPAC ? 1u : 0u;
+  r.emask = profile == PROFILE_DNA ? 6u : profile == PROFILE_IUPAC ? 15u : 255u;
+  r.mmask = profile == PROFILE_DNA ? 0xDFu : 255u;
+  return r;
 }
-__device__ __forceinline__ bool d_scan_eq(uint32_t pr, uint32_t p, uint32_t t) {
-  if (pr == PROFILE_DNA) return ((p >> 1) & 3u) == ((t >> 1) & 3u);
-  if (pr == PROFILE_IUPAC) return ((d_iupac_code(p) & d_iupac_code(t)) & 0x0Fu) != 0;
-  return p == t;
-}
-__device__ __forceinline__ bool d_is_match(uint32_t pr, uint32_t p, uint32_t t) {
-  if (pr == PROFILE_DNA) return (p | 0x20u) == (t | 0x20u);
-  if (pr == PROFILE_IUPAC) return (d_iupac_code(p) & d_iupac_code(t)) > 0;
-  return p == t;
+__device__ __forceinline__ bool rule_hit(const CharRule& r, uint32_t p, uint32_t t, uint32_t mask) {
+  const uint32_t x = r.iupac ? (p & t) : (p ^ t);
+  return ((x & mask) != 0u) == (r.iupac != 0u);
 }
 
-// IN_LDS: the band of every thread of the block fits into LDS (64 * scratch_stride bytes of dynamic
-// shared memory) -- the usual case; otherwise it lives in a global scratch slice.
-template <typename Cell, bool IN_LDS>
-__global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char trace_smem[];
-  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t nthreads = gridDim.x * blockDim.x;
-  uint32_t count = *P.cand_count;
-  if (count > P.cand_cap) count = P.cand_cap;
-  const long m = (long)P.m, k = (long)P.k;
-  const long bw = 2 * k + 3;
-  const int inf = (int)k + 1;
-  Cell* L = IN_LDS ? reinterpret_cast<Cell*>(trace_smem + (size_t)threadIdx.x * P.scratch_stride)
-                   : reinterpret_cast<Cell*>(P.scratch + (uint64_t)tid * P.scratch_stride);
-
-  for (uint32_t c = tid; c < count; c += nthreads) {
-    const uint64_t e = P.cand[c].pos;                 // global end position
-    const uint64_t fill = (uint64_t)(m + k);
-    const uint64_t o = e > fill ? e - fill : 0;        // global window start
-    const uint64_t we = e < P.total_len ? e : P.total_len;
-    const long wl = (long)(we - o);
-    const uint8_t* win = P.text + (o - P.global_offset);
-    const long dend = wl - m, dlo = dend - k - 1, dhi = dend + k + 1;
-    auto at = [&](long j, long i) -> int {
-      if (i < 0 || i > wl) return inf;
-      const long d = i - j;
-      if (d < dlo || d > dhi) return inf;
-      return (int)L[j * bw + (d - dlo)];
-    };
-    for (long j = 0; j <= m; ++j) {
-      long ilo = j + dlo, ihi = j + dhi;
-      if (ilo < 0) ilo = 0;
-      if (ihi > wl) ihi = wl;
-      const uint32_t pc = j > 0 ? P.pattern[j - 1] : 0u;
-      for (long i = ilo; i <= ihi; ++i) {
-        int v;
-        if (j == 0) v = 0;
-        else if (i == 0) v = j < inf ? (int)j : inf;
-        else {
-          v = at(j - 1, i - 1) + (d_scan_eq(P.profile, pc, win[i - 1]) ? 0 : 1);
-          const int l = at(j, i - 1) + 1, u = at(j - 1, i) + 1;
-          v = v < l ? v : l;
-          v = v < u ? v : u;
-          v = v < inf ? v : inf;
-        }
-        L[j * bw + (i - j - dlo)] = (Cell)v;
+// Window bytes of one report into the thread's slice: aligned 16-byte chunks, all loads of a batch
+// in flight together.  Only chunks that contain a valid text byte are touched (the text buffer is
+// 16-byte aligned, so such a chunk never leaves the allocation).  Returns the offset of window
+// byte 0 inside the slice's window area.
+__device__ __forceinline__ uint32_t load_window(const uint8_t* text, uint64_t o_rel, int wl,
+                                                unsigned char* wbuf) {
+  const uint64_t a0 = o_rel & ~15ull;
+  const uint32_t skew = (uint32_t)(o_rel - a0);
+  const uint32_t nch = wl > 0 ? (skew + (uint32_t)wl + 15u) / 16u : 0u;
+  const uint4* src = reinterpret_cast<const uint4*>(text + a0);
+  uint32_t* dst = reinterpret_cast<uint32_t*>(wbuf);
+  for (uint32_t q0 = 0; q0 < nch; q0 += 4) {
+    uint4 v[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) v[u] = q0 + u < nch ? src[q0 + u] : uint4{0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      if (q0 + u < nch) {
+        dst[4 * (q0 + u) + 0] = v[u].x;
+        dst[4 * (q0 + u) + 1] = v[u].y;
+        dst[4 * (q0 + u) + 2] = v[u].z;
+        dst[4 * (q0 + u) + 3] = v[u].w;
       }
     }
-    TraceRec r;
-    r.text_start = 0;
-    r.text_end = we;
-    r.cost = 0;
-    r.nops = 0;
-    r.ok = 0;
-    r.cand = c;
-    long j = m, i = wl;
-    int g = at(j, i);
-    r.cost = g;
-    uint8_t* ops = P.out_ops + (uint64_t)c * P.ops_stride;
+  }
+  return skew;
+}
+
+// KT >= 0: k is the compile-time constant KT (band row in registers); KT < 0: any k.
+template <typename Cell, bool IN_LDS, int KT>
+__global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char trace_smem[];
+  uint32_t count = *P.cand_count;
+  if (count > P.cand_cap) count = P.cand_cap;
+  const int m = (int)P.m, k = KT >= 0 ? KT : (int)P.k;
+  const int bw = 2 * k + 3;
+  const int inf = k + 1;
+  const uint32_t fill = P.m + P.k;
+  const uint32_t tid = threadIdx.x;
+  // block-shared pattern copy behind the 64 slices (LDS mode)
+  unsigned char* spat = trace_smem + (size_t)64 * P.scratch_stride;
+  const CharRule rule = char_rule(P.profile);
+  if (IN_LDS) {
+    for (uint32_t x = tid; x < P.m; x += 64) {
+      const uint32_t ch = P.pattern[x];
+      spat[x] = (unsigned char)(rule.iupac ? kIupacCode[ch & 31u] : ch);
+    }
+    __syncthreads();
+  }
+  auto pat_at = [&](int j) -> uint32_t {
+    if (IN_LDS) return spat[j];
+    const uint32_t ch = P.pattern[j];
+    return rule.iupac ? kIupacCode[ch & 31u] : ch;
+  };
+  unsigned char* slice = IN_LDS ? trace_smem + (size_t)tid * P.scratch_stride
+                                : P.scratch + ((uint64_t)blockIdx.x * 64 + tid) * P.scratch_stride;
+  Cell* L = reinterpret_cast<Cell*>(slice);
+  unsigned char* wbuf = slice + P.band_bytes;
+  unsigned char* ops = slice + P.band_bytes + P.win_bytes;
+
+  for (uint32_t c = blockIdx.x * 64 + tid; c < count; c += gridDim.x * 64) {
+    const Candidate cd = P.cand[c];
+    const uint64_t e = cd.pos;                             // global end position
+    const uint64_t o = e > fill ? e - fill : 0;            // global window start
+    const uint64_t we = e < P.total_len ? e : P.total_len;
+    const int wl = (int)(we - o);
+    const uint32_t skew = load_window(P.text, o - P.global_offset, wl, wbuf);
+    unsigned char* win = wbuf + skew;
+    if (rule.iupac)
+      for (int x = 0; x < wl; ++x) win[x] = kIupacCode[win[x] & 31u];
+    auto text_at = [&](int i) -> uint32_t { return win[i]; };
+
+    const int dend = wl - m, dlo = dend - k - 1;
+    // ---- fill the band ----
+    if constexpr (KT >= 0) {
+      constexpr int BW = 2 * KT + 3;
+      int prev[BW];
+      uint32_t tx[BW];  // tx[b] = text byte compared in cell (j, i = j+dlo+b): text[i-1]
+#pragma unroll
+      for (int b = 0; b < BW; ++b) {
+        const int i = dlo + b;
+        prev[b] = (i < 0 || i > wl) ? inf : 0;
+        L[b] = (Cell)prev[b];
+        const int ti = dlo + b;  // row 1: i - 1 = 1 + dlo + b - 1
+        tx[b] = (ti >= 0 && ti < wl) ? text_at(ti) : 0u;
+      }
+      for (int j = 1; j <= m; ++j) {
+        const uint32_t pc = pat_at(j - 1);
+        // the text byte that enters the band on the right in the next row
+        const int tn = j + dlo + BW - 1;
+        const uint32_t tnext = (tn >= 0 && tn < wl) ? text_at(tn) : 0u;
+        Cell* row = L + (size_t)j * BW;
+        int cur[BW];
+        int left = inf;
+#pragma unroll
+        for (int b = 0; b < BW; ++b) {
+          const int i = j + dlo + b;
+          int v;
+          if (i < 0 || i > wl) v = inf;
+          else if (i == 0) v = j < inf ? j : inf;
+          else {
+            v = prev[b] + (rule_hit(rule, pc, tx[b], rule.emask) ? 0 : 1);
+            const int l = left + 1;
+            const int u = (b + 1 < BW ? prev[b + 1] : inf) + 1;
+            v = v < l ? v : l;
+            v = v < u ? v : u;
+            v = v < inf ? v : inf;
+          }
+          cur[b] = v;
+          left = v;
+        }
+#pragma unroll
+        for (int b = 0; b < BW; ++b) {
+          row[b] = (Cell)cur[b];
+          prev[b] = cur[b];
+          tx[b] = b + 1 < BW ? tx[b + 1] : tnext;
+        }
+      }
+    } else {
+      for (int j = 0; j <= m; ++j) {
+        const uint32_t pc = j > 0 ? pat_at(j - 1) : 0u;
+        Cell* row = L + (size_t)j * bw;
+        const Cell* prev = row - bw;
+        int left = inf;
+        for (int b = 0; b < bw; ++b) {
+          const int i = j + dlo + b;
+          int v;
+          if (i < 0 || i > wl) v = inf;
+          else if (j == 0) v = 0;
+          else if (i == 0) v = j < inf ? j : inf;
+          else {
+            v = (int)prev[b] + (rule_hit(rule, pc, text_at(i - 1), rule.emask) ? 0 : 1);
+            const int l = left + 1;
+            const int u = (b + 1 < bw ? (int)prev[b + 1] : inf) + 1;
+            v = v < l ? v : l;
+            v = v < u ? v : u;
+            v = v < inf ? v : inf;
+          }
+          row[b] = (Cell)v;
+          left = v;
+        }
+      }
+    }
+    // ---- greedy walk from (m, wl) ----
+    int j = m, i = wl;
+    int g = (int)L[(size_t)m * bw + (k + 1)];
+    const int cost = g;
+    const uint32_t max_ops = P.m + P.k + 1;
     uint32_t nops = 0;
-    bool ok = g <= (int)k;
+    bool ok = g <= k;
     while (ok && j > 0) {
-      if (nops >= P.ops_stride) { ok = false; break; }
-      if (i > 0 && at(j - 1, i - 1) == g && d_is_match(P.profile, P.pattern[j - 1], win[i - 1])) {
+      if (nops >= max_ops) { ok = false; break; }
+      const int b = i - j - dlo;
+      const Cell* row = L + (size_t)j * bw;
+      const Cell* prev = row - bw;
+      const int diag = i > 0 ? (int)prev[b] : inf;
+      if (diag == g && rule_hit(rule, pat_at(j - 1), text_at(i - 1), rule.mmask)) {
         ops[nops++] = '='; --j; --i; continue;
       }
       g -= 1;
       if (g < 0) { ok = false; break; }
-      if (i > 0 && at(j - 1, i - 1) == g) { ops[nops++] = 'X'; --j; --i; continue; }
-      if (i > 0 && at(j, i - 1) == g) { ops[nops++] = 'D'; --i; continue; }
-      if (at(j - 1, i) == g) { ops[nops++] = 'I'; --j; continue; }
+      if (diag == g) { ops[nops++] = 'X'; --j; --i; continue; }
+      const int lft = (i > 0 && b > 0) ? (int)row[b - 1] : inf;
+      if (lft == g) { ops[nops++] = 'D'; --i; continue; }
+      const int up = (b + 1 < bw) ? (int)prev[b + 1] : inf;
+      if (up == g) { ops[nops++] = 'I'; --j; continue; }
       ok = false;  // the reference panics here ("Trace failed! No ancestor found")
     }
     if (ok && g != 0) ok = false;
+    // the reference asserts that the traced cost does not exceed the scanned one
+    // (src/search.rs:1672-1685)
+    if (cost > cd.cost) ok = false;
+    if (!ok) atomicAdd(P.fail_count, 1u);
+
+    // ---- run-length encoded cigar text, start -> end ----
+    unsigned char* str = P.out_str + (uint64_t)c * P.str_stride;
+    uint32_t w = 0;
+    int idx = ok ? (int)nops - 1 : -1;
+    while (idx >= 0) {
+      const unsigned char op = ops[idx];
+      uint32_t run = 1;
+      while (idx - (int)run >= 0 && ops[idx - (int)run] == op) ++run;
+      idx -= (int)run;
+      uint32_t p10 = 1;
+      while (p10 * 10 <= run) p10 *= 10;
+      while (p10) { str[w++] = (unsigned char)('0' + run / p10); run %= p10; p10 /= 10; }
+      str[w++] = op;
+    }
+    str[w] = 0;
+
+    MatchOut r;
+    r.pattern_idx = 0;
+    r.text_idx = 0;
     r.text_start = o + (uint64_t)i;
-    r.nops = nops;  // written end -> start; the host reverses while run-length encoding
-    r.ok = ok ? 1u : 0u;
+    r.text_end = we;
+    r.pattern_start = 0;
+    r.pattern_end = P.m;
+    r.cost = cost;
+    r.strand = 0;
+    r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+    r.cigar_off = c * P.str_stride;
+    r.cigar_len = w;
     P.out[c] = r;
   }
 }
 
+template <typename Cell, bool IN_LDS, int KT>
+static void launch_one(const TraceParams& P, uint32_t nblocks, size_t lds, hipStream_t stream) {
+  if (IN_LDS) {
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_kernel<Cell, IN_LDS, KT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL((trace_kernel<Cell, IN_LDS, KT>), dim3(nblocks), dim3(64), IN_LDS ? lds : 0, stream, P);
+}
+
 hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stream) {
-  const size_t lds = (size_t)64 * P.scratch_stride;
-  const bool in_lds = lds <= 64 * 1024;
-  if (P.k + 1 <= 255) {
-    if (in_lds) hipLaunchKernelGGL((trace_kernel<uint8_t, true>), dim3(nblocks), dim3(64), lds, stream, P);
-    else hipLaunchKernelGGL((trace_kernel<uint8_t, false>), dim3(nblocks), dim3(64), 0, stream, P);
+  // LDS mode: 64 slices + the pattern
+  const size_t lds = (size_t)64 * P.scratch_stride + ((P.m + 15) / 16) * 16;
+  const bool in_lds = lds <= kTraceLdsLimit;
+  if (P.k + 1 > 255) {
+    if (in_lds) launch_one<uint16_t, true, -1>(P, nblocks, lds, stream);
+    else launch_one<uint16_t, false, -1>(P, nblocks, lds, stream);
+  } else if (!in_lds) {
+    launch_one<uint8_t, false, -1>(P, nblocks, lds, stream);
   } else {
-    if (in_lds) hipLaunchKernelGGL((trace_kernel<uint16_t, true>), dim3(nblocks), dim3(64), lds, stream, P);
-    else hipLaunchKernelGGL((trace_kernel<uint16_t, false>), dim3(nblocks), dim3(64), 0, stream, P);
+    switch (P.k) {
+      case 0: launch_one<uint8_t, true, 0>(P, nblocks, lds, stream); break;
+      case 1: launch_one<uint8_t, true, 1>(P, nblocks, lds, stream); break;
+      case 2: launch_one<uint8_t, true, 2>(P, nblocks, lds, stream); break;
+      case 3: launch_one<uint8_t, true, 3>(P, nblocks, lds, stream); break;
+      case 4: launch_one<uint8_t, true, 4>(P, nblocks, lds, stream); break;
+      case 5: launch_one<uint8_t, true, 5>(P, nblocks, lds, stream); break;
+      case 6: launch_one<uint8_t, true, 6>(P, nblocks, lds, stream); break;
+      default: launch_one<uint8_t, true, -1>(P, nblocks, lds, stream); break;
+    }
   }
   return hipGetLastError();
 }
