@@ -73,6 +73,9 @@ struct ScanParams {
   uint32_t piece_groups;      // 0: generic path (table in LDS), 1 or 2: fast path
   uint32_t piece_tab[2][12];
   uint32_t piece_last[2];
+  // Dna bit-plane filter: per piece, bit j = code bit 0 / code bit 1 of piece row j
+  uint32_t piece_planes;      // 1: use filter_dna_kernel (Dna, <= 8 pieces)
+  uint32_t piece_bits[8][2];
   unsigned long long* hit_bitmap;  // one bit per text block: an exact piece occurrence ends in it
   unsigned long long* hit_count;   // device counter of hit blocks
   const ChunkDesc* desc;      // list mode: chunk descriptors

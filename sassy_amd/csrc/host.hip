@@ -400,10 +400,26 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
         }
       }
     }
+    // Dna with <= 8 pieces: the filter works on the two code bit planes (filter_dna_kernel)
+    static const int env_planes = getenv("SASSY_HIP_FILTER_PLANES") ? atoi(getenv("SASSY_HIP_FILTER_PLANES")) : 1;
+    F.piece_planes = (S->profile == PROFILE_DNA && F.piece_groups != 0 && env_planes != 0) ? 1u : 0u;
+    if (F.piece_planes) {
+      for (uint32_t pp = 0; pp < 8; ++pp) {
+        const uint32_t piece = pp < F.n_pieces ? pp : 0;  // a repeated piece changes nothing
+        uint32_t b0 = 0, b1 = 0;
+        for (uint32_t j = 0; j < q; ++j) {
+          const uint32_t code = (pat[piece * q + j] >> 1) & 3u;  // src/profiles/dna.rs:19-40
+          b0 |= (code & 1u) << j;
+          b1 |= (code >> 1) << j;
+        }
+        F.piece_bits[pp][0] = b0;
+        F.piece_bits[pp][1] = b1;
+      }
+    }
     static const int env_fsb = getenv("SASSY_HIP_FILTER_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_FILTER_STAGE_BLOCKS")) : 0;
     F.stage_blocks = env_fsb == 1 || env_fsb == 2 ? (uint32_t)env_fsb : 2u;
     if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, 1, &fgrid)) return rc;
-    F.lds_per_wave = 4096u * F.stage_blocks + 2u * bucket * 512u;
+    F.lds_per_wave = 4096u * F.stage_blocks + (F.piece_planes ? 0u : 2u * bucket * 512u);
     n_words = (n_blocks + 63) / 64;
     if (int rc = S->d_bitmap.reserve(n_words + 2)) return rc;
     F.hit_bitmap = S->d_bitmap.p;

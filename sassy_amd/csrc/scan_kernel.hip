@@ -703,6 +703,146 @@ __global__ __launch_bounds__(256) void filter_kernel(const ScanParams P) {
   if (lane == 0 && nhits) atomicAdd(P.hit_count, nhits);
 }
 
+// ====================================================================== K0 for Dna: bit planes only
+// The Dna code of a text byte is two bits ((c >> 1) & 3), so "text char i equals pattern char p"
+// is  (T0 ^ ~P0) & (T1 ^ ~P1)  on the two code bit planes T0, T1 of the block with P0, P1 the
+// replicated code bits of p -- wave-uniform values.  A piece occurrence ending at text bit i is the
+// AND over its rows j of that term taken at bit i - (q-1-j).  The planes are shifted once per
+// distance d = q-1-j (funnel shift with the previous block's planes, which this lane computed in
+// its previous iteration and keeps in registers) and shared by all pieces; every term is then two
+// v_bitop3_b32 (acc & (plane ^ scalar)) per 32-bit half.  No slot masks, no LDS besides the
+// staging tile: per 64-byte block about 130 VALU ops for the planes + 4 * q for the shifts +
+// 4 * (k+1) * q for the terms, which leaves the kernel bound by the HBM stream.
+// NPG: 1 / 2 = up to 4 / 8 pieces (missing pieces repeat piece 0).
+template <int SB, int NPG>
+__global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr uint32_t kRowBytes = 64u * SB;
+  constexpr uint32_t kSlots = 4u * SB;
+  constexpr uint32_t kOwnersPerInstr = 64u / kSlots;
+  constexpr int kStageInstr = 4 * SB;
+  constexpr int NP = 4 * NPG;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  unsigned char* tile = smem + (size_t)wave * P.lds_per_wave;
+
+  const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * kWavesPerGroup + wave) * kWave;
+  if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
+  const uint64_t chunk = wave_chunk0 + lane;
+  const uint32_t bpl = P.bpl;
+  const uint64_t first_owned = P.first_owned_block;
+  const uint32_t back = 1u + (uint32_t)((first_owned + 1u) & 1u);  // previous block + evenness
+  const uint64_t own_lo = first_owned + chunk * (uint64_t)bpl;
+  uint64_t own_hi = own_lo + bpl;
+  if (own_hi > P.n_blocks) own_hi = P.n_blocks;
+  const bool has_chunk = chunk < P.n_chunks && own_lo < P.n_blocks;
+  const uint64_t blk0 = chunk_blk0(first_owned, bpl, back, chunk);
+
+  const uint64_t wave_blk0 = chunk_blk0(first_owned, bpl, back, wave_chunk0);
+  const uint8_t* text_base = P.text + wave_blk0 * 64;
+  uint32_t soff[kStageInstr];
+#pragma unroll
+  for (int i = 0; i < kStageInstr; ++i) {
+    const uint32_t owner = (uint32_t)i * kOwnersPerInstr + lane / kSlots;
+    const uint32_t slot = lane % kSlots;
+    const uint32_t j = slot ^ (SB == 2 ? ((owner >> 1) & 7u) : ((owner >> 2) & 3u));
+    soff[i] = (uint32_t)((chunk_blk0(first_owned, bpl, back, wave_chunk0 + owner) - wave_blk0) * 64) + j * 16u;
+  }
+  const uint64_t wave_last = chunk_blk0(first_owned, bpl, back, wave_chunk0 + 63) + P.n_iter + 2;
+  const bool interior = wave_last * 64 <= P.text_len;
+  const uint32_t fsw = SB == 2 ? ((lane >> 1) & 7u) : ((lane >> 2) & 3u);
+  uint32_t rc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rc[c] = lane * kRowBytes + (((uint32_t)c ^ (fsw & 3u)) << 4);
+
+  const uint32_t q = P.piece_len;
+  // ~P0 / ~P1 of every piece row as bit masks (bit j = row j of the piece), wave-uniform
+  uint32_t nb0[NP], nb1[NP];
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp) {
+    nb0[pp] = ~P.piece_bits[pp][0];
+    nb1[pp] = ~P.piece_bits[pp][1];
+  }
+  uint32_t prev0 = 0, prev1 = 0;  // high halves of the previous block's planes
+  unsigned long long nhits = 0;
+
+  for (uint32_t it = 0; it < P.n_iter; ++it) {
+    const uint32_t sub = SB == 2 ? (it & 1u) : 0u;
+    if (sub == 0) {
+      if (interior) {
+#pragma unroll
+        for (int i = 0; i < kStageInstr; ++i) {
+          const uint4 v = *reinterpret_cast<const uint4*>(text_base + (uint64_t)it * 64 + soff[i]);
+          *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < kStageInstr; ++i) {
+          const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
+          uint4 v;
+          if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
+          else v = load_tail16(P.text, off, P.text_len);
+          *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+        }
+      }
+    }
+    uint2 t0, t1;
+    {
+      const uint32_t hs = SB == 2 ? (((sub << 2) ^ (fsw & 4u)) << 4) : 0u;
+      uint32_t x[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + rc[c] + hs);
+        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+      }
+      t0 = bit_plane<1>(x);  // code bit 0
+      t1 = bit_plane<2>(x);  // code bit 1
+    }
+    uint32_t al[NP], ah[NP];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) { al[pp] = 0xFFFFFFFFu; ah[pp] = 0xFFFFFFFFu; }
+#pragma unroll
+    for (int d = 0; d < 12; ++d) {
+      if ((uint32_t)d < q) {  // wave-uniform
+        uint32_t s0l, s0h, s1l, s1h;
+        if (d == 0) {
+          s0l = t0.x; s0h = t0.y; s1l = t1.x; s1h = t1.y;
+        } else {
+          s0l = __builtin_amdgcn_alignbit(t0.x, prev0, 32 - d);
+          s0h = __builtin_amdgcn_alignbit(t0.y, t0.x, 32 - d);
+          s1l = __builtin_amdgcn_alignbit(t1.x, prev1, 32 - d);
+          s1h = __builtin_amdgcn_alignbit(t1.y, t1.x, 32 - d);
+        }
+        const uint32_t j = q - 1u - (uint32_t)d;  // the piece row whose char sits d bits left of the end
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+          const uint32_t n0 = 0u - ((nb0[pp] >> j) & 1u);
+          const uint32_t n1 = 0u - ((nb1[pp] >> j) & 1u);
+          al[pp] = bitop3<0x60>(al[pp], s0l, n0);  // a & (b ^ c)
+          ah[pp] = bitop3<0x60>(ah[pp], s0h, n0);
+          al[pp] = bitop3<0x60>(al[pp], s1l, n1);
+          ah[pp] = bitop3<0x60>(ah[pp], s1h, n1);
+        }
+      }
+    }
+    prev0 = t0.y;
+    prev1 = t1.y;
+    uint32_t hit = 0;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) hit |= al[pp] | ah[pp];
+    const uint64_t b = blk0 + it;
+    const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
+    if (evaluate && hit != 0) {
+      atomicOr(&P.hit_bitmap[b >> 6], 1ull << (b & 63));
+      nhits += 1;
+    }
+  }
+  // one atomic per wave
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) nhits += __shfl_xor(nhits, d);
+  if (lane == 0 && nhits) atomicAdd(P.hit_count, nhits);
+}
+
 // ====================================================================== K1-list: DP over a chunk list
 // Same DP, same report rule, same seam bookkeeping as scan_kernel, but every lane takes its chunk
 // (first block, end block, flags) from a descriptor list built from the prefilter's hit bitmap.
@@ -882,7 +1022,18 @@ static hipError_t launch_list_one(const ScanParams& P, uint32_t grid, size_t sme
 hipError_t launch_scan_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
   return launch_one<PROFILE_DNA, 4>(P, grid, smem, stream);
 }
+template <int SB, int NPG>
+static hipError_t launch_filter_planes(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL((filter_dna_kernel<SB, NPG>), dim3(grid), dim3(256), (size_t)kWavesPerGroup * P.lds_per_wave,
+                     stream, P);
+  return hipGetLastError();
+}
 hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  if (P.piece_planes) {  // <= 8 pieces: the bit-plane kernel (lds_per_wave = the staging tile only)
+    if (P.stage_blocks == 1)
+      return P.piece_groups == 1 ? launch_filter_planes<1, 1>(P, grid, stream) : launch_filter_planes<1, 2>(P, grid, stream);
+    return P.piece_groups == 1 ? launch_filter_planes<2, 1>(P, grid, stream) : launch_filter_planes<2, 2>(P, grid, stream);
+  }
   return launch_filter_one<PROFILE_DNA, 4>(P, grid, smem, stream);
 }
 hipError_t launch_list_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
