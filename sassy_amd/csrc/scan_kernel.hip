@@ -766,14 +766,24 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
   uint32_t prev0 = 0, prev1 = 0;  // high halves of the previous block's planes
   unsigned long long nhits = 0;
 
+  // software pipeline: the loads of the next staging step are in flight while this one is processed
+  uint4 nxt[kStageInstr];
+#pragma unroll
+  for (int i = 0; i < kStageInstr; ++i) {
+    nxt[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (interior) nxt[i] = *reinterpret_cast<const uint4*>(text_base + soff[i]);
+  }
+
   for (uint32_t it = 0; it < P.n_iter; ++it) {
     const uint32_t sub = SB == 2 ? (it & 1u) : 0u;
     if (sub == 0) {
       if (interior) {
 #pragma unroll
-        for (int i = 0; i < kStageInstr; ++i) {
-          const uint4 v = *reinterpret_cast<const uint4*>(text_base + (uint64_t)it * 64 + soff[i]);
-          *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+        for (int i = 0; i < kStageInstr; ++i) *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = nxt[i];
+        if (it + SB < P.n_iter) {
+#pragma unroll
+          for (int i = 0; i < kStageInstr; ++i)
+            nxt[i] = *reinterpret_cast<const uint4*>(text_base + (uint64_t)(it + SB) * 64 + soff[i]);
         }
       } else {
 #pragma unroll

@@ -27,7 +27,7 @@ for f in find("*counter_collection.csv"):
     with open(f) as fh:
         for row in csv.DictReader(fh):
             kn = row.get("Kernel_Name", "")
-            short = next((x for x in ("scan_kernel", "filter_kernel", "list_kernel") if x in kn), None)
+            short = next((x for x in ("scan_kernel", "filter_kernel", "filter_dna_kernel", "list_kernel") if x in kn), None)
             if short is None:
                 continue
             acc[(short, row["Counter_Name"])].append(float(row["Counter_Value"]))
@@ -48,8 +48,8 @@ for f in find("*counter_collection.csv"):
             if row["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
                 continue
             kn = row.get("Kernel_Name", "")
-            short = next((x for x in ("scan_kernel", "filter_kernel", "list_kernel", "trace_kernel",
-                                      "build_chunks_kernel") if x in kn), None)
+            short = next((x for x in ("scan_kernel", "filter_kernel", "filter_dna_kernel", "list_kernel",
+                                      "trace_kernel", "build_chunks_kernel", "rank_count_kernel") if x in kn), None)
             if short:
                 acc[(short, row["Counter_Name"])].append(float(row["Counter_Value"]))
     for (kn, c), v in acc.items():
