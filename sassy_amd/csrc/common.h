@@ -119,6 +119,7 @@ struct TraceParams {
   uint8_t* out_str;         // cand_cap * str_stride bytes: NUL-terminated cigar text per record
   uint32_t str_stride;      // >= 2*(m+k+1) + 2
   uint32_t* fail_count;     // device counter: reports whose traceback found no ancestor
+  uint32_t wave_mode;       // 1: trace_wave_kernel (one wavefront per report; slices are per wave)
 };
 
 }  // namespace sassy_hip

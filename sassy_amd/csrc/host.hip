@@ -342,13 +342,22 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     const uint64_t win = ((uint64_t)plan.m + k + 15 + 15) / 16 * 16;  // whole 16-byte chunks
     const uint64_t opsb = ((uint64_t)plan.m + k + 1 + 3) / 4 * 4;
     uint64_t stride = band + win + opsb;
-    if ((stride / 4) % 2 == 0) stride += 4;  // odd number of LDS words: conflict-free slices
+    // k > 6 with a band of at most 64 columns: one wavefront per report, four slices per workgroup
+    const uint64_t pat_bytes = ((uint64_t)plan.m + 15) / 16 * 16;
+    const bool wave_mode = k > 6 && 2ull * k + 3 <= 64 && pat_bytes + 4 * ((stride + 15) / 16 * 16) <= 160 * 1024;
+    if (wave_mode) stride = (stride + 15) / 16 * 16;
+    else if ((stride / 4) % 2 == 0) stride += 4;  // odd number of LDS words: conflict-free slices
     if (stride > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "pattern/k too large for the traceback band");
-    uint64_t nthreads = (256ull << 20) / stride;
-    nthreads = std::max<uint64_t>(64, std::min<uint64_t>(16384, nthreads)) / 64 * 64;
-    trace_blocks = (uint32_t)(nthreads / 64);
-    if (64 * stride + (plan.m + 15) / 16 * 16 > kTraceLdsLimit)  // slices in global memory
-      if (int rc = S->d_scratch.reserve(nthreads * stride)) return rc;
+    if (wave_mode) {
+      trace_blocks = 1024;  // 4096 wavefronts, grid-stride over the reports
+    } else {
+      uint64_t nthreads = (256ull << 20) / stride;
+      nthreads = std::max<uint64_t>(64, std::min<uint64_t>(16384, nthreads)) / 64 * 64;
+      trace_blocks = (uint32_t)(nthreads / 64);
+      if (64 * stride + pat_bytes > kTraceLdsLimit)  // slices in global memory
+        if (int rc = S->d_scratch.reserve(nthreads * stride)) return rc;
+    }
+    T.wave_mode = wave_mode ? 1u : 0u;
     T.band_bytes = (uint32_t)band;
     T.win_bytes = (uint32_t)win;
     T.text = sh.d_text;

@@ -260,6 +260,163 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
   }
 }
 
+// ---------------------------------------------------------------- wave-per-report variant
+// For wider bands (k > 6) one thread per report is a very long serial chain and its slice no
+// longer fits LDS.  Here a whole wavefront fills the band of one report: lane b owns band column b
+// (2k+3 <= 64 columns).  Within a row, cell b needs its left neighbour: v[b] = min(t[b], v[b-1]+1)
+// with t[b] = min(diag + neq, up + 1), which unrolls to v[b] = b + prefix-min over b' <= b of
+// (t[b'] - b') -- a 6-step DPP scan across the wave.  The diagonal neighbour is the lane's own
+// previous value, the upper neighbour the next lane's (DPP wave shift).  The walk and the cigar
+// text are wave-uniform (every lane follows the same path through LDS).
+__device__ __forceinline__ int dpp_min_scan(int x) {
+  constexpr int kId = 0x7FFFFFFF;
+  // inclusive prefix minimum over the 64 lanes (lanes without a source keep the identity)
+  x = min(x, __builtin_amdgcn_update_dpp(kId, x, 0x111, 0xF, 0xF, false));  // row_shr:1
+  x = min(x, __builtin_amdgcn_update_dpp(kId, x, 0x112, 0xF, 0xF, false));  // row_shr:2
+  x = min(x, __builtin_amdgcn_update_dpp(kId, x, 0x114, 0xF, 0xF, false));  // row_shr:4
+  x = min(x, __builtin_amdgcn_update_dpp(kId, x, 0x118, 0xF, 0xF, false));  // row_shr:8
+  x = min(x, __builtin_amdgcn_update_dpp(kId, x, 0x142, 0xA, 0xF, false));  // row_bcast:15 -> rows 1, 3
+  x = min(x, __builtin_amdgcn_update_dpp(kId, x, 0x143, 0xC, 0xF, false));  // row_bcast:31 -> rows 2, 3
+  return x;
+}
+
+template <typename Cell>
+__global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char trace_smem[];
+  uint32_t count = *P.cand_count;
+  if (count > P.cand_cap) count = P.cand_cap;
+  const int m = (int)P.m, k = (int)P.k;
+  const int bw = 2 * k + 3;  // <= 64
+  const int inf = k + 1;
+  const uint32_t fill = P.m + P.k;
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const CharRule rule = char_rule(P.profile);
+  // LDS: pattern codes (shared) | per wave: band rows | window | ops
+  unsigned char* spat = trace_smem;
+  const uint32_t pat_bytes = (P.m + 15u) & ~15u;
+  for (uint32_t x = threadIdx.x; x < P.m; x += blockDim.x) {
+    const uint32_t ch = P.pattern[x];
+    spat[x] = (unsigned char)(rule.iupac ? kIupacCode[ch & 31u] : ch);
+  }
+  __syncthreads();
+  unsigned char* slice = trace_smem + pat_bytes + (size_t)wave * P.scratch_stride;
+  Cell* L = reinterpret_cast<Cell*>(slice);
+  unsigned char* win = slice + P.band_bytes;
+  unsigned char* ops = slice + P.band_bytes + P.win_bytes;
+  const uint32_t n_waves = gridDim.x * 4;
+
+  for (uint32_t c = blockIdx.x * 4 + wave; c < count; c += n_waves) {
+    const Candidate cd = P.cand[c];                        // wave-uniform
+    const uint64_t e = cd.pos;
+    const uint64_t o = e > fill ? e - fill : 0;
+    const uint64_t we = e < P.total_len ? e : P.total_len;
+    const int wl = (int)(we - o);
+    {  // window -> LDS (coalesced bytes), Iupac letters -> base sets
+      const uint8_t* src = P.text + (o - P.global_offset);
+      for (int x = (int)lane; x < wl; x += 64) {
+        const uint32_t ch = src[x];
+        win[x] = (unsigned char)(rule.iupac ? kIupacCode[ch & 31u] : ch);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int dend = wl - m, dlo = dend - k - 1;
+    const int b = (int)lane;
+    const bool in_band = b < bw;
+    // ---- fill: row 0, then rows 1..m ----
+    int prev;
+    {
+      const int i = dlo + b;
+      prev = (!in_band || i < 0 || i > wl) ? inf : 0;
+      if (in_band) L[b] = (Cell)prev;
+    }
+    for (int j = 1; j <= m; ++j) {
+      const uint32_t pc = spat[j - 1];
+      const int i = j + dlo + b;
+      const bool valid = in_band && i >= 0 && i <= wl;
+      // upper neighbour (j-1, i) = band column b+1 of the previous row
+      const int up = __builtin_amdgcn_update_dpp(inf, prev, 0x130, 0xF, 0xF, false);  // wave_shl:1
+      int t = inf;
+      if (valid) {
+        if (i == 0) t = j < inf ? j : inf;
+        else {
+          const uint32_t tc = win[i - 1];
+          const int dg = prev + (rule_hit(rule, pc, tc, rule.emask) ? 0 : 1);
+          const int u = up + 1;
+          t = dg < u ? dg : u;
+        }
+      }
+      // left dependency: v[b] = b + min_{b' <= b} (t[b'] - b'); invalid cells carry a large value
+      int v = dpp_min_scan(valid ? t - b : 0x3FFFFFFF) + b;
+      v = (valid && v < inf) ? v : inf;
+      if (in_band) L[(size_t)j * bw + b] = (Cell)v;
+      prev = v;
+    }
+    // make the band and the window visible to every lane (same wave: LDS ops are in order, this
+    // only keeps the compiler from reordering)
+    __builtin_amdgcn_wave_barrier();
+    // ---- greedy walk from (m, wl), wave-uniform ----
+    int j = m, i = wl;
+    int g = (int)L[(size_t)m * bw + (k + 1)];
+    const int cost = g;
+    const uint32_t max_ops = P.m + P.k + 1;
+    uint32_t nops = 0;
+    bool ok = g <= k;
+    while (ok && j > 0) {
+      if (nops >= max_ops) { ok = false; break; }
+      const int bb = i - j - dlo;
+      const Cell* row = L + (size_t)j * bw;
+      const Cell* prow = row - bw;
+      const int diag = i > 0 ? (int)prow[bb] : inf;
+      if (diag == g && rule_hit(rule, spat[j - 1], win[i - 1], rule.mmask)) {
+        if (lane == 0) ops[nops] = '=';
+        ++nops; --j; --i; continue;
+      }
+      g -= 1;
+      if (g < 0) { ok = false; break; }
+      if (diag == g) { if (lane == 0) ops[nops] = 'X'; ++nops; --j; --i; continue; }
+      const int lft = (i > 0 && bb > 0) ? (int)row[bb - 1] : inf;
+      if (lft == g) { if (lane == 0) ops[nops] = 'D'; ++nops; --i; continue; }
+      const int up = (bb + 1 < bw) ? (int)prow[bb + 1] : inf;
+      if (up == g) { if (lane == 0) ops[nops] = 'I'; ++nops; --j; continue; }
+      ok = false;  // the reference panics here ("Trace failed! No ancestor found")
+    }
+    if (ok && g != 0) ok = false;
+    if (cost > cd.cost) ok = false;  // src/search.rs:1672-1685
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      if (!ok) atomicAdd(P.fail_count, 1u);
+      unsigned char* str = P.out_str + (uint64_t)c * P.str_stride;
+      uint32_t w = 0;
+      int idx = ok ? (int)nops - 1 : -1;
+      while (idx >= 0) {
+        const unsigned char op = ops[idx];
+        uint32_t run = 1;
+        while (idx - (int)run >= 0 && ops[idx - (int)run] == op) ++run;
+        idx -= (int)run;
+        uint32_t p10 = 1;
+        while (p10 * 10 <= run) p10 *= 10;
+        while (p10) { str[w++] = (unsigned char)('0' + run / p10); run %= p10; p10 /= 10; }
+        str[w++] = op;
+      }
+      str[w] = 0;
+      MatchOut r;
+      r.pattern_idx = 0;
+      r.text_idx = 0;
+      r.text_start = o + (uint64_t)i;
+      r.text_end = we;
+      r.pattern_start = 0;
+      r.pattern_end = P.m;
+      r.cost = cost;
+      r.strand = 0;
+      r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
+      r.cigar_off = c * P.str_stride;
+      r.cigar_len = w;
+      P.out[c] = r;
+    }
+    __builtin_amdgcn_wave_barrier();  // the slice is reused by the next report
+  }
+}
+
 template <typename Cell, bool IN_LDS, int KT>
 static void launch_one(const TraceParams& P, uint32_t nblocks, size_t lds, hipStream_t stream) {
   if (IN_LDS) {
@@ -274,6 +431,27 @@ static void launch_one(const TraceParams& P, uint32_t nblocks, size_t lds, hipSt
 }
 
 hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stream) {
+  if (P.wave_mode) {  // one wavefront per report (host checked 2k+3 <= 64 and the LDS budget)
+    const size_t lds = (size_t)((P.m + 15u) & ~15u) + (size_t)4 * P.scratch_stride;
+    if (P.k + 1 <= 255) {
+      static bool attr8 = false;
+      if (!attr8) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint8_t>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr8 = true;
+      }
+      hipLaunchKernelGGL((trace_wave_kernel<uint8_t>), dim3(nblocks), dim3(256), lds, stream, P);
+    } else {
+      static bool attr16 = false;
+      if (!attr16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint16_t>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr16 = true;
+      }
+      hipLaunchKernelGGL((trace_wave_kernel<uint16_t>), dim3(nblocks), dim3(256), lds, stream, P);
+    }
+    return hipGetLastError();
+  }
   // LDS mode: 64 slices + the pattern
   const size_t lds = (size_t)64 * P.scratch_stride + ((P.m + 15) / 16) * 16;
   const bool in_lds = lds <= kTraceLdsLimit;

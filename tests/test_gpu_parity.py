@@ -203,6 +203,42 @@ def test_long_pattern_iupac_config3_shape(sassy):
     assert_same(got, want)
 
 
+@pytest.mark.parametrize("profile", ["dna", "iupac"])
+def test_traceback_variants(sassy, profile):
+    """Every traceback kernel variant against the oracle: k = 0..6 (band row in registers),
+    k = 7..30 (one wavefront per report), k > 30 (generic per-thread band, LDS or global scratch),
+    including text-start / text-end windows and search_all (dense, adjacent reports)."""
+    rng = random.Random(7 if profile == "dna" else 8)
+    cases = [(12, 0), (16, 1), (20, 2), (24, 4), (33, 5), (40, 6), (40, 7), (64, 9), (90, 13),
+             (130, 20), (200, 30), (70, 31), (120, 35), (300, 30)]
+    for m, k in cases:
+        pat = bytes(rng.choice(b"ACGT") for _ in range(m))
+        if profile == "iupac" and m >= 20:
+            p = bytearray(pat)
+            p[3], p[m // 2], p[m - 2] = ord("N"), ord("R"), ord("y")
+            pat = bytes(p)
+        plain = bytes(c if c in b"ACGT" else 65 for c in pat.upper())
+        n = 6000 + 10 * m
+        text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        # a match cut by the text start, several inside, one cut by the text end
+        head = mutate(rng, plain, min(k, 2))[m // 3:]
+        text[0:len(head)] = head
+        at = 300
+        for q in range(6):
+            ins = mutate(rng, plain, min(k, q * max(1, k // 5)))
+            text[at:at + len(ins)] = ins
+            at += len(ins) + 200 + 97 * q
+        tail = mutate(rng, plain, min(k, 1))
+        text[n - len(tail):] = tail
+        tb = bytes(text[:n])
+        s = sassy.Searcher(profile, rc=False)
+        want = oracle.search(profile, pat, tb, k)
+        assert len(want) >= 4, (m, k)
+        assert_same(s.search(pat, tb, k), want)
+        if m <= 130:
+            assert_same(s.search_all(pat, tb, k), oracle.search(profile, pat, tb, k, all_minima=True))
+
+
 def test_config1_shape_1mib(sassy):
     """BASELINE config 1: 'ATCG'x8, k=3, 1 MiB random ACGT (+ plants), Dna, forward only."""
     pat = b"ATCG" * 8

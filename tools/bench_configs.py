@@ -1,0 +1,93 @@
+"""Timings of the BASELINE.json configs that are not the bench.py line (configs 1, 3, 4), on one GPU.
+
+bench.py measures config 2 (the configuration the metric is quoted on) under the driver's contract;
+this script reports the other single-GPU configurations with the same synthetic text so
+that DESIGN.md can state where they stand.  One JSON line per config.
+
+    python tools/bench_configs.py [--configs 1,3,4] [--text-bytes N] [--patterns P] [--steps K]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import sassy_amd  # noqa: E402
+
+
+def dna_bytes(seed: int, n: int) -> bytes:
+    rng = np.random.default_rng(seed)
+    return bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, n)])
+
+
+def timed(fn, steps):
+    fn()  # warm-up (allocations, first launch)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = fn()
+    return (time.perf_counter() - t0) / steps, r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--configs", default="1,3,4")
+    ap.add_argument("--text-bytes", type=int, default=3_000_000_000)
+    ap.add_argument("--patterns", type=int, default=10_000)
+    ap.add_argument("--steps", type=int, default=5)
+    args = ap.parse_args()
+    todo = [int(c) for c in args.configs.split(",")]
+    n = args.text_bytes
+    buf = sassy_amd.DeviceBuffer(n + 64)
+    sassy_amd.generate_dna(buf.ptr, n, 42, 0)
+
+    if 1 in todo:
+        # config 1: 'ATCG' x 8, k=3, 1 MiB random ACGT (the reference's own CPU-runnable case)
+        pat = b"ATCG" * 8
+        n1 = 1 << 20
+        s = sassy_amd.Searcher("dna", rc=False)
+        dt, r = timed(lambda: s.search_shard(pat, buf.ptr, 0, n1, 0, n1, 3), 50)
+        print(json.dumps({"config": 1, "workload": "Dna new_fwd, 'ATCG'x8, k=3, 1 MiB random ACGT (device resident)",
+                          "ms_per_search": round(dt * 1e3, 4), "GB_per_s": round(n1 / dt / 1e9, 2),
+                          "matches": len(r), "stats": {k: s.stats()[k] for k in ("scan_ms", "trace_ms", "filtered")}}))
+
+    if 3 in todo:
+        # config 3: |pattern| = 200 with 4 IUPAC letters, k = 20, Iupac profile
+        p = bytearray(dna_bytes(44, 200))
+        p[50], p[100], p[150], p[199] = ord("N"), ord("R"), ord("Y"), ord("W")
+        pat = bytes(p)
+        planted = sassy_amd.plant(buf.ptr, n, 0, n, 42, pat, 20)
+        s = sassy_amd.Searcher("iupac", rc=False)
+        dt, r = timed(lambda: s.search_shard(pat, buf.ptr, 0, n, 0, n, 20), args.steps)
+        st = s.stats()
+        print(json.dumps({"config": 3, "workload": f"Iupac new_fwd, |pattern|=200 (N,R,Y,W at 50/100/150/199), k=20, {n} B random ACGT + plants",
+                          "ms_per_search": round(dt * 1e3, 3), "GB_per_s": round(n / dt / 1e9, 2),
+                          "matches": len(r), "planted": planted,
+                          "stats": {k: st[k] for k in ("scan_ms", "filter_ms", "trace_ms", "filtered", "piece_len", "hit_blocks", "chunks")}}))
+        sassy_amd.generate_dna(buf.ptr, n, 42, 0)  # undo the plants
+
+    if 4 in todo:
+        # config 4: search_encoded_patterns, P random 20-mers, k = 2, Iupac searcher, fwd only
+        P = args.patterns
+        pats = [dna_bytes(45 + i, 20) for i in range(P)]
+        s = sassy_amd.Searcher("iupac", rc=False)
+        enc = s.encode_patterns(pats)
+        t0 = time.perf_counter()
+        out = sassy_amd.C.c_void_p()
+        sassy_amd._check(sassy_amd.lib().sassy_hip_search_encoded(s._h, enc._h, buf.ptr, n, 2, sassy_amd.TEXT_ON_DEVICE,
+                                                                  sassy_amd.C.byref(out)))
+        dt = time.perf_counter() - t0
+        r = sassy_amd.Result(out)
+        st = s.stats()
+        print(json.dumps({"config": 4, "workload": f"search_encoded_patterns, {P} random 20-mers, k=2, Iupac new_fwd, {n} B random ACGT",
+                          "seconds": round(dt, 3), "text_GB_per_s": round(n / dt / 1e9, 3),
+                          "pattern_text_GB_per_s": round(n * P / dt / 1e9, 1), "matches": len(r),
+                          "stats": {k: st[k] for k in ("scan_ms", "filter_ms", "trace_ms", "scan_launches")}}))
+
+
+if __name__ == "__main__":
+    main()
