@@ -190,9 +190,21 @@ def main():
     elapsed, scan_avg_ms, filter_avg_ms = float(el[0]), float(el[1]), float(el[2])
     filtered = bool(st["filtered"])
     # the dominant kernel: the prefilter scan when the pattern splits into selective pieces
-    # (every text byte is read once by it), else the streaming DP kernel
+    # (every text byte is read once by it), else the streaming DP kernel.  Its HIP events are the
+    # only ones recorded inside the timed region (timing level 1).
     dom_ms = filter_avg_ms if filtered else scan_avg_ms
-    dom_name = "filter_kernel" if filtered else "scan_kernel"
+    dom_name = {0: "scan_kernel", 1: "filter_kernel", 2: "filter_dna_kernel"}[int(st["filtered"])]
+    # phase breakdown from a few extra, untimed steps with every phase timed (more events = more
+    # stream idle time, so these are not part of the measurement above)
+    searcher.set_timing(2)
+    phase = {"scan_path_ms": 0.0, "trace_ms": 0.0}
+    n_extra = min(5, max(1, args.steps))
+    for _ in range(n_extra):
+        searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
+        st2 = searcher.stats()
+        phase["scan_path_ms"] += st2["scan_ms"] / n_extra
+        phase["trace_ms"] += st2["trace_ms"] / n_extra
+    searcher.set_timing(1)
 
     if rank != 0:
         if dist is not None:
@@ -241,11 +253,10 @@ def main():
         "matches": len(matches),
         "matches_per_s": round(len(matches) * args.steps / elapsed, 1),
         "planted_rank0": planted,
-        "scan_path_ms": round(scan_avg_ms, 4),
         "dominant_kernel_ms": round(dom_ms, 4),
+        "phases_untimed_ms": {"scan_path": round(phase["scan_path_ms"], 4), "rank_and_trace": round(phase["trace_ms"], 4)},
         "prefilter": {"enabled": filtered, "piece_len": st["piece_len"], "hit_blocks": st["hit_blocks"],
                       "chunks": st["chunks"]},
-        "trace_ms_per_step": round(trace_ms / args.steps, 4),
         "host_ms_per_step": {"enqueue": round(host[0] / args.steps, 4), "wait": round(host[1] / args.steps, 4),
                              "post": round(host[2] / args.steps, 4)},
         "c_abi_call_ms_per_step": round(call_ms / args.steps, 4),

@@ -48,8 +48,9 @@ typedef struct sassy_hip_Encoded sassy_hip_Encoded;     /* opaque EncodedPattern
 
 /* Per-call statistics of the last search on a searcher (for bench.py's roofline object). */
 typedef struct sassy_hip_Stats {
-  double scan_ms;        /* HIP-event time of the scan kernel launch(es), all strands */
-  double trace_ms;       /* HIP-event time of candidate gathering / traceback kernels */
+  double scan_ms;        /* HIP-event time of the scan path (filter + chunk list + DP, or the streaming
+                            scan), all strands; 0 unless timed (sassy_hip_set_timing) */
+  double trace_ms;       /* HIP-event time of report ranking + traceback kernels (timing level 2) */
   double total_ms;       /* host wall time of the whole call */
   uint64_t text_bytes;   /* algorithmic bytes scanned (text_len per strand) */
   uint64_t scan_launches;
@@ -61,7 +62,8 @@ typedef struct sassy_hip_Stats {
   uint32_t blocks_per_chunk;
   uint32_t warmup_blocks;
   uint32_t grid;
-  uint32_t filtered;     /* 1: prefilter -> chunk list -> DP on the listed chunks; 0: DP over every block */
+  uint32_t filtered;     /* 0: DP over every block (scan_kernel); 1: prefilter (filter_kernel) -> chunk list ->
+                            DP on the listed chunks; 2: the same with the Dna bit-plane prefilter (filter_dna_kernel) */
   double filter_ms;      /* HIP-event time of the prefilter kernel (part of scan_ms) */
   uint64_t hit_blocks;   /* text blocks in which an exact pattern piece ends */
   uint32_t piece_len;    /* rows per pattern piece (k+1 pieces), 0 when unfiltered */
@@ -80,6 +82,10 @@ sassy_SearcherType *sassy_hip_searcher_new(const char *alphabet, bool rc, float 
 /* Use an existing HIP stream (hipStream_t) for all work of this searcher; NULL = own stream. */
 int sassy_hip_set_stream(sassy_SearcherType *s, void *hip_stream);
 int sassy_hip_get_stats(const sassy_SearcherType *s, sassy_hip_Stats *out);
+/* HIP-event timing behind the stats: 0 = none, 1 = the dominant kernel only (prefilter, or the
+ * streaming scan when unfiltered; default), 2 = every phase (scan_ms, filter_ms, trace_ms).  Each
+ * recorded event costs a few microseconds of stream idle time. */
+int sassy_hip_set_timing(sassy_SearcherType *s, int level);
 /* Count DP word-rows / blocks in the scan kernel (stats.word_rows, stats.blocks); off by default. */
 int sassy_hip_enable_counters(sassy_SearcherType *s, int on);
 

@@ -100,7 +100,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_searcher_new", "sassy_hip_set_stream", "sassy_hip_get_stats",
     "sassy_hip_search", "sassy_hip_search_shard", "sassy_hip_required_halo",
     "sassy_hip_result_len", "sassy_hip_result_matches", "sassy_hip_result_cigars",
-    "sassy_hip_result_cigars_len", "sassy_hip_enable_counters",
+    "sassy_hip_result_cigars_len", "sassy_hip_enable_counters", "sassy_hip_set_timing",
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
     "sassy_hip_generate_dna", "sassy_hip_plant",
@@ -144,6 +144,8 @@ def lib():
     L.sassy_hip_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.sassy_hip_enable_counters.restype = C.c_int
     L.sassy_hip_enable_counters.argtypes = [vp, C.c_int]
+    L.sassy_hip_set_timing.restype = C.c_int
+    L.sassy_hip_set_timing.argtypes = [vp, C.c_int]
     L.sassy_hip_search.restype = C.c_int
     L.sassy_hip_search.argtypes = [vp, u8p, sz, vp, sz, sz, C.c_uint32, C.POINTER(vp)]
     L.sassy_hip_search_shard.restype = C.c_int
@@ -355,6 +357,10 @@ class Searcher:
 
     def set_stream(self, hip_stream_handle: int):
         _check(lib().sassy_hip_set_stream(self._h, hip_stream_handle or None))
+
+    def set_timing(self, level: int):
+        """0 = no HIP events, 1 = dominant kernel only (default), 2 = every phase."""
+        _check(lib().sassy_hip_set_timing(self._h, int(level)))
 
     def enable_counters(self, on: bool = True):
         _check(lib().sassy_hip_enable_counters(self._h, int(on)))

@@ -98,6 +98,7 @@ struct BuildParams {
   ChunkDesc* desc;
   uint32_t* desc_count;
   uint32_t desc_cap;
+  unsigned long long* hit_count;  // statistics: number of hit blocks (one atomic per workgroup)
 };
 
 __device__ __forceinline__ unsigned long long dilated_word(const BuildParams& P, long long w) {
@@ -117,12 +118,18 @@ __device__ __forceinline__ bool dilated_bit(const BuildParams& P, uint64_t blk) 
   return (dilated_word(P, (long long)(blk >> 6)) >> (blk & 63)) & 1ull;
 }
 
-__global__ __launch_bounds__(256) void build_chunks_kernel(const BuildParams P) {
-  __shared__ uint32_t wave_sum[4];
+// 1024-thread workgroups: the descriptor slots are claimed with ONE atomic per workgroup, and all
+// workgroups hit the same counter, so their number bounds the kernel's duration.
+constexpr int kBuildWaves = 16;
+__global__ __launch_bounds__(1024) void build_chunks_kernel(const BuildParams P) {
+  __shared__ uint32_t wave_sum[kBuildWaves];
+  __shared__ uint32_t wave_hits[kBuildWaves];
   __shared__ uint32_t group_base;
   const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long A = 0, prev_top = 0, starts = 0;
+  uint32_t my_hits = 0;
   if (w < P.n_words) {
+    my_hits = (uint32_t)__popcll(P.hit[w]);
     A = dilated_word(P, (long long)w);
     if (A) {
       prev_top = w > 0 ? (dilated_word(P, (long long)w - 1) >> 63) : 0ull;
@@ -144,11 +151,15 @@ __global__ __launch_bounds__(256) void build_chunks_kernel(const BuildParams P) 
     const uint32_t up = __shfl_up(incl, d);
     if (lane >= (uint32_t)d) incl += up;
   }
-  if (lane == 63) wave_sum[wv] = incl;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) my_hits += __shfl_xor(my_hits, d);
+  if (lane == 63) { wave_sum[wv] = incl; wave_hits[wv] = my_hits; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    uint32_t total = 0, hits = 0;
+    for (int v = 0; v < kBuildWaves; ++v) { total += wave_sum[v]; hits += wave_hits[v]; }
     group_base = total ? atomicAdd(P.desc_count, total) : 0u;
+    if (hits) atomicAdd(P.hit_count, (unsigned long long)hits);
   }
   __syncthreads();
   uint32_t idx = group_base + (incl - mine);
@@ -227,26 +238,39 @@ __global__ __launch_bounds__(256) void rank_count_kernel(const Candidate* __rest
   }
 }
 
+// Also the hand-over to the host: the first host_cap reports in result order and the 64-byte
+// control block (counts, counters -- final once this kernel runs) are written straight into the
+// caller's pinned, device-mapped staging buffer, so that no copy has to be queued behind the kernels.
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const Candidate* __restrict__ cand,
                                                            const uint32_t* __restrict__ count_p, uint32_t cap,
                                                            const uint32_t* __restrict__ rank,
-                                                           Candidate* __restrict__ sorted) {
+                                                           Candidate* __restrict__ sorted,
+                                                           Candidate* __restrict__ host_sorted, uint32_t host_cap,
+                                                           uint4* __restrict__ host_ctl) {
   uint32_t count = *count_p;
+  if (blockIdx.x == 0 && threadIdx.x < 4 && host_ctl)
+    host_ctl[threadIdx.x] = reinterpret_cast<const uint4*>(count_p)[threadIdx.x];
   if (count > cap) count = cap;
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= count) return;
-  sorted[count > kRankLimit ? c : rank[c]] = cand[c];
+  const uint32_t r = count > kRankLimit ? c : rank[c];
+  const Candidate v = cand[c];
+  sorted[r] = v;
+  if (r < host_cap) host_sorted[r] = v;
 }
 
 // ------------------------------------------------------------------ launchers
 // d_rank: cap zeroed counters (zeroed by the caller together with its control block).
+// h_sorted / h_ctl: device-mapped pinned host memory (first host_cap sorted reports, 64-byte
+// control block); d_count points at the control block.
 hipError_t launch_rank(const Candidate* d_cand, const uint32_t* d_count, uint32_t cap, uint32_t* d_rank,
-                       Candidate* d_sorted, hipStream_t stream) {
+                       Candidate* d_sorted, Candidate* h_sorted, uint32_t host_cap, void* h_ctl,
+                       hipStream_t stream) {
   if (cap == 0) return hipSuccess;
   // the count lives on the device: fixed grid, surplus workgroups exit at once
   hipLaunchKernelGGL(rank_count_kernel, dim3(1024), dim3(256), 0, stream, d_cand, d_count, cap, d_rank);
   hipLaunchKernelGGL(rank_scatter_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, d_cand, d_count, cap,
-                     d_rank, d_sorted);
+                     d_rank, d_sorted, h_sorted, host_cap, reinterpret_cast<uint4*>(h_ctl));
   return hipGetLastError();
 }
 
@@ -279,12 +303,13 @@ hipError_t launch_reverse(const uint8_t* d_in, uint8_t* d_out, uint64_t n, hipSt
 hipError_t launch_build_chunks(const unsigned long long* d_hit, uint64_t n_words, uint64_t n_blocks,
                                uint64_t first_owned, uint32_t wb, uint32_t L, uint32_t maxlen,
                                ChunkDesc* d_desc, uint32_t* d_desc_count, uint32_t desc_cap,
-                               hipStream_t stream) {
+                               unsigned long long* d_hit_count, hipStream_t stream) {
   if (n_words == 0) return hipSuccess;
   BuildParams P;
   P.hit = d_hit; P.n_words = n_words; P.n_blocks = n_blocks; P.first_owned = first_owned;
   P.wb = wb; P.L = L; P.maxlen = maxlen; P.desc = d_desc; P.desc_count = d_desc_count; P.desc_cap = desc_cap;
-  hipLaunchKernelGGL(build_chunks_kernel, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, stream, P);
+  P.hit_count = d_hit_count;
+  hipLaunchKernelGGL(build_chunks_kernel, dim3((uint32_t)((n_words + 1023) / 1024)), dim3(1024), 0, stream, P);
   return hipGetLastError();
 }
 

@@ -112,14 +112,20 @@ struct TraceParams {
   uint32_t profile;
   const uint8_t* pattern;   // device copy of the (strand-specific) pattern
   uint8_t* scratch;         // nthreads * scratch_stride bytes (used when the slices do not fit LDS)
-  uint32_t scratch_stride;  // bytes per thread: band | window | ops
+  uint32_t scratch_stride;  // bytes per thread: band | window | ops | cigar text
   uint32_t band_bytes;      // (m+1) * (2k+3) * sizeof(cell), rounded up to 4
   uint32_t win_bytes;       // m+k rounded up to 4
   MatchOut* out;            // cand_cap records
   uint8_t* out_str;         // cand_cap * str_stride bytes: NUL-terminated cigar text per record
   uint32_t str_stride;      // >= 2*(m+k+1) + 2
-  uint32_t* fail_count;     // device counter: reports whose traceback found no ancestor
+  uint32_t ops_bytes;       // m+k+1 rounded up to 4; the slice ends with str_stride bytes of cigar text
   uint32_t wave_mode;       // 1: trace_wave_kernel (one wavefront per report; slices are per wave)
+  // the first host_cap records also go straight to device-mapped pinned host memory
+  MatchOut* host_out;
+  uint8_t* host_str;
+  uint32_t host_cap;
 };
+// MatchOut::pad_[0] of a record whose traceback found no ancestor / exceeded the scanned cost
+constexpr uint8_t kTraceFailed = 1;
 
 }  // namespace sassy_hip

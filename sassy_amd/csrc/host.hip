@@ -36,14 +36,15 @@ hipError_t launch_list_ascii(const ScanParams& P, uint32_t grid, size_t smem, hi
 hipError_t launch_build_chunks(const unsigned long long* d_hit, uint64_t n_words, uint64_t n_blocks,
                                uint64_t first_owned, uint32_t wb, uint32_t L, uint32_t maxlen,
                                ChunkDesc* d_desc, uint32_t* d_desc_count, uint32_t desc_cap,
-                               hipStream_t stream);
+                               unsigned long long* d_hit_count, hipStream_t stream);
 hipError_t launch_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first, hipStream_t stream);
 hipError_t launch_scatter_bytes(uint8_t* d_text, uint64_t n, uint64_t first, const uint64_t* d_pos,
                                 const uint8_t* d_val, uint64_t count, hipStream_t stream);
 hipError_t launch_reverse(const uint8_t* d_in, uint8_t* d_out, uint64_t n, hipStream_t stream);
 hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stream);
 hipError_t launch_rank(const Candidate* d_cand, const uint32_t* d_count, uint32_t cap, uint32_t* d_rank,
-                       Candidate* d_sorted, hipStream_t stream);
+                       Candidate* d_sorted, Candidate* h_sorted, uint32_t host_cap, void* h_ctl,
+                       hipStream_t stream);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -120,8 +121,12 @@ struct sassy_SearcherType {
   DevBuf<Candidate> d_cand, d_sorted;
   DevBuf<MatchOut> d_trace;
   DevBuf<ChunkDesc> d_desc;
-  DevBuf<unsigned long long> d_counters, d_bitmap;
+
   bool want_counters = false;
+  // HIP-event timing of the call's phases: 0 none, 1 the dominant kernel only (filter / streaming
+  // scan; default), 2 every phase.  Each event record costs a few microseconds of stream idle time.
+  int timing = getenv("SASSY_HIP_TIMING") ? atoi(getenv("SASSY_HIP_TIMING")) : 1;
+  unsigned char* h_pin_dev = nullptr;  // device address of h_pin (kernels write results into it)
   sassy_hip_Stats stats{};
   // pinned host staging area: counts, counters and the first kSpec reports of a call arrive with
   // one batch of async copies in front of the single stream synchronisation
@@ -132,8 +137,10 @@ struct sassy_SearcherType {
     if (h_pin) (void)hipHostFree(h_pin);
     h_pin = nullptr;
     h_pin_cap = 0;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h_pin), bytes, hipHostMallocDefault);
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h_pin), bytes, hipHostMallocMapped);
     if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h_pin_dev), h_pin, 0);
+    if (e != hipSuccess) return hip_fail(e, "hipHostGetDevicePointer");
     h_pin_cap = bytes;
     return 0;
   }
@@ -142,7 +149,7 @@ struct sassy_SearcherType {
     d_text.release(); d_rev.release(); d_state.release(); d_pattern.release(); d_scratch.release();
     d_str.release(); d_rowoff.release(); d_ctl.release(); d_cand.release(); d_sorted.release();
     d_trace.release();
-    d_counters.release(); d_desc.release(); d_bitmap.release();
+    d_desc.release();
     if (h_pin) (void)hipHostFree(h_pin);
     if (ev_f) (void)hipEventDestroy(ev_f);
     if (ev_a) (void)hipEventDestroy(ev_a);
@@ -322,9 +329,15 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       HIP_TRY(hipMemcpyAsync(S->d_pattern.p, S->up_pattern.data(), plan.m, hipMemcpyHostToDevice, S->stream));
     }
   }
-  // control block: [0] candidates, [1] descriptors (u32) | +16 B: counters [0] word rows
-  // [1] blocks [2] hit blocks (u64): one memset, one copy back
-  if (int rc = S->d_ctl.reserve(64)) return rc;
+  // One zero-initialised device area per call, cleared by a single memset:
+  //   [0, 64)   control block: u32 [0] reports, [1] chunk descriptors | +16: u64 counters
+  //             [0] word rows, [1] blocks, [2] hit blocks
+  //   [64, ..)  rank counters of the first kRankLimit reports
+  //   [kCtlHead, ..)  the prefilter's hit bitmap (one bit per text block)
+  constexpr size_t kCtlHead = 64 + 4 * (size_t)kRankLimit;
+  const uint64_t n_words = filtered ? (n_blocks + 63) / 64 : 0;
+  if (int rc = S->d_ctl.reserve(kCtlHead + (filtered ? (n_words + 2) * 8 : 0))) return rc;
+  unsigned long long* d_bitmap = reinterpret_cast<unsigned long long*>(S->d_ctl.p + kCtlHead);
   if (S->d_cand.cap == 0)
     if (int rc = S->d_cand.reserve(1u << 16)) return rc;
   uint32_t* d_counts = reinterpret_cast<uint32_t*>(S->d_ctl.p);
@@ -341,7 +354,8 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     const uint64_t band = ((uint64_t)(plan.m + 1) * (2ull * k + 3) * cell + 3) / 4 * 4;
     const uint64_t win = ((uint64_t)plan.m + k + 15 + 15) / 16 * 16;  // whole 16-byte chunks
     const uint64_t opsb = ((uint64_t)plan.m + k + 1 + 3) / 4 * 4;
-    uint64_t stride = band + win + opsb;
+    const uint64_t strb = ((2ull * (plan.m + k + 1) + 2 + 15) / 16 * 16);  // = T.str_stride
+    uint64_t stride = band + win + opsb + strb;
     // k > 6 with a band of at most 64 columns: one wavefront per report, four slices per workgroup
     const uint64_t pat_bytes = ((uint64_t)plan.m + 15) / 16 * 16;
     const bool wave_mode = k > 6 && 2ull * k + 3 <= 64 && pat_bytes + 4 * ((stride + 15) / 16 * 16) <= 160 * 1024;
@@ -371,7 +385,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     T.scratch = S->d_scratch.p;
     T.scratch_stride = (uint32_t)stride;
     T.str_stride = (2 * (plan.m + k + 1) + 2 + 15) / 16 * 16;
-    T.fail_count = d_counts + 2;
+    T.ops_bytes = (uint32_t)opsb;
   }
 
   // ---- geometry of the streaming kernel (full DP, or the prefilter) ----
@@ -379,7 +393,6 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   ScanParams F = P;           // prefilter launch
   uint32_t fgrid = 0;
   const uint32_t maxlen = 128;  // list mode: longest chunk in blocks (long runs are cut)
-  uint64_t n_words = 0;
   if (!filtered) {
     if (int rc = stream_geometry(P, owned, P.wb, &grid)) return rc;
     P.lds_per_wave = 4096u * P.stage_blocks + bucket * 512u + plan.nwords * 512u;
@@ -429,11 +442,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     F.stage_blocks = env_fsb == 1 || env_fsb == 2 ? (uint32_t)env_fsb : 2u;
     if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, 1, &fgrid)) return rc;
     F.lds_per_wave = 4096u * F.stage_blocks + (F.piece_planes ? 0u : 2u * bucket * 512u);
-    n_words = (n_blocks + 63) / 64;
-    if (int rc = S->d_bitmap.reserve(n_words + 2)) return rc;
-    F.hit_bitmap = S->d_bitmap.p;
-    F.hit_count = d_counters + 2;
-    HIP_TRY(hipMemsetAsync(S->d_bitmap.p, 0, (n_words + 2) * sizeof(unsigned long long), S->stream));
+    F.hit_bitmap = d_bitmap;
     if (S->d_desc.cap == 0)
       if (int rc = S->d_desc.reserve(1u << 18)) return rc;
     P.lds_per_wave = bucket * 512u + plan.nwords * 512u;
@@ -448,7 +457,8 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   const size_t pin_recs = pin_cands + (size_t)kSpec * sizeof(Candidate);
   const size_t pin_ops = pin_recs + (size_t)kSpec * sizeof(MatchOut);
   if (int rc = S->reserve_pinned(pin_ops + (size_t)kSpec * (do_trace ? T.str_stride : 0) + 64)) return rc;
-  uint32_t counts[3] = {0, 0, 0};  // reports, chunk descriptors, failed tracebacks
+  uint32_t counts[2] = {0, 0};  // reports, chunk descriptors
+  const int timing = S->timing;
   uint32_t desc_cap = 0;
   for (int attempt = 0; attempt < 4; ++attempt) {
     P.cand = S->d_cand.p;
@@ -464,19 +474,9 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       T.out = S->d_trace.p;
       T.out_str = S->d_str.p;
     }
-    // the control block and the rank counters of the reports (capped: beyond kRankLimit reports
-    // the host sorts) are zeroed together
-    const size_t n_rank = std::min<size_t>(P.cand_cap, kRankLimit);
-    if (int rc = S->d_ctl.reserve(64 + 4 * n_rank)) return rc;
-    d_counts = reinterpret_cast<uint32_t*>(S->d_ctl.p);
-    d_counters = reinterpret_cast<unsigned long long*>(S->d_ctl.p + 16);
-    P.cand_count = d_counts;
-    P.counters = S->want_counters ? d_counters : nullptr;
-    T.cand_count = d_counts;
-    T.fail_count = d_counts + 2;
-    F.hit_count = d_counters + 2;
-    HIP_TRY(hipMemsetAsync(S->d_ctl.p, 0, 64 + 4 * n_rank, S->stream));
-    HIP_TRY(hipEventRecord(S->ev_a, S->stream));
+    // control block, rank counters and (first attempt: the filter runs once) the hit bitmap
+    HIP_TRY(hipMemsetAsync(S->d_ctl.p, 0, kCtlHead + (filtered && attempt == 0 ? (n_words + 2) * 8 : 0), S->stream));
+    if (timing >= 1) HIP_TRY(hipEventRecord(S->ev_a, S->stream));
     hipError_t le;
     if (!filtered) {
       le = launch_scan_any(S->profile, P, grid, (size_t)kWavesPerGroup * P.lds_per_wave, S->stream);
@@ -486,12 +486,12 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
         le = launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, S->stream);
         if (le != hipSuccess) return hip_fail(le, "filter kernel launch");
       }
-      HIP_TRY(hipEventRecord(S->ev_f, S->stream));
+      if (timing >= 1 && attempt == 0) HIP_TRY(hipEventRecord(S->ev_f, S->stream));
       desc_cap = (uint32_t)std::min<size_t>(S->d_desc.cap, 0x7FFFFFFFu);
       if (int rc = S->d_state.reserve(desc_cap)) return rc;
       P.chunk_state = S->d_state.p;
-      le = launch_build_chunks(S->d_bitmap.p, n_words, n_blocks, first_owned, P.wb, P.wb, maxlen, S->d_desc.p,
-                               d_counts + 1, desc_cap, S->stream);
+      le = launch_build_chunks(d_bitmap, n_words, n_blocks, first_owned, P.wb, P.wb, maxlen, S->d_desc.p,
+                               d_counts + 1, desc_cap, d_counters + 2, S->stream);
       if (le != hipSuccess) return hip_fail(le, "chunk builder launch");
       P.desc = S->d_desc.p;
       P.desc_count = d_counts + 1;
@@ -501,27 +501,24 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       le = launch_list_any(S->profile, P, lgrid, (size_t)kWavesPerGroup * P.lds_per_wave, S->stream);
       if (le != hipSuccess) return hip_fail(le, "list kernel launch");
     }
-    HIP_TRY(hipEventRecord(S->ev_b, S->stream));
-    // reports into result order (by end position), then their traceback
+    const bool ev_scan = timing >= 2 || (timing == 1 && !filtered);
+    if (ev_scan) HIP_TRY(hipEventRecord(S->ev_b, S->stream));
+    // reports into result order (by end position) -- the head of the list and the control block
+    // straight into the pinned host buffer --, then their traceback
+    const uint32_t host_cap = std::min<uint32_t>(kSpec, P.cand_cap);
     le = launch_rank(S->d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(S->d_ctl.p + 64),
-                     S->d_sorted.p, S->stream);
+                     S->d_sorted.p, reinterpret_cast<Candidate*>(S->h_pin_dev + pin_cands), host_cap,
+                     S->h_pin_dev + kPinCounts, S->stream);
     if (le != hipSuccess) return hip_fail(le, "rank kernel launch");
     if (do_trace) {
+      T.host_out = reinterpret_cast<MatchOut*>(S->h_pin_dev + pin_recs);
+      T.host_str = S->h_pin_dev + pin_ops;
+      T.host_cap = host_cap;
       le = launch_trace(T, trace_blocks, S->stream);
       if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
-      HIP_TRY(hipEventRecord(S->ev_c, S->stream));
+      if (timing >= 2) HIP_TRY(hipEventRecord(S->ev_c, S->stream));
     }
-    // one batch of async copies into pinned memory, then the only synchronisation of the call
-    {
-      unsigned char* hp = S->h_pin;
-      HIP_TRY(hipMemcpyAsync(hp + kPinCounts, S->d_ctl.p, 64, hipMemcpyDeviceToHost, S->stream));
-      const uint32_t spec = std::min<uint32_t>(kSpec, P.cand_cap);
-      HIP_TRY(hipMemcpyAsync(hp + pin_cands, S->d_sorted.p, (size_t)spec * sizeof(Candidate), hipMemcpyDeviceToHost, S->stream));
-      if (do_trace) {
-        HIP_TRY(hipMemcpyAsync(hp + pin_recs, S->d_trace.p, (size_t)spec * sizeof(MatchOut), hipMemcpyDeviceToHost, S->stream));
-        HIP_TRY(hipMemcpyAsync(hp + pin_ops, S->d_str.p, (size_t)spec * T.str_stride, hipMemcpyDeviceToHost, S->stream));
-      }
-    }
+    // the only synchronisation of the call; the kernels have written the results into h_pin
     const double t_sync0 = now_ms();
     HIP_TRY(hipStreamSynchronize(S->stream));
     const double t_sync1 = now_ms();
@@ -531,14 +528,16 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     g_marks.start();
     memcpy(counts, S->h_pin + kPinCounts, sizeof counts);
     float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_b));
-    S->stats.scan_ms += ms;
+    if (ev_scan) {
+      HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_b));
+      S->stats.scan_ms += ms;
+    }
     S->stats.scan_launches += 1;
-    if (filtered && attempt == 0) {
+    if (filtered && attempt == 0 && timing >= 1) {
       HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_f));
       S->stats.filter_ms += ms;
     }
-    if (do_trace) {
+    if (do_trace && timing >= 2) {
       HIP_TRY(hipEventElapsedTime(&ms, S->ev_b, S->ev_c));
       S->stats.trace_ms += ms;
     }
@@ -562,7 +561,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   S->stats.warmup_blocks = P.wb;
   S->stats.grid = filtered ? fgrid : grid;
   S->stats.text_bytes += sh.text_len - sh.halo_len;
-  S->stats.filtered = filtered ? 1 : 0;
+  S->stats.filtered = filtered ? (F.piece_planes ? 2u : 1u) : 0u;
   S->stats.piece_len = q;
   {
     unsigned long long c[4];
@@ -572,9 +571,6 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     S->stats.hit_blocks += c[2];
   }
 
-  if (do_trace && counts[2] != 0)
-    // the reference asserts both conditions (src/search.rs:1672-1685) and panics in get_trace
-    return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
   out.cands.resize(count);
   if (count) {
     const uint32_t have = std::min<uint32_t>(count, kSpec);
@@ -594,6 +590,11 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     }
   }
   g_marks.mark("copy out");
+  if (do_trace)
+    for (const sassy_hip_Match& r : out.matches)
+      if (r.pad_[0] == kTraceFailed)
+        // the reference asserts both conditions (src/search.rs:1672-1685) and panics in get_trace
+        return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
   if (count > kRankLimit) {
     // too many reports for the device ranking pass: they arrived in append order, sort here
     std::vector<uint32_t> order(count);
@@ -889,6 +890,12 @@ int sassy_hip_get_stats(const sassy_SearcherType* s, sassy_hip_Stats* out) {
 int sassy_hip_enable_counters(sassy_SearcherType* s, int on) {
   if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
   s->want_counters = on != 0;
+  return 0;
+}
+
+int sassy_hip_set_timing(sassy_SearcherType* s, int level) {
+  if (!s || level < 0 || level > 2) return fail(SASSY_HIP_EINVAL, "timing level must be 0, 1 or 2");
+  s->timing = level;
   return 0;
 }
 

@@ -599,7 +599,6 @@ __global__ __launch_bounds__(256) void filter_kernel(const ScanParams P) {
   for (int c = 0; c < 4; ++c) rc[c] = lane * kRowBytes + (((uint32_t)c ^ (fsw & 3u)) << 4);
 
   const uint32_t q = P.piece_len;
-  unsigned long long nhits = 0;
 
   for (uint32_t it = 0; it < P.n_iter; ++it) {
     const uint32_t sub = SB == 2 ? (it & 1u) : 0u;
@@ -694,13 +693,8 @@ __global__ __launch_bounds__(256) void filter_kernel(const ScanParams P) {
     const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
     if (evaluate && (hl | hh) != 0) {
       atomicOr(&P.hit_bitmap[b >> 6], 1ull << (b & 63));
-      nhits += 1;
     }
   }
-  // one atomic per wave
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) nhits += __shfl_xor(nhits, d);
-  if (lane == 0 && nhits) atomicAdd(P.hit_count, nhits);
 }
 
 // ====================================================================== K0 for Dna: bit planes only
@@ -764,7 +758,6 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
     nb1[pp] = ~P.piece_bits[pp][1];
   }
   uint32_t prev0 = 0, prev1 = 0;  // high halves of the previous block's planes
-  unsigned long long nhits = 0;
 
   // software pipeline: the loads of the next staging step are in flight while this one is processed
   uint4 nxt[kStageInstr];
@@ -844,13 +837,8 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
     const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
     if (evaluate && hit != 0) {
       atomicOr(&P.hit_bitmap[b >> 6], 1ull << (b & 63));
-      nhits += 1;
     }
   }
-  // one atomic per wave
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) nhits += __shfl_xor(nhits, d);
-  if (lane == 0 && nhits) atomicAdd(P.hit_count, nhits);
 }
 
 // ====================================================================== K1-list: DP over a chunk list

@@ -82,6 +82,42 @@ __device__ __forceinline__ uint32_t load_window(const uint8_t* text, uint64_t o_
   return skew;
 }
 
+// Cigar text of a finished walk into `sbuf` (slice memory): run-length encoded, start -> end
+// (pa-types' Cigar::to_string form).  Returns its length; the text is NUL-padded to a dword.
+__device__ __forceinline__ uint32_t rle_text(const unsigned char* ops, uint32_t nops, bool ok, unsigned char* sbuf) {
+  uint32_t w = 0;
+  int idx = ok ? (int)nops - 1 : -1;
+  while (idx >= 0) {
+    const unsigned char op = ops[idx];
+    uint32_t run = 1;
+    while (idx - (int)run >= 0 && ops[idx - (int)run] == op) ++run;
+    idx -= (int)run;
+    uint32_t p10 = 1;
+    while (p10 * 10 <= run) p10 *= 10;
+    while (p10) { sbuf[w++] = (unsigned char)('0' + run / p10); run %= p10; p10 /= 10; }
+    sbuf[w++] = op;
+  }
+  sbuf[w] = 0; sbuf[w + 1] = 0; sbuf[w + 2] = 0; sbuf[w + 3] = 0;
+  return w;
+}
+__device__ __forceinline__ MatchOut make_row(const TraceParams& P, uint32_t c, uint64_t text_start, uint64_t text_end,
+                                             int cost, uint32_t len, bool ok) {
+  MatchOut r;
+  r.pattern_idx = 0;
+  r.text_idx = 0;
+  r.text_start = text_start;
+  r.text_end = text_end;
+  r.pattern_start = 0;
+  r.pattern_end = P.m;
+  r.cost = cost;
+  r.strand = 0;
+  r.pad_[0] = ok ? 0 : kTraceFailed;
+  r.pad_[1] = r.pad_[2] = 0;
+  r.cigar_off = c * P.str_stride;
+  r.cigar_len = len;
+  return r;
+}
+
 // KT >= 0: k is the compile-time constant KT (band row in registers); KT < 0: any k.
 template <typename Cell, bool IN_LDS, int KT>
 __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
@@ -226,37 +262,21 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
     // the reference asserts that the traced cost does not exceed the scanned one
     // (src/search.rs:1672-1685)
     if (cost > cd.cost) ok = false;
-    if (!ok) atomicAdd(P.fail_count, 1u);
 
-    // ---- run-length encoded cigar text, start -> end ----
-    unsigned char* str = P.out_str + (uint64_t)c * P.str_stride;
-    uint32_t w = 0;
-    int idx = ok ? (int)nops - 1 : -1;
-    while (idx >= 0) {
-      const unsigned char op = ops[idx];
-      uint32_t run = 1;
-      while (idx - (int)run >= 0 && ops[idx - (int)run] == op) ++run;
-      idx -= (int)run;
-      uint32_t p10 = 1;
-      while (p10 * 10 <= run) p10 *= 10;
-      while (p10) { str[w++] = (unsigned char)('0' + run / p10); run %= p10; p10 /= 10; }
-      str[w++] = op;
-    }
-    str[w] = 0;
-
-    MatchOut r;
-    r.pattern_idx = 0;
-    r.text_idx = 0;
-    r.text_start = o + (uint64_t)i;
-    r.text_end = we;
-    r.pattern_start = 0;
-    r.pattern_end = P.m;
-    r.cost = cost;
-    r.strand = 0;
-    r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
-    r.cigar_off = c * P.str_stride;
-    r.cigar_len = w;
+    // ---- cigar text and the finished row, to the device arrays and (head of the list) the host ----
+    unsigned char* sbuf = ops + P.ops_bytes;
+    const uint32_t w = rle_text(ops, nops, ok, sbuf);
+    const MatchOut r = make_row(P, c, o + (uint64_t)i, we, cost, w, ok);
+    const uint32_t ndw = w / 4 + 1;
+    uint32_t* dstr = reinterpret_cast<uint32_t*>(P.out_str + (uint64_t)c * P.str_stride);
+    const uint32_t* ssrc = reinterpret_cast<const uint32_t*>(sbuf);
+    for (uint32_t x = 0; x < ndw; ++x) dstr[x] = ssrc[x];
     P.out[c] = r;
+    if (c < P.host_cap) {
+      uint32_t* hstr = reinterpret_cast<uint32_t*>(P.host_str + (uint64_t)c * P.str_stride);
+      for (uint32_t x = 0; x < ndw; ++x) hstr[x] = ssrc[x];
+      P.host_out[c] = r;
+    }
   }
 }
 
@@ -383,35 +403,26 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
     if (ok && g != 0) ok = false;
     if (cost > cd.cost) ok = false;  // src/search.rs:1672-1685
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-      if (!ok) atomicAdd(P.fail_count, 1u);
-      unsigned char* str = P.out_str + (uint64_t)c * P.str_stride;
-      uint32_t w = 0;
-      int idx = ok ? (int)nops - 1 : -1;
-      while (idx >= 0) {
-        const unsigned char op = ops[idx];
-        uint32_t run = 1;
-        while (idx - (int)run >= 0 && ops[idx - (int)run] == op) ++run;
-        idx -= (int)run;
-        uint32_t p10 = 1;
-        while (p10 * 10 <= run) p10 *= 10;
-        while (p10) { str[w++] = (unsigned char)('0' + run / p10); run %= p10; p10 /= 10; }
-        str[w++] = op;
+    unsigned char* sbuf = ops + P.ops_bytes;
+    uint32_t w = 0;
+    if (lane == 0) w = rle_text(ops, nops, ok, sbuf);
+    w = __builtin_amdgcn_readfirstlane(w);
+    __builtin_amdgcn_wave_barrier();
+    {
+      const uint32_t ndw = w / 4 + 1;
+      const uint32_t* ssrc = reinterpret_cast<const uint32_t*>(sbuf);
+      uint32_t* dstr = reinterpret_cast<uint32_t*>(P.out_str + (uint64_t)c * P.str_stride);
+      uint32_t* hstr = reinterpret_cast<uint32_t*>(P.host_str + (uint64_t)c * P.str_stride);
+      for (uint32_t x = lane; x < ndw; x += 64) {
+        const uint32_t v = ssrc[x];
+        dstr[x] = v;
+        if (c < P.host_cap) hstr[x] = v;
       }
-      str[w] = 0;
-      MatchOut r;
-      r.pattern_idx = 0;
-      r.text_idx = 0;
-      r.text_start = o + (uint64_t)i;
-      r.text_end = we;
-      r.pattern_start = 0;
-      r.pattern_end = P.m;
-      r.cost = cost;
-      r.strand = 0;
-      r.pad_[0] = r.pad_[1] = r.pad_[2] = 0;
-      r.cigar_off = c * P.str_stride;
-      r.cigar_len = w;
-      P.out[c] = r;
+      if (lane == 0) {
+        const MatchOut r = make_row(P, c, o + (uint64_t)i, we, cost, w, ok);
+        P.out[c] = r;
+        if (c < P.host_cap) P.host_out[c] = r;
+      }
     }
     __builtin_amdgcn_wave_barrier();  // the slice is reused by the next report
   }
