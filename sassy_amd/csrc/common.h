@@ -120,6 +120,7 @@ struct TraceParams {
   uint32_t str_stride;      // >= 2*(m+k+1) + 2
   uint32_t ops_bytes;       // m+k+1 rounded up to 4; the slice ends with str_stride bytes of cigar text
   uint32_t wave_mode;       // 1: trace_wave_kernel (one wavefront per report; slices are per wave)
+  uint32_t count_min, count_max;  // the kernel runs only when count_min < number of reports <= count_max
   // the first host_cap records also go straight to device-mapped pinned host memory
   MatchOut* host_out;
   uint8_t* host_str;

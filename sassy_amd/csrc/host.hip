@@ -346,32 +346,40 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   P.cand_count = d_counts;
   P.counters = S->want_counters ? d_counters : nullptr;
 
-  // device traceback (K3) runs right behind the scan on the same stream: one host sync per strand
-  TraceParams T{};
-  uint32_t trace_blocks = 0;
+  // device traceback (K3) runs right behind the scan on the same stream: one host sync per strand.
+  // Two kernel shapes, chosen on the device by the number of reports (each launch returns at once
+  // when the count is outside its window):
+  //   Tw  one wavefront per report  -- latency-optimal, up to kTraceWaveMax reports (needs a band of
+  //       <= 64 columns and four slices in LDS);
+  //   Tt  one thread per report     -- throughput-optimal for dense results (k <= 6: band row in
+  //       registers), and the only shape for very wide bands.
+  constexpr uint32_t kTraceWaveMax = 8192;
+  TraceParams T{}, Tw{};
+  uint32_t trace_blocks = 0, wave_blocks = 0;
+  bool use_wave = false, use_thread = false;
   if (do_trace) {
     const uint64_t cell = (k + 1 <= 255) ? 1 : 2;
     const uint64_t band = ((uint64_t)(plan.m + 1) * (2ull * k + 3) * cell + 3) / 4 * 4;
     const uint64_t win = ((uint64_t)plan.m + k + 15 + 15) / 16 * 16;  // whole 16-byte chunks
     const uint64_t opsb = ((uint64_t)plan.m + k + 1 + 3) / 4 * 4;
     const uint64_t strb = ((2ull * (plan.m + k + 1) + 2 + 15) / 16 * 16);  // = T.str_stride
-    uint64_t stride = band + win + opsb + strb;
-    // k > 6 with a band of at most 64 columns: one wavefront per report, four slices per workgroup
+    const uint64_t raw = band + win + opsb + strb;
     const uint64_t pat_bytes = ((uint64_t)plan.m + 15) / 16 * 16;
-    const bool wave_mode = k > 6 && 2ull * k + 3 <= 64 && pat_bytes + 4 * ((stride + 15) / 16 * 16) <= 160 * 1024;
-    if (wave_mode) stride = (stride + 15) / 16 * 16;
-    else if ((stride / 4) % 2 == 0) stride += 4;  // odd number of LDS words: conflict-free slices
+    static const int env_wave = getenv("SASSY_HIP_TRACE_WAVE") ? atoi(getenv("SASSY_HIP_TRACE_WAVE")) : 1;
+    const uint64_t wstride = (raw + 15) / 16 * 16;
+    use_wave = env_wave != 0 && 2ull * k + 3 <= 64 && pat_bytes + 4 * wstride <= 160 * 1024;
+    use_thread = !use_wave || k <= 6;
+    uint64_t stride = raw;
+    if ((stride / 4) % 2 == 0) stride += 4;  // odd number of LDS words: conflict-free slices
     if (stride > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "pattern/k too large for the traceback band");
-    if (wave_mode) {
-      trace_blocks = 1024;  // 4096 wavefronts, grid-stride over the reports
-    } else {
+    if (use_thread) {
       uint64_t nthreads = (256ull << 20) / stride;
       nthreads = std::max<uint64_t>(64, std::min<uint64_t>(16384, nthreads)) / 64 * 64;
       trace_blocks = (uint32_t)(nthreads / 64);
       if (64 * stride + pat_bytes > kTraceLdsLimit)  // slices in global memory
         if (int rc = S->d_scratch.reserve(nthreads * stride)) return rc;
     }
-    T.wave_mode = wave_mode ? 1u : 0u;
+    wave_blocks = 1024;  // 4096 wavefronts, grid-stride over the reports
     T.band_bytes = (uint32_t)band;
     T.win_bytes = (uint32_t)win;
     T.text = sh.d_text;
@@ -386,6 +394,14 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     T.scratch_stride = (uint32_t)stride;
     T.str_stride = (2 * (plan.m + k + 1) + 2 + 15) / 16 * 16;
     T.ops_bytes = (uint32_t)opsb;
+    T.wave_mode = 0;
+    T.count_min = use_wave ? kTraceWaveMax : 0;   // runs when count_min < count <= count_max
+    T.count_max = 0xFFFFFFFFu;
+    Tw = T;
+    Tw.wave_mode = 1;
+    Tw.scratch_stride = (uint32_t)wstride;
+    Tw.count_min = 0;
+    Tw.count_max = use_thread ? kTraceWaveMax : 0xFFFFFFFFu;
   }
 
   // ---- geometry of the streaming kernel (full DP, or the prefilter) ----
@@ -469,10 +485,10 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
         return fail(SASSY_HIP_EUNSUPPORTED, "too many reports for one cigar pool (> 4 GiB of cigar text)");
       if (int rc = S->d_trace.reserve(P.cand_cap)) return rc;
       if (int rc = S->d_str.reserve((size_t)P.cand_cap * T.str_stride)) return rc;
-      T.cand = S->d_sorted.p;
-      T.cand_cap = P.cand_cap;
-      T.out = S->d_trace.p;
-      T.out_str = S->d_str.p;
+      T.cand = Tw.cand = S->d_sorted.p;
+      T.cand_cap = Tw.cand_cap = P.cand_cap;
+      T.out = Tw.out = S->d_trace.p;
+      T.out_str = Tw.out_str = S->d_str.p;
     }
     // control block, rank counters and (first attempt: the filter runs once) the hit bitmap
     HIP_TRY(hipMemsetAsync(S->d_ctl.p, 0, kCtlHead + (filtered && attempt == 0 ? (n_words + 2) * 8 : 0), S->stream));
@@ -511,11 +527,17 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
                      S->h_pin_dev + kPinCounts, S->stream);
     if (le != hipSuccess) return hip_fail(le, "rank kernel launch");
     if (do_trace) {
-      T.host_out = reinterpret_cast<MatchOut*>(S->h_pin_dev + pin_recs);
-      T.host_str = S->h_pin_dev + pin_ops;
-      T.host_cap = host_cap;
-      le = launch_trace(T, trace_blocks, S->stream);
-      if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
+      T.host_out = Tw.host_out = reinterpret_cast<MatchOut*>(S->h_pin_dev + pin_recs);
+      T.host_str = Tw.host_str = S->h_pin_dev + pin_ops;
+      T.host_cap = Tw.host_cap = host_cap;
+      if (use_wave) {
+        le = launch_trace(Tw, wave_blocks, S->stream);
+        if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
+      }
+      if (use_thread) {
+        le = launch_trace(T, trace_blocks, S->stream);
+        if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
+      }
       if (timing >= 2) HIP_TRY(hipEventRecord(S->ev_c, S->stream));
     }
     // the only synchronisation of the call; the kernels have written the results into h_pin

@@ -123,6 +123,7 @@ template <typename Cell, bool IN_LDS, int KT>
 __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char trace_smem[];
   uint32_t count = *P.cand_count;
+  if (count <= P.count_min || count > P.count_max) return;  // the other kernel shape handles it
   if (count > P.cand_cap) count = P.cand_cap;
   const int m = (int)P.m, k = KT >= 0 ? KT : (int)P.k;
   const int bw = 2 * k + 3;
@@ -304,6 +305,7 @@ template <typename Cell>
 __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char trace_smem[];
   uint32_t count = *P.cand_count;
+  if (count <= P.count_min || count > P.count_max) return;  // the other kernel shape handles it
   if (count > P.cand_cap) count = P.cand_cap;
   const int m = (int)P.m, k = (int)P.k;
   const int bw = 2 * k + 3;  // <= 64

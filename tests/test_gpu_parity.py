@@ -239,6 +239,24 @@ def test_traceback_variants(sassy, profile):
             assert_same(s.search_all(pat, tb, k), oracle.search(profile, pat, tb, k, all_minima=True))
 
 
+def test_dense_reports(sassy):
+    """Match-dense text: > 8192 reports (thread-per-report traceback instead of the wave-per-report
+    kernel), > 32768 reports (host sort instead of the device ranking pass), and more reports than
+    the initial candidate buffer holds (retry with a grown buffer)."""
+    rng = random.Random(99)
+    pat = b"ACGTTGCAAGGCTTACGATC"
+    for reps, k, more_than in ((1500, 3, 8192), (6500, 2, 8192), (14500, 3, 73792)):
+        unit = bytearray()
+        for _ in range(reps):
+            unit += mutate(rng, pat, rng.randrange(0, 3)) + bytes(rng.choice(b"ACGT") for _ in range(rng.randrange(0, 4)))
+        tb = bytes(unit)
+        s = sassy.Searcher("dna", rc=False)
+        want = oracle.search("dna", pat, tb, k, all_minima=True)
+        assert len(want) > more_than, len(want)
+        assert_same(s.search_all(pat, tb, k), want)
+        assert_same(s.search(pat, tb, k), oracle.search("dna", pat, tb, k))
+
+
 def test_config1_shape_1mib(sassy):
     """BASELINE config 1: 'ATCG'x8, k=3, 1 MiB random ACGT (+ plants), Dna, forward only."""
     pat = b"ATCG" * 8
