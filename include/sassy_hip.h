@@ -71,6 +71,8 @@ typedef struct sassy_hip_Stats {
   double host_enqueue_ms; /* host wall time spent queueing work on the stream */
   double host_wait_ms;    /* host wall time blocked in the stream synchronisation */
   double host_post_ms;    /* host wall time after it: sort, seams, cigar strings, result records */
+  uint64_t live_blocks;   /* blocks whose last row passed the cheap "may hold a cell <= k" test and were
+                             walked column by column (0 unless counters are enabled) */
 } sassy_hip_Stats;
 
 const char *sassy_hip_last_error(void);

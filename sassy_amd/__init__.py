@@ -87,6 +87,7 @@ class Stats(C.Structure):
         ("host_enqueue_ms", C.c_double),
         ("host_wait_ms", C.c_double),
         ("host_post_ms", C.c_double),
+        ("live_blocks", C.c_uint64),
     ]
 
     def as_dict(self):

@@ -591,6 +591,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     S->stats.word_rows += c[0];
     S->stats.blocks += c[1];
     S->stats.hit_blocks += c[2];
+    S->stats.live_blocks += c[3];
   }
 
   out.cands.resize(count);

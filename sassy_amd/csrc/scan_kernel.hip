@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   ctx.k = P.k;
   ctx.flags = P.flags;
 
-  unsigned long long cnt_rows = 0, cnt_blocks = 0;
+  unsigned long long cnt_rows = 0, cnt_blocks = 0, cnt_live = 0;
   const unsigned char* my_masks = mask_bytes + lane * 8;
 
   for (uint32_t it = 0; it < P.n_iter; ++it) {
@@ -515,6 +515,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
       if (P.counters) { cnt_rows += m; cnt_blocks += 1; }
       if (row_maybe_live(ds, V, k)) {
         const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
+        if (P.counters) cnt_live += 1;
         st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
       } else {
         st = kStDec;  // dec = true: a later <=k run can only be entered by a decrease; amb = false
@@ -527,6 +528,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   if (P.counters) {
     atomicAdd(&P.counters[0], cnt_rows);
     atomicAdd(&P.counters[1], cnt_blocks);
+    atomicAdd(&P.counters[3], cnt_live);
   }
 }
 
@@ -895,7 +897,7 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   ctx.cand_cap = P.cand_cap;
   ctx.k = P.k;
   ctx.flags = P.flags;
-  unsigned long long cnt_rows = 0, cnt_blocks = 0;
+  unsigned long long cnt_rows = 0, cnt_blocks = 0, cnt_live = 0;
   const unsigned char* my_masks = mask_bytes + lane * 8;
 
   for (uint32_t it = 0; __any(it < my_iters); ++it) {
@@ -943,6 +945,7 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
       if (P.counters) { cnt_rows += m; cnt_blocks += 1; }
       if (row_maybe_live(ds, V, k)) {
         const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
+        if (P.counters) cnt_live += 1;
         st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
       } else {
         st = kStDec;
@@ -953,6 +956,7 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   if (P.counters) {
     atomicAdd(&P.counters[0], cnt_rows);
     atomicAdd(&P.counters[1], cnt_blocks);
+    atomicAdd(&P.counters[3], cnt_live);
   }
 }
 
