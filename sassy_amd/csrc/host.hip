@@ -28,6 +28,7 @@ hipError_t launch_scan_dna(const ScanParams& P, uint32_t grid, size_t smem, hipS
 hipError_t launch_scan_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_scan_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
+hipError_t launch_filter_table(const ScanParams& P, uint32_t grid, hipStream_t stream);
 hipError_t launch_filter_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_filter_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_list_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
@@ -123,6 +124,11 @@ struct sassy_SearcherType {
   DevBuf<ChunkDesc> d_desc;
 
   bool want_counters = false;
+  // q-gram table of the last pattern searched with the table prefilter
+  DevBuf<uint8_t> d_table;
+  std::vector<uint8_t> h_table, table_pattern;
+  uint32_t table_q = 0, table_k = 0;
+  int table_profile = -1;
   // HIP-event timing of the call's phases: 0 none, 1 the dominant kernel only (filter / streaming
   // scan; default), 2 every phase.  Each event record costs a few microseconds of stream idle time.
   int timing = getenv("SASSY_HIP_TIMING") ? atoi(getenv("SASSY_HIP_TIMING")) : 1;
@@ -149,7 +155,7 @@ struct sassy_SearcherType {
     d_text.release(); d_rev.release(); d_state.release(); d_pattern.release(); d_scratch.release();
     d_str.release(); d_rowoff.release(); d_ctl.release(); d_cand.release(); d_sorted.release();
     d_trace.release();
-    d_desc.release();
+    d_desc.release(); d_table.release();
     if (h_pin) (void)hipHostFree(h_pin);
     if (ev_f) (void)hipEventDestroy(ev_f);
     if (ev_a) (void)hipEventDestroy(ev_a);
@@ -233,9 +239,43 @@ static uint32_t filter_piece_len(const PatternPlan& plan, uint32_t k) {
   const uint64_t pieces = (uint64_t)k + 1;
   uint64_t q = plan.m / pieces;
   if (q > 12) q = 12;
-  if (pieces * q > 255) return 0;            // the term table holds 256 piece rows
   if (q < (env == 1 ? 2u : 7u)) return 0;    // too unselective: stream the full DP instead
   return (uint32_t)q;
+}
+
+// The three prefilter kernels (scan_kernel.hip): which one evaluates the pieces.
+enum FilterKind : uint32_t {
+  kFilterGeneric = 1,  // filter_kernel: slot masks in LDS, any profile, <= 255 piece rows
+  kFilterPlanes = 2,   // filter_dna_kernel: Dna, <= 8 pieces
+  kFilterTable = 3,    // filter_table_kernel: q-gram bit table, Dna / Iupac, 7 <= q <= 9
+};
+
+// Bit table of every q-gram (2 bits per char, first piece row most significant; codes A0 C1 T2 G3)
+// that some piece accepts; rows with ambiguity letters are expanded.  False if that takes more
+// than `limit` q-grams (then the table says nothing useful anyway).
+static bool build_qgram_table(Profile pr, const uint8_t* pat, uint32_t q, uint32_t pieces, std::vector<uint8_t>& tab) {
+  const size_t limit = 1u << 16;
+  tab.assign((size_t)1 << (2 * q - 3), 0);
+  const uint32_t low_bits = 2 * q - 3;
+  std::vector<uint32_t> cur, nxt;
+  size_t total = 0;
+  for (uint32_t p = 0; p < pieces; ++p) {
+    cur.assign(1, 0u);
+    for (uint32_t j = 0; j < q && !cur.empty(); ++j) {
+      const uint8_t c = pat[p * q + j];
+      // base set of the row as a nibble whose bit index is the 2-bit text code
+      const uint32_t set = pr == PROFILE_IUPAC ? (iupac_code(c) & 15u) : (1u << ((c >> 1) & 3u));
+      nxt.clear();
+      for (uint32_t code : cur)
+        for (uint32_t b = 0; b < 4; ++b)
+          if ((set >> b) & 1u) nxt.push_back((code << 2) | b);
+      if (nxt.size() + total > limit) return false;
+      cur.swap(nxt);
+    }
+    total += cur.size();
+    for (uint32_t code : cur) tab[code & ((1u << low_bits) - 1u)] |= (uint8_t)(1u << (code >> low_bits));
+  }
+  return true;
 }
 
 static hipError_t launch_scan_any(Profile pr, const ScanParams& P, uint32_t grid, size_t smem, hipStream_t st) {
@@ -262,9 +302,10 @@ static hipError_t launch_list_any(Profile pr, const ScanParams& P, uint32_t grid
 
 // Chunk geometry of a streaming kernel: enough lanes to fill 256 CUs several times over, chunks
 // long enough that the extra blocks in front of each chunk stay a few percent of the work.
-static int stream_geometry(ScanParams& P, uint64_t owned, uint32_t extra_front, uint32_t* grid) {
+// wpc: resident waves per CU of the kernel (its workgroups are launched in two full rounds)
+static int stream_geometry(ScanParams& P, uint64_t owned, uint32_t extra_front, uint32_t* grid, int wpc = 16) {
   static const int env_wpc = getenv("SASSY_HIP_WAVES_PER_CU") ? atoi(getenv("SASSY_HIP_WAVES_PER_CU")) : 0;
-  const uint64_t target_lanes = 256ull * (env_wpc > 0 ? env_wpc : 16) * 64 * 2;
+  const uint64_t target_lanes = 256ull * (env_wpc > 0 ? env_wpc : wpc) * 64 * 2;
   uint64_t bpl = (owned + target_lanes - 1) / target_lanes;
   const uint64_t min_bpl = std::max<uint64_t>(8, 6ull * extra_front);
   if (bpl < min_bpl) bpl = min_bpl;
@@ -310,8 +351,38 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   static const int env_sb = getenv("SASSY_HIP_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_STAGE_BLOCKS")) : 0;
   P.stage_blocks = env_sb == 1 || env_sb == 2 ? (uint32_t)env_sb : 1u;
   for (int s = 0; s < kMaxSlots; ++s) P.slot_val[s] = plan.slot_val[s];
-  const uint32_t q = filter_piece_len(plan, k);
+  uint32_t q = filter_piece_len(plan, k);
   const bool filtered = q > 0;
+  // which prefilter kernel (SASSY_HIP_FILTER_KIND=1|2|3 forces one where it applies)
+  FilterKind fkind = kFilterGeneric;
+  if (filtered) {
+    static const int env_kind = getenv("SASSY_HIP_FILTER_KIND") ? atoi(getenv("SASSY_HIP_FILTER_KIND")) : 0;
+    const uint32_t pieces = k + 1;
+    const bool can_planes = S->profile == PROFILE_DNA && pieces <= 8;
+    const bool can_table = S->profile != PROFILE_ASCII && q >= 7;
+    const bool can_generic = (uint64_t)pieces * q <= 255;   // its term table holds 256 piece rows
+    if (can_planes && (env_kind == 0 || env_kind == kFilterPlanes)) fkind = kFilterPlanes;
+    else if (can_table && (env_kind == 0 || env_kind == kFilterTable || !can_generic)) fkind = kFilterTable;
+    else if (!can_generic) return fail(SASSY_HIP_EUNSUPPORTED, "k too large for the prefilter's piece table");
+    if (fkind == kFilterTable) {
+      const uint32_t tq = std::min<uint32_t>(q, 9);
+      const bool cached = S->table_q == tq && S->table_k == k && S->table_profile == (int)S->profile &&
+                          S->table_pattern.size() == plan.m && memcmp(S->table_pattern.data(), pat, plan.m) == 0;
+      if (!cached) {
+        if (build_qgram_table(S->profile, pat, tq, pieces, S->h_table)) {
+          if (int rc = S->d_table.reserve(S->h_table.size())) return rc;
+          HIP_TRY(hipMemcpyAsync(S->d_table.p, S->h_table.data(), S->h_table.size(), hipMemcpyHostToDevice, S->stream));
+          S->table_q = tq; S->table_k = k; S->table_profile = (int)S->profile;
+          S->table_pattern.assign(pat, pat + plan.m);
+        } else {
+          S->table_q = 0;
+          if (!can_generic) return fail(SASSY_HIP_EUNSUPPORTED, "pattern too ambiguous / k too large for the prefilter");
+          fkind = kFilterGeneric;
+        }
+      }
+      if (fkind == kFilterTable) q = tq;
+    }
+  }
 
   // pattern-dependent device data is uploaded only when the pattern changed since the last call
   if (int rc = S->d_rowoff.reserve(plan.row_tab.size())) return rc;
@@ -440,7 +511,9 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     }
     // Dna with <= 8 pieces: the filter works on the two code bit planes (filter_dna_kernel)
     static const int env_planes = getenv("SASSY_HIP_FILTER_PLANES") ? atoi(getenv("SASSY_HIP_FILTER_PLANES")) : 1;
-    F.piece_planes = (S->profile == PROFILE_DNA && F.piece_groups != 0 && env_planes != 0) ? 1u : 0u;
+    (void)env_planes;
+    F.piece_planes = fkind == kFilterPlanes ? 1u : 0u;
+    F.qgram_table = fkind == kFilterTable ? S->d_table.p : nullptr;
     if (F.piece_planes) {
       for (uint32_t pp = 0; pp < 8; ++pp) {
         const uint32_t piece = pp < F.n_pieces ? pp : 0;  // a repeated piece changes nothing
@@ -456,7 +529,14 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     }
     static const int env_fsb = getenv("SASSY_HIP_FILTER_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_FILTER_STAGE_BLOCKS")) : 0;
     F.stage_blocks = env_fsb == 1 || env_fsb == 2 ? (uint32_t)env_fsb : 2u;
-    if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, 1, &fgrid)) return rc;
+    int fwpc = 16;
+    if (fkind == kFilterTable) {
+      // one 4 KiB tile per wave + the table per workgroup decide how many workgroups a CU holds
+      F.stage_blocks = 1;
+      const uint32_t wg_lds = (1u << (2 * q - 3)) + 4 * 4096u;
+      fwpc = 4 * (int)std::min<uint32_t>(8, (160u * 1024u) / wg_lds);
+    }
+    if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, 1, &fgrid, fwpc)) return rc;
     F.lds_per_wave = 4096u * F.stage_blocks + (F.piece_planes ? 0u : 2u * bucket * 512u);
     F.hit_bitmap = d_bitmap;
     if (S->d_desc.cap == 0)
@@ -499,7 +579,9 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
     } else {
       if (attempt == 0) {  // the hit bitmap does not depend on buffer sizes: build it once
-        le = launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, S->stream);
+        le = fkind == kFilterTable
+                 ? launch_filter_table(F, fgrid, S->stream)
+                 : launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, S->stream);
         if (le != hipSuccess) return hip_fail(le, "filter kernel launch");
       }
       if (timing >= 1 && attempt == 0) HIP_TRY(hipEventRecord(S->ev_f, S->stream));
@@ -583,7 +665,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   S->stats.warmup_blocks = P.wb;
   S->stats.grid = filtered ? fgrid : grid;
   S->stats.text_bytes += sh.text_len - sh.halo_len;
-  S->stats.filtered = filtered ? (F.piece_planes ? 2u : 1u) : 0u;
+  S->stats.filtered = filtered ? (uint32_t)fkind : 0u;
   S->stats.piece_len = q;
   {
     unsigned long long c[4];

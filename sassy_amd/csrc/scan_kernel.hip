@@ -843,6 +843,128 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
   }
 }
 
+// ====================================================================== K0 with a q-gram table
+// Many pieces (k+1 > 8), or Iupac patterns: instead of evaluating every piece, every text position
+// looks its q-gram up in a bit table of all 4^Q q-grams that some piece accepts (built on the host;
+// ambiguous pattern letters are expanded).  The 2-bit code of a text byte is (c >> 1) & 3 -- exact
+// for A C G T U in either case, which is also the Dna profile's own definition for every byte
+// (src/profiles/dna.rs:19-40).  Under the Iupac profile other text bytes (N, R, ... or non-letters)
+// match more than their code says, so a block that holds one, and the block after it, are simply
+// recorded as hits (check_text).  The rolling code h lives in a register across the lane's
+// consecutive blocks; the table sits in LDS (4^Q / 8 bytes, shared by the workgroup): byte
+// h & (2^(2Q-3) - 1), bit h >> (2Q-3).  Cost per block: 64 x (6 VALU + one ds_read_u8), whatever
+// the number of pieces.
+template <int Q>
+__global__ __launch_bounds__(256) void filter_table_kernel(const ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr uint32_t kTableBytes = 1u << (2 * Q - 3);
+  constexpr uint32_t kRowBytes = 64u;   // SB = 1: more waves per CU, the kernel is VALU / LDS bound
+  constexpr uint32_t kSlots = 4u;
+  constexpr uint32_t kOwnersPerInstr = 16u;
+  constexpr int kStageInstr = 4;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  unsigned char* table = smem;
+  unsigned char* tile = smem + kTableBytes + (size_t)wave * 4096u;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(P.qgram_table);
+    uint4* dst = reinterpret_cast<uint4*>(table);
+    for (uint32_t x = threadIdx.x; x < kTableBytes / 16; x += blockDim.x) dst[x] = src[x];
+  }
+  __syncthreads();
+
+  const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * kWavesPerGroup + wave) * kWave;
+  if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
+  const uint64_t chunk = wave_chunk0 + lane;
+  const uint32_t bpl = P.bpl;
+  const uint64_t first_owned = P.first_owned_block;
+  const uint32_t back = 1u + (uint32_t)((first_owned + 1u) & 1u);  // previous block + evenness
+  const uint64_t own_lo = first_owned + chunk * (uint64_t)bpl;
+  uint64_t own_hi = own_lo + bpl;
+  if (own_hi > P.n_blocks) own_hi = P.n_blocks;
+  const bool has_chunk = chunk < P.n_chunks && own_lo < P.n_blocks;
+  const uint64_t blk0 = chunk_blk0(first_owned, bpl, back, chunk);
+
+  const uint64_t wave_blk0 = chunk_blk0(first_owned, bpl, back, wave_chunk0);
+  const uint8_t* text_base = P.text + wave_blk0 * 64;
+  uint32_t soff[kStageInstr];
+#pragma unroll
+  for (int i = 0; i < kStageInstr; ++i) {
+    const uint32_t owner = (uint32_t)i * kOwnersPerInstr + lane / kSlots;
+    const uint32_t slot = lane % kSlots;
+    const uint32_t j = slot ^ ((owner >> 2) & 3u);
+    soff[i] = (uint32_t)((chunk_blk0(first_owned, bpl, back, wave_chunk0 + owner) - wave_blk0) * 64) + j * 16u;
+  }
+  const uint64_t wave_last = chunk_blk0(first_owned, bpl, back, wave_chunk0 + 63) + P.n_iter + 2;
+  const bool interior = wave_last * 64 <= P.text_len;
+  const uint32_t fsw = (lane >> 2) & 3u;
+  uint32_t rc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rc[c] = lane * kRowBytes + (((uint32_t)c ^ fsw) << 4);
+  const bool check_text = P.profile == PROFILE_IUPAC;  // wave-uniform
+
+  uint32_t h = 0;          // rolling code of the last 16 text chars
+  uint32_t bad_prev = 0;   // the previous block held a byte that is not A C G T U
+  uint4 nxt[kStageInstr];
+#pragma unroll
+  for (int i = 0; i < kStageInstr; ++i) {
+    nxt[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (interior) nxt[i] = *reinterpret_cast<const uint4*>(text_base + soff[i]);
+  }
+
+  for (uint32_t it = 0; it < P.n_iter; ++it) {
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < kStageInstr; ++i) *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = nxt[i];
+      if (it + 1 < P.n_iter) {
+#pragma unroll
+        for (int i = 0; i < kStageInstr; ++i)
+          nxt[i] = *reinterpret_cast<const uint4*>(text_base + (uint64_t)(it + 1) * 64 + soff[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kStageInstr; ++i) {
+        const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
+        uint4 v;
+        if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
+        else v = load_tail16(P.text, off, P.text_len);
+        *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+      }
+    }
+    uint32_t x[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint4 v = *reinterpret_cast<const uint4*>(tile + rc[c]);
+      x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+    }
+    uint32_t acc = 0;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) {
+      const uint32_t code = __builtin_amdgcn_ubfe(x[c >> 2], 8 * (c & 3) + 1, 2);
+      h = (h << 2) | code;
+      const uint32_t byte = table[__builtin_amdgcn_ubfe(h, 0, 2 * Q - 3)];
+      acc |= byte >> __builtin_amdgcn_ubfe(h, 2 * Q - 3, 3);
+    }
+    uint32_t bad = 0;
+    if (check_text) {
+      // bytes other than A C G T U (either case): compare with the letter their code stands for
+#pragma unroll
+      for (int d = 0; d < 16; ++d) {
+        const uint32_t sel = (x[d] >> 1) & 0x03030303u;
+        const uint32_t up = x[d] & 0xDFDFDFDFu;
+        const uint32_t e1 = __builtin_amdgcn_perm(0u, 0x47544341u, sel);  // 'A' 'C' 'T' 'G' by code
+        const uint32_t e2 = __builtin_amdgcn_perm(0u, 0x47554341u, sel);  // 'A' 'C' 'U' 'G'
+        bad |= (up ^ e1) & (up ^ e2);
+      }
+    }
+    const uint64_t b = blk0 + it;
+    const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
+    if (evaluate && ((acc & 1u) | bad | bad_prev) != 0)
+      atomicOr(&P.hit_bitmap[b >> 6], 1ull << (b & 63));
+    bad_prev = bad;
+  }
+}
+
 // ====================================================================== K1-list: DP over a chunk list
 // Same DP, same report rule, same seam bookkeeping as scan_kernel, but every lane takes its chunk
 // (first block, end block, flags) from a descriptor list built from the prefilter's hit bitmap.
@@ -1029,6 +1151,21 @@ static hipError_t launch_filter_planes(const ScanParams& P, uint32_t grid, hipSt
   hipLaunchKernelGGL((filter_dna_kernel<SB, NPG>), dim3(grid), dim3(256), (size_t)kWavesPerGroup * P.lds_per_wave,
                      stream, P);
   return hipGetLastError();
+}
+template <int Q>
+static hipError_t launch_filter_table_q(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  const size_t smem = (1u << (2 * Q - 3)) + 4 * 4096u;
+  hipLaunchKernelGGL((filter_table_kernel<Q>), dim3(grid), dim3(256), smem, stream, P);
+  return hipGetLastError();
+}
+// the q-gram table filter is profile-independent code: it lives in the Dna translation unit
+hipError_t launch_filter_table(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  switch (P.piece_len) {
+    case 7: return launch_filter_table_q<7>(P, grid, stream);
+    case 8: return launch_filter_table_q<8>(P, grid, stream);
+    case 9: return launch_filter_table_q<9>(P, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
   if (P.piece_planes) {  // <= 8 pieces: the bit-plane kernel (lds_per_wave = the staging tile only)

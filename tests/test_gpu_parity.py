@@ -210,7 +210,7 @@ def test_traceback_variants(sassy, profile):
     including text-start / text-end windows and search_all (dense, adjacent reports)."""
     rng = random.Random(7 if profile == "dna" else 8)
     cases = [(12, 0), (16, 1), (20, 2), (24, 4), (33, 5), (40, 6), (40, 7), (64, 9), (90, 13),
-             (130, 20), (200, 30), (70, 31), (120, 35), (300, 30)]
+             (130, 20), (200, 30), (70, 31), (120, 35), (300, 30), (100, 9), (160, 15)]
     for m, k in cases:
         pat = bytes(rng.choice(b"ACGT") for _ in range(m))
         if profile == "iupac" and m >= 20:
@@ -255,6 +255,41 @@ def test_dense_reports(sassy):
         assert len(want) > more_than, len(want)
         assert_same(s.search_all(pat, tb, k), want)
         assert_same(s.search(pat, tb, k), oracle.search("dna", pat, tb, k))
+
+
+def test_qgram_table_filter_text_letters(sassy):
+    """The q-gram table prefilter (Iupac profile, or > 8 pieces) must stay exact when the TEXT holds
+    letters other than ACGT: ambiguity codes (match several bases), lower case, U, non-letters."""
+    rng = random.Random(2024)
+    for profile, m, k in (("iupac", 32, 3), ("iupac", 48, 4), ("iupac", 90, 9), ("dna", 100, 9)):
+        pat = bytearray(rng.choice(b"ACGT") for _ in range(m))
+        if profile == "iupac":
+            pat[5], pat[m // 2], pat[m - 3] = ord("N"), ord("S"), ord("w")
+        pat = bytes(pat)
+        plain = bytes(c if c in b"ACGT" else 67 for c in pat.upper())
+        n = 40_000
+        text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        at = 100
+        while at + 2 * m < n:
+            ins = bytearray(mutate(rng, plain, rng.randrange(0, k + 1)))
+            # replace some bases of the planted copy by codes that still (or no longer) match
+            # (the Dna profile only defines ACGT text, any case: the reference panics otherwise)
+            letters = b"NRYKMSWBDHVnacgtuUX-*@" if profile == "iupac" else b"acgtACGT"
+            for _ in range(rng.randrange(0, 4)):
+                ins[rng.randrange(len(ins))] = rng.choice(letters)
+            text[at:at + len(ins)] = ins
+            at += len(ins) + rng.randrange(50, 900)
+        for _ in range(200):  # stray letters in the background, some right at block borders
+            text[rng.randrange(n)] = rng.choice(b"NRYnu@-" if profile == "iupac" else b"acgt")
+        for b in (63, 64, 127, 128, 4095, 4096):
+            text[b] = ord("N") if profile == "iupac" else ord("g")
+        tb = bytes(text)
+        s = sassy.Searcher(profile, rc=False)
+        want = oracle.search(profile, pat, tb, k)
+        assert len(want) >= 20, (profile, m, k, len(want))
+        assert_same(s.search(pat, tb, k), want)
+        st = s.stats()
+        assert st["filtered"] == 3, st["filtered"]  # the table kernel really ran
 
 
 def test_config1_shape_1mib(sassy):
