@@ -91,10 +91,30 @@ int sassy_hip_set_timing(sassy_SearcherType *s, int level);
 /* Count DP word-rows / blocks in the scan kernel (stats.word_rows, stats.blocks); off by default. */
 int sassy_hip_enable_counters(sassy_SearcherType *s, int on);
 
+/* Reporting modes of the reference's Searcher builder, applied per strand by sassy_hip_search,
+ * sassy_hip_search_with_fn and sassy_hip_search_encoded (not by search_shard):
+ *   only_best_match()  (src/search.rs:442-446, 1392-1412): one match per strand -- minimal cost,
+ *                      rightmost end position;
+ *   with_max_n_frac(f) (src/search.rs:454-475, src/n_filter.rs): drop matches whose text span holds
+ *                      more than the fraction f of 'N'/'n'; f = 1.0 or NAN switches it off. */
+int sassy_hip_set_only_best_match(sassy_SearcherType *s, int on);
+int sassy_hip_set_max_n_frac(sassy_SearcherType *s, float max_n_frac);
+
 /* Searcher::search / search_all with full Match records (src/search.rs:510-525, 685-700). */
 int sassy_hip_search(sassy_SearcherType *s, const uint8_t *pattern, size_t pattern_len,
                      const uint8_t *text, size_t text_len, size_t k, uint32_t flags,
                      sassy_hip_Result **out);
+
+/* Searcher::search_with_fn (src/search.rs:767-784): keep only the end positions for which the
+ * callback returns non-zero.  It sees what the reference's closure sees: the pattern, the text up
+ * to the end position (text_till_end[0 .. end_pos)) and the strand (0 Fwd, 1 Rc); for the Rc strand
+ * both are the complemented pattern and the REVERSED text the scan ran on.  Host text only. */
+typedef int (*sassy_hip_end_filter)(const uint8_t *pattern, size_t pattern_len,
+                                    const uint8_t *text_till_end, size_t end_pos, int strand,
+                                    void *user);
+int sassy_hip_search_with_fn(sassy_SearcherType *s, const uint8_t *pattern, size_t pattern_len,
+                             const uint8_t *text, size_t text_len, size_t k, uint32_t flags,
+                             sassy_hip_end_filter fn, void *user, sassy_hip_Result **out);
 
 /* One shard of a larger text that lives on this device (multi-GPU).
  * d_text points at the first byte of the halo; the shard owns global end positions whose

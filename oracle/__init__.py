@@ -271,3 +271,53 @@ def profile_masks(profile, pattern: bytes, block64: bytes) -> List[int]:
     out = (C.c_uint64 * 256)()
     n = lib().rs_encode_block_test(_profile(profile), bytes(pattern), len(pattern), bytes(block64), out)
     return [int(out[i]) for i in range(n)]
+
+
+# ---------------------------------------------------------------- reporting modes of the Searcher
+def _n_frac_ok(n_count: int, denom: int, max_n_frac: float) -> bool:
+    import numpy as np
+    return bool(np.float32(n_count) / np.float32(denom) <= np.float32(max_n_frac))
+
+
+def _count_n(text: bytes, a: int, b: int) -> int:
+    return sum(1 for c in text[a:b] if c | 0x20 == 0x6E)
+
+
+def search_modes(profile, pattern: bytes, text: bytes, k: int, rc: bool = False, all_minima: bool = False,
+                 end_filter=None, max_n_frac=None, only_best: bool = False, without_trace: bool = False):
+    """What Searcher::search_one_strand does around the scan (src/search.rs:884-937), per strand:
+    end-position callback (search_with_fn, :895-906), N-fraction pre-filter on the end position
+    (src/n_filter.rs:38-52), only_best_match (:1392-1412: minimal cost, rightmost end), N-fraction
+    filter on the traced span (src/n_filter.rs:54-60); the Rc strand sees complement(pattern) and
+    the reversed text, results are mapped back (:813-878).
+    end_filter(pattern_of_strand, text_till_end, strand '+'/'-') -> bool."""
+    pattern, text = bytes(pattern), bytes(text)
+    n, m = len(text), len(pattern)
+    out = []
+    strands = [("+", pattern, text)]
+    if rc:
+        strands.append(("-", complement(profile, pattern), text[::-1]))
+    for strand, pat, txt in strands:
+        ms = search(profile, pat, txt, k, rc=False, all_minima=all_minima)
+        if end_filter is not None:
+            ms = [x for x in ms if end_filter(pat, txt[:min(x.text_end, n)], strand)]
+        if max_n_frac is not None and max_n_frac != 1.0:
+            keep = []
+            for x in ms:
+                end = min(x.text_end, n)
+                start = end - min(end, max(0, m - k))
+                if start >= n or start == end or _n_frac_ok(_count_n(txt, start, end), m + k, max_n_frac):
+                    keep.append(x)
+            ms = keep
+        if only_best and ms:
+            best = min(ms, key=lambda x: (x.cost, -x.text_end))
+            ms = [best]
+        if max_n_frac is not None and max_n_frac != 1.0 and not without_trace:
+            ms = [x for x in ms if x.text_start >= n or x.text_end == x.text_start or
+                  _n_frac_ok(_count_n(txt, x.text_start, x.text_end), x.text_end - x.text_start, max_n_frac)]
+        for x in ms:
+            if strand == "-":
+                x = Match(x.pattern_idx, n - x.text_end, n - x.text_start, x.pattern_start, x.pattern_end,
+                          x.cost, "-", x.cigar)
+            out.append(x)
+    return out

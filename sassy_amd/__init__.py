@@ -64,6 +64,11 @@ class _HipMatch(C.Structure):
     ]
 
 
+# int fn(pattern, pattern_len, text_till_end, end_pos, strand, user)  (include/sassy_hip.h)
+END_FILTER = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_uint8), C.c_size_t, C.POINTER(C.c_uint8), C.c_size_t, C.c_int,
+                         C.c_void_p)
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("scan_ms", C.c_double),
@@ -102,6 +107,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_search", "sassy_hip_search_shard", "sassy_hip_required_halo",
     "sassy_hip_result_len", "sassy_hip_result_matches", "sassy_hip_result_cigars",
     "sassy_hip_result_cigars_len", "sassy_hip_enable_counters", "sassy_hip_set_timing",
+    "sassy_hip_set_only_best_match", "sassy_hip_set_max_n_frac", "sassy_hip_search_with_fn",
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
     "sassy_hip_generate_dna", "sassy_hip_plant",
@@ -147,6 +153,13 @@ def lib():
     L.sassy_hip_enable_counters.argtypes = [vp, C.c_int]
     L.sassy_hip_set_timing.restype = C.c_int
     L.sassy_hip_set_timing.argtypes = [vp, C.c_int]
+    L.sassy_hip_set_only_best_match.restype = C.c_int
+    L.sassy_hip_set_only_best_match.argtypes = [vp, C.c_int]
+    L.sassy_hip_set_max_n_frac.restype = C.c_int
+    L.sassy_hip_set_max_n_frac.argtypes = [vp, C.c_float]
+    L.sassy_hip_search_with_fn.restype = C.c_int
+    L.sassy_hip_search_with_fn.argtypes = [vp, C.c_char_p, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_uint32,
+                                           END_FILTER, vp, C.POINTER(vp)]
     L.sassy_hip_search.restype = C.c_int
     L.sassy_hip_search.argtypes = [vp, u8p, sz, vp, sz, sz, C.c_uint32, C.POINTER(vp)]
     L.sassy_hip_search_shard.restype = C.c_int
@@ -325,6 +338,31 @@ class Searcher:
 
     def search_without_trace(self, pattern: bytes, text, k: int) -> List[Match]:
         return self._search(pattern, text, k, WITHOUT_TRACE).matches
+
+    def search_with_fn(self, pattern: bytes, text: bytes, k: int, all_minima: bool, filter_fn) -> List[Match]:
+        """Searcher::search_with_fn (src/search.rs:767-784): keep the end positions for which
+        filter_fn(pattern_of_strand: bytes, text_till_end: bytes, strand: '+'|'-') is true."""
+        pattern, text = bytes(pattern), bytes(text)
+
+        def tramp(p, plen, t, end, strand, _user):
+            return 1 if filter_fn(C.string_at(p, plen), C.string_at(t, end), "-" if strand else "+") else 0
+
+        cb = END_FILTER(tramp)
+        out = C.c_void_p()
+        addr = C.cast(C.c_char_p(text), C.c_void_p).value or 0
+        _check(lib().sassy_hip_search_with_fn(self._h, pattern, len(pattern), addr, len(text), k,
+                                              ALL_MINIMA if all_minima else 0, cb, None, C.byref(out)))
+        return Result(out).matches
+
+    def only_best_match(self, on: bool = True) -> "Searcher":
+        """Searcher::only_best_match (src/search.rs:442-446)."""
+        _check(lib().sassy_hip_set_only_best_match(self._h, int(on)))
+        return self
+
+    def with_max_n_frac(self, max_n_frac: Optional[float]) -> "Searcher":
+        """Searcher::with_max_n_frac / without_max_n_frac (src/search.rs:454-475)."""
+        _check(lib().sassy_hip_set_max_n_frac(self._h, float("nan") if max_n_frac is None else float(max_n_frac)))
+        return self
 
     def encode_patterns(self, patterns: Sequence[bytes]) -> EncodedPatterns:
         patterns = [bytes(p) for p in patterns]

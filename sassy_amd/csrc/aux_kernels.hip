@@ -259,7 +259,27 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const Candidate* __re
   if (r < host_cap) host_sorted[r] = v;
 }
 
+// ------------------------------------------------------------------ N counting (max_n_frac)
+// count[i] = number of 'N' / 'n' bytes in text[range[2i] .. range[2i+1]) -- the input of the
+// reference's N-fraction filters (src/n_filter.rs:8-60) when the text lives on the device.
+__global__ __launch_bounds__(256) void count_n_kernel(const uint8_t* __restrict__ text,
+                                                      const uint64_t* __restrict__ range, uint32_t n,
+                                                      uint32_t* __restrict__ count) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t c = 0;
+  for (uint64_t x = range[2 * i]; x < range[2 * i + 1]; ++x) c += ((text[x] | 0x20u) == 'n') ? 1u : 0u;
+  count[i] = c;
+}
+
 // ------------------------------------------------------------------ launchers
+hipError_t launch_count_n(const uint8_t* d_text, const uint64_t* d_range, uint32_t n, uint32_t* d_count,
+                          hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(count_n_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_text, d_range, n, d_count);
+  return hipGetLastError();
+}
+
 // d_rank: cap zeroed counters (zeroed by the caller together with its control block).
 // h_sorted / h_ctl: device-mapped pinned host memory (first host_cap sorted reports, 64-byte
 // control block); d_count points at the control block.

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <iterator>
 #include <memory>
 #include <cmath>
 #include <cstdio>
@@ -29,6 +30,8 @@ hipError_t launch_scan_iupac(const ScanParams& P, uint32_t grid, size_t smem, hi
 hipError_t launch_scan_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_filter_table(const ScanParams& P, uint32_t grid, hipStream_t stream);
+hipError_t launch_count_n(const uint8_t* d_text, const uint64_t* d_range, uint32_t n, uint32_t* d_count,
+                          hipStream_t stream);
 hipError_t launch_filter_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_filter_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_list_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
@@ -124,6 +127,11 @@ struct sassy_SearcherType {
   DevBuf<ChunkDesc> d_desc;
 
   bool want_counters = false;
+  // reporting modes of the reference's Searcher (src/search.rs:442-475)
+  bool only_best = false;        // only_best_match(): one match per strand, minimal cost, rightmost end
+  float max_n_frac = NAN;        // with_max_n_frac(): NaN = off (the reference's None)
+  DevBuf<uint64_t> d_range;      // N counting on device-resident text
+  DevBuf<uint32_t> d_ncount;
   // q-gram table of the last pattern searched with the table prefilter
   DevBuf<uint8_t> d_table;
   std::vector<uint8_t> h_table, table_pattern;
@@ -155,7 +163,7 @@ struct sassy_SearcherType {
     d_text.release(); d_rev.release(); d_state.release(); d_pattern.release(); d_scratch.release();
     d_str.release(); d_rowoff.release(); d_ctl.release(); d_cand.release(); d_sorted.release();
     d_trace.release();
-    d_desc.release(); d_table.release();
+    d_desc.release(); d_table.release(); d_range.release(); d_ncount.release();
     if (h_pin) (void)hipHostFree(h_pin);
     if (ev_f) (void)hipEventDestroy(ev_f);
     if (ev_a) (void)hipEventDestroy(ev_a);
@@ -855,9 +863,120 @@ static int append_matches(ScanOut& so, uint64_t total_len, const PatternPlan& pl
 
 // Searcher::search / search_all on one text (reference: src/search.rs:510-525, 685-700, 787-881).
 // `text` is a host pointer unless TEXT_ON_DEVICE.
+// End-position callback of search_with_fn (reference: src/search.rs:767-784, applied at :895-906).
+struct EndFilter {
+  sassy_hip_end_filter fn = nullptr;
+  void* user = nullptr;
+};
+
+// 'N' counts of text ranges, on the host copy of the text when there is one, else on the device.
+static int count_ns(sassy_SearcherType* S, const uint8_t* h_text, const uint8_t* d_text,
+                    const std::vector<uint64_t>& ranges, std::vector<uint32_t>& counts) {
+  const size_t n = ranges.size() / 2;
+  counts.assign(n, 0);
+  if (n == 0) return 0;
+  if (h_text) {
+    for (size_t i = 0; i < n; ++i) {
+      uint32_t c = 0;
+      for (uint64_t x = ranges[2 * i]; x < ranges[2 * i + 1]; ++x) c += ((h_text[x] | 0x20u) == 'n') ? 1u : 0u;
+      counts[i] = c;
+    }
+    return 0;
+  }
+  if (int rc = S->d_range.reserve(2 * n)) return rc;
+  if (int rc = S->d_ncount.reserve(n)) return rc;
+  HIP_TRY(hipMemcpyAsync(S->d_range.p, ranges.data(), 2 * n * sizeof(uint64_t), hipMemcpyHostToDevice, S->stream));
+  hipError_t le = launch_count_n(d_text, S->d_range.p, (uint32_t)n, S->d_ncount.p, S->stream);
+  if (le != hipSuccess) return hip_fail(le, "N count kernel launch");
+  HIP_TRY(hipMemcpyAsync(counts.data(), S->d_ncount.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost, S->stream));
+  HIP_TRY(hipStreamSynchronize(S->stream));
+  return 0;
+}
+
+// n_count / denominator <= max_n_frac in f32, as the reference computes it (src/n_filter.rs:8-36)
+static bool n_frac_ok(uint32_t n_count, uint64_t denominator, float max_n_frac) {
+  return (float)n_count / (float)denominator <= max_n_frac;
+}
+
+// What the reference does between finding the end positions and returning the matches of one
+// strand (src/search.rs:884-937): end-position callback, N-fraction pre-filter, only_best_match,
+// N-fraction filter on the traced span.  All are filters on the report list, so applying them to the
+// device-traced records gives the same result as tracing only the survivors.
+// h_text / d_text: this strand's text (reversed for Rc) on the host (may be null) and the device.
+static int post_filter(sassy_SearcherType* S, ScanOut& so, const PatternPlan& plan, const uint8_t* pat, uint32_t k,
+                       int strand, const uint8_t* h_text, const uint8_t* d_text, uint64_t tlen, bool with_trace,
+                       const EndFilter& ef) {
+  const bool n_filter = !std::isnan(S->max_n_frac);
+  if (!ef.fn && !n_filter && !S->only_best) return 0;
+  std::vector<char> keep(so.cands.size(), 1);
+  auto compact = [&]() {
+    size_t w = 0;
+    for (size_t i = 0; i < so.cands.size(); ++i) {
+      if (!keep[i]) continue;
+      if ((int64_t)i == so.conditional_index) so.conditional_index = (int64_t)w;
+      so.cands[w] = so.cands[i];
+      if (with_trace) so.matches[w] = so.matches[i];
+      ++w;
+    }
+    so.cands.resize(w);
+    if (with_trace) so.matches.resize(w);
+    keep.assign(w, 1);
+  };
+  if (ef.fn) {
+    if (!h_text) return fail(SASSY_HIP_EINVAL, "search_with_fn needs the text in host memory");
+    for (size_t i = 0; i < so.cands.size(); ++i) {
+      const uint64_t end = std::min<uint64_t>(so.cands[i].pos, tlen);
+      keep[i] = ef.fn(pat, plan.m, h_text, (size_t)end, strand, ef.user) ? 1 : 0;
+    }
+    compact();
+  }
+  if (n_filter) {  // satisfy_n_endpoint_filter (src/n_filter.rs:38-52)
+    std::vector<uint64_t> ranges;
+    ranges.reserve(2 * so.cands.size());
+    const uint64_t mandatory = plan.m > k ? plan.m - k : 0;
+    for (const Candidate& c : so.cands) {
+      const uint64_t end = std::min<uint64_t>(c.pos, tlen);
+      ranges.push_back(end - std::min<uint64_t>(end, mandatory));
+      ranges.push_back(end);
+    }
+    std::vector<uint32_t> counts;
+    if (int rc = count_ns(S, h_text, d_text, ranges, counts)) return rc;
+    for (size_t i = 0; i < so.cands.size(); ++i) {
+      const bool empty = ranges[2 * i] >= tlen || ranges[2 * i] == ranges[2 * i + 1];
+      keep[i] = (empty || n_frac_ok(counts[i], (uint64_t)plan.m + k, S->max_n_frac)) ? 1 : 0;
+    }
+    compact();
+  }
+  if (S->only_best && !so.cands.empty()) {  // minimal cost, then rightmost end (src/search.rs:1392-1412)
+    size_t best = 0;
+    for (size_t i = 1; i < so.cands.size(); ++i)
+      if (so.cands[i].cost < so.cands[best].cost ||
+          (so.cands[i].cost == so.cands[best].cost && so.cands[i].pos > so.cands[best].pos))
+        best = i;
+    for (size_t i = 0; i < so.cands.size(); ++i) keep[i] = i == best;
+    compact();
+  }
+  if (n_filter && with_trace) {  // traced_satisfy_n_frac (src/n_filter.rs:54-60)
+    std::vector<uint64_t> ranges;
+    ranges.reserve(2 * so.matches.size());
+    for (const sassy_hip_Match& r : so.matches) {
+      ranges.push_back(r.text_start);
+      ranges.push_back(r.text_end);
+    }
+    std::vector<uint32_t> counts;
+    if (int rc = count_ns(S, h_text, d_text, ranges, counts)) return rc;
+    for (size_t i = 0; i < so.matches.size(); ++i) {
+      const uint64_t len = ranges[2 * i + 1] - ranges[2 * i];
+      keep[i] = (ranges[2 * i] >= tlen || len == 0 || n_frac_ok(counts[i], len, S->max_n_frac)) ? 1 : 0;
+    }
+    compact();
+  }
+  return 0;
+}
+
 static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t plen, const uint8_t* text,
                        size_t tlen, size_t k, uint32_t flags, uint64_t pattern_idx, bool fwd_strand,
-                       bool rc_strand, sassy_hip_Result* R) {
+                       bool rc_strand, sassy_hip_Result* R, const EndFilter& ef = EndFilter()) {
   PatternPlan plan;
   std::string err;
   if (!make_plan(S->profile, pattern, plen, plan, err)) return fail(SASSY_HIP_EINVAL, err);
@@ -881,6 +1000,7 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
     ShardView sh{d_fwd, tlen, 0, 0, true, true};
     ScanOut so;
     if (int rc = run_scan(S, sh, plan, (uint32_t)k, all, pattern, !wo, tlen, so)) return rc;
+    if (int rc = post_filter(S, so, plan, pattern, (uint32_t)k, 0, on_dev ? nullptr : text, d_fwd, tlen, !wo, ef)) return rc;
     size_t first = 0;
     if (int rc = append_matches(so, tlen, plan, wo, pattern_idx, R, first)) return rc;
   }
@@ -897,6 +1017,11 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
     ShardView sh{S->d_rev.p, tlen, 0, 0, true, true};
     ScanOut so;
     if (int rc = run_scan(S, sh, cplan, (uint32_t)k, all, cp.data(), !wo, tlen, so)) return rc;
+    std::vector<uint8_t> h_rev;  // the callback sees the reversed text, like the reference's
+    if (ef.fn && !on_dev) h_rev.assign(std::reverse_iterator<const uint8_t*>(text + tlen),
+                                       std::reverse_iterator<const uint8_t*>(text));
+    if (int rc = post_filter(S, so, cplan, cp.data(), (uint32_t)k, 1, ef.fn && !on_dev ? h_rev.data() : nullptr,
+                             S->d_rev.p, tlen, !wo, ef)) return rc;
     size_t first = 0;
     if (int rc = append_matches(so, tlen, cplan, wo, pattern_idx, R, first)) return rc;
     for (size_t i = first; i < R->matches.size(); ++i) {
@@ -1001,6 +1126,38 @@ int sassy_hip_enable_counters(sassy_SearcherType* s, int on) {
 int sassy_hip_set_timing(sassy_SearcherType* s, int level) {
   if (!s || level < 0 || level > 2) return fail(SASSY_HIP_EINVAL, "timing level must be 0, 1 or 2");
   s->timing = level;
+  return 0;
+}
+
+int sassy_hip_set_only_best_match(sassy_SearcherType* s, int on) {
+  if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
+  s->only_best = on != 0;
+  return 0;
+}
+
+int sassy_hip_set_max_n_frac(sassy_SearcherType* s, float max_n_frac) {
+  if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
+  // the reference treats 1.0 as "no filter" (src/search.rs:454-460)
+  s->max_n_frac = (std::isnan(max_n_frac) || max_n_frac == 1.0f) ? NAN : max_n_frac;
+  return 0;
+}
+
+int sassy_hip_search_with_fn(sassy_SearcherType* s, const uint8_t* pattern, size_t pattern_len,
+                             const uint8_t* text, size_t text_len, size_t k, uint32_t flags,
+                             sassy_hip_end_filter fn, void* user, sassy_hip_Result** out) {
+  if (!s || !pattern || (!text && text_len) || !out || !fn) return fail(SASSY_HIP_EINVAL, "Pointers in search() must not be null");
+  if (flags & SASSY_HIP_TEXT_ON_DEVICE) return fail(SASSY_HIP_EINVAL, "search_with_fn needs the text in host memory");
+  const double t0 = now_ms();
+  reset_stats(s);
+  EndFilter ef;
+  ef.fn = fn;
+  ef.user = user;
+  sassy_hip_Result* R = new sassy_hip_Result();
+  if (int rc = search_text(s, pattern, pattern_len, text, text_len, k, flags, 0, true, s->rc, R, ef)) { delete R; return rc; }
+  if (R->pool.empty()) R->pool.push_back('\0');
+  s->stats.total_ms = now_ms() - t0;
+  s->stats.host_post_ms = s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms;
+  *out = R;
   return 0;
 }
 

@@ -292,6 +292,59 @@ def test_qgram_table_filter_text_letters(sassy):
         assert st["filtered"] == 3, st["filtered"]  # the table kernel really ran
 
 
+def test_reporting_modes(sassy, kats):
+    """search_with_fn, only_best_match, max_n_frac: the reference's known
+    answers, then seeded fuzz against the oracle's restatement of src/search.rs:884-937."""
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for e in kats["modes"]:
+        pat, text = e["pattern"].encode(), build_text(e)
+        s = sassy.Searcher(e["profile"], rc=e["rc"])
+        if "end_filter" in e:
+            fns = {
+                "text_len_gt_10_plus_m": lambda q, t, strand: len(t) > 10 + len(q),
+                "suffix_is_pattern_fwd_or_complement":
+                    lambda q, t, strand: (t[len(t) - len(q):] if strand == "+" else t[len(t) - len(q):].translate(comp)) == pat,
+            }
+            ms = s.search_with_fn(pat, text, e["k"], e["mode"] == "search_all", fns[e["end_filter"]])
+            assert [m.text_start for m in ms] == e["expect_text_start"], (e["id"], ms)
+        else:
+            s.with_max_n_frac(e["max_n_frac"])
+            ms = s.search_all(pat, text, e["k"])
+            assert [m.text_end for m in ms] == e["expect_text_end"], (e["id"], ms)
+    rng = random.Random(31)
+    for it in range(30):
+        profile = "iupac"
+        m, k = rng.randrange(8, 40), rng.randrange(0, 4)
+        pat = bytes(rng.choice(b"ACGT") for _ in range(m))
+        n = rng.randrange(200, 3000)
+        text = bytearray(rng.choice(b"ACGTN") if rng.random() < 0.3 else rng.choice(b"ACGT") for _ in range(n))
+        for _ in range(rng.randrange(1, 6)):
+            ins = bytearray(mutate(rng, pat, rng.randrange(0, k + 1)))
+            for _ in range(rng.randrange(0, 5)):
+                ins[rng.randrange(len(ins))] = ord("N")
+            at = rng.randrange(0, n - len(ins))
+            text[at:at + len(ins)] = ins
+        tb = bytes(text)
+        rc = bool(it & 1)
+        frac = rng.choice([0.0, 0.1, 0.25, 0.5])
+        allm = bool(it & 2)
+        # N-fraction filter
+        s = sassy.Searcher(profile, rc=rc).with_max_n_frac(frac)
+        got = s.search_all(pat, tb, k) if allm else s.search(pat, tb, k)
+        assert_same(got, oracle.search_modes(profile, pat, tb, k, rc=rc, all_minima=allm, max_n_frac=frac))
+        # only_best_match (+ the N filter in front of it)
+        s = sassy.Searcher(profile, rc=rc).only_best_match()
+        assert_same(s.search(pat, tb, k), oracle.search_modes(profile, pat, tb, k, rc=rc, only_best=True))
+        s.with_max_n_frac(frac)
+        assert_same(s.search(pat, tb, k),
+                    oracle.search_modes(profile, pat, tb, k, rc=rc, only_best=True, max_n_frac=frac))
+        # end-position callback: "the base before the match end is not G" (a PAM-like test)
+        fn = lambda q, t, strand: len(t) >= 2 and t[-2] != ord("G")
+        s = sassy.Searcher(profile, rc=rc)
+        assert_same(s.search_with_fn(pat, tb, k, allm, fn),
+                    oracle.search_modes(profile, pat, tb, k, rc=rc, all_minima=allm, end_filter=fn))
+
+
 def test_config1_shape_1mib(sassy):
     """BASELINE config 1: 'ATCG'x8, k=3, 1 MiB random ACGT (+ plants), Dna, forward only."""
     pat = b"ATCG" * 8

@@ -101,3 +101,27 @@ def test_complements():
     assert oracle.reverse_complement("dna", b"ATCGATCA") == b"TGATCGAT"
     assert oracle.complement("dna", b"ACGTacgtN") == b"TGCAacgtN"  # dna.rs:121-133: upper case only
     assert oracle.complement("iupac", b"ACGTRYSWKMBDHVNXacgtrykm") == b"TGCAYRSWMKVHDBNXtgcayrmk"
+
+
+def _end_filters(pattern_fwd: bytes):
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    return {
+        # the closures of the reference's tests (src/search.rs:2552, :2590-2595)
+        "text_len_gt_10_plus_m": lambda q, t, strand: len(t) > 10 + len(q),
+        "suffix_is_pattern_fwd_or_complement":
+            lambda q, t, strand: (t[len(t) - len(q):] if strand == "+" else t[len(t) - len(q):].translate(comp)) == pattern_fwd,
+    }
+
+
+def test_mode_kats(kats):
+    """search_with_fn / max_n_frac known answers against the oracle's restatement of the modes."""
+    for e in kats["modes"]:
+        pat = e["pattern"].encode()
+        text = build_text(e)
+        ms = oracle.search_modes(e["profile"], pat, text, e["k"], rc=e["rc"], all_minima=e["mode"] == "search_all",
+                                 end_filter=_end_filters(pat)[e["end_filter"]] if "end_filter" in e else None,
+                                 max_n_frac=e.get("max_n_frac"))
+        if "expect_text_start" in e:
+            assert [m.text_start for m in ms] == e["expect_text_start"], (e["id"], ms)
+        if "expect_text_end" in e:
+            assert [m.text_end for m in ms] == e["expect_text_end"], (e["id"], ms)
