@@ -116,6 +116,28 @@ int sassy_hip_search_with_fn(sassy_SearcherType *s, const uint8_t *pattern, size
                              const uint8_t *text, size_t text_len, size_t k, uint32_t flags,
                              sassy_hip_end_filter fn, void *user, sassy_hip_Result **out);
 
+/* Searcher::search_many / search_patterns / search_texts (src/search.rs:531-678): every pattern in
+ * every text; matches carry pattern_idx and text_idx and come pattern-major (pattern 0 in text 0,
+ * pattern 0 in text 1, ...), each pair in `search` order (Fwd by end position, then Rc) -- the order
+ * of the reference's SearchMode::Single.  With SASSY_HIP_TEXT_ON_DEVICE the text pointers are
+ * device pointers (16-byte aligned). */
+int sassy_hip_search_many(sassy_SearcherType *s, const uint8_t *const *patterns,
+                          const size_t *pattern_lens, size_t n_patterns, const uint8_t *const *texts,
+                          const size_t *text_lens, size_t n_texts, size_t k, uint32_t flags,
+                          sassy_hip_Result **out);
+
+/* One row of the reference CLI's match table (bin/grep.rs:465-470 header, :710-757 rows):
+ *   pat_id  text_id  cost  strand  start  end  match_region  cigar
+ * match_region = text[start..end), reverse-complemented for Rc matches unless `sam`; the cigar is
+ * reversed for Rc matches if `sam`.  `m` is a match record, `cigar` its NUL-terminated cigar text
+ * (sassy_hip_result_cigars(r) + m->cigar_off), `text` the host copy of the text it refers to.
+ * Writes at most cap bytes (NUL-terminated, '\n'-terminated row) and returns the length the full
+ * row needs (excluding the NUL), or a negative error code.  sassy_hip_tsv_header() is the header line. */
+const char *sassy_hip_tsv_header(void);
+long sassy_hip_format_tsv(const sassy_SearcherType *s, const sassy_hip_Match *m, const char *cigar,
+                          const char *pat_id, const char *text_id, const uint8_t *text,
+                          size_t text_len, int sam, char *buf, size_t cap);
+
 /* One shard of a larger text that lives on this device (multi-GPU).
  * d_text points at the first byte of the halo; the shard owns global end positions whose
  * 64-byte block lies in [global_offset, global_offset + shard_len); halo_len bytes precede it

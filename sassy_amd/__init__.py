@@ -108,6 +108,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_result_len", "sassy_hip_result_matches", "sassy_hip_result_cigars",
     "sassy_hip_result_cigars_len", "sassy_hip_enable_counters", "sassy_hip_set_timing",
     "sassy_hip_set_only_best_match", "sassy_hip_set_max_n_frac", "sassy_hip_search_with_fn",
+    "sassy_hip_search_many", "sassy_hip_tsv_header", "sassy_hip_format_tsv",
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
     "sassy_hip_generate_dna", "sassy_hip_plant",
@@ -157,6 +158,15 @@ def lib():
     L.sassy_hip_set_only_best_match.argtypes = [vp, C.c_int]
     L.sassy_hip_set_max_n_frac.restype = C.c_int
     L.sassy_hip_set_max_n_frac.argtypes = [vp, C.c_float]
+    L.sassy_hip_search_many.restype = C.c_int
+    L.sassy_hip_search_many.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t,
+                                        C.c_uint32, C.POINTER(vp)]
+    L.sassy_hip_tsv_header.restype = C.c_char_p
+    L.sassy_hip_tsv_header.argtypes = []
+    L.sassy_hip_format_tsv.restype = C.c_long
+    L.sassy_hip_format_tsv.argtypes = [vp, C.POINTER(_HipMatch), C.c_char_p, C.c_char_p, C.c_char_p, vp, C.c_size_t,
+                                       C.c_int, C.c_char_p, C.c_size_t]
     L.sassy_hip_search_with_fn.restype = C.c_int
     L.sassy_hip_search_with_fn.argtypes = [vp, C.c_char_p, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.c_uint32,
                                            END_FILTER, vp, C.POINTER(vp)]
@@ -353,6 +363,51 @@ class Searcher:
         _check(lib().sassy_hip_search_with_fn(self._h, pattern, len(pattern), addr, len(text), k,
                                               ALL_MINIMA if all_minima else 0, cb, None, C.byref(out)))
         return Result(out).matches
+
+    def search_many(self, patterns: Sequence[bytes], texts: Sequence, k: int, all_minima: bool = False) -> List[Match]:
+        """Searcher::search_many in SearchMode::Single order (src/search.rs:531-560): every pattern in
+        every text, pattern-major; matches carry pattern_idx and text_idx."""
+        patterns = [bytes(p) for p in patterns]
+        infos = [_ptr_len(t) for t in texts]
+        on_dev = [i[3] for i in infos]
+        if any(on_dev) and not all(on_dev):
+            raise SassyHipError("texts must be all on the host or all on the device")
+        pp = (C.c_char_p * len(patterns))(*patterns)
+        pl = (C.c_size_t * len(patterns))(*[len(p) for p in patterns])
+        tp = (C.c_void_p * len(infos))(*[i[0] for i in infos])
+        tl = (C.c_size_t * len(infos))(*[i[1] for i in infos])
+        flags = (ALL_MINIMA if all_minima else 0) | (TEXT_ON_DEVICE if infos and on_dev[0] else 0)
+        out = C.c_void_p()
+        _check(lib().sassy_hip_search_many(self._h, pp, pl, len(patterns), tp, tl, len(infos), k, flags, C.byref(out)))
+        return Result(out).matches
+
+    def search_patterns(self, patterns: Sequence[bytes], text, k: int) -> List[Match]:
+        """Searcher::search_patterns (src/search.rs:648-678): equal-length patterns in one text."""
+        patterns = [bytes(p) for p in patterns]
+        if patterns and any(len(p) != len(patterns[0]) for p in patterns):
+            raise SassyHipError("All patterns passed to search_patterns must have the same length")
+        return self.search_many(patterns, [text], k)
+
+    def search_texts(self, pattern: bytes, texts: Sequence, k: int) -> List[Match]:
+        """Searcher::search_texts (src/search.rs:615-637): one pattern in many texts."""
+        return self.search_many([pattern], texts, k)
+
+    def format_tsv(self, m: Match, pat_id: str, text_id: str, text: bytes, sam: bool = False) -> str:
+        """One row of the reference CLI's match table (bin/grep.rs:710-757)."""
+        cm = _HipMatch()
+        cm.pattern_idx, cm.text_idx = m.pattern_idx, m.text_idx
+        cm.text_start, cm.text_end = m.text_start, m.text_end
+        cm.pattern_start, cm.pattern_end = m.pattern_start, m.pattern_end
+        cm.cost, cm.strand = m.cost, 1 if m.strand == "-" else 0
+        text = bytes(text)
+        addr = C.cast(C.c_char_p(text), C.c_void_p).value or 0
+        args = (self._h, C.byref(cm), m.cigar.encode(), pat_id.encode(), text_id.encode(), addr, len(text), int(sam))
+        need = lib().sassy_hip_format_tsv(*args, None, 0)
+        if need < 0:
+            raise SassyHipError(lib().sassy_hip_last_error().decode())
+        buf = C.create_string_buffer(need + 1)
+        lib().sassy_hip_format_tsv(*args, buf, need + 1)
+        return buf.value.decode()
 
     def only_best_match(self, on: bool = True) -> "Searcher":
         """Searcher::only_best_match (src/search.rs:442-446)."""

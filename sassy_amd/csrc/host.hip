@@ -976,7 +976,8 @@ static int post_filter(sassy_SearcherType* S, ScanOut& so, const PatternPlan& pl
 
 static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t plen, const uint8_t* text,
                        size_t tlen, size_t k, uint32_t flags, uint64_t pattern_idx, bool fwd_strand,
-                       bool rc_strand, sassy_hip_Result* R, const EndFilter& ef = EndFilter()) {
+                       bool rc_strand, sassy_hip_Result* R, const EndFilter& ef = EndFilter(),
+                       bool already_uploaded = false) {
   PatternPlan plan;
   std::string err;
   if (!make_plan(S->profile, pattern, plen, plan, err)) return fail(SASSY_HIP_EINVAL, err);
@@ -989,8 +990,10 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
 
   const uint8_t* d_fwd = text;
   if (!on_dev) {
-    if (int rc = S->d_text.reserve(tlen + 64)) return rc;
-    HIP_TRY(hipMemcpyAsync(S->d_text.p, text, tlen, hipMemcpyHostToDevice, S->stream));
+    if (!already_uploaded) {
+      if (int rc = S->d_text.reserve(tlen + 64)) return rc;
+      HIP_TRY(hipMemcpyAsync(S->d_text.p, text, tlen, hipMemcpyHostToDevice, S->stream));
+    }
     d_fwd = S->d_text.p;
   } else if (((uintptr_t)text & 15) != 0) {
     return fail(SASSY_HIP_EINVAL, "device text pointer must be 16-byte aligned");
@@ -1159,6 +1162,90 @@ int sassy_hip_search_with_fn(sassy_SearcherType* s, const uint8_t* pattern, size
   s->stats.host_post_ms = s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms;
   *out = R;
   return 0;
+}
+
+int sassy_hip_search_many(sassy_SearcherType* s, const uint8_t* const* patterns, const size_t* pattern_lens,
+                          size_t n_patterns, const uint8_t* const* texts, const size_t* text_lens, size_t n_texts,
+                          size_t k, uint32_t flags, sassy_hip_Result** out) {
+  if (!s || !out || (n_patterns && (!patterns || !pattern_lens)) || (n_texts && (!texts || !text_lens)))
+    return fail(SASSY_HIP_EINVAL, "null argument");
+  const double t0 = now_ms();
+  reset_stats(s);
+  if (int rc = s->ensure_device()) return rc;
+  std::unique_ptr<sassy_hip_Result> R(new sassy_hip_Result());
+  // text-major internally (each host text is uploaded once), pattern-major in the result
+  for (size_t ti = 0; ti < n_texts; ++ti) {
+    const uint8_t* tptr = texts[ti];
+    uint32_t f = flags;
+    if (!tptr && text_lens[ti]) return fail(SASSY_HIP_EINVAL, "null text");
+    if (!(flags & SASSY_HIP_TEXT_ON_DEVICE) && text_lens[ti]) {
+      if (int rc = s->d_text.reserve(text_lens[ti] + 64)) return rc;
+      HIP_TRY(hipMemcpyAsync(s->d_text.p, tptr, text_lens[ti], hipMemcpyHostToDevice, s->stream));
+    }
+    for (size_t pi = 0; pi < n_patterns; ++pi) {
+      if (!patterns[pi]) return fail(SASSY_HIP_EINVAL, "null pattern");
+      const size_t first = R->matches.size();
+      // host texts: the scans read the uploaded copy, the host-side filters (if any) the original
+      if (int rc = search_text(s, patterns[pi], pattern_lens[pi], tptr, text_lens[ti], k, f, pi, true, s->rc, R.get(),
+                               EndFilter(), !(flags & SASSY_HIP_TEXT_ON_DEVICE))) return rc;
+      for (size_t i = first; i < R->matches.size(); ++i) R->matches[i].text_idx = ti;
+    }
+  }
+  std::stable_sort(R->matches.begin(), R->matches.end(), [](const sassy_hip_Match& a, const sassy_hip_Match& b) {
+    if (a.pattern_idx != b.pattern_idx) return a.pattern_idx < b.pattern_idx;
+    return a.text_idx < b.text_idx;
+  });
+  if (R->pool.empty()) R->pool.push_back('\0');
+  s->stats.total_ms = now_ms() - t0;
+  s->stats.host_post_ms = s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms;
+  *out = R.release();
+  return 0;
+}
+
+const char* sassy_hip_tsv_header(void) {
+  return "pat_id\ttext_id\tcost\tstrand\tstart\tend\tmatch_region\tcigar\n";  // bin/grep.rs:465-470
+}
+
+long sassy_hip_format_tsv(const sassy_SearcherType* s, const sassy_hip_Match* mp, const char* cigar, const char* pat_id,
+                          const char* text_id, const uint8_t* text, size_t text_len, int sam, char* buf, size_t cap) {
+  if (!s || !mp || !cigar || !pat_id || !text_id || (!text && text_len) || (!buf && cap))
+    return -(long)fail(SASSY_HIP_EINVAL, "null argument");
+  const sassy_hip_Match& m = *mp;
+  if (m.text_start > m.text_end || m.text_end > text_len)
+    return -(long)fail(SASSY_HIP_EINVAL, "match has no text span (searched without trace?) or exceeds the text");
+  std::string row;
+  row.reserve(64 + (m.text_end - m.text_start) + strlen(cigar));
+  row += pat_id; row += '\t'; row += text_id; row += '\t';
+  row += std::to_string(m.cost); row += '\t';
+  row += m.strand ? '-' : '+'; row += '\t';
+  row += std::to_string(m.text_start); row += '\t';
+  row += std::to_string(m.text_end); row += '\t';
+  if (m.strand && !sam) {  // pattern direction: reverse complement (bin/grep.rs:738-747)
+    for (uint64_t i = m.text_end; i > m.text_start; --i) row += (char)complement_char(s->profile, text[i - 1]);
+  } else {
+    row.append(reinterpret_cast<const char*>(text) + m.text_start, m.text_end - m.text_start);
+  }
+  row += '\t';
+  const char* cig = cigar;
+  if (m.strand && sam) {  // text direction: reverse the run list (bin/grep.rs:749-757)
+    std::vector<std::string> runs;
+    for (const char* p = cig; *p;) {
+      const char* q = p;
+      while (*q >= '0' && *q <= '9') ++q;
+      runs.emplace_back(p, q + 1);
+      p = q + 1;
+    }
+    for (size_t i = runs.size(); i > 0; --i) row += runs[i - 1];
+  } else {
+    row += cig;
+  }
+  row += '\n';
+  if (cap) {
+    const size_t ncopy = std::min(row.size(), cap - 1);
+    memcpy(buf, row.data(), ncopy);
+    buf[ncopy] = 0;
+  }
+  return (long)row.size();
 }
 
 int sassy_hip_search(sassy_SearcherType* s, const uint8_t* pattern, size_t pattern_len,

@@ -345,6 +345,62 @@ def test_reporting_modes(sassy, kats):
                     oracle.search_modes(profile, pat, tb, k, rc=rc, all_minima=allm, end_filter=fn))
 
 
+def test_search_many_and_tsv(sassy):
+    """search_many / search_patterns / search_texts = independent searches with
+    pattern_idx / text_idx, pattern-major; TSV rows as the reference CLI prints them (row 2)."""
+    rng = random.Random(5)
+    pats = [bytes(rng.choice(b"ACGT") for _ in range(16)) for _ in range(5)]
+    texts = []
+    for t in range(4):
+        n = rng.randrange(300, 5000)
+        text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        for p in pats:
+            ins = mutate(rng, p, rng.randrange(0, 3))
+            if rng.random() < 0.5:
+                ins = oracle.reverse_complement("dna", ins)
+            at = rng.randrange(0, n - len(ins))
+            text[at:at + len(ins)] = ins
+        texts.append(bytes(text))
+    texts.append(b"")  # an empty text has no matches
+    for rc in (False, True):
+        s = sassy.Searcher("dna", rc=rc)
+        got = s.search_many(pats, texts, 2)
+        want = []
+        for pi, p in enumerate(pats):
+            for ti, t in enumerate(texts):
+                for m in oracle.search("dna", p, t, 2, rc=rc):
+                    want.append((pi, ti, m.text_start, m.text_end, m.cost, m.strand, m.cigar))
+        assert [(m.pattern_idx, m.text_idx, m.text_start, m.text_end, m.cost, m.strand, m.cigar) for m in got] == want
+        assert len(want) >= 5
+        one_text = s.search_patterns(pats, texts[0], 2)
+        assert [(m.pattern_idx, m.text_start, m.cigar) for m in one_text] == \
+            [(w[0], w[2], w[6]) for w in want if w[1] == 0]
+        one_pat = s.search_texts(pats[1], texts, 2)
+        assert [(m.text_idx, m.text_start, m.cigar) for m in one_pat] == [(w[1], w[2], w[6]) for w in want if w[0] == 1]
+        # TSV rows (bin/grep.rs:710-757)
+        for m in got:
+            t = texts[m.text_idx]
+            region = t[m.text_start:m.text_end]
+            for sam in (False, True):
+                row = s.format_tsv(m, f"pat{m.pattern_idx}", f"text{m.text_idx}", t, sam=sam)
+                if m.strand == "-" and not sam:
+                    region_out = oracle.reverse_complement("dna", region)
+                else:
+                    region_out = region
+                cig = m.cigar
+                if m.strand == "-" and sam:
+                    import re
+                    cig = "".join(reversed(re.findall(r"\d+[=XID]", cig)))
+                assert row == f"pat{m.pattern_idx}\ttext{m.text_idx}\t{m.cost}\t{m.strand}\t{m.text_start}\t" \
+                              f"{m.text_end}\t{region_out.decode()}\t{cig}\n"
+    assert sassy.lib().sassy_hip_tsv_header() == b"pat_id\ttext_id\tcost\tstrand\tstart\tend\tmatch_region\tcigar\n"
+    # the reference's own format expectations (bin/grep.rs:800-817)
+    s = sassy.Searcher("dna", rc=True)
+    m = sassy.Match(0, 0, 4, 0, 4, 0, "-", "2=1X3D")
+    assert s.format_tsv(m, "p", "t", b"AAGT", sam=False).split("\t")[6:] == ["ACTT", "2=1X3D\n"]
+    assert s.format_tsv(m, "p", "t", b"AAGT", sam=True).split("\t")[6:] == ["AAGT", "3D1X2=\n"]
+
+
 def test_config1_shape_1mib(sassy):
     """BASELINE config 1: 'ATCG'x8, k=3, 1 MiB random ACGT (+ plants), Dna, forward only."""
     pat = b"ATCG" * 8
