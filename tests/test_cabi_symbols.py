@@ -105,3 +105,16 @@ def test_product_does_not_touch_the_oracle():
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "import oracle" not in src and "liboracle" not in src, f
                 assert "orc_" not in src.replace("orc_generate_dna", "").replace("orc_make_plant", "").replace("orc_plant_window", ""), f
+
+
+def test_cli_fastx_reader(tmp_path):
+    """FASTA (multi-line), FASTQ and gzip input of the CLI front end (host logic, no GPU)."""
+    import gzip
+    from sassy_amd.cli import read_fastx
+    (tmp_path / "a.fa").write_text(">chr1 desc\nACGT\nACGT\n>chr2\nTTTT\n")
+    (tmp_path / "b.fq").write_text("@r1 x\nACGTN\n+\nIIIII\n@r2\nGG\n+\n##\n")
+    with gzip.open(tmp_path / "c.fa.gz", "wb") as fh:
+        fh.write(b">z\nAC\nGT\n")
+    assert list(read_fastx(str(tmp_path / "a.fa"))) == [("chr1 desc", b"ACGTACGT"), ("chr2", b"TTTT")]
+    assert list(read_fastx(str(tmp_path / "b.fq"))) == [("r1 x", b"ACGTN"), ("r2", b"GG")]
+    assert list(read_fastx(str(tmp_path / "c.fa.gz"))) == [("z", b"ACGT")]

@@ -401,6 +401,56 @@ def test_search_many_and_tsv(sassy):
     assert s.format_tsv(m, "p", "t", b"AAGT", sam=True).split("\t")[6:] == ["AAGT", "3D1X2=\n"]
 
 
+def test_cli_search_tsv(sassy, tmp_path, capsys):
+    """`python -m sassy_amd search`: the reference CLI's TSV table for FASTA input,
+    defaults as in bin/grep.rs (iupac, rc on, max_n_frac 0.2), rows checked against the oracle."""
+    import gzip
+    import re
+    from sassy_amd import cli
+    rng = random.Random(77)
+    pats = [("guideA", b"ACGTTGCAAGGCTTACGATC"), ("guideB", b"TTGACCAGTNACGGATCCAT")]
+    recs = []
+    for r in range(3):
+        n = rng.randrange(500, 4000)
+        text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        for _, p in pats:
+            plain = bytes(c if c in b"ACGT" else 67 for c in p)
+            for _ in range(2):
+                ins = mutate(rng, plain, rng.randrange(0, 3))
+                if rng.random() < 0.5:
+                    ins = oracle.reverse_complement("iupac", ins)
+                at = rng.randrange(0, n - len(ins))
+                text[at:at + len(ins)] = ins
+        at = rng.randrange(0, n - 30)
+        text[at:at + 12] = b"N" * 12  # an N run: matches over it are dropped by max_n_frac
+        recs.append((f"rec{r} some description", bytes(text)))
+    fa = tmp_path / "texts.fa.gz"
+    with gzip.open(fa, "wb") as fh:
+        for rid, seq in recs:
+            fh.write(b">" + rid.encode() + b"\n")
+            for i in range(0, len(seq), 60):
+                fh.write(seq[i:i + 60] + b"\n")
+    pf = tmp_path / "pats.fa"
+    pf.write_bytes(b"".join(b">" + i.encode() + b"\n" + p + b"\n" for i, p in pats))
+    for sam in (False, True):
+        assert cli.main(["search", "-f", str(pf), "-k", "2", str(fa)] + (["--sam"] if sam else [])) == 0
+        lines = capsys.readouterr().out.splitlines()
+        assert lines[0] == "pat_id\ttext_id\tcost\tstrand\tstart\tend\tmatch_region\tcigar"
+        want = []
+        for rid, seq in recs:
+            for pid, p in pats:
+                for m in oracle.search_modes("iupac", p, seq, 2, rc=True, max_n_frac=0.2):
+                    region = seq[m.text_start:m.text_end]
+                    cig = m.cigar
+                    if m.strand == "-" and not sam:
+                        region = oracle.reverse_complement("iupac", region)
+                    if m.strand == "-" and sam:
+                        cig = "".join(reversed(re.findall(r"\d+[=XID]", cig)))
+                    want.append(f"{pid}\t{rid}\t{m.cost}\t{m.strand}\t{m.text_start}\t{m.text_end}\t{region.decode()}\t{cig}")
+        assert len(want) >= 8
+        assert lines[1:] == want
+
+
 def test_config1_shape_1mib(sassy):
     """BASELINE config 1: 'ATCG'x8, k=3, 1 MiB random ACGT (+ plants), Dna, forward only."""
     pat = b"ATCG" * 8
