@@ -106,25 +106,81 @@ struct sassy_hip_Encoded {
   size_t n_original;
 };
 
+// Everything one scan pipeline (filter -> chunk list -> DP -> rank -> traceback) needs for itself:
+// a stream, its timing events, its device work buffers and the pinned, device-mapped host buffer
+// its kernels write the results into.  A searcher owns several lanes so that a long text can be
+// cut into sub-shards whose pipelines overlap (the next sub-shard's bandwidth-bound filter runs
+// while the previous one's latency-bound DP / rank / traceback kernels finish).
+constexpr int kMaxLanes = 4;
+struct ScanLane {
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_f = nullptr, ev_filter_done = nullptr;
+  DevBuf<uint8_t> d_state, d_scratch, d_str, d_ctl;
+  DevBuf<Candidate> d_cand, d_sorted;
+  DevBuf<MatchOut> d_trace;
+  DevBuf<ChunkDesc> d_desc;
+  // pinned host staging area: control block and the first kSpec reports of a scan are written into
+  // it by the kernels themselves; one stream synchronisation makes them readable
+  unsigned char* h_pin = nullptr;
+  unsigned char* h_pin_dev = nullptr;  // device address of h_pin
+  size_t h_pin_cap = 0;
+  bool ready = false;
+  int reserve_pinned(size_t bytes) {
+    if (bytes <= h_pin_cap) return 0;
+    if (h_pin) (void)hipHostFree(h_pin);
+    h_pin = nullptr;
+    h_pin_cap = 0;
+    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h_pin), bytes, hipHostMallocMapped);
+    if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
+    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h_pin_dev), h_pin, 0);
+    if (e != hipSuccess) return hip_fail(e, "hipHostGetDevicePointer");
+    h_pin_cap = bytes;
+    return 0;
+  }
+  int init() {
+    if (ready) return 0;
+    if (!stream) {
+      HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+      own_stream = true;
+    }
+    HIP_TRY(hipEventCreate(&ev_a));
+    HIP_TRY(hipEventCreate(&ev_b));
+    HIP_TRY(hipEventCreate(&ev_c));
+    HIP_TRY(hipEventCreate(&ev_f));
+    HIP_TRY(hipEventCreateWithFlags(&ev_filter_done, hipEventDisableTiming));
+    ready = true;
+    return 0;
+  }
+  void destroy() {
+    d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release();
+    d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release();
+    if (h_pin) (void)hipHostFree(h_pin);
+    for (hipEvent_t e : {ev_a, ev_b, ev_c, ev_f, ev_filter_done})
+      if (e) (void)hipEventDestroy(e);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+  }
+};
+
 // The searcher.  Mirrors the configuration surface of the reference's Searcher<P>
 // (rc, alpha; reference: src/search.rs:227-256, 486-503) and caches device buffers the way the
 // reference caches its host buffers.
 struct sassy_SearcherType {
   Profile profile = PROFILE_DNA;
   bool rc = false;
+  // lanes[0].stream doubles as the searcher's stream: text / pattern uploads and everything that
+  // is not split into sub-shards run on it (sassy_hip_set_stream replaces it)
+  ScanLane lanes[kMaxLanes];
   hipStream_t stream = nullptr;
-  bool own_stream = false;
+  hipStream_t user_stream = nullptr;
+  hipEvent_t ev_inputs = nullptr;  // "uploads of this call are queued" (other lanes wait for it)
   bool device_ready = false;
-  hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_f = nullptr;
-  DevBuf<uint8_t> d_text, d_rev, d_state, d_pattern, d_scratch, d_str, d_ctl;
+  DevBuf<uint8_t> d_text, d_rev, d_pattern;
   DevBuf<uint32_t> d_rowoff;
   // what d_rowoff / d_pattern currently hold (uploads are skipped when the pattern repeats)
   std::vector<uint8_t> up_pattern;
   std::vector<uint32_t> up_rowtab;
   int up_profile = -1;
-  DevBuf<Candidate> d_cand, d_sorted;
-  DevBuf<MatchOut> d_trace;
-  DevBuf<ChunkDesc> d_desc;
 
   bool want_counters = false;
   // reporting modes of the reference's Searcher (src/search.rs:442-475)
@@ -140,36 +196,13 @@ struct sassy_SearcherType {
   // HIP-event timing of the call's phases: 0 none, 1 the dominant kernel only (filter / streaming
   // scan; default), 2 every phase.  Each event record costs a few microseconds of stream idle time.
   int timing = getenv("SASSY_HIP_TIMING") ? atoi(getenv("SASSY_HIP_TIMING")) : 1;
-  unsigned char* h_pin_dev = nullptr;  // device address of h_pin (kernels write results into it)
   sassy_hip_Stats stats{};
-  // pinned host staging area: counts, counters and the first kSpec reports of a call arrive with
-  // one batch of async copies in front of the single stream synchronisation
-  unsigned char* h_pin = nullptr;
-  size_t h_pin_cap = 0;
-  int reserve_pinned(size_t bytes) {
-    if (bytes <= h_pin_cap) return 0;
-    if (h_pin) (void)hipHostFree(h_pin);
-    h_pin = nullptr;
-    h_pin_cap = 0;
-    hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h_pin), bytes, hipHostMallocMapped);
-    if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
-    e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h_pin_dev), h_pin, 0);
-    if (e != hipSuccess) return hip_fail(e, "hipHostGetDevicePointer");
-    h_pin_cap = bytes;
-    return 0;
-  }
 
   ~sassy_SearcherType() {
-    d_text.release(); d_rev.release(); d_state.release(); d_pattern.release(); d_scratch.release();
-    d_str.release(); d_rowoff.release(); d_ctl.release(); d_cand.release(); d_sorted.release();
-    d_trace.release();
-    d_desc.release(); d_table.release(); d_range.release(); d_ncount.release();
-    if (h_pin) (void)hipHostFree(h_pin);
-    if (ev_f) (void)hipEventDestroy(ev_f);
-    if (ev_a) (void)hipEventDestroy(ev_a);
-    if (ev_b) (void)hipEventDestroy(ev_b);
-    if (ev_c) (void)hipEventDestroy(ev_c);
-    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    d_text.release(); d_rev.release(); d_pattern.release(); d_rowoff.release();
+    d_table.release(); d_range.release(); d_ncount.release();
+    for (ScanLane& l : lanes) l.destroy();
+    if (ev_inputs) (void)hipEventDestroy(ev_inputs);
   }
 
   int ensure_device() {
@@ -179,14 +212,11 @@ struct sassy_SearcherType {
     if (e != hipSuccess || n <= 0)
       return fail(SASSY_HIP_ENODEVICE,
                   "no usable HIP device (libsassy_hip has no CPU fallback; the scan runs on gfx950 only)");
-    if (!stream) {
-      HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-      own_stream = true;
-    }
-    HIP_TRY(hipEventCreate(&ev_a));
-    HIP_TRY(hipEventCreate(&ev_b));
-    HIP_TRY(hipEventCreate(&ev_c));
-    HIP_TRY(hipEventCreate(&ev_f));
+    lanes[0].stream = user_stream;  // null: the lane creates its own
+    for (ScanLane& l : lanes)
+      if (int rc = l.init()) return rc;
+    stream = lanes[0].stream;
+    HIP_TRY(hipEventCreateWithFlags(&ev_inputs, hipEventDisableTiming));
     device_ready = true;
     return 0;
   }
@@ -328,20 +358,68 @@ static int stream_geometry(ScanParams& P, uint64_t owned, uint32_t extra_front, 
   return 0;
 }
 
-// Runs the scan over one buffer and returns the resolved reports (+ device traceback records).
+// One scan of one buffer (shard or sub-shard) on one lane, in three phases so that several can be
+// in flight: prepare() sizes everything and uploads what the pattern needs, enqueue() queues the
+// whole kernel pipeline on the lane's stream without waiting, finish() waits for it, grows buffers
+// and re-runs on overflow, and turns the device output into resolved reports.
 // Two exact paths: the streaming DP over every block, or -- when the pattern splits into k+1
 // selective pieces -- prefilter (K0) -> chunk list (K0b) -> DP over the listed chunks (K1-list).
-static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPlan& plan, uint32_t k,
-                    bool all_minima, const uint8_t* pat, bool do_trace, uint64_t total_len, ScanOut& out) {
-  const double t_enter = now_ms();
-  out = ScanOut();
-  const uint64_t n_blocks = (sh.text_len + 63) / 64;
-  const uint64_t first_owned = sh.halo_len / 64;
-  if (n_blocks <= first_owned) return 0;  // nothing owned (empty text)
-  if (n_blocks > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "text longer than 2^38 bytes per buffer");
-  const uint64_t owned = n_blocks - first_owned;
+struct ScanJob {
+  sassy_SearcherType* S;
+  ScanLane& L;
+  ShardView sh;
+  const PatternPlan& plan;
+  uint32_t k;
+  bool all_minima;
+  const uint8_t* pat;
+  bool do_trace;
+  uint64_t total_len;
+  hipEvent_t wait_for = nullptr;     // pipelining: the previous sub-shard's "filter done"
+  bool signal_filter_done = false;   // pipelining: record L.ev_filter_done behind this filter
 
-  ScanParams P{};
+  static constexpr size_t kCtlHead = 64 + 4 * (size_t)kRankLimit;
+  static constexpr uint32_t kTraceWaveMax = 8192;
+  static constexpr uint32_t maxlen = 128;  // list mode: longest chunk in blocks (long runs are cut)
+  static constexpr uint32_t kSpec = 4096;  // reports the kernels also write into the host buffer
+  static constexpr size_t kPinCounts = 0, kPinCounters = 16;
+  static constexpr size_t pin_cands = 128;
+  static constexpr size_t pin_recs = pin_cands + (size_t)kSpec * sizeof(Candidate);
+  static constexpr size_t pin_ops = pin_recs + (size_t)kSpec * sizeof(MatchOut);
+
+  bool empty = false;
+  double t_enter = 0, t_mark = 0;
+  uint64_t n_blocks = 0, first_owned = 0, owned = 0, n_words = 0;
+  ScanParams P{}, F{};
+  uint32_t bucket = 4, q = 0;
+  bool filtered = false;
+  FilterKind fkind = kFilterGeneric;
+  unsigned long long* d_bitmap = nullptr;
+  uint32_t* d_counts = nullptr;
+  unsigned long long* d_counters = nullptr;
+  TraceParams T{}, Tw{};
+  uint32_t trace_blocks = 0, wave_blocks = 0, grid = 0, fgrid = 0, desc_cap = 0;
+  bool use_wave = false, use_thread = false, ev_scan = false;
+  uint32_t counts[2] = {0, 0};  // reports, chunk descriptors
+  int timing = 1;
+
+  ScanJob(sassy_SearcherType* S_, ScanLane& L_, const ShardView& sh_, const PatternPlan& plan_, uint32_t k_,
+          bool all_, const uint8_t* pat_, bool do_trace_, uint64_t total_len_)
+      : S(S_), L(L_), sh(sh_), plan(plan_), k(k_), all_minima(all_), pat(pat_), do_trace(do_trace_),
+        total_len(total_len_) {}
+  int prepare();
+  int enqueue(int attempt);
+  int finish(ScanOut& out);
+};
+
+int ScanJob::prepare() {
+  t_enter = now_ms();
+  n_blocks = (sh.text_len + 63) / 64;
+  first_owned = sh.halo_len / 64;
+  if (n_blocks <= first_owned) { empty = true; return 0; }  // nothing owned (empty text)
+  if (n_blocks > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "text longer than 2^38 bytes per buffer");
+  owned = n_blocks - first_owned;
+
+  P = ScanParams{};
   P.text = sh.d_text;
   P.text_len = sh.text_len;
   P.n_blocks = n_blocks;
@@ -355,14 +433,14 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   P.wb = warmup_blocks(plan.m, k);
   P.flags = (all_minima ? kScanAllMinima : 0u) | (sh.text_start ? kScanTextStart : 0u) |
             (sh.text_end ? kScanTextEnd : 0u);
-  const uint32_t bucket = plan.nslots <= 4 ? 4 : plan.nslots <= 8 ? 8 : 16;
+  bucket = plan.nslots <= 4 ? 4 : plan.nslots <= 8 ? 8 : 16;
   static const int env_sb = getenv("SASSY_HIP_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_STAGE_BLOCKS")) : 0;
   P.stage_blocks = env_sb == 1 || env_sb == 2 ? (uint32_t)env_sb : 1u;
   for (int s = 0; s < kMaxSlots; ++s) P.slot_val[s] = plan.slot_val[s];
-  uint32_t q = filter_piece_len(plan, k);
-  const bool filtered = q > 0;
+  q = filter_piece_len(plan, k);
+  filtered = q > 0;
   // which prefilter kernel (SASSY_HIP_FILTER_KIND=1|2|3 forces one where it applies)
-  FilterKind fkind = kFilterGeneric;
+  fkind = kFilterGeneric;
   if (filtered) {
     static const int env_kind = getenv("SASSY_HIP_FILTER_KIND") ? atoi(getenv("SASSY_HIP_FILTER_KIND")) : 0;
     const uint32_t pieces = k + 1;
@@ -413,14 +491,13 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   //             [0] word rows, [1] blocks, [2] hit blocks
   //   [64, ..)  rank counters of the first kRankLimit reports
   //   [kCtlHead, ..)  the prefilter's hit bitmap (one bit per text block)
-  constexpr size_t kCtlHead = 64 + 4 * (size_t)kRankLimit;
-  const uint64_t n_words = filtered ? (n_blocks + 63) / 64 : 0;
-  if (int rc = S->d_ctl.reserve(kCtlHead + (filtered ? (n_words + 2) * 8 : 0))) return rc;
-  unsigned long long* d_bitmap = reinterpret_cast<unsigned long long*>(S->d_ctl.p + kCtlHead);
-  if (S->d_cand.cap == 0)
-    if (int rc = S->d_cand.reserve(1u << 16)) return rc;
-  uint32_t* d_counts = reinterpret_cast<uint32_t*>(S->d_ctl.p);
-  unsigned long long* d_counters = reinterpret_cast<unsigned long long*>(S->d_ctl.p + 16);
+  n_words = filtered ? (n_blocks + 63) / 64 : 0;
+  if (int rc = L.d_ctl.reserve(kCtlHead + (filtered ? (n_words + 2) * 8 : 0))) return rc;
+  d_bitmap = reinterpret_cast<unsigned long long*>(L.d_ctl.p + kCtlHead);
+  if (L.d_cand.cap == 0)
+    if (int rc = L.d_cand.reserve(1u << 16)) return rc;
+  d_counts = reinterpret_cast<uint32_t*>(L.d_ctl.p);
+  d_counters = reinterpret_cast<unsigned long long*>(L.d_ctl.p + 16);
   P.row_tab = S->d_rowoff.p;
   P.cand_count = d_counts;
   P.counters = S->want_counters ? d_counters : nullptr;
@@ -432,10 +509,10 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   //       <= 64 columns and four slices in LDS);
   //   Tt  one thread per report     -- throughput-optimal for dense results (k <= 6: band row in
   //       registers), and the only shape for very wide bands.
-  constexpr uint32_t kTraceWaveMax = 8192;
-  TraceParams T{}, Tw{};
-  uint32_t trace_blocks = 0, wave_blocks = 0;
-  bool use_wave = false, use_thread = false;
+  T = TraceParams{};
+  Tw = TraceParams{};
+  trace_blocks = wave_blocks = 0;
+  use_wave = use_thread = false;
   if (do_trace) {
     const uint64_t cell = (k + 1 <= 255) ? 1 : 2;
     const uint64_t band = ((uint64_t)(plan.m + 1) * (2ull * k + 3) * cell + 3) / 4 * 4;
@@ -456,7 +533,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
       nthreads = std::max<uint64_t>(64, std::min<uint64_t>(16384, nthreads)) / 64 * 64;
       trace_blocks = (uint32_t)(nthreads / 64);
       if (64 * stride + pat_bytes > kTraceLdsLimit)  // slices in global memory
-        if (int rc = S->d_scratch.reserve(nthreads * stride)) return rc;
+        if (int rc = L.d_scratch.reserve(nthreads * stride)) return rc;
     }
     wave_blocks = 1024;  // 4096 wavefronts, grid-stride over the reports
     T.band_bytes = (uint32_t)band;
@@ -469,7 +546,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     T.k = k;
     T.profile = (uint32_t)S->profile;
     T.pattern = S->d_pattern.p;
-    T.scratch = S->d_scratch.p;
+    T.scratch = L.d_scratch.p;
     T.scratch_stride = (uint32_t)stride;
     T.str_stride = (2 * (plan.m + k + 1) + 2 + 15) / 16 * 16;
     T.ops_bytes = (uint32_t)opsb;
@@ -484,17 +561,16 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   }
 
   // ---- geometry of the streaming kernel (full DP, or the prefilter) ----
-  uint32_t grid = 0;
-  ScanParams F = P;           // prefilter launch
-  uint32_t fgrid = 0;
-  const uint32_t maxlen = 128;  // list mode: longest chunk in blocks (long runs are cut)
+  grid = 0;
+  F = P;           // prefilter launch
+  fgrid = 0;
   if (!filtered) {
     if (int rc = stream_geometry(P, owned, P.wb, &grid)) return rc;
     P.lds_per_wave = 4096u * P.stage_blocks + bucket * 512u + plan.nwords * 512u;
     if ((size_t)kWavesPerGroup * P.lds_per_wave > 160 * 1024)
       return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
-    if (int rc = S->d_state.reserve(P.n_chunks)) return rc;
-    P.chunk_state = S->d_state.p;
+    if (int rc = L.d_state.reserve(P.n_chunks)) return rc;
+    P.chunk_state = L.d_state.p;
   } else {
     // K0 also looks at the last halo blocks: a piece that ends there can belong to a match that
     // ends in the first owned blocks, and K0b must know whether the block left of the first
@@ -547,128 +623,138 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, 1, &fgrid, fwpc)) return rc;
     F.lds_per_wave = 4096u * F.stage_blocks + (F.piece_planes ? 0u : 2u * bucket * 512u);
     F.hit_bitmap = d_bitmap;
-    if (S->d_desc.cap == 0)
-      if (int rc = S->d_desc.reserve(1u << 18)) return rc;
+    if (L.d_desc.cap == 0)
+      if (int rc = L.d_desc.reserve(1u << 18)) return rc;
     P.lds_per_wave = bucket * 512u + plan.nwords * 512u;
     if ((size_t)kWavesPerGroup * P.lds_per_wave > 160 * 1024)
       return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
   }
 
-  double t_mark = t_enter;
-  constexpr uint32_t kSpec = 4096;               // reports fetched speculatively with the counts
-  constexpr size_t kPinCounts = 0, kPinCounters = 16;
-  const size_t pin_cands = 128;
-  const size_t pin_recs = pin_cands + (size_t)kSpec * sizeof(Candidate);
-  const size_t pin_ops = pin_recs + (size_t)kSpec * sizeof(MatchOut);
-  if (int rc = S->reserve_pinned(pin_ops + (size_t)kSpec * (do_trace ? T.str_stride : 0) + 64)) return rc;
-  uint32_t counts[2] = {0, 0};  // reports, chunk descriptors
-  const int timing = S->timing;
-  uint32_t desc_cap = 0;
-  for (int attempt = 0; attempt < 4; ++attempt) {
-    P.cand = S->d_cand.p;
-    P.cand_cap = (uint32_t)std::min<size_t>(S->d_cand.cap, 0xFFFFFFFFu);
-    if (int rc = S->d_sorted.reserve(P.cand_cap)) return rc;
-    if (do_trace) {
-      if ((uint64_t)P.cand_cap * T.str_stride > 0xFFFFFFFFull)
-        return fail(SASSY_HIP_EUNSUPPORTED, "too many reports for one cigar pool (> 4 GiB of cigar text)");
-      if (int rc = S->d_trace.reserve(P.cand_cap)) return rc;
-      if (int rc = S->d_str.reserve((size_t)P.cand_cap * T.str_stride)) return rc;
-      T.cand = Tw.cand = S->d_sorted.p;
-      T.cand_cap = Tw.cand_cap = P.cand_cap;
-      T.out = Tw.out = S->d_trace.p;
-      T.out_str = Tw.out_str = S->d_str.p;
+  t_mark = t_enter;
+  if (int rc = L.reserve_pinned(pin_ops + (size_t)kSpec * (do_trace ? T.str_stride : 0) + 64)) return rc;
+  counts[0] = counts[1] = 0;
+  timing = S->timing;
+  desc_cap = 0;
+  return 0;
+}
+
+int ScanJob::enqueue(int attempt) {
+  P.cand = L.d_cand.p;
+  P.cand_cap = (uint32_t)std::min<size_t>(L.d_cand.cap, 0xFFFFFFFFu);
+  if (int rc = L.d_sorted.reserve(P.cand_cap)) return rc;
+  if (do_trace) {
+    if ((uint64_t)P.cand_cap * T.str_stride > 0xFFFFFFFFull)
+      return fail(SASSY_HIP_EUNSUPPORTED, "too many reports for one cigar pool (> 4 GiB of cigar text)");
+    if (int rc = L.d_trace.reserve(P.cand_cap)) return rc;
+    if (int rc = L.d_str.reserve((size_t)P.cand_cap * T.str_stride)) return rc;
+    T.cand = Tw.cand = L.d_sorted.p;
+    T.cand_cap = Tw.cand_cap = P.cand_cap;
+    T.out = Tw.out = L.d_trace.p;
+    T.out_str = Tw.out_str = L.d_str.p;
+  }
+  // control block, rank counters and (first attempt: the filter runs once) the hit bitmap
+  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, kCtlHead + (filtered && attempt == 0 ? (n_words + 2) * 8 : 0), L.stream));
+  // pipelined sub-shards: this lane's filter starts when the previous sub-shard's filter is done,
+  // so that the previous lane's DP / rank / traceback kernels overlap this bandwidth-bound one
+  if (wait_for && attempt == 0) HIP_TRY(hipStreamWaitEvent(L.stream, wait_for, 0));
+  if (timing >= 1) HIP_TRY(hipEventRecord(L.ev_a, L.stream));
+  hipError_t le;
+  if (!filtered) {
+    le = launch_scan_any(S->profile, P, grid, (size_t)kWavesPerGroup * P.lds_per_wave, L.stream);
+    if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
+  } else {
+    if (attempt == 0) {  // the hit bitmap does not depend on buffer sizes: build it once
+      le = fkind == kFilterTable
+               ? launch_filter_table(F, fgrid, L.stream)
+               : launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, L.stream);
+      if (le != hipSuccess) return hip_fail(le, "filter kernel launch");
     }
-    // control block, rank counters and (first attempt: the filter runs once) the hit bitmap
-    HIP_TRY(hipMemsetAsync(S->d_ctl.p, 0, kCtlHead + (filtered && attempt == 0 ? (n_words + 2) * 8 : 0), S->stream));
-    if (timing >= 1) HIP_TRY(hipEventRecord(S->ev_a, S->stream));
-    hipError_t le;
-    if (!filtered) {
-      le = launch_scan_any(S->profile, P, grid, (size_t)kWavesPerGroup * P.lds_per_wave, S->stream);
-      if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
-    } else {
-      if (attempt == 0) {  // the hit bitmap does not depend on buffer sizes: build it once
-        le = fkind == kFilterTable
-                 ? launch_filter_table(F, fgrid, S->stream)
-                 : launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, S->stream);
-        if (le != hipSuccess) return hip_fail(le, "filter kernel launch");
-      }
-      if (timing >= 1 && attempt == 0) HIP_TRY(hipEventRecord(S->ev_f, S->stream));
-      desc_cap = (uint32_t)std::min<size_t>(S->d_desc.cap, 0x7FFFFFFFu);
-      if (int rc = S->d_state.reserve(desc_cap)) return rc;
-      P.chunk_state = S->d_state.p;
-      le = launch_build_chunks(d_bitmap, n_words, n_blocks, first_owned, P.wb, P.wb, maxlen, S->d_desc.p,
-                               d_counts + 1, desc_cap, d_counters + 2, S->stream);
-      if (le != hipSuccess) return hip_fail(le, "chunk builder launch");
-      P.desc = S->d_desc.p;
-      P.desc_count = d_counts + 1;
-      P.desc_cap = desc_cap;
-      // the descriptor count lives on the device: launch for the capacity, idle waves exit at once
-      const uint32_t lgrid = (desc_cap + 255) / 256;
-      le = launch_list_any(S->profile, P, lgrid, (size_t)kWavesPerGroup * P.lds_per_wave, S->stream);
-      if (le != hipSuccess) return hip_fail(le, "list kernel launch");
+    if (timing >= 1 && attempt == 0) HIP_TRY(hipEventRecord(L.ev_f, L.stream));
+    if (signal_filter_done && attempt == 0) HIP_TRY(hipEventRecord(L.ev_filter_done, L.stream));
+    desc_cap = (uint32_t)std::min<size_t>(L.d_desc.cap, 0x7FFFFFFFu);
+    if (int rc = L.d_state.reserve(desc_cap)) return rc;
+    P.chunk_state = L.d_state.p;
+    le = launch_build_chunks(d_bitmap, n_words, n_blocks, first_owned, P.wb, P.wb, maxlen, L.d_desc.p,
+                             d_counts + 1, desc_cap, d_counters + 2, L.stream);
+    if (le != hipSuccess) return hip_fail(le, "chunk builder launch");
+    P.desc = L.d_desc.p;
+    P.desc_count = d_counts + 1;
+    P.desc_cap = desc_cap;
+    // the descriptor count lives on the device: launch for the capacity, idle waves exit at once
+    const uint32_t lgrid = (desc_cap + 255) / 256;
+    le = launch_list_any(S->profile, P, lgrid, (size_t)kWavesPerGroup * P.lds_per_wave, L.stream);
+    if (le != hipSuccess) return hip_fail(le, "list kernel launch");
+  }
+  ev_scan = timing >= 2 || (timing == 1 && !filtered);
+  if (ev_scan) HIP_TRY(hipEventRecord(L.ev_b, L.stream));
+  // reports into result order (by end position) -- the head of the list and the control block
+  // straight into the pinned host buffer --, then their traceback
+  const uint32_t host_cap = std::min<uint32_t>(kSpec, P.cand_cap);
+  le = launch_rank(L.d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(L.d_ctl.p + 64),
+                   L.d_sorted.p, reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands), host_cap,
+                   L.h_pin_dev + kPinCounts, L.stream);
+  if (le != hipSuccess) return hip_fail(le, "rank kernel launch");
+  if (do_trace) {
+    T.host_out = Tw.host_out = reinterpret_cast<MatchOut*>(L.h_pin_dev + pin_recs);
+    T.host_str = Tw.host_str = L.h_pin_dev + pin_ops;
+    T.host_cap = Tw.host_cap = host_cap;
+    if (use_wave) {
+      le = launch_trace(Tw, wave_blocks, L.stream);
+      if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
     }
-    const bool ev_scan = timing >= 2 || (timing == 1 && !filtered);
-    if (ev_scan) HIP_TRY(hipEventRecord(S->ev_b, S->stream));
-    // reports into result order (by end position) -- the head of the list and the control block
-    // straight into the pinned host buffer --, then their traceback
-    const uint32_t host_cap = std::min<uint32_t>(kSpec, P.cand_cap);
-    le = launch_rank(S->d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(S->d_ctl.p + 64),
-                     S->d_sorted.p, reinterpret_cast<Candidate*>(S->h_pin_dev + pin_cands), host_cap,
-                     S->h_pin_dev + kPinCounts, S->stream);
-    if (le != hipSuccess) return hip_fail(le, "rank kernel launch");
-    if (do_trace) {
-      T.host_out = Tw.host_out = reinterpret_cast<MatchOut*>(S->h_pin_dev + pin_recs);
-      T.host_str = Tw.host_str = S->h_pin_dev + pin_ops;
-      T.host_cap = Tw.host_cap = host_cap;
-      if (use_wave) {
-        le = launch_trace(Tw, wave_blocks, S->stream);
-        if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
-      }
-      if (use_thread) {
-        le = launch_trace(T, trace_blocks, S->stream);
-        if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
-      }
-      if (timing >= 2) HIP_TRY(hipEventRecord(S->ev_c, S->stream));
+    if (use_thread) {
+      le = launch_trace(T, trace_blocks, L.stream);
+      if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
     }
+    if (timing >= 2) HIP_TRY(hipEventRecord(L.ev_c, L.stream));
+  }
+  return 0;
+}
+
+int ScanJob::finish(ScanOut& out) {
+  out = ScanOut();
+  if (empty) return 0;
+  for (int attempt = 0;; ++attempt) {
     // the only synchronisation of the call; the kernels have written the results into h_pin
     const double t_sync0 = now_ms();
-    HIP_TRY(hipStreamSynchronize(S->stream));
+    HIP_TRY(hipStreamSynchronize(L.stream));
     const double t_sync1 = now_ms();
     S->stats.host_enqueue_ms += t_sync0 - t_mark;
     S->stats.host_wait_ms += t_sync1 - t_sync0;
     t_mark = t_sync1;
     g_marks.start();
-    memcpy(counts, S->h_pin + kPinCounts, sizeof counts);
+    memcpy(counts, L.h_pin + kPinCounts, sizeof counts);
     float ms = 0;
     if (ev_scan) {
-      HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_b));
+      HIP_TRY(hipEventElapsedTime(&ms, L.ev_a, L.ev_b));
       S->stats.scan_ms += ms;
     }
     S->stats.scan_launches += 1;
     if (filtered && attempt == 0 && timing >= 1) {
-      HIP_TRY(hipEventElapsedTime(&ms, S->ev_a, S->ev_f));
+      HIP_TRY(hipEventElapsedTime(&ms, L.ev_a, L.ev_f));
       S->stats.filter_ms += ms;
     }
     if (do_trace && timing >= 2) {
-      HIP_TRY(hipEventElapsedTime(&ms, S->ev_b, S->ev_c));
+      HIP_TRY(hipEventElapsedTime(&ms, L.ev_b, L.ev_c));
       S->stats.trace_ms += ms;
     }
     g_marks.mark("event times");
     bool again = false;
     if (filtered && counts[1] > desc_cap) {  // more chunks than descriptors fit: grow, rebuild
-      if (int rc = S->d_desc.reserve((size_t)counts[1] + 1024)) return rc;
+      if (int rc = L.d_desc.reserve((size_t)counts[1] + 1024)) return rc;
       again = true;
     }
     if (counts[0] > P.cand_cap) {  // more reports than the buffer holds (dense matches)
-      if (int rc = S->d_cand.reserve((size_t)counts[0] + 1024)) return rc;
+      if (int rc = L.d_cand.reserve((size_t)counts[0] + 1024)) return rc;
       again = true;
     }
     if (!again) break;
     if (attempt == 3) return fail(SASSY_HIP_ENOMEM, "candidate / descriptor buffer overflow");
+    if (int rc = enqueue(attempt + 1)) return rc;
   }
   const uint32_t count = counts[0];
   const uint32_t n_desc = filtered ? counts[1] : 0;
-  S->stats.chunks = filtered ? n_desc : P.n_chunks;
+  S->stats.chunks += filtered ? n_desc : P.n_chunks;
   S->stats.blocks_per_chunk = filtered ? F.bpl : P.bpl;
   S->stats.warmup_blocks = P.wb;
   S->stats.grid = filtered ? fgrid : grid;
@@ -677,7 +763,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   S->stats.piece_len = q;
   {
     unsigned long long c[4];
-    memcpy(c, S->h_pin + kPinCounters, sizeof c);
+    memcpy(c, L.h_pin + kPinCounters, sizeof c);
     S->stats.word_rows += c[0];
     S->stats.blocks += c[1];
     S->stats.hit_blocks += c[2];
@@ -687,17 +773,17 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   out.cands.resize(count);
   if (count) {
     const uint32_t have = std::min<uint32_t>(count, kSpec);
-    memcpy(out.cands.data(), S->h_pin + pin_cands, (size_t)have * sizeof(Candidate));
+    memcpy(out.cands.data(), L.h_pin + pin_cands, (size_t)have * sizeof(Candidate));
     if (count > have)
-      HIP_TRY(hipMemcpy(out.cands.data() + have, S->d_sorted.p + have, (size_t)(count - have) * sizeof(Candidate), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(out.cands.data() + have, L.d_sorted.p + have, (size_t)(count - have) * sizeof(Candidate), hipMemcpyDeviceToHost));
     if (do_trace) {
       out.matches.resize(count);
       out.pool.resize((size_t)count * T.str_stride);
-      memcpy(out.matches.data(), S->h_pin + pin_recs, (size_t)have * sizeof(MatchOut));
-      memcpy(&out.pool[0], S->h_pin + pin_ops, (size_t)have * T.str_stride);
+      memcpy(out.matches.data(), L.h_pin + pin_recs, (size_t)have * sizeof(MatchOut));
+      memcpy(&out.pool[0], L.h_pin + pin_ops, (size_t)have * T.str_stride);
       if (count > have) {
-        HIP_TRY(hipMemcpy(out.matches.data() + have, S->d_trace.p + have, (size_t)(count - have) * sizeof(MatchOut), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&out.pool[0] + (size_t)have * T.str_stride, S->d_str.p + (size_t)have * T.str_stride,
+        HIP_TRY(hipMemcpy(out.matches.data() + have, L.d_trace.p + have, (size_t)(count - have) * sizeof(MatchOut), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(&out.pool[0] + (size_t)have * T.str_stride, L.d_str.p + (size_t)have * T.str_stride,
                           (size_t)(count - have) * T.str_stride, hipMemcpyDeviceToHost));
       }
     }
@@ -735,7 +821,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   if (need_state) {
     if (!filtered) {
       std::vector<uint8_t> state(P.n_chunks);
-      HIP_TRY(hipMemcpy(state.data(), S->d_state.p, P.n_chunks, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(state.data(), L.d_state.p, P.n_chunks, hipMemcpyDeviceToHost));
       chunks.resize(P.n_chunks);
       for (uint64_t c = 0; c < P.n_chunks; ++c) {
         const uint64_t lo = first_owned + c * P.bpl;
@@ -744,8 +830,8 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
     } else if (n_desc) {
       std::vector<ChunkDesc> desc(n_desc);
       std::vector<uint8_t> state(n_desc);
-      HIP_TRY(hipMemcpy(desc.data(), S->d_desc.p, (size_t)n_desc * sizeof(ChunkDesc), hipMemcpyDeviceToHost));
-      HIP_TRY(hipMemcpy(state.data(), S->d_state.p, n_desc, hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(desc.data(), L.d_desc.p, (size_t)n_desc * sizeof(ChunkDesc), hipMemcpyDeviceToHost));
+      HIP_TRY(hipMemcpy(state.data(), L.d_state.p, n_desc, hipMemcpyDeviceToHost));
       chunks.resize(n_desc);
       for (uint32_t c = 0; c < n_desc; ++c)
         chunks[c] = ChunkInfo{desc[c].own_lo, desc[c].own_hi, state[c], (desc[c].flags & kDescClearBefore) != 0};
@@ -814,6 +900,16 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   S->stats.cond_resolved += out.cond_seen;
   g_marks.mark("seams");
   return 0;
+}
+
+// One buffer on the searcher's first lane: prepare, queue, wait.
+static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPlan& plan, uint32_t k,
+                    bool all_minima, const uint8_t* pat, bool do_trace, uint64_t total_len, ScanOut& out) {
+  ScanJob job(S, S->lanes[0], sh, plan, k, all_minima, pat, do_trace, total_len);
+  if (int rc = job.prepare()) return rc;
+  if (!job.empty)
+    if (int rc = job.enqueue(0)) return rc;
+  return job.finish(out);
 }
 
 // Append the matches of one scan to a result: the device already produced finished records and
@@ -1104,13 +1200,16 @@ void sassy_searcher_free(sassy_SearcherType* ptr) {
 
 int sassy_hip_set_stream(sassy_SearcherType* s, void* hip_stream) {
   if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
-  if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
-  s->stream = reinterpret_cast<hipStream_t>(hip_stream);
-  s->own_stream = false;
+  ScanLane& l0 = s->lanes[0];
+  if (l0.own_stream && l0.stream) (void)hipStreamDestroy(l0.stream);
+  s->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
+  l0.stream = s->user_stream;
+  l0.own_stream = false;
   if (!hip_stream && s->device_ready) {
-    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    s->own_stream = true;
+    HIP_TRY(hipStreamCreateWithFlags(&l0.stream, hipStreamNonBlocking));
+    l0.own_stream = true;
   }
+  s->stream = l0.stream;
   return 0;
 }
 
