@@ -12,6 +12,11 @@ constexpr int kTileBytes = 64 * 128;   // text tile of one wave: 64 lane chunks 
                                        // 16-byte slots XOR-swizzled by (owner>>1)&7
 constexpr int kMaxSlots = 16;          // profile slots (distinct pattern letters) per search
 
+// Control block (64 bytes, device): u32 [0] reports, [1] chunk descriptors | bytes 16..47: u64
+// counters | words 12..15 (tail): the chunk that ends the buffer -- own_lo, exit state, descriptor
+// flags, found -- written by the scan / list kernel for the shard seam protocol.
+constexpr int kCtlTailWord = 12;
+
 // candidate flags
 constexpr uint32_t kCandCond = 1u;     // report depends on the plateau-entry direction left of the chunk
 // chunk exit states

@@ -213,8 +213,10 @@ struct sassy_SearcherType {
       return fail(SASSY_HIP_ENODEVICE,
                   "no usable HIP device (libsassy_hip has no CPU fallback; the scan runs on gfx950 only)");
     lanes[0].stream = user_stream;  // null: the lane creates its own
-    for (ScanLane& l : lanes)
+    for (ScanLane& l : lanes) {
+      if (getenv("SASSY_HIP_PIPE_ONESTREAM") && &l != &lanes[0]) l.stream = lanes[0].stream;
       if (int rc = l.init()) return rc;
+    }
     stream = lanes[0].stream;
     HIP_TRY(hipEventCreateWithFlags(&ev_inputs, hipEventDisableTiming));
     device_ready = true;
@@ -814,7 +816,17 @@ int ScanJob::finish(ScanOut& out) {
   // ---- seams: reports that depend on how a plateau was entered left of their chunk ----
   bool any_cond = false;
   for (const Candidate& c : out.cands) any_cond |= (c.flags & kCandCond) != 0;
-  const bool need_state = any_cond || !sh.text_end;  // non-final shards publish their exit state
+  bool need_state = any_cond || !sh.text_end;  // non-final shards publish their exit state
+  if (need_state && !any_cond) {
+    // common case: no report hangs on a chunk seam, only the exit state is wanted, and the chunk that
+    // ends the buffer has published it in the control block (no chunk there = the last block is > k)
+    uint32_t tail[4];
+    memcpy(tail, L.h_pin + kPinCounts + 4 * kCtlTailWord, sizeof tail);
+    if (!tail[3]) { out.exit_state = kStateDecTrue; need_state = false; }
+    else if (tail[1] != kStatePass) { out.exit_state = (int)tail[1]; need_state = false; }
+    else if (tail[2] & kDescClearBefore) { out.exit_state = kStateDecTrue; need_state = false; }
+    // else: one plateau from the chunk's start to the buffer end -- walk the chain below
+  }
   // chunk table in text order: [own_lo, own_hi), exit state, "its left edge is known to be > k"
   struct ChunkInfo { uint64_t lo, hi; uint8_t state; bool clear_before; };
   std::vector<ChunkInfo> chunks;
@@ -903,13 +915,118 @@ int ScanJob::finish(ScanOut& out) {
 }
 
 // One buffer on the searcher's first lane: prepare, queue, wait.
-static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPlan& plan, uint32_t k,
-                    bool all_minima, const uint8_t* pat, bool do_trace, uint64_t total_len, ScanOut& out) {
+static int run_scan_single(sassy_SearcherType* S, const ShardView& sh, const PatternPlan& plan, uint32_t k,
+                           bool all_minima, const uint8_t* pat, bool do_trace, uint64_t total_len, ScanOut& out) {
   ScanJob job(S, S->lanes[0], sh, plan, k, all_minima, pat, do_trace, total_len);
   if (int rc = job.prepare()) return rc;
   if (!job.empty)
     if (int rc = job.enqueue(0)) return rc;
   return job.finish(out);
+}
+
+static uint64_t required_halo_bytes(size_t pattern_len, size_t k) {
+  // warm-up blocks of the scan + the traceback window, whole 128-byte lines
+  const uint64_t wb = warmup_blocks((uint32_t)pattern_len, (uint32_t)k);
+  uint64_t h = std::max<uint64_t>(64 * (wb + 4), pattern_len + k);
+  return (h + 127) / 128 * 128;
+}
+
+// Optional (SASSY_HIP_LANES=2..4; default 1 = off): long buffers are cut into sub-shards, one per
+// lane.  The prefilter of sub-shard j+1 waits for the prefilter of sub-shard j (they would only
+// share the HBM bandwidth), so that the chunk list / DP / rank / traceback kernels of sub-shard j --
+// short, latency-bound, few waves -- could run underneath the next prefilter instead of after it.
+// The sub-shards are exact shards (halo to the left, seam protocol of DESIGN.md 5.1); their results
+// are concatenated with the plateau state handed from one to the next (parity-tested with
+// SASSY_HIP_SUBSHARD_MIN=2048).  Measured on MI355X (config 2): 0.81 ms with 1 lane, 0.97 / 1.00 /
+// 1.22 ms with 2 / 3 / 4 lanes -- the prefilter's long-lived workgroups fill every CU, so the
+// other queue's small kernels do not get scheduled underneath it and the extra launches only add
+// time.  Hence off by default; the lanes stay as the unit a future scheduler can build on.
+static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPlan& plan, uint32_t k,
+                    bool all_minima, const uint8_t* pat, bool do_trace, uint64_t total_len, ScanOut& out) {
+  static const int env_lanes = getenv("SASSY_HIP_LANES") ? atoi(getenv("SASSY_HIP_LANES")) : 1;
+  static const uint64_t min_sub = getenv("SASSY_HIP_SUBSHARD_MIN") ? strtoull(getenv("SASSY_HIP_SUBSHARD_MIN"), nullptr, 10)
+                                                                    : (128ull << 20);
+  const uint64_t halo = required_halo_bytes(plan.m, k);
+  const uint64_t own0 = sh.halo_len;
+  const uint64_t owned_bytes = sh.text_len > own0 ? sh.text_len - own0 : 0;
+  uint64_t nl = std::min<uint64_t>(std::min<int>(env_lanes, kMaxLanes), owned_bytes / std::max<uint64_t>(min_sub, 2 * halo + 64));
+  if (nl < 2 || filter_piece_len(plan, k) == 0)
+    return run_scan_single(S, sh, plan, k, all_minima, pat, do_trace, total_len, out);
+
+  const uint64_t owned_blocks = (owned_bytes + 63) / 64;
+  const uint64_t per = (owned_blocks + nl - 1) / nl;  // blocks per sub-shard
+  std::vector<std::unique_ptr<ScanJob>> jobs;
+  for (uint64_t j = 0; j < nl; ++j) {
+    const uint64_t a = own0 + j * per * 64;
+    if (a >= sh.text_len) break;
+    const uint64_t b = std::min<uint64_t>(sh.text_len, a + per * 64);
+    const uint64_t h = j == 0 ? own0 : halo;
+    ShardView sub{sh.d_text + (a - h), h + (b - a), h, sh.global_offset + (a - h), j == 0 && sh.text_start,
+                  b == sh.text_len && sh.text_end};
+    jobs.emplace_back(new ScanJob(S, S->lanes[j], sub, plan, k, all_minima, pat, do_trace, total_len));
+  }
+  const size_t n = jobs.size();
+  for (size_t j = 0; j < n; ++j) {
+    ScanJob& job = *jobs[j];
+    if (j == 1) {
+      // the uploads prepare() of sub-shard 0 queued on the searcher's stream must be done before any
+      // other lane reads the pattern tables (and the text, if this call uploaded it)
+      HIP_TRY(hipEventRecord(S->ev_inputs, S->stream));
+    }
+    if (j >= 1) HIP_TRY(hipStreamWaitEvent(S->lanes[j].stream, S->ev_inputs, 0));
+    if (int rc = job.prepare()) return rc;
+    static const bool nowait = getenv("SASSY_HIP_PIPE_NOWAIT") != nullptr;
+    job.wait_for = (j >= 1 && !nowait) ? S->lanes[j - 1].ev_filter_done : nullptr;
+    job.signal_filter_done = j + 1 < n && !nowait;
+    if (!job.empty)
+      if (int rc = job.enqueue(0)) return rc;
+  }
+  std::vector<ScanOut> outs(n);
+  int first_rc = 0;
+  for (size_t j = 0; j < n; ++j) {  // always wait for every lane, also after an error
+    const int rc = jobs[j]->finish(outs[j]);
+    if (rc && !first_rc) first_rc = rc;
+  }
+  if (first_rc) {
+    for (size_t j = 0; j < n; ++j) (void)hipStreamSynchronize(S->lanes[j].stream);
+    return first_rc;
+  }
+
+  // ---- concatenate, handing the plateau state across the sub-shard seams ----
+  out = ScanOut();
+  size_t total = 0;
+  for (const ScanOut& o : outs) total += o.cands.size();
+  out.cands.reserve(total);
+  if (do_trace) out.matches.reserve(total);
+  int incoming = sh.text_start ? kStateDecTrue : kStatePass;  // decreasing-state arriving at sub-shard j
+  for (size_t j = 0; j < n; ++j) {
+    ScanOut& o = outs[j];
+    const size_t base = out.pool.size();
+    if (base + o.pool.size() > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB");
+    out.pool.append(o.pool);
+    for (size_t i = 0; i < o.cands.size(); ++i) {
+      Candidate c = o.cands[i];
+      if ((int64_t)i == o.conditional_index) {
+        if (incoming == kStateDecFalse) continue;  // its plateau was entered by an increase: not a report
+        if (incoming == kStateDecTrue) c.flags &= ~kCandCond;
+        else {
+          if (out.conditional_index >= 0)  // two reports that depend on the previous shard: give up pipelining
+            return run_scan_single(S, sh, plan, k, all_minima, pat, do_trace, total_len, out);
+          out.conditional_index = (int64_t)out.cands.size();
+        }
+      }
+      out.cands.push_back(c);
+      if (do_trace) {
+        sassy_hip_Match r = o.matches[i];
+        r.cigar_off = (uint32_t)(r.cigar_off + base);
+        out.matches.push_back(r);
+      }
+    }
+    out.cond_seen += o.cond_seen;
+    if (o.exit_state != kStatePass) incoming = o.exit_state;
+  }
+  out.exit_state = incoming;
+  return 0;
 }
 
 // Append the matches of one scan to a result: the device already produced finished records and

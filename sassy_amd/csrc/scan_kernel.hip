@@ -523,8 +523,15 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
     }
   }
 
-  if (chunk < P.n_chunks)
-    P.chunk_state[chunk] = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
+  if (chunk < P.n_chunks) {
+    const uint32_t fin = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
+    P.chunk_state[chunk] = (uint8_t)fin;
+    // the chunk that ends the buffer publishes what a following shard needs (control block tail)
+    if (chunk + 1 == P.n_chunks) {
+      uint32_t* tail = P.cand_count + kCtlTailWord;
+      tail[0] = (uint32_t)own_lo; tail[1] = fin; tail[2] = 0u; tail[3] = 1u;
+    }
+  }
   if (P.counters) {
     atomicAdd(&P.counters[0], cnt_rows);
     atomicAdd(&P.counters[1], cnt_blocks);
@@ -1074,7 +1081,15 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
       }
     }
   }
-  if (has_chunk) P.chunk_state[di] = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
+  if (has_chunk) {
+    const uint32_t fin = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
+    P.chunk_state[di] = (uint8_t)fin;
+    // the chunk that reaches the end of the buffer publishes what a following shard needs
+    if (own_hi == P.n_blocks) {
+      uint32_t* tail = P.cand_count + kCtlTailWord;
+      tail[0] = (uint32_t)own_lo; tail[1] = fin; tail[2] = d.flags; tail[3] = 1u;
+    }
+  }
   if (P.counters) {
     atomicAdd(&P.counters[0], cnt_rows);
     atomicAdd(&P.counters[1], cnt_blocks);
