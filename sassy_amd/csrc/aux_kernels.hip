@@ -238,15 +238,32 @@ __global__ __launch_bounds__(256) void rank_count_kernel(const Candidate* __rest
   }
 }
 
+// Index of the text that holds (or is followed by the separator that holds) buffer position pos:
+// the largest t with start[t] <= pos (0 if pos lies before the first text).
+__device__ __forceinline__ uint32_t text_of(const TextTable& T, uint64_t pos) {
+  uint32_t lo = 0, hi = T.n;  // invariant: start[lo] <= pos < start[hi]
+  while (lo + 1 < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (T.start[mid] <= pos) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 // Also the hand-over to the host: the first host_cap reports in result order and the 64-byte
 // control block (counts, counters -- final once this kernel runs) are written straight into the
 // caller's pinned, device-mapped staging buffer, so that no copy has to be queued behind the kernels.
+// Multi-text buffers: the report learns its text here.  A report that ends inside the separator
+// behind text t can only be the right end of a plateau that started at or before the text's end
+// (costs never decrease across characters that match nothing, and after k of them the cost
+// exceeds k): it stands for the end-of-text report of text t (reference: src/search.rs:1352-1366)
+// and is moved there; in search_all mode such positions do not exist in the single-text search and
+// are dropped.
 __global__ __launch_bounds__(256) void rank_scatter_kernel(const Candidate* __restrict__ cand,
                                                            const uint32_t* __restrict__ count_p, uint32_t cap,
                                                            const uint32_t* __restrict__ rank,
                                                            Candidate* __restrict__ sorted,
                                                            Candidate* __restrict__ host_sorted, uint32_t host_cap,
-                                                           uint4* __restrict__ host_ctl) {
+                                                           uint4* __restrict__ host_ctl, const TextTable texts) {
   uint32_t count = *count_p;
   if (blockIdx.x == 0 && threadIdx.x < 4 && host_ctl)
     host_ctl[threadIdx.x] = reinterpret_cast<const uint4*>(count_p)[threadIdx.x];
@@ -254,7 +271,16 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const Candidate* __re
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= count) return;
   const uint32_t r = count > kRankLimit ? c : rank[c];
-  const Candidate v = cand[c];
+  Candidate v = cand[c];
+  if (texts.n) {
+    const uint32_t t = text_of(texts, v.pos);
+    const uint64_t te = texts.start[t] + texts.len[t];
+    v.flags = (v.flags & 0xFFu) | (t << kCandTextShift);
+    if (v.pos > te) {
+      if (texts.all_minima) v.flags |= kCandDrop;
+      else v.pos = te;
+    }
+  }
   sorted[r] = v;
   if (r < host_cap) host_sorted[r] = v;
 }
@@ -285,12 +311,12 @@ hipError_t launch_count_n(const uint8_t* d_text, const uint64_t* d_range, uint32
 // control block); d_count points at the control block.
 hipError_t launch_rank(const Candidate* d_cand, const uint32_t* d_count, uint32_t cap, uint32_t* d_rank,
                        Candidate* d_sorted, Candidate* h_sorted, uint32_t host_cap, void* h_ctl,
-                       hipStream_t stream) {
+                       const TextTable& texts, hipStream_t stream) {
   if (cap == 0) return hipSuccess;
   // the count lives on the device: fixed grid, surplus workgroups exit at once
   hipLaunchKernelGGL(rank_count_kernel, dim3(1024), dim3(256), 0, stream, d_cand, d_count, cap, d_rank);
   hipLaunchKernelGGL(rank_scatter_kernel, dim3((cap + 255) / 256), dim3(256), 0, stream, d_cand, d_count, cap,
-                     d_rank, d_sorted, h_sorted, host_cap, reinterpret_cast<uint4*>(h_ctl));
+                     d_rank, d_sorted, h_sorted, host_cap, reinterpret_cast<uint4*>(h_ctl), texts);
   return hipGetLastError();
 }
 

@@ -19,6 +19,19 @@ constexpr int kCtlTailWord = 12;
 
 // candidate flags
 constexpr uint32_t kCandCond = 1u;     // report depends on the plateau-entry direction left of the chunk
+constexpr uint32_t kCandDrop = 2u;     // multi-text buffers: the report lies in a separator, not in a text
+constexpr int kCandTextShift = 8;      // multi-text buffers: bits 8..31 = index of the text (< 2^24)
+
+// Several texts in one device buffer (search_texts / search_many on many short texts): text t
+// occupies [start[t], start[t] + len[t]); the bytes between two texts are >= m+k+1 copies of a
+// character that matches nothing ('X' for Iupac).  The scan runs over the whole buffer as if it were
+// one text; the tables let the later stages cut the results back into per-text results.
+struct TextTable {
+  const uint64_t* start;  // device, n entries, ascending
+  const uint64_t* len;    // device, n entries
+  uint32_t n;             // 0 = the buffer is a single text
+  uint32_t all_minima;    // search_all: reports inside a separator are dropped (else: moved to the text end)
+};
 // chunk exit states
 constexpr uint8_t kStateDecFalse = 0, kStateDecTrue = 1, kStatePass = 2;
 
@@ -128,6 +141,7 @@ struct TraceParams {
   uint32_t ops_bytes;       // m+k+1 rounded up to 4; the slice ends with str_stride bytes of cigar text
   uint32_t wave_mode;       // 1: trace_wave_kernel (one wavefront per report; slices are per wave)
   uint32_t count_min, count_max;  // the kernel runs only when count_min < number of reports <= count_max
+  TextTable texts;          // n = 0 unless the buffer holds several texts
   // the first host_cap records also go straight to device-mapped pinned host memory
   MatchOut* host_out;
   uint8_t* host_str;

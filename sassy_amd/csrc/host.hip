@@ -48,7 +48,7 @@ hipError_t launch_reverse(const uint8_t* d_in, uint8_t* d_out, uint64_t n, hipSt
 hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stream);
 hipError_t launch_rank(const Candidate* d_cand, const uint32_t* d_count, uint32_t cap, uint32_t* d_rank,
                        Candidate* d_sorted, Candidate* h_sorted, uint32_t host_cap, void* h_ctl,
-                       hipStream_t stream);
+                       const TextTable& texts, hipStream_t stream);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -186,6 +186,7 @@ struct sassy_SearcherType {
   // reporting modes of the reference's Searcher (src/search.rs:442-475)
   bool only_best = false;        // only_best_match(): one match per strand, minimal cost, rightmost end
   float max_n_frac = NAN;        // with_max_n_frac(): NaN = off (the reference's None)
+  DevBuf<uint64_t> d_tables;     // multi-text buffers: start / len tables (both strands)
   DevBuf<uint64_t> d_range;      // N counting on device-resident text
   DevBuf<uint32_t> d_ncount;
   // q-gram table of the last pattern searched with the table prefilter
@@ -200,7 +201,7 @@ struct sassy_SearcherType {
 
   ~sassy_SearcherType() {
     d_text.release(); d_rev.release(); d_pattern.release(); d_rowoff.release();
-    d_table.release(); d_range.release(); d_ncount.release();
+    d_table.release(); d_range.release(); d_ncount.release(); d_tables.release();
     for (ScanLane& l : lanes) l.destroy();
     if (ev_inputs) (void)hipEventDestroy(ev_inputs);
   }
@@ -376,6 +377,7 @@ struct ScanJob {
   const uint8_t* pat;
   bool do_trace;
   uint64_t total_len;
+  TextTable texts{};                 // several texts in the buffer (n = 0: one text)
   hipEvent_t wait_for = nullptr;     // pipelining: the previous sub-shard's "filter done"
   bool signal_filter_done = false;   // pipelining: record L.ev_filter_done behind this filter
 
@@ -694,9 +696,10 @@ int ScanJob::enqueue(int attempt) {
   const uint32_t host_cap = std::min<uint32_t>(kSpec, P.cand_cap);
   le = launch_rank(L.d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(L.d_ctl.p + 64),
                    L.d_sorted.p, reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands), host_cap,
-                   L.h_pin_dev + kPinCounts, L.stream);
+                   L.h_pin_dev + kPinCounts, texts, L.stream);
   if (le != hipSuccess) return hip_fail(le, "rank kernel launch");
   if (do_trace) {
+    T.texts = Tw.texts = texts;
     T.host_out = Tw.host_out = reinterpret_cast<MatchOut*>(L.h_pin_dev + pin_recs);
     T.host_str = Tw.host_str = L.h_pin_dev + pin_ops;
     T.host_cap = Tw.host_cap = host_cap;
@@ -791,6 +794,17 @@ int ScanJob::finish(ScanOut& out) {
     }
   }
   g_marks.mark("copy out");
+  if (texts.n) {  // multi-text buffer, search_all: reports that lie in a separator are no reports
+    size_t w = 0;
+    for (size_t i = 0; i < out.cands.size(); ++i) {
+      if (out.cands[i].flags & kCandDrop) continue;
+      out.cands[w] = out.cands[i];
+      if (do_trace) out.matches[w] = out.matches[i];
+      ++w;
+    }
+    out.cands.resize(w);
+    if (do_trace) out.matches.resize(w);
+  }
   if (do_trace)
     for (const sassy_hip_Match& r : out.matches)
       if (r.pad_[0] == kTraceFailed)
@@ -916,8 +930,11 @@ int ScanJob::finish(ScanOut& out) {
 
 // One buffer on the searcher's first lane: prepare, queue, wait.
 static int run_scan_single(sassy_SearcherType* S, const ShardView& sh, const PatternPlan& plan, uint32_t k,
-                           bool all_minima, const uint8_t* pat, bool do_trace, uint64_t total_len, ScanOut& out) {
+                           bool all_minima, const uint8_t* pat, bool do_trace, uint64_t total_len, ScanOut& out,
+                           const TextTable& texts = TextTable{}) {
   ScanJob job(S, S->lanes[0], sh, plan, k, all_minima, pat, do_trace, total_len);
+  job.texts = texts;
+  job.texts.all_minima = all_minima ? 1u : 0u;
   if (int rc = job.prepare()) return rc;
   if (!job.empty)
     if (int rc = job.enqueue(0)) return rc;
@@ -1029,19 +1046,40 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   return 0;
 }
 
+// Host view of a multi-text buffer (see TextTable in common.h).  Null = the buffer is one text.
+struct HostTexts {
+  std::vector<uint64_t> start, len;
+};
+// [ts, te) of the text report c belongs to, in buffer coordinates
+static inline void text_bounds(const HostTexts* ht, const Candidate& c, uint64_t total_len, uint64_t& ts, uint64_t& te,
+                               uint64_t& text_idx) {
+  if (ht) {
+    text_idx = c.flags >> kCandTextShift;
+    ts = ht->start[text_idx];
+    te = ts + ht->len[text_idx];
+  } else {
+    text_idx = 0;
+    ts = 0;
+    te = total_len;
+  }
+}
+
 // Append the matches of one scan to a result: the device already produced finished records and
 // cigar text (trace_kernel.hip); only the pool offsets are rebased.  Returns the index of the
 // first appended match.
 static int append_matches(ScanOut& so, uint64_t total_len, const PatternPlan& plan, bool without_trace,
-                          uint64_t pattern_idx, sassy_hip_Result* R, size_t& first) {
+                          uint64_t pattern_idx, sassy_hip_Result* R, size_t& first, const HostTexts* ht = nullptr) {
   first = R->matches.size();
   if (without_trace) {  // reference: src/search.rs:1464-1475
     R->matches.reserve(first + so.cands.size());
     for (const Candidate& c : so.cands) {
       sassy_hip_Match r{};
+      uint64_t ts, te, ti;
+      text_bounds(ht, c, total_len, ts, te, ti);
       r.pattern_idx = pattern_idx;
+      r.text_idx = ti;
       r.text_start = UINT64_MAX;
-      r.text_end = std::min<uint64_t>(c.pos, total_len);
+      r.text_end = std::min<uint64_t>(c.pos, te) - ts;
       r.pattern_start = UINT64_MAX;
       r.pattern_end = plan.m;
       r.cost = c.cost;
@@ -1118,7 +1156,7 @@ static bool n_frac_ok(uint32_t n_count, uint64_t denominator, float max_n_frac) 
 // h_text / d_text: this strand's text (reversed for Rc) on the host (may be null) and the device.
 static int post_filter(sassy_SearcherType* S, ScanOut& so, const PatternPlan& plan, const uint8_t* pat, uint32_t k,
                        int strand, const uint8_t* h_text, const uint8_t* d_text, uint64_t tlen, bool with_trace,
-                       const EndFilter& ef) {
+                       const EndFilter& ef, const HostTexts* ht = nullptr) {
   const bool n_filter = !std::isnan(S->max_n_frac);
   if (!ef.fn && !n_filter && !S->only_best) return 0;
   std::vector<char> keep(so.cands.size(), 1);
@@ -1147,40 +1185,61 @@ static int post_filter(sassy_SearcherType* S, ScanOut& so, const PatternPlan& pl
     std::vector<uint64_t> ranges;
     ranges.reserve(2 * so.cands.size());
     const uint64_t mandatory = plan.m > k ? plan.m - k : 0;
+    std::vector<uint64_t> ends_of_text;
     for (const Candidate& c : so.cands) {
-      const uint64_t end = std::min<uint64_t>(c.pos, tlen);
-      ranges.push_back(end - std::min<uint64_t>(end, mandatory));
+      uint64_t ts, te, ti;
+      text_bounds(ht, c, tlen, ts, te, ti);
+      const uint64_t end = std::min<uint64_t>(c.pos, te);
+      ranges.push_back(end - std::min<uint64_t>(end - ts, mandatory));
       ranges.push_back(end);
+      ends_of_text.push_back(te);
     }
     std::vector<uint32_t> counts;
     if (int rc = count_ns(S, h_text, d_text, ranges, counts)) return rc;
     for (size_t i = 0; i < so.cands.size(); ++i) {
-      const bool empty = ranges[2 * i] >= tlen || ranges[2 * i] == ranges[2 * i + 1];
+      const bool empty = ranges[2 * i] >= ends_of_text[i] || ranges[2 * i] == ranges[2 * i + 1];
       keep[i] = (empty || n_frac_ok(counts[i], (uint64_t)plan.m + k, S->max_n_frac)) ? 1 : 0;
     }
     compact();
   }
-  if (S->only_best && !so.cands.empty()) {  // minimal cost, then rightmost end (src/search.rs:1392-1412)
-    size_t best = 0;
-    for (size_t i = 1; i < so.cands.size(); ++i)
-      if (so.cands[i].cost < so.cands[best].cost ||
-          (so.cands[i].cost == so.cands[best].cost && so.cands[i].pos > so.cands[best].pos))
-        best = i;
-    for (size_t i = 0; i < so.cands.size(); ++i) keep[i] = i == best;
+  if (S->only_best && !so.cands.empty()) {
+    // minimal cost, then rightmost end (src/search.rs:1392-1412); one per text in a multi-text buffer
+    // (the reports are sorted by position, so those of one text are adjacent)
+    for (size_t i = 0; i < so.cands.size(); ++i) keep[i] = 0;
+    size_t g0 = 0;
+    while (g0 < so.cands.size()) {
+      size_t g1 = g0 + 1;
+      if (ht)
+        while (g1 < so.cands.size() && (so.cands[g1].flags >> kCandTextShift) == (so.cands[g0].flags >> kCandTextShift)) ++g1;
+      else
+        g1 = so.cands.size();
+      size_t best = g0;
+      for (size_t i = g0 + 1; i < g1; ++i)
+        if (so.cands[i].cost < so.cands[best].cost ||
+            (so.cands[i].cost == so.cands[best].cost && so.cands[i].pos > so.cands[best].pos))
+          best = i;
+      keep[best] = 1;
+      g0 = g1;
+    }
     compact();
   }
   if (n_filter && with_trace) {  // traced_satisfy_n_frac (src/n_filter.rs:54-60)
     std::vector<uint64_t> ranges;
     ranges.reserve(2 * so.matches.size());
-    for (const sassy_hip_Match& r : so.matches) {
-      ranges.push_back(r.text_start);
-      ranges.push_back(r.text_end);
+    std::vector<uint64_t> ends_of_text;
+    for (size_t i = 0; i < so.matches.size(); ++i) {
+      const sassy_hip_Match& r = so.matches[i];
+      uint64_t ts, te, ti;
+      text_bounds(ht, so.cands[i], tlen, ts, te, ti);
+      ranges.push_back(ts + r.text_start);  // the records carry text-relative coordinates
+      ranges.push_back(ts + r.text_end);
+      ends_of_text.push_back(te);
     }
     std::vector<uint32_t> counts;
     if (int rc = count_ns(S, h_text, d_text, ranges, counts)) return rc;
     for (size_t i = 0; i < so.matches.size(); ++i) {
       const uint64_t len = ranges[2 * i + 1] - ranges[2 * i];
-      keep[i] = (ranges[2 * i] >= tlen || len == 0 || n_frac_ok(counts[i], len, S->max_n_frac)) ? 1 : 0;
+      keep[i] = (ranges[2 * i] >= ends_of_text[i] || len == 0 || n_frac_ok(counts[i], len, S->max_n_frac)) ? 1 : 0;
     }
     compact();
   }
@@ -1380,6 +1439,141 @@ int sassy_hip_search_with_fn(sassy_SearcherType* s, const uint8_t* pattern, size
   return 0;
 }
 
+// ---- many host texts: one buffer, one scan per pattern and strand ----
+// search_texts / search_many are meant for many short texts (reads).  Running the whole kernel
+// pipeline once per (pattern, text) pair would be launch-latency bound (~70 us per pair), so the
+// texts of a batch are laid out in ONE device buffer, separated by m+k+1 (or more) 'X' -- the Iupac
+// letter that matches nothing -- and every pattern is scanned over that buffer once per strand.
+// Exactness ("batched texts"): after m+k+1 non-matching characters every DP column
+// equals the text-start column D[j][0] = j, so a text's cells do not depend on its predecessors;
+// costs never decrease across a separator, so the only report that can fall into one is the right
+// end of a plateau that reached the text's end -- the single-text search reports exactly that one
+// at the text end (end-of-text rule); rank_scatter_kernel moves it there (search_all: drops it), and
+// the traceback windows are clipped at the text's own start.  A Dna searcher runs these scans with
+// the Iupac kernels, which give identical results on ACGT text (other Dna text is outside the
+// reference's contract, src/profiles/dna.rs:60-75 valid_seq), and falls back to the pair loop otherwise.
+static bool acgt_only(const uint8_t* p, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t c = p[i] & (uint8_t)~0x20;
+    if (c != 'A' && c != 'C' && c != 'G' && c != 'T') return false;
+  }
+  return true;
+}
+
+static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patterns, const size_t* pattern_lens,
+                               size_t n_patterns, const uint8_t* const* texts, const size_t* text_lens, size_t n_texts,
+                               size_t k, uint32_t flags, sassy_hip_Result* R, bool& handled) {
+  handled = false;
+  static const bool off = getenv("SASSY_HIP_BATCH_TEXTS") && atoi(getenv("SASSY_HIP_BATCH_TEXTS")) == 0;
+  if (off || n_texts < 2 || n_patterns == 0 || (flags & SASSY_HIP_TEXT_ON_DEVICE) || s->profile == PROFILE_ASCII) return 0;
+  if (n_texts >= (1u << (32 - kCandTextShift))) return 0;
+  size_t max_m = 0;
+  for (size_t pi = 0; pi < n_patterns; ++pi) {
+    if (!patterns[pi] || pattern_lens[pi] == 0 || k >= pattern_lens[pi]) return 0;
+    max_m = std::max(max_m, pattern_lens[pi]);
+    if (s->profile == PROFILE_DNA && !acgt_only(patterns[pi], pattern_lens[pi])) return 0;
+  }
+  for (size_t ti = 0; ti < n_texts; ++ti) {
+    if (!texts[ti] && text_lens[ti]) return fail(SASSY_HIP_EINVAL, "null text");
+    if (s->profile == PROFILE_DNA && !acgt_only(texts[ti], text_lens[ti])) return 0;
+  }
+  handled = true;
+  struct ProfileGuard {  // Dna searchers borrow the Iupac kernels for the batch (see above)
+    sassy_SearcherType* s; Profile saved;
+    ~ProfileGuard() { s->profile = saved; }
+  } guard{s, s->profile};
+  s->profile = PROFILE_IUPAC;
+
+  const bool all = (flags & SASSY_HIP_ALL_MINIMA) != 0;
+  const bool wo = (flags & SASSY_HIP_WITHOUT_TRACE) != 0;
+  const uint64_t pad = ((uint64_t)max_m + k + 1 + 15) / 16 * 16;
+  const uint64_t batch_cap = 1ull << 30;  // bytes of device buffer per batch
+  std::vector<uint8_t> hbuf;
+  HostTexts ht, ht_rev;
+  size_t t0 = 0;
+  while (t0 < n_texts) {
+    // ---- lay out texts t0 .. t1 ----
+    size_t t1 = t0;
+    uint64_t total = 0;
+    ht.start.clear(); ht.len.clear();
+    while (t1 < n_texts && (t1 == t0 || total + pad + text_lens[t1] <= batch_cap)) {
+      if (t1 > t0) total += pad;
+      ht.start.push_back(total);
+      ht.len.push_back(text_lens[t1]);
+      total += text_lens[t1];
+      ++t1;
+    }
+    const size_t nt = t1 - t0;
+    if (total > 0) {
+      hbuf.assign(total, (uint8_t)'X');
+      for (size_t i = 0; i < nt; ++i)
+        if (text_lens[t0 + i]) memcpy(hbuf.data() + ht.start[i], texts[t0 + i], text_lens[t0 + i]);
+      if (int rc = s->d_text.reserve(total + 64)) return rc;
+      if (int rc = s->d_tables.reserve(4 * nt)) return rc;
+      HIP_TRY(hipMemcpyAsync(s->d_text.p, hbuf.data(), total, hipMemcpyHostToDevice, s->stream));
+      uint64_t* d_tab = s->d_tables.p;
+      HIP_TRY(hipMemcpyAsync(d_tab, ht.start.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(d_tab + nt, ht.len.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
+      TextTable tt{d_tab, d_tab + nt, (uint32_t)nt, all ? 1u : 0u}, tt_rev{};
+      if (s->rc) {
+        // the reversed buffer holds the texts in reverse order, each one reversed
+        ht_rev.start.resize(nt); ht_rev.len.resize(nt);
+        for (size_t r = 0; r < nt; ++r) {
+          const size_t t = nt - 1 - r;
+          ht_rev.start[r] = total - (ht.start[t] + ht.len[t]);
+          ht_rev.len[r] = ht.len[t];
+        }
+        HIP_TRY(hipMemcpyAsync(d_tab + 2 * nt, ht_rev.start.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(d_tab + 3 * nt, ht_rev.len.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
+        tt_rev = TextTable{d_tab + 2 * nt, d_tab + 3 * nt, (uint32_t)nt, all ? 1u : 0u};
+        if (int rc = s->d_rev.reserve(total + 64)) return rc;
+        hipError_t le = launch_reverse(s->d_text.p, s->d_rev.p, total, s->stream);
+        if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
+      }
+      std::string err;
+      std::vector<uint8_t> h_rev;  // host copy of the reversed buffer, only for N counting
+      for (size_t pi = 0; pi < n_patterns; ++pi) {
+        PatternPlan plan;
+        if (!make_plan(s->profile, patterns[pi], pattern_lens[pi], plan, err)) return fail(SASSY_HIP_EINVAL, err);
+        {
+          ShardView sh{s->d_text.p, total, 0, 0, true, true};
+          ScanOut so;
+          if (int rc = run_scan_single(s, sh, plan, (uint32_t)k, all, patterns[pi], !wo, total, so, tt)) return rc;
+          if (int rc = post_filter(s, so, plan, patterns[pi], (uint32_t)k, 0, hbuf.data(), s->d_text.p, total, !wo,
+                                   EndFilter(), &ht)) return rc;
+          size_t first = 0;
+          if (int rc = append_matches(so, total, plan, wo, pi, R, first, &ht)) return rc;
+          for (size_t i = first; i < R->matches.size(); ++i) R->matches[i].text_idx += t0;
+        }
+        if (s->rc) {
+          std::vector<uint8_t> cp(pattern_lens[pi]);
+          for (size_t i = 0; i < cp.size(); ++i) cp[i] = complement_char(s->profile, patterns[pi][i]);
+          PatternPlan cplan;
+          if (!make_plan(s->profile, cp.data(), cp.size(), cplan, err)) return fail(SASSY_HIP_EINVAL, err);
+          ShardView sh{s->d_rev.p, total, 0, 0, true, true};
+          ScanOut so;
+          if (int rc = run_scan_single(s, sh, cplan, (uint32_t)k, all, cp.data(), !wo, total, so, tt_rev)) return rc;
+          if (int rc = post_filter(s, so, cplan, cp.data(), (uint32_t)k, 1, nullptr, s->d_rev.p, total, !wo,
+                                   EndFilter(), &ht_rev)) return rc;
+          size_t first = 0;
+          if (int rc = append_matches(so, total, cplan, wo, pi, R, first, &ht_rev)) return rc;
+          for (size_t i = first; i < R->matches.size(); ++i) {  // reference: src/search.rs:859-873
+            sassy_hip_Match& m = R->matches[i];
+            const size_t t = nt - 1 - (size_t)m.text_idx;
+            const uint64_t len = ht.len[t], rs = m.text_start, re = m.text_end;
+            m.strand = 1;
+            m.text_idx = t0 + t;
+            m.text_start = len - re;
+            m.text_end = wo ? UINT64_MAX : len - rs;
+          }
+        }
+      }
+    }
+    t0 = t1;
+  }
+  return 0;
+}
+
 int sassy_hip_search_many(sassy_SearcherType* s, const uint8_t* const* patterns, const size_t* pattern_lens,
                           size_t n_patterns, const uint8_t* const* texts, const size_t* text_lens, size_t n_texts,
                           size_t k, uint32_t flags, sassy_hip_Result** out) {
@@ -1389,8 +1583,11 @@ int sassy_hip_search_many(sassy_SearcherType* s, const uint8_t* const* patterns,
   reset_stats(s);
   if (int rc = s->ensure_device()) return rc;
   std::unique_ptr<sassy_hip_Result> R(new sassy_hip_Result());
-  // text-major internally (each host text is uploaded once), pattern-major in the result
-  for (size_t ti = 0; ti < n_texts; ++ti) {
+  bool handled = false;
+  if (int rc = search_many_batched(s, patterns, pattern_lens, n_patterns, texts, text_lens, n_texts, k, flags, R.get(), handled))
+    return rc;
+  // otherwise: text-major (each host text is uploaded once), pattern-major in the result
+  for (size_t ti = 0; !handled && ti < n_texts; ++ti) {
     const uint8_t* tptr = texts[ti];
     uint32_t f = flags;
     if (!tptr && text_lens[ti]) return fail(SASSY_HIP_EINVAL, "null text");

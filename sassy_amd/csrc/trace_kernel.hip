@@ -100,13 +100,42 @@ __device__ __forceinline__ uint32_t rle_text(const unsigned char* ops, uint32_t 
   sbuf[w] = 0; sbuf[w + 1] = 0; sbuf[w + 2] = 0; sbuf[w + 3] = 0;
   return w;
 }
-__device__ __forceinline__ MatchOut make_row(const TraceParams& P, uint32_t c, uint64_t text_start, uint64_t text_end,
+// Window of a report: text[o .. we) with o = e - (m+k) clipped at the start of the text and we = e
+// clipped at its end (reference: src/search.rs:1477-1478).  In a multi-text buffer "the text" is
+// the one the report belongs to (its index travels in the candidate's flags); `base` is that text's
+// first byte, so that the record carries text-relative coordinates.
+struct Window {
+  uint64_t o, we, base;
+  uint32_t text_idx;
+  bool skip;
+};
+__device__ __forceinline__ Window report_window(const TraceParams& P, const Candidate& cd) {
+  Window w;
+  const uint64_t fill = (uint64_t)P.m + P.k;
+  const uint64_t e = cd.pos;
+  w.skip = (cd.flags & kCandDrop) != 0;
+  if (P.texts.n) {
+    w.text_idx = cd.flags >> kCandTextShift;
+    w.base = P.texts.start[w.text_idx];
+    const uint64_t te = w.base + P.texts.len[w.text_idx];
+    w.o = e > w.base + fill ? e - fill : w.base;
+    w.we = e < te ? e : te;
+  } else {
+    w.text_idx = 0;
+    w.base = 0;
+    w.o = e > fill ? e - fill : 0;
+    w.we = e < P.total_len ? e : P.total_len;
+  }
+  return w;
+}
+
+__device__ __forceinline__ MatchOut make_row(const TraceParams& P, uint32_t c, const Window& win, uint64_t text_start,
                                              int cost, uint32_t len, bool ok) {
   MatchOut r;
   r.pattern_idx = 0;
-  r.text_idx = 0;
-  r.text_start = text_start;
-  r.text_end = text_end;
+  r.text_idx = win.text_idx;
+  r.text_start = text_start - win.base;
+  r.text_end = win.we - win.base;
   r.pattern_start = 0;
   r.pattern_end = P.m;
   r.cost = cost;
@@ -128,7 +157,6 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
   const int m = (int)P.m, k = KT >= 0 ? KT : (int)P.k;
   const int bw = 2 * k + 3;
   const int inf = k + 1;
-  const uint32_t fill = P.m + P.k;
   const uint32_t tid = threadIdx.x;
   // block-shared pattern copy behind the 64 slices (LDS mode)
   unsigned char* spat = trace_smem + (size_t)64 * P.scratch_stride;
@@ -153,9 +181,9 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
 
   for (uint32_t c = blockIdx.x * 64 + tid; c < count; c += gridDim.x * 64) {
     const Candidate cd = P.cand[c];
-    const uint64_t e = cd.pos;                             // global end position
-    const uint64_t o = e > fill ? e - fill : 0;            // global window start
-    const uint64_t we = e < P.total_len ? e : P.total_len;
+    const Window W = report_window(P, cd);
+    if (W.skip) continue;
+    const uint64_t o = W.o, we = W.we;                     // global window bounds
     const int wl = (int)(we - o);
     const uint32_t skew = load_window(P.text, o - P.global_offset, wl, wbuf);
     unsigned char* win = wbuf + skew;
@@ -267,7 +295,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
     // ---- cigar text and the finished row, to the device arrays and (head of the list) the host ----
     unsigned char* sbuf = ops + P.ops_bytes;
     const uint32_t w = rle_text(ops, nops, ok, sbuf);
-    const MatchOut r = make_row(P, c, o + (uint64_t)i, we, cost, w, ok);
+    const MatchOut r = make_row(P, c, W, o + (uint64_t)i, cost, w, ok);
     const uint32_t ndw = w / 4 + 1;
     uint32_t* dstr = reinterpret_cast<uint32_t*>(P.out_str + (uint64_t)c * P.str_stride);
     const uint32_t* ssrc = reinterpret_cast<const uint32_t*>(sbuf);
@@ -310,7 +338,6 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
   const int m = (int)P.m, k = (int)P.k;
   const int bw = 2 * k + 3;  // <= 64
   const int inf = k + 1;
-  const uint32_t fill = P.m + P.k;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const CharRule rule = char_rule(P.profile);
   // LDS: pattern codes (shared) | per wave: band rows | window | ops
@@ -329,9 +356,9 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
 
   for (uint32_t c = blockIdx.x * 4 + wave; c < count; c += n_waves) {
     const Candidate cd = P.cand[c];                        // wave-uniform
-    const uint64_t e = cd.pos;
-    const uint64_t o = e > fill ? e - fill : 0;
-    const uint64_t we = e < P.total_len ? e : P.total_len;
+    const Window W = report_window(P, cd);
+    if (W.skip) continue;
+    const uint64_t o = W.o, we = W.we;
     const int wl = (int)(we - o);
     {  // window -> LDS (coalesced bytes), Iupac letters -> base sets
       const uint8_t* src = P.text + (o - P.global_offset);
@@ -421,7 +448,7 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
         if (c < P.host_cap) hstr[x] = v;
       }
       if (lane == 0) {
-        const MatchOut r = make_row(P, c, o + (uint64_t)i, we, cost, w, ok);
+        const MatchOut r = make_row(P, c, W, o + (uint64_t)i, cost, w, ok);
         P.out[c] = r;
         if (c < P.host_cap) P.host_out[c] = r;
       }

@@ -453,6 +453,69 @@ def test_cli_search_tsv(sassy, tmp_path, capsys):
         assert lines[1:] == want
 
 
+def test_batched_texts(sassy):
+    """Many short texts go through ONE buffer with 'X' separators (host.hip: search_many_batched).
+    Every (pattern, text) pair must equal the independent search: matches cut by the text end
+    (end-of-text rule -> a plateau that runs into the separator), matches at the text start, empty
+    and tiny texts, search_all, without_trace, only_best_match, max_n_frac, both strands."""
+    rng = random.Random(404)
+    for profile in ("dna", "iupac"):
+        pats = [bytes(rng.choice(b"ACGT") for _ in range(m)) for m in (12, 20, 20, 33)]
+        if profile == "iupac":
+            p = bytearray(pats[1]); p[4] = ord("N"); p[10] = ord("R"); pats[1] = bytes(p)
+        texts = []
+        for t in range(40):
+            n = rng.choice([0, 1, 5, 19, 20, 21, 40, 63, 64, 65, 100, 300, 1000, 2500])
+            text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+            for p in pats:
+                plain = bytes(c if c in b"ACGT" else 65 for c in p)
+                if n >= len(p) + 5 and rng.random() < 0.7:
+                    ins = mutate(rng, plain, rng.randrange(0, 3))
+                    at = rng.randrange(0, n - len(ins))
+                    text[at:at + len(ins)] = ins
+            if n >= 40:
+                p = bytes(c if c in b"ACGT" else 65 for c in pats[t % 4])
+                kind = t % 4
+                if kind == 0:    # the text ends inside a match: pattern minus its last 1..2 chars
+                    cut = p[:len(p) - 1 - (t // 4) % 2]
+                    text[n - len(cut):] = cut
+                elif kind == 1:  # the text starts inside a match
+                    cut = p[1 + (t // 4) % 2:]
+                    text[:len(cut)] = cut
+                elif kind == 2:  # exact match flush with the end
+                    text[n - len(p):] = p
+                if profile == "iupac" and rng.random() < 0.5:
+                    text[rng.randrange(n)] = ord("N")
+            texts.append(bytes(text))
+        for rc in (False, True):
+            for k in (0, 2):
+                s = sassy.Searcher(profile, rc=rc)
+                for mode in ("search", "search_all"):
+                    allm = mode == "search_all"
+                    got = s.search_many(pats, texts, k, all_minima=allm)
+                    want = []
+                    for pi, p in enumerate(pats):
+                        for ti, t in enumerate(texts):
+                            for m in oracle.search(profile, p, t, k, rc=rc, all_minima=allm):
+                                want.append((pi, ti, m.text_start, m.text_end, m.cost, m.strand, m.cigar))
+                    assert [(m.pattern_idx, m.text_idx, m.text_start, m.text_end, m.cost, m.strand, m.cigar)
+                            for m in got] == want, (profile, rc, k, mode)
+                    assert len(want) > 10
+                    # one scan per pattern and strand, not one per (pattern, text) pair
+                    assert s.stats()["scan_launches"] == len(pats) * (2 if rc else 1)
+                # modes on top of the batched path
+                s2 = sassy.Searcher(profile, rc=rc).only_best_match().with_max_n_frac(0.1 if profile == "iupac" else None)
+                got = s2.search_many(pats, texts, k)
+                want = []
+                for pi, p in enumerate(pats):
+                    for ti, t in enumerate(texts):
+                        for m in oracle.search_modes(profile, p, t, k, rc=rc, only_best=True,
+                                                     max_n_frac=0.1 if profile == "iupac" else None):
+                            want.append((pi, ti, m.text_start, m.text_end, m.cost, m.strand, m.cigar))
+                assert [(m.pattern_idx, m.text_idx, m.text_start, m.text_end, m.cost, m.strand, m.cigar)
+                        for m in got] == want, (profile, rc, k, "best")
+
+
 def test_config1_shape_1mib(sassy):
     """BASELINE config 1: 'ATCG'x8, k=3, 1 MiB random ACGT (+ plants), Dna, forward only."""
     pat = b"ATCG" * 8
