@@ -1071,7 +1071,6 @@ static int append_matches(ScanOut& so, uint64_t total_len, const PatternPlan& pl
                           uint64_t pattern_idx, sassy_hip_Result* R, size_t& first, const HostTexts* ht = nullptr) {
   first = R->matches.size();
   if (without_trace) {  // reference: src/search.rs:1464-1475
-    R->matches.reserve(first + so.cands.size());
     for (const Candidate& c : so.cands) {
       sassy_hip_Match r{};
       uint64_t ts, te, ti;
@@ -1103,7 +1102,6 @@ static int append_matches(ScanOut& so, uint64_t total_len, const PatternPlan& pl
   if (base + so.pool.size() > 0xFFFFFFFFull)
     return fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB");
   R->pool.append(so.pool);
-  R->matches.reserve(first + so.matches.size());
   for (sassy_hip_Match r : so.matches) {
     r.pattern_idx = pattern_idx;
     r.cigar_off = (uint32_t)(r.cigar_off + base);
@@ -1505,12 +1503,15 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
     }
     const size_t nt = t1 - t0;
     if (total > 0) {
+      g_marks.start();
       hbuf.assign(total, (uint8_t)'X');
       for (size_t i = 0; i < nt; ++i)
         if (text_lens[t0 + i]) memcpy(hbuf.data() + ht.start[i], texts[t0 + i], text_lens[t0 + i]);
+      g_marks.mark("batch layout");
       if (int rc = s->d_text.reserve(total + 64)) return rc;
       if (int rc = s->d_tables.reserve(4 * nt)) return rc;
       HIP_TRY(hipMemcpyAsync(s->d_text.p, hbuf.data(), total, hipMemcpyHostToDevice, s->stream));
+      g_marks.mark("batch upload");
       uint64_t* d_tab = s->d_tables.p;
       HIP_TRY(hipMemcpyAsync(d_tab, ht.start.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
       HIP_TRY(hipMemcpyAsync(d_tab + nt, ht.len.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
