@@ -79,7 +79,11 @@ const char *sassy_hip_last_error(void);
 const char *sassy_hip_version(void);
 int sassy_hip_device_count(void); /* number of visible HIP devices, 0 if none / no runtime */
 
-/* Mirrors Searcher::new(rc, alpha) (src/search.rs:486-503) without aborting: NULL on error. */
+/* Mirrors Searcher::new(rc, alpha) (src/search.rs:486-503) without aborting: NULL on error.
+ * alpha = NAN: no overhang.  Otherwise (Iupac only, 0 <= alpha <= 1; src/search.rs:373-400) the
+ * pattern may hang over either end of the text at alpha per overhanging character: matches then
+ * carry pattern_start > 0 / pattern_end < pattern_len.  Overhang searches stream the full DP (the
+ * pigeonhole prefilter does not cover partial patterns) and report nothing for an empty text. */
 sassy_SearcherType *sassy_hip_searcher_new(const char *alphabet, bool rc, float alpha);
 /* Use an existing HIP stream (hipStream_t) for all work of this searcher; NULL = own stream. */
 int sassy_hip_set_stream(sassy_SearcherType *s, void *hip_stream);
@@ -98,6 +102,9 @@ int sassy_hip_enable_counters(sassy_SearcherType *s, int on);
  *   with_max_n_frac(f) (src/search.rs:454-475, src/n_filter.rs): drop matches whose text span holds
  *                      more than the fraction f of 'N'/'n'; f = 1.0 or NAN switches it off. */
 int sassy_hip_set_only_best_match(sassy_SearcherType *s, int on);
+/* Searcher::with_max_overhang (src/search.rs:436-440): at most this many overhanging characters are
+ * priced with alpha (the rest cost 1 each); negative = no limit. */
+int sassy_hip_set_max_overhang(sassy_SearcherType *s, long max_overhang);
 int sassy_hip_set_max_n_frac(sassy_SearcherType *s, float max_n_frac);
 
 /* Searcher::search / search_all with full Match records (src/search.rs:510-525, 685-700). */

@@ -19,7 +19,7 @@ import ctypes as C
 import os
 import subprocess
 from dataclasses import dataclass
-from typing import List, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _BUILD = os.path.join(_HERE, "_build")
@@ -37,7 +37,7 @@ def build(force: bool = False) -> str:
         srcs_present and any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRCS)
     )
     if force or stale:
-        cmd = ["gcc", "-O3", "-mavx2", "-mbmi2", "-shared", "-fPIC", "-o", _SO] + _SRCS
+        cmd = ["gcc", "-O3", "-mavx2", "-mbmi2", "-shared", "-fPIC", "-o", _SO] + _SRCS + ["-lm"]
         subprocess.check_call(cmd)
     return _SO
 
@@ -70,6 +70,9 @@ def lib():
     L.orc_search_encoded.restype = C.c_void_p
     L.orc_search_encoded.argtypes = [C.c_int, C.c_int, C.c_int, u8p, C.c_size_t, C.c_size_t, u8p,
                                      C.c_size_t, C.c_int32]
+    L.orc_search_overhang.restype = C.c_void_p
+    L.orc_search_overhang.argtypes = [C.c_int, C.c_int, C.c_int, u8p, C.c_size_t, u8p, C.c_size_t, C.c_int32,
+                                      C.c_float, C.c_long]
     L.orc_result_len.restype = C.c_size_t
     L.orc_result_len.argtypes = [C.c_void_p]
     L.orc_result_failed.restype = C.c_int
@@ -170,6 +173,15 @@ def search(profile, pattern: bytes, text: bytes, k: int, rc: bool = False,
     pattern, text = bytes(pattern), bytes(text)
     res = lib().orc_search(_profile(profile), int(rc), int(all_minima), pattern, len(pattern),
                            text, len(text), k)
+    return _collect(res)
+
+
+def search_overhang(profile, pattern: bytes, text: bytes, k: int, alpha: float, rc: bool = False,
+                    all_minima: bool = False, max_overhang: Optional[int] = None) -> List[Match]:
+    """Searcher::new_{fwd,rc}_with_overhang(alpha)[.with_max_overhang(mo)].search / search_all."""
+    pattern, text = bytes(pattern), bytes(text)
+    res = lib().orc_search_overhang(_profile(profile), int(rc), int(all_minima), pattern, len(pattern),
+                                    text, len(text), k, alpha, -1 if max_overhang is None else max_overhang)
     return _collect(res)
 
 

@@ -31,6 +31,7 @@
  */
 #include <stdint.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 #define ORC_ASCII 0
@@ -363,6 +364,211 @@ orc_result *orc_search_encoded(int profile, int rc, int all_minima, const uint8_
         }
     }
     free(rcp);
+    return r;
+}
+
+/* ------------------------------------------------------------------ overhang
+ * Searcher::new_*_with_overhang(alpha) / with_max_overhang (Iupac only, src/search.rs:373-440):
+ *  - left edge: the vertical delta of pattern row i at text position 0 is
+ *    floor((i+1) alpha) - floor(i alpha) for i < max_overhang, else 1 (search.rs:1695-1748), i.e.
+ *    D[j][0] = floor(min(j, mo) alpha) + max(0, j - mo) (trace.rs:36-47);
+ *  - right edge: the text is virtually extended by steps = min(m, ceil((k + alpha) / alpha), mo)
+ *    'N' columns (search.rs:347-356, :1024-1026); an end position pos > n costs an extra
+ *    floor(alpha (pos - n)) (search.rs:1274-1282) and positions up to n + steps are considered
+ *    (search.rs:1298-1308);
+ *  - traceback (trace.rs:273-406): window text[e-(m+k) .. min(e, n)) whose local matrix ALWAYS has
+ *    the overhang left column (also when the window starts inside the text) and 'N' beyond the
+ *    text; an end past the text first steps back diagonally (pattern_end = m - overshoot); a walk
+ *    that reaches column 0 stops there (pattern_start = remaining rows).
+ * All float arithmetic is f32, as in the reference. */
+static size_t ov_steps(size_t m, int32_t k, float alpha, long mo) {
+    size_t s = m;
+    if (alpha > 0.0f) {
+        float q = ceilf(((float)k + alpha) / alpha);
+        if (q < (float)s) s = (size_t)q;
+    }
+    if (mo >= 0 && (size_t)mo < s) s = (size_t)mo;
+    return s;
+}
+static int32_t ov_left(size_t j, float alpha, long mo) {
+    size_t a = j, extra = 0;
+    if (mo >= 0 && (size_t)mo < j) { a = (size_t)mo; extra = j - (size_t)mo; }
+    return (int32_t)floorf((float)a * alpha) + (int32_t)extra;
+}
+static int32_t ov_cost(size_t overshoot, float alpha) {
+    return overshoot ? (int32_t)floorf(alpha * (float)overshoot) : 0;
+}
+
+/* Last DP row over the text extended by `steps` 'N' columns: C[i], i = 0 .. n + steps. */
+static void last_row_ov(int profile, const uint8_t *pat, size_t m, const uint8_t *text, size_t n,
+                        size_t steps, float alpha, long mo, int32_t *C) {
+    int32_t *col = (int32_t *)malloc((m + 1) * sizeof(int32_t));
+    for (size_t j = 0; j <= m; j++) col[j] = ov_left(j, alpha, mo);
+    C[0] = col[m];
+    for (size_t i = 1; i <= n + steps; i++) {
+        const uint8_t t = i <= n ? text[i - 1] : (uint8_t)'N';
+        int32_t diag = col[0];
+        col[0] = 0;
+        for (size_t j = 1; j <= m; j++) {
+            int32_t left = col[j], up = col[j - 1];
+            int32_t v = diag + (scan_eq(profile, pat[j - 1], t) ? 0 : 1);
+            if (left + 1 < v) v = left + 1;
+            if (up + 1 < v) v = up + 1;
+            diag = left;
+            col[j] = v;
+        }
+        C[i] = col[m];
+    }
+    free(col);
+}
+
+/* find_minima_with_overhang (search.rs:1286-1369) on total costs, positions 0 .. n + steps. */
+static size_t find_ends_ov(const int32_t *C, size_t n, size_t steps, int32_t k, int all_minima, float alpha,
+                           uint64_t *pos, int32_t *cost, size_t cap) {
+    size_t cnt = 0, max_pos = n + steps;
+    if (max_pos == 0) return 0;
+#define TOT(i) (C[i] + ov_cost((i) > n ? (i) - n : 0, alpha))
+    if (all_minima) {
+        for (size_t i = 0; i <= max_pos; i++)
+            if (TOT(i) <= k) {
+                if (cnt < cap) { pos[cnt] = i; cost[cnt] = TOT(i); }
+                cnt++;
+            }
+        return cnt;
+    }
+    int dec = 1;
+    int32_t prev = TOT(0);
+    for (size_t i = 1; i <= max_pos; i++) {
+        int32_t t = TOT(i);
+        if (dec && t > prev && prev <= k) {
+            if (cnt < cap) { pos[cnt] = i - 1; cost[cnt] = prev; }
+            cnt++;
+        }
+        dec = (t < prev) || (dec && t == prev);
+        prev = t;
+    }
+    if (dec && prev <= k) {
+        if (cnt < cap) { pos[cnt] = max_pos; cost[cnt] = prev; }
+        cnt++;
+    }
+#undef TOT
+    return cnt;
+}
+
+/* get_trace with overhang (trace.rs:273-406); fills the match fields, returns the number of ops
+ * (pattern direction) or < 0 where the reference would panic. */
+static long trace_ov(int profile, const uint8_t *pat, size_t m, const uint8_t *text, size_t n, size_t e,
+                     int32_t k, float alpha, long mo, orc_match *mm, char *ops, size_t ops_cap) {
+    size_t fill = m + (size_t)k;
+    size_t o = e > fill ? e - fill : 0;
+    size_t wend = e < n ? e : n;
+    size_t wl = wend > o ? wend - o : 0;  /* text chars in the window */
+    size_t iend = e - o;                   /* column of the end cell; > wl past the text end */
+    size_t W = iend + 1;
+    int32_t *L = (int32_t *)malloc((m + 1) * W * sizeof(int32_t));
+#define LL(j, i) L[(j) * W + (i)]
+    for (size_t i = 0; i <= iend; i++) LL(0, i) = 0;
+    for (size_t j = 1; j <= m; j++) {
+        LL(j, 0) = ov_left(j, alpha, mo);
+        for (size_t i = 1; i <= iend; i++) {
+            const uint8_t t = i <= wl ? text[o + i - 1] : (uint8_t)'N';
+            int32_t v = LL(j - 1, i - 1) + (scan_eq(profile, pat[j - 1], t) ? 0 : 1);
+            if (LL(j, i - 1) + 1 < v) v = LL(j, i - 1) + 1;
+            if (LL(j - 1, i) + 1 < v) v = LL(j - 1, i) + 1;
+            LL(j, i) = v;
+        }
+    }
+    size_t j = m, i = iend;
+    int32_t g = LL(j, i);
+    int32_t total = g;
+    size_t pattern_start = 0, pattern_end = m;
+    long rc = 0;
+    if (i > wl) {
+        size_t over = i - wl;
+        if (over > m) { free(L); return -4; }
+        pattern_end -= over;
+        total += ov_cost(over, alpha);
+        i -= over;
+        j -= over;
+    }
+    size_t nops = 0;
+    for (;;) {
+        if (j == 0) break;
+        if (i == 0) {  /* overshoot at the start */
+            pattern_start = j;
+            g -= ov_left(j, alpha, mo);
+            break;
+        }
+        if (nops >= ops_cap) { rc = -2; break; }
+        if (LL(j - 1, i - 1) == g && trace_is_match(profile, pat[j - 1], text[o + i - 1])) {
+            ops[nops++] = '='; j--; i--; continue;
+        }
+        g -= 1;
+        if (LL(j - 1, i - 1) == g) { ops[nops++] = 'X'; j--; i--; continue; }
+        if (LL(j, i - 1) == g) { ops[nops++] = 'D'; i--; continue; }
+        if (LL(j - 1, i) == g) { ops[nops++] = 'I'; j--; continue; }
+        rc = -1;
+        break;
+    }
+#undef LL
+    free(L);
+    if (rc < 0) return rc;
+    if (g != 0) return -3;
+    for (size_t a = 0, b = nops; a + 1 < b; a++, b--) {
+        char tmp = ops[a]; ops[a] = ops[b - 1]; ops[b - 1] = tmp;
+    }
+    mm->text_start = o + i;
+    mm->text_end = o + wl;
+    mm->pattern_start = pattern_start;
+    mm->pattern_end = pattern_end;
+    mm->cost = total;
+    return (long)nops;
+}
+
+static void one_strand_ov(int profile, const uint8_t *pat, size_t m, const uint8_t *text, size_t n,
+                          int32_t k, int all_minima, float alpha, long mo, orc_result *r) {
+    if (n == 0) return; /* this build reports nothing for an empty text (overhang) */
+    size_t steps = ov_steps(m, k, alpha, mo);
+    int32_t *C = (int32_t *)malloc((n + steps + 1) * sizeof(int32_t));
+    last_row_ov(profile, pat, m, text, n, steps, alpha, mo, C);
+    size_t cap = n + steps + 2;
+    uint64_t *pos = (uint64_t *)malloc(cap * sizeof(uint64_t));
+    int32_t *cost = (int32_t *)malloc(cap * sizeof(int32_t));
+    size_t cnt = find_ends_ov(C, n, steps, k, all_minima, alpha, pos, cost, cap);
+    char *ops = (char *)malloc(2 * (m + (size_t)k) + 8);
+    for (size_t q = 0; q < cnt; q++) {
+        orc_match mm;
+        memset(&mm, 0, sizeof mm);
+        long nops = trace_ov(profile, pat, m, text, n, pos[q], k, alpha, mo, &mm, ops, 2 * (m + (size_t)k) + 8);
+        if (nops < 0 || mm.cost > cost[q] || mm.cost > k) { r->failed = 1; continue; }
+        mm.strand = 0;
+        res_push(r, mm, ops, (size_t)nops);
+    }
+    free(ops); free(pos); free(cost); free(C);
+}
+
+/* Searcher::<Iupac>::new_{fwd,rc}_with_overhang(alpha).with_max_overhang(mo).search / search_all;
+ * mo < 0 = no max_overhang. */
+orc_result *orc_search_overhang(int profile, int rc, int all_minima, const uint8_t *pat, size_t m,
+                                const uint8_t *text, size_t n, int32_t k, float alpha, long mo) {
+    orc_result *r = (orc_result *)calloc(1, sizeof(orc_result));
+    iupac_init();
+    one_strand_ov(profile, pat, m, text, n, k, all_minima, alpha, mo, r);
+    if (rc) {
+        size_t first = r->n;
+        uint8_t *cp = (uint8_t *)malloc(m ? m : 1);
+        uint8_t *rt = (uint8_t *)malloc(n ? n : 1);
+        orc_complement(profile, pat, m, cp);
+        for (size_t i = 0; i < n; i++) rt[i] = text[n - 1 - i];
+        one_strand_ov(profile, cp, m, rt, n, k, all_minima, alpha, mo, r);
+        for (size_t q = first; q < r->n; q++) {
+            uint64_t s = r->m[q].text_start, e = r->m[q].text_end;
+            r->m[q].strand = 1;
+            r->m[q].text_start = n - e;
+            r->m[q].text_end = n - s;
+        }
+        free(cp); free(rt);
+    }
     return r;
 }
 

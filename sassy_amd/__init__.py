@@ -108,6 +108,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_result_len", "sassy_hip_result_matches", "sassy_hip_result_cigars",
     "sassy_hip_result_cigars_len", "sassy_hip_enable_counters", "sassy_hip_set_timing",
     "sassy_hip_set_only_best_match", "sassy_hip_set_max_n_frac", "sassy_hip_search_with_fn",
+    "sassy_hip_set_max_overhang",
     "sassy_hip_search_many", "sassy_hip_tsv_header", "sassy_hip_format_tsv",
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
@@ -156,6 +157,8 @@ def lib():
     L.sassy_hip_set_timing.argtypes = [vp, C.c_int]
     L.sassy_hip_set_only_best_match.restype = C.c_int
     L.sassy_hip_set_only_best_match.argtypes = [vp, C.c_int]
+    L.sassy_hip_set_max_overhang.restype = C.c_int
+    L.sassy_hip_set_max_overhang.argtypes = [vp, C.c_long]
     L.sassy_hip_set_max_n_frac.restype = C.c_int
     L.sassy_hip_set_max_n_frac.argtypes = [vp, C.c_float]
     L.sassy_hip_search_many.restype = C.c_int
@@ -412,6 +415,11 @@ class Searcher:
     def only_best_match(self, on: bool = True) -> "Searcher":
         """Searcher::only_best_match (src/search.rs:442-446)."""
         _check(lib().sassy_hip_set_only_best_match(self._h, int(on)))
+        return self
+
+    def with_max_overhang(self, max_overhang: Optional[int]) -> "Searcher":
+        """Searcher::with_max_overhang (src/search.rs:436-440)."""
+        _check(lib().sassy_hip_set_max_overhang(self._h, -1 if max_overhang is None else int(max_overhang)))
         return self
 
     def with_max_n_frac(self, max_n_frac: Optional[float]) -> "Searcher":

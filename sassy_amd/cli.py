@@ -8,7 +8,7 @@ pattern against every record of the given FASTA / FASTQ files (plain or gzip), o
 
 Defaults follow the reference: alphabet iupac, reverse complement on, max_n_frac 0.2.  Rows come
 text record by text record, patterns in input order (the reference's order depends on its thread
-scheduling).  Not mirrored: --overhang (not built yet), grep / filter output modes, --v2, threads.
+scheduling).  Not mirrored: grep / filter output modes, --v2, threads.
 """
 from __future__ import annotations
 
@@ -74,6 +74,8 @@ def main(argv=None) -> int:
     g.add_argument("-f", "--pattern-fasta")
     sp.add_argument("-k", type=int, required=True)
     sp.add_argument("-a", "--alphabet", choices=["dna", "iupac"], default="iupac")
+    sp.add_argument("--overhang", type=float, default=None,
+                    help="cost per base of overhang alignment in [0, 1] (iupac only); default disabled")
     sp.add_argument("--no-rc", action="store_true")
     sp.add_argument("--max-n-frac", type=float, default=0.2)
     sp.add_argument("--sam", action="store_true")
@@ -81,7 +83,7 @@ def main(argv=None) -> int:
     args = ap.parse_args(argv)
 
     patterns = load_patterns(args)
-    searcher = Searcher(args.alphabet, rc=not args.no_rc).with_max_n_frac(args.max_n_frac)
+    searcher = Searcher(args.alphabet, rc=not args.no_rc, alpha=args.overhang).with_max_n_frac(args.max_n_frac)
     out = sys.stdout
     out.write("pat_id\ttext_id\tcost\tstrand\tstart\tend\tmatch_region\tcigar\n")
     for path in args.paths:

@@ -50,6 +50,8 @@ struct ChunkDesc {
 constexpr uint32_t kScanAllMinima = 1u;  // report every end position with cost <= k
 constexpr uint32_t kScanTextStart = 2u;  // buffer byte 0 is the true start of the text (column 0)
 constexpr uint32_t kScanTextEnd = 4u;    // buffer end is the true end of the text
+constexpr uint32_t kScanOverhang = 8u;   // overhang (alpha): special left edge at the text start, virtual
+                                         // 'N' columns and an extra cost past the text end
 
 // One (end position, cost) report of the scan kernel.  16 bytes.
 struct Candidate {
@@ -102,6 +104,11 @@ struct ScanParams {
   const uint32_t* desc_count; // list mode: number of descriptors (device)
   uint32_t desc_cap;
   uint8_t slot_val[kMaxSlots]; // per slot: Dna 2-bit code, Iupac base-set nibble, Ascii byte
+  // ---- overhang (kScanOverhang; reference: src/search.rs:347-356, 1274-1282, 1695-1748) ----
+  const uint32_t* ov_tab;     // device, nwords words: left-edge vertical deltas at the text start
+                              // (row r of word w at bit 31-r, like the carries)
+  float alpha;                // cost per overhanging pattern character
+  uint32_t ov_steps;          // virtual 'N' columns behind the text end (0 unless kScanTextEnd)
 };
 
 // A finished match record as the trace kernel writes it; same layout as sassy_hip_Match
@@ -142,6 +149,12 @@ struct TraceParams {
   uint32_t wave_mode;       // 1: trace_wave_kernel (one wavefront per report; slices are per wave)
   uint32_t count_min, count_max;  // the kernel runs only when count_min < number of reports <= count_max
   TextTable texts;          // n = 0 unless the buffer holds several texts
+  // overhang (reference: src/trace.rs:36-47, 273-335): use_alpha = 1 switches the window's left
+  // column to floor(min(j, max_overhang) * alpha) + max(0, j - max_overhang), pads the window with
+  // 'N' behind the text and lets the walk stop at column 0
+  uint32_t use_alpha;
+  float alpha;
+  uint32_t max_overhang;    // 0xFFFFFFFF = none
   // the first host_cap records also go straight to device-mapped pinned host memory
   MatchOut* host_out;
   uint8_t* host_str;

@@ -184,6 +184,10 @@ struct sassy_SearcherType {
 
   bool want_counters = false;
   // reporting modes of the reference's Searcher (src/search.rs:442-475)
+  float alpha = NAN;             // overhang cost per pattern character (NaN = no overhang), Iupac only
+  long max_overhang = -1;        // with_max_overhang(): -1 = none
+  DevBuf<uint32_t> d_ovtab;      // overhang: left-edge deltas of the current pattern
+  std::vector<uint32_t> up_ovtab;
   bool only_best = false;        // only_best_match(): one match per strand, minimal cost, rightmost end
   float max_n_frac = NAN;        // with_max_n_frac(): NaN = off (the reference's None)
   DevBuf<uint64_t> d_tables;     // multi-text buffers: start / len tables (both strands)
@@ -201,7 +205,7 @@ struct sassy_SearcherType {
 
   ~sassy_SearcherType() {
     d_text.release(); d_rev.release(); d_pattern.release(); d_rowoff.release();
-    d_table.release(); d_range.release(); d_ncount.release(); d_tables.release();
+    d_table.release(); d_range.release(); d_ncount.release(); d_tables.release(); d_ovtab.release();
     for (ScanLane& l : lanes) l.destroy();
     if (ev_inputs) (void)hipEventDestroy(ev_inputs);
   }
@@ -417,7 +421,20 @@ struct ScanJob {
 
 int ScanJob::prepare() {
   t_enter = now_ms();
-  n_blocks = (sh.text_len + 63) / 64;
+  // overhang (reference: get_overhang_steps, src/search.rs:347-356): the text is virtually extended
+  // by ov_steps 'N' columns, f32 arithmetic as there
+  const bool overhang = !std::isnan(S->alpha);
+  uint32_t ov_steps = 0;
+  if (overhang && sh.text_end) {
+    uint64_t st = plan.m;
+    if (S->alpha > 0.0f) {
+      const float qf = std::ceil(((float)k + S->alpha) / S->alpha);
+      if (qf < (float)st) st = (uint64_t)qf;
+    }
+    if (S->max_overhang >= 0) st = std::min<uint64_t>(st, (uint64_t)S->max_overhang);
+    ov_steps = (uint32_t)st;
+  }
+  n_blocks = (sh.text_len + ov_steps + 63) / 64;
   first_owned = sh.halo_len / 64;
   if (n_blocks <= first_owned) { empty = true; return 0; }  // nothing owned (empty text)
   if (n_blocks > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "text longer than 2^38 bytes per buffer");
@@ -436,12 +453,17 @@ int ScanJob::prepare() {
   P.profile = (uint32_t)S->profile;
   P.wb = warmup_blocks(plan.m, k);
   P.flags = (all_minima ? kScanAllMinima : 0u) | (sh.text_start ? kScanTextStart : 0u) |
-            (sh.text_end ? kScanTextEnd : 0u);
+            (sh.text_end ? kScanTextEnd : 0u) | (overhang ? kScanOverhang : 0u);
+  P.alpha = overhang ? S->alpha : 0.0f;
+  P.ov_steps = ov_steps;
   bucket = plan.nslots <= 4 ? 4 : plan.nslots <= 8 ? 8 : 16;
   static const int env_sb = getenv("SASSY_HIP_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_STAGE_BLOCKS")) : 0;
   P.stage_blocks = env_sb == 1 || env_sb == 2 ? (uint32_t)env_sb : 1u;
   for (int s = 0; s < kMaxSlots; ++s) P.slot_val[s] = plan.slot_val[s];
   q = filter_piece_len(plan, k);
+  // a match that hangs over an end of the text contains only part of the pattern: the pigeonhole
+  // argument of the prefilter does not cover it, so overhang searches stream the full DP
+  if (overhang) q = 0;
   filtered = q > 0;
   // which prefilter kernel (SASSY_HIP_FILTER_KIND=1|2|3 forces one where it applies)
   fkind = kFilterGeneric;
@@ -490,6 +512,23 @@ int ScanJob::prepare() {
       HIP_TRY(hipMemcpyAsync(S->d_pattern.p, S->up_pattern.data(), plan.m, hipMemcpyHostToDevice, S->stream));
     }
   }
+  if (overhang) {
+    // left-edge vertical deltas at the text start: floor((i+1) alpha) - floor(i alpha) for the first
+    // min(m, max_overhang) rows, 1 below (reference: src/search.rs:1713-1731); row r of word w at bit 31-r
+    std::vector<uint32_t> tab(plan.nwords, 0u);
+    const uint64_t mo = S->max_overhang >= 0 ? (uint64_t)S->max_overhang : UINT64_MAX;
+    for (uint32_t i = 0; i < plan.m; ++i) {
+      uint32_t d = 1;
+      if (i < mo) d = (uint32_t)((uint64_t)std::floor((float)(i + 1) * S->alpha) - (uint64_t)std::floor((float)i * S->alpha));
+      tab[i >> 5] |= (d & 1u) << (31 - (i & 31));
+    }
+    if (int rc = S->d_ovtab.reserve(plan.nwords)) return rc;
+    if (tab != S->up_ovtab) {
+      S->up_ovtab = tab;
+      HIP_TRY(hipMemcpyAsync(S->d_ovtab.p, S->up_ovtab.data(), plan.nwords * sizeof(uint32_t), hipMemcpyHostToDevice, S->stream));
+    }
+    P.ov_tab = S->d_ovtab.p;
+  }
   // One zero-initialised device area per call, cleared by a single memset:
   //   [0, 64)   control block: u32 [0] reports, [1] chunk descriptors | +16: u64 counters
   //             [0] word rows, [1] blocks, [2] hit blocks
@@ -528,7 +567,7 @@ int ScanJob::prepare() {
     static const int env_wave = getenv("SASSY_HIP_TRACE_WAVE") ? atoi(getenv("SASSY_HIP_TRACE_WAVE")) : 1;
     const uint64_t wstride = (raw + 15) / 16 * 16;
     use_wave = env_wave != 0 && 2ull * k + 3 <= 64 && pat_bytes + 4 * wstride <= 160 * 1024;
-    use_thread = !use_wave || k <= 6;
+    use_thread = !use_wave || (k <= 6 && !overhang);  // overhang: wave shape or the generic thread shape
     uint64_t stride = raw;
     if ((stride / 4) % 2 == 0) stride += 4;  // odd number of LDS words: conflict-free slices
     if (stride > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "pattern/k too large for the traceback band");
@@ -554,6 +593,9 @@ int ScanJob::prepare() {
     T.scratch_stride = (uint32_t)stride;
     T.str_stride = (2 * (plan.m + k + 1) + 2 + 15) / 16 * 16;
     T.ops_bytes = (uint32_t)opsb;
+    T.use_alpha = overhang ? 1u : 0u;
+    T.alpha = overhang ? S->alpha : 0.0f;
+    T.max_overhang = S->max_overhang >= 0 ? (uint32_t)std::min<long>(S->max_overhang, 0x7FFFFFFF) : 0xFFFFFFFFu;
     T.wave_mode = 0;
     T.count_min = use_wave ? kTraceWaveMax : 0;   // runs when count_min < count <= count_max
     T.count_max = 0xFFFFFFFFu;
@@ -1080,7 +1122,8 @@ static int append_matches(ScanOut& so, uint64_t total_len, const PatternPlan& pl
       r.text_start = UINT64_MAX;
       r.text_end = std::min<uint64_t>(c.pos, te) - ts;
       r.pattern_start = UINT64_MAX;
-      r.pattern_end = plan.m;
+      // an end position past the text (overhang) leaves that many pattern characters outside
+      r.pattern_end = plan.m - (c.pos > te ? std::min<uint64_t>(c.pos - te, plan.m) : 0);
       r.cost = c.cost;
       r.cigar_off = (uint32_t)R->pool.size();  // empty string: points at a NUL
       r.cigar_len = 0;
@@ -1341,9 +1384,15 @@ sassy_SearcherType* sassy_hip_searcher_new(const char* alphabet, bool rc, float 
     fail(SASSY_HIP_EINVAL, std::string("Unsupported alphabet: ") + alphabet);
     return nullptr;
   }
-  if (!std::isnan(alpha)) {
-    fail(SASSY_HIP_EUNSUPPORTED, "overhang (alpha) is not built yet; pass NAN");
-    return nullptr;
+  if (!std::isnan(alpha)) {  // reference: Searcher::_overhang_check (src/search.rs:373-383)
+    if (pr != PROFILE_IUPAC) {
+      fail(SASSY_HIP_EUNSUPPORTED, "Overhang is not supported for this alphabet (iupac only)");
+      return nullptr;
+    }
+    if (!(alpha >= 0.0f && alpha <= 1.0f)) {
+      fail(SASSY_HIP_EINVAL, "Alpha must be in range 0.0 <= alpha <= 1.0");
+      return nullptr;
+    }
   }
   if (rc && pr == PROFILE_ASCII) {
     // the reference panics at the first rc search (Profile::complement is unimplemented for Ascii)
@@ -1353,7 +1402,14 @@ sassy_SearcherType* sassy_hip_searcher_new(const char* alphabet, bool rc, float 
   sassy_SearcherType* s = new sassy_SearcherType();
   s->profile = pr;
   s->rc = rc;
+  s->alpha = alpha;
   return s;
+}
+
+int sassy_hip_set_max_overhang(sassy_SearcherType* s, long max_overhang) {
+  if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
+  s->max_overhang = max_overhang < 0 ? -1 : max_overhang;
+  return 0;
 }
 
 [[noreturn]] static void die(const char* msg) {
@@ -1464,6 +1520,7 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
   handled = false;
   static const bool off = getenv("SASSY_HIP_BATCH_TEXTS") && atoi(getenv("SASSY_HIP_BATCH_TEXTS")) == 0;
   if (off || n_texts < 2 || n_patterns == 0 || (flags & SASSY_HIP_TEXT_ON_DEVICE) || s->profile == PROFILE_ASCII) return 0;
+  if (!std::isnan(s->alpha)) return 0;  // overhang gives every text its own special edges: pair by pair
   if (n_texts >= (1u << (32 - kCandTextShift))) return 0;
   size_t max_m = 0;
   for (size_t pi = 0; pi < n_patterns; ++pi) {

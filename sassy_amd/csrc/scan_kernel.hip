@@ -116,6 +116,8 @@ struct EmitCtx {
   uint32_t cand_cap;
   uint32_t k;
   uint32_t flags;
+  float alpha;        // overhang: extra cost floor(alpha * (pos - text_len)) past the text end
+  uint32_t ov_steps;  // overhang: end positions up to text_len + ov_steps exist
 };
 
 __device__ __forceinline__ void emit(const EmitCtx& P, uint64_t gpos, int cost, uint32_t flags) {
@@ -142,9 +144,16 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
   const int k = (int)P.k;
   const bool all = (P.flags & kScanAllMinima) != 0;
   const uint64_t base = b * 64;
-  const uint64_t max_pos = P.text_len;
+  // with overhang the end positions run on into the virtual 'N' columns behind the text, at an
+  // extra cost (reference: add_overshoot_cost, src/search.rs:1274-1282)
+  const uint64_t max_pos = P.text_len + P.ov_steps;
   if (base >= max_pos) return state;
-  int cost = ds, prev_cost = ds;
+  const bool ov = P.ov_steps != 0;
+  auto total_of = [&](int c, uint64_t pos) -> int {
+    return (ov && pos > P.text_len) ? c + __float2int_rd(P.alpha * (float)(pos - P.text_len)) : c;
+  };
+  int raw = ds;                        // cost without the overshoot part
+  int cost = total_of(raw, base), prev_cost = cost;
   uint64_t prev_pos = base;
   if (all && owned && cost <= k && base == 0 && P.global_offset == 0 && (P.flags & kScanTextStart))
     emit(P, 0, cost, 0);
@@ -152,8 +161,9 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
   for (int bit = 1; bit <= 64; ++bit) {
     const uint64_t pos = base + (uint64_t)bit;
     if (pos > max_pos) break;
-    cost += (int)((vp >> (bit - 1)) & 1);
-    cost -= (int)((vm >> (bit - 1)) & 1);
+    raw += (int)((vp >> (bit - 1)) & 1);
+    raw -= (int)((vm >> (bit - 1)) & 1);
+    cost = total_of(raw, pos);
     if (all) {
       if (owned && cost <= k) emit(P, P.global_offset + pos, cost, 0);
     } else {
@@ -180,8 +190,8 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
 
 // 16 text bytes that straddle or lie past the end of the buffer (cold path): bytes past the end
 // read as 'X' (reference: src/search.rs:202-207).
-__device__ __noinline__ uint4 load_tail16(const uint8_t* text, uint64_t off, uint64_t text_len) {
-  uint64_t lo = 0x5858585858585858ull, hi = 0x5858585858585858ull;
+__device__ __noinline__ uint4 load_tail16(const uint8_t* text, uint64_t off, uint64_t text_len, uint32_t pad = 'X') {
+  uint64_t lo = 0x0101010101010101ull * pad, hi = lo;  // 'X', or 'N' with overhang
   if (off < text_len) {
     const uint32_t valid = (uint32_t)min((uint64_t)16, text_len - off);
 #pragma unroll 1
@@ -406,10 +416,15 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   // per-row carries between horizontally adjacent blocks, 32 rows per word, row r of a word at
   // bit 31-r, one LDS slot pair per word and lane.  Fresh start: every vertical delta on the left
   // edge is +1 (D[j][start] = j).
+  // With overhang the chunk that starts at column 0 of the text gets the alpha left edge instead.
+  const bool ov_seed = exact_start && (P.flags & kScanOverhang);
   for (uint32_t w = 0; w < nwords; ++w) {
-    carry[(w * 2 + 0) * 64 + lane] = (w == nwords - 1) ? last_word_init : 0xFFFFFFFFu;
+    uint32_t hp0 = (w == nwords - 1) ? last_word_init : 0xFFFFFFFFu;
+    if (ov_seed) hp0 = P.ov_tab[w];
+    carry[(w * 2 + 0) * 64 + lane] = hp0;
     carry[(w * 2 + 1) * 64 + lane] = 0;
   }
+  const uint32_t tail_pad = (P.flags & kScanOverhang) ? (uint32_t)'N' : (uint32_t)'X';
 
   // ---- staging geometry: instruction i of a stage loads, for tile row `owner`, the 16-byte
   // chunk that belongs into slot (lane % kSlots) of that row.  Slots are XOR-swizzled so that the
@@ -443,6 +458,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   ctx.cand_cap = P.cand_cap;
   ctx.k = P.k;
   ctx.flags = P.flags;
+  ctx.alpha = P.alpha;
+  ctx.ov_steps = (P.flags & kScanOverhang) ? P.ov_steps : 0u;
 
   unsigned long long cnt_rows = 0, cnt_blocks = 0, cnt_live = 0;
   const unsigned char* my_masks = mask_bytes + lane * 8;
@@ -463,7 +480,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
           const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
           uint4 v;
           if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
-          else v = load_tail16(P.text, off, P.text_len);
+          else v = load_tail16(P.text, off, P.text_len, tail_pad);
           *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
         }
       }
@@ -1026,6 +1043,8 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   ctx.cand_cap = P.cand_cap;
   ctx.k = P.k;
   ctx.flags = P.flags;
+  ctx.alpha = P.alpha;
+  ctx.ov_steps = (P.flags & kScanOverhang) ? P.ov_steps : 0u;
   unsigned long long cnt_rows = 0, cnt_blocks = 0, cnt_live = 0;
   const unsigned char* my_masks = mask_bytes + lane * 8;
 

@@ -129,15 +129,23 @@ __device__ __forceinline__ Window report_window(const TraceParams& P, const Cand
   return w;
 }
 
+// Overhang: cost of having the first j pattern characters hang over the start of the text,
+// floor(min(j, max_overhang) * alpha) + max(0, j - max_overhang) in f32 (reference: src/trace.rs:36-47).
+__device__ __forceinline__ int ov_left(const TraceParams& P, int j) {
+  const int a = (uint32_t)j < P.max_overhang ? j : (int)P.max_overhang;
+  return __float2int_rd((float)a * P.alpha) + (j - a);
+}
+
 __device__ __forceinline__ MatchOut make_row(const TraceParams& P, uint32_t c, const Window& win, uint64_t text_start,
-                                             int cost, uint32_t len, bool ok) {
+                                             int cost, uint32_t len, bool ok, uint32_t pattern_start = 0,
+                                             uint32_t pattern_end = 0xFFFFFFFFu) {
   MatchOut r;
   r.pattern_idx = 0;
   r.text_idx = win.text_idx;
   r.text_start = text_start - win.base;
   r.text_end = win.we - win.base;
-  r.pattern_start = 0;
-  r.pattern_end = P.m;
+  r.pattern_start = pattern_start;
+  r.pattern_end = pattern_end == 0xFFFFFFFFu ? P.m : pattern_end;
   r.cost = cost;
   r.strand = 0;
   r.pad_[0] = ok ? 0 : kTraceFailed;
@@ -191,7 +199,11 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
       for (int x = 0; x < wl; ++x) win[x] = kIupacCode[win[x] & 31u];
     auto text_at = [&](int i) -> uint32_t { return win[i]; };
 
-    const int dend = wl - m, dlo = dend - k - 1;
+    // overhang: the end cell may lie past the text (columns wl+1 .. iend are 'N')
+    const bool alpha_on = KT < 0 && P.use_alpha != 0;
+    const int iend = alpha_on ? (int)(cd.pos - o) : wl;
+    const uint32_t ncode = rule.iupac ? 15u : (uint32_t)'N';
+    const int dend = iend - m, dlo = dend - k - 1;
     // ---- fill the band ----
     if constexpr (KT >= 0) {
       constexpr int BW = 2 * KT + 3;
@@ -246,11 +258,14 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
         for (int b = 0; b < bw; ++b) {
           const int i = j + dlo + b;
           int v;
-          if (i < 0 || i > wl) v = inf;
+          if (i < 0 || i > iend) v = inf;
           else if (j == 0) v = 0;
-          else if (i == 0) v = j < inf ? j : inf;
-          else {
-            v = (int)prev[b] + (rule_hit(rule, pc, text_at(i - 1), rule.emask) ? 0 : 1);
+          else if (i == 0) {
+            const int lc = alpha_on ? ov_left(P, j) : j;
+            v = lc < inf ? lc : inf;
+          } else {
+            const uint32_t tc = i - 1 < wl ? text_at(i - 1) : ncode;
+            v = (int)prev[b] + (rule_hit(rule, pc, tc, rule.emask) ? 0 : 1);
             const int l = left + 1;
             const int u = (b + 1 < bw ? (int)prev[b + 1] : inf) + 1;
             v = v < l ? v : l;
@@ -262,14 +277,30 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
         }
       }
     }
-    // ---- greedy walk from (m, wl) ----
-    int j = m, i = wl;
+    // ---- greedy walk from (m, iend) ----
+    int j = m, i = iend;
     int g = (int)L[(size_t)m * bw + (k + 1)];
-    const int cost = g;
+    int cost = g;
+    uint32_t pattern_start = 0, pattern_end = P.m;
     const uint32_t max_ops = P.m + P.k + 1;
     uint32_t nops = 0;
     bool ok = g <= k;
+    if (ok && i > wl) {  // the match ends past the text: step back along the diagonal (trace.rs:299-312)
+      const int over = i - wl;
+      if (over > m) ok = false;
+      else {
+        pattern_end -= (uint32_t)over;
+        cost += __float2int_rd((float)over * P.alpha);
+        i -= over;
+        j -= over;
+      }
+    }
     while (ok && j > 0) {
+      if (alpha_on && i == 0) {  // the rest of the pattern hangs over the text start (trace.rs:322-335)
+        pattern_start = (uint32_t)j;
+        g -= ov_left(P, j);
+        break;
+      }
       if (nops >= max_ops) { ok = false; break; }
       const int b = i - j - dlo;
       const Cell* row = L + (size_t)j * bw;
@@ -295,7 +326,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
     // ---- cigar text and the finished row, to the device arrays and (head of the list) the host ----
     unsigned char* sbuf = ops + P.ops_bytes;
     const uint32_t w = rle_text(ops, nops, ok, sbuf);
-    const MatchOut r = make_row(P, c, W, o + (uint64_t)i, cost, w, ok);
+    const MatchOut r = make_row(P, c, W, o + (uint64_t)i, cost, w, ok, pattern_start, pattern_end);
     const uint32_t ndw = w / 4 + 1;
     uint32_t* dstr = reinterpret_cast<uint32_t*>(P.out_str + (uint64_t)c * P.str_stride);
     const uint32_t* ssrc = reinterpret_cast<const uint32_t*>(sbuf);
@@ -360,34 +391,39 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
     if (W.skip) continue;
     const uint64_t o = W.o, we = W.we;
     const int wl = (int)(we - o);
+    // overhang: the end cell may lie past the text; columns wl+1 .. iend are virtual 'N'
+    const bool alpha_on = P.use_alpha != 0;
+    const int iend = alpha_on ? (int)(cd.pos - o) : wl;
     {  // window -> LDS (coalesced bytes), Iupac letters -> base sets
       const uint8_t* src = P.text + (o - P.global_offset);
-      for (int x = (int)lane; x < wl; x += 64) {
-        const uint32_t ch = src[x];
+      for (int x = (int)lane; x < iend; x += 64) {
+        const uint32_t ch = x < wl ? src[x] : (uint32_t)'N';
         win[x] = (unsigned char)(rule.iupac ? kIupacCode[ch & 31u] : ch);
       }
     }
     __builtin_amdgcn_wave_barrier();
-    const int dend = wl - m, dlo = dend - k - 1;
+    const int dend = iend - m, dlo = dend - k - 1;
     const int b = (int)lane;
     const bool in_band = b < bw;
     // ---- fill: row 0, then rows 1..m ----
     int prev;
     {
       const int i = dlo + b;
-      prev = (!in_band || i < 0 || i > wl) ? inf : 0;
+      prev = (!in_band || i < 0 || i > iend) ? inf : 0;
       if (in_band) L[b] = (Cell)prev;
     }
     for (int j = 1; j <= m; ++j) {
       const uint32_t pc = spat[j - 1];
       const int i = j + dlo + b;
-      const bool valid = in_band && i >= 0 && i <= wl;
+      const bool valid = in_band && i >= 0 && i <= iend;
       // upper neighbour (j-1, i) = band column b+1 of the previous row
       const int up = __builtin_amdgcn_update_dpp(inf, prev, 0x130, 0xF, 0xF, false);  // wave_shl:1
       int t = inf;
       if (valid) {
-        if (i == 0) t = j < inf ? j : inf;
-        else {
+        if (i == 0) {
+          const int lc = alpha_on ? ov_left(P, j) : j;
+          t = lc < inf ? lc : inf;
+        } else {
           const uint32_t tc = win[i - 1];
           const int dg = prev + (rule_hit(rule, pc, tc, rule.emask) ? 0 : 1);
           const int u = up + 1;
@@ -403,14 +439,30 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
     // make the band and the window visible to every lane (same wave: LDS ops are in order, this
     // only keeps the compiler from reordering)
     __builtin_amdgcn_wave_barrier();
-    // ---- greedy walk from (m, wl), wave-uniform ----
-    int j = m, i = wl;
+    // ---- greedy walk from (m, iend), wave-uniform ----
+    int j = m, i = iend;
     int g = (int)L[(size_t)m * bw + (k + 1)];
-    const int cost = g;
+    int cost = g;
+    uint32_t pattern_start = 0, pattern_end = P.m;
     const uint32_t max_ops = P.m + P.k + 1;
     uint32_t nops = 0;
     bool ok = g <= k;
+    if (ok && i > wl) {  // the match ends past the text: step back along the diagonal (trace.rs:299-312)
+      const int over = i - wl;
+      if (over > m) ok = false;
+      else {
+        pattern_end -= (uint32_t)over;
+        cost += __float2int_rd((float)over * P.alpha);
+        i -= over;
+        j -= over;
+      }
+    }
     while (ok && j > 0) {
+      if (alpha_on && i == 0) {  // the rest of the pattern hangs over the text start (trace.rs:322-335)
+        pattern_start = (uint32_t)j;
+        g -= ov_left(P, j);
+        break;
+      }
       if (nops >= max_ops) { ok = false; break; }
       const int bb = i - j - dlo;
       const Cell* row = L + (size_t)j * bw;
@@ -448,7 +500,7 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
         if (c < P.host_cap) hstr[x] = v;
       }
       if (lane == 0) {
-        const MatchOut r = make_row(P, c, W, o + (uint64_t)i, cost, w, ok);
+        const MatchOut r = make_row(P, c, W, o + (uint64_t)i, cost, w, ok, pattern_start, pattern_end);
         P.out[c] = r;
         if (c < P.host_cap) P.host_out[c] = r;
       }
@@ -500,6 +552,8 @@ hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stre
     else launch_one<uint16_t, false, -1>(P, nblocks, lds, stream);
   } else if (!in_lds) {
     launch_one<uint8_t, false, -1>(P, nblocks, lds, stream);
+  } else if (P.use_alpha) {  // overhang lives in the generic variant only
+    launch_one<uint8_t, true, -1>(P, nblocks, lds, stream);
   } else {
     switch (P.k) {
       case 0: launch_one<uint8_t, true, 0>(P, nblocks, lds, stream); break;

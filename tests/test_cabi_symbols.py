@@ -52,8 +52,12 @@ def test_match_struct_layout(sassy):
 def test_searcher_constructor_errors(sassy):
     with pytest.raises(sassy.SassyHipError, match="Unsupported alphabet"):
         sassy.Searcher("protein")
-    with pytest.raises(sassy.SassyHipError, match="overhang"):
-        sassy.Searcher("iupac", rc=False, alpha=0.5)
+    # overhang: Iupac only, 0 <= alpha <= 1 (reference: Searcher::_overhang_check, src/search.rs:373-383)
+    with pytest.raises(sassy.SassyHipError, match="[Oo]verhang"):
+        sassy.Searcher("dna", rc=False, alpha=0.5)
+    with pytest.raises(sassy.SassyHipError, match="Alpha"):
+        sassy.Searcher("iupac", rc=False, alpha=1.5)
+    sassy.Searcher("iupac", rc=False, alpha=0.5)
     with pytest.raises(sassy.SassyHipError):
         sassy.Searcher("ascii", rc=True)
     for a in ("dna", "DNA", "Iupac", "ascii"):

@@ -516,6 +516,60 @@ def test_batched_texts(sassy):
                         for m in got] == want, (profile, rc, k, "best")
 
 
+def test_overhang(sassy, kats):
+    """Overhang: the reference's known answers, then seeded fuzz of
+    Searcher::<Iupac>::new_{fwd,rc}_with_overhang(alpha)[.with_max_overhang(mo)] against the oracle --
+    matches hanging over the text start / end, alpha in {0, 0.25, 0.5, 1}, search and search_all,
+    k small (wave-shape traceback) and > 30 (thread-shape traceback), N-fraction filter on top."""
+    for e in kats["overhang"]:
+        pat, text = e["pattern"].encode(), e["text"].encode()
+        s = sassy.Searcher(e["profile"], rc=e["rc"], alpha=e["alpha"])
+        if "max_n_frac" in e:
+            s.with_max_n_frac(e["max_n_frac"])
+        ms = s.search_all(pat, text, e["k"]) if e["mode"] == "search_all" else s.search(pat, text, e["k"])
+        assert_same(ms, oracle.search_overhang(e["profile"], pat, text, e["k"], e["alpha"], rc=e["rc"],
+                                               all_minima=e["mode"] == "search_all"))
+        if "expect" in e:
+            for m, x in zip(ms, e["expect"]):
+                for f, v in x.items():
+                    assert getattr(m, f) == v, (e["id"], f, m)
+        if "expect_len" in e:
+            assert len(ms) == e["expect_len"]
+    rng = random.Random(515)
+    for it in range(120):
+        m = rng.choice([4, 8, 12, 20, 33, 40, 70])
+        k = rng.randrange(0, min(6, m // 2) + 1)
+        if it % 40 == 39:
+            m, k = 80, 34  # band wider than a wavefront: thread-shape traceback
+        alpha = rng.choice([0.0, 0.25, 0.5, 0.5, 1.0])
+        mo = rng.choice([None, None, 0, 3, m // 2])
+        pat = bytearray(rng.choice(b"ACGT") for _ in range(m))
+        if rng.random() < 0.3:
+            pat[rng.randrange(m)] = rng.choice(b"NRYW")
+        pat = bytes(pat)
+        plain = bytes(c if c in b"ACGT" else 65 for c in pat)
+        n = rng.choice([3, 10, 40, 63, 64, 65, 130, 500, 2000])
+        text = bytearray(rng.choice(b"ACGTN") if rng.random() < 0.05 else rng.choice(b"ACGT") for _ in range(n))
+        # a suffix of the pattern at the text start, a prefix at the text end, something in the middle
+        cut = rng.randrange(1, m)
+        head = mutate(rng, plain, rng.randrange(0, 2))[cut:][:n]
+        text[:len(head)] = head
+        cut = rng.randrange(1, m)
+        tail = mutate(rng, plain, rng.randrange(0, 2))[:cut][-n:]
+        text[n - len(tail):] = tail
+        if n > 3 * m:
+            mid = mutate(rng, plain, rng.randrange(0, k + 1))
+            at = rng.randrange(m, n - 2 * m)
+            text[at:at + len(mid)] = mid
+        tb = bytes(text)
+        rc = bool(it & 1)
+        allm = bool(it & 2)
+        s = sassy.Searcher("iupac", rc=rc, alpha=alpha).with_max_overhang(mo)
+        got = s.search_all(pat, tb, k) if allm else s.search(pat, tb, k)
+        want = oracle.search_overhang("iupac", pat, tb, k, alpha, rc=rc, all_minima=allm, max_overhang=mo)
+        assert_same(got, want), (it, m, k, alpha, mo, n)
+
+
 def test_config1_shape_1mib(sassy):
     """BASELINE config 1: 'ATCG'x8, k=3, 1 MiB random ACGT (+ plants), Dna, forward only."""
     pat = b"ATCG" * 8

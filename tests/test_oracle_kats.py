@@ -125,3 +125,35 @@ def test_mode_kats(kats):
             assert [m.text_start for m in ms] == e["expect_text_start"], (e["id"], ms)
         if "expect_text_end" in e:
             assert [m.text_end for m in ms] == e["expect_text_end"], (e["id"], ms)
+
+
+def test_overhang_kats(kats):
+    """Overhang known answers (lib.rs doctest, the two trace-path tests, the N-filter test)."""
+    for e in kats["overhang"]:
+        pat, text = e["pattern"].encode(), e["text"].encode()
+        ms = oracle.search_overhang(e["profile"], pat, text, e["k"], e["alpha"], rc=e["rc"],
+                                    all_minima=e["mode"] == "search_all")
+        if "expect" in e:
+            assert len(ms) == len(e["expect"]), (e["id"], ms)
+            for m, x in zip(ms, e["expect"]):
+                for f, v in x.items():
+                    assert getattr(m, f) == v, (e["id"], f, m)
+        if "expect_len" in e:
+            assert len(ms) == e["expect_len"], (e["id"], ms)
+        if "expect_first" in e:
+            m, x = ms[0], e["expect_first"]
+            for f in ("pattern_start", "pattern_end", "text_start", "text_end"):
+                if f in x:
+                    assert getattr(m, f) == x[f], (e["id"], f, m)
+            # Match::to_path (src/search.rs:83-103): the cells of the alignment inside the text
+            path, j, i = [], m.pattern_start, m.text_start
+            import re
+            for cnt, op in re.findall(r"(\d+)([=XID])", m.cigar):
+                for _ in range(int(cnt)):
+                    if op in "=X":
+                        path.append([j, i]); j += 1; i += 1
+                    elif op == "I":
+                        path.append([j, i]); j += 1
+                    else:
+                        path.append([j, i]); i += 1
+            assert path == x["path"], (e["id"], path)
