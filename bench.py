@@ -119,14 +119,22 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    # one rank per GPU over RCCL; on a box with fewer GPUs than ranks (debugging the N > 1 path on a
+    # single GPU) the ranks share devices and the match gather goes over gloo with host tensors
+    shared_gpu = world > n_dev
+    torch.cuda.set_device(local_rank % n_dev)
+    device = torch.device("cuda", local_rank % n_dev)
+    coll_device = torch.device("cpu") if shared_gpu else device
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        if shared_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
 
     # ---------------------------------------------------------------- workload
     n_per = args.text_bytes // 64 * 64
@@ -157,7 +165,7 @@ def main():
             # the records are already on the host in their final form (r.array + r.pool)
             return r, searcher.stats()
         local = multigpu.pack_result(r)
-        shards = multigpu.gather_shard_results(local, torch, dist, device)
+        shards = multigpu.gather_shard_results(local, torch, dist, coll_device)
         merged = multigpu.merge_shard_results(shards) if rank == 0 else None
         return merged, searcher.stats()
 
@@ -184,7 +192,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed, scan_ms / max(1, args.steps), filter_ms / max(1, args.steps)],
-                      dtype=torch.float64, device=device)
+                      dtype=torch.float64, device=coll_device)
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed, scan_avg_ms, filter_avg_ms = float(el[0]), float(el[1]), float(el[2])
