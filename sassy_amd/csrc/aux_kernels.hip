@@ -285,6 +285,33 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const Candidate* __re
   if (r < host_cap) host_sorted[r] = v;
 }
 
+// ------------------------------------------------------------------ "is the text plain ACGT?"
+// Sets *flag when some byte is not one of A C G T a c g t.  On such text the Iupac profile computes
+// exactly what the Dna profile computes (same Eq relation, same is_match), and the Dna kernels are
+// cheaper (two bit planes instead of a five-plane table lookup), so multi-pattern searches test
+// the text once and then run the Dna kernels.  Same SWAR test as filter_table_kernel: the byte must
+// equal the letter its 2-bit code stands for.
+__global__ __launch_bounds__(256) void acgt_check_kernel(const uint4* __restrict__ text16, uint64_t n16,
+                                                         const uint8_t* __restrict__ tail, uint32_t n_tail,
+                                                         uint32_t* __restrict__ flag) {
+  uint32_t bad = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 v = text16[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t sel = (w[d] >> 1) & 0x03030303u;
+      const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, sel);  // 'A' 'C' 'T' 'G' by code
+      bad |= (w[d] & 0xDFDFDFDFu) ^ expect;
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < n_tail) {
+    const uint32_t c = tail[threadIdx.x] & 0xDFu;
+    bad |= (c != 'A' && c != 'C' && c != 'G' && c != 'T') ? 1u : 0u;
+  }
+  if (bad) *flag = 1u;
+}
+
 // ------------------------------------------------------------------ N counting (max_n_frac)
 // count[i] = number of 'N' / 'n' bytes in text[range[2i] .. range[2i+1]) -- the input of the
 // reference's N-fraction filters (src/n_filter.rs:8-60) when the text lives on the device.
@@ -299,6 +326,13 @@ __global__ __launch_bounds__(256) void count_n_kernel(const uint8_t* __restrict_
 }
 
 // ------------------------------------------------------------------ launchers
+hipError_t launch_acgt_check(const uint8_t* d_text, uint64_t n, uint32_t* d_flag, hipStream_t stream) {
+  const uint64_t n16 = n / 16;
+  hipLaunchKernelGGL(acgt_check_kernel, dim3(4096), dim3(256), 0, stream, reinterpret_cast<const uint4*>(d_text), n16,
+                     d_text + n16 * 16, (uint32_t)(n - n16 * 16), d_flag);
+  return hipGetLastError();
+}
+
 hipError_t launch_count_n(const uint8_t* d_text, const uint64_t* d_range, uint32_t n, uint32_t* d_count,
                           hipStream_t stream) {
   if (n == 0) return hipSuccess;

@@ -32,6 +32,7 @@ hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hi
 hipError_t launch_filter_table(const ScanParams& P, uint32_t grid, hipStream_t stream);
 hipError_t launch_count_n(const uint8_t* d_text, const uint64_t* d_range, uint32_t n, uint32_t* d_count,
                           hipStream_t stream);
+hipError_t launch_acgt_check(const uint8_t* d_text, uint64_t n, uint32_t* d_flag, hipStream_t stream);
 hipError_t launch_filter_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_filter_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_list_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
@@ -1863,6 +1864,27 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
   }
   const uint8_t* tptr = (flags & SASSY_HIP_TEXT_ON_DEVICE) ? d_text : s->d_text.p;
   f |= SASSY_HIP_TEXT_ON_DEVICE;  // search_text must not upload the text again per pattern
+  // Many plain-ACGT patterns on an Iupac searcher (the CRISPR-guide case): if the text is plain
+  // ACGT as well, the Dna kernels give identical results and are cheaper -- test the text once.
+  struct ProfileGuard {
+    sassy_SearcherType* s; Profile saved;
+    ~ProfileGuard() { s->profile = saved; }
+  } pguard{s, s->profile};
+  if (s->profile == PROFILE_IUPAC && std::isnan(s->alpha) && e->patterns.size() >= 4 && text_len >= 16 &&
+      ((uintptr_t)tptr & 15) == 0) {
+    bool plain = true;
+    for (const auto& p : e->patterns) plain = plain && acgt_only(p.data(), p.size());
+    if (plain) {
+      if (int rc = s->d_ncount.reserve(4)) return rc;
+      HIP_TRY(hipMemsetAsync(s->d_ncount.p, 0, 4, s->stream));
+      hipError_t le = launch_acgt_check(tptr, text_len, s->d_ncount.p, s->stream);
+      if (le != hipSuccess) return hip_fail(le, "text check kernel launch");
+      uint32_t bad = 1;
+      HIP_TRY(hipMemcpyAsync(&bad, s->d_ncount.p, 4, hipMemcpyDeviceToHost, s->stream));
+      HIP_TRY(hipStreamSynchronize(s->stream));
+      if (!bad) s->profile = PROFILE_DNA;
+    }
+  }
   for (size_t p = 0; p < e->patterns.size(); ++p) {
     const size_t first = R->matches.size();
     if (int rc = search_text(s, e->patterns[p].data(), e->plen, tptr, text_len, k, f,

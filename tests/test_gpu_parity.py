@@ -570,6 +570,40 @@ def test_overhang(sassy, kats):
         assert_same(got, want), (it, m, k, alpha, mo, n)
 
 
+def test_encoded_many_patterns(sassy):
+    """search_encoded_patterns with many plain-ACGT patterns on an Iupac searcher (BASELINE config 4
+    shape): on plain-ACGT text the scans run with the Dna kernels, on text with other letters with the
+    Iupac kernels -- both must equal the oracle's search_encoded."""
+    rng = random.Random(45)
+    pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(12)]
+    for variant in ("plain", "lower", "with_n"):
+        n = 30_000 + (7 if variant == "lower" else 0)  # also a length that is not a multiple of 16
+        text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        for p in pats:
+            for _ in range(2):
+                ins = mutate(rng, p, rng.randrange(0, 3))
+                if rng.random() < 0.5:
+                    ins = oracle.reverse_complement("iupac", ins)
+                at = rng.randrange(0, n - len(ins))
+                text[at:at + len(ins)] = ins
+        if variant == "lower":
+            for _ in range(300):
+                i = rng.randrange(n); text[i] = text[i] | 0x20
+        if variant == "with_n":
+            for _ in range(50):
+                text[rng.randrange(n)] = rng.choice(b"NRY")
+            text[n - 1] = ord("N")  # in the tail bytes behind the last full 16-byte chunk
+        tb = bytes(text)
+        for rc in (False, True):
+            s = sassy.Searcher("iupac", rc=rc)
+            enc = s.encode_patterns(pats)
+            got = s.search_encoded_patterns(enc, tb, 2)
+            want = oracle.search_encoded("iupac", pats, tb, 2, rc=rc)
+            assert len(want) >= 6
+            assert sorted(key(m) for m in got) == sorted(key(m) for m in want), (variant, rc)
+            assert s.stats()["filtered"] == 0  # 20-mers at k=2: pieces too short, streaming DP
+
+
 def test_config1_shape_1mib(sassy):
     """BASELINE config 1: 'ATCG'x8, k=3, 1 MiB random ACGT (+ plants), Dna, forward only."""
     pat = b"ATCG" * 8
