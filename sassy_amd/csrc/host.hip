@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
 #include <iterator>
 #include <memory>
 #include <cmath>
@@ -121,6 +122,15 @@ struct ScanLane {
   DevBuf<Candidate> d_cand, d_sorted;
   DevBuf<MatchOut> d_trace;
   DevBuf<ChunkDesc> d_desc;
+  // pattern-dependent device data of the scan that runs on this lane, and what it currently holds
+  // (uploads are skipped when the pattern repeats); per lane, so that scans of different patterns
+  // can be in flight on different lanes
+  DevBuf<uint8_t> d_pattern, d_table;
+  DevBuf<uint32_t> d_rowoff, d_ovtab;
+  std::vector<uint8_t> up_pattern, h_table, table_pattern;
+  std::vector<uint32_t> up_rowtab, up_ovtab;
+  int up_profile = -1, table_profile = -1;
+  uint32_t table_q = 0, table_k = 0;
   // pinned host staging area: control block and the first kSpec reports of a scan are written into
   // it by the kernels themselves; one stream synchronisation makes them readable
   unsigned char* h_pin = nullptr;
@@ -156,6 +166,7 @@ struct ScanLane {
   void destroy() {
     d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release();
     d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release();
+    d_pattern.release(); d_table.release(); d_rowoff.release(); d_ovtab.release();
     if (h_pin) (void)hipHostFree(h_pin);
     for (hipEvent_t e : {ev_a, ev_b, ev_c, ev_f, ev_filter_done})
       if (e) (void)hipEventDestroy(e);
@@ -176,37 +187,25 @@ struct sassy_SearcherType {
   hipStream_t user_stream = nullptr;
   hipEvent_t ev_inputs = nullptr;  // "uploads of this call are queued" (other lanes wait for it)
   bool device_ready = false;
-  DevBuf<uint8_t> d_text, d_rev, d_pattern;
-  DevBuf<uint32_t> d_rowoff;
-  // what d_rowoff / d_pattern currently hold (uploads are skipped when the pattern repeats)
-  std::vector<uint8_t> up_pattern;
-  std::vector<uint32_t> up_rowtab;
-  int up_profile = -1;
+  DevBuf<uint8_t> d_text, d_rev;
 
   bool want_counters = false;
   // reporting modes of the reference's Searcher (src/search.rs:442-475)
   float alpha = NAN;             // overhang cost per pattern character (NaN = no overhang), Iupac only
   long max_overhang = -1;        // with_max_overhang(): -1 = none
-  DevBuf<uint32_t> d_ovtab;      // overhang: left-edge deltas of the current pattern
-  std::vector<uint32_t> up_ovtab;
   bool only_best = false;        // only_best_match(): one match per strand, minimal cost, rightmost end
   float max_n_frac = NAN;        // with_max_n_frac(): NaN = off (the reference's None)
   DevBuf<uint64_t> d_tables;     // multi-text buffers: start / len tables (both strands)
   DevBuf<uint64_t> d_range;      // N counting on device-resident text
   DevBuf<uint32_t> d_ncount;
-  // q-gram table of the last pattern searched with the table prefilter
-  DevBuf<uint8_t> d_table;
-  std::vector<uint8_t> h_table, table_pattern;
-  uint32_t table_q = 0, table_k = 0;
-  int table_profile = -1;
   // HIP-event timing of the call's phases: 0 none, 1 the dominant kernel only (filter / streaming
   // scan; default), 2 every phase.  Each event record costs a few microseconds of stream idle time.
   int timing = getenv("SASSY_HIP_TIMING") ? atoi(getenv("SASSY_HIP_TIMING")) : 1;
   sassy_hip_Stats stats{};
 
   ~sassy_SearcherType() {
-    d_text.release(); d_rev.release(); d_pattern.release(); d_rowoff.release();
-    d_table.release(); d_range.release(); d_ncount.release(); d_tables.release(); d_ovtab.release();
+    d_text.release(); d_rev.release();
+    d_range.release(); d_ncount.release(); d_tables.release();
     for (ScanLane& l : lanes) l.destroy();
     if (ev_inputs) (void)hipEventDestroy(ev_inputs);
   }
@@ -479,16 +478,16 @@ int ScanJob::prepare() {
     else if (!can_generic) return fail(SASSY_HIP_EUNSUPPORTED, "k too large for the prefilter's piece table");
     if (fkind == kFilterTable) {
       const uint32_t tq = std::min<uint32_t>(q, 9);
-      const bool cached = S->table_q == tq && S->table_k == k && S->table_profile == (int)S->profile &&
-                          S->table_pattern.size() == plan.m && memcmp(S->table_pattern.data(), pat, plan.m) == 0;
+      const bool cached = L.table_q == tq && L.table_k == k && L.table_profile == (int)S->profile &&
+                          L.table_pattern.size() == plan.m && memcmp(L.table_pattern.data(), pat, plan.m) == 0;
       if (!cached) {
-        if (build_qgram_table(S->profile, pat, tq, pieces, S->h_table)) {
-          if (int rc = S->d_table.reserve(S->h_table.size())) return rc;
-          HIP_TRY(hipMemcpyAsync(S->d_table.p, S->h_table.data(), S->h_table.size(), hipMemcpyHostToDevice, S->stream));
-          S->table_q = tq; S->table_k = k; S->table_profile = (int)S->profile;
-          S->table_pattern.assign(pat, pat + plan.m);
+        if (build_qgram_table(S->profile, pat, tq, pieces, L.h_table)) {
+          if (int rc = L.d_table.reserve(L.h_table.size())) return rc;
+          HIP_TRY(hipMemcpyAsync(L.d_table.p, L.h_table.data(), L.h_table.size(), hipMemcpyHostToDevice, L.stream));
+          L.table_q = tq; L.table_k = k; L.table_profile = (int)S->profile;
+          L.table_pattern.assign(pat, pat + plan.m);
         } else {
-          S->table_q = 0;
+          L.table_q = 0;
           if (!can_generic) return fail(SASSY_HIP_EUNSUPPORTED, "pattern too ambiguous / k too large for the prefilter");
           fkind = kFilterGeneric;
         }
@@ -498,19 +497,19 @@ int ScanJob::prepare() {
   }
 
   // pattern-dependent device data is uploaded only when the pattern changed since the last call
-  if (int rc = S->d_rowoff.reserve(plan.row_tab.size())) return rc;
-  if (int rc = S->d_pattern.reserve(plan.m)) return rc;
+  if (int rc = L.d_rowoff.reserve(plan.row_tab.size())) return rc;
+  if (int rc = L.d_pattern.reserve(plan.m)) return rc;
   {
-    const bool same = S->up_profile == (int)S->profile && S->up_pattern.size() == plan.m &&
-                      memcmp(S->up_pattern.data(), pat, plan.m) == 0 && S->up_rowtab == plan.row_tab;
+    const bool same = L.up_profile == (int)S->profile && L.up_pattern.size() == plan.m &&
+                      memcmp(L.up_pattern.data(), pat, plan.m) == 0 && L.up_rowtab == plan.row_tab;
     if (!same) {
-      S->up_pattern.assign(pat, pat + plan.m);
-      S->up_rowtab = plan.row_tab;
-      S->up_profile = (int)S->profile;
+      L.up_pattern.assign(pat, pat + plan.m);
+      L.up_rowtab = plan.row_tab;
+      L.up_profile = (int)S->profile;
       // the sources must stay valid until the copies ran: use the searcher-owned copies
-      HIP_TRY(hipMemcpyAsync(S->d_rowoff.p, S->up_rowtab.data(), S->up_rowtab.size() * sizeof(uint32_t),
-                             hipMemcpyHostToDevice, S->stream));
-      HIP_TRY(hipMemcpyAsync(S->d_pattern.p, S->up_pattern.data(), plan.m, hipMemcpyHostToDevice, S->stream));
+      HIP_TRY(hipMemcpyAsync(L.d_rowoff.p, L.up_rowtab.data(), L.up_rowtab.size() * sizeof(uint32_t),
+                             hipMemcpyHostToDevice, L.stream));
+      HIP_TRY(hipMemcpyAsync(L.d_pattern.p, L.up_pattern.data(), plan.m, hipMemcpyHostToDevice, L.stream));
     }
   }
   if (overhang) {
@@ -523,12 +522,12 @@ int ScanJob::prepare() {
       if (i < mo) d = (uint32_t)((uint64_t)std::floor((float)(i + 1) * S->alpha) - (uint64_t)std::floor((float)i * S->alpha));
       tab[i >> 5] |= (d & 1u) << (31 - (i & 31));
     }
-    if (int rc = S->d_ovtab.reserve(plan.nwords)) return rc;
-    if (tab != S->up_ovtab) {
-      S->up_ovtab = tab;
-      HIP_TRY(hipMemcpyAsync(S->d_ovtab.p, S->up_ovtab.data(), plan.nwords * sizeof(uint32_t), hipMemcpyHostToDevice, S->stream));
+    if (int rc = L.d_ovtab.reserve(plan.nwords)) return rc;
+    if (tab != L.up_ovtab) {
+      L.up_ovtab = tab;
+      HIP_TRY(hipMemcpyAsync(L.d_ovtab.p, L.up_ovtab.data(), plan.nwords * sizeof(uint32_t), hipMemcpyHostToDevice, L.stream));
     }
-    P.ov_tab = S->d_ovtab.p;
+    P.ov_tab = L.d_ovtab.p;
   }
   // One zero-initialised device area per call, cleared by a single memset:
   //   [0, 64)   control block: u32 [0] reports, [1] chunk descriptors | +16: u64 counters
@@ -542,7 +541,7 @@ int ScanJob::prepare() {
     if (int rc = L.d_cand.reserve(1u << 16)) return rc;
   d_counts = reinterpret_cast<uint32_t*>(L.d_ctl.p);
   d_counters = reinterpret_cast<unsigned long long*>(L.d_ctl.p + 16);
-  P.row_tab = S->d_rowoff.p;
+  P.row_tab = L.d_rowoff.p;
   P.cand_count = d_counts;
   P.counters = S->want_counters ? d_counters : nullptr;
 
@@ -589,7 +588,7 @@ int ScanJob::prepare() {
     T.m = plan.m;
     T.k = k;
     T.profile = (uint32_t)S->profile;
-    T.pattern = S->d_pattern.p;
+    T.pattern = L.d_pattern.p;
     T.scratch = L.d_scratch.p;
     T.scratch_stride = (uint32_t)stride;
     T.str_stride = (2 * (plan.m + k + 1) + 2 + 15) / 16 * 16;
@@ -644,7 +643,7 @@ int ScanJob::prepare() {
     static const int env_planes = getenv("SASSY_HIP_FILTER_PLANES") ? atoi(getenv("SASSY_HIP_FILTER_PLANES")) : 1;
     (void)env_planes;
     F.piece_planes = fkind == kFilterPlanes ? 1u : 0u;
-    F.qgram_table = fkind == kFilterTable ? S->d_table.p : nullptr;
+    F.qgram_table = fkind == kFilterTable ? L.d_table.p : nullptr;
     if (F.piece_planes) {
       for (uint32_t pp = 0; pp < 8; ++pp) {
         const uint32_t piece = pp < F.n_pieces ? pp : 0;  // a repeated piece changes nothing
@@ -1088,6 +1087,87 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   out.exit_state = incoming;
   return 0;
 }
+
+// Several independent scans (different patterns over the same resident buffer) in flight, one per
+// lane: while the GPU runs one pattern's kernels the host already queues the next one's and unpacks
+// the previous one's results.  submit() blocks only when every lane is busy; results come back in
+// submission order through the callback.
+struct ScanQueue {
+  struct Slot {
+    PatternPlan plan;
+    std::vector<uint8_t> pat;
+    std::unique_ptr<ScanJob> job;
+    uint64_t tag = 0;
+    bool busy = false;
+  };
+  typedef std::function<int(uint64_t tag, ScanOut& so, const PatternPlan& plan, const uint8_t* pat)> Done;
+  sassy_SearcherType* S;
+  int n_lanes;
+  Slot slots[kMaxLanes];
+  int head = 0, tail = 0, in_flight = 0;  // ring over the lanes
+  bool inputs_marked = false;
+  Done done;
+
+  ScanQueue(sassy_SearcherType* S_, Done d) : S(S_), done(std::move(d)) {
+    static const int env = getenv("SASSY_HIP_QUEUE_LANES") ? atoi(getenv("SASSY_HIP_QUEUE_LANES")) : kMaxLanes;
+    n_lanes = std::max(1, std::min(env, kMaxLanes));
+  }
+  int drain_one() {
+    Slot& sl = slots[head];
+    ScanOut so;
+    int rc = sl.job->finish(so);
+    sl.job.reset();
+    sl.busy = false;
+    head = (head + 1) % n_lanes;
+    --in_flight;
+    if (rc) return rc;
+    return done(sl.tag, so, sl.plan, sl.pat.data());
+  }
+  int drain_all() {
+    int first = 0;
+    while (in_flight) {
+      const int rc = drain_one();
+      if (rc && !first) first = rc;
+    }
+    return first;
+  }
+  int submit(const PatternPlan& plan, const uint8_t* pat, const ShardView& sh, const TextTable& texts, uint32_t k,
+             bool all_minima, bool do_trace, uint64_t total_len, uint64_t tag) {
+    if (in_flight == n_lanes)
+      if (int rc = drain_one()) return rc;
+    if (!inputs_marked) {
+      // text uploads / the reverse kernel of this call were queued on the searcher's stream: every
+      // other lane waits for them once
+      HIP_TRY(hipEventRecord(S->ev_inputs, S->stream));
+      for (int l = 1; l < n_lanes; ++l) HIP_TRY(hipStreamWaitEvent(S->lanes[l].stream, S->ev_inputs, 0));
+      inputs_marked = true;
+    }
+    Slot& sl = slots[tail];
+    sl.plan = plan;
+    sl.pat.assign(pat, pat + plan.m);
+    sl.tag = tag;
+    sl.job.reset(new ScanJob(S, S->lanes[tail], sh, sl.plan, k, all_minima, sl.pat.data(), do_trace, total_len));
+    sl.job->texts = texts;
+    sl.job->texts.all_minima = all_minima ? 1u : 0u;
+    sl.busy = true;
+    tail = (tail + 1) % n_lanes;
+    ++in_flight;
+    ScanJob& job = *sl.job;
+    if (int rc = job.prepare()) return rc;
+    if (!job.empty)
+      if (int rc = job.enqueue(0)) return rc;
+    return 0;
+  }
+  ~ScanQueue() {  // never leave work in flight behind an error return
+    while (in_flight) {
+      ScanOut so;
+      (void)slots[head].job->finish(so);
+      slots[head].job.reset();
+      head = (head + 1) % n_lanes;
+      --in_flight;
+    }
+  }
+};
 
 // Host view of a multi-text buffer (see TextTable in common.h).  Null = the buffer is one text.
 struct HostTexts {
@@ -1590,43 +1670,43 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
         if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
       }
       std::string err;
-      std::vector<uint8_t> h_rev;  // host copy of the reversed buffer, only for N counting
+      // one scan per pattern and strand, several in flight (ScanQueue); tag = 2 * pattern + strand
+      ScanQueue queue(s, [&](uint64_t tag, ScanOut& so, const PatternPlan& plan, const uint8_t* pat) -> int {
+        const size_t pi = (size_t)(tag >> 1);
+        const bool is_rc = (tag & 1) != 0;
+        const HostTexts& h = is_rc ? ht_rev : ht;
+        if (int rc = post_filter(s, so, plan, pat, (uint32_t)k, is_rc ? 1 : 0, is_rc ? nullptr : hbuf.data(),
+                                 is_rc ? s->d_rev.p : s->d_text.p, total, !wo, EndFilter(), &h)) return rc;
+        size_t first = 0;
+        if (int rc = append_matches(so, total, plan, wo, pi, R, first, &h)) return rc;
+        for (size_t i = first; i < R->matches.size(); ++i) {
+          sassy_hip_Match& m = R->matches[i];
+          if (!is_rc) { m.text_idx += t0; continue; }
+          // reference: src/search.rs:859-873
+          const size_t t = nt - 1 - (size_t)m.text_idx;
+          const uint64_t len = ht.len[t], rs = m.text_start, re = m.text_end;
+          m.strand = 1;
+          m.text_idx = t0 + t;
+          m.text_start = len - re;
+          m.text_end = wo ? UINT64_MAX : len - rs;
+        }
+        return 0;
+      });
       for (size_t pi = 0; pi < n_patterns; ++pi) {
         PatternPlan plan;
         if (!make_plan(s->profile, patterns[pi], pattern_lens[pi], plan, err)) return fail(SASSY_HIP_EINVAL, err);
-        {
-          ShardView sh{s->d_text.p, total, 0, 0, true, true};
-          ScanOut so;
-          if (int rc = run_scan_single(s, sh, plan, (uint32_t)k, all, patterns[pi], !wo, total, so, tt)) return rc;
-          if (int rc = post_filter(s, so, plan, patterns[pi], (uint32_t)k, 0, hbuf.data(), s->d_text.p, total, !wo,
-                                   EndFilter(), &ht)) return rc;
-          size_t first = 0;
-          if (int rc = append_matches(so, total, plan, wo, pi, R, first, &ht)) return rc;
-          for (size_t i = first; i < R->matches.size(); ++i) R->matches[i].text_idx += t0;
-        }
+        ShardView sh{s->d_text.p, total, 0, 0, true, true};
+        if (int rc = queue.submit(plan, patterns[pi], sh, tt, (uint32_t)k, all, !wo, total, 2 * pi)) return rc;
         if (s->rc) {
           std::vector<uint8_t> cp(pattern_lens[pi]);
           for (size_t i = 0; i < cp.size(); ++i) cp[i] = complement_char(s->profile, patterns[pi][i]);
           PatternPlan cplan;
           if (!make_plan(s->profile, cp.data(), cp.size(), cplan, err)) return fail(SASSY_HIP_EINVAL, err);
-          ShardView sh{s->d_rev.p, total, 0, 0, true, true};
-          ScanOut so;
-          if (int rc = run_scan_single(s, sh, cplan, (uint32_t)k, all, cp.data(), !wo, total, so, tt_rev)) return rc;
-          if (int rc = post_filter(s, so, cplan, cp.data(), (uint32_t)k, 1, nullptr, s->d_rev.p, total, !wo,
-                                   EndFilter(), &ht_rev)) return rc;
-          size_t first = 0;
-          if (int rc = append_matches(so, total, cplan, wo, pi, R, first, &ht_rev)) return rc;
-          for (size_t i = first; i < R->matches.size(); ++i) {  // reference: src/search.rs:859-873
-            sassy_hip_Match& m = R->matches[i];
-            const size_t t = nt - 1 - (size_t)m.text_idx;
-            const uint64_t len = ht.len[t], rs = m.text_start, re = m.text_end;
-            m.strand = 1;
-            m.text_idx = t0 + t;
-            m.text_start = len - re;
-            m.text_end = wo ? UINT64_MAX : len - rs;
-          }
+          ShardView shr{s->d_rev.p, total, 0, 0, true, true};
+          if (int rc = queue.submit(cplan, cp.data(), shr, tt_rev, (uint32_t)k, all, !wo, total, 2 * pi + 1)) return rc;
         }
       }
+      if (int rc = queue.drain_all()) return rc;
     }
     t0 = t1;
   }
@@ -1885,11 +1965,28 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
       if (!bad) s->profile = PROFILE_DNA;
     }
   }
-  for (size_t p = 0; p < e->patterns.size(); ++p) {
-    const size_t first = R->matches.size();
-    if (int rc = search_text(s, e->patterns[p].data(), e->plen, tptr, text_len, k, f,
-                             p % e->n_original, true, false, R)) return rc;
-    for (size_t i = first; i < R->matches.size(); ++i) R->matches[i].strand = p >= e->n_original ? 1 : 0;
+  (void)f;
+  if (text_len > 0) {
+    if (k > 0x7FFFFFFFu) return fail(SASSY_HIP_EINVAL, "k too large");
+    const bool all = (flags & SASSY_HIP_ALL_MINIMA) != 0;
+    const bool wo = (flags & SASSY_HIP_WITHOUT_TRACE) != 0;
+    const uint8_t* h_text = (flags & SASSY_HIP_TEXT_ON_DEVICE) ? nullptr : text;
+    // one forward scan per pattern, several in flight (ScanQueue); results in pattern order
+    ScanQueue queue(s, [&](uint64_t p, ScanOut& so, const PatternPlan& plan, const uint8_t* pat) -> int {
+      if (int rc = post_filter(s, so, plan, pat, (uint32_t)k, 0, h_text, tptr, text_len, !wo, EndFilter())) return rc;
+      size_t first = 0;
+      if (int rc = append_matches(so, text_len, plan, wo, p % e->n_original, R, first)) return rc;
+      for (size_t i = first; i < R->matches.size(); ++i) R->matches[i].strand = p >= e->n_original ? 1 : 0;
+      return 0;
+    });
+    std::string err;
+    for (size_t p = 0; p < e->patterns.size(); ++p) {
+      PatternPlan plan;
+      if (!make_plan(s->profile, e->patterns[p].data(), e->plen, plan, err)) return fail(SASSY_HIP_EINVAL, err);
+      ShardView sh{tptr, text_len, 0, 0, true, true};
+      if (int rc = queue.submit(plan, e->patterns[p].data(), sh, TextTable{}, (uint32_t)k, all, !wo, text_len, p)) return rc;
+    }
+    if (int rc = queue.drain_all()) return rc;
   }
   // The reference's order is an artefact of its range bookkeeping; its own differential test
   // sorts by this key before comparing (pattern_tiling/search.rs:748-757).
