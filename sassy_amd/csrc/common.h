@@ -96,6 +96,8 @@ struct ScanParams {
   // Dna bit-plane filter: per piece, bit j = code bit 0 / code bit 1 of piece row j
   uint32_t piece_planes;      // 1: use filter_dna_kernel (Dna, <= 8 pieces)
   uint32_t piece_bits[8][2];
+  uint32_t piece_rem[8];      // pattern rows behind piece p: a match that contains the piece exactly, ending
+                              // at text position e, ends in [e + rem - k, e + rem + k]
   // q-gram table filter: 4^piece_len bits, byte = code & (2^(2q-3)-1), bit = code >> (2q-3)
   const uint8_t* qgram_table; // device; null unless the table filter is used
   unsigned long long* hit_bitmap;  // one bit per text block: an exact piece occurrence ends in it

@@ -655,6 +655,7 @@ int ScanJob::prepare() {
         }
         F.piece_bits[pp][0] = b0;
         F.piece_bits[pp][1] = b1;
+        F.piece_rem[pp] = plan.m - (piece + 1) * q;
       }
     }
     static const int env_fsb = getenv("SASSY_HIP_FILTER_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_FILTER_STAGE_BLOCKS")) : 0;
@@ -720,7 +721,9 @@ int ScanJob::enqueue(int attempt) {
     desc_cap = (uint32_t)std::min<size_t>(L.d_desc.cap, 0x7FFFFFFFu);
     if (int rc = L.d_state.reserve(desc_cap)) return rc;
     P.chunk_state = L.d_state.p;
-    le = launch_build_chunks(d_bitmap, n_words, n_blocks, first_owned, P.wb, P.wb, maxlen, L.d_desc.p,
+    // right dilation: blocks a match END can reach from a piece occurrence; the bit-plane filter
+    // marks those blocks itself (it knows the piece), the other filters mark the occurrence's block
+    le = launch_build_chunks(d_bitmap, n_words, n_blocks, first_owned, P.wb, fkind == kFilterPlanes ? 0u : P.wb, maxlen, L.d_desc.p,
                              d_counts + 1, desc_cap, d_counters + 2, L.stream);
     if (le != hipSuccess) return hip_fail(le, "chunk builder launch");
     P.desc = L.d_desc.p;

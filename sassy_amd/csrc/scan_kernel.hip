@@ -862,7 +862,25 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
     const uint64_t b = blk0 + it;
     const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
     if (evaluate && hit != 0) {
-      atomicOr(&P.hit_bitmap[b >> 6], 1ull << (b & 63));
+      // Rare.  The piece is known here, so the blocks that can hold the END of a match around this
+      // occurrence are known exactly: with rem pattern rows behind the piece and <= k edits, a match
+      // that contains the occurrence ending at text position e ends in [e + rem - k, e + rem + k].
+      // The blocks of those columns and of the one behind them are marked (not the block of the
+      // occurrence); K0b adds the warm-up in front.
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        const uint64_t bits = ((uint64_t)ah[pp] << 32) | al[pp];
+        if (bits == 0) continue;
+        const int64_t e_lo = (int64_t)(b * 64) + __ffsll((long long)bits);        // first end position
+        const int64_t e_hi = (int64_t)(b * 64) + 64 - __clzll((long long)bits);   // last end position
+        int64_t c_lo = e_lo + (int64_t)P.piece_rem[pp] - (int64_t)P.k;
+        // + 1: the report rule decides about an end position when it sees the next column
+        const int64_t c_hi = e_hi + (int64_t)P.piece_rem[pp] + (int64_t)P.k + 1;
+        if (c_lo < 1) c_lo = 1;
+        uint64_t blo = (uint64_t)(c_lo - 1) >> 6, bhi = (uint64_t)(c_hi - 1) >> 6;
+        if (bhi >= P.n_blocks) bhi = P.n_blocks - 1;
+        for (uint64_t x = blo; x <= bhi; ++x) atomicOr(&P.hit_bitmap[x >> 6], 1ull << (x & 63));
+      }
     }
   }
 }

