@@ -164,8 +164,7 @@ def main():
         if world == 1:
             # the records are already on the host in their final form (r.array + r.pool)
             return r, searcher.stats()
-        local = multigpu.pack_result(r)
-        shards = multigpu.gather_shard_results(local, torch, dist, coll_device)
+        shards = multigpu.gather_shard_results(r, torch, dist, coll_device)  # packs while the headers travel
         merged = multigpu.merge_shard_results(shards) if rank == 0 else None
         return merged, searcher.stats()
 

@@ -57,18 +57,29 @@ def pack_result(result) -> ShardResult:
     n = len(a)
     rows = np.zeros((n, COLS), dtype=np.int64)
     if n:
-        for col, f in enumerate(("pattern_idx", "text_start", "text_end", "pattern_start", "pattern_end")):
-            rows[:, col] = a[f].view(np.int64) if a[f].dtype == np.uint64 else a[f]
+        # text_start, text_end, pattern_start, pattern_end are bytes 16..47 of the 64-byte record
+        raw = a.view(np.uint8).reshape(n, 64)
+        rows[:, 0] = a["pattern_idx"].view(np.int64)
+        rows[:, 1:5] = raw[:, 16:48].view(np.int64).reshape(n, 4)
         rows[:, 5] = a["cost"]
         rows[:, 6] = a["strand"]
         clen = a["cigar_len"].astype(np.int64)
         if int(clen.max(initial=0)) > CIGAR_BYTES:
             raise ValueError("cigar longer than the fixed gather field")
         pool = np.frombuffer(result.pool, dtype=np.uint8) if result.pool else np.zeros(1, np.uint8)
-        idx = a["cigar_off"].astype(np.int64)[:, None] + np.arange(CIGAR_BYTES, dtype=np.int64)[None, :]
-        keep = np.arange(CIGAR_BYTES, dtype=np.int64)[None, :] < clen[:, None]
-        cig = np.where(keep, pool[np.minimum(idx, len(pool) - 1)], 0).astype(np.uint8)
-        rows[:, 7:] = cig.view(np.int64)
+        off = a["cigar_off"].astype(np.int64)
+        stride = int(off[1] - off[0]) if n > 1 else 0
+        if n > 1 and stride >= CIGAR_BYTES and len(pool) >= int(off[-1]) + CIGAR_BYTES and \
+                bool((off == off[0] + stride * np.arange(n, dtype=np.int64)).all()):
+            # the device wrote the cigar strings into equally spaced, NUL-padded slots: one strided view
+            cig = np.lib.stride_tricks.as_strided(pool[int(off[0]):], shape=(n, CIGAR_BYTES), strides=(stride, 1))
+            keep = np.arange(CIGAR_BYTES, dtype=np.int64)[None, :] < clen[:, None]
+            cig = np.where(keep, cig, 0).astype(np.uint8)
+        else:
+            idx = off[:, None] + np.arange(CIGAR_BYTES, dtype=np.int64)[None, :]
+            keep = np.arange(CIGAR_BYTES, dtype=np.int64)[None, :] < clen[:, None]
+            cig = np.where(keep, pool[np.minimum(idx, len(pool) - 1)], 0).astype(np.uint8)
+        rows[:, 7:] = np.ascontiguousarray(cig).view(np.int64)
     return ShardResult(rows, result.exit_state, result.conditional_index)
 
 
@@ -120,15 +131,19 @@ def merge_shard_results(shards: Sequence[ShardResult]) -> np.ndarray:
     return np.concatenate(parts, axis=0) if parts else np.zeros((0, COLS), dtype=np.int64)
 
 
-def gather_shard_results(local: ShardResult, torch, dist, device) -> Optional[List[ShardResult]]:
+def gather_shard_results(local, torch, dist, device) -> Optional[List[ShardResult]]:
     """The one exchange of the path: all ranks' match lists to rank 0.
     Two collectives: all_gather of the 3-word headers (count, exit state, conditional index),
-    then gather of the records padded to the largest count."""
+    then gather of the records padded to the largest count.  `local` is a ShardResult or a
+    sassy_amd.Result; a Result is packed while the header exchange is in flight."""
     world, rank = dist.get_world_size(), dist.get_rank()
-    head = torch.tensor([len(local), local.exit_state, local.conditional_index],
-                        dtype=torch.int64, device=device)
+    n_local = len(local)
+    head = torch.tensor([n_local, local.exit_state, local.conditional_index], dtype=torch.int64, device=device)
     heads = [torch.empty_like(head) for _ in range(world)]
-    dist.all_gather(heads, head)
+    work = dist.all_gather(heads, head, async_op=True)
+    if not isinstance(local, ShardResult):
+        local = pack_result(local)
+    work.wait()
     heads = torch.stack(heads).cpu().tolist()
     counts = [h[0] for h in heads]
     maxc = max(counts)

@@ -606,6 +606,27 @@ def test_encoded_many_patterns(sassy):
                 assert s.stats()["filtered"] == 0  # 20-mers at k=2: pieces too short, streaming DP
 
 
+def test_pack_result_for_gather(sassy):
+    """multigpu.pack_result (vectorised wire format of the match gather) against the per-match packer."""
+    from sassy_amd import multigpu
+    rng = random.Random(12)
+    pat = bytes(rng.choice(b"ACGT") for _ in range(32))
+    n = 200_000
+    text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+    for q in range(40):
+        ins = mutate(rng, pat, q % 4)
+        text[1000 + q * 4000:1000 + q * 4000 + len(ins)] = ins
+    buf = sassy.DeviceBuffer(n + 64)
+    buf.upload(bytes(text))
+    s = sassy.Searcher("dna", rc=False)
+    r = s.search_shard(pat, buf.ptr, 0, n, 0, n, 3)
+    assert len(r) >= 40
+    packed = multigpu.pack_result(r)
+    assert (packed.rows == multigpu.rows_from_matches(r.matches)).all()
+    back = multigpu.matches_from_rows(packed.rows, sassy.Match)
+    assert [key(m) for m in back] == [key(m) for m in r.matches]
+
+
 def test_config1_shape_1mib(sassy):
     """BASELINE config 1: 'ATCG'x8, k=3, 1 MiB random ACGT (+ plants), Dna, forward only."""
     pat = b"ATCG" * 8
