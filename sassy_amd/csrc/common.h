@@ -98,6 +98,12 @@ struct ScanParams {
   uint32_t piece_bits[8][2];
   uint32_t piece_rem[8];      // pattern rows behind piece p: a match that contains the piece exactly, ending
                               // at text position e, ends in [e + rem - k, e + rem + k]
+  // multi-pattern bit-plane filter (filter_dna_multi_kernel): multi_n patterns of equal length and
+  // piece geometry; pattern p's piece_bits at multi_bits[16 p + 2 piece + plane], its hit bitmap at
+  // hit_bitmap + p * multi_stride (64-bit words)
+  const uint32_t* multi_bits;
+  uint32_t multi_n;
+  uint64_t multi_stride;
   // q-gram table filter: 4^piece_len bits, byte = code & (2^(2q-3)-1), bit = code >> (2q-3)
   const uint8_t* qgram_table; // device; null unless the table filter is used
   unsigned long long* hit_bitmap;  // one bit per text block: an exact piece occurrence ends in it

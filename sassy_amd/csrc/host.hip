@@ -31,6 +31,7 @@ hipError_t launch_scan_iupac(const ScanParams& P, uint32_t grid, size_t smem, hi
 hipError_t launch_scan_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_filter_table(const ScanParams& P, uint32_t grid, hipStream_t stream);
+hipError_t launch_filter_dna_multi(const ScanParams& P, uint32_t grid, hipStream_t stream);
 hipError_t launch_count_n(const uint8_t* d_text, const uint64_t* d_range, uint32_t n, uint32_t* d_count,
                           hipStream_t stream);
 hipError_t launch_acgt_check(const uint8_t* d_text, uint64_t n, uint32_t* d_flag, hipStream_t stream);
@@ -196,6 +197,10 @@ struct sassy_SearcherType {
   bool only_best = false;        // only_best_match(): one match per strand, minimal cost, rightmost end
   float max_n_frac = NAN;        // with_max_n_frac(): NaN = off (the reference's None)
   DevBuf<uint64_t> d_tables;     // multi-text buffers: start / len tables (both strands)
+  DevBuf<unsigned long long> d_multi_bitmap;  // multi-pattern prefilter: one hit bitmap per pattern of the batch
+  DevBuf<uint32_t> d_multi_bits;
+  hipEvent_t ev_multi = nullptr, ev_multi_a = nullptr;
+  hipEvent_t ev_a_multi() { return ev_multi_a; }
   DevBuf<uint64_t> d_range;      // N counting on device-resident text
   DevBuf<uint32_t> d_ncount;
   // HIP-event timing of the call's phases: 0 none, 1 the dominant kernel only (filter / streaming
@@ -205,7 +210,9 @@ struct sassy_SearcherType {
 
   ~sassy_SearcherType() {
     d_text.release(); d_rev.release();
-    d_range.release(); d_ncount.release(); d_tables.release();
+    d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
+    if (ev_multi) (void)hipEventDestroy(ev_multi);
+    if (ev_multi_a) (void)hipEventDestroy(ev_multi_a);
     for (ScanLane& l : lanes) l.destroy();
     if (ev_inputs) (void)hipEventDestroy(ev_inputs);
   }
@@ -224,6 +231,8 @@ struct sassy_SearcherType {
     }
     stream = lanes[0].stream;
     HIP_TRY(hipEventCreateWithFlags(&ev_inputs, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&ev_multi));
+    HIP_TRY(hipEventCreate(&ev_multi_a));
     device_ready = true;
     return 0;
   }
@@ -382,6 +391,11 @@ struct ScanJob {
   bool do_trace;
   uint64_t total_len;
   TextTable texts{};                 // several texts in the buffer (n = 0: one text)
+  // multi-pattern search: the hit bitmap was filled by filter_dna_multi_kernel (piece length ext_q);
+  // this job only waits for it (ext_wait) and runs chunk list -> DP -> rank -> traceback
+  unsigned long long* ext_bitmap = nullptr;
+  uint32_t ext_q = 0;
+  hipEvent_t ext_wait = nullptr;
   hipEvent_t wait_for = nullptr;     // pipelining: the previous sub-shard's "filter done"
   bool signal_filter_done = false;   // pipelining: record L.ev_filter_done behind this filter
 
@@ -464,10 +478,12 @@ int ScanJob::prepare() {
   // a match that hangs over an end of the text contains only part of the pattern: the pigeonhole
   // argument of the prefilter does not cover it, so overhang searches stream the full DP
   if (overhang) q = 0;
+  if (ext_bitmap) q = ext_q;
   filtered = q > 0;
   // which prefilter kernel (SASSY_HIP_FILTER_KIND=1|2|3 forces one where it applies)
   fkind = kFilterGeneric;
-  if (filtered) {
+  if (ext_bitmap) fkind = kFilterPlanes;  // marked like filter_dna_kernel does (end blocks of matches)
+  if (filtered && !ext_bitmap) {
     static const int env_kind = getenv("SASSY_HIP_FILTER_KIND") ? atoi(getenv("SASSY_HIP_FILTER_KIND")) : 0;
     const uint32_t pieces = k + 1;
     const bool can_planes = S->profile == PROFILE_DNA && pieces <= 8;
@@ -535,8 +551,8 @@ int ScanJob::prepare() {
   //   [64, ..)  rank counters of the first kRankLimit reports
   //   [kCtlHead, ..)  the prefilter's hit bitmap (one bit per text block)
   n_words = filtered ? (n_blocks + 63) / 64 : 0;
-  if (int rc = L.d_ctl.reserve(kCtlHead + (filtered ? (n_words + 2) * 8 : 0))) return rc;
-  d_bitmap = reinterpret_cast<unsigned long long*>(L.d_ctl.p + kCtlHead);
+  if (int rc = L.d_ctl.reserve(kCtlHead + (filtered && !ext_bitmap ? (n_words + 2) * 8 : 0))) return rc;
+  d_bitmap = ext_bitmap ? ext_bitmap : reinterpret_cast<unsigned long long*>(L.d_ctl.p + kCtlHead);
   if (L.d_cand.cap == 0)
     if (int rc = L.d_cand.reserve(1u << 16)) return rc;
   d_counts = reinterpret_cast<uint32_t*>(L.d_ctl.p);
@@ -670,8 +686,13 @@ int ScanJob::prepare() {
     if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, 1, &fgrid, fwpc)) return rc;
     F.lds_per_wave = 4096u * F.stage_blocks + (F.piece_planes ? 0u : 2u * bucket * 512u);
     F.hit_bitmap = d_bitmap;
-    if (L.d_desc.cap == 0)
-      if (int rc = L.d_desc.reserve(1u << 18)) return rc;
+    {
+      // room for the expected number of chunks on random text (64 (k+1) / 4^q of the blocks hold a piece
+      // end); a denser text overflows into the grow-and-retry path of finish()
+      double frac = 64.0 * (k + 1.0) / std::pow(4.0, (double)q);
+      const size_t expect = (size_t)std::min<double>(1.5 * frac * (double)n_blocks, (double)n_blocks) + 1024;
+      if (int rc = L.d_desc.reserve(std::max<size_t>(1u << 18, expect))) return rc;
+    }
     P.lds_per_wave = bucket * 512u + plan.nwords * 512u;
     if ((size_t)kWavesPerGroup * P.lds_per_wave > 160 * 1024)
       return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
@@ -700,7 +721,8 @@ int ScanJob::enqueue(int attempt) {
     T.out_str = Tw.out_str = L.d_str.p;
   }
   // control block, rank counters and (first attempt: the filter runs once) the hit bitmap
-  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, kCtlHead + (filtered && attempt == 0 ? (n_words + 2) * 8 : 0), L.stream));
+  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, kCtlHead + (filtered && !ext_bitmap && attempt == 0 ? (n_words + 2) * 8 : 0), L.stream));
+  if (ext_wait && attempt == 0) HIP_TRY(hipStreamWaitEvent(L.stream, ext_wait, 0));
   // pipelined sub-shards: this lane's filter starts when the previous sub-shard's filter is done,
   // so that the previous lane's DP / rank / traceback kernels overlap this bandwidth-bound one
   if (wait_for && attempt == 0) HIP_TRY(hipStreamWaitEvent(L.stream, wait_for, 0));
@@ -710,7 +732,7 @@ int ScanJob::enqueue(int attempt) {
     le = launch_scan_any(S->profile, P, grid, (size_t)kWavesPerGroup * P.lds_per_wave, L.stream);
     if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
   } else {
-    if (attempt == 0) {  // the hit bitmap does not depend on buffer sizes: build it once
+    if (attempt == 0 && !ext_bitmap) {  // the hit bitmap does not depend on buffer sizes: build it once
       le = fkind == kFilterTable
                ? launch_filter_table(F, fgrid, L.stream)
                : launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, L.stream);
@@ -1135,7 +1157,8 @@ struct ScanQueue {
     return first;
   }
   int submit(const PatternPlan& plan, const uint8_t* pat, const ShardView& sh, const TextTable& texts, uint32_t k,
-             bool all_minima, bool do_trace, uint64_t total_len, uint64_t tag) {
+             bool all_minima, bool do_trace, uint64_t total_len, uint64_t tag, unsigned long long* ext_bitmap = nullptr,
+             uint32_t ext_q = 0, hipEvent_t ext_wait = nullptr) {
     if (in_flight == n_lanes)
       if (int rc = drain_one()) return rc;
     if (!inputs_marked) {
@@ -1152,6 +1175,9 @@ struct ScanQueue {
     sl.job.reset(new ScanJob(S, S->lanes[tail], sh, sl.plan, k, all_minima, sl.pat.data(), do_trace, total_len));
     sl.job->texts = texts;
     sl.job->texts.all_minima = all_minima ? 1u : 0u;
+    sl.job->ext_bitmap = ext_bitmap;
+    sl.job->ext_q = ext_q;
+    sl.job->ext_wait = ext_wait;
     sl.busy = true;
     tail = (tail + 1) % n_lanes;
     ++in_flight;
@@ -1983,11 +2009,74 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
       return 0;
     });
     std::string err;
-    for (size_t p = 0; p < e->patterns.size(); ++p) {
-      PatternPlan plan;
-      if (!make_plan(s->profile, e->patterns[p].data(), e->plen, plan, err)) return fail(SASSY_HIP_EINVAL, err);
-      ShardView sh{tptr, text_len, 0, 0, true, true};
-      if (int rc = queue.submit(plan, e->patterns[p].data(), sh, TextTable{}, (uint32_t)k, all, !wo, text_len, p)) return rc;
+    // Many Dna patterns over a long text: one multi-pattern prefilter pass per batch of patterns
+    // (filter_dna_multi_kernel), then chunk list -> DP -> rank -> traceback per pattern.
+    const uint64_t multi_min = getenv("SASSY_HIP_MULTI_MIN_TEXT") ? strtoull(getenv("SASSY_HIP_MULTI_MIN_TEXT"), nullptr, 10)
+                                                                   : (16ull << 20);
+    const uint32_t mq = (uint32_t)std::min<size_t>(e->plen / (k + 1), 12);
+    const bool multi = s->profile == PROFILE_DNA && std::isnan(s->alpha) && e->patterns.size() >= 8 && k + 1 <= 8 &&
+                       mq >= 6 && text_len >= multi_min && (((uintptr_t)tptr) & 15) == 0;
+    const size_t batch = multi ? 64 : 1;
+    for (size_t p0 = 0; p0 < e->patterns.size(); p0 += batch) {
+      const size_t nb = std::min(batch, e->patterns.size() - p0);
+      unsigned long long* bm_base = nullptr;
+      uint64_t bm_stride = 0;
+      if (multi) {
+        const uint64_t n_blocks = (text_len + 63) / 64;
+        bm_stride = ((n_blocks + 63) / 64 + 2 + 7) / 8 * 8;
+        if (int rc = s->d_multi_bitmap.reserve(nb * bm_stride)) return rc;
+        if (int rc = s->d_multi_bits.reserve(16 * nb)) return rc;
+        bm_base = s->d_multi_bitmap.p;
+        std::vector<uint32_t> bits(16 * nb, 0u);
+        for (size_t i = 0; i < nb; ++i) {
+          const uint8_t* pt = e->patterns[p0 + i].data();
+          for (uint32_t pp = 0; pp < k + 1; ++pp)
+            for (uint32_t j = 0; j < mq; ++j) {
+              const uint32_t code = (pt[pp * mq + j] >> 1) & 3u;  // src/profiles/dna.rs:19-40
+              bits[16 * i + 2 * pp] |= (code & 1u) << j;
+              bits[16 * i + 2 * pp + 1] |= (code >> 1) << j;
+            }
+        }
+        ScanParams F{};
+        F.text = tptr;
+        F.text_len = text_len;
+        F.n_blocks = n_blocks;
+        F.first_owned_block = 0;
+        F.m = (uint32_t)e->plen;
+        F.k = (uint32_t)k;
+        F.n_pieces = (uint32_t)k + 1;
+        F.piece_len = mq;
+        for (uint32_t pp = 0; pp < 8; ++pp) F.piece_rem[pp] = (uint32_t)e->plen - (std::min<uint32_t>(pp, (uint32_t)k) + 1) * mq;
+        F.stage_blocks = 2;
+        F.lds_per_wave = 4096u * 2;
+        F.hit_bitmap = bm_base;
+        F.multi_bits = s->d_multi_bits.p;
+        F.multi_n = (uint32_t)nb;
+        F.multi_stride = bm_stride;
+        uint32_t fgrid = 0;
+        // register-heavy kernel (two blocks of shifted planes): 3 resident waves per SIMD up to q = 8, 2 above
+        if (int rc = stream_geometry(F, n_blocks, 1, &fgrid, mq <= 8 ? 12 : 8)) return rc;
+        HIP_TRY(hipMemsetAsync(bm_base, 0, nb * bm_stride * 8, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->d_multi_bits.p, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipEventRecord(s->ev_a_multi(), s->stream));
+        hipError_t le = launch_filter_dna_multi(F, fgrid, s->stream);
+        if (le != hipSuccess) return hip_fail(le, "multi-pattern filter launch");
+        HIP_TRY(hipEventRecord(s->ev_multi, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));  // `bits` must outlive the upload; also times the pass
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
+        s->stats.filter_ms += ms;
+      }
+      for (size_t i = 0; i < nb; ++i) {
+        const size_t p = p0 + i;
+        PatternPlan plan;
+        if (!make_plan(s->profile, e->patterns[p].data(), e->plen, plan, err)) return fail(SASSY_HIP_EINVAL, err);
+        ShardView sh{tptr, text_len, 0, 0, true, true};
+        if (int rc = queue.submit(plan, e->patterns[p].data(), sh, TextTable{}, (uint32_t)k, all, !wo, text_len, p,
+                                  multi ? bm_base + i * bm_stride : nullptr, multi ? mq : 0, nullptr)) return rc;
+      }
+      if (multi)  // the bitmaps are reused by the next batch
+        if (int rc = queue.drain_all()) return rc;
     }
     if (int rc = queue.drain_all()) return rc;
   }

@@ -885,6 +885,163 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
   }
 }
 
+// ====================================================================== K0 for many Dna patterns
+// search_encoded_patterns with thousands of equal-length patterns (CRISPR guides): the text bytes,
+// the two code bit planes and their q shifted copies are the same for every pattern, only the
+// scalar piece bits differ.  So one pass over the text evaluates a whole batch of patterns: per
+// block the planes and shifts are built once (kept in registers), then every pattern costs
+// (k+1) * q * 4 v_bitop3 -- about 90 VALU for 20-mers at k = 2 against 800 for a full DP pass --
+// and marks, in its own bitmap, the blocks a match around a piece occurrence can end in (as
+// filter_dna_kernel does).  The chunk list / DP / rank / traceback stages then run per pattern.
+// Q: piece length (compile time: the shifts, the bit positions of the piece rows and the unrolling
+// depend on it); up to 8 pieces per pattern.
+template <int SB, int Q>
+__global__ __launch_bounds__(256) void filter_dna_multi_kernel(const ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr uint32_t kRowBytes = 64u * SB;
+  constexpr uint32_t kSlots = 4u * SB;
+  constexpr uint32_t kOwnersPerInstr = 64u / kSlots;
+  constexpr int kStageInstr = 4 * SB;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  unsigned char* tile = smem + (size_t)wave * P.lds_per_wave;
+
+  const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * kWavesPerGroup + wave) * kWave;
+  if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
+  const uint64_t chunk = wave_chunk0 + lane;
+  const uint32_t bpl = P.bpl;
+  const uint64_t first_owned = P.first_owned_block;
+  const uint32_t back = 1u + (uint32_t)((first_owned + 1u) & 1u);
+  const uint64_t own_lo = first_owned + chunk * (uint64_t)bpl;
+  uint64_t own_hi = own_lo + bpl;
+  if (own_hi > P.n_blocks) own_hi = P.n_blocks;
+  const bool has_chunk = chunk < P.n_chunks && own_lo < P.n_blocks;
+  const uint64_t blk0 = chunk_blk0(first_owned, bpl, back, chunk);
+  const uint64_t wave_blk0 = chunk_blk0(first_owned, bpl, back, wave_chunk0);
+  const uint8_t* text_base = P.text + wave_blk0 * 64;
+  uint32_t soff[kStageInstr];
+#pragma unroll
+  for (int i = 0; i < kStageInstr; ++i) {
+    const uint32_t owner = (uint32_t)i * kOwnersPerInstr + lane / kSlots;
+    const uint32_t slot = lane % kSlots;
+    const uint32_t j = slot ^ (SB == 2 ? ((owner >> 1) & 7u) : ((owner >> 2) & 3u));
+    soff[i] = (uint32_t)((chunk_blk0(first_owned, bpl, back, wave_chunk0 + owner) - wave_blk0) * 64) + j * 16u;
+  }
+  const uint64_t wave_last = chunk_blk0(first_owned, bpl, back, wave_chunk0 + 63) + P.n_iter + 2;
+  const bool interior = wave_last * 64 <= P.text_len;
+  const uint32_t fsw = SB == 2 ? ((lane >> 1) & 7u) : ((lane >> 2) & 3u);
+  uint32_t rc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rc[c] = lane * kRowBytes + (((uint32_t)c ^ (fsw & 3u)) << 4);
+
+  const uint32_t n_pieces = P.n_pieces;
+  const_u32_ptr bits = (const_u32_ptr)(P.multi_bits);
+  uint32_t prev0 = 0, prev1 = 0;
+
+  // Two blocks per lane and iteration (the staged pair): the scalar work per piece row -- turning a
+  // pattern bit into a 0 / ~0 word -- is shared by both, which keeps the loop VALU-bound.
+  for (uint32_t it = 0; it < P.n_iter; it += 2) {
+#pragma unroll
+    for (int i = 0; i < kStageInstr; ++i) {
+      const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
+      uint4 v;
+      if (interior) v = *reinterpret_cast<const uint4*>(text_base + (uint64_t)it * 64 + soff[i]);
+      else if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
+      else v = load_tail16(P.text, off, P.text_len);
+      *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+    }
+    // planes of the two blocks, shifted by d = 0 .. Q-1 with the previous block's bits shifted in
+    uint32_t sl[2][2][Q], sh[2][2][Q];  // [block][plane][d]
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const uint32_t hs = (((uint32_t)blk << 2) ^ (fsw & 4u)) << 4;
+      uint32_t x[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + rc[c] + hs);
+        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+      }
+      const uint2 t0 = bit_plane<1>(x), t1 = bit_plane<2>(x);
+      sl[blk][0][0] = t0.x; sh[blk][0][0] = t0.y; sl[blk][1][0] = t1.x; sh[blk][1][0] = t1.y;
+#pragma unroll
+      for (int d = 1; d < Q; ++d) {
+        sl[blk][0][d] = __builtin_amdgcn_alignbit(t0.x, prev0, 32 - d);
+        sh[blk][0][d] = __builtin_amdgcn_alignbit(t0.y, t0.x, 32 - d);
+        sl[blk][1][d] = __builtin_amdgcn_alignbit(t1.x, prev1, 32 - d);
+        sh[blk][1][d] = __builtin_amdgcn_alignbit(t1.y, t1.x, 32 - d);
+      }
+      prev0 = t0.y;
+      prev1 = t1.y;
+    }
+    const uint64_t b0 = blk0 + it;
+    const bool eval0 = has_chunk && b0 >= own_lo && b0 < own_hi;
+    const bool eval1 = has_chunk && it + 1 < P.n_iter && b0 + 1 >= own_lo && b0 + 1 < own_hi;
+
+    // the 16 piece words of a pattern arrive with one scalar load, fetched one pattern ahead
+    uint32_t wn[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wn[i] = bits[i];
+    for (uint32_t p = 0; p < P.multi_n; ++p) {
+      uint32_t w[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) w[i] = wn[i];
+      const uint32_t pn = p + 1 < P.multi_n ? p + 1 : p;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) wn[i] = bits[16 * pn + i];
+      uint32_t marks = 0;
+#pragma unroll
+      for (int pp = 0; pp < 8; ++pp) {
+        if ((uint32_t)pp < n_pieces) {  // wave-uniform
+          const int32_t nb0 = (int32_t)~w[2 * pp], nb1 = (int32_t)~w[2 * pp + 1];
+          uint32_t al0 = 0xFFFFFFFFu, ah0 = 0xFFFFFFFFu, al1 = 0xFFFFFFFFu, ah1 = 0xFFFFFFFFu;
+#pragma unroll
+          for (int d = 0; d < Q; ++d) {
+            const uint32_t n0s = (uint32_t)__builtin_amdgcn_sbfe(nb0, Q - 1 - d, 1);  // 0 or ~0 (uniform)
+            const uint32_t n1s = (uint32_t)__builtin_amdgcn_sbfe(nb1, Q - 1 - d, 1);
+            // into vector registers once: v_bitop3 with a scalar source operand issues at half rate
+            uint32_t n0, n1;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(n0) : "s"(n0s));
+            asm volatile("v_mov_b32 %0, %1" : "=v"(n1) : "s"(n1s));
+            al0 = bitop3<0x60>(al0, sl[0][0][d], n0);
+            ah0 = bitop3<0x60>(ah0, sh[0][0][d], n0);
+            al1 = bitop3<0x60>(al1, sl[1][0][d], n0);
+            ah1 = bitop3<0x60>(ah1, sh[1][0][d], n0);
+            al0 = bitop3<0x60>(al0, sl[0][1][d], n1);
+            ah0 = bitop3<0x60>(ah0, sh[0][1][d], n1);
+            al1 = bitop3<0x60>(al1, sl[1][1][d], n1);
+            ah1 = bitop3<0x60>(ah1, sh[1][1][d], n1);
+          }
+          // Rare per lane, but some lane of the wave hits almost every time: keep this path short.
+          // The blocks a match around the occurrence can end in (as in filter_dna_kernel), relative
+          // to the lane's block pair, collected over the pieces and marked once per pattern.
+          const int rem = (int)P.piece_rem[pp], kk = (int)P.k;
+          if (eval0 && (al0 | ah0) != 0) {
+            const uint64_t hb = ((uint64_t)ah0 << 32) | al0;
+            const int r_lo = (__ffsll((long long)hb) + rem - kk - 1) >> 6;          // -1 .. 1
+            const int r_hi = (64 - __clzll((long long)hb) + rem + kk) >> 6;         //  0 .. 2
+            marks |= ((2u << (r_hi + 1)) - 1u) & ~((1u << (r_lo + 1)) - 1u);        // bit r+1: block b0 + r
+          }
+          if (eval1 && (al1 | ah1) != 0) {
+            const uint64_t hb = ((uint64_t)ah1 << 32) | al1;
+            const int r_lo = (__ffsll((long long)hb) + rem - kk - 1) >> 6;
+            const int r_hi = (64 - __clzll((long long)hb) + rem + kk) >> 6;
+            marks |= (((2u << (r_hi + 1)) - 1u) & ~((1u << (r_lo + 1)) - 1u)) << 1;  // relative to b0 + 1
+          }
+        }
+      }
+      if (marks) {
+        unsigned long long* bm = P.hit_bitmap + (uint64_t)p * P.multi_stride;
+        while (marks) {
+          const int t = __ffs((int)marks) - 1;
+          marks &= marks - 1u;
+          const int64_t blk = (int64_t)b0 - 1 + t;
+          if (blk >= 0 && (uint64_t)blk < P.n_blocks) atomicOr(&bm[blk >> 6], 1ull << (blk & 63));
+        }
+      }
+    }
+  }
+}
+
 // ====================================================================== K0 with a q-gram table
 // Many pieces (k+1 > 8), or Iupac patterns: instead of evaluating every piece, every text position
 // looks its q-gram up in a bit table of all 4^Q q-grams that some piece accepts (built on the host;
@@ -1209,6 +1366,24 @@ static hipError_t launch_filter_table_q(const ScanParams& P, uint32_t grid, hipS
   const size_t smem = (1u << (2 * Q - 3)) + 4 * 4096u;
   hipLaunchKernelGGL((filter_table_kernel<Q>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
+}
+template <int Q>
+static hipError_t launch_filter_dna_multi_q(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  hipLaunchKernelGGL((filter_dna_multi_kernel<2, Q>), dim3(grid), dim3(256), (size_t)kWavesPerGroup * P.lds_per_wave, stream, P);
+  return hipGetLastError();
+}
+// piece lengths 6 .. 12 (stage_blocks = 2)
+hipError_t launch_filter_dna_multi(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  switch (P.piece_len) {
+    case 6: return launch_filter_dna_multi_q<6>(P, grid, stream);
+    case 7: return launch_filter_dna_multi_q<7>(P, grid, stream);
+    case 8: return launch_filter_dna_multi_q<8>(P, grid, stream);
+    case 9: return launch_filter_dna_multi_q<9>(P, grid, stream);
+    case 10: return launch_filter_dna_multi_q<10>(P, grid, stream);
+    case 11: return launch_filter_dna_multi_q<11>(P, grid, stream);
+    case 12: return launch_filter_dna_multi_q<12>(P, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 // the q-gram table filter is profile-independent code: it lives in the Dna translation unit
 hipError_t launch_filter_table(const ScanParams& P, uint32_t grid, hipStream_t stream) {

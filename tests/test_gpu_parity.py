@@ -574,10 +574,17 @@ def test_encoded_many_patterns(sassy):
     """search_encoded_patterns with many plain-ACGT patterns on an Iupac searcher (BASELINE config 4
     shape): on plain-ACGT text the scans run with the Dna kernels, on text with other letters with the
     Iupac kernels -- both must equal the oracle's search_encoded."""
+    import os
     rng = random.Random(45)
     pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(12)]
-    for variant in ("plain", "lower", "with_n"):
-        n = 30_000 + (7 if variant == "lower" else 0)  # also a length that is not a multiple of 16
+    for variant in ("plain", "lower", "with_n", "plain_multi", "lower_multi"):
+        # *_multi: force the multi-pattern prefilter (one filter_dna_multi_kernel pass per batch of
+        # patterns) that long texts get by default
+        if variant.endswith("_multi"):
+            os.environ["SASSY_HIP_MULTI_MIN_TEXT"] = "1"
+        else:
+            os.environ.pop("SASSY_HIP_MULTI_MIN_TEXT", None)
+        n = 30_000 + (7 if variant.startswith("lower") else 0)  # also a length that is not a multiple of 16
         text = bytearray(rng.choice(b"ACGT") for _ in range(n))
         for p in pats:
             for _ in range(2):
@@ -586,7 +593,7 @@ def test_encoded_many_patterns(sassy):
                     ins = oracle.reverse_complement("iupac", ins)
                 at = rng.randrange(0, n - len(ins))
                 text[at:at + len(ins)] = ins
-        if variant == "lower":
+        if variant.startswith("lower"):
             for _ in range(300):
                 i = rng.randrange(n); text[i] = text[i] | 0x20
         if variant == "with_n":
@@ -601,9 +608,11 @@ def test_encoded_many_patterns(sassy):
             want = oracle.search_encoded("iupac", pats, tb, 2, rc=rc)
             assert len(want) >= 6
             assert sorted(key(m) for m in got) == sorted(key(m) for m in want), (variant, rc)
-            import os
-            if not os.environ.get("SASSY_HIP_PREFILTER"):
+            if variant.endswith("_multi"):
+                assert s.stats()["filtered"] == 2  # chunk lists from the multi-pattern prefilter's bitmaps
+            elif not os.environ.get("SASSY_HIP_PREFILTER"):
                 assert s.stats()["filtered"] == 0  # 20-mers at k=2: pieces too short, streaming DP
+    os.environ.pop("SASSY_HIP_MULTI_MIN_TEXT", None)
 
 
 def test_pack_result_for_gather(sassy):
