@@ -103,6 +103,8 @@ struct ScanParams {
   // hit_bitmap + p * multi_stride (64-bit words)
   const uint32_t* multi_bits;
   uint32_t multi_n;
+  uint32_t multi_long;        // bit p: piece p has piece_len + 1 rows (the pattern's m mod (k+1) spare rows
+                              // lengthen the first pieces: fewer chance hits at no loss of exactness)
   uint64_t multi_stride;
   // q-gram table filter: 4^piece_len bits, byte = code & (2^(2q-3)-1), bit = code >> (2q-3)
   const uint8_t* qgram_table; // device; null unless the table filter is used

@@ -2027,14 +2027,25 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
         if (int rc = s->d_multi_bitmap.reserve(nb * bm_stride)) return rc;
         if (int rc = s->d_multi_bits.reserve(16 * nb)) return rc;
         bm_base = s->d_multi_bitmap.p;
+        // piece p covers rows [start, start + len): len = q + 1 for the first m mod (k+1) pieces (the spare
+        // rows make those pieces more selective), q otherwise; bit d of a piece word = code bit of the
+        // row at distance d from the piece's end
+        const uint32_t spare = (uint32_t)(e->plen - (size_t)mq * (k + 1));
+        uint32_t p_start[8], p_len[8], long_mask = 0;
+        for (uint32_t pp = 0; pp < 8; ++pp) {
+          const uint32_t pc = std::min<uint32_t>(pp, (uint32_t)k);
+          p_len[pp] = mq + (pc < spare ? 1u : 0u);
+          p_start[pp] = pc * mq + std::min(pc, spare);
+          if (pp <= k && pc < spare) long_mask |= 1u << pp;
+        }
         std::vector<uint32_t> bits(16 * nb, 0u);
         for (size_t i = 0; i < nb; ++i) {
           const uint8_t* pt = e->patterns[p0 + i].data();
           for (uint32_t pp = 0; pp < k + 1; ++pp)
-            for (uint32_t j = 0; j < mq; ++j) {
-              const uint32_t code = (pt[pp * mq + j] >> 1) & 3u;  // src/profiles/dna.rs:19-40
-              bits[16 * i + 2 * pp] |= (code & 1u) << j;
-              bits[16 * i + 2 * pp + 1] |= (code >> 1) << j;
+            for (uint32_t d = 0; d < p_len[pp]; ++d) {
+              const uint32_t code = (pt[p_start[pp] + p_len[pp] - 1 - d] >> 1) & 3u;  // src/profiles/dna.rs:19-40
+              bits[16 * i + 2 * pp] |= (code & 1u) << d;
+              bits[16 * i + 2 * pp + 1] |= (code >> 1) << d;
             }
         }
         ScanParams F{};
@@ -2046,7 +2057,8 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
         F.k = (uint32_t)k;
         F.n_pieces = (uint32_t)k + 1;
         F.piece_len = mq;
-        for (uint32_t pp = 0; pp < 8; ++pp) F.piece_rem[pp] = (uint32_t)e->plen - (std::min<uint32_t>(pp, (uint32_t)k) + 1) * mq;
+        for (uint32_t pp = 0; pp < 8; ++pp) F.piece_rem[pp] = (uint32_t)e->plen - (p_start[pp] + p_len[pp]);
+        F.multi_long = long_mask;
         F.stage_blocks = 2;
         F.lds_per_wave = 4096u * 2;
         F.hit_bitmap = bm_base;

@@ -951,7 +951,7 @@ __global__ __launch_bounds__(256) void filter_dna_multi_kernel(const ScanParams 
       *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
     }
     // planes of the two blocks, shifted by d = 0 .. Q-1 with the previous block's bits shifted in
-    uint32_t sl[2][2][Q], sh[2][2][Q];  // [block][plane][d]
+    uint32_t sl[2][2][Q + 1], sh[2][2][Q + 1];  // [block][plane][d]; d = Q only for the long pieces
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       const uint32_t hs = (((uint32_t)blk << 2) ^ (fsw & 4u)) << 4;
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(256) void filter_dna_multi_kernel(const ScanParams 
       const uint2 t0 = bit_plane<1>(x), t1 = bit_plane<2>(x);
       sl[blk][0][0] = t0.x; sh[blk][0][0] = t0.y; sl[blk][1][0] = t1.x; sh[blk][1][0] = t1.y;
 #pragma unroll
-      for (int d = 1; d < Q; ++d) {
+      for (int d = 1; d <= Q; ++d) {
         sl[blk][0][d] = __builtin_amdgcn_alignbit(t0.x, prev0, 32 - d);
         sh[blk][0][d] = __builtin_amdgcn_alignbit(t0.y, t0.x, 32 - d);
         sl[blk][1][d] = __builtin_amdgcn_alignbit(t1.x, prev1, 32 - d);
@@ -994,22 +994,26 @@ __global__ __launch_bounds__(256) void filter_dna_multi_kernel(const ScanParams 
         if ((uint32_t)pp < n_pieces) {  // wave-uniform
           const int32_t nb0 = (int32_t)~w[2 * pp], nb1 = (int32_t)~w[2 * pp + 1];
           uint32_t al0 = 0xFFFFFFFFu, ah0 = 0xFFFFFFFFu, al1 = 0xFFFFFFFFu, ah1 = 0xFFFFFFFFu;
+          // the piece words hold the row at distance d from the piece's end at bit d
+          const bool is_long = (P.multi_long >> pp) & 1u;  // wave-uniform
 #pragma unroll
-          for (int d = 0; d < Q; ++d) {
-            const uint32_t n0s = (uint32_t)__builtin_amdgcn_sbfe(nb0, Q - 1 - d, 1);  // 0 or ~0 (uniform)
-            const uint32_t n1s = (uint32_t)__builtin_amdgcn_sbfe(nb1, Q - 1 - d, 1);
-            // into vector registers once: v_bitop3 with a scalar source operand issues at half rate
-            uint32_t n0, n1;
-            asm volatile("v_mov_b32 %0, %1" : "=v"(n0) : "s"(n0s));
-            asm volatile("v_mov_b32 %0, %1" : "=v"(n1) : "s"(n1s));
-            al0 = bitop3<0x60>(al0, sl[0][0][d], n0);
-            ah0 = bitop3<0x60>(ah0, sh[0][0][d], n0);
-            al1 = bitop3<0x60>(al1, sl[1][0][d], n0);
-            ah1 = bitop3<0x60>(ah1, sh[1][0][d], n0);
-            al0 = bitop3<0x60>(al0, sl[0][1][d], n1);
-            ah0 = bitop3<0x60>(ah0, sh[0][1][d], n1);
-            al1 = bitop3<0x60>(al1, sl[1][1][d], n1);
-            ah1 = bitop3<0x60>(ah1, sh[1][1][d], n1);
+          for (int d = 0; d <= Q; ++d) {
+            if (d < Q || is_long) {  // wave-uniform
+              const uint32_t n0s = (uint32_t)__builtin_amdgcn_sbfe(nb0, d, 1);  // 0 or ~0 (uniform)
+              const uint32_t n1s = (uint32_t)__builtin_amdgcn_sbfe(nb1, d, 1);
+              // into vector registers once: v_bitop3 with a scalar source operand issues at half rate
+              uint32_t n0, n1;
+              asm volatile("v_mov_b32 %0, %1" : "=v"(n0) : "s"(n0s));
+              asm volatile("v_mov_b32 %0, %1" : "=v"(n1) : "s"(n1s));
+              al0 = bitop3<0x60>(al0, sl[0][0][d], n0);
+              ah0 = bitop3<0x60>(ah0, sh[0][0][d], n0);
+              al1 = bitop3<0x60>(al1, sl[1][0][d], n0);
+              ah1 = bitop3<0x60>(ah1, sh[1][0][d], n0);
+              al0 = bitop3<0x60>(al0, sl[0][1][d], n1);
+              ah0 = bitop3<0x60>(ah0, sh[0][1][d], n1);
+              al1 = bitop3<0x60>(al1, sl[1][1][d], n1);
+              ah1 = bitop3<0x60>(ah1, sh[1][1][d], n1);
+            }
           }
           // Rare per lane, but some lane of the wave hits almost every time: keep this path short.
           // The blocks a match around the occurrence can end in (as in filter_dna_kernel), relative
