@@ -153,7 +153,7 @@ def main():
     buf = torch.empty(halo + n_per + 4096, dtype=torch.uint8, device=device)
     sassy_amd.generate_dna(buf.data_ptr(), halo + n_per, seed_text, a - halo)
     planted = sassy_amd.plant(buf.data_ptr(), halo + n_per, a - halo, total, seed_text,
-                              bytes(c if c in b"ACGT" else 65 for c in pat), k, args.plant_stride)
+                              bytes({ord("Y"): 67}.get(c, c if c in b"ACGT" else 65) for c in pat), k, args.plant_stride)
     torch.cuda.synchronize()
     searcher = sassy_amd.Searcher(args.profile, rc=False)
 

@@ -801,3 +801,57 @@ def test_full_size_3gb_properties(sassy):
     st = s.stats()
     assert st["scan_launches"] in (1, 2, 3, 4) and st["text_bytes"] == n  # one launch per sub-shard lane
     buf.free()
+
+
+def test_full_size_configs_3_and_4_properties(sassy):
+    """BASELINE configs 3 and 4 at full text size (3 GB).  Config 3 (Iupac, |P|=200 with N/R/Y/W, k=20):
+    every plant found at its place, sorted, and a 1 MiB slice equal to the oracle.  Config 4 shape
+    (search_encoded_patterns, 20-mers, k=2, 16 patterns through the multi-pattern prefilter): per
+    pattern the same matches as a plain single-pattern search of the same text."""
+    n = 3_000_000_000
+    try:
+        buf = sassy.DeviceBuffer(n + 4096)
+    except sassy.SassyHipError:
+        pytest.skip("cannot allocate 3 GB on this device")
+    sassy.generate_dna(buf.ptr, n, 42, 0)
+    # ---- config 4 shape first (plain random text) ----
+    rng = random.Random(45)
+    pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(16)]
+    s = sassy.Searcher("iupac", rc=False)
+    enc = s.encode_patterns(pats)
+    got = s.search_encoded_patterns(enc, _DevText(buf.ptr, n), 2)
+    assert s.stats()["filtered"] == 2 and s.stats()["scan_launches"] == 16
+    assert len(got) > 100
+    single = sassy.Searcher("dna", rc=False)
+    for pi in (0, 7, 15):
+        want = single._search(pats[pi], _DevText(buf.ptr, n), 2, sassy.TEXT_ON_DEVICE).matches
+        mine = [m for m in got if m.pattern_idx == pi]
+        assert sorted((m.text_start, m.text_end, m.cost, m.cigar) for m in mine) == \
+               sorted((m.text_start, m.text_end, m.cost, m.cigar) for m in want)
+    # ---- config 3 ----
+    p = bytearray(oracle.generate_dna(44, 0, 200).tobytes())
+    p[50], p[100], p[150], p[199] = ord("N"), ord("R"), ord("Y"), ord("W")
+    pat = bytes(p)
+    # the planted copies spell the ambiguity letters with a base they contain (N, R, W -> A; Y -> C)
+    plain = bytes({ord("N"): 65, ord("R"): 65, ord("W"): 65, ord("Y"): 67}.get(c, c) for c in pat)
+    planted = sassy.plant(buf.ptr, n, 0, n, 42, plain, 20, stride=1 << 20)
+    s = sassy.Searcher("iupac", rc=False)
+    got = s._search(pat, _DevText(buf.ptr, n), 20, sassy.TEXT_ON_DEVICE).matches
+    assert s.stats()["filtered"] == 3
+    assert planted <= len(got) <= planted + planted // 5
+    seen = set()
+    for m in got:
+        q = m.text_start >> 20
+        assert abs(m.text_start - (q * (1 << 20) + (1 << 19))) <= 40, m
+        assert m.cost <= 20
+        seen.add(q)
+    assert len(seen) == planted
+    assert [m.text_end for m in got] == sorted(m.text_end for m in got)
+    off = 2_000_000_000 - 4096
+    sl = buf.download(1 << 20, off)
+    want = oracle.search("iupac", pat, sl, 20)
+    sub = [m for m in got if off + 256 <= m.text_start and m.text_end <= off + (1 << 20)]
+    assert [(m.text_start - off, m.text_end - off, m.cost, m.cigar) for m in sub] == \
+           [(m.text_start, m.text_end, m.cost, m.cigar) for m in want if m.text_start >= 256]
+    buf.free()
+
