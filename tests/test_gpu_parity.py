@@ -704,6 +704,18 @@ def test_device_resident_search_and_shards(sassy):
     s = sassy.Searcher("dna", rc=False)
     got = s._search(pat, _DevText(buf.ptr, n), 3, sassy.TEXT_ON_DEVICE).matches
     assert_same(got, want)
+    # both strands, search_all and without_trace on the resident text (reverse_kernel on the device)
+    both = sassy.Searcher("dna", rc=True)
+    rcpat = oracle.reverse_complement("dna", pat)  # its Rc strand finds the planted copies
+    assert_same(both._search(rcpat, _DevText(buf.ptr, n), 3, sassy.TEXT_ON_DEVICE).matches,
+                oracle.search("dna", rcpat, host, 3, rc=True))
+    assert_same(both._search(rcpat, _DevText(buf.ptr, n), 2, sassy.TEXT_ON_DEVICE | sassy.ALL_MINIMA).matches,
+                oracle.search("dna", rcpat, host, 2, rc=True, all_minima=True))
+    wo = both._search(rcpat, _DevText(buf.ptr, n), 3, sassy.TEXT_ON_DEVICE | sassy.WITHOUT_TRACE).matches
+    ref = oracle.search("dna", rcpat, host, 3, rc=True)
+    # without_trace (src/search.rs:1464-1475, :868-873): Fwd keeps text_end, Rc keeps text_start
+    assert [(m.text_end if m.strand == "+" else m.text_start, m.cost, m.strand) for m in wo] == \
+           [(m.text_end if m.strand == "+" else m.text_start, m.cost, m.strand) for m in ref]
     halo = sassy.required_halo(len(pat), 3)
     bounds = [0, 1 << 20, (1 << 21) + 64 * 777, n]
     allm = []
