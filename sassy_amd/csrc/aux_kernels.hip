@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const Candidate* __re
   if (c >= count) return;
   const uint32_t r = count > kRankLimit ? c : rank[c];
   Candidate v = cand[c];
-  if (texts.n) {
+  if (texts.n && !texts.per_text) {
     const uint32_t t = text_of(texts, v.pos);
     const uint64_t te = texts.start[t] + texts.len[t];
     v.flags = (v.flags & 0xFFu) | (t << kCandTextShift);
@@ -283,6 +283,20 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const Candidate* __re
   }
   sorted[r] = v;
   if (r < host_cap) host_sorted[r] = v;
+}
+
+// ------------------------------------------------------------------ per-text reversal
+// Block-aligned multi-text buffer (per-text mode): every text reversed inside its own slot, the
+// padding behind it kept in place.  blk2text maps each 64-byte block to the text it belongs to.
+__global__ __launch_bounds__(256) void reverse_texts_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
+                                                            uint64_t n, const uint32_t* __restrict__ blk2text,
+                                                            const uint64_t* __restrict__ start,
+                                                            const uint64_t* __restrict__ len, uint32_t pad) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t t = blk2text[i >> 6];
+    const uint64_t off = i - start[t];
+    dst[i] = off < len[t] ? src[start[t] + len[t] - 1 - off] : (uint8_t)pad;
+  }
 }
 
 // ------------------------------------------------------------------ "is the text plain ACGT?"
@@ -326,6 +340,13 @@ __global__ __launch_bounds__(256) void count_n_kernel(const uint8_t* __restrict_
 }
 
 // ------------------------------------------------------------------ launchers
+hipError_t launch_reverse_texts(const uint8_t* d_src, uint8_t* d_dst, uint64_t n, const uint32_t* d_blk2text,
+                                const uint64_t* d_start, const uint64_t* d_len, uint32_t pad, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(reverse_texts_kernel, dim3(8192), dim3(256), 0, stream, d_src, d_dst, n, d_blk2text, d_start, d_len, pad);
+  return hipGetLastError();
+}
+
 hipError_t launch_acgt_check(const uint8_t* d_text, uint64_t n, uint32_t* d_flag, hipStream_t stream) {
   const uint64_t n16 = n / 16;
   hipLaunchKernelGGL(acgt_check_kernel, dim3(4096), dim3(256), 0, stream, reinterpret_cast<const uint4*>(d_text), n16,

@@ -31,12 +31,16 @@ struct TextTable {
   const uint64_t* len;    // device, n entries
   uint32_t n;             // 0 = the buffer is a single text
   uint32_t all_minima;    // search_all: reports inside a separator are dropped (else: moved to the text end)
+  uint32_t per_text;      // 1: block-aligned texts scanned one lane per text -- the reports already carry
+                          // their text index and lie where they belong (nothing to look up or move)
 };
 // chunk exit states
 constexpr uint8_t kStateDecFalse = 0, kStateDecTrue = 1, kStatePass = 2;
 
 // chunk descriptor flags (list mode)
 constexpr uint32_t kDescClearBefore = 1u;  // the block left of own_lo holds no cell <= k
+constexpr uint32_t kDescWholeText = 2u;    // per-text mode: the chunk is one whole text (index in pad_), which
+                                           // starts at block own_lo: exact start, own end-of-text rule
 
 // A chunk of consecutive text blocks handed to one lane of the list-mode DP kernel.  16 bytes.
 struct ChunkDesc {
@@ -50,6 +54,8 @@ struct ChunkDesc {
 constexpr uint32_t kScanAllMinima = 1u;  // report every end position with cost <= k
 constexpr uint32_t kScanTextStart = 2u;  // buffer byte 0 is the true start of the text (column 0)
 constexpr uint32_t kScanTextEnd = 4u;    // buffer end is the true end of the text
+constexpr uint32_t kScanPerText = 16u;   // list mode over whole texts: one lane per text of a block-aligned
+                                         // multi-text buffer (ScanParams::texts), no prefilter
 constexpr uint32_t kScanOverhang = 8u;   // overhang (alpha): special left edge at the text start, virtual
                                          // 'N' columns and an extra cost past the text end
 
@@ -119,6 +125,9 @@ struct ScanParams {
                               // (row r of word w at bit 31-r, like the carries)
   float alpha;                // cost per overhanging pattern character
   uint32_t ov_steps;          // virtual 'N' columns behind the text end (0 unless kScanTextEnd)
+  // ---- per-text mode (kScanPerText): where the texts lie in the buffer ----
+  const uint64_t* texts_start;  // device: first byte of text t (a multiple of 64)
+  const uint64_t* texts_len;    // device: its length
 };
 
 // A finished match record as the trace kernel writes it; same layout as sassy_hip_Match

@@ -35,6 +35,8 @@ hipError_t launch_filter_dna_multi(const ScanParams& P, uint32_t grid, hipStream
 hipError_t launch_count_n(const uint8_t* d_text, const uint64_t* d_range, uint32_t n, uint32_t* d_count,
                           hipStream_t stream);
 hipError_t launch_acgt_check(const uint8_t* d_text, uint64_t n, uint32_t* d_flag, hipStream_t stream);
+hipError_t launch_reverse_texts(const uint8_t* d_src, uint8_t* d_dst, uint64_t n, const uint32_t* d_blk2text,
+                                const uint64_t* d_start, const uint64_t* d_len, uint32_t pad, hipStream_t stream);
 hipError_t launch_filter_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_filter_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_list_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
@@ -396,6 +398,10 @@ struct ScanJob {
   unsigned long long* ext_bitmap = nullptr;
   uint32_t ext_q = 0;
   hipEvent_t ext_wait = nullptr;
+  // per-text mode: the chunk descriptors come from the caller (one per text of a block-aligned
+  // multi-text buffer); no prefilter, no chunk builder -- list DP -> rank -> traceback
+  const ChunkDesc* ext_desc = nullptr;
+  uint32_t ext_ndesc = 0;
   hipEvent_t wait_for = nullptr;     // pipelining: the previous sub-shard's "filter done"
   bool signal_filter_done = false;   // pipelining: record L.ev_filter_done behind this filter
 
@@ -479,11 +485,17 @@ int ScanJob::prepare() {
   // argument of the prefilter does not cover it, so overhang searches stream the full DP
   if (overhang) q = 0;
   if (ext_bitmap) q = ext_q;
+  if (ext_desc) q = 1;  // list mode without a filter
   filtered = q > 0;
   // which prefilter kernel (SASSY_HIP_FILTER_KIND=1|2|3 forces one where it applies)
   fkind = kFilterGeneric;
-  if (ext_bitmap) fkind = kFilterPlanes;  // marked like filter_dna_kernel does (end blocks of matches)
-  if (filtered && !ext_bitmap) {
+  if (ext_bitmap || ext_desc) fkind = kFilterPlanes;  // (ext_bitmap: marked like filter_dna_kernel does)
+  if (ext_desc) {
+    P.flags |= kScanPerText;
+    P.texts_start = texts.start;
+    P.texts_len = texts.len;
+  }
+  if (filtered && !ext_bitmap && !ext_desc) {
     static const int env_kind = getenv("SASSY_HIP_FILTER_KIND") ? atoi(getenv("SASSY_HIP_FILTER_KIND")) : 0;
     const uint32_t pieces = k + 1;
     const bool can_planes = S->profile == PROFILE_DNA && pieces <= 8;
@@ -551,7 +563,7 @@ int ScanJob::prepare() {
   //   [64, ..)  rank counters of the first kRankLimit reports
   //   [kCtlHead, ..)  the prefilter's hit bitmap (one bit per text block)
   n_words = filtered ? (n_blocks + 63) / 64 : 0;
-  if (int rc = L.d_ctl.reserve(kCtlHead + (filtered && !ext_bitmap ? (n_words + 2) * 8 : 0))) return rc;
+  if (int rc = L.d_ctl.reserve(kCtlHead + (filtered && !ext_bitmap && !ext_desc ? (n_words + 2) * 8 : 0))) return rc;
   d_bitmap = ext_bitmap ? ext_bitmap : reinterpret_cast<unsigned long long*>(L.d_ctl.p + kCtlHead);
   if (L.d_cand.cap == 0)
     if (int rc = L.d_cand.reserve(1u << 16)) return rc;
@@ -691,7 +703,8 @@ int ScanJob::prepare() {
       // end); a denser text overflows into the grow-and-retry path of finish()
       double frac = 64.0 * (k + 1.0) / std::pow(4.0, (double)q);
       const size_t expect = (size_t)std::min<double>(1.5 * frac * (double)n_blocks, (double)n_blocks) + 1024;
-      if (int rc = L.d_desc.reserve(std::max<size_t>(1u << 18, expect))) return rc;
+      if (!ext_desc)
+        if (int rc = L.d_desc.reserve(std::max<size_t>(1u << 18, expect))) return rc;
     }
     P.lds_per_wave = bucket * 512u + plan.nwords * 512u;
     if ((size_t)kWavesPerGroup * P.lds_per_wave > 160 * 1024)
@@ -721,7 +734,7 @@ int ScanJob::enqueue(int attempt) {
     T.out_str = Tw.out_str = L.d_str.p;
   }
   // control block, rank counters and (first attempt: the filter runs once) the hit bitmap
-  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, kCtlHead + (filtered && !ext_bitmap && attempt == 0 ? (n_words + 2) * 8 : 0), L.stream));
+  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, kCtlHead + (filtered && !ext_bitmap && !ext_desc && attempt == 0 ? (n_words + 2) * 8 : 0), L.stream));
   if (ext_wait && attempt == 0) HIP_TRY(hipStreamWaitEvent(L.stream, ext_wait, 0));
   // pipelined sub-shards: this lane's filter starts when the previous sub-shard's filter is done,
   // so that the previous lane's DP / rank / traceback kernels overlap this bandwidth-bound one
@@ -732,7 +745,7 @@ int ScanJob::enqueue(int attempt) {
     le = launch_scan_any(S->profile, P, grid, (size_t)kWavesPerGroup * P.lds_per_wave, L.stream);
     if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
   } else {
-    if (attempt == 0 && !ext_bitmap) {  // the hit bitmap does not depend on buffer sizes: build it once
+    if (attempt == 0 && !ext_bitmap && !ext_desc) {  // the hit bitmap does not depend on buffer sizes: build it once
       le = fkind == kFilterTable
                ? launch_filter_table(F, fgrid, L.stream)
                : launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, L.stream);
@@ -740,15 +753,19 @@ int ScanJob::enqueue(int attempt) {
     }
     if (timing >= 1 && attempt == 0) HIP_TRY(hipEventRecord(L.ev_f, L.stream));
     if (signal_filter_done && attempt == 0) HIP_TRY(hipEventRecord(L.ev_filter_done, L.stream));
-    desc_cap = (uint32_t)std::min<size_t>(L.d_desc.cap, 0x7FFFFFFFu);
-    if (int rc = L.d_state.reserve(desc_cap)) return rc;
+    desc_cap = ext_desc ? ext_ndesc : (uint32_t)std::min<size_t>(L.d_desc.cap, 0x7FFFFFFFu);
+    if (int rc = L.d_state.reserve(std::max<uint32_t>(desc_cap, 1))) return rc;
     P.chunk_state = L.d_state.p;
+    if (ext_desc)  // the descriptor count the list kernel reads
+      HIP_TRY(hipMemcpyAsync(d_counts + 1, &ext_ndesc, sizeof(uint32_t), hipMemcpyHostToDevice, L.stream));
     // right dilation: blocks a match END can reach from a piece occurrence; the bit-plane filter
     // marks those blocks itself (it knows the piece), the other filters mark the occurrence's block
-    le = launch_build_chunks(d_bitmap, n_words, n_blocks, first_owned, P.wb, fkind == kFilterPlanes ? 0u : P.wb, maxlen, L.d_desc.p,
-                             d_counts + 1, desc_cap, d_counters + 2, L.stream);
-    if (le != hipSuccess) return hip_fail(le, "chunk builder launch");
-    P.desc = L.d_desc.p;
+    if (!ext_desc) {
+      le = launch_build_chunks(d_bitmap, n_words, n_blocks, first_owned, P.wb, fkind == kFilterPlanes ? 0u : P.wb, maxlen, L.d_desc.p,
+                               d_counts + 1, desc_cap, d_counters + 2, L.stream);
+      if (le != hipSuccess) return hip_fail(le, "chunk builder launch");
+    }
+    P.desc = ext_desc ? ext_desc : L.d_desc.p;
     P.desc_count = d_counts + 1;
     P.desc_cap = desc_cap;
     // the descriptor count lives on the device: launch for the capacity, idle waves exit at once
@@ -1158,7 +1175,8 @@ struct ScanQueue {
   }
   int submit(const PatternPlan& plan, const uint8_t* pat, const ShardView& sh, const TextTable& texts, uint32_t k,
              bool all_minima, bool do_trace, uint64_t total_len, uint64_t tag, unsigned long long* ext_bitmap = nullptr,
-             uint32_t ext_q = 0, hipEvent_t ext_wait = nullptr) {
+             uint32_t ext_q = 0, hipEvent_t ext_wait = nullptr, const ChunkDesc* ext_desc = nullptr,
+             uint32_t ext_ndesc = 0) {
     if (in_flight == n_lanes)
       if (int rc = drain_one()) return rc;
     if (!inputs_marked) {
@@ -1178,6 +1196,8 @@ struct ScanQueue {
     sl.job->ext_bitmap = ext_bitmap;
     sl.job->ext_q = ext_q;
     sl.job->ext_wait = ext_wait;
+    sl.job->ext_desc = ext_desc;
+    sl.job->ext_ndesc = ext_ndesc;
     sl.busy = true;
     tail = (tail + 1) % n_lanes;
     ++in_flight;
@@ -1742,6 +1762,150 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
   return 0;
 }
 
+// ---- many host texts, one lane per text ----
+// The other way to run search_many over many short texts: the texts are laid out block-aligned
+// (each starts at a multiple of 64 bytes, padded to whole blocks) and the list-mode DP kernel gets
+// one descriptor per text, so every lane walks exactly one text from its column 0 to its end --
+// what the reference's multi-text SIMD mode does with its lanes (src/search.rs:615-637).  Nothing
+// has to be cut back afterwards: a lane seeds the true text-start column (or the overhang left edge),
+// applies the end-of-text rule (or the overhang columns and costs) at its own text's end, and tags
+// its reports with the text index.  There is no prefilter in this mode, so it is used where the
+// separator layout (search_many_batched) cannot be: overhang searches, the Ascii profile, Dna text
+// with other letters, and patterns whose pieces are too short to filter anyway.
+static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patterns, const size_t* pattern_lens,
+                               size_t n_patterns, const uint8_t* const* texts, const size_t* text_lens, size_t n_texts,
+                               size_t k, uint32_t flags, sassy_hip_Result* R, bool& handled) {
+  handled = false;
+  static const bool off = getenv("SASSY_HIP_BATCH_TEXTS") && atoi(getenv("SASSY_HIP_BATCH_TEXTS")) == 0;
+  if (off || n_texts < 2 || n_patterns == 0 || (flags & SASSY_HIP_TEXT_ON_DEVICE)) return 0;
+  if (n_texts >= (1u << (32 - kCandTextShift))) return 0;
+  const bool overhang = !std::isnan(s->alpha);
+  size_t max_m = 0;
+  bool filterable = true;  // every pattern has selective pieces: the separator layout + prefilter is faster
+  for (size_t pi = 0; pi < n_patterns; ++pi) {
+    if (!patterns[pi] || pattern_lens[pi] == 0 || k >= pattern_lens[pi]) return 0;
+    max_m = std::max(max_m, pattern_lens[pi]);
+    if (pattern_lens[pi] / (k + 1) < 7) filterable = false;
+  }
+  uint64_t longest = 0;
+  for (size_t ti = 0; ti < n_texts; ++ti) {
+    if (!texts[ti] && text_lens[ti]) return fail(SASSY_HIP_EINVAL, "null text");
+    longest = std::max<uint64_t>(longest, text_lens[ti]);
+  }
+  if (longest > (1u << 20)) return 0;                      // a lane per text only pays for short texts
+  if (!overhang && s->profile != PROFILE_ASCII && filterable) return 0;  // search_many_batched takes it
+  handled = true;
+  if (int rc = s->ensure_device()) return rc;
+  const bool all = (flags & SASSY_HIP_ALL_MINIMA) != 0;
+  const bool wo = (flags & SASSY_HIP_WITHOUT_TRACE) != 0;
+  // virtual columns behind a text's end (overhang): at most max_m; padded with 'N' (any other profile
+  // never looks at the padding: no end position lies beyond the text)
+  const uint64_t steps = overhang ? max_m : 0;
+  const uint8_t pad = overhang ? (uint8_t)'N' : (uint8_t)'X';
+  const uint64_t batch_cap = 1ull << 30;
+  std::vector<uint8_t> hbuf;
+  HostTexts ht;
+  std::vector<uint32_t> blk2text;
+  std::vector<ChunkDesc> desc;
+  std::vector<size_t> order;
+  size_t t0 = 0;
+  while (t0 < n_texts) {
+    // ---- lay out texts t0 .. t1, each in its own whole blocks ----
+    size_t t1 = t0;
+    uint64_t total = 0;
+    ht.start.clear(); ht.len.clear();
+    while (t1 < n_texts) {
+      const uint64_t slot = (text_lens[t1] + steps + 63) / 64 * 64;
+      if (t1 > t0 && total + slot > batch_cap) break;
+      ht.start.push_back(total);
+      ht.len.push_back(text_lens[t1]);
+      total += slot;
+      ++t1;
+    }
+    const size_t nt = t1 - t0;
+    if (total > 0) {
+      hbuf.assign(total, pad);
+      blk2text.assign(total / 64, 0u);
+      for (size_t i = 0; i < nt; ++i) {
+        if (text_lens[t0 + i]) memcpy(hbuf.data() + ht.start[i], texts[t0 + i], text_lens[t0 + i]);
+        const uint64_t b0 = ht.start[i] / 64, b1 = (i + 1 < nt ? ht.start[i + 1] : total) / 64;
+        for (uint64_t b = b0; b < b1; ++b) blk2text[b] = (uint32_t)i;
+      }
+      // descriptors, longest texts first so that the lanes of a wave have similar work
+      order.resize(nt);
+      for (size_t i = 0; i < nt; ++i) order[i] = i;
+      std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return ht.len[a] > ht.len[b]; });
+      desc.clear();
+      for (size_t i : order) {
+        if (ht.len[i] == 0) continue;  // an empty text has no matches
+        ChunkDesc d;
+        d.own_lo = (uint32_t)(ht.start[i] / 64);
+        d.own_hi = (uint32_t)((i + 1 < nt ? ht.start[i + 1] : total) / 64);
+        d.flags = kDescWholeText;
+        d.pad_ = (uint32_t)i;
+        desc.push_back(d);
+      }
+      if (desc.empty()) { t0 = t1; continue; }
+      if (int rc = s->d_text.reserve(total + 64)) return rc;
+      if (int rc = s->d_tables.reserve(2 * nt + 2 * desc.size() + total / 64 / 2 + 8)) return rc;
+      uint64_t* d_tab = s->d_tables.p;
+      ChunkDesc* d_desc = reinterpret_cast<ChunkDesc*>(d_tab + 2 * nt);
+      uint32_t* d_b2t = reinterpret_cast<uint32_t*>(d_tab + 2 * nt + 2 * desc.size());
+      HIP_TRY(hipMemcpyAsync(s->d_text.p, hbuf.data(), total, hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(d_tab, ht.start.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(d_tab + nt, ht.len.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
+      HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice, s->stream));
+      TextTable tt{d_tab, d_tab + nt, (uint32_t)nt, all ? 1u : 0u, 1u};
+      if (s->rc) {
+        HIP_TRY(hipMemcpyAsync(d_b2t, blk2text.data(), blk2text.size() * 4, hipMemcpyHostToDevice, s->stream));
+        if (int rc = s->d_rev.reserve(total + 64)) return rc;
+        hipError_t le = launch_reverse_texts(s->d_text.p, s->d_rev.p, total, d_b2t, d_tab, d_tab + nt, pad, s->stream);
+        if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
+      }
+      std::string err;
+      ScanQueue queue(s, [&](uint64_t tag, ScanOut& so, const PatternPlan& plan, const uint8_t* pat) -> int {
+        const size_t pi = (size_t)(tag >> 1);
+        const bool is_rc = (tag & 1) != 0;
+        // N counting for max_n_frac: the forward buffer has a host copy, the reversed one lives on the device
+        if (int rc = post_filter(s, so, plan, pat, (uint32_t)k, is_rc ? 1 : 0, is_rc ? nullptr : hbuf.data(),
+                                 is_rc ? s->d_rev.p : s->d_text.p, total, !wo, EndFilter(), &ht)) return rc;
+        size_t first = 0;
+        if (int rc = append_matches(so, total, plan, wo, pi, R, first, &ht)) return rc;
+        for (size_t i = first; i < R->matches.size(); ++i) {
+          sassy_hip_Match& m = R->matches[i];
+          if (is_rc) {  // reference: src/search.rs:859-873 (each text was reversed in its own slot)
+            const uint64_t len = ht.len[m.text_idx], rs = m.text_start, re = m.text_end;
+            m.strand = 1;
+            m.text_start = len - re;
+            m.text_end = wo ? UINT64_MAX : len - rs;
+          }
+          m.text_idx += t0;
+        }
+        return 0;
+      });
+      for (size_t pi = 0; pi < n_patterns; ++pi) {
+        PatternPlan plan;
+        if (!make_plan(s->profile, patterns[pi], pattern_lens[pi], plan, err)) return fail(SASSY_HIP_EINVAL, err);
+        ShardView sh{s->d_text.p, total, 0, 0, true, true};
+        if (int rc = queue.submit(plan, patterns[pi], sh, tt, (uint32_t)k, all, !wo, total, 2 * pi, nullptr, 0, nullptr,
+                                  d_desc, (uint32_t)desc.size())) return rc;
+        if (s->rc) {
+          std::vector<uint8_t> cp(pattern_lens[pi]);
+          for (size_t i = 0; i < cp.size(); ++i) cp[i] = complement_char(s->profile, patterns[pi][i]);
+          PatternPlan cplan;
+          if (!make_plan(s->profile, cp.data(), cp.size(), cplan, err)) return fail(SASSY_HIP_EINVAL, err);
+          ShardView shr{s->d_rev.p, total, 0, 0, true, true};
+          if (int rc = queue.submit(cplan, cp.data(), shr, tt, (uint32_t)k, all, !wo, total, 2 * pi + 1, nullptr, 0, nullptr,
+                                    d_desc, (uint32_t)desc.size())) return rc;
+        }
+      }
+      if (int rc = queue.drain_all()) return rc;
+    }
+    t0 = t1;
+  }
+  return 0;
+}
+
 int sassy_hip_search_many(sassy_SearcherType* s, const uint8_t* const* patterns, const size_t* pattern_lens,
                           size_t n_patterns, const uint8_t* const* texts, const size_t* text_lens, size_t n_texts,
                           size_t k, uint32_t flags, sassy_hip_Result** out) {
@@ -1752,8 +1916,11 @@ int sassy_hip_search_many(sassy_SearcherType* s, const uint8_t* const* patterns,
   if (int rc = s->ensure_device()) return rc;
   std::unique_ptr<sassy_hip_Result> R(new sassy_hip_Result());
   bool handled = false;
-  if (int rc = search_many_batched(s, patterns, pattern_lens, n_patterns, texts, text_lens, n_texts, k, flags, R.get(), handled))
+  if (int rc = search_many_pertext(s, patterns, pattern_lens, n_patterns, texts, text_lens, n_texts, k, flags, R.get(), handled))
     return rc;
+  if (!handled)
+    if (int rc = search_many_batched(s, patterns, pattern_lens, n_patterns, texts, text_lens, n_texts, k, flags, R.get(), handled))
+      return rc;
   // otherwise: text-major (each host text is uploaded once), pattern-major in the result
   for (size_t ti = 0; !handled && ti < n_texts; ++ti) {
     const uint8_t* tptr = texts[ti];

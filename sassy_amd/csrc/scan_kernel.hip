@@ -118,6 +118,8 @@ struct EmitCtx {
   uint32_t flags;
   float alpha;        // overhang: extra cost floor(alpha * (pos - text_len)) past the text end
   uint32_t ov_steps;  // overhang: end positions up to text_len + ov_steps exist
+  uint64_t text_begin; // buffer position of the text's column 0 (0 unless per-text mode)
+  uint32_t tag;        // OR-ed into the flags of every report (per-text mode: the text index)
 };
 
 __device__ __forceinline__ void emit(const EmitCtx& P, uint64_t gpos, int cost, uint32_t flags) {
@@ -126,7 +128,7 @@ __device__ __forceinline__ void emit(const EmitCtx& P, uint64_t gpos, int cost, 
     Candidate c;
     c.pos = gpos;
     c.cost = cost;
-    c.flags = flags;
+    c.flags = flags | P.tag;
     P.cand[idx] = c;
   }
 }
@@ -155,8 +157,8 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
   int raw = ds;                        // cost without the overshoot part
   int cost = total_of(raw, base), prev_cost = cost;
   uint64_t prev_pos = base;
-  if (all && owned && cost <= k && base == 0 && P.global_offset == 0 && (P.flags & kScanTextStart))
-    emit(P, 0, cost, 0);
+  if (all && owned && cost <= k && base == P.text_begin && P.global_offset == 0 && (P.flags & kScanTextStart))
+    emit(P, base, cost, 0);
   bool determined = (x0 < 0);
   for (int bit = 1; bit <= 64; ++bit) {
     const uint64_t pos = base + (uint64_t)bit;
@@ -460,6 +462,8 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   ctx.flags = P.flags;
   ctx.alpha = P.alpha;
   ctx.ov_steps = (P.flags & kScanOverhang) ? P.ov_steps : 0u;
+  ctx.text_begin = 0;
+  ctx.tag = 0;
 
   unsigned long long cnt_rows = 0, cnt_blocks = 0, cnt_live = 0;
   const unsigned char* my_masks = mask_bytes + lane * 8;
@@ -1194,9 +1198,12 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   const bool clear_before = (d.flags & kDescClearBefore) != 0;
   // a chunk whose left neighbour block holds no cell <= k starts fresh at its own first block;
   // a continuation chunk (split of a long run) needs the warm-up blocks in front of it
+  // per-text mode: the chunk is a whole text that starts at block own_lo
+  const bool whole_text = (d.flags & kDescWholeText) != 0;
   uint64_t blk0 = own_lo;
-  if (!clear_before) blk0 = own_lo > P.wb ? own_lo - P.wb : 0;
-  const bool exact_start = clear_before || (blk0 == 0 && (P.flags & kScanTextStart));
+  if (!clear_before && !whole_text) blk0 = own_lo > P.wb ? own_lo - P.wb : 0;
+  const bool at_text_start = whole_text || (blk0 == 0 && (P.flags & kScanTextStart));
+  const bool exact_start = clear_before || at_text_start;
   const int64_t x0 = exact_start ? -1 : (int64_t)(blk0 * 64 + P.m + P.k);
   const uint32_t my_iters = has_chunk ? (uint32_t)(own_hi - blk0) : 0u;
 
@@ -1209,8 +1216,13 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   uint32_t pkw0[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) pkw0[i] = row_tab[i];
+  // fresh start: every vertical delta on the left edge is +1; with overhang a chunk that starts at
+  // column 0 of its text gets the alpha left edge instead
+  const bool ov_seed = at_text_start && (P.flags & kScanOverhang);
   for (uint32_t w = 0; w < nwords; ++w) {
-    carry[(w * 2 + 0) * 64 + lane] = (w == nwords - 1) ? last_word_init : 0xFFFFFFFFu;
+    uint32_t hp0 = (w == nwords - 1) ? last_word_init : 0xFFFFFFFFu;
+    if (ov_seed) hp0 = P.ov_tab[w];
+    carry[(w * 2 + 0) * 64 + lane] = hp0;
     carry[(w * 2 + 1) * 64 + lane] = 0;
   }
   uint32_t st = kStDec;
@@ -1224,6 +1236,13 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   ctx.flags = P.flags;
   ctx.alpha = P.alpha;
   ctx.ov_steps = (P.flags & kScanOverhang) ? P.ov_steps : 0u;
+  ctx.text_begin = 0;
+  ctx.tag = 0;
+  if (whole_text) {  // this lane's text: its own column 0, its own end, its index on every report
+    ctx.text_begin = own_lo * 64;
+    ctx.text_len = P.texts_start[d.pad_] + P.texts_len[d.pad_];
+    ctx.tag = d.pad_ << kCandTextShift;
+  }
   unsigned long long cnt_rows = 0, cnt_blocks = 0, cnt_live = 0;
   const unsigned char* my_masks = mask_bytes + lane * 8;
 

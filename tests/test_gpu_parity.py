@@ -636,6 +636,62 @@ def test_pack_result_for_gather(sassy):
     assert [key(m) for m in back] == [key(m) for m in r.matches]
 
 
+def test_per_text_lanes(sassy):
+    """search_many in "one lane per text" mode (host.hip: search_many_pertext): overhang searches,
+    the Ascii profile and unfilterable patterns over many short texts must equal the pair-by-pair
+    searches -- incl. overhang at every text's own start and end."""
+    rng = random.Random(808)
+    # ---- overhang over many reads ----
+    pats = [bytes(rng.choice(b"ACGT") for _ in range(m)) for m in (10, 16, 24)]
+    texts = []
+    for t in range(60):
+        n = rng.choice([0, 1, 3, 9, 30, 63, 64, 65, 100, 129, 400, 1500])
+        text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        p = pats[t % 3]
+        if n >= 8:
+            cut = rng.randrange(1, len(p))
+            if t % 4 == 0:
+                head = p[cut:][:n]; text[:len(head)] = head              # pattern hangs over the start
+            elif t % 4 == 1:
+                tail = p[:cut][-n:]; text[n - len(tail):] = tail         # ... over the end
+            elif n > 2 * len(p):
+                ins = mutate(rng, p, rng.randrange(0, 3)); at = rng.randrange(0, n - len(ins)); text[at:at + len(ins)] = ins
+        texts.append(bytes(text))
+    for alpha, mo in ((0.5, None), (0.25, 4), (1.0, None)):
+        for rc in (False, True):
+            for allm in (False, True):
+                s = sassy.Searcher("iupac", rc=rc, alpha=alpha).with_max_overhang(mo)
+                got = s.search_many(pats, texts, 2, all_minima=allm)
+                assert s.stats()["scan_launches"] == len(pats) * (2 if rc else 1)
+                want = []
+                for pi, p in enumerate(pats):
+                    for ti, t in enumerate(texts):
+                        for m in oracle.search_overhang("iupac", p, t, 2, alpha, rc=rc, all_minima=allm, max_overhang=mo):
+                            want.append((pi, ti) + key(m)[1:])
+                assert [(m.pattern_idx, m.text_idx) + key(m)[1:] for m in got] == want, (alpha, mo, rc, allm)
+                assert len(want) > 20
+    # ---- Ascii ----
+    words = [b"hello", b"world!", b"needle"]
+    docs = []
+    for t in range(40):
+        n = rng.choice([0, 2, 7, 64, 65, 200, 900])
+        doc = bytearray(rng.choice(b"abcdefghij lmnopqrstuvwxyz!") for _ in range(n))
+        if n > 20:
+            w = words[t % 3]; ins = bytearray(w)
+            if t % 2: ins[rng.randrange(len(ins))] = ord("#")
+            at = rng.randrange(0, n - len(ins)); doc[at:at + len(ins)] = ins
+        docs.append(bytes(doc))
+    s = sassy.Searcher("ascii", rc=False)
+    got = s.search_many(words, docs, 1)
+    want = []
+    for pi, p in enumerate(words):
+        for ti, t in enumerate(docs):
+            for m in oracle.search("ascii", p, t, 1):
+                want.append((pi, ti) + key(m)[1:])
+    assert [(m.pattern_idx, m.text_idx) + key(m)[1:] for m in got] == want
+    assert len(want) > 5 and s.stats()["scan_launches"] == len(words)
+
+
 def test_config1_shape_1mib(sassy):
     """BASELINE config 1: 'ATCG'x8, k=3, 1 MiB random ACGT (+ plants), Dna, forward only."""
     pat = b"ATCG" * 8

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--pattern-len", type=int, default=24)
     ap.add_argument("--k", type=int, default=3)
     ap.add_argument("--profile", default="iupac")
+    ap.add_argument("--overhang", type=float, default=None)
     args = ap.parse_args()
     rng = np.random.default_rng(7)
     acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -40,7 +41,7 @@ def main():
         flat[r, at[r]:at[r] + args.pattern_len] = p
     texts = [flat[r].tobytes() for r in range(args.reads)]
     total = args.reads * args.read_len
-    s = sassy_amd.Searcher(args.profile, rc=True)
+    s = sassy_amd.Searcher(args.profile, rc=True, alpha=args.overhang)
     s.search_many(pats[:2], texts[:100], args.k)  # warm-up
     t0 = time.perf_counter()
     ms = s.search_many(pats, texts, args.k)
@@ -48,7 +49,8 @@ def main():
     st = s.stats()
     print(json.dumps({
         "workload": f"{args.patterns} x {args.pattern_len} bp patterns, {args.reads} reads x {args.read_len} bp "
-                    f"({total / 1e6:.0f} MB), k={args.k}, {args.profile}, both strands",
+                    f"({total / 1e6:.0f} MB), k={args.k}, {args.profile}, both strands"
+                    + (f", overhang {args.overhang}" if args.overhang is not None else ""),
         "seconds_python_call": round(dt, 3), "seconds_c_abi": round(st["total_ms"] / 1e3, 3),
         "pattern_text_GB_per_s": round(total * args.patterns / (st["total_ms"] / 1e3) / 1e9, 1),
         "matches": len(ms), "scan_launches": st["scan_launches"], "scan_kernel_ms": round(st["scan_ms"], 2),
