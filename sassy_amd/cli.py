@@ -19,6 +19,8 @@ from typing import Iterator, List, Tuple
 
 from . import Searcher
 
+BATCH_BYTES = 64 << 20  # text bytes per search_many call
+
 
 def read_fastx(path: str) -> Iterator[Tuple[str, bytes]]:
     """(id, sequence) of every FASTA / FASTQ record; id = the header line without its marker, as
@@ -86,8 +88,26 @@ def main(argv=None) -> int:
     searcher = Searcher(args.alphabet, rc=not args.no_rc, alpha=args.overhang).with_max_n_frac(args.max_n_frac)
     out = sys.stdout
     out.write("pat_id\ttext_id\tcost\tstrand\tstart\tend\tmatch_region\tcigar\n")
+    pats = [p for _, p in patterns]
+
+    def flush(batch):
+        # every pattern against every record of the batch in one call (many short records -- reads --
+        # share one device buffer); rows record by record, patterns in input order
+        if not batch:
+            return
+        ms = searcher.search_many(pats, [seq for _, seq in batch], args.k)
+        ms.sort(key=lambda m: (m.text_idx, m.pattern_idx))  # stable: keeps each pair's match order
+        for m in ms:
+            text_id, seq = batch[m.text_idx]
+            out.write(searcher.format_tsv(m, patterns[m.pattern_idx][0], text_id, seq, sam=args.sam))
+
+    batch, batch_bytes = [], 0
     for path in args.paths:
-        for text_id, seq in read_fastx(path):
-            for m in searcher.search_many([p for _, p in patterns], [seq], args.k):
-                out.write(searcher.format_tsv(m, patterns[m.pattern_idx][0], text_id, seq, sam=args.sam))
+        for rec in read_fastx(path):
+            batch.append(rec)
+            batch_bytes += len(rec[1])
+            if batch_bytes >= BATCH_BYTES:  # the reference batches ~1 MB of records per task (bin/input_iterator.rs:6)
+                flush(batch)
+                batch, batch_bytes = [], 0
+    flush(batch)
     return 0
