@@ -210,7 +210,7 @@ def test_traceback_variants(sassy, profile):
     including text-start / text-end windows and search_all (dense, adjacent reports)."""
     rng = random.Random(7 if profile == "dna" else 8)
     cases = [(12, 0), (16, 1), (20, 2), (24, 4), (33, 5), (40, 6), (40, 7), (64, 9), (90, 13),
-             (130, 20), (200, 30), (70, 31), (120, 35), (300, 30), (100, 9), (160, 15)]
+             (130, 20), (200, 30), (70, 31), (120, 35), (300, 30), (100, 9), (160, 15), (1000, 40), (2100, 12)]
     for m, k in cases:
         pat = bytes(rng.choice(b"ACGT") for _ in range(m))
         if profile == "iupac" and m >= 20:
