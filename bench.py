@@ -200,7 +200,7 @@ def main():
     # (every text byte is read once by it), else the streaming DP kernel.  Its HIP events are the
     # only ones recorded inside the timed region (timing level 1).
     dom_ms = filter_avg_ms if filtered else scan_avg_ms
-    dom_name = {0: "scan_kernel", 1: "filter_kernel", 2: "filter_dna_kernel"}[int(st["filtered"])]
+    dom_name = {0: "scan_kernel", 1: "filter_kernel", 2: "filter_dna_kernel", 3: "filter_table_kernel", 4: "filter_count_kernel"}[int(st["filtered"])]
     # phase breakdown from a few extra, untimed steps with every phase timed (more events = more
     # stream idle time, so these are not part of the measurement above)
     searcher.set_timing(2)

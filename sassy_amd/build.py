@@ -26,6 +26,7 @@ UNITS = [
     ("scan_kernel.hip", "scan_ascii.o", ["-DSASSY_SCAN_PROFILE=0"]),
     ("scan_kernel.hip", "scan_dna.o", ["-DSASSY_SCAN_PROFILE=1"]),
     ("scan_kernel.hip", "scan_iupac.o", ["-DSASSY_SCAN_PROFILE=2"]),
+    ("count_filter.hip", "count_filter.o", []),
     ("aux_kernels.hip", "aux_kernels.o", []),
     ("trace_kernel.hip", "trace_kernel.o", []),
     ("host.hip", "host.o", []),

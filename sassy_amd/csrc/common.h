@@ -113,7 +113,13 @@ struct ScanParams {
                               // lengthen the first pieces: fewer chance hits at no loss of exactness)
   uint64_t multi_stride;
   // q-gram table filter: 4^piece_len bits, byte = code & (2^(2q-3)-1), bit = code >> (2q-3)
-  const uint8_t* qgram_table; // device; null unless the table filter is used
+  const uint8_t* qgram_table; // device; null unless the table / count filter is used
+  // q-gram counting filter (filter_count_kernel): piece_len = Q; one byte per (Q+R-1)-gram = how many
+  // of its R q-grams occur in the pattern; a match can only end in a block whose last
+  // count_window blocks hold >= count_thresh q-gram hits
+  uint32_t count_r;           // positions per table lookup (1, 2 or 4)
+  uint32_t count_window;      // W = ceil((m + k - Q) / 64) + 1 blocks
+  uint32_t count_thresh;      // t = m + 1 - (k+1) Q
   unsigned long long* hit_bitmap;  // one bit per text block: an exact piece occurrence ends in it
   unsigned long long* hit_count;   // device counter of hit blocks
   const ChunkDesc* desc;      // list mode: chunk descriptors

@@ -32,6 +32,7 @@ hipError_t launch_scan_ascii(const ScanParams& P, uint32_t grid, size_t smem, hi
 hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
 hipError_t launch_filter_table(const ScanParams& P, uint32_t grid, hipStream_t stream);
 hipError_t launch_filter_dna_multi(const ScanParams& P, uint32_t grid, hipStream_t stream);
+hipError_t launch_filter_count(const ScanParams& P, uint32_t grid, hipStream_t stream);
 hipError_t launch_count_n(const uint8_t* d_text, const uint64_t* d_range, uint32_t n, uint32_t* d_count,
                           hipStream_t stream);
 hipError_t launch_acgt_check(const uint8_t* d_text, uint64_t n, uint32_t* d_flag, hipStream_t stream);
@@ -133,7 +134,8 @@ struct ScanLane {
   std::vector<uint8_t> up_pattern, h_table, table_pattern;
   std::vector<uint32_t> up_rowtab, up_ovtab;
   int up_profile = -1, table_profile = -1;
-  uint32_t table_q = 0, table_k = 0;
+  uint32_t table_q = 0, table_k = 0, table_r = 0;   // table_r: 0 = piece bit table, else the counting table's R
+  double table_density = 0;
   // pinned host staging area: control block and the first kSpec reports of a scan are written into
   // it by the kernels themselves; one stream synchronisation makes them readable
   unsigned char* h_pin = nullptr;
@@ -304,6 +306,7 @@ enum FilterKind : uint32_t {
   kFilterGeneric = 1,  // filter_kernel: slot masks in LDS, any profile, <= 255 piece rows
   kFilterPlanes = 2,   // filter_dna_kernel: Dna, <= 8 pieces
   kFilterTable = 3,    // filter_table_kernel: q-gram bit table, Dna / Iupac, 7 <= q <= 9
+  kFilterCount = 4,    // filter_count_kernel: q-gram lemma (count the pattern's q-grams per window), Dna / Iupac
 };
 
 // Bit table of every q-gram (2 bits per char, first piece row most significant; codes A0 C1 T2 G3)
@@ -332,6 +335,68 @@ static bool build_qgram_table(Profile pr, const uint8_t* pat, uint32_t q, uint32
     for (uint32_t code : cur) tab[code & ((1u << low_bits) - 1u)] |= (uint8_t)(1u << (code >> low_bits));
   }
   return true;
+}
+
+// The counting filter's table (count_filter.hip): H = every Q-gram some Q consecutive pattern rows
+// accept (2 bits per letter, first row most significant, codes A0 C1 T2 G3; ambiguous rows are
+// expanded); entry w of the table, w a (Q+R-1)-gram, = how many of the R Q-grams w ends with are
+// in H.  density = |H| / 4^Q, the chance that a random position counts.  False if the expansion
+// takes more than `limit` Q-grams.
+static bool build_count_table(Profile pr, const uint8_t* pat, uint32_t m, uint32_t Q, uint32_t R,
+                              std::vector<uint8_t>& tab, double* density) {
+  const size_t limit = 1u << 20;
+  const uint32_t nq = 1u << (2 * Q);
+  std::vector<uint8_t> H(nq, 0);
+  std::vector<uint32_t> cur, nxt;
+  size_t total = 0;
+  for (uint32_t o = 0; o + Q <= m; ++o) {
+    cur.assign(1, 0u);
+    for (uint32_t j = 0; j < Q; ++j) {
+      const uint8_t c = pat[o + j];
+      const uint32_t set = pr == PROFILE_IUPAC ? (iupac_code(c) & 15u) : (1u << ((c >> 1) & 3u));
+      nxt.clear();
+      for (uint32_t code : cur)
+        for (uint32_t b = 0; b < 4; ++b)
+          if ((set >> b) & 1u) nxt.push_back((code << 2) | b);
+      if (nxt.size() + total > limit) return false;
+      cur.swap(nxt);
+    }
+    total += cur.size();
+    for (uint32_t code : cur) H[code] = 1;
+  }
+  size_t set_bits = 0;
+  for (uint8_t v : H) set_bits += v;
+  *density = (double)set_bits / (double)nq;
+  const uint32_t nw = 1u << (2 * (Q + R - 1));
+  tab.assign(nw, 0);
+  for (uint32_t w = 0; w < nw; ++w) {
+    uint32_t c = 0;
+    for (uint32_t r = 0; r < R; ++r) c += H[(w >> (2 * r)) & (nq - 1)];
+    tab[w] = (uint8_t)c;
+  }
+  return true;
+}
+
+// How often a window of random text reaches the threshold t when it holds lambda q-gram hits on
+// average.  Hits come in clumps (a text stretch that equals L >= Q pattern rows gives L - Q + 1 of
+// them): clumps arrive Poisson(lambda (1 - r)) with geometric sizes, P(j) = (1 - r) r^(j-1), r = 1/4
+// the chance that the next letter extends the stretch.  P(S >= t) by Panjer's recursion.
+static double clumped_tail(double lambda, uint32_t t) {
+  if (t == 0) return 1.0;
+  if (lambda <= 0) return 0.0;
+  if (lambda >= (double)t) return 1.0;  // at or above the mean: no filter
+  const double r = 0.25, lc = lambda * (1.0 - r);
+  std::vector<double> p(t, 0.0);
+  p[0] = std::exp(-lc);
+  if (p[0] <= 0) return 1.0;
+  double below = p[0];
+  for (uint32_t s = 1; s < t; ++s) {
+    double acc = 0, g = 1.0 - r;  // g = P(size j)
+    for (uint32_t j = 1; j <= s && j <= 48; ++j, g *= r) acc += (double)j * g * p[s - j];
+    p[s] = lc / (double)s * acc;
+    below += p[s];
+  }
+  return std::min(1.0, std::max(0.0, 1.0 - below));
 }
 
 static hipError_t launch_scan_any(Profile pr, const ScanParams& P, uint32_t grid, size_t smem, hipStream_t st) {
@@ -421,6 +486,8 @@ struct ScanJob {
   uint32_t bucket = 4, q = 0;
   bool filtered = false;
   FilterKind fkind = kFilterGeneric;
+  uint32_t count_r = 0, count_w = 0, count_t = 0;  // counting filter: R, window blocks, threshold
+  double count_tail = 0;                           // ... and the expected fraction of candidate blocks
   unsigned long long* d_bitmap = nullptr;
   uint32_t* d_counts = nullptr;
   unsigned long long* d_counters = nullptr;
@@ -486,8 +553,9 @@ int ScanJob::prepare() {
   if (overhang) q = 0;
   if (ext_bitmap) q = ext_q;
   if (ext_desc) q = 1;  // list mode without a filter
-  filtered = q > 0;
-  // which prefilter kernel (SASSY_HIP_FILTER_KIND=1|2|3 forces one where it applies)
+  // which prefilter kernel (SASSY_HIP_FILTER_KIND=1|2|3|4 forces one where it applies)
+  static const int env_kind = getenv("SASSY_HIP_FILTER_KIND") ? atoi(getenv("SASSY_HIP_FILTER_KIND")) : 0;
+  static const int env_pre = getenv("SASSY_HIP_PREFILTER") ? atoi(getenv("SASSY_HIP_PREFILTER")) : -1;
   fkind = kFilterGeneric;
   if (ext_bitmap || ext_desc) fkind = kFilterPlanes;  // (ext_bitmap: marked like filter_dna_kernel does)
   if (ext_desc) {
@@ -495,10 +563,71 @@ int ScanJob::prepare() {
     P.texts_start = texts.start;
     P.texts_len = texts.len;
   }
-  if (filtered && !ext_bitmap && !ext_desc) {
-    static const int env_kind = getenv("SASSY_HIP_FILTER_KIND") ? atoi(getenv("SASSY_HIP_FILTER_KIND")) : 0;
-    const uint32_t pieces = k + 1;
-    const bool can_planes = S->profile == PROFILE_DNA && pieces <= 8;
+  const uint32_t pieces = k + 1;
+  const bool can_planes = q > 0 && S->profile == PROFILE_DNA && pieces <= 8;
+  // q-gram counting (count_filter.hip): per (Q, R) variant the threshold t = m + 1 - (k+1) Q, the
+  // window W, and how often a window of random text reaches t by chance (the pattern's q-grams,
+  // ambiguity letters expanded, against 4^Q; Poisson tail).  Taken when that beats the expected
+  // hit blocks of the k+1 pieces, except where the cheaper bit-plane kernel applies.
+  count_r = 0;
+  if (!overhang && !ext_bitmap && !ext_desc && S->profile != PROFILE_ASCII && env_pre != 0 &&
+      (env_kind == 0 || env_kind == kFilterCount) && !(can_planes && env_kind == 0)) {
+    // two positions per lookup first (half the LDS traffic of (7,1)); the 7-gram variant only where
+    // the shorter q-grams are not selective enough
+    static const uint32_t variants[][2] = {{6, 2}, {5, 2}, {7, 1}};
+    double best = 1.0;
+    uint32_t bq = 0, br = 0;
+    // the same pattern as in the last call on this lane: the decision and the table are still there
+    const bool same_as_last = L.table_r != 0 && L.table_k == k && L.table_profile == (int)S->profile &&
+                              L.table_pattern.size() == plan.m && memcmp(L.table_pattern.data(), pat, plan.m) == 0;
+    if (same_as_last) { bq = L.table_q; br = L.table_r; best = 0.0; }
+    for (const auto& v : variants) {
+      if (same_as_last) break;
+      const uint32_t Q = v[0];
+      if (v[1] == 1 && best < 1e-3) break;
+      if ((uint64_t)pieces * Q > plan.m) continue;  // t >= 1
+      const uint32_t t = plan.m + 1 - pieces * Q;
+      const uint32_t W = (plan.m + k - Q + 63) / 64 + 1;
+      if (W > 64) continue;
+      double grams = 0;  // expected size of H: the product of the rows' base-set sizes, per q-gram
+      for (uint32_t o = 0; o + Q <= plan.m; ++o) {
+        double e = 1;
+        for (uint32_t j = 0; j < Q; ++j)
+          e *= S->profile == PROFILE_IUPAC ? (double)__builtin_popcount(iupac_code(pat[o + j]) & 15u) : 1.0;
+        grams += e;
+      }
+      const double dens = std::min(1.0, grams / std::pow(4.0, (double)Q));
+      const double tail = clumped_tail(64.0 * W * dens, t);
+      if (tail < (v[1] == 1 ? 0.1 * best : best)) { best = tail; bq = Q; br = v[1]; }
+    }
+    const double piece_frac = q > 0 ? std::min(1.0, 64.0 * pieces / std::pow(4.0, (double)std::min<uint32_t>(q, 9))) : 1.0;
+    if (bq && best < 0.05 && (same_as_last || best < 0.5 * piece_frac || env_kind == kFilterCount)) {
+      const bool cached = L.table_q == bq && L.table_r == br && L.table_k == k && L.table_profile == (int)S->profile &&
+                          L.table_pattern.size() == plan.m && memcmp(L.table_pattern.data(), pat, plan.m) == 0;
+      bool ok = true;
+      if (!cached) {
+        ok = build_count_table(S->profile, pat, plan.m, bq, br, L.h_table, &L.table_density);
+        if (ok) {
+          if (int rc = L.d_table.reserve(L.h_table.size())) return rc;
+          HIP_TRY(hipMemcpyAsync(L.d_table.p, L.h_table.data(), L.h_table.size(), hipMemcpyHostToDevice, L.stream));
+          L.table_q = bq; L.table_r = br; L.table_k = k; L.table_profile = (int)S->profile;
+          L.table_pattern.assign(pat, pat + plan.m);
+        } else {
+          L.table_q = 0;
+        }
+      }
+      if (ok) {
+        fkind = kFilterCount;
+        q = bq;
+        count_r = br;
+        count_w = (plan.m + k - bq + 63) / 64 + 1;
+        count_t = plan.m + 1 - pieces * bq;
+        count_tail = clumped_tail(64.0 * count_w * L.table_density, count_t);
+      }
+    }
+  }
+  filtered = q > 0;
+  if (filtered && !ext_bitmap && !ext_desc && fkind != kFilterCount) {
     const bool can_table = S->profile != PROFILE_ASCII && q >= 7;
     const bool can_generic = (uint64_t)pieces * q <= 255;   // its term table holds 256 piece rows
     if (can_planes && (env_kind == 0 || env_kind == kFilterPlanes)) fkind = kFilterPlanes;
@@ -506,13 +635,13 @@ int ScanJob::prepare() {
     else if (!can_generic) return fail(SASSY_HIP_EUNSUPPORTED, "k too large for the prefilter's piece table");
     if (fkind == kFilterTable) {
       const uint32_t tq = std::min<uint32_t>(q, 9);
-      const bool cached = L.table_q == tq && L.table_k == k && L.table_profile == (int)S->profile &&
+      const bool cached = L.table_q == tq && L.table_r == 0 && L.table_k == k && L.table_profile == (int)S->profile &&
                           L.table_pattern.size() == plan.m && memcmp(L.table_pattern.data(), pat, plan.m) == 0;
       if (!cached) {
         if (build_qgram_table(S->profile, pat, tq, pieces, L.h_table)) {
           if (int rc = L.d_table.reserve(L.h_table.size())) return rc;
           HIP_TRY(hipMemcpyAsync(L.d_table.p, L.h_table.data(), L.h_table.size(), hipMemcpyHostToDevice, L.stream));
-          L.table_q = tq; L.table_k = k; L.table_profile = (int)S->profile;
+          L.table_q = tq; L.table_r = 0; L.table_k = k; L.table_profile = (int)S->profile;
           L.table_pattern.assign(pat, pat + plan.m);
         } else {
           L.table_q = 0;
@@ -671,7 +800,10 @@ int ScanJob::prepare() {
     static const int env_planes = getenv("SASSY_HIP_FILTER_PLANES") ? atoi(getenv("SASSY_HIP_FILTER_PLANES")) : 1;
     (void)env_planes;
     F.piece_planes = fkind == kFilterPlanes ? 1u : 0u;
-    F.qgram_table = fkind == kFilterTable ? L.d_table.p : nullptr;
+    F.qgram_table = fkind == kFilterTable || fkind == kFilterCount ? L.d_table.p : nullptr;
+    F.count_r = count_r;
+    F.count_window = count_w;
+    F.count_thresh = count_t;
     if (F.piece_planes) {
       for (uint32_t pp = 0; pp < 8; ++pp) {
         const uint32_t piece = pp < F.n_pieces ? pp : 0;  // a repeated piece changes nothing
@@ -695,13 +827,23 @@ int ScanJob::prepare() {
       const uint32_t wg_lds = (1u << (2 * q - 3)) + 4 * 4096u;
       fwpc = 4 * (int)std::min<uint32_t>(8, (160u * 1024u) / wg_lds);
     }
-    if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, 1, &fgrid, fwpc)) return rc;
+    uint32_t extra_front = 1;
+    if (fkind == kFilterCount) {
+      static const int env_csb = getenv("SASSY_HIP_COUNT_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_COUNT_STAGE_BLOCKS")) : 0;
+      F.stage_blocks = env_csb == 2 ? 2u : 1u;
+      const uint32_t wg_lds = (1u << (2 * (q + count_r - 1))) + 4 * (4096u * F.stage_blocks + 64u * count_w);
+      fwpc = 4 * (int)std::min<uint32_t>(8, (160u * 1024u) / wg_lds);
+      extra_front = count_w + 1;
+    }
+    if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, extra_front, &fgrid, fwpc)) return rc;
     F.lds_per_wave = 4096u * F.stage_blocks + (F.piece_planes ? 0u : 2u * bucket * 512u);
+    if (fkind == kFilterCount) F.lds_per_wave = 4096u * F.stage_blocks + 64u * count_w;
     F.hit_bitmap = d_bitmap;
     {
       // room for the expected number of chunks on random text (64 (k+1) / 4^q of the blocks hold a piece
       // end); a denser text overflows into the grow-and-retry path of finish()
       double frac = 64.0 * (k + 1.0) / std::pow(4.0, (double)q);
+      if (fkind == kFilterCount) frac = 2.0 * count_tail;
       const size_t expect = (size_t)std::min<double>(1.5 * frac * (double)n_blocks, (double)n_blocks) + 1024;
       if (!ext_desc)
         if (int rc = L.d_desc.reserve(std::max<size_t>(1u << 18, expect))) return rc;
@@ -746,7 +888,8 @@ int ScanJob::enqueue(int attempt) {
     if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
   } else {
     if (attempt == 0 && !ext_bitmap && !ext_desc) {  // the hit bitmap does not depend on buffer sizes: build it once
-      le = fkind == kFilterTable
+      le = fkind == kFilterCount ? launch_filter_count(F, fgrid, L.stream)
+           : fkind == kFilterTable
                ? launch_filter_table(F, fgrid, L.stream)
                : launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, L.stream);
       if (le != hipSuccess) return hip_fail(le, "filter kernel launch");
@@ -761,7 +904,7 @@ int ScanJob::enqueue(int attempt) {
     // right dilation: blocks a match END can reach from a piece occurrence; the bit-plane filter
     // marks those blocks itself (it knows the piece), the other filters mark the occurrence's block
     if (!ext_desc) {
-      le = launch_build_chunks(d_bitmap, n_words, n_blocks, first_owned, P.wb, fkind == kFilterPlanes ? 0u : P.wb, maxlen, L.d_desc.p,
+      le = launch_build_chunks(d_bitmap, n_words, n_blocks, first_owned, P.wb, fkind == kFilterPlanes || fkind == kFilterCount ? 0u : P.wb, maxlen, L.d_desc.p,
                                d_counts + 1, desc_cap, d_counters + 2, L.stream);
       if (le != hipSuccess) return hip_fail(le, "chunk builder launch");
     }

@@ -1,0 +1,27 @@
+import sys, time, json
+sys.path.insert(0, '.')
+import numpy as np, sassy_amd
+n = 3_000_000_000
+buf = sassy_amd.DeviceBuffer(n + 64)
+sassy_amd.generate_dna(buf.ptr, n, 42, 0)
+rng = np.random.default_rng(1)
+def pat(m, seed): 
+    r = np.random.default_rng(seed); return bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0,4,m)])
+def run(profile, p, k, steps=5):
+    s = sassy_amd.Searcher(profile, rc=False)
+    s.set_timing(2)
+    s.search_shard(p, buf.ptr, 0, n, 0, n, k)
+    t0 = time.perf_counter()
+    for _ in range(steps): r = s.search_shard(p, buf.ptr, 0, n, 0, n, k)
+    dt = (time.perf_counter() - t0) / steps
+    st = s.stats()
+    print(json.dumps({"profile": profile, "m": len(p), "k": k, "ms": round(dt*1e3, 3), "matches": len(r),
+        **{q: (round(st[q], 3) if isinstance(st[q], float) else st[q]) for q in ("filtered", "piece_len", "filter_ms", "scan_ms", "trace_ms", "hit_blocks", "chunks")}}), flush=True)
+run("dna", pat(32, 43), 3)
+run("iupac", pat(32, 43), 3)
+p = bytearray(pat(200, 44)); p[50], p[100], p[150], p[199] = ord("N"), ord("R"), ord("Y"), ord("W")
+run("iupac", bytes(p), 20)
+run("iupac", pat(20, 45), 2)
+run("dna", pat(100, 46), 10)
+run("iupac", pat(64, 47), 6)
+run("iupac", pat(1000, 48), 100, steps=2)
