@@ -632,7 +632,7 @@ int ScanJob::prepare() {
     const bool can_generic = (uint64_t)pieces * q <= 255;   // its term table holds 256 piece rows
     if (can_planes && (env_kind == 0 || env_kind == kFilterPlanes)) fkind = kFilterPlanes;
     else if (can_table && (env_kind == 0 || env_kind == kFilterTable || !can_generic)) fkind = kFilterTable;
-    else if (!can_generic) return fail(SASSY_HIP_EUNSUPPORTED, "k too large for the prefilter's piece table");
+    else if (!can_generic) { q = 0; filtered = false; }  // too many piece rows for any filter: stream the full DP
     if (fkind == kFilterTable) {
       const uint32_t tq = std::min<uint32_t>(q, 9);
       const bool cached = L.table_q == tq && L.table_r == 0 && L.table_k == k && L.table_profile == (int)S->profile &&
@@ -645,8 +645,8 @@ int ScanJob::prepare() {
           L.table_pattern.assign(pat, pat + plan.m);
         } else {
           L.table_q = 0;
-          if (!can_generic) return fail(SASSY_HIP_EUNSUPPORTED, "pattern too ambiguous / k too large for the prefilter");
           fkind = kFilterGeneric;
+          if (!can_generic) { q = 0; filtered = false; }
         }
       }
       if (fkind == kFilterTable) q = tq;

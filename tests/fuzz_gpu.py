@@ -1,0 +1,146 @@
+"""Time-boxed differential fuzz of the HIP path against the oracle on a GPU box (beyond the seeded
+cases of tests/test_gpu_parity.py): random profiles, pattern shapes, text compositions (random,
+periodic, low complexity, planted near-matches with worst-case edit spacing, stray letters), both
+strands, search / search_all, overhang.  Stops at the first mismatch and prints the reproducer.
+
+    python tests/fuzz_gpu.py [--seconds 120] [--seed 1]
+"""
+import argparse
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402  (test infrastructure: this tool is a checker, not the product)
+import sassy_amd  # noqa: E402
+
+
+def rand_seq(rng, n, alphabet):
+    return bytes(rng.choice(alphabet) for _ in range(n))
+
+
+def mutate(rng, seq, edits, spaced=0):
+    out = bytearray(seq)
+    for e in range(edits):
+        if not out:
+            break
+        i = (spaced * (e + 1) - 1) % len(out) if spaced else rng.randrange(len(out))
+        kind = rng.randrange(3)
+        if kind == 0:
+            out[i] = rng.choice([x for x in b"ACGT" if x != out[i]] or b"A")
+        elif kind == 1:
+            out.insert(i, rng.choice(b"ACGT"))
+        else:
+            del out[i]
+    return bytes(out)
+
+
+def key(ms):
+    return [(m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, m.strand, m.cigar) for m in ms]
+
+
+def one_case(rng, searchers):
+    profile = rng.choice(["dna", "iupac", "iupac", "ascii"])
+    m = rng.choice([4, 8, 12, 16, 20, 21, 24, 31, 32, 33, 40, 48, 63, 64, 65, 70, 96, 100, 128, 150, 200, 257, 400])
+    kmax = max(0, min(m - 1, m // 4))
+    k = rng.choice([0, 1, 2, 3, 4, 6, 8, 10, 16, 25, 40])
+    k = min(k, kmax)
+    n = rng.choice([500, 5_000, 20_000, 70_000, 150_000, 300_000])
+    if m >= 200:
+        n = min(n, 70_000)
+    pal = {"dna": b"ACGT", "iupac": b"ACGTNRYSWKMBDHV", "ascii": b"ACGTXYZ acgt"}[profile]
+    pat = rand_seq(rng, m, pal if rng.random() < 0.3 else pal[:4])
+    if rng.random() < 0.15:  # low-complexity pattern
+        unit = rand_seq(rng, rng.randrange(1, 5), b"ACGT")
+        pat = (unit * (m // len(unit) + 1))[:m]
+    comp = rng.random()
+    if comp < 0.55:
+        text = bytearray(rand_seq(rng, n, b"ACGT"))
+    elif comp < 0.75:
+        unit = rand_seq(rng, rng.randrange(1, 40), b"ACGT")
+        text = bytearray((unit * (n // len(unit) + 1))[:n])
+        for _ in range(n // 200):
+            text[rng.randrange(n)] = rng.choice(b"ACGT")
+    else:  # text made of pieces of the pattern
+        text = bytearray()
+        plain = bytes(c if c in b"ACGT" else 65 for c in pat.upper())
+        while len(text) < n:
+            a = rng.randrange(len(plain))
+            b = rng.randrange(a, len(plain)) + 1
+            text += plain[a:b]
+            if rng.random() < 0.5:
+                text += rand_seq(rng, rng.randrange(0, 30), b"ACGT")
+        text = text[:n]
+    plain = bytes(c if c in b"ACGT" else 65 for c in pat.upper())
+    for _ in range(rng.randrange(0, 8)):
+        ins = mutate(rng, plain, rng.randrange(0, k + 2), spaced=rng.choice([0, 0, 5, 6, 7, max(1, m // (k + 1))]))
+        if len(ins) + 2 >= n:
+            continue
+        at = rng.choice([0, n - len(ins), rng.randrange(0, n - len(ins))])
+        text[at:at + len(ins)] = ins
+    if profile != "dna" and rng.random() < 0.4:
+        stray = {"iupac": b"NRYnacgtuUX-*", "ascii": b"XYZ xyz"}[profile]
+        for _ in range(rng.randrange(1, 40)):
+            text[rng.randrange(n)] = rng.choice(stray)
+    elif profile == "dna" and rng.random() < 0.3:
+        for _ in range(rng.randrange(1, 200)):
+            i = rng.randrange(n)
+            text[i] = text[i] | 0x20
+    text = bytes(text)
+    rc = profile != "ascii" and rng.random() < 0.4
+    allm = rng.random() < 0.25
+    overhang = profile == "iupac" and rng.random() < 0.12 and n <= 20_000
+    desc = dict(profile=profile, m=m, k=k, n=n, rc=rc, all_minima=allm, overhang=overhang)
+    if overhang:
+        alpha = rng.choice([0.0, 0.3, 0.5, 1.0])
+        s = sassy_amd.Searcher(profile, rc=rc, alpha=alpha)
+        got = s.search_all(pat, text, k) if allm else s.search(pat, text, k)
+        want = oracle.search_overhang(profile, pat, text, k, alpha, rc=rc, all_minima=allm)
+        desc["alpha"] = alpha
+    else:
+        s = searchers[(profile, rc)]
+        got = s.search_all(pat, text, k) if allm else s.search(pat, text, k)
+        want = oracle.search(profile, pat, text, k, rc=rc, all_minima=allm)
+    desc["filtered"] = s.stats()["filtered"]
+    desc["matches"] = len(want)
+    ok = key(got) == key(want)
+    return ok, desc, pat, text, got, want
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = random.Random(args.seed)
+    searchers = {(p, rc): sassy_amd.Searcher(p, rc=rc) for p in ("dna", "iupac", "ascii") for rc in (False, True)
+                 if not (p == "ascii" and rc)}
+    t0 = time.time()
+    cases = 0
+    kinds = {}
+    total_matches = 0
+    while time.time() - t0 < args.seconds:
+        ok, desc, pat, text, got, want = one_case(rng, searchers)
+        cases += 1
+        kinds[desc["filtered"]] = kinds.get(desc["filtered"], 0) + 1
+        total_matches += desc["matches"]
+        if not ok:
+            print("MISMATCH", desc)
+            print("pattern", pat)
+            gk, wk = key(got), key(want)
+            print("got", len(gk), "want", len(wk))
+            extra = [x for x in gk if x not in set(wk)][:5]
+            missing = [x for x in wk if x not in set(gk)][:5]
+            print("extra", extra)
+            print("missing", missing)
+            with open(os.path.join(ROOT, "gpurun_out", "fuzz_fail.bin"), "wb") as fh:
+                fh.write(repr(desc).encode() + b"\n" + pat + b"\n" + text)
+            sys.exit(1)
+    print(f"fuzz ok: {cases} cases, {total_matches} matches compared, prefilter kinds used {kinds}, seed {args.seed}")
+
+
+if __name__ == "__main__":
+    main()

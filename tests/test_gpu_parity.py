@@ -346,6 +346,21 @@ def test_qgram_count_filter_worst_case_edits(sassy):
             assert s.stats()["filtered"] in (3, 4), (profile, m, k, s.stats()["filtered"])
 
 
+def test_many_pieces_without_a_filter_stream(sassy):
+    """Ascii with more piece rows than any prefilter takes (41 pieces of 9 rows): the search must fall
+    back to the streaming DP, not refuse (found by tests/fuzz_gpu.py)."""
+    rng = random.Random(9)
+    m, k = 400, 40
+    pat = bytes(rng.choice(b"ACGTXYZ acgt") for _ in range(m))
+    text = bytearray(rng.choice(b"ACGT xyz") for _ in range(20_000))
+    for at in (0, 5000, 12_345, 20_000 - m):
+        text[at:at + m] = mutate(rng, pat, rng.randrange(0, k + 1))[:m]
+    s = sassy.Searcher("ascii", rc=False)
+    want = oracle.search("ascii", pat, bytes(text), k)
+    assert len(want) >= 3
+    assert_same(s.search(pat, bytes(text), k), want)
+
+
 def test_reporting_modes(sassy, kats):
     """search_with_fn, only_best_match, max_n_frac: the reference's known
     answers, then seeded fuzz against the oracle's restatement of src/search.rs:884-937."""
