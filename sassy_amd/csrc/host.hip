@@ -797,8 +797,6 @@ int ScanJob::prepare() {
       }
     }
     // Dna with <= 8 pieces: the filter works on the two code bit planes (filter_dna_kernel)
-    static const int env_planes = getenv("SASSY_HIP_FILTER_PLANES") ? atoi(getenv("SASSY_HIP_FILTER_PLANES")) : 1;
-    (void)env_planes;
     F.piece_planes = fkind == kFilterPlanes ? 1u : 0u;
     F.qgram_table = fkind == kFilterTable || fkind == kFilterCount ? L.d_table.p : nullptr;
     F.count_r = count_r;

@@ -14,6 +14,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("SASSY_HIP_MULTI_MIN_TEXT", "16384")  # let the multi-pattern prefilter see small texts
 import oracle  # noqa: E402  (test infrastructure: this tool is a checker, not the product)
 import sassy_amd  # noqa: E402
 
@@ -110,6 +111,123 @@ def one_case(rng, searchers):
     return ok, desc, pat, text, got, want
 
 
+def many_case(rng, searchers):
+    """search_many: several patterns x several texts (batched / per-text paths) against per-pair oracle calls."""
+    profile = rng.choice(["dna", "iupac", "iupac", "ascii"])
+    rc = profile != "ascii" and rng.random() < 0.5
+    allm = rng.random() < 0.2
+    pal = {"dna": b"ACGT", "iupac": b"ACGTNRY", "ascii": b"ACGTXYZ "}[profile]
+    npat = rng.randrange(1, 5)
+    pats = []
+    for _ in range(npat):
+        m = rng.choice([8, 16, 20, 24, 32, 40, 64, 100])
+        pats.append(rand_seq(rng, m, pal if rng.random() < 0.3 else pal[:4]))
+    k = rng.choice([0, 1, 2, 3, 5])
+    k = min(k, min(len(p) for p in pats) - 1)
+    texts = []
+    for _ in range(rng.choice([1, 2, 5, 30, 200])):
+        n = rng.choice([0, 1, 10, 63, 64, 65, 150, 300, 1000, 5000])
+        t = bytearray(rand_seq(rng, n, b"ACGT"))
+        if n > 120 and rng.random() < 0.7:
+            p = rng.choice(pats)
+            ins = mutate(rng, bytes(c if c in b"ACGT" else 65 for c in p), rng.randrange(0, k + 2))
+            if len(ins) < n:
+                at = rng.choice([0, n - len(ins), rng.randrange(0, n - len(ins) + 1)])
+                t[at:at + len(ins)] = ins
+        if profile == "iupac" and rng.random() < 0.3 and n:
+            t[rng.randrange(n)] = rng.choice(b"NRYn")
+        texts.append(bytes(t))
+    s = searchers[(profile, rc)]
+    got = s.search_many(pats, texts, k, all_minima=allm)
+    gk = [(m.pattern_idx, m.text_idx, m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, m.strand, m.cigar)
+          for m in got]
+    wk = []
+    for pi, p in enumerate(pats):
+        for ti, t in enumerate(texts):
+            for m in oracle.search(profile, p, t, k, rc=rc, all_minima=allm):
+                wk.append((pi, ti, m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, m.strand, m.cigar))
+    desc = dict(mode="many", profile=profile, k=k, rc=rc, all_minima=allm, npat=npat, ntext=len(texts),
+                filtered=s.stats()["filtered"], matches=len(wk))
+    return sorted(gk) == sorted(wk), desc, b"|".join(pats), b"|".join(texts), gk, wk
+
+
+def encoded_case(rng, searchers):
+    """search_encoded_patterns (incl. the multi-pattern prefilter when the text is long enough)."""
+    profile = rng.choice(["dna", "iupac"])
+    rc = rng.random() < 0.5
+    m = rng.choice([12, 16, 20, 23, 24, 32, 40])
+    k = min(rng.choice([0, 1, 2, 3]), m // 6)
+    npat = rng.choice([1, 3, 8, 9, 40, 70])
+    pats = [rand_seq(rng, m, b"ACGT") for _ in range(npat)]
+    n = rng.choice([200, 3000, 20_000, 60_000])
+    t = bytearray(rand_seq(rng, n, b"ACGT"))
+    for p in pats[:20]:
+        ins = mutate(rng, p, rng.randrange(0, k + 2))
+        if len(ins) < n:
+            at = rng.randrange(0, n - len(ins) + 1)
+            t[at:at + len(ins)] = ins
+    if rng.random() < 0.2:
+        for _ in range(20):
+            i = rng.randrange(n); t[i] = t[i] | 0x20
+    if profile == "iupac" and rng.random() < 0.2:
+        t[rng.randrange(n)] = ord("N")
+    t = bytes(t)
+    s = searchers[(profile, rc)]
+    enc = s.encode_patterns(pats)
+    got = s.search_encoded_patterns(enc, t, k)
+    want = oracle.search_encoded(profile, pats, t, k, rc=rc)
+    kk = lambda m: (m.pattern_idx, m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, m.strand, m.cigar)
+    gk, wk = sorted(kk(m) for m in got), sorted(kk(m) for m in want)
+    desc = dict(mode="encoded", profile=profile, m=m, k=k, rc=rc, npat=npat, n=n, filtered=s.stats()["filtered"],
+                matches=len(wk))
+    return gk == wk, desc, b"|".join(pats), t, gk, wk
+
+
+def shard_case(rng, searchers):
+    """search_shard over random 64-aligned cuts of a device text, chain resolved like multigpu does."""
+    profile = rng.choice(["dna", "iupac"])
+    m = rng.choice([8, 20, 32, 33, 64, 100])
+    k = min(rng.choice([0, 1, 3, 5, 8]), m // 4)
+    n = rng.choice([3000, 20_000, 100_000])
+    pat = rand_seq(rng, m, b"ACGT")
+    if rng.random() < 0.3:
+        unit = rand_seq(rng, rng.randrange(1, 4), b"ACGT")
+        pat = (unit * (m // len(unit) + 1))[:m]
+        t = bytearray((unit * (n // len(unit) + 1))[:n])
+        for _ in range(n // 300):
+            t[rng.randrange(n)] = rng.choice(b"ACGT")
+    else:
+        t = bytearray(rand_seq(rng, n, b"ACGT"))
+    cuts = sorted({64 * rng.randrange(1, n // 64) for _ in range(rng.randrange(1, 6))})
+    for c in cuts:  # near-matches across the cuts
+        ins = mutate(rng, pat, rng.randrange(0, k + 1))
+        at = max(0, min(n - len(ins), c - rng.randrange(0, len(ins) + 1)))
+        t[at:at + len(ins)] = ins
+    t = bytes(t)
+    halo = sassy_amd.required_halo(m, k)
+    cuts = [c for c in cuts if c >= halo] or [64 * ((n // 2) // 64)]
+    cuts = [c for c in cuts if c >= halo]
+    bounds = [0] + cuts + [n]
+    buf = sassy_amd.DeviceBuffer(n + 256)
+    buf.upload(t)
+    s = searchers[(profile, False)]
+    allm = []
+    prev_state = 1
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        h = 0 if a == 0 else halo
+        r = s.search_shard(pat, buf.ptr + a - h, h, b - a, a, n, k)
+        ms = list(r.matches)
+        if r.conditional_index >= 0 and prev_state != 1:
+            del ms[r.conditional_index]
+        allm += ms
+        if r.exit_state != 2:
+            prev_state = r.exit_state
+    buf.free()
+    want = oracle.search(profile, pat, t, k)
+    desc = dict(mode="shard", profile=profile, m=m, k=k, n=n, bounds=bounds, filtered=s.stats()["filtered"], matches=len(want))
+    return key(allm) == key(want), desc, pat, t, allm, want
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -123,14 +241,16 @@ def main():
     kinds = {}
     total_matches = 0
     while time.time() - t0 < args.seconds:
-        ok, desc, pat, text, got, want = one_case(rng, searchers)
+        mode = rng.random()
+        fn = one_case if mode < 0.55 else many_case if mode < 0.7 else encoded_case if mode < 0.85 else shard_case
+        ok, desc, pat, text, got, want = fn(rng, searchers)
         cases += 1
         kinds[desc["filtered"]] = kinds.get(desc["filtered"], 0) + 1
         total_matches += desc["matches"]
         if not ok:
             print("MISMATCH", desc)
             print("pattern", pat)
-            gk, wk = key(got), key(want)
+            gk, wk = (key(got), key(want)) if desc.get("mode") is None or desc.get("mode") == "shard" else (got, want)
             print("got", len(gk), "want", len(wk))
             extra = [x for x in gk if x not in set(wk)][:5]
             missing = [x for x in wk if x not in set(gk)][:5]
