@@ -125,6 +125,10 @@ struct ScanParams {
   const ChunkDesc* desc;      // list mode: chunk descriptors
   const uint32_t* desc_count; // list mode: number of descriptors (device)
   uint32_t desc_cap;
+  // list_words_kernel (a group of 2^list_group_log lanes per chunk, one pattern word each) takes the
+  // launch when there are at most list_words_max chunks (0: never), list_kernel otherwise
+  uint32_t list_words_max;
+  uint32_t list_group_log;
   uint8_t slot_val[kMaxSlots]; // per slot: Dna 2-bit code, Iupac base-set nibble, Ascii byte
   // ---- overhang (kScanOverhang; reference: src/search.rs:347-356, 1274-1282, 1695-1748) ----
   const uint32_t* ov_tab;     // device, nwords words: left-edge vertical deltas at the text start

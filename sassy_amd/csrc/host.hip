@@ -909,6 +909,17 @@ int ScanJob::enqueue(int attempt) {
     P.desc = ext_desc ? ext_desc : L.d_desc.p;
     P.desc_count = d_counts + 1;
     P.desc_cap = desc_cap;
+    // multi-word patterns with few chunks: one lane per pattern word instead of one lane per chunk
+    // (up to 8192 waves' worth of chunks; beyond that the lane-per-chunk kernel fills the chip anyway)
+    P.list_words_max = 0;
+    P.list_group_log = 0;
+    static const int env_words = getenv("SASSY_HIP_LIST_WORDS") ? atoi(getenv("SASSY_HIP_LIST_WORDS")) : 1;
+    if (env_words && !ext_desc && plan.nwords >= 2 && plan.nwords <= 64 && !(P.flags & kScanOverhang)) {
+      uint32_t glog = 1;
+      while ((1u << glog) < plan.nwords) ++glog;
+      P.list_group_log = glog;
+      P.list_words_max = (8192u * 64u) >> glog;
+    }
     // the descriptor count lives on the device: launch for the capacity, idle waves exit at once
     const uint32_t lgrid = (desc_cap + 255) / 256;
     le = launch_list_any(S->profile, P, lgrid, (size_t)kWavesPerGroup * P.lds_per_wave, L.stream);

@@ -34,6 +34,8 @@
 // No MFMA: this is integer bit-twiddling bounded by VALU issue and HBM reads.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace sassy_hip {
@@ -324,6 +326,9 @@ __device__ __forceinline__ uint32_t row_mask_off(const uint32_t (&pk)[8], int r)
 }
 
 // The rows of one 32-row word.  pk_in holds the profile slot of each row (one byte per row).
+// SCALAR_PK: the word (and so its row table) is the same for the whole wave (scalar registers);
+// false: every lane works on its own word (list_words_kernel).
+template <bool SCALAR_PK = true>
 __device__ __forceinline__ void dp_word(DpWord& V, const unsigned char* my_masks, uint32_t ohp, uint32_t ohm,
                                         const uint32_t (&pk_in)[8], uint32_t rows, uint32_t& nhp_out,
                                         uint32_t& nhm_out) {
@@ -333,7 +338,7 @@ __device__ __forceinline__ void dp_word(DpWord& V, const unsigned char* my_masks
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     pk[i] = pk_in[i];
-    asm volatile("" : "+s"(pk[i]));
+    if constexpr (SCALAR_PK) asm volatile("" : "+s"(pk[i]));
   }
   uint32_t nhp = 0, nhm = 0, done = 0;
   uint2 eqn[4];
@@ -1189,6 +1194,7 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   if (n_desc > P.desc_cap) n_desc = P.desc_cap;
   const uint32_t wave_first = (blockIdx.x * kWavesPerGroup + wave) * kWave;
   if (wave_first >= n_desc) return;  // wave-uniform
+  if (n_desc <= P.list_words_max) return;  // few chunks of a multi-word pattern: list_words_kernel runs them
   const uint32_t di = wave_first + lane;
   const bool has_chunk = di < n_desc;
   ChunkDesc d;
@@ -1314,6 +1320,145 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   }
 }
 
+// ====================================================================== K1-list, few long chunks
+// The lane-per-chunk list kernel is bound by the instruction latency of ONE wave when the chunks
+// are few and the pattern has several 32-row words (a q-gram counting prefilter leaves a few
+// thousand chunks of ~10 blocks x 7 words for config 3: 0.4 ms with most SIMDs idle).  Here a chunk
+// is worked on by a group of G = 2^j >= nwords lanes, lane w of the group owning pattern word w, as
+// a software pipeline over the blocks: in step s lane w processes block s - w with the horizontal
+// deltas lane w-1 produced for that block one step earlier (ds_bpermute within the group) and the
+// vertical deltas it kept in registers from block s - w - 1.  A chunk of n blocks takes
+// n + nwords - 1 word steps instead of n * nwords, and a wave holds 64 / G chunks, so the same
+// work spreads over G times as many SIMDs.  Same row code, report rule and seam bookkeeping
+// (scan_block, by the lane of the last word) as list_kernel; which of the two kernels takes a
+// launch is decided on the device from the number of chunks (P.list_words_max).
+template <int PROFILE, int NS>
+__global__ __launch_bounds__(256) void list_words_kernel(const ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  unsigned char* mask_bytes = smem + (size_t)wave * (NS * 512u);  // [NS][64] u64, private per lane
+
+  uint32_t n_desc = *P.desc_count;
+  if (n_desc > P.desc_cap) n_desc = P.desc_cap;
+  if (n_desc > P.list_words_max) return;  // many chunks: list_kernel (one lane each) runs them
+  const uint32_t glog = P.list_group_log;
+  const uint32_t G = 1u << glog;
+  const uint32_t per_wave = 64u >> glog;
+  const uint32_t wave_first = (blockIdx.x * kWavesPerGroup + wave) * per_wave;
+  if (wave_first >= n_desc) return;  // wave-uniform
+  const uint32_t w = lane & (G - 1u);
+  const uint32_t di = wave_first + (lane >> glog);
+  const uint32_t nwords = P.nwords;
+  const bool has_chunk = di < n_desc && w < nwords;
+  ChunkDesc d;
+  d.own_lo = d.own_hi = d.flags = d.pad_ = 0;
+  if (di < n_desc) d = P.desc[di];
+  const uint64_t own_lo = d.own_lo, own_hi = d.own_hi;
+  const bool clear_before = (d.flags & kDescClearBefore) != 0;
+  uint64_t blk0 = own_lo;
+  if (!clear_before) blk0 = own_lo > P.wb ? own_lo - P.wb : 0;
+  const bool at_text_start = blk0 == 0 && (P.flags & kScanTextStart);
+  const bool exact_start = clear_before || at_text_start;
+  const int64_t x0 = exact_start ? -1 : (int64_t)(blk0 * 64 + P.m + P.k);
+  const uint32_t my_iters = has_chunk ? (uint32_t)(own_hi - blk0) : 0u;
+
+  const int k = (int)P.k;
+  const uint32_t m = P.m;
+  const bool last_word = w + 1 == nwords;
+  const uint32_t last_rows = m - 32 * (nwords - 1);
+  const uint32_t rows = last_word ? last_rows : 32u;
+  uint32_t pkw[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) pkw[i] = has_chunk ? P.row_tab[8 * w + i] : 0u;
+  // fresh start: every vertical delta on the left edge is +1
+  uint32_t ohp = (last_word && last_rows != 32) ? ~(0xFFFFFFFFu >> last_rows) : 0xFFFFFFFFu;
+  uint32_t ohm = 0;
+  uint32_t st = kStDec;
+  EmitCtx ctx;
+  ctx.cand = P.cand;
+  ctx.cand_count = P.cand_count;
+  ctx.text_len = P.text_len;
+  ctx.global_offset = P.global_offset;
+  ctx.cand_cap = P.cand_cap;
+  ctx.k = P.k;
+  ctx.flags = P.flags;
+  ctx.alpha = 0.0f;
+  ctx.ov_steps = 0u;
+  ctx.text_begin = 0;
+  ctx.tag = 0;
+  const unsigned char* my_masks = mask_bytes + lane * 8;
+  DpWord Vout;
+  Vout.vpl = Vout.vph = Vout.vml = Vout.vmh = 0;
+  int ds_out = 0;
+
+  // the text of the lane's next block is fetched one step ahead (a lone wave per SIMD cannot hide
+  // the load latency behind other waves)
+  auto fetch = [&](uint32_t step, uint32_t (&dst)[16]) {
+    const bool on = has_chunk && step >= w && step - w < my_iters;
+    const uint64_t blk = blk0 + (uint64_t)(step - w);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint64_t off = blk * 64 + (uint64_t)c * 16;
+      uint4 v = make_uint4(0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u);
+      if (on) {
+        if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
+        else v = load_tail16(P.text, off, P.text_len);
+      }
+      dst[4 * c] = v.x; dst[4 * c + 1] = v.y; dst[4 * c + 2] = v.z; dst[4 * c + 3] = v.w;
+    }
+  };
+  uint32_t xn[16];
+  fetch(0, xn);
+  for (uint32_t s = 0; __any(s < my_iters + nwords - 1u && my_iters != 0); ++s) {
+    const bool active = has_chunk && s >= w && s - w < my_iters;
+    const uint64_t b = blk0 + (uint64_t)(s - w);
+    uint32_t x[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) x[c] = xn[c];
+    fetch(s + 1, xn);
+    {
+      uint2 msk[NS];
+      build_masks<PROFILE, NS>(x, P, msk);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) *reinterpret_cast<uint2*>(mask_bytes + q * 512 + lane * 8) = msk[q];
+    }
+    // the row above this word: what the lane of word w-1 left for this block one step ago
+    DpWord V;
+    V.vpl = __shfl_up(Vout.vpl, 1, 64);
+    V.vph = __shfl_up(Vout.vph, 1, 64);
+    V.vml = __shfl_up(Vout.vml, 1, 64);
+    V.vmh = __shfl_up(Vout.vmh, 1, 64);
+    int ds = __shfl_up(ds_out, 1, 64);
+    if (w == 0) { V.vpl = V.vph = V.vml = V.vmh = 0; ds = 0; }
+    ds += __popc(ohp) - __popc(ohm);
+    uint32_t nhp, nhm;
+    dp_word<false>(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm);
+    if (active) {
+      ohp = nhp;
+      ohm = nhm;
+      Vout = V;
+      ds_out = ds;
+      if (last_word) {
+        if (row_maybe_live(ds, V, k)) {
+          const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
+          st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
+        } else {
+          st = kStDec;
+        }
+      }
+    }
+  }
+  if (has_chunk && last_word) {
+    const uint32_t fin = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
+    P.chunk_state[di] = (uint8_t)fin;
+    if (own_hi == P.n_blocks) {
+      uint32_t* tail = P.cand_count + kCtlTailWord;
+      tail[0] = (uint32_t)own_lo; tail[1] = fin; tail[2] = d.flags; tail[3] = 1u;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ launcher
 template <int PROFILE, int NS, int SB>
 static hipError_t launch_sb(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
@@ -1364,6 +1509,12 @@ static hipError_t launch_list_one(const ScanParams& P, uint32_t grid, size_t sme
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
+  }
+  if (P.list_words_max) {  // few chunks of a multi-word pattern are taken by the word-pipelined kernel
+    const uint32_t per_group = 256u >> P.list_group_log;
+    const uint32_t wgrid = (std::min(P.list_words_max, P.desc_cap) + per_group - 1) / per_group;
+    hipLaunchKernelGGL((list_words_kernel<PROFILE, NS>), dim3(wgrid), dim3(256), (size_t)kWavesPerGroup * NS * 512u,
+                       stream, P);
   }
   hipLaunchKernelGGL((list_kernel<PROFILE, NS>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
