@@ -25,6 +25,9 @@ extern "C" {
 #define SASSY_HIP_ALL_MINIMA 1u     /* Searcher::search_all (src/search.rs:685-700) */
 #define SASSY_HIP_WITHOUT_TRACE 2u  /* Searcher::without_trace (src/search.rs:448-451,1464-1475) */
 #define SASSY_HIP_TEXT_ON_DEVICE 4u /* `text` is a device pointer (e.g. a torch tensor's data_ptr) */
+#define SASSY_HIP_TEXT_UNCHANGED 8u /* with TEXT_ON_DEVICE: the bytes at `text` are the same as in this searcher's
+                                       previous call with this pointer and length (many patterns, one resident
+                                       text): the reversed copy the Rc strand scans is reused, not rebuilt */
 
 /* Full match record = reference Match (src/search.rs:35-62).  cigar is the SAM text the
  * reference's Cigar::to_string gives ("3=1X"), stored in the result's string pool.

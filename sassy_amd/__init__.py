@@ -29,6 +29,7 @@ _SO = os.path.join(_HERE, "lib", "libsassy_hip.so")
 ALL_MINIMA = 1
 WITHOUT_TRACE = 2
 TEXT_ON_DEVICE = 4
+TEXT_UNCHANGED = 8
 UINT64_MAX = (1 << 64) - 1
 
 
@@ -472,11 +473,20 @@ class Searcher:
         _check(lib().sassy_hip_get_stats(self._h, C.byref(st)))
         return st.as_dict()
 
+    def text_unchanged(self, on: bool = True) -> "Searcher":
+        """Promise that a device-resident text passed to the following searches holds the same bytes as
+        in this searcher's previous call with that tensor (SASSY_HIP_TEXT_UNCHANGED): the reversed copy
+        the Rc strand scans is then reused instead of rebuilt for every pattern."""
+        self._text_unchanged = bool(on)
+        return self
+
     def _search(self, pattern: bytes, text, k: int, flags: int) -> Result:
         pattern = bytes(pattern)
         addr, n, keep, on_dev = _ptr_len(text)
         if on_dev:
             flags |= TEXT_ON_DEVICE
+            if getattr(self, "_text_unchanged", False):
+                flags |= TEXT_UNCHANGED
         out = C.c_void_p()
         _check(lib().sassy_hip_search(self._h, pattern, len(pattern), addr, n, k, flags, C.byref(out)))
         return Result(out)

@@ -62,23 +62,54 @@ __global__ void scatter_bytes_kernel(uint8_t* text, uint64_t n, uint64_t first, 
 }
 
 // out[i] = in[n-1-i]   (the reference searches complement(pattern) against the reversed text for
-// the Rc strand, reference: src/search.rs:813-858).  16 output bytes per thread.
-__global__ __launch_bounds__(256) void reverse_kernel(const uint8_t* in, uint8_t* out, uint64_t n) {
+// the Rc strand, reference: src/search.rs:813-858).  HBM bound (n bytes in, n bytes out): every
+// thread writes one aligned 16-byte vector; its 16 source bytes [n-o-16, n-o) are misaligned by
+// n mod 16, so it reads the two aligned vectors that hold them (misaligned 16-byte loads cost a
+// third of the stream rate, tools/ubench/unaligned_read.hip) and one v_perm_b32 per output dword
+// does the byte shift and the reversal at once.  `in` and `out` are 16-byte aligned.
+__global__ __launch_bounds__(256) void reverse_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                      uint64_t n) {
   const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
   const uint64_t nv = (n + 15) / 16;
+  const uint32_t r = (uint32_t)(n & 15u);      // the source pieces start r bytes into an aligned vector
+  const uint32_t rb = r & 3u, rd = r >> 2;
+  // v_perm_b32(hi, lo, sel): byte k of the result = byte sel[k] of (hi:lo); reversed bytes rb+3 .. rb
+  const uint32_t sel = ((rb + 3u)) | ((rb + 2u) << 8) | ((rb + 1u) << 16) | (rb << 24);
   for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nv; t += stride) {
     const uint64_t o0 = t * 16;
-    uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const uint64_t o = o0 + q;
-      const uint32_t ch = o < n ? in[n - 1 - o] : 0u;
-      w[q >> 2] |= ch << (8 * (q & 3));
-    }
-    if (o0 + 16 <= n) {
-      *reinterpret_cast<uint4*>(out + o0) = make_uint4(w[0], w[1], w[2], w[3]);
-    } else {
-      for (int q = 0; q < 16 && o0 + q < n; ++q) out[o0 + q] = (uint8_t)((w[q >> 2] >> (8 * (q & 3))) & 0xFFu);
+    if (t >= 1 && o0 + 16 <= n) {
+      const uint64_t a = n - o0 - 16 - r;      // aligned; [a, a + 32) lies inside the text for t >= 1
+      const uint4 lo = *reinterpret_cast<const uint4*>(in + a);
+      uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, 0u, 0u, 0u, 0u};
+      if (r != 0) {
+        const uint4 hi = *reinterpret_cast<const uint4*>(in + a + 16);
+        w[4] = hi.x; w[5] = hi.y; w[6] = hi.z; w[7] = hi.w;
+      }
+      // source dword j (bytes r + 4j .. r + 4j + 3 of the 32) -> output dword 3 - j, bytes reversed;
+      // rd is uniform, so the dword pick is a scalar switch with static register indices
+      uint32_t d[4];
+#define SASSY_REV_CASE(RD)                                                                   \
+  case RD:                                                                                   \
+    d[3] = __builtin_amdgcn_perm(w[RD + 1], w[RD], sel);                                     \
+    d[2] = __builtin_amdgcn_perm(w[RD + 2], w[RD + 1], sel);                                 \
+    d[1] = __builtin_amdgcn_perm(w[RD + 3], w[RD + 2], sel);                                 \
+    d[0] = __builtin_amdgcn_perm(w[RD + 4], w[RD + 3], sel);                                 \
+    break;
+      switch (rd) {
+        SASSY_REV_CASE(0)
+        SASSY_REV_CASE(1)
+        SASSY_REV_CASE(2)
+        default:
+          d[3] = __builtin_amdgcn_perm(w[4], w[3], sel);
+          d[2] = __builtin_amdgcn_perm(w[5], w[4], sel);
+          d[1] = __builtin_amdgcn_perm(w[6], w[5], sel);
+          d[0] = __builtin_amdgcn_perm(w[7], w[6], sel);  // rb = 3 at most: bytes 3..6 of (w7:w6)
+          break;
+      }
+#undef SASSY_REV_CASE
+      *reinterpret_cast<uint4*>(out + o0) = make_uint4(d[0], d[1], d[2], d[3]);
+    } else {  // the first vector (its second source vector would lie past the text) and the ragged last one
+      for (int q = 0; q < 16 && o0 + q < n; ++q) out[o0 + q] = in[n - 1 - (o0 + q)];
     }
   }
 }

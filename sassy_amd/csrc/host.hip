@@ -193,6 +193,8 @@ struct sassy_SearcherType {
   hipEvent_t ev_inputs = nullptr;  // "uploads of this call are queued" (other lanes wait for it)
   bool device_ready = false;
   DevBuf<uint8_t> d_text, d_rev;
+  const uint8_t* rev_src = nullptr;  // d_rev holds reverse(rev_src[0 .. rev_len)) (SASSY_HIP_TEXT_UNCHANGED)
+  uint64_t rev_len = 0;
 
   bool want_counters = false;
   // reporting modes of the reference's Searcher (src/search.rs:442-475)
@@ -1609,9 +1611,17 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
     for (size_t i = 0; i < plen; ++i) cp[i] = complement_char(S->profile, pattern[i]);
     PatternPlan cplan;
     if (!make_plan(S->profile, cp.data(), plen, cplan, err)) return fail(SASSY_HIP_EINVAL, err);
-    if (int rc = S->d_rev.reserve(tlen + 64)) return rc;
-    hipError_t le = launch_reverse(d_fwd, S->d_rev.p, tlen, S->stream);
-    if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
+    // the caller may promise that a device text did not change since this searcher last saw it:
+    // the reversed copy (n bytes read + n written, more than the search itself) is then still valid
+    const bool reuse = on_dev && (flags & SASSY_HIP_TEXT_UNCHANGED) && S->rev_src == d_fwd && S->rev_len == tlen &&
+                       S->d_rev.p != nullptr;
+    if (!reuse) {
+      S->rev_src = nullptr;
+      if (int rc = S->d_rev.reserve(tlen + 64)) return rc;
+      hipError_t le = launch_reverse(d_fwd, S->d_rev.p, tlen, S->stream);
+      if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
+      if (on_dev) { S->rev_src = d_fwd; S->rev_len = tlen; }
+    }
     ShardView sh{S->d_rev.p, tlen, 0, 0, true, true};
     ScanOut so;
     if (int rc = run_scan(S, sh, cplan, (uint32_t)k, all, cp.data(), !wo, tlen, so)) return rc;
@@ -1866,6 +1876,7 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
         HIP_TRY(hipMemcpyAsync(d_tab + 2 * nt, ht_rev.start.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
         HIP_TRY(hipMemcpyAsync(d_tab + 3 * nt, ht_rev.len.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
         tt_rev = TextTable{d_tab + 2 * nt, d_tab + 3 * nt, (uint32_t)nt, all ? 1u : 0u};
+        s->rev_src = nullptr;
         if (int rc = s->d_rev.reserve(total + 64)) return rc;
         hipError_t le = launch_reverse(s->d_text.p, s->d_rev.p, total, s->stream);
         if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
@@ -2010,6 +2021,7 @@ static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patt
       TextTable tt{d_tab, d_tab + nt, (uint32_t)nt, all ? 1u : 0u, 1u};
       if (s->rc) {
         HIP_TRY(hipMemcpyAsync(d_b2t, blk2text.data(), blk2text.size() * 4, hipMemcpyHostToDevice, s->stream));
+        s->rev_src = nullptr;
         if (int rc = s->d_rev.reserve(total + 64)) return rc;
         hipError_t le = launch_reverse_texts(s->d_text.p, s->d_rev.p, total, d_b2t, d_tab, d_tab + nt, pad, s->stream);
         if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");

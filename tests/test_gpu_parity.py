@@ -361,6 +361,47 @@ def test_many_pieces_without_a_filter_stream(sassy):
     assert_same(s.search(pat, bytes(text), k), want)
 
 
+def test_rc_strand_all_text_alignments_and_resident_text_reuse(sassy):
+    """The Rc strand scans a reversed copy of the text (vectorised reverse_kernel: aligned loads +
+    v_perm): every text length mod 16 and mod 64, tiny texts included; then the same device-resident
+    text searched again under SASSY_HIP_TEXT_UNCHANGED (reversed copy reused) with other patterns."""
+    rng = random.Random(123)
+    s = sassy.Searcher("dna", rc=True)
+    for n in list(range(0, 70)) + [127, 128, 129, 1000, 1001, 1007, 1015, 1016, 4099, 65_537]:
+        text = bytes(rng.choice(b"ACGT") for _ in range(n))
+        pat = bytes(rng.choice(b"ACGT") for _ in range(rng.choice([3, 8, 20])))
+        if n > 40:
+            ins = oracle.reverse_complement("dna", pat)
+            at = rng.randrange(0, n - len(ins))
+            text = text[:at] + ins + text[at + len(ins):]
+        k = rng.randrange(0, 2)
+        assert_same(s.search(pat, text, k), oracle.search("dna", pat, text, k, rc=True), (n, pat))
+    # device-resident text, many patterns
+    n = 200_003
+    text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+    pats = [bytes(rng.choice(b"ACGT") for _ in range(24)) for _ in range(6)]
+    for p in pats:
+        for strand in (0, 1):
+            ins = mutate(rng, oracle.reverse_complement("dna", p) if strand else p, rng.randrange(0, 3))
+            at = rng.randrange(0, n - 40)
+            text[at:at + len(ins)] = ins
+    text = bytes(text)
+    buf = sassy.DeviceBuffer(n + 64)
+    buf.upload(text)
+    dev = _DevText(buf.ptr, n)
+    s2 = sassy.Searcher("dna", rc=True)
+    assert_same(s2.search(pats[0], dev, 2), oracle.search("dna", pats[0], text, 2, rc=True))
+    s2.text_unchanged(True)
+    for p in pats:
+        assert_same(s2.search(p, dev, 2), oracle.search("dna", p, text, 2, rc=True))
+    # a changed text without the promise is picked up again
+    text2 = bytes(reversed(text))
+    buf.upload(text2)
+    s2.text_unchanged(False)
+    assert_same(s2.search(pats[1], dev, 2), oracle.search("dna", pats[1], text2, 2, rc=True))
+    buf.free()
+
+
 def test_reporting_modes(sassy, kats):
     """search_with_fn, only_best_match, max_n_frac: the reference's known
     answers, then seeded fuzz against the oracle's restatement of src/search.rs:884-937."""
