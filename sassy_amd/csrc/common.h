@@ -121,6 +121,17 @@ struct ScanParams {
   uint32_t count_window;      // W = ceil((m + k - Q) / 64) + 1 blocks
   uint32_t count_thresh;      // t = m + 1 - (k+1) Q
   unsigned long long* hit_bitmap;  // one bit per text block: an exact piece occurrence ends in it
+  // ---- both strands from one pass over the forward text (reference: the Rc strand is complement(pattern)
+  // against the REVERSED text, src/search.rs:813-878) ----
+  // Filters: pieces flagged in piece_mirror / the counting filter with count_rc are evaluated on the
+  // forward text for the Rc strand's pattern (their strings reversed) and mark, in hit_bitmap_rc, the
+  // blocks OF THE REVERSED TEXT (block = reversed column / 64) in which such a match can end.
+  unsigned long long* hit_bitmap_rc;
+  uint32_t piece_mirror;      // bit p: piece p belongs to the Rc strand
+  uint32_t count_rc;          // counting filter: the table holds both strands' q-grams, mark both bitmaps
+  // DP kernels (list mode): rev_n != 0 = the text this launch scans is the reverse of the rev_n bytes at
+  // `text` (logical byte i = text[rev_n - 1 - i]); never materialised
+  uint64_t rev_n;
   unsigned long long* hit_count;   // device counter of hit blocks
   const ChunkDesc* desc;      // list mode: chunk descriptors
   const uint32_t* desc_count; // list mode: number of descriptors (device)
@@ -159,6 +170,7 @@ constexpr uint32_t kTraceLdsLimit = 128 * 1024;
 
 struct TraceParams {
   const uint8_t* text;      // device buffer the candidates refer to
+  uint64_t rev_n;           // != 0: the candidates refer to the reverse of text[0 .. rev_n)
   uint64_t global_offset;   // global position of text[0]
   uint64_t total_len;       // length of the whole text (window end is clipped to it)
   const Candidate* cand;    // reports in output order (ranked by rank_kernel)

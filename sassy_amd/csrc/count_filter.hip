@@ -182,6 +182,23 @@ __global__ __launch_bounds__(256) void filter_count_kernel(const ScanParams P) {
     if (evaluate && reach) {
       atomicOr(&P.hit_bitmap[b >> 6], 1ull << (b & 63));
       if (b + 1 < P.n_blocks) atomicOr(&P.hit_bitmap[(b + 1) >> 6], 1ull << ((b + 1) & 63));
+      if (P.count_rc) {
+        // The table also holds the Rc strand's q-grams (reversed).  An Rc match that ends at column
+        // c of the REVERSED text covers forward positions [n - c, n - c + m + k); all its q-gram
+        // ends lie in this window when b is the block of forward position n - c + m + k - 1 (or
+        // the last block, for matches that start within m + k of the reversed text's start).
+        const int64_t n = (int64_t)P.text_len;
+        const int64_t top = n + (int64_t)P.m + (int64_t)P.k - 1;
+        int64_t c_lo = top - (int64_t)(b * 64) - 63;       // reversed end columns whose window ends in b
+        int64_t c_hi = top - (int64_t)(b * 64) + 1;         // (+ 1: the look-ahead column)
+        if (b + 1 == P.n_blocks) c_lo = 1;
+        if (c_lo < 1) c_lo = 1;
+        if (c_hi >= 1) {
+          uint64_t blo = (uint64_t)(c_lo - 1) >> 6, bhi = (uint64_t)(c_hi - 1) >> 6;
+          if (bhi >= P.n_blocks) bhi = P.n_blocks - 1;
+          for (uint64_t x = blo; x <= bhi; ++x) atomicOr(&P.hit_bitmap_rc[x >> 6], 1ull << (x & 63));
+        }
+      }
     }
   }
 }

@@ -135,6 +135,7 @@ struct ScanLane {
   std::vector<uint32_t> up_rowtab, up_ovtab;
   int up_profile = -1, table_profile = -1;
   uint32_t table_q = 0, table_k = 0, table_r = 0;   // table_r: 0 = piece bit table, else the counting table's R
+  bool table_rc = false;                            // the counting table also holds the Rc strand's q-grams
   double table_density = 0;
   // pinned host staging area: control block and the first kSpec reports of a scan are written into
   // it by the kernels themselves; one stream synchronisation makes them readable
@@ -193,6 +194,7 @@ struct sassy_SearcherType {
   hipEvent_t ev_inputs = nullptr;  // "uploads of this call are queued" (other lanes wait for it)
   bool device_ready = false;
   DevBuf<uint8_t> d_text, d_rev;
+  DevBuf<unsigned long long> d_rc_bitmap;  // the Rc strand's candidate blocks, marked by the forward pass
   const uint8_t* rev_src = nullptr;  // d_rev holds reverse(rev_src[0 .. rev_len)) (SASSY_HIP_TEXT_UNCHANGED)
   uint64_t rev_len = 0;
 
@@ -215,7 +217,7 @@ struct sassy_SearcherType {
   sassy_hip_Stats stats{};
 
   ~sassy_SearcherType() {
-    d_text.release(); d_rev.release();
+    d_text.release(); d_rev.release(); d_rc_bitmap.release();
     d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
     if (ev_multi) (void)hipEventDestroy(ev_multi);
     if (ev_multi_a) (void)hipEventDestroy(ev_multi_a);
@@ -344,17 +346,19 @@ static bool build_qgram_table(Profile pr, const uint8_t* pat, uint32_t q, uint32
 // expanded); entry w of the table, w a (Q+R-1)-gram, = how many of the R Q-grams w ends with are
 // in H.  density = |H| / 4^Q, the chance that a random position counts.  False if the expansion
 // takes more than `limit` Q-grams.
-static bool build_count_table(Profile pr, const uint8_t* pat, uint32_t m, uint32_t Q, uint32_t R,
+static bool build_count_table(Profile pr, const uint8_t* pat, const uint8_t* pat2, uint32_t m, uint32_t Q, uint32_t R,
                               std::vector<uint8_t>& tab, double* density) {
   const size_t limit = 1u << 20;
   const uint32_t nq = 1u << (2 * Q);
   std::vector<uint8_t> H(nq, 0);
   std::vector<uint32_t> cur, nxt;
   size_t total = 0;
-  for (uint32_t o = 0; o + Q <= m; ++o) {
+  // pat2: a second pattern whose q-grams also count (the Rc strand's, in forward orientation)
+  for (uint32_t o = 0; o + Q <= (pat2 ? 2 * m : m); ++o) {
+    if (o + Q > m && o < m) continue;  // no q-gram across the two patterns
     cur.assign(1, 0u);
     for (uint32_t j = 0; j < Q; ++j) {
-      const uint8_t c = pat[o + j];
+      const uint8_t c = o < m ? pat[o + j] : pat2[o - m + j];
       const uint32_t set = pr == PROFILE_IUPAC ? (iupac_code(c) & 15u) : (1u << ((c >> 1) & 3u));
       nxt.clear();
       for (uint32_t code : cur)
@@ -469,6 +473,17 @@ struct ScanJob {
   // multi-text buffer); no prefilter, no chunk builder -- list DP -> rank -> traceback
   const ChunkDesc* ext_desc = nullptr;
   uint32_t ext_ndesc = 0;
+  // both strands from one pass (whole texts): the prefilter of this, the forward strand's, job also
+  // evaluates the Rc strand's pattern rc_pat (= complement(pattern)) on the forward text and marks
+  // rc_bitmap in the coordinates of the reversed text; rc_marked tells whether the chosen filter did
+  // (bit-plane and counting filters do).  The Rc job then takes that bitmap as ext_bitmap and reads
+  // the forward buffer backwards (rev_n = its length): no reversed copy exists.
+  unsigned long long* rc_bitmap = nullptr;
+  const uint8_t* rc_pat = nullptr;
+  bool rc_marked = false;
+  bool rc_second_pass = false;       // more than 4 pieces: the Rc pieces get their own filter launch
+  ScanParams F2{};
+  uint64_t rev_n = 0;
   hipEvent_t wait_for = nullptr;     // pipelining: the previous sub-shard's "filter done"
   bool signal_filter_done = false;   // pipelining: record L.ev_filter_done behind this filter
 
@@ -545,6 +560,7 @@ int ScanJob::prepare() {
             (sh.text_end ? kScanTextEnd : 0u) | (overhang ? kScanOverhang : 0u);
   P.alpha = overhang ? S->alpha : 0.0f;
   P.ov_steps = ov_steps;
+  P.rev_n = rev_n;
   bucket = plan.nslots <= 4 ? 4 : plan.nslots <= 8 ? 8 : 16;
   static const int env_sb = getenv("SASSY_HIP_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_STAGE_BLOCKS")) : 0;
   P.stage_blocks = env_sb == 1 || env_sb == 2 ? (uint32_t)env_sb : 1u;
@@ -580,7 +596,10 @@ int ScanJob::prepare() {
     double best = 1.0;
     uint32_t bq = 0, br = 0;
     // the same pattern as in the last call on this lane: the decision and the table are still there
-    const bool same_as_last = L.table_r != 0 && L.table_k == k && L.table_profile == (int)S->profile &&
+    const bool with_rc = rc_bitmap != nullptr;
+    std::vector<uint8_t> rc_fwd;  // the Rc strand's pattern as it reads on the forward text: reversed
+    if (with_rc) rc_fwd.assign(std::reverse_iterator<const uint8_t*>(rc_pat + plan.m), std::reverse_iterator<const uint8_t*>(rc_pat));
+    const bool same_as_last = L.table_r != 0 && L.table_k == k && L.table_profile == (int)S->profile && L.table_rc == with_rc &&
                               L.table_pattern.size() == plan.m && memcmp(L.table_pattern.data(), pat, plan.m) == 0;
     if (same_as_last) { bq = L.table_q; br = L.table_r; best = 0.0; }
     for (const auto& v : variants) {
@@ -598,21 +617,24 @@ int ScanJob::prepare() {
           e *= S->profile == PROFILE_IUPAC ? (double)__builtin_popcount(iupac_code(pat[o + j]) & 15u) : 1.0;
         grams += e;
       }
-      const double dens = std::min(1.0, grams / std::pow(4.0, (double)Q));
+      const double dens = std::min(1.0, (with_rc ? 2.0 : 1.0) * grams / std::pow(4.0, (double)Q));
       const double tail = clumped_tail(64.0 * W * dens, t);
       if (tail < (v[1] == 1 ? 0.1 * best : best)) { best = tail; bq = Q; br = v[1]; }
     }
-    const double piece_frac = q > 0 ? std::min(1.0, 64.0 * pieces / std::pow(4.0, (double)std::min<uint32_t>(q, 9))) : 1.0;
-    if (bq && best < 0.05 && (same_as_last || best < 0.5 * piece_frac || env_kind == kFilterCount)) {
+    // (the piece-table kernel this competes with is the slower kernel -- 1.0 against 0.64 ms per 3 GB -- so a
+    // modest candidate rate is enough; beyond ~5 % of the blocks the chunk DP behind it would dominate)
+    if (bq && best < 0.05) {
       const bool cached = L.table_q == bq && L.table_r == br && L.table_k == k && L.table_profile == (int)S->profile &&
+                          L.table_rc == with_rc &&
                           L.table_pattern.size() == plan.m && memcmp(L.table_pattern.data(), pat, plan.m) == 0;
       bool ok = true;
       if (!cached) {
-        ok = build_count_table(S->profile, pat, plan.m, bq, br, L.h_table, &L.table_density);
+        ok = build_count_table(S->profile, pat, with_rc ? rc_fwd.data() : nullptr, plan.m, bq, br, L.h_table, &L.table_density);
         if (ok) {
           if (int rc = L.d_table.reserve(L.h_table.size())) return rc;
           HIP_TRY(hipMemcpyAsync(L.d_table.p, L.h_table.data(), L.h_table.size(), hipMemcpyHostToDevice, L.stream));
           L.table_q = bq; L.table_r = br; L.table_k = k; L.table_profile = (int)S->profile;
+          L.table_rc = with_rc;
           L.table_pattern.assign(pat, pat + plan.m);
         } else {
           L.table_q = 0;
@@ -620,6 +642,7 @@ int ScanJob::prepare() {
       }
       if (ok) {
         fkind = kFilterCount;
+        rc_marked = with_rc;
         q = bq;
         count_r = br;
         count_w = (plan.m + k - bq + 63) / 64 + 1;
@@ -741,6 +764,7 @@ int ScanJob::prepare() {
     T.band_bytes = (uint32_t)band;
     T.win_bytes = (uint32_t)win;
     T.text = sh.d_text;
+    T.rev_n = rev_n;
     T.global_offset = sh.global_offset;
     T.total_len = total_len;
     T.cand_count = d_counts;
@@ -804,18 +828,38 @@ int ScanJob::prepare() {
     F.count_r = count_r;
     F.count_window = count_w;
     F.count_thresh = count_t;
+    F.piece_mirror = 0;
+    F.hit_bitmap_rc = rc_bitmap;
+    F.count_rc = fkind == kFilterCount && rc_marked ? 1u : 0u;
     if (F.piece_planes) {
-      for (uint32_t pp = 0; pp < 8; ++pp) {
-        const uint32_t piece = pp < F.n_pieces ? pp : 0;  // a repeated piece changes nothing
+      // piece `piece` of the forward pattern, or (mirror) of the Rc strand's pattern with its string
+      // reversed: rows q-1 .. 0 of complement(pattern)'s piece, as they read on the forward text
+      auto set_piece = [&](ScanParams& X, uint32_t pp, uint32_t piece, bool mirror) {
         uint32_t b0 = 0, b1 = 0;
         for (uint32_t j = 0; j < q; ++j) {
-          const uint32_t code = (pat[piece * q + j] >> 1) & 3u;  // src/profiles/dna.rs:19-40
+          const uint8_t ch = mirror ? rc_pat[piece * q + (q - 1 - j)] : pat[piece * q + j];
+          const uint32_t code = (ch >> 1) & 3u;  // src/profiles/dna.rs:19-40
           b0 |= (code & 1u) << j;
           b1 |= (code >> 1) << j;
         }
-        F.piece_bits[pp][0] = b0;
-        F.piece_bits[pp][1] = b1;
-        F.piece_rem[pp] = plan.m - (piece + 1) * q;
+        X.piece_bits[pp][0] = b0;
+        X.piece_bits[pp][1] = b1;
+        X.piece_rem[pp] = plan.m - (piece + 1) * q;
+        if (mirror) X.piece_mirror |= 1u << pp;
+      };
+      const uint32_t np = k + 1;
+      const bool with_rc = rc_bitmap != nullptr && !ext_bitmap && !ext_desc;
+      if (with_rc && np <= 4) {  // both strands' pieces in one launch (a repeated piece changes nothing)
+        for (uint32_t pp = 0; pp < 4; ++pp) set_piece(F, pp, pp < np ? pp : 0, false);
+        for (uint32_t pp = 0; pp < 4; ++pp) set_piece(F, 4 + pp, pp < np ? pp : 0, true);
+        F.n_pieces = 8;
+        F.piece_groups = 2;
+        rc_marked = true;
+      } else {
+        for (uint32_t pp = 0; pp < 8; ++pp) set_piece(F, pp, pp < F.n_pieces ? pp : 0, false);
+        if (with_rc) {  // 5 .. 8 pieces per strand: a second launch for the Rc strand's pieces
+          rc_marked = rc_second_pass = true;
+        }
       }
     }
     static const int env_fsb = getenv("SASSY_HIP_FILTER_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_FILTER_STAGE_BLOCKS")) : 0;
@@ -847,6 +891,23 @@ int ScanJob::prepare() {
       const size_t expect = (size_t)std::min<double>(1.5 * frac * (double)n_blocks, (double)n_blocks) + 1024;
       if (!ext_desc)
         if (int rc = L.d_desc.reserve(std::max<size_t>(1u << 18, expect))) return rc;
+    }
+    if (rc_second_pass) {  // same launch, the Rc strand's pieces (all mirrored) instead of the forward ones
+      F2 = F;
+      F2.piece_mirror = 0;
+      for (uint32_t pp = 0; pp < 8; ++pp) {
+        const uint32_t piece = pp < k + 1 ? pp : 0;
+        uint32_t b0 = 0, b1 = 0;
+        for (uint32_t j = 0; j < q; ++j) {
+          const uint32_t code = (rc_pat[piece * q + (q - 1 - j)] >> 1) & 3u;
+          b0 |= (code & 1u) << j;
+          b1 |= (code >> 1) << j;
+        }
+        F2.piece_bits[pp][0] = b0;
+        F2.piece_bits[pp][1] = b1;
+        F2.piece_rem[pp] = plan.m - (piece + 1) * q;
+        F2.piece_mirror |= 1u << pp;
+      }
     }
     P.lds_per_wave = bucket * 512u + plan.nwords * 512u;
     if ((size_t)kWavesPerGroup * P.lds_per_wave > 160 * 1024)
@@ -888,6 +949,11 @@ int ScanJob::enqueue(int attempt) {
     if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
   } else {
     if (attempt == 0 && !ext_bitmap && !ext_desc) {  // the hit bitmap does not depend on buffer sizes: build it once
+      if (rc_marked) HIP_TRY(hipMemsetAsync(rc_bitmap, 0, (n_words + 2) * 8, L.stream));
+      if (rc_second_pass) {
+        le = launch_filter_any(S->profile, F2, fgrid, 1024 + (size_t)kWavesPerGroup * F2.lds_per_wave, L.stream);
+        if (le != hipSuccess) return hip_fail(le, "filter kernel launch (Rc pieces)");
+      }
       le = fkind == kFilterCount ? launch_filter_count(F, fgrid, L.stream)
            : fkind == kFilterTable
                ? launch_filter_table(F, fgrid, L.stream)
@@ -1596,21 +1662,71 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
     return fail(SASSY_HIP_EINVAL, "device text pointer must be 16-byte aligned");
   }
 
+  // complement(pattern) for the Rc strand (reference: src/search.rs:813-878)
+  std::vector<uint8_t> cp;
+  PatternPlan cplan;
+  if (rc_strand) {
+    cp.resize(plen);
+    for (size_t i = 0; i < plen; ++i) cp[i] = complement_char(S->profile, pattern[i]);
+    if (!make_plan(S->profile, cp.data(), plen, cplan, err)) return fail(SASSY_HIP_EINVAL, err);
+  }
+  // Both strands from one pass over the forward text: the forward job's prefilter also marks the Rc
+  // strand's candidate blocks (in reversed-text coordinates), and the Rc job's chunk DP and traceback
+  // read the forward buffer backwards -- no reversed copy, no second streaming pass.  Needs a filter
+  // that can do it (bit-plane / counting) and no option that wants the reversed text as such.
+  static const int env_fuse = getenv("SASSY_HIP_RC_FUSED") ? atoi(getenv("SASSY_HIP_RC_FUSED")) : 1;
+  const bool can_fuse = fwd_strand && rc_strand && env_fuse != 0 && !ef.fn && std::isnan(S->max_n_frac) &&
+                        std::isnan(S->alpha) && S->profile != PROFILE_ASCII;
+  bool rc_by_bitmap = false;
+  uint32_t rc_q = 0;
+
   if (fwd_strand) {
     ShardView sh{d_fwd, tlen, 0, 0, true, true};
     ScanOut so;
-    if (int rc = run_scan(S, sh, plan, (uint32_t)k, all, pattern, !wo, tlen, so)) return rc;
+    if (can_fuse) {
+      const uint64_t nb = ((uint64_t)tlen + 63) / 64;
+      if (int rc = S->d_rc_bitmap.reserve((nb + 63) / 64 + 4)) return rc;
+      ScanJob job(S, S->lanes[0], sh, plan, (uint32_t)k, all, pattern, !wo, tlen);
+      job.texts.all_minima = all ? 1u : 0u;
+      job.rc_bitmap = S->d_rc_bitmap.p;
+      job.rc_pat = cp.data();
+      if (int rc = job.prepare()) return rc;
+      if (!job.empty)
+        if (int rc = job.enqueue(0)) return rc;
+      if (int rc = job.finish(so)) return rc;
+      rc_by_bitmap = job.rc_marked && !job.empty;
+      rc_q = job.q;
+    } else {
+      if (int rc = run_scan(S, sh, plan, (uint32_t)k, all, pattern, !wo, tlen, so)) return rc;
+    }
     if (int rc = post_filter(S, so, plan, pattern, (uint32_t)k, 0, on_dev ? nullptr : text, d_fwd, tlen, !wo, ef)) return rc;
     size_t first = 0;
     if (int rc = append_matches(so, tlen, plan, wo, pattern_idx, R, first)) return rc;
   }
-  if (rc_strand) {
-    // complement(pattern) against reverse(text), coordinates mapped back
-    // (reference: src/search.rs:813-878)
-    std::vector<uint8_t> cp(plen);
-    for (size_t i = 0; i < plen; ++i) cp[i] = complement_char(S->profile, pattern[i]);
-    PatternPlan cplan;
-    if (!make_plan(S->profile, cp.data(), plen, cplan, err)) return fail(SASSY_HIP_EINVAL, err);
+  if (rc_strand && rc_by_bitmap) {
+    ShardView sh{d_fwd, tlen, 0, 0, true, true};
+    ScanOut so;
+    ScanJob job(S, S->lanes[0], sh, cplan, (uint32_t)k, all, cp.data(), !wo, tlen);
+    job.texts.all_minima = all ? 1u : 0u;
+    job.ext_bitmap = S->d_rc_bitmap.p;
+    job.ext_q = rc_q;
+    job.rev_n = tlen;
+    if (int rc = job.prepare()) return rc;
+    if (!job.empty)
+      if (int rc = job.enqueue(0)) return rc;
+    if (int rc = job.finish(so)) return rc;
+    if (int rc = post_filter(S, so, cplan, cp.data(), (uint32_t)k, 1, nullptr, nullptr, tlen, !wo, ef)) return rc;
+    size_t first = 0;
+    if (int rc = append_matches(so, tlen, cplan, wo, pattern_idx, R, first)) return rc;
+    for (size_t i = first; i < R->matches.size(); ++i) {
+      sassy_hip_Match& r = R->matches[i];
+      const uint64_t rs = r.text_start, re = r.text_end;
+      r.strand = 1;
+      r.text_start = tlen - re;
+      r.text_end = wo ? UINT64_MAX : tlen - rs;  // reference: src/search.rs:868-873
+    }
+  } else if (rc_strand) {
+    // complement(pattern) against a reversed copy of the text, coordinates mapped back
     // the caller may promise that a device text did not change since this searcher last saw it:
     // the reversed copy (n bytes read + n written, more than the search itself) is then still valid
     const bool reuse = on_dev && (flags & SASSY_HIP_TEXT_UNCHANGED) && S->rev_src == d_fwd && S->rev_len == tlen &&

@@ -209,6 +209,31 @@ __device__ __noinline__ uint4 load_tail16(const uint8_t* text, uint64_t off, uin
   return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 
+// 16 bytes of the text a list-mode launch scans, at logical offset `off`: the buffer itself, or --
+// Rc strand without a reversed copy -- the rev_n bytes at `text` read backwards (one misaligned
+// 16-byte load + four byte swaps; the list kernels read a few MB, the misalignment costs nothing there).
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(1)));
+__device__ __noinline__ uint4 load_tail16_rev(const uint8_t* text, uint64_t off, uint64_t n) {
+  uint32_t w[4] = {0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u};  // past the end: 'X'
+#pragma unroll 1
+  for (uint32_t q = 0; q < 16 && off + q < n; ++q) {
+    const uint32_t sh = 8u * (q & 3u);
+    w[q >> 2] = (w[q >> 2] & ~(0xFFu << sh)) | ((uint32_t)text[n - 1 - (off + q)] << sh);
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ uint4 load_text16(const ScanParams& P, uint64_t off) {
+  if (P.rev_n == 0) {
+    if (off + 16 <= P.text_len) return *reinterpret_cast<const uint4*>(P.text + off);
+    return load_tail16(P.text, off, P.text_len);
+  }
+  if (off + 16 <= P.rev_n) {
+    const u32x4_unaligned v = *reinterpret_cast<const u32x4_unaligned*>(P.text + (P.rev_n - off - 16));
+    return make_uint4(__builtin_bswap32(v.w), __builtin_bswap32(v.z), __builtin_bswap32(v.y), __builtin_bswap32(v.x));
+  }
+  return load_tail16_rev(P.text, off, P.rev_n);
+}
+
 // ------------------------------------------------------------------ the profile, lane-parallel
 // Bit-plane BIT of the lane's 64 text bytes: bit c of the result = bit BIT of byte c.
 // Per dword: v_and isolates the bit of its 4 bytes, v_dot4_u32_u8 with weights 1,2,4,8 (even
@@ -880,15 +905,25 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
       for (int pp = 0; pp < NP; ++pp) {
         const uint64_t bits = ((uint64_t)ah[pp] << 32) | al[pp];
         if (bits == 0) continue;
-        const int64_t e_lo = (int64_t)(b * 64) + __ffsll((long long)bits);        // first end position
-        const int64_t e_hi = (int64_t)(b * 64) + 64 - __clzll((long long)bits);   // last end position
+        int64_t e_lo = (int64_t)(b * 64) + __ffsll((long long)bits);        // first end position
+        int64_t e_hi = (int64_t)(b * 64) + 64 - __clzll((long long)bits);   // last end position
+        unsigned long long* bitmap = P.hit_bitmap;
+        if ((P.piece_mirror >> pp) & 1u) {
+          // a piece of the Rc strand's pattern, its string reversed: the occurrence T[f-q, f) is, in
+          // the reversed text, that piece ending at reversed column n - f + q
+          const int64_t n = (int64_t)P.text_len;
+          const int64_t r_lo = n - e_hi + (int64_t)q, r_hi = n - e_lo + (int64_t)q;
+          e_lo = r_lo;
+          e_hi = r_hi;
+          bitmap = P.hit_bitmap_rc;
+        }
         int64_t c_lo = e_lo + (int64_t)P.piece_rem[pp] - (int64_t)P.k;
         // + 1: the report rule decides about an end position when it sees the next column
         const int64_t c_hi = e_hi + (int64_t)P.piece_rem[pp] + (int64_t)P.k + 1;
         if (c_lo < 1) c_lo = 1;
         uint64_t blo = (uint64_t)(c_lo - 1) >> 6, bhi = (uint64_t)(c_hi - 1) >> 6;
         if (bhi >= P.n_blocks) bhi = P.n_blocks - 1;
-        for (uint64_t x = blo; x <= bhi; ++x) atomicOr(&P.hit_bitmap[x >> 6], 1ull << (x & 63));
+        for (uint64_t x = blo; x <= bhi; ++x) atomicOr(&bitmap[x >> 6], 1ull << (x & 63));
       }
     }
   }
@@ -1260,10 +1295,7 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
     for (int c = 0; c < 4; ++c) {
       const uint64_t off = b * 64 + (uint64_t)c * 16;
       uint4 v = make_uint4(0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u);
-      if (active) {
-        if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
-        else v = load_tail16(P.text, off, P.text_len);
-      }
+      if (active) v = load_text16(P, off);
       x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
     }
     {
@@ -1401,10 +1433,7 @@ __global__ __launch_bounds__(256) void list_words_kernel(const ScanParams P) {
     for (int c = 0; c < 4; ++c) {
       const uint64_t off = blk * 64 + (uint64_t)c * 16;
       uint4 v = make_uint4(0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u);
-      if (on) {
-        if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
-        else v = load_tail16(P.text, off, P.text_len);
-      }
+      if (on) v = load_text16(P, off);
       dst[4 * c] = v.x; dst[4 * c + 1] = v.y; dst[4 * c + 2] = v.z; dst[4 * c + 3] = v.w;
     }
   };

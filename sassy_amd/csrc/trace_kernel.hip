@@ -193,8 +193,18 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
     if (W.skip) continue;
     const uint64_t o = W.o, we = W.we;                     // global window bounds
     const int wl = (int)(we - o);
-    const uint32_t skew = load_window(P.text, o - P.global_offset, wl, wbuf);
+    // Rc strand without a reversed copy: the window [o, o + wl) of the reversed text is the forward
+    // bytes [n - o - wl, n - o), fetched the same way and turned around in place
+    const uint32_t skew = load_window(P.text, P.rev_n ? P.rev_n - (o - P.global_offset) - (uint64_t)wl : o - P.global_offset,
+                                      wl, wbuf);
     unsigned char* win = wbuf + skew;
+    if (P.rev_n) {
+      for (int x = 0; x < wl / 2; ++x) {
+        const unsigned char a = win[x];
+        win[x] = win[wl - 1 - x];
+        win[wl - 1 - x] = a;
+      }
+    }
     if (rule.iupac)
       for (int x = 0; x < wl; ++x) win[x] = kIupacCode[win[x] & 31u];
     auto text_at = [&](int i) -> uint32_t { return win[i]; };
@@ -396,8 +406,9 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
     const int iend = alpha_on ? (int)(cd.pos - o) : wl;
     {  // window -> LDS (coalesced bytes), Iupac letters -> base sets
       const uint8_t* src = P.text + (o - P.global_offset);
+      const uint8_t* rsrc = P.text + (P.rev_n - 1 - (o - P.global_offset));  // reversed view: byte x = rsrc[-x]
       for (int x = (int)lane; x < iend; x += 64) {
-        const uint32_t ch = x < wl ? src[x] : (uint32_t)'N';
+        const uint32_t ch = x < wl ? (P.rev_n ? rsrc[-(int64_t)x] : src[x]) : (uint32_t)'N';
         win[x] = (unsigned char)(rule.iupac ? kIupacCode[ch & 31u] : ch);
       }
     }

@@ -376,6 +376,23 @@ def test_rc_strand_all_text_alignments_and_resident_text_reuse(sassy):
             text = text[:at] + ins + text[at + len(ins):]
         k = rng.randrange(0, 2)
         assert_same(s.search(pat, text, k), oracle.search("dna", pat, text, k, rc=True), (n, pat))
+    # both strands from one forward pass: bit-plane filter with 1-4 pieces per strand (one launch),
+    # 5-8 pieces (second launch for the Rc pieces), counting filter (Iupac / many pieces), long
+    # patterns (word-pipelined chunk DP reading the text backwards), search_all
+    for profile, m, k in (("dna", 32, 3), ("dna", 24, 0), ("dna", 60, 5), ("dna", 64, 7), ("dna", 120, 12),
+                          ("iupac", 32, 3), ("iupac", 150, 15), ("iupac", 20, 1)):
+        n = 50_003 + m
+        text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        pat = bytes(rng.choice(b"ACGT") for _ in range(m))
+        for t in range(12):
+            src = oracle.reverse_complement(profile, pat) if t % 2 else pat
+            ins = mutate(rng, src, rng.randrange(0, k + 1))
+            at = [0, n - len(ins)][t] if t < 2 else rng.randrange(0, n - len(ins))
+            text[at:at + len(ins)] = ins
+        text = bytes(text)
+        sb = sassy.Searcher(profile, rc=True)
+        assert_same(sb.search(pat, text, k), oracle.search(profile, pat, text, k, rc=True), (profile, m, k))
+        assert_same(sb.search_all(pat, text, k), oracle.search(profile, pat, text, k, rc=True, all_minima=True), (profile, m, k))
     # device-resident text, many patterns
     n = 200_003
     text = bytearray(rng.choice(b"ACGT") for _ in range(n))
