@@ -586,10 +586,11 @@ int ScanJob::prepare() {
   // q-gram counting (count_filter.hip): per (Q, R) variant the threshold t = m + 1 - (k+1) Q, the
   // window W, and how often a window of random text reaches t by chance (the pattern's q-grams,
   // ambiguity letters expanded, against 4^Q; Poisson tail).  Taken when that beats the expected
-  // hit blocks of the k+1 pieces, except where the cheaper bit-plane kernel applies.
+  // hit blocks of the k+1 pieces, except where the cheaper bit-plane kernel applies (one strand: both
+  // strands in one pass cost the bit-plane kernel 8 pieces, 0.85 ms per 3 GB, the counting kernel nothing extra).
   count_r = 0;
   if (!overhang && !ext_bitmap && !ext_desc && S->profile != PROFILE_ASCII && env_pre != 0 &&
-      (env_kind == 0 || env_kind == kFilterCount) && !(can_planes && env_kind == 0)) {
+      (env_kind == 0 || env_kind == kFilterCount) && !(can_planes && env_kind == 0 && rc_bitmap == nullptr)) {
     // two positions per lookup first (half the LDS traffic of (7,1)); the 7-gram variant only where
     // the shorter q-grams are not selective enough
     static const uint32_t variants[][2] = {{6, 2}, {5, 2}, {7, 1}};
@@ -1678,7 +1679,6 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
   const bool can_fuse = fwd_strand && rc_strand && env_fuse != 0 && !ef.fn && std::isnan(S->max_n_frac) &&
                         std::isnan(S->alpha) && S->profile != PROFILE_ASCII;
   bool rc_by_bitmap = false;
-  uint32_t rc_q = 0;
 
   if (fwd_strand) {
     ShardView sh{d_fwd, tlen, 0, 0, true, true};
@@ -1690,41 +1690,51 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
       job.texts.all_minima = all ? 1u : 0u;
       job.rc_bitmap = S->d_rc_bitmap.p;
       job.rc_pat = cp.data();
+      job.signal_filter_done = true;
       if (int rc = job.prepare()) return rc;
       if (!job.empty)
         if (int rc = job.enqueue(0)) return rc;
-      if (int rc = job.finish(so)) return rc;
       rc_by_bitmap = job.rc_marked && !job.empty;
-      rc_q = job.q;
+      // the Rc strand's chunk list / DP / rank / traceback -- short, latency-bound kernels -- run on a
+      // second lane next to the forward strand's, behind the shared filter pass
+      ScanOut so_rc;
+      std::unique_ptr<ScanJob> rj;
+      if (rc_by_bitmap) {
+        rj.reset(new ScanJob(S, S->lanes[1], sh, cplan, (uint32_t)k, all, cp.data(), !wo, tlen));
+        rj->texts.all_minima = all ? 1u : 0u;
+        rj->ext_bitmap = S->d_rc_bitmap.p;
+        rj->ext_q = job.q;
+        rj->ext_wait = S->lanes[0].ev_filter_done;
+        rj->rev_n = tlen;
+        if (int rc = rj->prepare()) return rc;
+        if (!rj->empty)
+          if (int rc = rj->enqueue(0)) return rc;
+      }
+      if (int rc = job.finish(so)) return rc;
+      if (int rc = post_filter(S, so, plan, pattern, (uint32_t)k, 0, on_dev ? nullptr : text, d_fwd, tlen, !wo, ef)) return rc;
+      size_t first = 0;
+      if (int rc = append_matches(so, tlen, plan, wo, pattern_idx, R, first)) return rc;
+      if (rj) {
+        if (int rc = rj->finish(so_rc)) return rc;
+        if (int rc = post_filter(S, so_rc, cplan, cp.data(), (uint32_t)k, 1, nullptr, nullptr, tlen, !wo, ef)) return rc;
+        if (int rc = append_matches(so_rc, tlen, cplan, wo, pattern_idx, R, first)) return rc;
+        for (size_t i = first; i < R->matches.size(); ++i) {
+          sassy_hip_Match& r = R->matches[i];
+          const uint64_t rs = r.text_start, re = r.text_end;
+          r.strand = 1;
+          r.text_start = tlen - re;
+          r.text_end = wo ? UINT64_MAX : tlen - rs;  // reference: src/search.rs:868-873
+        }
+      }
     } else {
       if (int rc = run_scan(S, sh, plan, (uint32_t)k, all, pattern, !wo, tlen, so)) return rc;
+      if (int rc = post_filter(S, so, plan, pattern, (uint32_t)k, 0, on_dev ? nullptr : text, d_fwd, tlen, !wo, ef)) return rc;
+      size_t first = 0;
+      if (int rc = append_matches(so, tlen, plan, wo, pattern_idx, R, first)) return rc;
     }
-    if (int rc = post_filter(S, so, plan, pattern, (uint32_t)k, 0, on_dev ? nullptr : text, d_fwd, tlen, !wo, ef)) return rc;
-    size_t first = 0;
-    if (int rc = append_matches(so, tlen, plan, wo, pattern_idx, R, first)) return rc;
   }
   if (rc_strand && rc_by_bitmap) {
-    ShardView sh{d_fwd, tlen, 0, 0, true, true};
-    ScanOut so;
-    ScanJob job(S, S->lanes[0], sh, cplan, (uint32_t)k, all, cp.data(), !wo, tlen);
-    job.texts.all_minima = all ? 1u : 0u;
-    job.ext_bitmap = S->d_rc_bitmap.p;
-    job.ext_q = rc_q;
-    job.rev_n = tlen;
-    if (int rc = job.prepare()) return rc;
-    if (!job.empty)
-      if (int rc = job.enqueue(0)) return rc;
-    if (int rc = job.finish(so)) return rc;
-    if (int rc = post_filter(S, so, cplan, cp.data(), (uint32_t)k, 1, nullptr, nullptr, tlen, !wo, ef)) return rc;
-    size_t first = 0;
-    if (int rc = append_matches(so, tlen, cplan, wo, pattern_idx, R, first)) return rc;
-    for (size_t i = first; i < R->matches.size(); ++i) {
-      sassy_hip_Match& r = R->matches[i];
-      const uint64_t rs = r.text_start, re = r.text_end;
-      r.strand = 1;
-      r.text_start = tlen - re;
-      r.text_end = wo ? UINT64_MAX : tlen - rs;  // reference: src/search.rs:868-873
-    }
+    // done above, next to the forward strand
   } else if (rc_strand) {
     // complement(pattern) against a reversed copy of the text, coordinates mapped back
     // the caller may promise that a device text did not change since this searcher last saw it:
