@@ -144,6 +144,31 @@ struct ScanLane {
   unsigned char* h_pin_dev = nullptr;  // device address of h_pin
   size_t h_pin_cap = 0;
   bool ready = false;
+  // small host -> device uploads (pattern, row table, tables) go through pinned memory: a copy from
+  // pageable memory makes the host wait for the device, which serialises the lanes of a ScanQueue
+  uint8_t* h_up = nullptr;
+  size_t h_up_cap = 0, h_up_used = 0;
+  int upload(void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return 0;
+    const size_t need = h_up_used + ((bytes + 63) & ~(size_t)63);
+    if (need > h_up_cap) {
+      if (h_up_used != 0) {  // no room left behind the copies already queued: an ordinary copy
+        hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+        return e == hipSuccess ? 0 : hip_fail(e, "hipMemcpyAsync");
+      }
+      if (h_up) (void)hipHostFree(h_up);
+      h_up = nullptr;
+      h_up_cap = 0;
+      const size_t want = std::max<size_t>(need * 2, 256 * 1024);
+      hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h_up), want, hipHostMallocDefault);
+      if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (upload staging)");
+      h_up_cap = want;
+    }
+    memcpy(h_up + h_up_used, src, bytes);
+    hipError_t e = hipMemcpyAsync(dst, h_up + h_up_used, bytes, hipMemcpyHostToDevice, stream);
+    h_up_used = need;
+    return e == hipSuccess ? 0 : hip_fail(e, "hipMemcpyAsync");
+  }
   int reserve_pinned(size_t bytes) {
     if (bytes <= h_pin_cap) return 0;
     if (h_pin) (void)hipHostFree(h_pin);
@@ -171,6 +196,8 @@ struct ScanLane {
     return 0;
   }
   void destroy() {
+    if (h_up) (void)hipHostFree(h_up);
+    h_up = nullptr; h_up_cap = h_up_used = 0;
     d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release();
     d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release();
     d_pattern.release(); d_table.release(); d_rowoff.release(); d_ovtab.release();
@@ -543,6 +570,7 @@ struct ScanJob {
 
 int ScanJob::prepare() {
   t_enter = now_ms();
+  L.h_up_used = 0;  // the lane's previous job is finished: its upload staging is free again
   // overhang (reference: get_overhang_steps, src/search.rs:347-356): the text is virtually extended
   // by ov_steps 'N' columns, f32 arithmetic as there
   const bool overhang = !std::isnan(S->alpha);
@@ -651,7 +679,7 @@ int ScanJob::prepare() {
         ok = build_count_table(S->profile, pat, with_rc ? rc_fwd.data() : nullptr, plan.m, bq, br, L.h_table, &L.table_density);
         if (ok) {
           if (int rc = L.d_table.reserve(L.h_table.size())) return rc;
-          HIP_TRY(hipMemcpyAsync(L.d_table.p, L.h_table.data(), L.h_table.size(), hipMemcpyHostToDevice, L.stream));
+          if (int rc = L.upload(L.d_table.p, L.h_table.data(), L.h_table.size())) return rc;
           L.table_q = bq; L.table_r = br; L.table_k = k; L.table_profile = (int)S->profile;
           L.table_rc = with_rc;
           L.table_pattern.assign(pat, pat + plan.m);
@@ -684,7 +712,7 @@ int ScanJob::prepare() {
       if (!cached) {
         if (build_qgram_table(S->profile, pat, tq, pieces, L.h_table)) {
           if (int rc = L.d_table.reserve(L.h_table.size())) return rc;
-          HIP_TRY(hipMemcpyAsync(L.d_table.p, L.h_table.data(), L.h_table.size(), hipMemcpyHostToDevice, L.stream));
+          if (int rc = L.upload(L.d_table.p, L.h_table.data(), L.h_table.size())) return rc;
           L.table_q = tq; L.table_r = 0; L.table_k = k; L.table_profile = (int)S->profile;
           L.table_pattern.assign(pat, pat + plan.m);
         } else {
@@ -708,9 +736,8 @@ int ScanJob::prepare() {
       L.up_rowtab = plan.row_tab;
       L.up_profile = (int)S->profile;
       // the sources must stay valid until the copies ran: use the searcher-owned copies
-      HIP_TRY(hipMemcpyAsync(L.d_rowoff.p, L.up_rowtab.data(), L.up_rowtab.size() * sizeof(uint32_t),
-                             hipMemcpyHostToDevice, L.stream));
-      HIP_TRY(hipMemcpyAsync(L.d_pattern.p, L.up_pattern.data(), plan.m, hipMemcpyHostToDevice, L.stream));
+      if (int rc = L.upload(L.d_rowoff.p, L.up_rowtab.data(), L.up_rowtab.size() * sizeof(uint32_t))) return rc;
+      if (int rc = L.upload(L.d_pattern.p, L.up_pattern.data(), plan.m)) return rc;
     }
   }
   if (overhang) {
@@ -726,7 +753,7 @@ int ScanJob::prepare() {
     if (int rc = L.d_ovtab.reserve(plan.nwords)) return rc;
     if (tab != L.up_ovtab) {
       L.up_ovtab = tab;
-      HIP_TRY(hipMemcpyAsync(L.d_ovtab.p, L.up_ovtab.data(), plan.nwords * sizeof(uint32_t), hipMemcpyHostToDevice, L.stream));
+      if (int rc = L.upload(L.d_ovtab.p, L.up_ovtab.data(), plan.nwords * sizeof(uint32_t))) return rc;
     }
     P.ov_tab = L.d_ovtab.p;
   }
@@ -985,7 +1012,7 @@ int ScanJob::enqueue(int attempt) {
     if (int rc = L.d_state.reserve(std::max<uint32_t>(desc_cap, 1))) return rc;
     P.chunk_state = L.d_state.p;
     if (ext_desc)  // the descriptor count the list kernel reads
-      HIP_TRY(hipMemcpyAsync(d_counts + 1, &ext_ndesc, sizeof(uint32_t), hipMemcpyHostToDevice, L.stream));
+      if (int rc = L.upload(d_counts + 1, &ext_ndesc, sizeof(uint32_t))) return rc;
     // right dilation: blocks a match END can reach from a piece occurrence; the bit-plane filter
     // marks those blocks itself (it knows the piece), the other filters mark the occurrence's block
     if (!ext_desc) {
