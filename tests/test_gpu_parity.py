@@ -1048,3 +1048,31 @@ def test_full_size_configs_3_and_4_properties(sassy):
            [(m.text_start, m.text_end, m.cost, m.cigar) for m in want if m.text_start >= 256]
     buf.free()
 
+
+
+def test_text_beyond_4gib_both_strands(sassy):
+    """A 5 GB text (positions beyond 2^32), both strands in one pass: every plant found at its place and
+    the slice that straddles the 2^32 byte border equal to the oracle's answer (with its two plants)."""
+    n = 5_000_000_000
+    try:
+        buf = sassy.DeviceBuffer(n + 4096)
+    except sassy.SassyHipError:
+        pytest.skip("cannot allocate 5 GB on this device")
+    sassy.generate_dna(buf.ptr, n, 42, 0)
+    pat = bytes(oracle.generate_dna(43, 0, 32))
+    planted = sassy.plant(buf.ptr, n, 0, n, 42, pat, 3, stride=1 << 20)
+    for profile in ("dna", "iupac"):
+        s = sassy.Searcher(profile, rc=True)
+        ms = s.search(pat, _DevText(buf.ptr, n), 3)
+        assert [m.text_end for m in ms if m.strand == "+"] == sorted(m.text_end for m in ms if m.strand == "+")
+        slots = {m.text_start >> 20 for m in ms if m.strand == "+"}
+        assert len(slots) >= planted - 1, (len(slots), planted)
+        off = (1 << 32) - (1 << 20)
+        sl = buf.download(1 << 21, off)
+        want = oracle.search(profile, pat, sl, 3, rc=True)
+        inner = lambda a, b: a >= 64 and b <= (1 << 21) - 64
+        got = sorted((m.text_start - off, m.text_end - off, m.cost, m.strand, m.cigar) for m in ms
+                     if m.text_start >= off and inner(m.text_start - off, m.text_end - off))
+        exp = sorted((m.text_start, m.text_end, m.cost, m.strand, m.cigar) for m in want if inner(m.text_start, m.text_end))
+        assert len(exp) >= 2 and got == exp
+    buf.free()
