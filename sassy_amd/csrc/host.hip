@@ -988,7 +988,9 @@ int ScanJob::enqueue(int attempt) {
   // pipelined sub-shards: this lane's filter starts when the previous sub-shard's filter is done,
   // so that the previous lane's DP / rank / traceback kernels overlap this bandwidth-bound one
   if (wait_for && attempt == 0) HIP_TRY(hipStreamWaitEvent(L.stream, wait_for, 0));
-  if (timing >= 1) HIP_TRY(hipEventRecord(L.ev_a, L.stream));
+  // (a job that only consumes a bitmap has no filter to time: no events at level 1, each costs ~6 us of stream idle)
+  const bool time_head = timing >= 2 || (timing == 1 && !ext_bitmap);
+  if (time_head) HIP_TRY(hipEventRecord(L.ev_a, L.stream));
   hipError_t le;
   if (!filtered) {
     le = launch_scan_any(S->profile, P, grid, (size_t)kWavesPerGroup * P.lds_per_wave, L.stream);
@@ -1006,7 +1008,7 @@ int ScanJob::enqueue(int attempt) {
                : launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, L.stream);
       if (le != hipSuccess) return hip_fail(le, "filter kernel launch");
     }
-    if (timing >= 1 && attempt == 0) HIP_TRY(hipEventRecord(L.ev_f, L.stream));
+    if (time_head && attempt == 0) HIP_TRY(hipEventRecord(L.ev_f, L.stream));
     if (signal_filter_done && attempt == 0) HIP_TRY(hipEventRecord(L.ev_filter_done, L.stream));
     desc_cap = ext_desc ? ext_ndesc : (uint32_t)std::min<size_t>(L.d_desc.cap, 0x7FFFFFFFu);
     if (int rc = L.d_state.reserve(std::max<uint32_t>(desc_cap, 1))) return rc;
@@ -1085,7 +1087,7 @@ int ScanJob::finish(ScanOut& out) {
       S->stats.scan_ms += ms;
     }
     S->stats.scan_launches += 1;
-    if (filtered && attempt == 0 && timing >= 1) {
+    if (filtered && attempt == 0 && (timing >= 2 || (timing == 1 && !ext_bitmap))) {
       HIP_TRY(hipEventElapsedTime(&ms, L.ev_a, L.ev_f));
       S->stats.filter_ms += ms;
     }
