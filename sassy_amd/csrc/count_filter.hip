@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void filter_count_kernel(const ScanParams P) {
   const bool check_text = P.profile == PROFILE_IUPAC;  // wave-uniform
   const uint32_t thresh = P.count_thresh;
 
-  uint32_t h = 0;        // 2-bit codes of the last text letters, newest lowest
+  uint32_t h2 = 0;       // twice the 2-bit codes of the last text letters, newest lowest
   uint32_t sum = 0;      // hits in the last W blocks
   uint32_t pos = 0;      // ring slot of the oldest block (wave-uniform)
   uint32_t forced = 0;   // blocks (this one included) whose window still holds a block with such a byte
@@ -151,12 +151,13 @@ __global__ __launch_bounds__(256) void filter_count_kernel(const ScanParams P) {
     for (int d = 0; d < 16; ++d) {
       // four letters -> 8 bits, first letter highest: the byte values are 2 * code, so the
       // weights 64 16 4 1 give twice the packed code
-      const uint32_t p2 = __builtin_amdgcn_udot4(x[d] & 0x06060606u, 0x01041040u, 0u, false);
-      h = (h << 8) | (p2 >> 1);
+      // (h2 = twice the rolling code: the dot product accumulates onto the shifted register, and the
+      // factor two comes off in the bit-field extract of the lookup index)
+      h2 = __builtin_amdgcn_udot4(x[d] & 0x06060606u, 0x01041040u, h2 << 8, false);
 #pragma unroll
       for (int j = 0; j < 4 / R; ++j) {
         const uint32_t shift = 2u * (4u - (uint32_t)(j + 1) * R);
-        cnt += table[(h >> shift) & kIdxMask];
+        cnt += table[__builtin_amdgcn_ubfe(h2, shift + 1u, 2 * (Q + R - 1))];
       }
     }
     uint32_t bad = 0;
@@ -166,8 +167,9 @@ __global__ __launch_bounds__(256) void filter_count_kernel(const ScanParams P) {
       for (int d = 0; d < 16; ++d) {
         const uint32_t sel = (x[d] >> 1) & 0x03030303u;
         const uint32_t e1 = __builtin_amdgcn_perm(0u, 0x47544341u, sel);   // 'A' 'C' 'T' 'G' by code
-        const uint32_t ok1 = __builtin_amdgcn_perm(0u, 0xFFFEFFFFu, sel);  // code 2: 'U' = 'T' + 1 is fine too
-        bad |= ((x[d] & 0xDFDFDFDFu) ^ e1) & ok1;
+        // what may differ from that letter: the case bit, and for code 2 bit 0 ('U' = 'T' + 1)
+        const uint32_t ok1 = __builtin_amdgcn_perm(0u, 0xDFDEDFDFu, sel);
+        bad |= (x[d] ^ e1) & ok1;
       }
     }
     // a q-gram that holds the bad byte ends in its block or (Q <= 64) the next one: W + 1 windows
