@@ -1059,7 +1059,10 @@ int ScanJob::enqueue(int attempt) {
       le = launch_trace(Tw, wave_blocks, L.stream);
       if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
     }
-    if (use_thread) {
+    // the thread-per-report kernel only acts on more than kTraceWaveMax reports: when the wave kernel
+    // covers the usual case its launch (an empty kernel otherwise, ~8 us of stream time) is left to
+    // finish(), which knows the count
+    if (use_thread && !use_wave) {
       le = launch_trace(T, trace_blocks, L.stream);
       if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
     }
@@ -1105,7 +1108,14 @@ int ScanJob::finish(ScanOut& out) {
       if (int rc = L.d_cand.reserve((size_t)counts[0] + 1024)) return rc;
       again = true;
     }
-    if (!again) break;
+    if (!again) {
+      if (do_trace && use_wave && use_thread && counts[0] > kTraceWaveMax) {  // the deferred thread-per-report traceback
+        hipError_t le = launch_trace(T, trace_blocks, L.stream);
+        if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
+        HIP_TRY(hipStreamSynchronize(L.stream));
+      }
+      break;
+    }
     if (attempt == 3) return fail(SASSY_HIP_ENOMEM, "candidate / descriptor buffer overflow");
     if (int rc = enqueue(attempt + 1)) return rc;
   }
