@@ -157,6 +157,15 @@ def main():
     torch.cuda.synchronize()
     searcher = sassy_amd.Searcher(args.profile, rc=False)
 
+    # N > 1: the match lists go to rank 0 in one fixed-size collective per search (header + rows,
+    # capacity from what the workload can report: twice the plants of a shard), issued by a worker
+    # thread so that the exchange of search i overlaps search i+1; every timed step's exchange is
+    # complete before the closing barrier (sync() drains the worker)
+    gather_worker = None
+    if world > 1:
+        capacity = 2 * (n_per // args.plant_stride) + 1024
+        gather_worker = multigpu.GatherWorker(multigpu.MatchGather(torch, dist, coll_device, capacity))
+
     def step():
         # one full search of the resident shard; Match records arrive on the host as one packed
         # array (include/sassy_hip.h: sassy_hip_Match + cigar pool), for N > 1 gathered to rank 0
@@ -164,11 +173,12 @@ def main():
         if world == 1:
             # the records are already on the host in their final form (r.array + r.pool)
             return r, searcher.stats()
-        shards = multigpu.gather_shard_results(r, torch, dist, coll_device)  # packs while the headers travel
-        merged = multigpu.merge_shard_results(shards) if rank == 0 else None
-        return merged, searcher.stats()
+        gather_worker.submit(r)
+        return gather_worker.last, searcher.stats()
 
     def sync():
+        if gather_worker is not None:
+            gather_worker.flush()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -190,6 +200,8 @@ def main():
         call_ms += st["total_ms"]
     sync()
     elapsed = time.perf_counter() - t0
+    if gather_worker is not None:
+        matches = gather_worker.last  # rank 0: the merged rows of the last search; None elsewhere
     el = torch.tensor([elapsed, scan_ms / max(1, args.steps), filter_ms / max(1, args.steps)],
                       dtype=torch.float64, device=coll_device)
     if dist is not None:
@@ -214,6 +226,8 @@ def main():
     searcher.set_timing(1)
 
     if rank != 0:
+        if gather_worker is not None:
+            gather_worker.close()
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -249,7 +263,7 @@ def main():
             "workload": (f"BASELINE config {'2' if world == 1 else '5'}: Searcher::<{args.profile.capitalize()}>::new_fwd()"
                          f".search, |pattern|={m} (seeded random), k={k}, {n_per} B random-ACGT text per GPU "
                          f"resident in HBM, one planted near-match per {args.plant_stride} B; step = scan + "
-                         f"traceback + Match records on host" + (" + RCCL gather to rank 0" if world > 1 else "")),
+                         f"traceback + Match records on host" + (" + RCCL gather to rank 0 (one collective per search, overlapped with the next search)" if world > 1 else "")),
             "text_bytes_per_gpu": n_per,
             "total_text_bytes": total,
             "pattern_len": m,
@@ -283,6 +297,8 @@ def main():
         gpu_ends = [(int(e), int(c)) for e, c in zip(matches.array["text_end"], matches.array["cost"])]
         out["cpu_baseline"] = cpu_baseline(host, pat, k, args.profile, gpu_ends, args.cpu_passes)
     print(json.dumps(out), flush=True)
+    if gather_worker is not None:
+        gather_worker.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -166,6 +166,12 @@ size_t sassy_hip_result_len(const sassy_hip_Result *r);
 const sassy_hip_Match *sassy_hip_result_matches(const sassy_hip_Result *r);
 const char *sassy_hip_result_cigars(const sassy_hip_Result *r); /* string pool */
 size_t sassy_hip_result_cigars_len(const sassy_hip_Result *r);   /* bytes in the pool */
+/* Wire format of the multi-GPU match gather (sassy_amd/multigpu.py): one row of 7 + cigar_bytes/8
+ * int64 per match -- pattern_idx, text_start, text_end, pattern_start, pattern_end, cost, strand, then
+ * cigar_bytes bytes of NUL-padded cigar text.  Pure host helper (no device needed); `cigar_bytes` is a
+ * multiple of 8.  SASSY_HIP_EINVAL if a cigar string does not fit. */
+int sassy_hip_pack_rows(const sassy_hip_Match *matches, size_t n, const char *cigars, size_t cigars_len,
+                        int64_t *rows, size_t cigar_bytes);
 /* Shard bookkeeping for the cross-shard plateau rule (see DESIGN.md "seams"):
  * entry_state: 0 = the shard's first report did not depend on the previous shard,
  *              1 = it did (the record with SASSY flag is still in the result, marked below);

@@ -107,7 +107,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_searcher_new", "sassy_hip_set_stream", "sassy_hip_get_stats",
     "sassy_hip_search", "sassy_hip_search_shard", "sassy_hip_required_halo",
     "sassy_hip_result_len", "sassy_hip_result_matches", "sassy_hip_result_cigars",
-    "sassy_hip_result_cigars_len", "sassy_hip_enable_counters", "sassy_hip_set_timing",
+    "sassy_hip_result_cigars_len", "sassy_hip_pack_rows", "sassy_hip_enable_counters", "sassy_hip_set_timing",
     "sassy_hip_set_only_best_match", "sassy_hip_set_max_n_frac", "sassy_hip_search_with_fn",
     "sassy_hip_set_max_overhang",
     "sassy_hip_search_many", "sassy_hip_tsv_header", "sassy_hip_format_tsv",
@@ -189,6 +189,8 @@ def lib():
     L.sassy_hip_result_cigars.argtypes = [vp]
     L.sassy_hip_result_cigars_len.restype = sz
     L.sassy_hip_result_cigars_len.argtypes = [vp]
+    L.sassy_hip_pack_rows.restype = C.c_int
+    L.sassy_hip_pack_rows.argtypes = [vp, sz, C.c_char_p, sz, vp, sz]
     L.sassy_hip_result_exit_state.restype = C.c_int
     L.sassy_hip_result_exit_state.argtypes = [vp]
     L.sassy_hip_result_conditional_index.restype = C.c_int64
@@ -340,7 +342,10 @@ class Searcher:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().sassy_searcher_free(self._h)
+            try:
+                lib().sassy_searcher_free(self._h)
+            except Exception:  # interpreter shutdown: the module globals may be gone already
+                pass
             self._h = None
 
     # --- reference API ---

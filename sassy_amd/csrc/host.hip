@@ -2443,6 +2443,29 @@ size_t sassy_hip_result_len(const sassy_hip_Result* r) { return r ? r->matches.s
 const sassy_hip_Match* sassy_hip_result_matches(const sassy_hip_Result* r) { return r ? r->matches.data() : nullptr; }
 const char* sassy_hip_result_cigars(const sassy_hip_Result* r) { return r ? r->pool.c_str() : nullptr; }
 size_t sassy_hip_result_cigars_len(const sassy_hip_Result* r) { return r ? r->pool.size() : 0; }
+
+int sassy_hip_pack_rows(const sassy_hip_Match* matches, size_t n, const char* cigars, size_t cigars_len, int64_t* rows,
+                        size_t cigar_bytes) {
+  if ((n && (!matches || !rows)) || cigar_bytes % 8 != 0) return fail(SASSY_HIP_EINVAL, "bad argument");
+  const size_t cols = 7 + cigar_bytes / 8;
+  for (size_t i = 0; i < n; ++i) {
+    const sassy_hip_Match& m = matches[i];
+    int64_t* r = rows + i * cols;
+    r[0] = (int64_t)m.pattern_idx;
+    r[1] = (int64_t)m.text_start;
+    r[2] = (int64_t)m.text_end;
+    r[3] = (int64_t)m.pattern_start;
+    r[4] = (int64_t)m.pattern_end;
+    r[5] = m.cost;
+    r[6] = m.strand;
+    if (m.cigar_len > cigar_bytes || (m.cigar_len && (!cigars || (size_t)m.cigar_off + m.cigar_len > cigars_len)))
+      return fail(SASSY_HIP_EINVAL, "cigar longer than the fixed gather field");
+    char* c = reinterpret_cast<char*>(r + 7);
+    if (m.cigar_len) memcpy(c, cigars + m.cigar_off, m.cigar_len);
+    memset(c + m.cigar_len, 0, cigar_bytes - m.cigar_len);
+  }
+  return 0;
+}
 int sassy_hip_result_exit_state(const sassy_hip_Result* r) { return r ? r->exit_state : -1; }
 int64_t sassy_hip_result_conditional_index(const sassy_hip_Result* r) { return r ? r->conditional_index : -1; }
 void sassy_hip_result_free(sassy_hip_Result* r) { delete r; }

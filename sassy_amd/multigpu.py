@@ -51,8 +51,20 @@ class ShardResult:
         return int(self.rows.shape[0])
 
 
-def pack_result(result) -> ShardResult:
-    """sassy_amd.Result -> ShardResult (vectorised; no per-match Python work)."""
+def pack_result(result, out: Optional[np.ndarray] = None) -> ShardResult:
+    """sassy_amd.Result -> ShardResult: the C-ABI's row packer (sassy_hip_pack_rows), straight into
+    `out` (e.g. a pinned staging buffer) when given."""
+    a = result.array
+    n = len(a)
+    rows = out[:n] if out is not None and out.shape[0] >= n else np.empty((n, COLS), dtype=np.int64)
+    if n:
+        from . import lib, _check
+        _check(lib().sassy_hip_pack_rows(a.ctypes.data, n, result.pool, len(result.pool), rows.ctypes.data, CIGAR_BYTES))
+    return ShardResult(rows, result.exit_state, result.conditional_index)
+
+
+def pack_result_numpy(result) -> ShardResult:
+    """The same in numpy (kept as the cross-check of the C packer in the tests)."""
     a = result.array
     n = len(a)
     rows = np.zeros((n, COLS), dtype=np.int64)
@@ -159,3 +171,101 @@ def gather_shard_results(local, torch, dist, device) -> Optional[List[ShardResul
     if rank != 0:
         return None
     return [ShardResult(bufs[r][: counts[r]].cpu().numpy(), heads[r][1], heads[r][2]) for r in range(world)]
+
+
+class MatchGather:
+    """The same exchange set up once for a stream of searches (bench.py): every rank's header and rows
+    travel in ONE collective of fixed size -- `capacity_rows` rows per rank, chosen by the caller from
+    what the workload can report -- through pinned staging buffers on both sides; no per-call
+    allocation, no second round for the sizes.  A rank that has more rows than the capacity makes
+    rank 0 raise (use gather_shard_results for unbounded lists)."""
+
+    def __init__(self, torch, dist, device, capacity_rows: int):
+        self.torch, self.dist, self.device = torch, dist, device
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        self.cap = int(capacity_rows)
+        self.words = 3 + self.cap * COLS
+        pin = device.type == "cuda"
+        self.stage = torch.empty(self.words, dtype=torch.int64, pin_memory=pin)
+        self.stage_np = self.stage.numpy()
+        self.rows_np = self.stage_np[3:].reshape(self.cap, COLS)
+        self.dev = torch.empty(self.words, dtype=torch.int64, device=device)
+        self.copied = torch.cuda.Event() if pin else None
+        if self.rank == 0:
+            self.all_dev = torch.empty((self.world, self.words), dtype=torch.int64, device=device)
+            self.all_host = torch.empty((self.world, self.words), dtype=torch.int64, pin_memory=pin)
+            self.all_np = self.all_host.numpy()
+
+    def gather(self, local) -> Optional[List[ShardResult]]:
+        """local: a ShardResult or a sassy_amd.Result (packed straight into the staging buffer)."""
+        if self.copied is not None:
+            self.copied.synchronize()  # the previous call's upload has left the staging buffer
+        n = len(local)
+        if n <= self.cap:
+            if isinstance(local, ShardResult):
+                self.rows_np[:n] = local.rows
+            else:
+                pack_result(local, out=self.rows_np)
+        self.stage_np[0], self.stage_np[1], self.stage_np[2] = n, local.exit_state, local.conditional_index
+        self.dev.copy_(self.stage, non_blocking=True)
+        if self.copied is not None:
+            self.copied.record()
+        if self.rank != 0:
+            self.dist.gather(self.dev, dst=0)
+            return None
+        self.dist.gather(self.dev, gather_list=list(self.all_dev.unbind(0)), dst=0)
+        self.all_host.copy_(self.all_dev)  # one device -> host copy (synchronous)
+        out = []
+        for r in range(self.world):
+            cnt = int(self.all_np[r, 0])
+            if cnt > self.cap:
+                raise OverflowError(f"rank {r} reports {cnt} matches, gather capacity is {self.cap}")
+            rows = self.all_np[r, 3:3 + cnt * COLS].reshape(cnt, COLS)
+            out.append(ShardResult(rows, int(self.all_np[r, 1]), int(self.all_np[r, 2])))
+        return out
+
+
+class GatherWorker:
+    """Runs MatchGather.gather + merge_shard_results on a worker thread, in submission order (every
+    rank issues its collectives in the same order), so that the exchange of search i overlaps
+    search i+1.  flush() returns when everything submitted has been gathered."""
+
+    def __init__(self, gatherer: MatchGather):
+        import queue
+        import threading
+        self.g = gatherer
+        self.q = queue.Queue()
+        self.last = None
+        self.error = None
+        self.t = threading.Thread(target=self._run, daemon=True)
+        self.t.start()
+
+    def _run(self):
+        if self.g.device.type == "cuda":
+            self.g.torch.cuda.set_device(self.g.device)
+        while True:
+            item = self.q.get()
+            try:
+                if item is None:
+                    return
+                if self.error is None:
+                    shards = self.g.gather(item)
+                    if shards is not None:
+                        self.last = merge_shard_results(shards).copy()
+            except BaseException as e:  # surfaced by flush()
+                self.error = e
+            finally:
+                self.q.task_done()
+
+    def submit(self, local):
+        self.q.put(local)
+
+    def flush(self):
+        self.q.join()
+        if self.error is not None:
+            raise self.error
+        return self.last
+
+    def close(self):
+        self.q.put(None)
+        self.t.join()

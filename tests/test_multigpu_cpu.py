@@ -80,6 +80,23 @@ def _worker(rank, world, port, q):
         got = multigpu.gather_shard_results(empty, torch, dist, dev)
         if rank == 0:
             assert [len(g) for g in got] == [0, 0]
+        # the fixed-capacity, one-collective variant bench.py uses, directly and on its worker thread
+        mg = multigpu.MatchGather(torch, dist, dev, capacity_rows=8)
+        for _ in range(3):
+            got = mg.gather(local)
+            if rank == 0:
+                assert [len(g) for g in got] == [2, 3] and got[1].conditional_index == 0
+                merged = multigpu.matches_from_rows(multigpu.merge_shard_results(got), Match)
+                assert [m.text_start for m in merged] == [3, 90, big, 3_000_000_900]
+            else:
+                assert got is None
+        w = multigpu.GatherWorker(mg)
+        for i in range(5):
+            w.submit(local if i % 2 == 0 else empty)
+        last = w.flush()
+        if rank == 0:
+            assert last is not None and [int(r[1]) for r in last] == [3, 90, -1, 3_000_000_900]
+        w.close()
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
