@@ -17,6 +17,8 @@ bash tools/prof_configs.sh cfg > /dev/null 2>&1
 cp gpurun_out/prof_cfg/summary.txt $OUT/${TAG}_configs_prof.txt
 { python tools/bench_reads.py; python tools/bench_reads.py --reads 330000; python tools/bench_reads.py --overhang 0.5; } > $OUT/${TAG}_reads.json 2> $OUT/reads.err
 { python tools/probe_count.py; python tools/probe_rc.py; } > $OUT/${TAG}_shapes.json 2> $OUT/shapes.err
-./tools/ubench/unaligned_read > $OUT/${TAG}_unaligned_read.txt 2>&1
+mkdir -p tools/ubench/bin
+[ -x tools/ubench/bin/unaligned_read ] || hipcc --offload-arch=gfx950 -O3 -o tools/ubench/bin/unaligned_read tools/ubench/unaligned_read.hip 2> /dev/null
+./tools/ubench/bin/unaligned_read > $OUT/${TAG}_unaligned_read.txt 2>&1
 tail -2 $OUT/*.err
 ls -la $OUT
