@@ -757,6 +757,33 @@ __global__ __launch_bounds__(256) void filter_kernel(const ScanParams P) {
   }
 }
 
+// Rare path of filter_dna_kernel, kept out of line so that it does not shape the register allocation
+// and scheduling of the streaming loop.  `bits`: end positions (bit i = text index 64 b + i) of exact
+// occurrences of piece pp in block b.  The piece is known, so the blocks that can hold the END of a
+// match around the occurrence are known exactly: with rem pattern rows behind the piece and <= k
+// edits, a match that contains the occurrence ending at text position e ends in
+// [e + rem - k, e + rem + k].  The blocks of those columns and of the one behind them are marked
+// (not the block of the occurrence); K0b adds the warm-up in front.
+__device__ __noinline__ void mark_piece_ends(unsigned long long* bitmap, uint64_t bits, uint64_t b, int64_t mirror_n_plus_q,
+                                             int64_t rem, int64_t k, uint64_t n_blocks) {
+  int64_t e_lo = (int64_t)(b * 64) + __ffsll((long long)bits);        // first end position
+  int64_t e_hi = (int64_t)(b * 64) + 64 - __clzll((long long)bits);   // last end position
+  if (mirror_n_plus_q >= 0) {
+    // a piece of the Rc strand's pattern, its string reversed: the occurrence T[f-q, f) is, in
+    // the reversed text, that piece ending at reversed column n - f + q (bitmap: the Rc strand's)
+    const int64_t r_lo = mirror_n_plus_q - e_hi, r_hi = mirror_n_plus_q - e_lo;
+    e_lo = r_lo;
+    e_hi = r_hi;
+  }
+  int64_t c_lo = e_lo + rem - k;
+  // + 1: the report rule decides about an end position when it sees the next column
+  const int64_t c_hi = e_hi + rem + k + 1;
+  if (c_lo < 1) c_lo = 1;
+  uint64_t blo = (uint64_t)(c_lo - 1) >> 6, bhi = (uint64_t)(c_hi - 1) >> 6;
+  if (bhi >= n_blocks) bhi = n_blocks - 1;
+  for (uint64_t x = blo; x <= bhi; ++x) atomicOr(&bitmap[x >> 6], 1ull << (x & 63));
+}
+
 // ====================================================================== K0 for Dna: bit planes only
 // The Dna code of a text byte is two bits ((c >> 1) & 3), so "text char i equals pattern char p"
 // is  (T0 ^ ~P0) & (T1 ^ ~P1)  on the two code bit planes T0, T1 of the block with P0, P1 the
@@ -896,34 +923,15 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
     const uint64_t b = blk0 + it;
     const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
     if (evaluate && hit != 0) {
-      // Rare.  The piece is known here, so the blocks that can hold the END of a match around this
-      // occurrence are known exactly: with rem pattern rows behind the piece and <= k edits, a match
-      // that contains the occurrence ending at text position e ends in [e + rem - k, e + rem + k].
-      // The blocks of those columns and of the one behind them are marked (not the block of the
-      // occurrence); K0b adds the warm-up in front.
 #pragma unroll
       for (int pp = 0; pp < NP; ++pp) {
         const uint64_t bits = ((uint64_t)ah[pp] << 32) | al[pp];
-        if (bits == 0) continue;
-        int64_t e_lo = (int64_t)(b * 64) + __ffsll((long long)bits);        // first end position
-        int64_t e_hi = (int64_t)(b * 64) + 64 - __clzll((long long)bits);   // last end position
-        unsigned long long* bitmap = P.hit_bitmap;
-        if ((P.piece_mirror >> pp) & 1u) {
-          // a piece of the Rc strand's pattern, its string reversed: the occurrence T[f-q, f) is, in
-          // the reversed text, that piece ending at reversed column n - f + q
-          const int64_t n = (int64_t)P.text_len;
-          const int64_t r_lo = n - e_hi + (int64_t)q, r_hi = n - e_lo + (int64_t)q;
-          e_lo = r_lo;
-          e_hi = r_hi;
-          bitmap = P.hit_bitmap_rc;
+        if (bits != 0) {
+          const bool mirror = (P.piece_mirror >> pp) & 1u;
+          mark_piece_ends(mirror ? P.hit_bitmap_rc : P.hit_bitmap, bits, b,
+                          mirror ? (int64_t)P.text_len + (int64_t)q : (int64_t)-1, (int64_t)P.piece_rem[pp], (int64_t)P.k,
+                          P.n_blocks);
         }
-        int64_t c_lo = e_lo + (int64_t)P.piece_rem[pp] - (int64_t)P.k;
-        // + 1: the report rule decides about an end position when it sees the next column
-        const int64_t c_hi = e_hi + (int64_t)P.piece_rem[pp] + (int64_t)P.k + 1;
-        if (c_lo < 1) c_lo = 1;
-        uint64_t blo = (uint64_t)(c_lo - 1) >> 6, bhi = (uint64_t)(c_hi - 1) >> 6;
-        if (bhi >= P.n_blocks) bhi = P.n_blocks - 1;
-        for (uint64_t x = blo; x <= bhi; ++x) atomicOr(&bitmap[x >> 6], 1ull << (x & 63));
       }
     }
   }
