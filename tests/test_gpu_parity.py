@@ -1034,7 +1034,9 @@ def test_full_size_configs_3_and_4_properties(sassy):
     planted = sassy.plant(buf.ptr, n, 0, n, 42, plain, 20, stride=1 << 20)
     s = sassy.Searcher("iupac", rc=False)
     got = s._search(pat, _DevText(buf.ptr, n), 20, sassy.TEXT_ON_DEVICE).matches
-    assert s.stats()["filtered"] in (3, 4)  # a q-gram prefilter (counting by default)
+    import os
+    if os.environ.get("SASSY_HIP_PREFILTER") != "0":
+        assert s.stats()["filtered"] in (3, 4)  # a q-gram prefilter (counting by default)
     assert planted <= len(got) <= planted + planted // 5
     seen = set()
     for m in got:
