@@ -161,7 +161,12 @@ struct ScanLane {
       h_up_cap = 0;
       const size_t want = std::max<size_t>(need * 2, 256 * 1024);
       hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h_up), want, hipHostMallocDefault);
-      if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (upload staging)");
+      if (e != hipSuccess) {  // no pinned memory to be had: an ordinary (host-blocking) copy
+        (void)hipGetLastError();
+        h_up = nullptr;
+        e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream);
+        return e == hipSuccess ? 0 : hip_fail(e, "hipMemcpyAsync");
+      }
       h_up_cap = want;
     }
     memcpy(h_up + h_up_used, src, bytes);
@@ -227,14 +232,26 @@ struct sassy_SearcherType {
   // across calls)
   uint8_t* h_stage = nullptr;
   size_t h_stage_cap = 0;
-  int reserve_stage(size_t bytes) {
-    if (bytes <= h_stage_cap) return 0;
-    if (h_stage) (void)hipHostFree(h_stage);
+  bool h_stage_pinned = false;
+  void free_stage() {
+    if (h_stage) {
+      if (h_stage_pinned) (void)hipHostFree(h_stage);
+      else free(h_stage);
+    }
     h_stage = nullptr;
     h_stage_cap = 0;
+  }
+  int reserve_stage(size_t bytes) {
+    if (bytes <= h_stage_cap) return 0;
+    free_stage();
     const size_t want = bytes + bytes / 4 + 4096;
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h_stage), want, hipHostMallocDefault);
-    if (e != hipSuccess) return hip_fail(e, "hipHostMalloc (text staging)");
+    h_stage_pinned = e == hipSuccess;
+    if (!h_stage_pinned) {  // no pinned memory to be had (locked-memory limit): ordinary memory, slower upload
+      (void)hipGetLastError();
+      h_stage = static_cast<uint8_t*>(malloc(want));
+      if (!h_stage) return fail(SASSY_HIP_ENOMEM, "out of host memory (text staging)");
+    }
     h_stage_cap = want;
     return 0;
   }
@@ -261,8 +278,7 @@ struct sassy_SearcherType {
 
   ~sassy_SearcherType() {
     d_text.release(); d_rev.release(); d_rc_bitmap.release();
-    if (h_stage) (void)hipHostFree(h_stage);
-    h_stage = nullptr; h_stage_cap = 0;
+    free_stage();
     d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
     if (ev_multi) (void)hipEventDestroy(ev_multi);
     if (ev_multi_a) (void)hipEventDestroy(ev_multi_a);
