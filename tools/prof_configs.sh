@@ -19,11 +19,11 @@ root = sys.argv[1]
 dur = defaultdict(list)
 for f in glob.glob(os.path.join(root, "trace", "**", "*kernel_trace.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        dur[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        dur[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 pmc = defaultdict(lambda: defaultdict(list))
 for f in glob.glob(os.path.join(root, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
-        pmc[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        pmc[r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("kernel | launches | avg us | VALU wave-instr per launch | VALU lane-ops/s (x64 lanes) | HBM read GB/s (FETCH_SIZE*2048/avg)")
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     if "sassy_hip" not in k:
