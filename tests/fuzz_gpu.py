@@ -111,6 +111,43 @@ def one_case(rng, searchers):
     return ok, desc, pat, text, got, want
 
 
+def count_case(rng, searchers):
+    """The q-gram counting filter and the one-pass two-strand marks on larger texts: patterns with
+    ambiguity letters, stray non-ACGT text letters (forced windows), both strands."""
+    profile = rng.choice(["iupac", "iupac", "dna"])
+    m = rng.choice([24, 32, 40, 64, 90, 128, 200, 330])
+    k = rng.choice([1, 2, 3, 5, 8, 12, 20, 33])
+    k = max(0, min(k, m // 6 if profile == "iupac" else m // 9 + 1))
+    if profile == "dna" and k < 8:
+        k = max(k, 8 if m >= 90 else k)  # more than 8 pieces: the counting filter takes Dna too
+    k = min(k, m - 1)
+    n = rng.choice([100_000, 400_000, 1_000_000])
+    pat = bytearray(rand_seq(rng, m, b"ACGT"))
+    if profile == "iupac":
+        for _ in range(rng.randrange(0, 4)):
+            pat[rng.randrange(m)] = rng.choice(b"NRYSWKM")
+    pat = bytes(pat)
+    plain = bytes(c if c in b"ACGT" else 65 for c in pat)
+    text = bytearray(rand_seq(rng, n, b"ACGT"))
+    for _ in range(rng.randrange(2, 12)):
+        src = plain if rng.random() < 0.5 else oracle.reverse_complement(profile, plain)
+        ins = mutate(rng, src, rng.randrange(0, k + 2), spaced=rng.choice([0, 5, 6, 7]))
+        at = rng.choice([0, n - len(ins), rng.randrange(0, n - len(ins))])
+        text[at:at + len(ins)] = ins
+    if profile == "iupac":
+        for _ in range(rng.randrange(0, 30)):
+            text[rng.randrange(n)] = rng.choice(b"NRYnacgtuU-")
+    text = bytes(text)
+    rc = rng.random() < 0.7
+    allm = rng.random() < 0.2
+    s = searchers[(profile, rc)]
+    got = s.search_all(pat, text, k) if allm else s.search(pat, text, k)
+    want = oracle.search(profile, pat, text, k, rc=rc, all_minima=allm)
+    desc = dict(mode="count", profile=profile, m=m, k=k, n=n, rc=rc, all_minima=allm, filtered=s.stats()["filtered"],
+                matches=len(want))
+    return key(got) == key(want), desc, pat, text, got, want
+
+
 def many_case(rng, searchers):
     """search_many: several patterns x several texts (batched / per-text paths) against per-pair oracle calls."""
     profile = rng.choice(["dna", "iupac", "iupac", "ascii"])
@@ -232,6 +269,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--focus", default="", help="'count': larger texts through the q-gram counting filter, both strands")
     args = ap.parse_args()
     rng = random.Random(args.seed)
     searchers = {(p, rc): sassy_amd.Searcher(p, rc=rc) for p in ("dna", "iupac", "ascii") for rc in (False, True)
@@ -243,6 +281,8 @@ def main():
     while time.time() - t0 < args.seconds:
         mode = rng.random()
         fn = one_case if mode < 0.55 else many_case if mode < 0.7 else encoded_case if mode < 0.85 else shard_case
+        if args.focus == "count":
+            fn = count_case
         ok, desc, pat, text, got, want = fn(rng, searchers)
         cases += 1
         kinds[desc["filtered"]] = kinds.get(desc["filtered"], 0) + 1
@@ -250,7 +290,7 @@ def main():
         if not ok:
             print("MISMATCH", desc)
             print("pattern", pat)
-            gk, wk = (key(got), key(want)) if desc.get("mode") is None or desc.get("mode") == "shard" else (got, want)
+            gk, wk = (key(got), key(want)) if desc.get("mode") in (None, "shard", "count") else (got, want)
             print("got", len(gk), "want", len(wk))
             extra = [x for x in gk if x not in set(wk)][:5]
             missing = [x for x in wk if x not in set(gk)][:5]
