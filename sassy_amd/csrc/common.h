@@ -200,6 +200,12 @@ struct TraceParams {
   MatchOut* host_out;
   uint8_t* host_str;
   uint32_t host_cap;
+  // trace_wave_kernel ranking its own reports (single text, at most kTraceWaveMax reports): `unsorted` is
+  // the append-order list, `cand` the sorted one it fills; host_cand / host_ctl: the host copies the
+  // rank kernels would have written (sorted head of the list, 64-byte control block)
+  const Candidate* unsorted;
+  Candidate* host_cand;
+  uint4* host_ctl;
 };
 // MatchOut::pad_[0] of a record whose traceback found no ancestor / exceeded the scanned cost
 constexpr uint8_t kTraceFailed = 1;

@@ -571,7 +571,7 @@ struct ScanJob {
   unsigned long long* d_counters = nullptr;
   TraceParams T{}, Tw{};
   uint32_t trace_blocks = 0, wave_blocks = 0, grid = 0, fgrid = 0, desc_cap = 0;
-  bool use_wave = false, use_thread = false, ev_scan = false;
+  bool use_wave = false, use_thread = false, ev_scan = false, self_rank = false;
   uint32_t counts[2] = {0, 0};  // reports, chunk descriptors
   int timing = 1;
 
@@ -1062,15 +1062,26 @@ int ScanJob::enqueue(int attempt) {
   // reports into result order (by end position) -- the head of the list and the control block
   // straight into the pinned host buffer --, then their traceback
   const uint32_t host_cap = std::min<uint32_t>(kSpec, P.cand_cap);
-  le = launch_rank(L.d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(L.d_ctl.p + 64),
-                   L.d_sorted.p, reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands), host_cap,
-                   L.h_pin_dev + kPinCounts, texts, L.stream);
-  if (le != hipSuccess) return hip_fail(le, "rank kernel launch");
+  // One text, traceback by the wave kernel: that kernel ranks its reports itself (up to kTraceWaveMax of
+  // them; finish() falls back to the ranking kernels beyond) -- two launches fewer per search.
+  static const int env_selfrank = getenv("SASSY_HIP_SELF_RANK") ? atoi(getenv("SASSY_HIP_SELF_RANK")) : 1;
+  self_rank = env_selfrank != 0 && do_trace && use_wave && texts.n == 0;
+  if (!self_rank) {
+    le = launch_rank(L.d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(L.d_ctl.p + 64),
+                     L.d_sorted.p, reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands), host_cap,
+                     L.h_pin_dev + kPinCounts, texts, L.stream);
+    if (le != hipSuccess) return hip_fail(le, "rank kernel launch");
+  }
   if (do_trace) {
     T.texts = Tw.texts = texts;
     T.host_out = Tw.host_out = reinterpret_cast<MatchOut*>(L.h_pin_dev + pin_recs);
     T.host_str = Tw.host_str = L.h_pin_dev + pin_ops;
     T.host_cap = Tw.host_cap = host_cap;
+    T.unsorted = nullptr;
+    Tw.unsorted = self_rank ? L.d_cand.p : nullptr;
+    Tw.host_cand = reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands);
+    Tw.host_ctl = reinterpret_cast<uint4*>(L.h_pin_dev + kPinCounts);
+    if (self_rank) Tw.count_max = kTraceWaveMax;
     if (use_wave) {
       le = launch_trace(Tw, wave_blocks, L.stream);
       if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
@@ -1125,8 +1136,24 @@ int ScanJob::finish(ScanOut& out) {
       again = true;
     }
     if (!again) {
-      if (do_trace && use_wave && use_thread && counts[0] > kTraceWaveMax) {  // the deferred thread-per-report traceback
-        hipError_t le = launch_trace(T, trace_blocks, L.stream);
+      if (do_trace && use_wave && counts[0] > kTraceWaveMax && (use_thread || self_rank)) {
+        // many reports: what enqueue() left out -- the ranking kernels (self-ranking mode), then the
+        // thread-per-report traceback, or the wave kernel on the ranked list where only it applies
+        hipError_t le = hipSuccess;
+        if (self_rank) {
+          le = launch_rank(L.d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(L.d_ctl.p + 64), L.d_sorted.p,
+                           reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands), std::min<uint32_t>(kSpec, P.cand_cap),
+                           L.h_pin_dev + kPinCounts, texts, L.stream);
+          if (le != hipSuccess) return hip_fail(le, "rank kernel launch");
+        }
+        if (use_thread) {
+          le = launch_trace(T, trace_blocks, L.stream);
+        } else {
+          TraceParams Tall = Tw;
+          Tall.unsorted = nullptr;
+          Tall.count_max = 0xFFFFFFFFu;
+          le = launch_trace(Tall, wave_blocks, L.stream);
+        }
         if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
         HIP_TRY(hipStreamSynchronize(L.stream));
       }

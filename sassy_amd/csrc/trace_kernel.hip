@@ -374,6 +374,9 @@ template <typename Cell>
 __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char trace_smem[];
   uint32_t count = *P.cand_count;
+  // self-ranking mode (no rank kernels in front): the control block goes to the host from here
+  if (P.unsorted && blockIdx.x == 0 && threadIdx.x < 4 && P.host_ctl)
+    P.host_ctl[threadIdx.x] = reinterpret_cast<const uint4*>(P.cand_count)[threadIdx.x];
   if (count <= P.count_min || count > P.count_max) return;  // the other kernel shape handles it
   if (count > P.cand_cap) count = P.cand_cap;
   const int m = (int)P.m, k = (int)P.k;
@@ -395,8 +398,27 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
   unsigned char* ops = slice + P.band_bytes + P.win_bytes;
   const uint32_t n_waves = gridDim.x * 4;
 
-  for (uint32_t c = blockIdx.x * 4 + wave; c < count; c += n_waves) {
-    const Candidate cd = P.cand[c];                        // wave-uniform
+  for (uint32_t u = blockIdx.x * 4 + wave; u < count; u += n_waves) {
+    uint32_t c = u;
+    Candidate cd;
+    if (P.unsorted) {
+      // The reports arrive in append order; the result order is by end position (unique per strand).
+      // With a few thousand reports every wave ranks its own: it counts the reports that precede
+      // it (64 lanes over the list, which sits in L2) and files the report, and everything it
+      // derives from it, under that rank -- no ranking kernels, two launches fewer per search.
+      cd = P.unsorted[u];
+      uint32_t r = 0;
+      for (uint32_t v = lane; v < count; v += 64) r += P.unsorted[v].pos < cd.pos ? 1u : 0u;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) r += __shfl_xor(r, d);
+      c = r;
+      if (lane == 0) {
+        const_cast<Candidate*>(P.cand)[c] = cd;
+        if (c < P.host_cap && P.host_cand) P.host_cand[c] = cd;
+      }
+    } else {
+      cd = P.cand[c];                                      // wave-uniform
+    }
     const Window W = report_window(P, cd);
     if (W.skip) continue;
     const uint64_t o = W.o, we = W.we;
