@@ -408,7 +408,16 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
       // derives from it, under that rank -- no ranking kernels, two launches fewer per search.
       cd = P.unsorted[u];
       uint32_t r = 0;
-      for (uint32_t v = lane; v < count; v += 64) r += P.unsorted[v].pos < cd.pos ? 1u : 0u;
+      {
+        // four independent loads in flight per lane (the list is L2 resident; the loop is latency bound)
+        uint32_t v = lane;
+        for (; v + 192 < count; v += 256) {
+          const uint64_t p0 = P.unsorted[v].pos, p1 = P.unsorted[v + 64].pos, p2 = P.unsorted[v + 128].pos,
+                         p3 = P.unsorted[v + 192].pos;
+          r += (p0 < cd.pos ? 1u : 0u) + (p1 < cd.pos ? 1u : 0u) + (p2 < cd.pos ? 1u : 0u) + (p3 < cd.pos ? 1u : 0u);
+        }
+        for (; v < count; v += 64) r += P.unsorted[v].pos < cd.pos ? 1u : 0u;
+      }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) r += __shfl_xor(r, d);
       c = r;
