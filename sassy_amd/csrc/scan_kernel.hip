@@ -1295,17 +1295,28 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   unsigned long long cnt_rows = 0, cnt_blocks = 0, cnt_live = 0;
   const unsigned char* my_masks = mask_bytes + lane * 8;
 
+  // the lane's next block is fetched while this one is computed (two or three waves per SIMD do not
+  // hide a load that is issued and consumed in the same iteration)
+  auto fetch = [&](uint32_t step, uint32_t (&dst)[16]) {
+    const bool on = step < my_iters;
+    const uint64_t blk = blk0 + step;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const uint64_t off = blk * 64 + (uint64_t)c * 16;
+      uint4 v = make_uint4(0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u);
+      if (on) v = load_text16(P, off);
+      dst[4 * c] = v.x; dst[4 * c + 1] = v.y; dst[4 * c + 2] = v.z; dst[4 * c + 3] = v.w;
+    }
+  };
+  uint32_t xn[16];
+  fetch(0, xn);
   for (uint32_t it = 0; __any(it < my_iters); ++it) {
     const bool active = it < my_iters;
     const uint64_t b = blk0 + it;
     uint32_t x[16];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const uint64_t off = b * 64 + (uint64_t)c * 16;
-      uint4 v = make_uint4(0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u);
-      if (active) v = load_text16(P, off);
-      x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
-    }
+    for (int c = 0; c < 16; ++c) x[c] = xn[c];
+    fetch(it + 1, xn);
     {
       uint2 msk[NS];
       build_masks<PROFILE, NS>(x, P, msk);
