@@ -96,8 +96,10 @@ def cpu_baseline(host_text, pat, k, profile, gpu_ends, passes):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: a quarter of a second of searches -- the first few dozen calls after start-up run ~2 % slower
+    # than the steady state (clocks, first touches)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--text-bytes", type=int, default=3_000_000_000, help="text bytes per GPU")
     ap.add_argument("--pattern-len", type=int, default=32)
     ap.add_argument("--k", type=int, default=3)
