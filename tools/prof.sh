@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
-BENCH_STATS="python bench.py --steps 20 --warmup 3 --no-cpu-baseline $*"
+BENCH_STATS="python bench.py --steps 100 --warmup 20 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- $BENCH_STATS > $OUT/bench_trace.json 2> $OUT/trace.err
 pass() { # name counters...
   local name=$1; shift
