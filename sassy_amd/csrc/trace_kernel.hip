@@ -370,7 +370,8 @@ __device__ __forceinline__ int dpp_min_scan(int x) {
   return x;
 }
 
-template <typename Cell>
+// ALPHA: overhang (use_alpha) -- the common searches get a fill loop without its branches
+template <typename Cell, bool ALPHA>
 __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char trace_smem[];
   uint32_t count = *P.cand_count;
@@ -433,7 +434,7 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
     const uint64_t o = W.o, we = W.we;
     const int wl = (int)(we - o);
     // overhang: the end cell may lie past the text; columns wl+1 .. iend are virtual 'N'
-    const bool alpha_on = P.use_alpha != 0;
+    const bool alpha_on = ALPHA;
     const int iend = alpha_on ? (int)(cd.pos - o) : wl;
     {  // window -> LDS (coalesced bytes), Iupac letters -> base sets
       const uint8_t* src = P.text + (o - P.global_offset);
@@ -461,16 +462,28 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
       // upper neighbour (j-1, i) = band column b+1 of the previous row
       const int up = __builtin_amdgcn_update_dpp(inf, prev, 0x130, 0xF, 0xF, false);  // wave_shl:1
       int t = inf;
-      if (valid) {
-        if (i == 0) {
-          const int lc = alpha_on ? ov_left(P, j) : j;
-          t = lc < inf ? lc : inf;
-        } else {
-          const uint32_t tc = win[i - 1];
-          const int dg = prev + (rule_hit(rule, pc, tc, rule.emask) ? 0 : 1);
-          const int u = up + 1;
-          t = dg < u ? dg : u;
+      if constexpr (ALPHA) {
+        if (valid) {
+          if (i == 0) {
+            const int lc = ov_left(P, j);
+            t = lc < inf ? lc : inf;
+          } else {
+            const uint32_t tc = win[i - 1];
+            const int dg = prev + (rule_hit(rule, pc, tc, rule.emask) ? 0 : 1);
+            const int u = up + 1;
+            t = dg < u ? dg : u;
+          }
         }
+      } else {
+        // branch-free: the byte index is clamped into the window, cells that do not use it are overwritten
+        int ci = i - 1;
+        ci = ci < 0 ? 0 : (ci > iend ? iend : ci);
+        const uint32_t tc = win[ci];
+        const int dg = prev + (rule_hit(rule, pc, tc, rule.emask) ? 0 : 1);
+        const int u = up + 1;
+        t = dg < u ? dg : u;
+        t = i == 0 ? (j < inf ? j : inf) : t;
+        t = valid ? t : inf;
       }
       // left dependency: v[b] = b + min_{b' <= b} (t[b'] - b'); invalid cells carry a large value
       int v = dpp_min_scan(valid ? t - b : 0x3FFFFFFF) + b;
@@ -570,19 +583,25 @@ hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stre
     if (P.k + 1 <= 255) {
       static bool attr8 = false;
       if (!attr8) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint8_t>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint8_t, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint8_t, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr8 = true;
       }
-      hipLaunchKernelGGL((trace_wave_kernel<uint8_t>), dim3(nblocks), dim3(256), lds, stream, P);
+      if (P.use_alpha) hipLaunchKernelGGL((trace_wave_kernel<uint8_t, true>), dim3(nblocks), dim3(256), lds, stream, P);
+      else hipLaunchKernelGGL((trace_wave_kernel<uint8_t, false>), dim3(nblocks), dim3(256), lds, stream, P);
     } else {
       static bool attr16 = false;
       if (!attr16) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint16_t>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint16_t, false>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint16_t, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr16 = true;
       }
-      hipLaunchKernelGGL((trace_wave_kernel<uint16_t>), dim3(nblocks), dim3(256), lds, stream, P);
+      if (P.use_alpha) hipLaunchKernelGGL((trace_wave_kernel<uint16_t, true>), dim3(nblocks), dim3(256), lds, stream, P);
+      else hipLaunchKernelGGL((trace_wave_kernel<uint16_t, false>), dim3(nblocks), dim3(256), lds, stream, P);
     }
     return hipGetLastError();
   }
