@@ -1180,17 +1180,20 @@ int ScanJob::finish(ScanOut& out) {
     S->stats.live_blocks += c[3];
   }
 
-  out.cands.resize(count);
   if (count) {
     const uint32_t have = std::min<uint32_t>(count, kSpec);
-    memcpy(out.cands.data(), L.h_pin + pin_cands, (size_t)have * sizeof(Candidate));
+    // (assign, not resize + memcpy: one pass over the memory instead of a zero fill and a copy)
+    const Candidate* hc = reinterpret_cast<const Candidate*>(L.h_pin + pin_cands);
+    out.cands.assign(hc, hc + have);
+    out.cands.resize(count);
     if (count > have)
       HIP_TRY(hipMemcpy(out.cands.data() + have, L.d_sorted.p + have, (size_t)(count - have) * sizeof(Candidate), hipMemcpyDeviceToHost));
     if (do_trace) {
+      const sassy_hip_Match* hm = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + pin_recs);
+      out.matches.assign(hm, hm + have);
       out.matches.resize(count);
+      out.pool.assign(reinterpret_cast<const char*>(L.h_pin + pin_ops), (size_t)have * T.str_stride);
       out.pool.resize((size_t)count * T.str_stride);
-      memcpy(out.matches.data(), L.h_pin + pin_recs, (size_t)have * sizeof(MatchOut));
-      memcpy(&out.pool[0], L.h_pin + pin_ops, (size_t)have * T.str_stride);
       if (count > have) {
         HIP_TRY(hipMemcpy(out.matches.data() + have, L.d_trace.p + have, (size_t)(count - have) * sizeof(MatchOut), hipMemcpyDeviceToHost));
         HIP_TRY(hipMemcpy(&out.pool[0] + (size_t)have * T.str_stride, L.d_str.p + (size_t)have * T.str_stride,
