@@ -498,6 +498,14 @@ static int stream_geometry(ScanParams& P, uint64_t owned, uint32_t extra_front, 
   const uint64_t min_bpl = std::max<uint64_t>(8, 6ull * extra_front);
   if (bpl < min_bpl) bpl = min_bpl;
   bpl += bpl & 1;  // even: a staged pair of blocks is then always one aligned 128-byte line
+  // The lanes of a wave read addresses bpl * 64 bytes apart and the chip holds ~1.6 rounds of the grid:
+  // both the stride and the lane count decide how evenly the HBM channels are loaded, and the kernel
+  // time is sensitive to it (bit-plane filter, % of the 8 TB/s roofline: 3.0 GB bpl 88 / 90 / 92 / 94 ->
+  // 51 / 64 / 64 / 53; 2.7 GB 78 / 82 / 84 -> 61 / 53 / 58; 2.0 GB 58 / 60 / 64 -> 54 / 63 / 47).  No static
+  // rule fits every size (multiples of 6 blocks are never bad but not always best); SASSY_HIP_BPL=<n>
+  // overrides the choice for experiments, an on-line tuner per resident text is the planned fix.
+  static const char* env_bpl = getenv("SASSY_HIP_BPL");
+  if (env_bpl != nullptr && atoll(env_bpl) > 0) bpl = (uint64_t)atoll(env_bpl);
   if (bpl > 0xFFFFFFFFull / 2) return fail(SASSY_HIP_EUNSUPPORTED, "text too large for one launch");
   P.bpl = (uint32_t)bpl;
   P.n_chunks = (owned + bpl - 1) / bpl;
