@@ -216,6 +216,49 @@ struct ScanLane {
 // The searcher.  Mirrors the configuration surface of the reference's Searcher<P>
 // (rc, alpha; reference: src/search.rs:227-256, 486-503) and caches device buffers the way the
 // reference caches its host buffers.
+// On-line choice of the lane-chunk length of the prefilter for a resident text.  The kernel time depends
+// chaotically on it (HBM channel mapping against the lane stride and the lane count: +-10 % between
+// neighbouring even values, see stream_geometry), so the first searches of a (text, filter kind) try
+// the even values around the default, two calls each, and the rest use the fastest.  Every trial is a
+// complete, correct search; only its prefilter geometry differs.
+struct GeoTuner {
+  const void* text = nullptr;
+  uint64_t len = 0, owned = 0;
+  uint32_t kind = 0, extra = 0;
+  std::vector<uint32_t> cand;
+  std::vector<float> best;
+  uint32_t trials = 0, chosen = 0;
+  // the chunk length to use for this call (0: the default)
+  uint32_t next(const void* t, uint64_t l, uint64_t own, uint32_t k, uint32_t ex, uint32_t dflt, uint32_t min_bpl) {
+    if (t != text || l != len || own != owned || k != kind || ex != extra) {
+      text = t; len = l; owned = own; kind = k; extra = ex;
+      cand.clear();
+      for (int d = 0; d <= 14; d += 2) {
+        for (int sgn = (d ? -1 : 1); sgn <= 1; sgn += 2) {
+          const int64_t v = (int64_t)dflt + sgn * d;
+          if (v >= (int64_t)min_bpl && v >= 4) cand.push_back((uint32_t)v);
+        }
+      }
+      best.assign(cand.size(), 1e30f);
+      trials = 0;
+      chosen = 0;
+    }
+    if (chosen) return chosen;
+    if (trials < 2 * cand.size()) return cand[trials % cand.size()];
+    size_t b = 0;
+    for (size_t i = 1; i < cand.size(); ++i)
+      if (best[i] < best[b]) b = i;
+    chosen = cand[b];
+    return chosen;
+  }
+  void report(uint32_t bpl, float ms) {
+    if (chosen) return;
+    for (size_t i = 0; i < cand.size(); ++i)
+      if (cand[i] == bpl) { best[i] = std::min(best[i], ms); break; }
+    ++trials;
+  }
+};
+
 struct sassy_SearcherType {
   Profile profile = PROFILE_DNA;
   bool rc = false;
@@ -264,6 +307,7 @@ struct sassy_SearcherType {
   long max_overhang = -1;        // with_max_overhang(): -1 = none
   bool only_best = false;        // only_best_match(): one match per strand, minimal cost, rightmost end
   float max_n_frac = NAN;        // with_max_n_frac(): NaN = off (the reference's None)
+  GeoTuner tuner;                // prefilter geometry per resident text
   DevBuf<uint64_t> d_tables;     // multi-text buffers: start / len tables (both strands)
   DevBuf<unsigned long long> d_multi_bitmap;  // multi-pattern prefilter: one hit bitmap per pattern of the batch
   DevBuf<uint32_t> d_multi_bits;
@@ -491,7 +535,9 @@ static hipError_t launch_list_any(Profile pr, const ScanParams& P, uint32_t grid
 // Chunk geometry of a streaming kernel: enough lanes to fill 256 CUs several times over, chunks
 // long enough that the extra blocks in front of each chunk stay a few percent of the work.
 // wpc: resident waves per CU of the kernel (its workgroups are launched in two full rounds)
-static int stream_geometry(ScanParams& P, uint64_t owned, uint32_t extra_front, uint32_t* grid, int wpc = 16) {
+static int stream_geometry(ScanParams& P, uint64_t owned, uint32_t extra_front, uint32_t* grid, int wpc = 16,
+                           GeoTuner* tuner = nullptr, const void* tune_text = nullptr, uint64_t tune_len = 0,
+                           uint32_t tune_kind = 0) {
   static const int env_wpc = getenv("SASSY_HIP_WAVES_PER_CU") ? atoi(getenv("SASSY_HIP_WAVES_PER_CU")) : 0;
   const uint64_t target_lanes = 256ull * (env_wpc > 0 ? env_wpc : wpc) * 64 * 2;
   uint64_t bpl = (owned + target_lanes - 1) / target_lanes;
@@ -502,10 +548,16 @@ static int stream_geometry(ScanParams& P, uint64_t owned, uint32_t extra_front, 
   // both the stride and the lane count decide how evenly the HBM channels are loaded, and the kernel
   // time is sensitive to it (bit-plane filter, % of the 8 TB/s roofline: 3.0 GB bpl 88 / 90 / 92 / 94 ->
   // 51 / 64 / 64 / 53; 2.7 GB 78 / 82 / 84 -> 61 / 53 / 58; 2.0 GB 58 / 60 / 64 -> 54 / 63 / 47).  No static
-  // rule fits every size (multiples of 6 blocks are never bad but not always best); SASSY_HIP_BPL=<n>
-  // overrides the choice for experiments, an on-line tuner per resident text is the planned fix.
+  // rule fits every size (multiples of 6 blocks are never bad but not always best): GeoTuner tries the
+  // neighbouring even values during the first searches of a resident text and keeps the fastest;
+  // SASSY_HIP_BPL=<n> fixes the value, SASSY_HIP_TUNE=0 keeps the default.
   static const char* env_bpl = getenv("SASSY_HIP_BPL");
+  static const bool env_tune = getenv("SASSY_HIP_TUNE") == nullptr || atoi(getenv("SASSY_HIP_TUNE")) != 0;
   if (env_bpl != nullptr && atoll(env_bpl) > 0) bpl = (uint64_t)atoll(env_bpl);
+  else if (tuner != nullptr && env_tune && env_wpc == 0 && owned * 64 >= (256ull << 20)) {
+    const uint32_t t = tuner->next(tune_text, tune_len, owned, tune_kind, extra_front, (uint32_t)bpl, (uint32_t)(min_bpl + (min_bpl & 1)));
+    if (t) bpl = t;
+  }
   if (bpl > 0xFFFFFFFFull / 2) return fail(SASSY_HIP_EUNSUPPORTED, "text too large for one launch");
   P.bpl = (uint32_t)bpl;
   P.n_chunks = (owned + bpl - 1) / bpl;
@@ -579,7 +631,7 @@ struct ScanJob {
   unsigned long long* d_counters = nullptr;
   TraceParams T{}, Tw{};
   uint32_t trace_blocks = 0, wave_blocks = 0, grid = 0, fgrid = 0, desc_cap = 0;
-  bool use_wave = false, use_thread = false, ev_scan = false, self_rank = false;
+  bool use_wave = false, use_thread = false, ev_scan = false, self_rank = false, tuned = false;
   uint32_t counts[2] = {0, 0};  // reports, chunk descriptors
   int timing = 1;
 
@@ -949,7 +1001,10 @@ int ScanJob::prepare() {
       fwpc = 4 * (int)std::min<uint32_t>(8, (160u * 1024u) / wg_lds);
       extra_front = count_w + 1;
     }
-    if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, extra_front, &fgrid, fwpc)) return rc;
+    // (timing level >= 1 records the two events around the filter: that is what the tuner learns from)
+    tuned = S->timing >= 1 && !ext_bitmap && !ext_desc;
+    if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, extra_front, &fgrid, fwpc, tuned ? &S->tuner : nullptr,
+                                 sh.d_text, sh.text_len, (uint32_t)fkind * 16u + (rc_marked ? 1u : 0u))) return rc;
     F.lds_per_wave = 4096u * F.stage_blocks + (F.piece_planes ? 0u : 2u * bucket * 512u);
     if (fkind == kFilterCount) F.lds_per_wave = 4096u * F.stage_blocks + 64u * count_w;
     F.hit_bitmap = d_bitmap;
@@ -1128,6 +1183,7 @@ int ScanJob::finish(ScanOut& out) {
     if (filtered && attempt == 0 && (timing >= 2 || (timing == 1 && !ext_bitmap))) {
       HIP_TRY(hipEventElapsedTime(&ms, L.ev_a, L.ev_f));
       S->stats.filter_ms += ms;
+      if (tuned) S->tuner.report(F.bpl, ms);
     }
     if (do_trace && timing >= 2) {
       HIP_TRY(hipEventElapsedTime(&ms, L.ev_b, L.ev_c));
