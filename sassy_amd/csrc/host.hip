@@ -307,7 +307,7 @@ struct sassy_SearcherType {
   long max_overhang = -1;        // with_max_overhang(): -1 = none
   bool only_best = false;        // only_best_match(): one match per strand, minimal cost, rightmost end
   float max_n_frac = NAN;        // with_max_n_frac(): NaN = off (the reference's None)
-  GeoTuner tuner;                // prefilter geometry per resident text
+  GeoTuner tuner, tuner_scan;    // prefilter / streaming-DP geometry per resident text
   DevBuf<uint64_t> d_tables;     // multi-text buffers: start / len tables (both strands)
   DevBuf<unsigned long long> d_multi_bitmap;  // multi-pattern prefilter: one hit bitmap per pattern of the batch
   DevBuf<uint32_t> d_multi_bits;
@@ -916,7 +916,9 @@ int ScanJob::prepare() {
   F = P;           // prefilter launch
   fgrid = 0;
   if (!filtered) {
-    if (int rc = stream_geometry(P, owned, P.wb, &grid)) return rc;
+    tuned = S->timing >= 1 && !ext_desc;  // (level 1 times the streaming DP when there is no filter)
+    if (int rc = stream_geometry(P, owned, P.wb, &grid, 16, tuned ? &S->tuner_scan : nullptr, sh.d_text, sh.text_len,
+                                 1000u + plan.nwords)) return rc;
     P.lds_per_wave = 4096u * P.stage_blocks + bucket * 512u + plan.nwords * 512u;
     if ((size_t)kWavesPerGroup * P.lds_per_wave > 160 * 1024)
       return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
@@ -1178,6 +1180,7 @@ int ScanJob::finish(ScanOut& out) {
     if (ev_scan) {
       HIP_TRY(hipEventElapsedTime(&ms, L.ev_a, L.ev_b));
       S->stats.scan_ms += ms;
+      if (!filtered && tuned && attempt == 0) S->tuner_scan.report(P.bpl, ms);
     }
     S->stats.scan_launches += 1;
     if (filtered && attempt == 0 && (timing >= 2 || (timing == 1 && !ext_bitmap))) {
