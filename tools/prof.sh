@@ -8,8 +8,11 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
-BENCH_STATS="python bench.py --steps 100 --warmup 20 --no-cpu-baseline $*"
+# (profiling runs: no geometry trials -- SASSY_HIP_TUNE=0 keeps the default lane-chunk length, which is what the
+# tuner settles on at the bench size -- so that the per-kernel averages are those of the steady state)
+export SASSY_HIP_TUNE=0
+BENCH="python bench.py --steps 3 --warmup 1 --tune-searches 0 --no-cpu-baseline $*"
+BENCH_STATS="python bench.py --steps 100 --warmup 20 --tune-searches 0 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- $BENCH_STATS > $OUT/bench_trace.json 2> $OUT/trace.err
 pass() { # name counters...
   local name=$1; shift
