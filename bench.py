@@ -106,8 +106,8 @@ def main():
     ap.add_argument("--profile", default="dna")
     ap.add_argument("--plant-stride", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tune-searches", type=int, default=34,
-                    help="untimed searches before the warm-up (the library's geometry tuner settles within 30)")
+    ap.add_argument("--tune-searches", type=int, default=40,
+                    help="untimed searches before the warm-up (the library's geometry tuner settles within 36)")
     ap.add_argument("--cpu-passes", type=int, default=4)
     args = ap.parse_args()
 
@@ -188,7 +188,7 @@ def main():
         torch.cuda.synchronize()
 
     # set-up, untimed like the text generation above: the library tunes the prefilter's lane-chunk length
-    # for a resident text during its first ~30 searches (sassy_amd/csrc/host.hip: GeoTuner); they happen
+    # for a resident text during its first ~36 searches (sassy_amd/csrc/host.hip: GeoTuner); they happen
     # here so that neither the W warm-up steps nor the K timed steps contain a trial geometry
     for _ in range(args.tune_searches):
         step()

@@ -239,6 +239,12 @@ struct GeoTuner {
           if (v >= (int64_t)min_bpl && v >= 4) cand.push_back((uint32_t)v);
         }
       }
+      // ... and around two thirds of it (half again as many lanes: the other basin seen in the sweeps)
+      for (int d = -2; d <= 2; d += 2) {
+        const int64_t v = ((int64_t)dflt * 2 / 3) / 2 * 2 + d;
+        if (v >= (int64_t)min_bpl && v >= 4 && std::find(cand.begin(), cand.end(), (uint32_t)v) == cand.end())
+          cand.push_back((uint32_t)v);
+      }
       best.assign(cand.size(), 1e30f);
       trials = 0;
       chosen = 0;

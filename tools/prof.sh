@@ -8,11 +8,10 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-# (profiling runs: no geometry trials -- SASSY_HIP_TUNE=0 keeps the default lane-chunk length, which is what the
-# tuner settles on at the bench size -- so that the per-kernel averages are those of the steady state)
-export SASSY_HIP_TUNE=0
-BENCH="python bench.py --steps 3 --warmup 1 --tune-searches 0 --no-cpu-baseline $*"
-BENCH_STATS="python bench.py --steps 100 --warmup 20 --tune-searches 0 --no-cpu-baseline $*"
+# (counter passes: no geometry trials, the byte and instruction counts do not depend on them; the timed stats run
+# keeps the tuner on -- prof_summary.py reports the last 100 dispatches of every kernel as the steady state)
+BENCH="env SASSY_HIP_TUNE=0 python bench.py --steps 3 --warmup 1 --tune-searches 0 --no-cpu-baseline $*"
+BENCH_STATS="python bench.py --steps 100 --warmup 20 --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- $BENCH_STATS > $OUT/bench_trace.json 2> $OUT/trace.err
 pass() { # name counters...
   local name=$1; shift

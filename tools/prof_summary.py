@@ -21,6 +21,22 @@ for f in find("*kernel_stats.csv"):
             print(f"{name:60s} calls={row.get('Calls')} avg_ns={row.get('AverageNs')} "
                   f"min_ns={row.get('MinNs')} max_ns={row.get('MaxNs')} pct={row.get('Percentage')}")
 
+# The first ~36 searches of the run are the library's geometry trials (host.hip: GeoTuner) and the very first call
+# is cold: the steady state is the LAST 100 dispatches of every kernel, from the kernel trace of the same run.
+print("== steady state: the last 100 dispatches of each kernel (same run, kernel trace) ==")
+for f in find("*kernel_trace.csv"):
+    if os.sep + "trace" + os.sep not in f and not f.endswith(os.path.join("trace", "t_kernel_trace.csv")):
+        continue
+    per = defaultdict(list)
+    with open(f) as fh:
+        for row in csv.DictReader(fh):
+            per[row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0][:60]].append(
+                (int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    for name, v in sorted(per.items(), key=lambda kv: -sum(d for _, d in kv[1])):
+        v.sort()
+        last = [d for _, d in v[-100:]]
+        print(f"{name:60s} n={len(last)} avg_ns={sum(last) / len(last):.0f} min_ns={min(last)} max_ns={max(last)}")
+
 print("== PMC (average per dispatch, kernels scan_kernel / filter_kernel / list_kernel) ==")
 for f in find("*counter_collection.csv"):
     acc = defaultdict(list)
