@@ -1082,3 +1082,29 @@ def test_text_beyond_4gib_both_strands(sassy):
         exp = sorted((m.text_start, m.text_end, m.cost, m.strand, m.cigar) for m in want if inner(m.text_start, m.text_end))
         assert len(exp) >= 2 and got == exp
     buf.free()
+
+
+@pytest.mark.parametrize("profile,k", [("dna", 3), ("iupac", 3), ("dna", 8)])
+def test_geometry_tuner_trials_are_exact(sassy, profile, k):
+    """The library tries ~20 lane-chunk lengths on a resident text during its first searches (GeoTuner):
+    every trial must return the same matches (bit-plane filter, counting filter, streaming DP at k = 8)."""
+    n = 300_000_000
+    buf = sassy.DeviceBuffer(n + 4096)
+    sassy.generate_dna(buf.ptr, n, 42, 0)
+    pat = bytes(oracle.generate_dna(43, 0, 32))
+    planted = sassy.plant(buf.ptr, n, 0, n, 42, pat, 3, stride=1 << 20)
+    s = sassy.Searcher(profile, rc=False)
+    first = None
+    for it in range(45):
+        r = s.search_shard(pat, buf.ptr, 0, n, 0, n, k)
+        got = (r.array.tobytes(), bytes(r.pool))
+        if first is None:
+            first = got
+            assert len(r) >= planted
+        assert got == first, it
+    sl = buf.download(1 << 20, 64 << 20)
+    want = oracle.search(profile, pat, sl, k)
+    ms = [m for m in r.matches if (64 << 20) + 64 <= m.text_start and m.text_end <= (65 << 20)]
+    assert [(m.text_start - (64 << 20), m.text_end - (64 << 20), m.cost, m.cigar) for m in ms] == \
+           [(m.text_start, m.text_end, m.cost, m.cigar) for m in want if m.text_start >= 64]
+    buf.free()
