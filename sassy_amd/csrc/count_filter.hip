@@ -52,7 +52,6 @@ template <int Q, int R, int SB>
 __global__ __launch_bounds__(256) void filter_count_kernel(const ScanParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr uint32_t kTableBytes = 1u << (2 * (Q + R - 1));
-  constexpr uint32_t kIdxMask = kTableBytes - 1u;
   constexpr uint32_t kRowBytes = 64u * SB;
   constexpr uint32_t kSlots = 4u * SB;
   constexpr uint32_t kOwnersPerInstr = 64u / kSlots;

@@ -1015,6 +1015,17 @@ int ScanJob::prepare() {
                                  sh.d_text, sh.text_len, (uint32_t)fkind * 16u + (rc_marked ? 1u : 0u))) return rc;
     F.lds_per_wave = 4096u * F.stage_blocks + (F.piece_planes ? 0u : 2u * bucket * 512u);
     if (fkind == kFilterCount) F.lds_per_wave = 4096u * F.stage_blocks + 64u * count_w;
+    // the bit-plane filter as a linear stream (filter_dna_linear_kernel): every wave owns one contiguous
+    // range of 128-block steps; SASSY_HIP_FILTER_LINEAR=<waves> sets how many waves the text is cut into
+    F.lin_steps = 0;
+    static const int env_lin = getenv("SASSY_HIP_FILTER_LINEAR") ? atoi(getenv("SASSY_HIP_FILTER_LINEAR")) : 0;
+    if (fkind == kFilterPlanes && env_lin > 0 && !ext_bitmap && !ext_desc) {
+      const uint64_t cover = n_blocks - (F.first_owned_block & ~1ull);
+      const uint64_t steps = std::max<uint64_t>(1, (cover + 128ull * env_lin - 1) / (128ull * env_lin));
+      F.lin_steps = (uint32_t)std::min<uint64_t>(steps, 0x7FFFFFFFu);
+      const uint64_t waves = (cover + 128ull * F.lin_steps - 1) / (128ull * F.lin_steps);
+      fgrid = (uint32_t)((waves + kWavesPerGroup - 1) / kWavesPerGroup);
+    }
     F.hit_bitmap = d_bitmap;
     {
       // room for the expected number of chunks on random text (64 (k+1) / 4^q of the blocks hold a piece

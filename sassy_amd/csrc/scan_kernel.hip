@@ -937,6 +937,158 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
   }
 }
 
+// ====================================================================== K0 for Dna, linear streaming
+// Same bit-plane evaluation as filter_dna_kernel, other data movement: a wave walks ONE contiguous text
+// range, 128 consecutive blocks (8 KiB) per step, lane l taking blocks 2l and 2l+1 of the step.  The
+// loads of a wave are then one contiguous 8 KiB read per step (the access pattern the HBM likes best,
+// profiles/r01_stream_read.txt) instead of 64 streams bpl * 64 bytes apart, whose speed depends on how
+// that stride and the lane count fall onto the channel mapping (host.hip: GeoTuner).  What a block
+// needs from its predecessor -- the high halves of its two code planes -- comes from the neighbour
+// lane by DPP (wave_shr:1; lane 0 gets the previous step's last block through the `old` operand), the
+// second block of a lane from its own first.  Every block is evaluated exactly once; a wave primes its
+// planes with one extra step in front of its range.
+template <int NPG>
+__global__ __launch_bounds__(256) void filter_dna_linear_kernel(const ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NP = 4 * NPG;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  unsigned char* tile = smem + (size_t)wave * 8192u;
+
+  const uint64_t cover_lo = P.first_owned_block & ~1ull;  // rows are pairs of blocks = aligned 128-byte lines
+  const uint64_t range = 128ull * P.lin_steps;
+  const uint64_t w_lo = cover_lo + ((uint64_t)blockIdx.x * kWavesPerGroup + wave) * range;
+  if (w_lo >= P.n_blocks) return;  // wave-uniform
+  const uint64_t w_hi = w_lo + range;
+
+  // staging: instruction i fetches the 128-byte rows of lanes 8i .. 8i+7 (1 KiB contiguous), the 16-byte
+  // pieces of a row swizzled so that the owners' ds_read_b128 are conflict free (as in filter_dna_kernel)
+  uint32_t soff[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t owner = (uint32_t)i * 8u + lane / 8u;
+    const uint32_t slot = lane % 8u;
+    const uint32_t j = slot ^ ((owner >> 1) & 7u);
+    soff[i] = owner * 128u + j * 16u;
+  }
+  const uint32_t fsw = (lane >> 1) & 7u;
+  uint32_t rc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rc[c] = lane * 128u + (((uint32_t)c ^ (fsw & 3u)) << 4);
+
+  const uint32_t q = P.piece_len;
+  uint32_t nb0[NP], nb1[NP];
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp) {
+    nb0[pp] = ~P.piece_bits[pp][0];
+    nb1[pp] = ~P.piece_bits[pp][1];
+  }
+  // steps: one priming step in front of the range (unless the range starts the buffer), then lin_steps
+  const bool prime = w_lo >= 128;
+  const uint64_t base0 = prime ? w_lo - 128 : w_lo;
+  const uint32_t n_steps = P.lin_steps + (prime ? 1u : 0u);
+  const bool interior = (base0 + 128ull * n_steps) * 64 <= P.text_len;
+  const uint8_t* text_base = P.text + base0 * 64;
+  uint32_t carry0 = 0, carry1 = 0;  // plane high halves of the last block of the previous step
+
+  uint4 nxt[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    nxt[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (interior) nxt[i] = *reinterpret_cast<const uint4*>(text_base + soff[i]);
+  }
+  for (uint32_t st = 0; st < n_steps; ++st) {
+    const uint64_t base = base0 + 128ull * st;
+    if (base >= P.n_blocks) break;  // wave-uniform
+    if (interior) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = nxt[i];
+      if (st + 1 < n_steps) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          nxt[i] = *reinterpret_cast<const uint4*>(text_base + (uint64_t)(st + 1) * 8192 + soff[i]);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint64_t off = base * 64 + soff[i];
+        uint4 v;
+        if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
+        else v = load_tail16(P.text, off, P.text_len);
+        *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+      }
+    }
+    // the planes of the lane's two blocks
+    uint2 ta0, ta1, tb0, tb1;
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const uint32_t hs = ((((uint32_t)sub << 2) ^ (fsw & 4u)) << 4);
+      uint32_t x[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + rc[c] + hs);
+        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+      }
+      if (sub == 0) { ta0 = bit_plane<1>(x); ta1 = bit_plane<2>(x); }
+      else { tb0 = bit_plane<1>(x); tb1 = bit_plane<2>(x); }
+    }
+    // predecessor of block 2l: block 2l-1 = the neighbour lane's second block (lane 0: the previous step's)
+    const uint32_t pa0 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry0, (int)tb0.y, 0x138, 0xF, 0xF, false);  // wave_shr:1
+    const uint32_t pa1 = (uint32_t)__builtin_amdgcn_update_dpp((int)carry1, (int)tb1.y, 0x138, 0xF, 0xF, false);
+    carry0 = (uint32_t)__builtin_amdgcn_readlane((int)tb0.y, 63);
+    carry1 = (uint32_t)__builtin_amdgcn_readlane((int)tb1.y, 63);
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub) {
+      const uint2 t0 = sub == 0 ? ta0 : tb0, t1 = sub == 0 ? ta1 : tb1;
+      const uint32_t prev0 = sub == 0 ? pa0 : ta0.y, prev1 = sub == 0 ? pa1 : ta1.y;
+      uint32_t al[NP], ah[NP];
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) { al[pp] = 0xFFFFFFFFu; ah[pp] = 0xFFFFFFFFu; }
+#pragma unroll
+      for (int d = 0; d < 12; ++d) {
+        if ((uint32_t)d < q) {  // wave-uniform
+          uint32_t s0l, s0h, s1l, s1h;
+          if (d == 0) {
+            s0l = t0.x; s0h = t0.y; s1l = t1.x; s1h = t1.y;
+          } else {
+            s0l = __builtin_amdgcn_alignbit(t0.x, prev0, 32 - d);
+            s0h = __builtin_amdgcn_alignbit(t0.y, t0.x, 32 - d);
+            s1l = __builtin_amdgcn_alignbit(t1.x, prev1, 32 - d);
+            s1h = __builtin_amdgcn_alignbit(t1.y, t1.x, 32 - d);
+          }
+          const uint32_t j = q - 1u - (uint32_t)d;
+#pragma unroll
+          for (int pp = 0; pp < NP; ++pp) {
+            const uint32_t n0 = 0u - ((nb0[pp] >> j) & 1u);
+            const uint32_t n1 = 0u - ((nb1[pp] >> j) & 1u);
+            al[pp] = bitop3<0x60>(al[pp], s0l, n0);  // a & (b ^ c)
+            ah[pp] = bitop3<0x60>(ah[pp], s0h, n0);
+            al[pp] = bitop3<0x60>(al[pp], s1l, n1);
+            ah[pp] = bitop3<0x60>(ah[pp], s1h, n1);
+          }
+        }
+      }
+      uint32_t hit = 0;
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) hit |= al[pp] | ah[pp];
+      const uint64_t b = base + 2ull * lane + (uint64_t)sub;
+      const bool evaluate = b >= w_lo && b < w_hi && b >= P.first_owned_block && b < P.n_blocks;
+      if (evaluate && hit != 0) {
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+          const uint64_t bits = ((uint64_t)ah[pp] << 32) | al[pp];
+          if (bits != 0) {
+            const bool mirror = (P.piece_mirror >> pp) & 1u;
+            mark_piece_ends(mirror ? P.hit_bitmap_rc : P.hit_bitmap, bits, b,
+                            mirror ? (int64_t)P.text_len + (int64_t)q : (int64_t)-1, (int64_t)P.piece_rem[pp], (int64_t)P.k,
+                            P.n_blocks);
+          }
+        }
+      }
+    }
+  }
+}
+
 // ====================================================================== K0 for many Dna patterns
 // search_encoded_patterns with thousands of equal-length patterns (CRISPR guides): the text bytes,
 // the two code bit planes and their q shifted copies are the same for every pattern, only the
@@ -1617,6 +1769,13 @@ hipError_t launch_filter_table(const ScanParams& P, uint32_t grid, hipStream_t s
   }
 }
 hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  if (P.piece_planes && P.lin_steps) {  // linear streaming variant (grid sized by the host for its wave ranges)
+    if (P.piece_groups == 1)
+      hipLaunchKernelGGL((filter_dna_linear_kernel<1>), dim3(grid), dim3(256), (size_t)kWavesPerGroup * 8192u, stream, P);
+    else
+      hipLaunchKernelGGL((filter_dna_linear_kernel<2>), dim3(grid), dim3(256), (size_t)kWavesPerGroup * 8192u, stream, P);
+    return hipGetLastError();
+  }
   if (P.piece_planes) {  // <= 8 pieces: the bit-plane kernel (lds_per_wave = the staging tile only)
     if (P.stage_blocks == 1)
       return P.piece_groups == 1 ? launch_filter_planes<1, 1>(P, grid, stream) : launch_filter_planes<1, 2>(P, grid, stream);
