@@ -264,24 +264,57 @@ class Result:
     first use (a Python object per match is far slower than the search itself)."""
 
     def __init__(self, handle):
+        # The C call has left the finished records on the host (sassy_hip_Result); they are copied into
+        # Python objects only when somebody looks at them (`array`, `pool`, `matches`).
+        L = lib()
+        self._h = handle
+        self._n = L.sassy_hip_result_len(handle)
+        self.exit_state = L.sassy_hip_result_exit_state(handle)
+        self.conditional_index = L.sassy_hip_result_conditional_index(handle)
+        self._array = None
+        self._pool = None
+        self._matches = None
+
+    def _materialise(self):
+        if self._array is not None:
+            return
         import numpy as np
         L = lib()
+        h, self._h = self._h, None
         try:
-            n = L.sassy_hip_result_len(handle)
-            ptr = L.sassy_hip_result_matches(handle)
+            n = self._n
+            ptr = L.sassy_hip_result_matches(h)
             raw = C.string_at(ptr, n * 64) if n else b""
-            self.array = np.frombuffer(raw, dtype=match_dtype())
-            plen = L.sassy_hip_result_cigars_len(handle)
-            pool = L.sassy_hip_result_cigars(handle)
-            self.pool = C.string_at(pool, plen) if plen else b""
-            self.exit_state = L.sassy_hip_result_exit_state(handle)
-            self.conditional_index = L.sassy_hip_result_conditional_index(handle)
-            self._matches = None
+            self._array = np.frombuffer(raw, dtype=match_dtype())
+            plen = L.sassy_hip_result_cigars_len(h)
+            pool = L.sassy_hip_result_cigars(h)
+            self._pool = C.string_at(pool, plen) if plen else b""
         finally:
-            L.sassy_hip_result_free(handle)
+            L.sassy_hip_result_free(h)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                lib().sassy_hip_result_free(h)
+            except Exception:  # interpreter shutdown
+                pass
+            self._h = None
+
+    @property
+    def array(self):
+        """The C match array copied once into a numpy structured array (match_dtype)."""
+        self._materialise()
+        return self._array
+
+    @property
+    def pool(self) -> bytes:
+        """The cigar string pool."""
+        self._materialise()
+        return self._pool
 
     def __len__(self):
-        return len(self.array)
+        return self._n
 
     @property
     def matches(self) -> List["Match"]:
