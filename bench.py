@@ -34,63 +34,60 @@ METRIC = "GB text/sec (+ matches/sec) |P|=32 k=3 DNA, 1/2/4/8 MI355X vs CPU"
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def cpu_baseline(host_text, pat, k, profile, gpu_ends, passes):
-    """Reference-shaped CPU port on all host cores over the same text (see module docstring)."""
-    import threading
-
-    import numpy as np
-
+def cpu_baseline(host_text, pat, k, profile, gpu_ends, min_seconds):
+    """Reference-shaped CPU port on all host cores over the same text (see module docstring): the
+    threads live inside liboracle.so (oracle/sassy_refstyle.c: rs_scan_mt -- persistent pthreads, one
+    shard each, the clock runs between two barriers so thread creation is not timed, passes repeat
+    until min_seconds have gone by)."""
     import oracle
 
     n = host_text.size
-    m = len(pat)
     cores = os.cpu_count() or 1
-    T = max(1, min(cores, 256))
-    ov = -(-(m + k + 1) // 64) * 64
-    per = -(-n // T)
-    per = -(-per // 64) * 64
-    shards = []
-    for t in range(T):
-        a, b = t * per, min((t + 1) * per, n)
-        if a >= b:
-            break
-        shards.append((a, b, max(0, a - ov)))
-    results = [None] * len(shards)
-
-    def work(i):
-        a, b, s = shards[i]
-        ends, _ = oracle.refstyle_ends(profile, pat, host_text[s:b], k)
-        results[i] = [(p + s, c) for p, c in ends if (p + s > a or a == 0) and p + s <= b]
-
     oracle.lib()  # build / load outside the timed region
-    t0 = time.perf_counter()
-    for _ in range(passes):
-        th = [threading.Thread(target=work, args=(i,)) for i in range(len(shards))]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-    dt = time.perf_counter() - t0
-    ends = [e for r in results for e in r]
+    ends, info = oracle.refstyle_ends_mt(profile, pat, host_text, k, cores, min_seconds)
+    T = info["shards"]
+    gbps = n * info["passes"] / info["seconds"] / 1e9
     # single thread, one search call, on a 2^28-byte slice (comparable to the reference's
     # published 1.2-2.1 GB/s per thread, BASELINE.md)
     sl = host_text[: min(n, 1 << 28)]
     t1 = time.perf_counter()
     oracle.refstyle_ends(profile, pat, sl, k)
     st = time.perf_counter() - t1
+    single = sl.size / st / 1e9
     return {
-        "value": round(n * passes / dt / 1e9, 3),
+        "value": round(gbps, 3),
         "unit": "GB/s",
-        "cores": len(shards),
+        "cores": T,
         "kind": "port",
-        "sample": f"{passes} passes over the full {n} byte text of this run, split into {len(shards)} "
-                  f"shards with {ov} bytes overlap, one thread each "
-                  f"(oracle/sassy_refstyle.c, gcc -O3 -mavx2 -mbmi2, 4x u64 lanes)",
-        "single_thread_gbps": round(sl.size / st / 1e9, 3),
-        "cpu_seconds": round(dt * len(shards), 2),
+        "sample": f"{info['passes']} passes ({info['seconds']:.2f} s wall) over the full {n} byte text of this run, "
+                  f"{T} persistent pthreads inside liboracle.so, one shard each with m+k+1 bytes of overlap (whole "
+                  f"blocks), clock between two barriers (oracle/sassy_refstyle.c rs_scan_mt, gcc -O3 -mavx2 -mbmi2, "
+                  f"4x u64 lanes)",
+        "single_thread_gbps": round(single, 3),
+        "per_thread_gbps": round(gbps / T, 4),
+        "parallel_efficiency": round(gbps / T / single, 3) if single > 0 else None,
+        "cpu_seconds": round(info["busy_seconds"], 2),
         "host_cpus": cores,
         "ends_equal_gpu": ends == gpu_ends,
     }
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here (one
+    process per GPU under torch.distributed.run, rendezvous on 127.0.0.1) and hand their exit code
+    back.  Under a launcher (WORLD_SIZE set) this is never reached."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -108,8 +105,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tune-searches", type=int, default=40,
                     help="untimed searches before the warm-up (the library's geometry tuner settles within 36)")
-    ap.add_argument("--cpu-passes", type=int, default=4)
+    ap.add_argument("--cpu-seconds", type=float, default=2.0,
+                    help="wall seconds the CPU baseline's threads keep scanning (at least one pass)")
+    ap.add_argument("--allow-shared-gpu", action="store_true",
+                    help="debugging the N > 1 path on a box with fewer GPUs than ranks: ranks share devices and "
+                         "the match exchange goes over gloo; never a valid scaling measurement")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
 
     import torch
 
@@ -119,14 +124,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the number of ranks must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (torch.cuda.is_available() is False)")
     n_dev = torch.cuda.device_count()
-    # one rank per GPU over RCCL; on a box with fewer GPUs than ranks (debugging the N > 1 path on a
-    # single GPU) the ranks share devices and the match gather goes over gloo with host tensors
+    # one rank per GPU over RCCL; --allow-shared-gpu (debugging the N > 1 path on a box with fewer GPUs
+    # than ranks): the ranks share devices and the match exchange goes over gloo with host tensors
     shared_gpu = world > n_dev
+    if shared_gpu and not args.allow_shared_gpu:
+        raise SystemExit(f"--gpus {args.gpus} but only {n_dev} HIP device(s) visible (one rank per GPU)")
     torch.cuda.set_device(local_rank % n_dev)
     device = torch.device("cuda", local_rank % n_dev)
     coll_device = torch.device("cpu") if shared_gpu else device
@@ -161,22 +168,27 @@ def main():
     torch.cuda.synchronize()
     searcher = sassy_amd.Searcher(args.profile, rc=False)
 
-    # N > 1: the match lists go to rank 0 in one fixed-size collective per search (header + rows,
-    # capacity from what the workload can report: twice the plants of a shard), issued by a worker
-    # thread so that the exchange of search i overlaps search i+1; every timed step's exchange is
-    # complete before the closing barrier (sync() drains the worker)
+    # N > 1: the match lists go to rank 0 in one fixed-size collective per search (header + rows; the
+    # capacity starts at 1024 rows and every rank doubles it alike when a header shows that some list did
+    # not fit -- nothing here knows how many matches the text holds), issued by a worker thread so that the
+    # exchange of search i overlaps search i+1; every timed step's exchange is complete before the closing
+    # barrier (sync() drains the worker)
     gather_worker = None
     if world > 1:
-        capacity = 2 * (n_per // args.plant_stride) + 1024
-        gather_worker = multigpu.GatherWorker(multigpu.MatchGather(torch, dist, coll_device, capacity))
+        gather_worker = multigpu.GatherWorker(multigpu.MatchGather(
+            torch, dist, coll_device, capacity_rows=1024, cigar_bytes=multigpu.cigar_bytes_for(m, k)))
 
     def step():
         # one full search of the resident shard; Match records arrive on the host as one packed
         # array (include/sassy_hip.h: sassy_hip_Match + cigar pool), for N > 1 gathered to rank 0
-        r = searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
         if world == 1:
             # the records are already on the host in their final form (r.array + r.pool)
-            return r, searcher.stats()
+            return searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k), searcher.stats()
+        try:
+            r = searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
+        except Exception:
+            gather_worker.submit_error()  # the other ranks must not wait for this one's rows forever
+            raise
         gather_worker.submit(r)
         return gather_worker.last, searcher.stats()
 
@@ -245,7 +257,7 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total * args.steps / elapsed / 1e9
     achieved = n_per / (dom_ms / 1e3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
@@ -254,6 +266,8 @@ def main():
             t = json.load(open(tpath))
             if t.get("text_bytes_per_gpu") == n_per:
                 traffic = t.get("kernels", {}).get(dom_name, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic_source = "profiles/hbm_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this workload, separate passes (tools/prof.sh); not measured in this run"
         except Exception:
             traffic = None
     out = {
@@ -279,7 +293,8 @@ def main():
             "pattern_len": m,
             "k": k,
             "profile": args.profile,
-            "parallelism": f"text sharded x{world}, one process per GPU",
+            "parallelism": f"text sharded x{world}, one process per GPU"
+                           + ("" if world == 1 else f", {dist.get_backend()} ({'RCCL' if dist.get_backend() == 'nccl' else 'debug: shared GPU'}) world {dist.get_world_size()}"),
             "setup": f"{args.tune_searches} untimed searches before the warm-up (geometry tuner of the resident text)",
         },
         "matches": len(matches),
@@ -299,6 +314,7 @@ def main():
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             "traffic": traffic,
+            "traffic_source": traffic_source,
             "kernel": dom_name,
             "algorithmic_bytes_per_launch": n_per,
         },
@@ -306,12 +322,40 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         host = buf[:n_per].cpu().numpy()
         gpu_ends = [(int(e), int(c)) for e, c in zip(matches.array["text_end"], matches.array["cost"])]
-        out["cpu_baseline"] = cpu_baseline(host, pat, k, args.profile, gpu_ends, args.cpu_passes)
+        out["cpu_baseline"] = cpu_baseline(host, pat, k, args.profile, gpu_ends, args.cpu_seconds)
+        out["h2d_inclusive"] = h2d_inclusive(sassy_amd, args.profile, pat, host, k, len(matches))
     print(json.dumps(out), flush=True)
     if gather_worker is not None:
         gather_worker.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def h2d_inclusive(sassy_amd, profile, pat, host_text, k, want_matches):
+    """The drop-in entry point's rate: `search(searcher, pattern, text, ...)` of include/sassy.h takes a HOST
+    text pointer (reference: src/c.rs:89-122), so each call moves the text over PCIe before it can be
+    scanned.  Timed here on the same text through the same C symbol, after one untimed call (buffers)."""
+    import ctypes as C
+    L = sassy_amd.lib()
+    s = L.sassy_searcher(profile.encode(), False, float("nan"))
+    out = C.POINTER(sassy_amd.CMatch)()
+    addr = host_text.ctypes.data
+    n = host_text.size
+    times = []
+    cnt = 0
+    for i in range(3):
+        t0 = time.perf_counter()
+        cnt = L.search(s, pat, len(pat), C.cast(addr, C.c_char_p), n, k, C.byref(out))
+        dt = time.perf_counter() - t0
+        L.sassy_matches_free(out, cnt)
+        if i:
+            times.append(dt)
+    L.sassy_searcher_free(s)
+    best = min(times)
+    return {"value": round(n / best / 1e9, 2), "unit": "GB/s", "ms_per_search": round(best * 1e3, 2),
+            "what": "drop-in search() of include/sassy.h on a host text (pageable numpy memory): upload over PCIe + "
+                    "scan + matches, best of 2 calls after one untimed call; never the headline value",
+            "matches": int(cnt), "matches_equal_resident": int(cnt) == int(want_matches)}
 
 
 def _dna_bytes(seed, first, n):

@@ -38,8 +38,11 @@ typedef struct sassy_Match {
 
 /* Replaces `sassy_searcher` (c/sassy.h:38, src/c.rs:52-70).
  * alphabet: "ascii" | "dna" | "iupac" (case-insensitive).  rc: also search the reverse
- * complement strand.  alpha: overhang cost, NAN disables (overhang itself is not built yet:
- * a non-NAN alpha aborts with a message instead of silently ignoring it). */
+ * complement strand.  alpha: overhang cost per overhanging pattern character, 0 <= alpha <= 1,
+ * NAN disables; overhang is defined for "iupac" only -- any other alphabet with a non-NAN alpha
+ * aborts with a message, like the reference's Searcher::new panics (src/search.rs:373-383).
+ * "ascii" with rc = true constructs (as in the reference) and aborts at the first search: the
+ * reference's Ascii profile has no complement. */
 struct sassy_SearcherType *sassy_searcher(const char *alphabet, bool rc, float alpha);
 
 /* Replaces `sassy_searcher_free` (c/sassy.h:43, src/c.rs:74-81). */

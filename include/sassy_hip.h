@@ -96,6 +96,11 @@ int sassy_hip_get_stats(const sassy_SearcherType *s, sassy_hip_Stats *out);
  * streaming scan when unfiltered; default), 2 = every phase (scan_ms, filter_ms, trace_ms).  Each
  * recorded event costs a few microseconds of stream idle time. */
 int sassy_hip_set_timing(sassy_SearcherType *s, int level);
+/* Which scan path a searcher takes: -1 = the library's choice (exact prefilter where the pattern's pieces are
+ * selective, the streaming DP otherwise; process-wide override: SASSY_HIP_PREFILTER), 0 = always the streaming
+ * DP over every block, 1 = prefilter also with short pieces.  All give the same matches; the setting exists so
+ * that the paths can be checked against each other (tests) and timed apart. */
+int sassy_hip_set_prefilter(sassy_SearcherType *s, int mode);
 /* Count DP word-rows / blocks in the scan kernel (stats.word_rows, stats.blocks); off by default. */
 int sassy_hip_enable_counters(sassy_SearcherType *s, int on);
 

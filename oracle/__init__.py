@@ -37,7 +37,7 @@ def build(force: bool = False) -> str:
         srcs_present and any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in _SRCS)
     )
     if force or stale:
-        cmd = ["gcc", "-O3", "-mavx2", "-mbmi2", "-shared", "-fPIC", "-o", _SO] + _SRCS + ["-lm"]
+        cmd = ["gcc", "-O3", "-mavx2", "-mbmi2", "-shared", "-fPIC", "-pthread", "-o", _SO] + _SRCS + ["-lm"]
         subprocess.check_call(cmd)
     return _SO
 
@@ -104,6 +104,10 @@ def lib():
     L.rs_scan.restype = C.c_size_t
     L.rs_scan.argtypes = [C.c_int, u8p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32, C.c_int,
                           C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]
+    L.rs_scan_mt.restype = C.c_size_t
+    L.rs_scan_mt.argtypes = [C.c_int, u8p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32, C.c_int, C.c_double,
+                             C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int),
+                             C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_double)]
     L.rs_free.restype = None
     L.rs_free.argtypes = [C.c_void_p]
     L.rs_lanes.restype = C.c_int
@@ -254,6 +258,30 @@ def refstyle_ends(profile, pattern: bytes, text, k: int, all_minima: bool = Fals
     L.rs_free(oc)
     ends = [(int(p), int(c)) for p, c in zip(pos, cost)]
     return ends, {"word_rows": int(stats[0]), "blocks": int(stats[1]), "lanes": L.rs_lanes()}
+
+
+def refstyle_ends_mt(profile, pattern: bytes, text, k: int, threads: int, min_seconds: float = 1.0):
+    """The reference-shaped scan on `threads` persistent host threads (one shard each, m+k+1 bytes of
+    overlap rounded up to whole blocks), repeated until `min_seconds` have passed; thread creation is
+    outside the clock (oracle/sassy_refstyle.c: rs_scan_mt).  Returns (ends of the last pass, info)
+    with info = {'passes', 'seconds', 'shards', 'busy_seconds'}."""
+    import numpy as np
+    L = lib()
+    if isinstance(text, (bytes, bytearray)):
+        arr = np.frombuffer(text, dtype=np.uint8)
+    else:
+        arr = np.ascontiguousarray(text, dtype=np.uint8)
+    op, oc = C.c_void_p(), C.c_void_p()
+    passes, shards, secs, busy = C.c_int(), C.c_int(), C.c_double(), C.c_double()
+    cnt = L.rs_scan_mt(_profile(profile), bytes(pattern), len(pattern), arr.ctypes.data, arr.size, k, int(threads),
+                       float(min_seconds), C.byref(op), C.byref(oc), C.byref(passes), C.byref(secs), C.byref(shards),
+                       C.byref(busy))
+    pos = np.ctypeslib.as_array(C.cast(op, C.POINTER(C.c_uint64)), shape=(max(cnt, 1),))[:cnt].copy()
+    cost = np.ctypeslib.as_array(C.cast(oc, C.POINTER(C.c_int32)), shape=(max(cnt, 1),))[:cnt].copy()
+    L.rs_free(op)
+    L.rs_free(oc)
+    ends = [(int(p), int(c)) for p, c in zip(pos, cost)]
+    return ends, {"passes": passes.value, "seconds": secs.value, "shards": shards.value, "busy_seconds": busy.value}
 
 
 def generate_dna(seed: int, first: int, n: int):

@@ -431,6 +431,113 @@ size_t rs_scan(int profile, const uint8_t *pat, size_t m, const uint8_t *text, s
     return total;
 }
 
+
+/* ------------------------------------------------------------ many host threads (bench.py's cpu_baseline)
+ * The analogue of the reference CLI's record-parallel threads (bin/grep.rs:476-503: N threads, each with
+ * its own Searcher): the text is cut into `threads` shards, every persistent worker scans its shard plus
+ * `overlap` bytes to its left with rs_scan and keeps the reports it owns (end position inside the shard;
+ * shard 0 also owns position 0).  The workers are created once, meet at a barrier, and then repeat the
+ * scan pass after pass until `min_seconds` of wall time have gone by (at least one pass); the clock
+ * runs between the first barrier and the last one, so thread creation is not timed.  Returns the number
+ * of owned reports of the last pass (merged in shard order into *out_pos / *out_cost, malloc'ed) and
+ * writes the passes done and the seconds they took. */
+#include <pthread.h>
+#include <time.h>
+
+typedef struct {
+    int profile; const uint8_t *pat; size_t m; const uint8_t *text; size_t n; int32_t k;
+    size_t a, b, s;              /* owns (a, b] (+ 0 if a == 0), scans [s, b) */
+    uint64_t *pos; int32_t *cost; size_t cnt;
+    double busy;                 /* seconds this worker spent scanning */
+    pthread_barrier_t *bar; volatile int *stop; int id;
+    double min_seconds; double *elapsed; int *passes;
+} rs_mt_worker;
+
+static double rs_now(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *rs_mt_main(void *arg) {
+    rs_mt_worker *w = (rs_mt_worker *)arg;
+    double t0 = 0;
+    pthread_barrier_wait(w->bar);
+    if (w->id == 0) t0 = rs_now();
+    for (;;) {
+        uint64_t *op = NULL; int32_t *oc = NULL;
+        const double b0 = rs_now();
+        size_t c = rs_scan(w->profile, w->pat, w->m, w->text + w->s, w->b - w->s, w->k, 0, &op, &oc, NULL);
+        size_t keep = 0;
+        for (size_t i = 0; i < c; i++) {
+            const uint64_t g = op[i] + w->s;
+            if ((g > w->a || w->a == 0) && g <= w->b) { op[keep] = g; oc[keep] = oc[i]; keep++; }
+        }
+        w->busy += rs_now() - b0;
+        free(w->pos); free(w->cost);
+        w->pos = op; w->cost = oc; w->cnt = keep;
+        pthread_barrier_wait(w->bar);
+        if (w->id == 0) {
+            *w->passes += 1;
+            *w->elapsed = rs_now() - t0;
+            if (*w->elapsed >= w->min_seconds) *w->stop = 1;
+        }
+        pthread_barrier_wait(w->bar);
+        if (*w->stop) break;
+    }
+    return NULL;
+}
+
+size_t rs_scan_mt(int profile, const uint8_t *pat, size_t m, const uint8_t *text, size_t n, int32_t k,
+                  int threads, double min_seconds, uint64_t **out_pos, int32_t **out_cost,
+                  int *passes_out, double *seconds_out, int *shards_out, double *busy_out) {
+    init_tables();
+    *out_pos = NULL; *out_cost = NULL;
+    if (threads < 1) threads = 1;
+    const size_t ov = ((m + (size_t)k + 1 + 63) / 64) * 64;
+    size_t per = (n + (size_t)threads - 1) / (size_t)threads;
+    per = (per + 63) / 64 * 64;
+    if (per == 0) per = 64;
+    rs_mt_worker *ws = (rs_mt_worker *)calloc((size_t)threads, sizeof *ws);
+    int T = 0;
+    for (int t = 0; t < threads; t++) {
+        const size_t a = (size_t)t * per, b = a + per < n ? a + per : n;
+        if (a >= b) break;
+        ws[T].a = a; ws[T].b = b; ws[T].s = a > ov ? a - ov : 0;
+        T++;
+    }
+    if (T == 0) { free(ws); *passes_out = 0; *seconds_out = 0; *shards_out = 0; return 0; }
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)T);
+    volatile int stop = 0;
+    int passes = 0;
+    double elapsed = 0;
+    pthread_t *th = (pthread_t *)calloc((size_t)T, sizeof *th);
+    for (int t = 0; t < T; t++) {
+        rs_mt_worker *w = &ws[t];
+        w->profile = profile; w->pat = pat; w->m = m; w->text = text; w->n = n; w->k = k;
+        w->bar = &bar; w->stop = &stop; w->id = t; w->min_seconds = min_seconds;
+        w->elapsed = &elapsed; w->passes = &passes;
+        pthread_create(&th[t], NULL, rs_mt_main, w);
+    }
+    size_t total = 0;
+    double busy = 0;
+    for (int t = 0; t < T; t++) { pthread_join(th[t], NULL); total += ws[t].cnt; busy += ws[t].busy; }
+    pthread_barrier_destroy(&bar);
+    uint64_t *op = (uint64_t *)malloc((total ? total : 1) * sizeof *op);
+    int32_t *oc = (int32_t *)malloc((total ? total : 1) * sizeof *oc);
+    size_t w = 0;
+    for (int t = 0; t < T; t++) {
+        for (size_t i = 0; i < ws[t].cnt; i++) { op[w] = ws[t].pos[i]; oc[w] = ws[t].cost[i]; w++; }
+        free(ws[t].pos); free(ws[t].cost);
+    }
+    free(th); free(ws);
+    *out_pos = op; *out_cost = oc;
+    *passes_out = passes; *seconds_out = elapsed; *shards_out = T;
+    if (busy_out) *busy_out = busy;
+    return total;
+}
+
 int rs_lanes(void) { return RS_LANES; }
 void rs_free(void *p) { free(p); }
 

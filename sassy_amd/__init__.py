@@ -109,7 +109,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_result_len", "sassy_hip_result_matches", "sassy_hip_result_cigars",
     "sassy_hip_result_cigars_len", "sassy_hip_pack_rows", "sassy_hip_enable_counters", "sassy_hip_set_timing",
     "sassy_hip_set_only_best_match", "sassy_hip_set_max_n_frac", "sassy_hip_search_with_fn",
-    "sassy_hip_set_max_overhang",
+    "sassy_hip_set_max_overhang", "sassy_hip_set_prefilter",
     "sassy_hip_search_many", "sassy_hip_tsv_header", "sassy_hip_format_tsv",
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
@@ -156,6 +156,8 @@ def lib():
     L.sassy_hip_enable_counters.argtypes = [vp, C.c_int]
     L.sassy_hip_set_timing.restype = C.c_int
     L.sassy_hip_set_timing.argtypes = [vp, C.c_int]
+    L.sassy_hip_set_prefilter.restype = C.c_int
+    L.sassy_hip_set_prefilter.argtypes = [vp, C.c_int]
     L.sassy_hip_set_only_best_match.restype = C.c_int
     L.sassy_hip_set_only_best_match.argtypes = [vp, C.c_int]
     L.sassy_hip_set_max_overhang.restype = C.c_int
@@ -479,12 +481,16 @@ class Searcher:
         return EncodedPatterns(h, len(patterns), plen)
 
     def search_encoded_patterns(self, encoded: EncodedPatterns, text, k: int,
-                                all_minima: bool = False) -> List[Match]:
+                                all_minima: bool = False, as_result: bool = False):
+        """Searcher::search_encoded_patterns (src/search.rs:415-423).  as_result: hand back the Result
+        (numpy record array + cigar pool) instead of a list of Match objects -- for result sets with
+        10^5 and more matches, where a Python object per match costs more than the search."""
         addr, n, keep, on_dev = _ptr_len(text)
         out = C.c_void_p()
         flags = (ALL_MINIMA if all_minima else 0) | (TEXT_ON_DEVICE if on_dev else 0)
         _check(lib().sassy_hip_search_encoded(self._h, encoded._h, addr, n, k, flags, C.byref(out)))
-        return Result(out).matches
+        r = Result(out)
+        return r if as_result else r.matches
 
     # --- device-resident / multi-GPU entry points ---
     def search_shard(self, pattern: bytes, d_text_ptr: int, halo_len: int, shard_len: int,
@@ -502,6 +508,11 @@ class Searcher:
     def set_timing(self, level: int):
         """0 = no HIP events, 1 = dominant kernel only (default), 2 = every phase."""
         _check(lib().sassy_hip_set_timing(self._h, int(level)))
+
+    def set_prefilter(self, mode: int):
+        """-1 = the library's choice, 0 = streaming DP over every block, 1 = prefilter also with short pieces."""
+        _check(lib().sassy_hip_set_prefilter(self._h, int(mode)))
+        return self
 
     def enable_counters(self, on: bool = True):
         _check(lib().sassy_hip_enable_counters(self._h, int(on)))
@@ -559,6 +570,11 @@ class DeviceBuffer:
 
     def upload(self, data: bytes, offset: int = 0):
         _check(lib().sassy_hip_memcpy_h2d(self.ptr + offset, data, len(data)))
+
+    def download_into(self, array, offset: int = 0):
+        """Device bytes [offset, offset + array.nbytes) into a writable numpy array (no intermediate copy)."""
+        _check(lib().sassy_hip_memcpy_d2h(array.ctypes.data, self.ptr + offset, array.nbytes))
+        return array
 
     def download(self, nbytes: Optional[int] = None, offset: int = 0) -> bytes:
         nbytes = self.nbytes - offset if nbytes is None else nbytes

@@ -10,7 +10,8 @@ constexpr int kWave = 64;              // gfx950 wavefront
 constexpr int kWavesPerGroup = 4;      // 256-thread workgroups, every wave works alone
 constexpr int kTileBytes = 64 * 128;   // text tile of one wave: 64 lane chunks x 2 blocks x 64 B,
                                        // 16-byte slots XOR-swizzled by (owner>>1)&7
-constexpr int kMaxSlots = 16;          // profile slots (distinct pattern letters) per search
+constexpr int kMaxSlots = 64;          // profile slots (distinct pattern letters) per search: Dna 4, Iupac <= 16,
+                                       // Ascii <= 64 distinct pattern bytes
 
 // Control block (64 bytes, device): u32 [0] reports, [1] chunk descriptors | bytes 16..47: u64
 // counters | words 12..15 (tail): the chunk that ends the buffer -- own_lo, exit state, descriptor

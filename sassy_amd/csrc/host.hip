@@ -308,6 +308,7 @@ struct sassy_SearcherType {
   uint64_t rev_len = 0;
 
   bool want_counters = false;
+  int prefilter = -1;            // sassy_hip_set_prefilter: -1 process default, 0 never, 1 also with short pieces
   // reporting modes of the reference's Searcher (src/search.rs:442-475)
   float alpha = NAN;             // overhang cost per pattern character (NaN = no overhang), Iupac only
   long max_overhang = -1;        // with_max_overhang(): -1 = none
@@ -406,8 +407,13 @@ static uint32_t warmup_blocks(uint32_t m, uint32_t k) { return (m + k + 1 + 63) 
 
 // Prefilter geometry: k+1 disjoint pattern pieces of q rows.  Enabled when the pieces are long
 // enough to be selective (expected hit blocks on random DNA: 64*(k+1)/4^q of all blocks).
-static uint32_t filter_piece_len(const PatternPlan& plan, uint32_t k) {
+// mode: the searcher's own setting (sassy_hip_set_prefilter), -1 = the process default (SASSY_HIP_PREFILTER)
+static int prefilter_mode(int mode) {
   static const int env = getenv("SASSY_HIP_PREFILTER") ? atoi(getenv("SASSY_HIP_PREFILTER")) : -1;
+  return mode >= 0 ? mode : env;
+}
+static uint32_t filter_piece_len(const PatternPlan& plan, uint32_t k, int mode) {
+  const int env = prefilter_mode(mode);
   if (env == 0) return 0;
   const uint64_t pieces = (uint64_t)k + 1;
   uint64_t q = plan.m / pieces;
@@ -689,19 +695,21 @@ int ScanJob::prepare() {
   P.alpha = overhang ? S->alpha : 0.0f;
   P.ov_steps = ov_steps;
   P.rev_n = rev_n;
-  bucket = plan.nslots <= 4 ? 4 : plan.nslots <= 8 ? 8 : 16;
+  bucket = plan.nslots <= 4 ? 4 : plan.nslots <= 8 ? 8 : plan.nslots <= 16 ? 16 : plan.nslots <= 32 ? 32 : 64;
   static const int env_sb = getenv("SASSY_HIP_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_STAGE_BLOCKS")) : 0;
   P.stage_blocks = env_sb == 1 || env_sb == 2 ? (uint32_t)env_sb : 1u;
   for (int s = 0; s < kMaxSlots; ++s) P.slot_val[s] = plan.slot_val[s];
-  q = filter_piece_len(plan, k);
+  q = filter_piece_len(plan, k, S->prefilter);
   // a match that hangs over an end of the text contains only part of the pattern: the pigeonhole
   // argument of the prefilter does not cover it, so overhang searches stream the full DP
   if (overhang) q = 0;
+  // Ascii patterns with more than 16 distinct bytes: only the DP kernels carry that many slot masks
+  if (plan.nslots > 16) q = 0;
   if (ext_bitmap) q = ext_q;
   if (ext_desc) q = 1;  // list mode without a filter
   // which prefilter kernel (SASSY_HIP_FILTER_KIND=1|2|3|4 forces one where it applies)
   static const int env_kind = getenv("SASSY_HIP_FILTER_KIND") ? atoi(getenv("SASSY_HIP_FILTER_KIND")) : 0;
-  static const int env_pre = getenv("SASSY_HIP_PREFILTER") ? atoi(getenv("SASSY_HIP_PREFILTER")) : -1;
+  const int env_pre = prefilter_mode(S->prefilter);
   fkind = kFilterGeneric;
   if (ext_bitmap || ext_desc) fkind = kFilterPlanes;  // (ext_bitmap: marked like filter_dna_kernel does)
   if (ext_desc) {
@@ -1459,7 +1467,7 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   const uint64_t own0 = sh.halo_len;
   const uint64_t owned_bytes = sh.text_len > own0 ? sh.text_len - own0 : 0;
   uint64_t nl = std::min<uint64_t>(std::min<int>(env_lanes, kMaxLanes), owned_bytes / std::max<uint64_t>(min_sub, 2 * halo + 64));
-  if (nl < 2 || filter_piece_len(plan, k) == 0)
+  if (nl < 2 || filter_piece_len(plan, k, S->prefilter) == 0)
     return run_scan_single(S, sh, plan, k, all_minima, pat, do_trace, total_len, out);
 
   const uint64_t owned_blocks = (owned_bytes + 63) / 64;
@@ -1606,13 +1614,20 @@ struct ScanQueue {
     sl.job->ext_wait = ext_wait;
     sl.job->ext_desc = ext_desc;
     sl.job->ext_ndesc = ext_ndesc;
+    ScanJob& job = *sl.job;
+    // the slot counts as in flight only once its kernels are queued: a job whose prepare() / enqueue()
+    // failed must never reach finish() (it would read the lane's previous counts and re-run on
+    // half-initialised parameters)
+    int rc = job.prepare();
+    if (rc == 0 && !job.empty) rc = job.enqueue(0);
+    if (rc != 0) {
+      (void)hipStreamSynchronize(S->lanes[tail].stream);  // whatever part of it was queued
+      sl.job.reset();
+      return rc;
+    }
     sl.busy = true;
     tail = (tail + 1) % n_lanes;
     ++in_flight;
-    ScanJob& job = *sl.job;
-    if (int rc = job.prepare()) return rc;
-    if (!job.empty)
-      if (int rc = job.enqueue(0)) return rc;
     return 0;
   }
   ~ScanQueue() {  // never leave work in flight behind an error return
@@ -1856,6 +1871,10 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
   std::string err;
   if (!make_plan(S->profile, pattern, plen, plan, err)) return fail(SASSY_HIP_EINVAL, err);
   if (k > 0x7FFFFFFFu) return fail(SASSY_HIP_EINVAL, "k too large");
+  if (rc_strand && S->profile == PROFILE_ASCII)
+    // the reference constructs such a searcher and panics at its first search: Profile::complement is
+    // unimplemented for Ascii (the trait default, src/profiles.rs:57-60), reached from src/search.rs:813-820
+    return fail(SASSY_HIP_EUNSUPPORTED, "reverse complement is not defined for the ascii alphabet");
   if (int rc = S->ensure_device()) return rc;
   const bool on_dev = (flags & SASSY_HIP_TEXT_ON_DEVICE) != 0;
   const bool all = (flags & SASSY_HIP_ALL_MINIMA) != 0;
@@ -2022,11 +2041,6 @@ sassy_SearcherType* sassy_hip_searcher_new(const char* alphabet, bool rc, float 
       return nullptr;
     }
   }
-  if (rc && pr == PROFILE_ASCII) {
-    // the reference panics at the first rc search (Profile::complement is unimplemented for Ascii)
-    fail(SASSY_HIP_EUNSUPPORTED, "reverse complement is not defined for the ascii alphabet");
-    return nullptr;
-  }
   sassy_SearcherType* s = new sassy_SearcherType();
   s->profile = pr;
   s->rc = rc;
@@ -2080,6 +2094,12 @@ int sassy_hip_get_stats(const sassy_SearcherType* s, sassy_hip_Stats* out) {
 int sassy_hip_enable_counters(sassy_SearcherType* s, int on) {
   if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
   s->want_counters = on != 0;
+  return 0;
+}
+
+int sassy_hip_set_prefilter(sassy_SearcherType* s, int mode) {
+  if (!s || mode < -1 || mode > 1) return fail(SASSY_HIP_EINVAL, "prefilter mode must be -1, 0 or 1");
+  s->prefilter = mode;
   return 0;
 }
 
@@ -2423,6 +2443,8 @@ int sassy_hip_search_many(sassy_SearcherType* s, const uint8_t* const* patterns,
                           size_t k, uint32_t flags, sassy_hip_Result** out) {
   if (!s || !out || (n_patterns && (!patterns || !pattern_lens)) || (n_texts && (!texts || !text_lens)))
     return fail(SASSY_HIP_EINVAL, "null argument");
+  if (s->rc && s->profile == PROFILE_ASCII && n_patterns && n_texts)  // as in search_text: the reference panics here
+    return fail(SASSY_HIP_EUNSUPPORTED, "reverse complement is not defined for the ascii alphabet");
   const double t0 = now_ms();
   reset_stats(s);
   if (int rc = s->ensure_device()) return rc;
@@ -2640,6 +2662,10 @@ sassy_hip_Encoded* sassy_hip_encode_patterns(sassy_SearcherType* s, const uint8_
     fail(SASSY_HIP_EINVAL, "Invalid pattern length (must be 1..=64)");
     return nullptr;
   }
+  if (s->rc && s->profile == PROFILE_ASCII) {
+    fail(SASSY_HIP_EUNSUPPORTED, "reverse complement is not defined for the ascii alphabet");
+    return nullptr;
+  }
   sassy_hip_Encoded* e = new sassy_hip_Encoded();
   e->profile = s->profile;
   e->rc = s->rc;
@@ -2674,6 +2700,8 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
     HIP_TRY(hipMemcpyAsync(s->d_text.p, text, text_len, hipMemcpyHostToDevice, s->stream));
   }
   const uint8_t* tptr = (flags & SASSY_HIP_TEXT_ON_DEVICE) ? d_text : s->d_text.p;
+  if ((flags & SASSY_HIP_TEXT_ON_DEVICE) && text_len && ((uintptr_t)tptr & 15) != 0)
+    return fail(SASSY_HIP_EINVAL, "device text pointer must be 16-byte aligned");  // the kernels load 16-byte chunks
   f |= SASSY_HIP_TEXT_ON_DEVICE;  // search_text must not upload the text again per pattern
   // Many plain-ACGT patterns on an Iupac searcher (the CRISPR-guide case): if the text is plain
   // ACGT as well, the Dna kernels give identical results and are cheaper -- test the text once.

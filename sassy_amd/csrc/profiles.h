@@ -112,12 +112,15 @@ inline bool make_plan(Profile pr, const uint8_t* pat, size_t m, PatternPlan& pla
     size_t s = 0;
     while (s < letters.size() && letters[s] != c) ++s;
     if (s == letters.size()) letters.push_back(c);
-    if (s < 16) set_row(j, (uint32_t)s);
+    if (s < (size_t)kMaxSlots) set_row(j, (uint32_t)s);
   }
-  if (letters.size() > 16) {
-    // Iupac: the reference's profile holds 16 masks and asserts (iupac.rs:69); Ascii: 256 in the
-    // reference, 16 distinct pattern bytes here (documented limit).
-    err = "pattern uses more than 16 distinct letters";
+  // Iupac: the reference's profile holds 16 masks and asserts (iupac.rs:69).  Ascii: 256 slots in the
+  // reference (ascii.rs:13-29); here every distinct pattern byte takes one LDS mask slot per lane, up to
+  // 64 of them (documented limit, DESIGN.md: a pattern with more distinct bytes is binary data, not text).
+  const size_t limit = pr == PROFILE_IUPAC ? 16 : (size_t)kMaxSlots;
+  if (letters.size() > limit) {
+    err = pr == PROFILE_IUPAC ? "pattern uses more than 16 distinct letters"
+                              : "pattern uses more than 64 distinct bytes";
     return false;
   }
   plan.nslots = (uint32_t)letters.size();

@@ -1797,6 +1797,11 @@ hipError_t launch_scan_ascii(const ScanParams& P, uint32_t grid, size_t smem, hi
   if (P.nslots <= 4) return launch_one<PR, 4>(P, grid, smem, stream);
   if (P.nslots <= 8) return launch_one<PR, 8>(P, grid, smem, stream);
   if (P.nslots <= 16) return launch_one<PR, 16>(P, grid, smem, stream);
+#if SASSY_SCAN_PROFILE == 0
+  // Ascii patterns with many distinct bytes (the reference's Ascii profile has 256 slots)
+  if (P.nslots <= 32) return launch_one<PR, 32>(P, grid, smem, stream);
+  if (P.nslots <= 64) return launch_one<PR, 64>(P, grid, smem, stream);
+#endif
   return hipErrorInvalidValue;
 }
 #if SASSY_SCAN_PROFILE == 2
@@ -1821,6 +1826,10 @@ hipError_t launch_list_ascii(const ScanParams& P, uint32_t grid, size_t smem, hi
   if (P.nslots <= 4) return launch_list_one<PR3, 4>(P, grid, smem, stream);
   if (P.nslots <= 8) return launch_list_one<PR3, 8>(P, grid, smem, stream);
   if (P.nslots <= 16) return launch_list_one<PR3, 16>(P, grid, smem, stream);
+#if SASSY_SCAN_PROFILE == 0
+  if (P.nslots <= 32) return launch_list_one<PR3, 32>(P, grid, smem, stream);
+  if (P.nslots <= 64) return launch_list_one<PR3, 64>(P, grid, smem, stream);
+#endif
   return hipErrorInvalidValue;
 }
 #endif

@@ -5,15 +5,18 @@ The reference has no distributed code (it is a single-process CPU library; its t
 parallelism over independent records is the model: bin/grep.rs:476-503).  What shards here is
 what SURVEY 8(e) names: the text is cut into G contiguous shards; shard g owns the end positions
 whose 64-byte block lies inside it and scans from `halo` bytes to its left; no data-path
-collective is needed, only a gather of match records to rank 0 (torch.distributed backend
-"nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  Payload is kilobytes: this
-is latency-bound, never link-bound.
+collective is needed, only an exchange of match records (torch.distributed backend "nccl" = RCCL
+over xGMI on the GPU box, "gloo" in the CPU tests).  Payload is kilobytes: this is latency-bound,
+never link-bound.
 
 Cross-shard exactness: a <=k plateau that runs across a shard border is resolved exactly like
 across lane chunks inside one GPU -- every shard reports its exit state (decreasing TRUE / FALSE /
 PASS) and marks the one report that depends on its left neighbour; rank 0 walks the chain.
 
-Records travel as numpy / torch arrays (one row per match), never as Python objects.
+Records travel as numpy / torch arrays (one row per match), never as Python objects.  A row is
+7 + cigar_bytes / 8 int64 words; the width of the cigar field follows from the search
+(cigar_bytes_for(m, k): a cigar of a match of an m-row pattern with at most k edits never has more
+than 2 (m + k + 1) + 2 characters -- the device's own string slot), it is not a constant.
 """
 from __future__ import annotations
 
@@ -23,8 +26,20 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 STATE_FALSE, STATE_TRUE, STATE_PASS = 0, 1, 2
-CIGAR_BYTES = 40
-COLS = 7 + CIGAR_BYTES // 8  # int64 columns per packed match
+FIXED_COLS = 7   # pattern_idx, text_start, text_end, pattern_start, pattern_end, cost, strand
+HEAD_WORDS = 4   # rows, exit state, conditional index, error flag
+
+
+def cigar_bytes_for(pattern_len: int, k: int) -> int:
+    """Width of the cigar field that holds every cigar a search with this (m, k) can produce: the
+    device's string slot 2 (m + k + 1) + 2 (host.hip: T.str_stride), in whole 8-byte words."""
+    return (2 * (pattern_len + k + 1) + 2 + 7) // 8 * 8
+
+
+def cols_for(cigar_bytes: int) -> int:
+    if cigar_bytes % 8:
+        raise ValueError("cigar_bytes must be a multiple of 8")
+    return FIXED_COLS + cigar_bytes // 8
 
 
 def shard_bounds(total_len: int, world: int) -> List[Tuple[int, int]]:
@@ -41,8 +56,8 @@ def shard_bounds(total_len: int, world: int) -> List[Tuple[int, int]]:
 
 @dataclass
 class ShardResult:
-    """rows: int64 array [n, COLS] = pattern_idx, text_start, text_end, pattern_start,
-    pattern_end, cost, strand, then CIGAR_BYTES bytes of NUL-padded cigar text."""
+    """rows: int64 array [n, 7 + cigar_bytes / 8] = pattern_idx, text_start, text_end,
+    pattern_start, pattern_end, cost, strand, then cigar_bytes bytes of NUL-padded cigar text."""
     rows: np.ndarray
     exit_state: int          # STATE_*
     conditional_index: int   # row of the report that depends on the left shard, or -1
@@ -50,24 +65,42 @@ class ShardResult:
     def __len__(self):
         return int(self.rows.shape[0])
 
+    @property
+    def cigar_bytes(self) -> int:
+        return 8 * (int(self.rows.shape[1]) - FIXED_COLS)
 
-def pack_result(result, out: Optional[np.ndarray] = None) -> ShardResult:
+
+def _needed_cigar_bytes(result) -> int:
+    a = result.array
+    longest = int(a["cigar_len"].max(initial=0)) if len(a) else 0
+    return max(8, (longest + 7) // 8 * 8)
+
+
+def pack_result(result, out: Optional[np.ndarray] = None, cigar_bytes: Optional[int] = None) -> ShardResult:
     """sassy_amd.Result -> ShardResult: the C-ABI's row packer (sassy_hip_pack_rows), straight into
-    `out` (e.g. a pinned staging buffer) when given."""
+    `out` (e.g. a pinned staging buffer, shape [cap, 7 + cigar_bytes / 8]) when given.  Without an
+    explicit width the field is as wide as the longest cigar of this result."""
     a = result.array
     n = len(a)
-    rows = out[:n] if out is not None and out.shape[0] >= n else np.empty((n, COLS), dtype=np.int64)
+    if out is not None:
+        cigar_bytes = 8 * (int(out.shape[1]) - FIXED_COLS)
+    elif cigar_bytes is None:
+        cigar_bytes = _needed_cigar_bytes(result)
+    cols = cols_for(cigar_bytes)
+    rows = out[:n] if out is not None and out.shape[0] >= n else np.empty((n, cols), dtype=np.int64)
     if n:
         from . import lib, _check
-        _check(lib().sassy_hip_pack_rows(a.ctypes.data, n, result.pool, len(result.pool), rows.ctypes.data, CIGAR_BYTES))
+        _check(lib().sassy_hip_pack_rows(a.ctypes.data, n, result.pool, len(result.pool), rows.ctypes.data, cigar_bytes))
     return ShardResult(rows, result.exit_state, result.conditional_index)
 
 
-def pack_result_numpy(result) -> ShardResult:
+def pack_result_numpy(result, cigar_bytes: Optional[int] = None) -> ShardResult:
     """The same in numpy (kept as the cross-check of the C packer in the tests)."""
     a = result.array
     n = len(a)
-    rows = np.zeros((n, COLS), dtype=np.int64)
+    if cigar_bytes is None:
+        cigar_bytes = _needed_cigar_bytes(result)
+    rows = np.zeros((n, cols_for(cigar_bytes)), dtype=np.int64)
     if n:
         # text_start, text_end, pattern_start, pattern_end are bytes 16..47 of the 64-byte record
         raw = a.view(np.uint8).reshape(n, 64)
@@ -76,44 +109,39 @@ def pack_result_numpy(result) -> ShardResult:
         rows[:, 5] = a["cost"]
         rows[:, 6] = a["strand"]
         clen = a["cigar_len"].astype(np.int64)
-        if int(clen.max(initial=0)) > CIGAR_BYTES:
-            raise ValueError("cigar longer than the fixed gather field")
+        if int(clen.max(initial=0)) > cigar_bytes:
+            raise ValueError("cigar longer than the gather field")
         pool = np.frombuffer(result.pool, dtype=np.uint8) if result.pool else np.zeros(1, np.uint8)
         off = a["cigar_off"].astype(np.int64)
-        stride = int(off[1] - off[0]) if n > 1 else 0
-        if n > 1 and stride >= CIGAR_BYTES and len(pool) >= int(off[-1]) + CIGAR_BYTES and \
-                bool((off == off[0] + stride * np.arange(n, dtype=np.int64)).all()):
-            # the device wrote the cigar strings into equally spaced, NUL-padded slots: one strided view
-            cig = np.lib.stride_tricks.as_strided(pool[int(off[0]):], shape=(n, CIGAR_BYTES), strides=(stride, 1))
-            keep = np.arange(CIGAR_BYTES, dtype=np.int64)[None, :] < clen[:, None]
-            cig = np.where(keep, cig, 0).astype(np.uint8)
-        else:
-            idx = off[:, None] + np.arange(CIGAR_BYTES, dtype=np.int64)[None, :]
-            keep = np.arange(CIGAR_BYTES, dtype=np.int64)[None, :] < clen[:, None]
-            cig = np.where(keep, pool[np.minimum(idx, len(pool) - 1)], 0).astype(np.uint8)
-        rows[:, 7:] = np.ascontiguousarray(cig).view(np.int64)
+        idx = off[:, None] + np.arange(cigar_bytes, dtype=np.int64)[None, :]
+        keep = np.arange(cigar_bytes, dtype=np.int64)[None, :] < clen[:, None]
+        cig = np.where(keep, pool[np.minimum(idx, len(pool) - 1)], 0).astype(np.uint8)
+        rows[:, FIXED_COLS:] = np.ascontiguousarray(cig).view(np.int64)
     return ShardResult(rows, result.exit_state, result.conditional_index)
 
 
-def rows_from_matches(matches) -> np.ndarray:
+def rows_from_matches(matches, cigar_bytes: Optional[int] = None) -> np.ndarray:
     """Match objects -> packed rows (tests / small inputs)."""
-    rows = np.zeros((len(matches), COLS), dtype=np.int64)
+    if cigar_bytes is None:
+        longest = max((len(m.cigar) for m in matches), default=0)
+        cigar_bytes = max(8, (longest + 7) // 8 * 8)
+    rows = np.zeros((len(matches), cols_for(cigar_bytes)), dtype=np.int64)
     for i, m in enumerate(matches):
         cig = m.cigar.encode()
-        if len(cig) > CIGAR_BYTES:
-            raise ValueError("cigar longer than the fixed gather field")
+        if len(cig) > cigar_bytes:
+            raise ValueError("cigar longer than the gather field")
         r = rows[i]
         r[0], r[1], r[2], r[3], r[4] = m.pattern_idx, _s64(m.text_start), _s64(m.text_end), \
             _s64(m.pattern_start), _s64(m.pattern_end)
         r[5], r[6] = m.cost, 1 if m.strand == "-" else 0
-        r[7:].view(np.uint8)[: len(cig)] = np.frombuffer(cig, dtype=np.uint8)
+        r[FIXED_COLS:].view(np.uint8)[: len(cig)] = np.frombuffer(cig, dtype=np.uint8)
     return rows
 
 
 def matches_from_rows(rows: np.ndarray, Match) -> list:
     out = []
     for row in rows:
-        cig = bytes(row[7:].view(np.uint8)).rstrip(b"\0").decode()
+        cig = bytes(row[FIXED_COLS:].view(np.uint8)).rstrip(b"\0").decode()
         out.append(Match(int(row[0]), _u64(row[1]), _u64(row[2]), _u64(row[3]), _u64(row[4]),
                          int(row[5]), "-" if row[6] else "+", cig))
     return out
@@ -128,43 +156,58 @@ def _u64(v) -> int:
     return v + (1 << 64) if v < 0 else v
 
 
+def widen_rows(rows: np.ndarray, cols: int) -> np.ndarray:
+    """Rows with a narrower cigar field padded (with NULs) to `cols` columns."""
+    if rows.shape[1] == cols:
+        return rows
+    if rows.shape[1] > cols:
+        raise ValueError("cannot narrow packed rows")
+    out = np.zeros((rows.shape[0], cols), dtype=np.int64)
+    out[:, : rows.shape[1]] = rows
+    return out
+
+
 def merge_shard_results(shards: Sequence[ShardResult]) -> np.ndarray:
     """Concatenate shard rows in text order, dropping conditional reports whose plateau was
     entered by an increase (decreasing = FALSE arriving from the left)."""
     parts = []
     incoming = STATE_TRUE  # column 0 of the text: decreasing = true (src/search.rs:1055)
+    cols = max((int(sh.rows.shape[1]) for sh in shards), default=cols_for(8))
     for sh in shards:
-        rows = sh.rows
+        rows = widen_rows(sh.rows, cols)
         if sh.conditional_index >= 0 and incoming != STATE_TRUE:
             rows = np.delete(rows, sh.conditional_index, axis=0)
         parts.append(rows)
         if sh.exit_state != STATE_PASS:
             incoming = sh.exit_state
-    return np.concatenate(parts, axis=0) if parts else np.zeros((0, COLS), dtype=np.int64)
+    return np.concatenate(parts, axis=0) if parts else np.zeros((0, cols), dtype=np.int64)
 
 
 def gather_shard_results(local, torch, dist, device) -> Optional[List[ShardResult]]:
-    """The one exchange of the path: all ranks' match lists to rank 0.
-    Two collectives: all_gather of the 3-word headers (count, exit state, conditional index),
-    then gather of the records padded to the largest count.  `local` is a ShardResult or a
-    sassy_amd.Result; a Result is packed while the header exchange is in flight."""
+    """The one exchange of the path for lists of unknown size: all ranks' match lists to rank 0.
+    Two collectives: all_gather of the 4-word headers (count, exit state, conditional index, cigar
+    field width), then gather of the records padded to the largest count and the widest field.
+    `local` is a ShardResult or a sassy_amd.Result; a Result is packed while the header exchange is
+    in flight."""
     world, rank = dist.get_world_size(), dist.get_rank()
     n_local = len(local)
-    head = torch.tensor([n_local, local.exit_state, local.conditional_index], dtype=torch.int64, device=device)
+    cb_local = local.cigar_bytes if isinstance(local, ShardResult) else _needed_cigar_bytes(local)
+    head = torch.tensor([n_local, local.exit_state, local.conditional_index, cb_local], dtype=torch.int64, device=device)
     heads = [torch.empty_like(head) for _ in range(world)]
     work = dist.all_gather(heads, head, async_op=True)
     if not isinstance(local, ShardResult):
-        local = pack_result(local)
+        local = pack_result(local, cigar_bytes=cb_local)
     work.wait()
     heads = torch.stack(heads).cpu().tolist()
     counts = [h[0] for h in heads]
     maxc = max(counts)
+    cols = cols_for(max(h[3] for h in heads))
     if maxc == 0:
         if rank != 0:
             return None
-        return [ShardResult(np.zeros((0, COLS), np.int64), h[1], h[2]) for h in heads]
-    padded = np.zeros((maxc, COLS), dtype=np.int64)
-    padded[: len(local)] = local.rows
+        return [ShardResult(np.zeros((0, cols), np.int64), h[1], h[2]) for h in heads]
+    padded = np.zeros((maxc, cols), dtype=np.int64)
+    padded[: len(local), : local.rows.shape[1]] = local.rows
     mine = torch.from_numpy(padded).to(device)
     bufs = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
     dist.gather(mine, gather_list=bufs, dst=0)
@@ -173,54 +216,98 @@ def gather_shard_results(local, torch, dist, device) -> Optional[List[ShardResul
     return [ShardResult(bufs[r][: counts[r]].cpu().numpy(), heads[r][1], heads[r][2]) for r in range(world)]
 
 
+class GatherError(RuntimeError):
+    """Raised on EVERY rank when some rank flagged an error in its header: the ranks fail together
+    instead of one leaving the others inside a collective."""
+
+
 class MatchGather:
     """The same exchange set up once for a stream of searches (bench.py): every rank's header and rows
-    travel in ONE collective of fixed size -- `capacity_rows` rows per rank, chosen by the caller from
-    what the workload can report -- through pinned staging buffers on both sides; no per-call
-    allocation, no second round for the sizes.  A rank that has more rows than the capacity makes
-    rank 0 raise (use gather_shard_results for unbounded lists)."""
+    travel in ONE collective of fixed size (all_gather: every rank sees every header) through pinned
+    staging buffers; no per-call allocation, no second round for the sizes.  The capacity is not
+    derived from the workload: when some rank has more rows than fit, every rank sees that in the
+    headers, all of them grow to the next power of two that holds the largest list, and the exchange
+    of that search is repeated -- after the first few searches of a stream it never happens again.
+    Only rank 0 copies the rows to the host; the others read the headers.
 
-    def __init__(self, torch, dist, device, capacity_rows: int):
+    cigar_bytes: width of the cigar field, cigar_bytes_for(m, k) of the searches to come."""
+
+    def __init__(self, torch, dist, device, capacity_rows: int = 1024, cigar_bytes: int = 40):
         self.torch, self.dist, self.device = torch, dist, device
         self.world, self.rank = dist.get_world_size(), dist.get_rank()
-        self.cap = int(capacity_rows)
-        self.words = 3 + self.cap * COLS
-        pin = device.type == "cuda"
-        self.stage = torch.empty(self.words, dtype=torch.int64, pin_memory=pin)
+        self.cols = cols_for(cigar_bytes)
+        self.cigar_bytes = cigar_bytes
+        self.pin = device.type == "cuda"
+        self.copied = torch.cuda.Event() if self.pin else None
+        self.regrown = 0
+        self._alloc(max(1, int(capacity_rows)))
+
+    def _alloc(self, cap: int):
+        torch = self.torch
+        self.cap = cap
+        self.words = HEAD_WORDS + cap * self.cols
+        self.stage = torch.empty(self.words, dtype=torch.int64, pin_memory=self.pin)
         self.stage_np = self.stage.numpy()
-        self.rows_np = self.stage_np[3:].reshape(self.cap, COLS)
-        self.dev = torch.empty(self.words, dtype=torch.int64, device=device)
-        self.copied = torch.cuda.Event() if pin else None
+        self.rows_np = self.stage_np[HEAD_WORDS:].reshape(cap, self.cols)
+        self.dev = torch.empty(self.words, dtype=torch.int64, device=self.device)
+        self.all_dev = torch.empty((self.world, self.words), dtype=torch.int64, device=self.device)
+        self.heads_host = torch.empty((self.world, HEAD_WORDS), dtype=torch.int64, pin_memory=self.pin)
+        self.heads_np = self.heads_host.numpy()
         if self.rank == 0:
-            self.all_dev = torch.empty((self.world, self.words), dtype=torch.int64, device=device)
-            self.all_host = torch.empty((self.world, self.words), dtype=torch.int64, pin_memory=pin)
+            self.all_host = torch.empty((self.world, self.words), dtype=torch.int64, pin_memory=self.pin)
             self.all_np = self.all_host.numpy()
 
-    def gather(self, local) -> Optional[List[ShardResult]]:
-        """local: a ShardResult or a sassy_amd.Result (packed straight into the staging buffer)."""
-        if self.copied is not None:
-            self.copied.synchronize()  # the previous call's upload has left the staging buffer
-        n = len(local)
-        if n <= self.cap:
-            if isinstance(local, ShardResult):
-                self.rows_np[:n] = local.rows
-            else:
-                pack_result(local, out=self.rows_np)
-        self.stage_np[0], self.stage_np[1], self.stage_np[2] = n, local.exit_state, local.conditional_index
-        self.dev.copy_(self.stage, non_blocking=True)
-        if self.copied is not None:
-            self.copied.record()
+    def _exchange(self):
+        d = self.dist
+        if hasattr(d, "all_gather_into_tensor"):
+            try:
+                d.all_gather_into_tensor(self.all_dev.view(-1), self.dev)
+                return
+            except (RuntimeError, NotImplementedError):  # a backend without the flat form
+                pass
+        d.all_gather(list(self.all_dev.unbind(0)), self.dev)
+
+    def gather(self, local, error: bool = False) -> Optional[List[ShardResult]]:
+        """local: a ShardResult or a sassy_amd.Result (packed straight into the staging buffer), or
+        None with error=True (this rank failed before the exchange: all ranks raise GatherError)."""
+        while True:
+            if self.copied is not None:
+                self.copied.synchronize()  # the previous call's upload has left the staging buffer
+            n, state, cond = 0, STATE_PASS, -1
+            if local is not None and not error:
+                try:
+                    n, state, cond = len(local), local.exit_state, local.conditional_index
+                    if n <= self.cap:
+                        if isinstance(local, ShardResult):
+                            self.rows_np[:n] = widen_rows(local.rows, self.cols)
+                        else:
+                            pack_result(local, out=self.rows_np)
+                except Exception:  # keep the collective going: the header tells everybody
+                    error = True
+            self.stage_np[0], self.stage_np[1], self.stage_np[2], self.stage_np[3] = n, state, cond, 1 if error else 0
+            self.dev.copy_(self.stage, non_blocking=True)
+            if self.copied is not None:
+                self.copied.record()
+            self._exchange()
+            self.heads_host.copy_(self.all_dev[:, :HEAD_WORDS])  # synchronous device -> host copy
+            if int(self.heads_np[:, 3].max()) != 0:
+                bad = [r for r in range(self.world) if self.heads_np[r, 3]]
+                raise GatherError(f"rank(s) {bad} reported an error before the match exchange")
+            need = int(self.heads_np[:, 0].max())
+            if need <= self.cap:
+                break
+            cap = self.cap
+            while cap < need:
+                cap *= 2
+            self._alloc(cap)  # every rank sees the same headers: all grow alike and repeat
+            self.regrown += 1
         if self.rank != 0:
-            self.dist.gather(self.dev, dst=0)
             return None
-        self.dist.gather(self.dev, gather_list=list(self.all_dev.unbind(0)), dst=0)
-        self.all_host.copy_(self.all_dev)  # one device -> host copy (synchronous)
+        self.all_host.copy_(self.all_dev)
         out = []
         for r in range(self.world):
             cnt = int(self.all_np[r, 0])
-            if cnt > self.cap:
-                raise OverflowError(f"rank {r} reports {cnt} matches, gather capacity is {self.cap}")
-            rows = self.all_np[r, 3:3 + cnt * COLS].reshape(cnt, COLS)
+            rows = self.all_np[r, HEAD_WORDS:HEAD_WORDS + cnt * self.cols].reshape(cnt, self.cols)
             out.append(ShardResult(rows, int(self.all_np[r, 1]), int(self.all_np[r, 2])))
         return out
 
@@ -228,7 +315,9 @@ class MatchGather:
 class GatherWorker:
     """Runs MatchGather.gather + merge_shard_results on a worker thread, in submission order (every
     rank issues its collectives in the same order), so that the exchange of search i overlaps
-    search i+1.  flush() returns when everything submitted has been gathered."""
+    search i+1.  flush() returns when everything submitted has been gathered.  After a GatherError
+    -- which every rank gets for the same submission -- the rest of the queue is dropped on all ranks
+    alike, so no rank is left inside a collective."""
 
     def __init__(self, gatherer: MatchGather):
         import queue
@@ -249,7 +338,8 @@ class GatherWorker:
                 if item is None:
                     return
                 if self.error is None:
-                    shards = self.g.gather(item)
+                    local, failed = item
+                    shards = self.g.gather(local, error=failed)
                     if shards is not None:
                         self.last = merge_shard_results(shards).copy()
             except BaseException as e:  # surfaced by flush()
@@ -258,7 +348,11 @@ class GatherWorker:
                 self.q.task_done()
 
     def submit(self, local):
-        self.q.put(local)
+        self.q.put((local, False))
+
+    def submit_error(self):
+        """This rank's search failed: take part in the exchange with the error flag set."""
+        self.q.put((None, True))
 
     def flush(self):
         self.q.join()

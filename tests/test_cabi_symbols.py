@@ -58,8 +58,10 @@ def test_searcher_constructor_errors(sassy):
     with pytest.raises(sassy.SassyHipError, match="Alpha"):
         sassy.Searcher("iupac", rc=False, alpha=1.5)
     sassy.Searcher("iupac", rc=False, alpha=0.5)
-    with pytest.raises(sassy.SassyHipError):
-        sassy.Searcher("ascii", rc=True)
+    # Ascii has no complement: like the reference, the searcher constructs and its first search fails
+    # (src/c.rs:64 builds Searcher::<Ascii>::new(rc, ..); the panic comes from Profile::complement)
+    with pytest.raises(sassy.SassyHipError, match="reverse complement is not defined"):
+        sassy.Searcher("ascii", rc=True).search(b"abc", b"xxabcxx", 0)
     for a in ("dna", "DNA", "Iupac", "ascii"):
         sassy.Searcher(a, rc=False)
 
@@ -122,3 +124,24 @@ def test_cli_fastx_reader(tmp_path):
     assert list(read_fastx(str(tmp_path / "a.fa"))) == [("chr1 desc", b"ACGTACGT"), ("chr2", b"TTTT")]
     assert list(read_fastx(str(tmp_path / "b.fq"))) == [("r1 x", b"ACGTN"), ("r2", b"GG")]
     assert list(read_fastx(str(tmp_path / "c.fa.gz"))) == [("z", b"ACGT")]
+
+
+def test_c_client_compiles_and_links_against_the_headers(tmp_path):
+    """include/sassy.h is a C header and libsassy_hip.so a C library: a C11 translation unit that uses
+    the reference's four symbols compiles without warnings and links with -lsassy_hip (it is RUN,
+    against the oracle, by the GPU suite: test_compiled_c_client_links_and_runs)."""
+    exe = str(tmp_path / "dropin_client")
+    p = subprocess.run(["gcc", "-O2", "-Wall", "-Wextra", "-Werror", "-std=c11", os.path.join(ROOT, "tests", "c", "dropin_client.c"),
+                        "-I" + os.path.join(ROOT, "include"), "-L" + os.path.join(ROOT, "sassy_amd", "lib"), "-lsassy_hip",
+                        "-lpthread", "-lm", "-o", exe], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    # the additive header is plain C as well
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "sassy_hip.h"\nint main(void) { return sassy_hip_required_halo(32, 3) ? 0 : 1; }\n')
+    p = subprocess.run(["gcc", "-Wall", "-Wextra", "-Werror", "-std=c11", str(src), "-I" + os.path.join(ROOT, "include"),
+                        "-L" + os.path.join(ROOT, "sassy_amd", "lib"), "-lsassy_hip", "-o", str(tmp_path / "hdr")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "sassy_amd", "lib")
+    assert subprocess.run([str(tmp_path / "hdr")], env=env).returncode == 0

@@ -3,7 +3,10 @@ and the reference's known-answer tests.  Bit-exact: integer / byte / index work 
 
 Run on the MI355X box with `pytest -m gpu`."""
 import ctypes as C
+import json
+import os
 import random
+import sys
 
 import numpy as np
 import pytest
@@ -860,6 +863,49 @@ def test_ascii_profile(sassy):
         assert_same(s.search(pat, text, k), oracle.search("ascii", pat, text, k), (pat, k))
 
 
+def test_ascii_many_distinct_bytes(sassy):
+    """The reference's Ascii profile has 256 slots (src/profiles/ascii.rs:13-29): ordinary text patterns
+    with more than 16 distinct bytes must search, not abort -- here 17 .. 64 distinct pattern bytes
+    (32- and 64-slot kernels), one text and many texts (per-text lanes), against the oracle; more than
+    64 distinct bytes is the documented limit and fails with a message."""
+    rng = random.Random(31)
+    sent = b"The quick brown fox jumps over the lazy dog, 1234567890 times; WHY? (because: it_can!)"
+    assert len(set(sent)) > 32
+    text = bytearray(rng.choice(b"abcdefghij klmnop") for _ in range(30_000))
+    for at, e in ((0, 0), (1000, 2), (7777, 5), (15000, 8), (30_000 - len(sent), 1)):
+        ins = mutate(rng, sent, e)[:len(sent)]
+        text[at:at + len(ins)] = ins
+    text = bytes(text)
+    s = sassy.Searcher("ascii", rc=False)
+    for pat, k in [(sent[:24], 2), (sent[:40], 4), (sent, 8), (sent[10:70], 0), (bytes(range(60, 124)), 3)]:
+        assert 16 < len(set(pat)) <= 64, len(set(pat))
+        want = oracle.search("ascii", pat, text, k)
+        assert_same(s.search(pat, text, k), want, (pat, k))
+        assert_same(s.search_all(pat, text, 2), oracle.search("ascii", pat, text, 2, all_minima=True), (pat, "all"))
+    assert len(oracle.search("ascii", sent, text, 8)) >= 4
+    # the drop-in symbol too (it aborted for such patterns)
+    L = sassy.lib()
+    h = L.sassy_searcher(b"ascii", False, float("nan"))
+    out = C.POINTER(sassy.CMatch)()
+    n = L.search(h, sent, len(sent), text, len(text), 8, C.byref(out))
+    want = oracle.search("ascii", sent, text, 8)
+    assert [(out[i].text_start, out[i].text_end, out[i].cost) for i in range(n)] == \
+           [(m.text_start, m.text_end, m.cost) for m in want]
+    L.sassy_matches_free(out, n)
+    L.sassy_searcher_free(h)
+    # many short texts: one lane per text
+    texts = [text[i:i + 700] for i in range(0, 30_000, 650)]
+    got = s.search_many([sent[:40], sent], texts, 4)
+    want = []
+    for pi, pat in enumerate([sent[:40], sent]):
+        for ti, t in enumerate(texts):
+            want += [(pi, ti, m.text_start, m.text_end, m.cost, m.cigar) for m in oracle.search("ascii", pat, t, 4)]
+    assert [(m.pattern_idx, m.text_idx, m.text_start, m.text_end, m.cost, m.cigar) for m in got] == want
+    assert len(want) >= 3
+    with pytest.raises(sassy.SassyHipError, match="more than 64 distinct bytes"):
+        s.search(bytes(range(40, 140)), text, 3)
+
+
 # ------------------------------------------------------------------ device-resident text
 def test_device_generator_matches_cpu_twin(sassy):
     n = 1 << 20
@@ -1000,31 +1046,145 @@ def test_full_size_3gb_properties(sassy):
     buf.free()
 
 
-def test_full_size_configs_3_and_4_properties(sassy):
-    """BASELINE configs 3 and 4 at full text size (3 GB).  Config 3 (Iupac, |P|=200 with N/R/Y/W, k=20):
-    every plant found at its place, sorted, and a 1 MiB slice equal to the oracle.  Config 4 shape
-    (search_encoded_patterns, 20-mers, k=2, 16 patterns through the multi-pattern prefilter): per
-    pattern the same matches as a plain single-pattern search of the same text."""
+def _cfg4_patterns(npat):
+    """BASELINE config 4's pattern set: seeded random ACGT 20-mers, seed 45."""
+    flat = oracle.generate_dna(45, 0, 20 * npat).tobytes()
+    return [flat[20 * i:20 * i + 20] for i in range(npat)]
+
+
+def _rows_of(arr, pool, sel):
+    """(pattern_idx, text_start, text_end, cost, strand, cigar) of the selected records."""
+    out = []
+    for r in arr[sel]:
+        out.append((int(r["pattern_idx"]), int(r["text_start"]), int(r["text_end"]), int(r["cost"]), int(r["strand"]),
+                    pool[int(r["cigar_off"]):int(r["cigar_off"]) + int(r["cigar_len"])].decode()))
+    return out
+
+
+def test_config4_full_size_10000_patterns_against_the_oracle(sassy):
+    """BASELINE config 4 at its own size: search_encoded_patterns with 10 000 pre-encoded 20-mers, k = 2,
+    Iupac searcher, on the 3 GB text -- checked against the oracle, not against another HIP path:
+      (a) 240 sampled patterns: on a 4 MiB slice around one of their matches and on a second, fixed 4 MiB
+          slice, the complete set of matches inside the slice equals oracle.search_encoded on the slice;
+      (b) EVERY reported match (all ~1.8e5) is re-derived by the oracle on a window around it: same end,
+          cost, start and cigar;
+      (c) for 24 patterns the full list equals a single-pattern search that streams the DP over every
+          block (prefilter off, sassy_hip_set_prefilter(0)) -- a path that shares no filter with (a);
+      (d) the result is sorted by the reference's comparison key and every pattern index is in range.
+    Then the same text with N runs and other IUPAC letters scattered in (Iupac semantics: N matches
+    everything, src/pattern_tiling/tqueries.rs:101-110): 600 patterns, slices with N runs against the oracle."""
+    n = 3_000_000_000
+    npat, m, k = 10_000, 20, 2
+    try:
+        buf = sassy.DeviceBuffer(n + 4096)
+        host = np.empty(n, dtype=np.uint8)
+    except (sassy.SassyHipError, MemoryError):
+        pytest.skip("cannot allocate 3 GB on this device / host")
+    sassy.generate_dna(buf.ptr, n, 42, 0)
+    buf.download_into(host)
+    pats = _cfg4_patterns(npat)
+    s = sassy.Searcher("iupac", rc=False)
+    enc = s.encode_patterns(pats)
+    r = s.search_encoded_patterns(enc, _DevText(buf.ptr, n), k, as_result=True)
+    st = s.stats()
+    arr, pool = r.array, r.pool
+    assert st["scan_launches"] == npat and len(arr) > 100_000
+    pidx = arr["pattern_idx"].astype(np.int64)
+    # (d) order and ranges
+    assert int(pidx.min()) >= 0 and int(pidx.max()) < npat
+    keyc = np.stack([pidx, arr["text_start"].astype(np.int64), arr["text_end"].astype(np.int64)], axis=1)
+    assert (np.lexsort((keyc[:, 2], keyc[:, 1], keyc[:, 0])) == np.arange(len(arr))).all()
+    assert int(arr["cost"].max()) <= k and int(arr["text_end"].max()) <= n and (arr["strand"] == 0).all()
+    first_of = np.searchsorted(pidx, np.arange(npat + 1))
+
+    # (b) every match, re-derived on its own window
+    LEFT, RIGHT = 96, 8
+    bad = 0
+    for i in range(len(arr)):
+        rec = arr[i]
+        e = int(rec["text_end"])
+        o = max(0, e - LEFT)
+        hi = min(n, e + RIGHT)
+        win = host[o:hi].tobytes()
+        want = (int(rec["text_start"]) - o, e - o, int(rec["cost"]),
+                pool[int(rec["cigar_off"]):int(rec["cigar_off"]) + int(rec["cigar_len"])].decode())
+        found = [(w.text_start, w.text_end, w.cost, w.cigar) for w in oracle.search("iupac", pats[int(rec["pattern_idx"])], win, k)]
+        if want not in found:
+            bad += 1
+            assert bad < 5, (i, want, found)
+    assert bad == 0
+
+    # (a) sampled patterns on slices, complete sets
+    rng = random.Random(4)
+    SL = 4 << 20
+    sample = rng.sample(range(npat), 240)
+    checked = 0
+    for p in sample:
+        lo, hi = int(first_of[p]), int(first_of[p + 1])
+        starts = [((p * 7919) % 700) * SL]  # a fixed slice (usually without a match of this pattern)
+        if hi > lo:
+            anchor = int(arr["text_start"][lo + (hi - lo) // 2])
+            starts.append(max(0, min(n - SL, (anchor - SL // 2) // 64 * 64)))
+        for a in starts:
+            sl = host[a:a + SL].tobytes()
+            want = [(w.text_start + a, w.text_end + a, w.cost, w.cigar)
+                    for w in oracle.search_encoded("iupac", [pats[p]], sl, k) if w.text_start >= 64 and w.text_end <= SL - 64]
+            sel = [i for i in range(lo, hi) if int(arr["text_start"][i]) >= a + 64 and int(arr["text_end"][i]) <= a + SL - 64]
+            got = [(ts, te, c, cg) for (_, ts, te, c, _, cg) in _rows_of(arr, pool, sel)]
+            assert sorted(got) == sorted(want), (p, a)
+            checked += len(want)
+    assert checked >= 200
+
+    # (c) against the streaming DP (no prefilter at all)
+    plain = sassy.Searcher("iupac", rc=False).set_prefilter(0)
+    for p in rng.sample(range(npat), 24):
+        rr = plain._search(pats[p], _DevText(buf.ptr, n), k, sassy.TEXT_ON_DEVICE)
+        assert plain.stats()["filtered"] == 0
+        want = sorted((int(x["text_start"]), int(x["text_end"]), int(x["cost"])) for x in rr.array)
+        lo, hi = int(first_of[p]), int(first_of[p + 1])
+        got = sorted((int(x["text_start"]), int(x["text_end"]), int(x["cost"])) for x in arr[lo:hi])
+        assert got == want, p
+
+    # ---- the same text with N runs and other IUPAC letters: Iupac semantics for the text ----
+    patch_rng = random.Random(9)
+    spots = []
+    for q in range(40):
+        at = patch_rng.randrange(1 << 20, n - (1 << 20))
+        ln = patch_rng.choice([1, 2, 5, 17, 23, 60, 400])
+        run = b"N" * ln if q % 10 < 7 else bytes(patch_rng.choice(b"NNNNNNRYKMSWBDHVn") for _ in range(ln))
+        buf.upload(run, at)
+        host[at:at + len(run)] = np.frombuffer(run, dtype=np.uint8)
+        spots.append(at)
+    sub = pats[:600]
+    enc2 = s.encode_patterns(sub)
+    r2 = s.search_encoded_patterns(enc2, _DevText(buf.ptr, n), k, as_result=True)
+    arr2, pool2 = r2.array, r2.pool
+    pidx2 = arr2["pattern_idx"].astype(np.int64)
+    first2 = np.searchsorted(pidx2, np.arange(len(sub) + 1))
+    assert len(arr2) > 600 * 5  # the long N runs match every pattern
+    SL2 = 1 << 16
+    for p in patch_rng.sample(range(len(sub)), 40):
+        lo, hi = int(first2[p]), int(first2[p + 1])
+        for at in patch_rng.sample(spots, 6):
+            a = (at - SL2 // 2) // 64 * 64
+            sl = host[a:a + SL2].tobytes()
+            want = [(w.text_start + a, w.text_end + a, w.cost, w.cigar)
+                    for w in oracle.search_encoded("iupac", [sub[p]], sl, k) if w.text_start >= 64 and w.text_end <= SL2 - 64]
+            sel = [i for i in range(lo, hi) if int(arr2["text_start"][i]) >= a + 64 and int(arr2["text_end"][i]) <= a + SL2 - 64]
+            got = [(ts, te, c, cg) for (_, ts, te, c, _, cg) in _rows_of(arr2, pool2, sel)]
+            assert sorted(got) == sorted(want), (p, at)
+    buf.free()
+
+
+def test_full_size_config_3_properties(sassy):
+    """BASELINE config 3 at full text size (3 GB; Iupac, |P|=200 with N/R/Y/W, k=20): every plant found at
+    its place, sorted, and a 1 MiB slice equal to the oracle."""
     n = 3_000_000_000
     try:
         buf = sassy.DeviceBuffer(n + 4096)
     except sassy.SassyHipError:
         pytest.skip("cannot allocate 3 GB on this device")
     sassy.generate_dna(buf.ptr, n, 42, 0)
-    # ---- config 4 shape first (plain random text) ----
-    rng = random.Random(45)
-    pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(16)]
-    s = sassy.Searcher("iupac", rc=False)
-    enc = s.encode_patterns(pats)
-    got = s.search_encoded_patterns(enc, _DevText(buf.ptr, n), 2)
-    assert s.stats()["filtered"] == 2 and s.stats()["scan_launches"] == 16
-    assert len(got) > 100
-    single = sassy.Searcher("dna", rc=False)
-    for pi in (0, 7, 15):
-        want = single._search(pats[pi], _DevText(buf.ptr, n), 2, sassy.TEXT_ON_DEVICE).matches
-        mine = [m for m in got if m.pattern_idx == pi]
-        assert sorted((m.text_start, m.text_end, m.cost, m.cigar) for m in mine) == \
-               sorted((m.text_start, m.text_end, m.cost, m.cigar) for m in want)
     # ---- config 3 ----
     p = bytearray(oracle.generate_dna(44, 0, 200).tobytes())
     p[50], p[100], p[150], p[199] = ord("N"), ord("R"), ord("Y"), ord("W")
@@ -1108,3 +1268,152 @@ def test_geometry_tuner_trials_are_exact(sassy, profile, k):
     assert [(m.text_start - (64 << 20), m.text_end - (64 << 20), m.cost, m.cigar) for m in ms] == \
            [(m.text_start, m.text_end, m.cost, m.cigar) for m in want if m.text_start >= 64]
     buf.free()
+
+
+# ------------------------------------------------------------------ Dna profile on real-genome letters
+def test_dna_profile_text_with_other_letters(sassy):
+    """Every real genome holds N runs, soft-masked (lower-case) stretches and a few other IUPAC letters.
+    The reference's Dna profile scans them through the 2-bit code (c >> 1) & 3 -- N reads as G, R as C,
+    Y as A, ... (src/profiles/dna.rs:19-40) -- but its traceback compares bytes case-insensitively
+    (:48-50), so a match that runs over such a letter either gets an alignment with an X where the scan
+    saw a match, or the walk finds no ancestor and the reference panics (src/trace.rs:360-388).  The
+    HIP path must agree with the oracle's restatement of exactly that, case by case: same matches, or
+    a loud failure where the reference would panic -- through the streaming DP and the prefilters alike."""
+    rng = random.Random(77)
+    outcomes = {"same": 0, "both_fail": 0}
+    s_fwd = sassy.Searcher("dna", rc=False)
+    s_rc = sassy.Searcher("dna", rc=True)
+    for case in range(60):
+        m = rng.choice([12, 20, 32, 32, 48, 90])
+        k = rng.choice([0, 1, 2, 3]) if m < 40 else rng.choice([3, 5, 8])
+        pat = rand_seq(rng, m)
+        n = rng.choice([300, 5000, 70_000])
+        text = bytearray(rand_seq(rng, n))
+        # N runs, a soft-masked stretch, scattered ambiguity letters
+        for _ in range(rng.randrange(1, 4)):
+            a = rng.randrange(0, n)
+            ln = rng.choice([1, 3, 40, 500])
+            text[a:a + ln] = b"N" * len(text[a:a + ln])
+        a = rng.randrange(0, n)
+        text[a:a + 200] = bytes(text[a:a + 200]).lower()
+        for _ in range(n // 2000):
+            text[rng.randrange(0, n)] = rng.choice(b"RYKMSWnryx-")
+        # near-copies of the pattern, some with their letters replaced by what aliases to them
+        alias = {ord("G"): b"NnKg", ord("C"): b"RrSc", ord("A"): b"YyXa", ord("T"): b"Ut"}
+        for _ in range(rng.randrange(2, 6)):
+            ins = bytearray(mutate(rng, pat, rng.randrange(0, k + 1)))
+            if rng.random() < 0.12:
+                x = rng.randrange(0, len(ins))
+                ins[x] = rng.choice(alias.get(ins[x], bytes([ins[x]])))
+            at = rng.randrange(0, max(1, n - len(ins)))
+            text[at:at + len(ins)] = ins
+        text = bytes(text[:n])
+        for s, rc in ((s_fwd, False), (s_rc, True)):
+            try:
+                want = oracle.search("dna", pat, text, k, rc=rc)
+            except RuntimeError:
+                want = None
+            if want is None:
+                with pytest.raises(sassy.SassyHipError, match="traceback failed"):
+                    s.search(pat, text, k)
+                outcomes["both_fail"] += 1
+            else:
+                assert_same(s.search(pat, text, k), want, (case, m, k, n, rc))
+                outcomes["same"] += 1
+            # end positions and costs never depend on the traceback
+            wo = s.search_without_trace(pat, text, k)
+            ends = oracle.find_ends(oracle.last_row("dna", pat, text), k)
+            assert [(x.text_end, x.cost) for x in wo if x.strand == "+"] == ends, (case, rc)
+    assert outcomes["same"] >= 30 and outcomes["both_fail"] >= 10, outcomes
+
+
+# ------------------------------------------------------------------ N > 1 on one GPU
+def _run_ranks(script_args, world, timeout=600):
+    """torch.distributed.run with `world` ranks on this box (they share the GPU)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + script_args
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_two_ranks_share_one_gpu_seam_plateau(sassy):
+    """Two ranks (one process each, sharing the GPU; gloo for the exchange) search their shards of texts
+    whose <=k plateau crosses the rank seam, exchange the match rows in one collective (capacity grows
+    from 2 rows, cigars of a 200-row pattern included) and rank 0's merged list equals the oracle's
+    search of the whole text (tests/helpers/shard_ranks.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = _run_ranks([os.path.join(root, "tests", "helpers", "shard_ranks.py")], 2)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-2000:])
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    rep = json.loads(line)
+    assert rep["ok"] and rep["world"] == 2 and len(rep["cases"]) == 3
+    assert all(c["same"] and c["matches"] > 0 for c in rep["cases"])
+    assert rep["cases"][2]["longest_cigar"] > 40 and rep["cases"][1]["regrown"] >= 1
+
+
+def test_bench_launches_its_own_ranks(sassy):
+    """`python bench.py --gpus 2` starts two ranks by itself, prints n_gpus = 2 and a whole-job value;
+    with one visible GPU it refuses unless told that the ranks may share it; --gpus must equal the
+    launcher's world size."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bench = os.path.join(root, "bench.py")
+    small = ["--steps", "3", "--warmup", "1", "--text-bytes", str(64 << 20), "--tune-searches", "0"]
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--allow-shared-gpu"] + small,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-3000:])
+    line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["total_text_bytes"] == 2 * (64 << 20)
+    assert out["matches"] >= 2 * 63 and out["value"] > 0 and "cpu_baseline" not in out
+    import torch
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run([sys.executable, bench, "--gpus", "2"] + small, capture_output=True, text=True, timeout=900)
+        assert p.returncode != 0 and "one rank per GPU" in (p.stdout + p.stderr)
+    p = _run_ranks([bench, "--gpus", "3", "--allow-shared-gpu"] + small, 2)
+    assert p.returncode != 0 and "must equal --gpus" in (p.stdout + p.stderr)
+
+
+# ------------------------------------------------------------------ the boundary from C
+def test_compiled_c_client_links_and_runs(sassy, tmp_path):
+    """A C translation unit written against include/sassy.h only (tests/c/dropin_client.c: the call
+    order of the reference's c/example.c:14-29), compiled with gcc, linked with -lsassy_hip, run as its
+    own process with two host threads that each own a searcher: every match it prints equals the
+    oracle's on the same bytes."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "dropin_client")
+    libdir = os.path.join(root, "sassy_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-std=c11", os.path.join(root, "tests", "c", "dropin_client.c"),
+                           "-I" + os.path.join(root, "include"), "-L" + libdir, "-lsassy_hip", "-lpthread", "-lm", "-o", exe])
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = libdir + ":" + env.get("LD_LIBRARY_PATH", "")
+    p = subprocess.run([exe], env=env, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    texts, got = {}, {}
+    for line in p.stdout.split(b"\n"):
+        if line.startswith(b"text "):
+            _, t, body = line.split(b" ", 2)
+            texts[int(t)] = body
+        elif line and line[:1].isdigit():
+            f = line.split()
+            got.setdefault((int(f[0]), int(f[1])), []).append((int(f[2]), int(f[3]), int(f[4]), int(f[5]), int(f[6]), f[7].decode()))
+    assert p.stdout.rstrip().endswith(b"done 0") and len(texts) == 2 and len(texts[0]) == 200000
+    jobs = {0: ("dna", True, [(b"ACGGTCAGGTTACGATCGGATCAGTTAGCAAT", 3), (b"TTGACCAGTA", 1), (b"GATTACAGATTACA", 2)]),
+            1: ("iupac", False, [(b"ACGNTCAGGTYACGATCGRATCAGTTAGCWAT", 3), (b"CCATGGCATGCCATGG", 2), (b"A" * 20, 3)])}
+    total = 0
+    for t, (profile, rc, searches) in jobs.items():
+        for q, (pat, k) in enumerate(searches):
+            want = [(m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, m.strand)
+                    for m in oracle.search(profile, pat, texts[t], k, rc=rc)]
+            assert got.get((t, q), []) == want, (t, q)
+            total += len(want)
+    assert total >= 20

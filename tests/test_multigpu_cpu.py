@@ -80,14 +80,18 @@ def _worker(rank, world, port, q):
         got = multigpu.gather_shard_results(empty, torch, dist, dev)
         if rank == 0:
             assert [len(g) for g in got] == [0, 0]
-        # the fixed-capacity, one-collective variant bench.py uses, directly and on its worker thread
-        mg = multigpu.MatchGather(torch, dist, dev, capacity_rows=8)
-        for _ in range(3):
+        # the one-collective variant bench.py uses, directly and on its worker thread; capacity 2 is
+        # too small for rank 1's three rows: every rank grows and repeats the exchange once
+        cb = multigpu.cigar_bytes_for(32, 3)
+        mg = multigpu.MatchGather(torch, dist, dev, capacity_rows=2, cigar_bytes=cb)
+        for it in range(3):
             got = mg.gather(local)
+            assert mg.cap == 4 and mg.regrown == 1
             if rank == 0:
                 assert [len(g) for g in got] == [2, 3] and got[1].conditional_index == 0
                 merged = multigpu.matches_from_rows(multigpu.merge_shard_results(got), Match)
                 assert [m.text_start for m in merged] == [3, 90, big, 3_000_000_900]
+                assert merged[0].cigar == "3=1X" and merged[3].cigar == "4="
             else:
                 assert got is None
         w = multigpu.GatherWorker(mg)
@@ -96,6 +100,31 @@ def _worker(rank, world, port, q):
         last = w.flush()
         if rank == 0:
             assert last is not None and [int(r[1]) for r in last] == [3, 90, -1, 3_000_000_900]
+        # config-3 shapes: cigars of a 200-row pattern with k = 20 (up to 442 characters) travel too
+        long_cigar = "".join(f"{3 + (i % 5)}={1}X" for i in range(40))[:400]
+        cb3 = multigpu.cigar_bytes_for(200, 20)
+        assert cb3 >= len(long_cigar)
+        mg3 = multigpu.MatchGather(torch, dist, dev, capacity_rows=4, cigar_bytes=cb3)
+        mine3 = [M(1000 * rank + 5, 1000 * rank + 210, 7, "+", long_cigar)]
+        got = mg3.gather(multigpu.ShardResult(multigpu.rows_from_matches(mine3), multigpu.STATE_TRUE, -1))
+        if rank == 0:
+            merged = multigpu.matches_from_rows(multigpu.merge_shard_results(got), Match)
+            assert [m.cigar for m in merged] == [long_cigar, long_cigar] and merged[1].text_start == 1005
+        # a rank that fails before the exchange takes every rank down with it, together: rank 1 flags
+        # an error for the 2nd submission, both ranks raise GatherError from flush(), nobody hangs
+        w2 = multigpu.GatherWorker(mg)
+        w2.submit(local)
+        if rank == 1:
+            w2.submit_error()
+        else:
+            w2.submit(local)
+        w2.submit(local)  # dropped on both ranks
+        try:
+            w2.flush()
+            raise AssertionError("no GatherError")
+        except multigpu.GatherError as e:
+            assert "[1]" in str(e)
+        w2.close()
         w.close()
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
