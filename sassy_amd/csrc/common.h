@@ -57,6 +57,7 @@ constexpr uint32_t kScanTextStart = 2u;  // buffer byte 0 is the true start of t
 constexpr uint32_t kScanTextEnd = 4u;    // buffer end is the true end of the text
 constexpr uint32_t kScanPerText = 16u;   // list mode over whole texts: one lane per text of a block-aligned
                                          // multi-text buffer (ScanParams::texts), no prefilter
+constexpr uint32_t kScanNoRowCut = 32u;  // DP kernels: compute every pattern row of every block (SASSY_HIP_ROW_CUT=0)
 constexpr uint32_t kScanOverhang = 8u;   // overhang (alpha): special left edge at the text start, virtual
                                          // 'N' columns and an extra cost past the text end
 

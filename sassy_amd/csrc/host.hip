@@ -692,6 +692,8 @@ int ScanJob::prepare() {
   P.wb = warmup_blocks(plan.m, k);
   P.flags = (all_minima ? kScanAllMinima : 0u) | (sh.text_start ? kScanTextStart : 0u) |
             (sh.text_end ? kScanTextEnd : 0u) | (overhang ? kScanOverhang : 0u);
+  static const bool env_nocut = getenv("SASSY_HIP_ROW_CUT") && atoi(getenv("SASSY_HIP_ROW_CUT")) == 0;
+  if (env_nocut) P.flags |= kScanNoRowCut;
   P.alpha = overhang ? S->alpha : 0.0f;
   P.ov_steps = ov_steps;
   P.rev_n = rev_n;

@@ -350,13 +350,38 @@ __device__ __forceinline__ uint32_t row_mask_off(const uint32_t (&pk)[8], int r)
   return ((pk[r >> 2] >> (8 * (r & 3))) & 0xFFu) << 8;
 }
 
+// Bounded rows (reference: src/search.rs:1129-1162 early-termination check, :941-975 check_lanes /
+// min_in_lane, :1244-1249 reset_rows).  After `done` rows of a word, row `done` of the
+// block (the one just finished) is DEAD for a lane when
+//   (1) none of its 65 cells (left edge + 64 columns) can be <= k: the byte-granular popcount bound
+//       row_maybe_live on the row's horizontal deltas, and
+//   (2) no left-edge cell further down is <= k either: the left-edge cost L at this row minus every
+//       -1 vertical delta below it is still > k.
+// Then every cell below this row inside the block is > k (a cell <= k needs a neighbour <= k above it or
+// on the left edge), so the remaining rows are skipped and their right-edge carries are reset to (+1, 0) --
+// an over-estimate that only ever reaches cells whose true value is > k.  The lanes of a wave run in
+// lockstep, so the rows stop when ALL lanes of the wave are dead (a wave vote; the reference votes over
+// its 4 / 8 SIMD lanes).  Tests cost about two rows' worth of VALU: they start at the row count the wave
+// learnt from its previous blocks (first_test) and repeat every 4 rows.
+constexpr uint32_t kCutFirstRows = 8;  // a wave's first block tests from here (reference: CHECK_AT_LEAST_ROWS = 8)
+struct CutCtx {
+  int k;
+  int ds_word;         // left-edge cost above this word's first row
+  int minus_below;     // -1 vertical deltas on the left edge in all LATER words
+  uint32_t first_test; // test when at least this many rows of the word are done (> 32: never)
+  bool more_words;     // rows follow behind this word
+  bool idle;           // the lane's block does not count (no chunk / outside its range): votes "dead"
+};
+
 // The rows of one 32-row word.  pk_in holds the profile slot of each row (one byte per row).
 // SCALAR_PK: the word (and so its row table) is the same for the whole wave (scalar registers);
 // false: every lane works on its own word (list_words_kernel).
-template <bool SCALAR_PK = true>
-__device__ __forceinline__ void dp_word(DpWord& V, const unsigned char* my_masks, uint32_t ohp, uint32_t ohm,
-                                        const uint32_t (&pk_in)[8], uint32_t rows, uint32_t& nhp_out,
-                                        uint32_t& nhm_out) {
+// CUT: bounded rows (see CutCtx).  Returns 0 when all rows of the word were computed, else the number of
+// rows (4 .. 32) after which the wave stopped (nhp / nhm then hold (+1, 0) for the skipped rows).
+template <bool SCALAR_PK = true, bool CUT = false>
+__device__ __forceinline__ uint32_t dp_word(DpWord& V, const unsigned char* my_masks, uint32_t ohp, uint32_t ohm,
+                                            const uint32_t (&pk_in)[8], uint32_t rows, uint32_t& nhp_out,
+                                            uint32_t& nhm_out, const CutCtx* cut = nullptr) {
   // Opaque copies: keeps the 32 per-row offsets from being hoisted out of the block loop as 32
   // live scalars (SGPR spills cost VALU v_readlane ops); re-deriving them is one s_bfe each.
   uint32_t pk[8];
@@ -366,12 +391,13 @@ __device__ __forceinline__ void dp_word(DpWord& V, const unsigned char* my_masks
     if constexpr (SCALAR_PK) asm volatile("" : "+s"(pk[i]));
   }
   uint32_t nhp = 0, nhm = 0, done = 0;
+  bool stopped = false;  // wave-uniform
   uint2 eqn[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) eqn[u] = *reinterpret_cast<const uint2*>(my_masks + row_mask_off(pk, u));
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
-    if (4u * g + 4u <= rows) {
+    if (!stopped && 4u * g + 4u <= rows) {
       uint2 eqc[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) eqc[u] = eqn[u];
@@ -384,22 +410,101 @@ __device__ __forceinline__ void dp_word(DpWord& V, const unsigned char* my_masks
       for (int u = 0; u < 4; ++u)
         dp_row(V, eqc[u], (ohp >> (31 - (4 * g + u))) & 1u, (ohm >> (31 - (4 * g + u))) & 1u, nhp, nhm);
       done = 4u * g + 4u;
+      if constexpr (CUT) {
+        if (done >= cut->first_test && (done < rows || cut->more_words)) {  // wave-uniform
+          const uint32_t top = 0xFFFFFFFFu << (28 - 4 * g);  // rows 0 .. done-1 of the word (compile-time: g is unrolled)
+          // (HIP's __popc returns unsigned: keep the arithmetic signed, the bound is often negative)
+          const int here = cut->ds_word + (int)__popc(ohp & top) - (int)__popc(ohm & top);
+          const bool below_dead = here - (int)__popc(ohm & ~top) - cut->minus_below > cut->k;
+          const bool dead = cut->idle || (below_dead && !row_maybe_live(here, V, cut->k));
+          stopped = __all(dead);
+        }
+      }
     }
   }
-  // up to three leftover rows when the word's row count is not a multiple of 4: they all lie in
-  // table word done/4
-  if (done < rows) {
-    const uint32_t q = done >> 2;
-    const uint32_t pw = q == 0 ? pk[0] : q == 1 ? pk[1] : q == 2 ? pk[2] : q == 3 ? pk[3]
-                      : q == 4 ? pk[4] : q == 5 ? pk[5] : q == 6 ? pk[6] : pk[7];
-    for (uint32_t r = done; r < rows; ++r) {
-      const uint2 eq = *reinterpret_cast<const uint2*>(my_masks + (((pw >> (8 * (r & 3))) & 0xFFu) << 8));
-      dp_row(V, eq, (ohp >> (31 - r)) & 1u, (ohm >> (31 - r)) & 1u, nhp, nhm);
+  if (!stopped) {
+    // up to three leftover rows when the word's row count is not a multiple of 4: they all lie in
+    // table word done/4
+    if (done < rows) {
+      const uint32_t q = done >> 2;
+      const uint32_t pw = q == 0 ? pk[0] : q == 1 ? pk[1] : q == 2 ? pk[2] : q == 3 ? pk[3]
+                        : q == 4 ? pk[4] : q == 5 ? pk[5] : q == 6 ? pk[6] : pk[7];
+      for (uint32_t r = done; r < rows; ++r) {
+        const uint2 eq = *reinterpret_cast<const uint2*>(my_masks + (((pw >> (8 * (r & 3))) & 0xFFu) << 8));
+        dp_row(V, eq, (ohp >> (31 - r)) & 1u, (ohm >> (31 - r)) & 1u, nhp, nhm);
+      }
     }
+    if (rows < 32) { nhp <<= (32 - rows); nhm <<= (32 - rows); }
+    nhp_out = nhp;
+    nhm_out = nhm;
+    return 0;
   }
-  if (rows < 32) { nhp <<= (32 - rows); nhm <<= (32 - rows); }
-  nhp_out = nhp;
-  nhm_out = nhm;
+  // stopped after `done` (4 .. 32) rows: row r of the word sits at bit 31 - r; the skipped rows done .. rows-1
+  // get the right-edge carry (+1, 0)
+  const uint32_t word_rows_mask = rows == 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> rows);
+  const uint32_t done_mask = done == 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> done);
+  const uint32_t sh = 32u - done;  // 0 .. 28
+  nhp_out = (sh ? (nhp << sh) : nhp) | (word_rows_mask & ~done_mask);
+  nhm_out = sh ? (nhm << sh) : nhm;
+  return done;
+}
+
+// The DP rows of one block for a lane whose per-row carries live in LDS (scan_kernel, list_kernel): all
+// words top-down with the wave-wide row cut-off.  Returns true when the block ran to its last row (then
+// V / ds describe that row), false when the rows were cut (no cell <= k in the block for any lane).
+// first_rows (wave-uniform, in/out): the row count from which this wave tests; it follows the text --
+// down to four rows before the last stop, up by four after a block that ran through.
+// minus_total (per lane, in/out): -1 vertical deltas on the block's left edge over all words.
+__device__ __forceinline__ bool dp_block(DpWord& V, int& ds, const unsigned char* my_masks, uint32_t* carry, uint32_t lane,
+                                         const_u32_ptr row_tab, const uint32_t (&pkw0)[8], uint32_t nwords, uint32_t last_rows,
+                                         uint32_t last_word_init, int k, bool idle, uint32_t& first_rows, int& minus_total,
+                                         uint32_t m, bool counting, unsigned long long& cnt_rows) {
+  V.vpl = V.vph = V.vml = V.vmh = 0;  // row 0 of the matrix is all 0: horizontal deltas 0
+  ds = 0;                             // cost at the block's left edge, rows above the current word
+  int seen_minus = 0, next_minus = 0;
+  uint32_t stop_at = 0;               // != 0: the wave stopped after this many rows of the block
+  for (uint32_t w = 0; w < nwords; ++w) {
+    const bool last = w == nwords - 1;
+    if (stop_at) {  // wave-uniform: the rows of this word are skipped, right-edge carry (+1, 0)
+      carry[(w * 2 + 0) * 64 + lane] = last ? last_word_init : 0xFFFFFFFFu;
+      carry[(w * 2 + 1) * 64 + lane] = 0;
+      continue;
+    }
+    const uint32_t ohp = carry[(w * 2 + 0) * 64 + lane];
+    const uint32_t ohm = carry[(w * 2 + 1) * 64 + lane];
+    seen_minus += (int)__popc(ohm);
+    const uint32_t rows = last ? last_rows : 32u;
+    uint32_t pkw[8];
+    if (w == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pkw[i] = pkw0[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) pkw[i] = row_tab[8 * w + i];
+    }
+    CutCtx cc;
+    cc.k = k;
+    cc.ds_word = ds;
+    cc.minus_below = minus_total - seen_minus;
+    cc.first_test = first_rows > 32u * w ? first_rows - 32u * w : 4u;
+    cc.more_words = !last;
+    cc.idle = idle;
+    uint32_t nhp, nhm;
+    const uint32_t cut_at = dp_word<true, true>(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm, &cc);
+    ds += (int)__popc(ohp) - (int)__popc(ohm);
+    carry[(w * 2 + 0) * 64 + lane] = nhp;
+    carry[(w * 2 + 1) * 64 + lane] = nhm;
+    next_minus += (int)__popc(nhm);
+    if (cut_at) stop_at = 32u * w + cut_at;
+  }
+  minus_total = next_minus;
+  if (counting) cnt_rows += stop_at ? stop_at : m;
+  if (stop_at) {
+    first_rows = stop_at;  // the next block tests there first
+    return false;
+  }
+  if (first_rows < m) first_rows = first_rows + 4u < m ? first_rows + 4u : m;  // ran through: test later (never, on match-dense text)
+  return true;
 }
 
 // SB = text blocks per lane chunk fetched by one staging step: 2 = one full 128-byte line per
@@ -497,6 +602,9 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
 
   unsigned long long cnt_rows = 0, cnt_blocks = 0, cnt_live = 0;
   const unsigned char* my_masks = mask_bytes + lane * 8;
+  // bounded rows: where this wave starts testing (wave-uniform; beyond every pattern = never)
+  uint32_t first_rows = (P.flags & kScanNoRowCut) ? 0x40000000u : kCutFirstRows;
+  int minus_total = 0;                  // -1 deltas on the current block's left edge (none at a fresh start)
 
   for (uint32_t it = 0; it < P.n_iter; ++it) {
     const uint32_t sub = SB == 2 ? (it & 1u) : 0u;
@@ -536,35 +644,20 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
         *reinterpret_cast<uint2*>(mask_bytes + s * 512 + lane * 8) = msk[s];
     }
 
-    // ---- the DP rows of this block ----
-    DpWord V;
-    V.vpl = V.vph = V.vml = V.vmh = 0;  // row 0 of the matrix is all 0: horizontal deltas 0
-    int ds = 0;                         // cost at the block's left edge in the last row
-    for (uint32_t w = 0; w < nwords; ++w) {
-      const uint32_t ohp = carry[(w * 2 + 0) * 64 + lane];
-      const uint32_t ohm = carry[(w * 2 + 1) * 64 + lane];
-      ds += __popc(ohp) - __popc(ohm);
-      const uint32_t rows = (w == nwords - 1) ? last_rows : 32u;
-      uint32_t pkw[8];
-      if (w == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pkw[i] = pkw0[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pkw[i] = row_tab[8 * w + i];
-      }
-      uint32_t nhp, nhm;
-      dp_word(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm);
-      carry[(w * 2 + 0) * 64 + lane] = nhp;
-      carry[(w * 2 + 1) * 64 + lane] = nhm;
-    }
-
-    // ---- last row of the block: anything <= k ? ----
+    // ---- the DP rows of this block (bounded: the wave stops at the first row below which no lane can
+    // hold a cell <= k) ----
     const uint64_t b = blk0 + it;
     const bool active = has_chunk && b < own_hi;
+    if ((it & 7u) == 7u && first_rows > 8u && first_rows <= m) first_rows -= 4u;  // now and then try an earlier row again
+    DpWord V;
+    int ds;  // cost at the block's left edge in the last row
+    const bool ran_through = dp_block(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
+                                      !active, first_rows, minus_total, m, P.counters != nullptr && active, cnt_rows);
+
+    // ---- last row of the block: anything <= k ? ----
     if (active) {
-      if (P.counters) { cnt_rows += m; cnt_blocks += 1; }
-      if (row_maybe_live(ds, V, k)) {
+      if (P.counters) cnt_blocks += 1;
+      if (ran_through && row_maybe_live(ds, V, k)) {
         const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
         if (P.counters) cnt_live += 1;
         st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
@@ -1446,6 +1539,8 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   }
   unsigned long long cnt_rows = 0, cnt_blocks = 0, cnt_live = 0;
   const unsigned char* my_masks = mask_bytes + lane * 8;
+  uint32_t first_rows = (P.flags & kScanNoRowCut) ? 0x40000000u : kCutFirstRows;
+  int minus_total = 0;
 
   // the lane's next block is fetched while this one is computed (two or three waves per SIMD do not
   // hide a load that is issued and consumed in the same iteration)
@@ -1475,30 +1570,14 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
 #pragma unroll
       for (int s = 0; s < NS; ++s) *reinterpret_cast<uint2*>(mask_bytes + s * 512 + lane * 8) = msk[s];
     }
+    if ((it & 7u) == 7u && first_rows > 8u && first_rows <= m) first_rows -= 4u;
     DpWord V;
-    V.vpl = V.vph = V.vml = V.vmh = 0;
-    int ds = 0;
-    for (uint32_t w = 0; w < nwords; ++w) {
-      const uint32_t ohp = carry[(w * 2 + 0) * 64 + lane];
-      const uint32_t ohm = carry[(w * 2 + 1) * 64 + lane];
-      ds += __popc(ohp) - __popc(ohm);
-      const uint32_t rows = (w == nwords - 1) ? last_rows : 32u;
-      uint32_t pkw[8];
-      if (w == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pkw[i] = pkw0[i];
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) pkw[i] = row_tab[8 * w + i];
-      }
-      uint32_t nhp, nhm;
-      dp_word(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm);
-      carry[(w * 2 + 0) * 64 + lane] = nhp;
-      carry[(w * 2 + 1) * 64 + lane] = nhm;
-    }
+    int ds;
+    const bool ran_through = dp_block(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
+                                      !active, first_rows, minus_total, m, P.counters != nullptr && active, cnt_rows);
     if (active) {
-      if (P.counters) { cnt_rows += m; cnt_blocks += 1; }
-      if (row_maybe_live(ds, V, k)) {
+      if (P.counters) cnt_blocks += 1;
+      if (ran_through && row_maybe_live(ds, V, k)) {
         const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
         if (P.counters) cnt_live += 1;
         st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
