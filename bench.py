@@ -103,10 +103,13 @@ def main():
     ap.add_argument("--profile", default="dna")
     ap.add_argument("--plant-stride", type=int, default=1 << 20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--tune-searches", type=int, default=40,
-                    help="untimed searches before the warm-up (the library's geometry tuner settles within 36)")
+    ap.add_argument("--tune-searches", type=int, default=0,
+                    help="extra untimed searches before the warm-up (only of use with SASSY_HIP_TUNE=1: the opt-in "
+                         "geometry tuner settles within 36 searches); the default run has none")
     ap.add_argument("--cpu-seconds", type=float, default=2.0,
                     help="wall seconds the CPU baseline's threads keep scanning (at least one pass)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="searches in flight on the device (1 = every search alone: begin, wait, next)")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="debugging the N > 1 path on a box with fewer GPUs than ranks: ranks share devices and "
                          "the match exchange goes over gloo; never a valid scaling measurement")
@@ -167,6 +170,7 @@ def main():
                               bytes({ord("Y"): 67}.get(c, c if c in b"ACGT" else 65) for c in pat), k, args.plant_stride)
     torch.cuda.synchronize()
     searcher = sassy_amd.Searcher(args.profile, rc=False)
+    searcher.set_pipe_depth(max(1, min(4, args.in_flight)))
 
     # N > 1: the match lists go to rank 0 in one fixed-size collective per search (header + rows; the
     # capacity starts at 1024 rows and every rank doubles it alike when a header shows that some list did
@@ -178,33 +182,78 @@ def main():
         gather_worker = multigpu.GatherWorker(multigpu.MatchGather(
             torch, dist, coll_device, capacity_rows=1024, cigar_bytes=multigpu.cigar_bytes_for(m, k)))
 
+    # A stream of searches over the resident text keeps `--in-flight` (default 2) of them in flight on the
+    # device (include/sassy_hip.h: sassy_hip_search_shard_begin / sassy_hip_search_finish): step i queues
+    # search i and then waits for search i-1, whose chunk DP / traceback tail ran underneath search i's
+    # prefilter.  Every step is one complete search with its Match records on the host; all K searches of
+    # the timed region are begun AND finished inside it (drain() before the closing barrier).
+    pending = []
+
+    def finish_oldest():
+        r = searcher.search_finish(pending.pop(0))
+        st_ = searcher.stats()
+        if world > 1:
+            gather_worker.submit(r)
+            return gather_worker.last, st_
+        return r, st_  # the records are already on the host in their final form (r.array + r.pool)
+
+    last = [None, None]
+
     def step():
         # one full search of the resident shard; Match records arrive on the host as one packed
         # array (include/sassy_hip.h: sassy_hip_Match + cigar pool), for N > 1 gathered to rank 0
-        if world == 1:
-            # the records are already on the host in their final form (r.array + r.pool)
-            return searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k), searcher.stats()
         try:
-            r = searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
+            if args.in_flight <= 1:
+                r = searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
+                st_ = searcher.stats()
+                if world > 1:
+                    gather_worker.submit(r)
+                    r = gather_worker.last
+                last[0], last[1] = r, st_
+                return r, st_
+            pending.append(searcher.search_shard_begin(pat, buf.data_ptr(), halo, n_per, a, total, k))
+            if len(pending) >= args.in_flight:
+                last[0], last[1] = finish_oldest()
+            return last[0], last[1]
         except Exception:
-            gather_worker.submit_error()  # the other ranks must not wait for this one's rows forever
+            if world > 1:
+                gather_worker.submit_error()  # the other ranks must not wait for this one's rows forever
             raise
-        gather_worker.submit(r)
-        return gather_worker.last, searcher.stats()
+
+    def drain():
+        while pending:
+            last[0], last[1] = finish_oldest()
 
     def sync():
+        drain()
         if gather_worker is not None:
             gather_worker.flush()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up, untimed like the text generation above: the library tunes the prefilter's lane-chunk length
-    # for a resident text during its first ~36 searches (sassy_amd/csrc/host.hip: GeoTuner); they happen
-    # here so that neither the W warm-up steps nor the K timed steps contain a trial geometry
+    # the very first search of this process on this text: buffers are allocated, the pattern tables uploaded,
+    # kernels loaded -- reported on its own, never part of the timed region
+    t_cold = time.perf_counter()
+    searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
+    cold_ms = (time.perf_counter() - t_cold) * 1e3
     for _ in range(args.tune_searches):
         step()
     sync()
+    # One search at a time (nothing else in flight): its latency, and the dominant kernel's HIP-event duration for
+    # the roofline object (with searches in flight two launches of that kernel overlap and share the HBM).  Runs
+    # BEFORE the warm-up steps: 50 searches, reported as single_search_latency_ms, not part of the timed region.
+    lat_t0 = time.perf_counter()
+    n_lat = 50
+    alone_scan_ms = alone_filter_ms = 0.0
+    for _ in range(n_lat):
+        searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
+        st1 = searcher.stats()
+        alone_scan_ms += st1["scan_ms"] / n_lat
+        alone_filter_ms += st1["filter_ms"] / n_lat
+    torch.cuda.synchronize()
+    latency_ms = (time.perf_counter() - lat_t0) / n_lat * 1e3
+
     for _ in range(args.warmup):
         step()
     sync()
@@ -213,6 +262,8 @@ def main():
     host = [0.0, 0.0, 0.0]
     for _ in range(args.steps):
         matches, st = step()
+        if st is None:  # the first steps of a pipeline only queue work
+            continue
         host[0] += st["host_enqueue_ms"]
         host[1] += st["host_wait_ms"]
         host[2] += st["host_post_ms"]
@@ -222,6 +273,7 @@ def main():
         call_ms += st["total_ms"]
     sync()
     elapsed = time.perf_counter() - t0
+    matches, st = last[0], last[1]
     if gather_worker is not None:
         matches = gather_worker.last  # rank 0: the merged rows of the last search; None elsewhere
     el = torch.tensor([elapsed, scan_ms / max(1, args.steps), filter_ms / max(1, args.steps)],
@@ -233,7 +285,12 @@ def main():
     # the dominant kernel: the prefilter scan when the pattern splits into selective pieces
     # (every text byte is read once by it), else the streaming DP kernel.  Its HIP events are the
     # only ones recorded inside the timed region (timing level 1).
-    dom_ms = filter_avg_ms if filtered else scan_avg_ms
+    # With searches in flight two launches of the dominant kernel overlap and share the HBM: its duration in the
+    # timed region (dom_inflight_ms) says how long a launch was resident, not how fast the kernel streams.  The
+    # roofline object therefore uses the HIP-event duration of the same kernel in the one-search-at-a-time loop
+    # of this same run (n_lat launches right behind the timed region); both are reported.
+    dom_inflight_ms = filter_avg_ms if filtered else scan_avg_ms
+    dom_ms = (alone_filter_ms if filtered else alone_scan_ms) if args.in_flight > 1 else dom_inflight_ms
     dom_name = {0: "scan_kernel", 1: "filter_kernel", 2: "filter_dna_kernel", 3: "filter_table_kernel", 4: "filter_count_kernel"}[int(st["filtered"])]
     # phase breakdown from a few extra, untimed steps with every phase timed (more events = more
     # stream idle time, so these are not part of the measurement above)
@@ -278,6 +335,8 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
+        "single_search_latency_ms": round(latency_ms, 4),
+        "cold_first_search_ms": round(cold_ms, 3),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -287,20 +346,23 @@ def main():
             "workload": (f"BASELINE config {'2' if world == 1 else '5'}: Searcher::<{args.profile.capitalize()}>::new_fwd()"
                          f".search, |pattern|={m} (seeded random), k={k}, {n_per} B random-ACGT text per GPU "
                          f"resident in HBM, one planted near-match per {args.plant_stride} B; step = scan + "
-                         f"traceback + Match records on host" + (" + RCCL gather to rank 0 (one collective per search, overlapped with the next search)" if world > 1 else "")),
+                         f"traceback + Match records on host, {max(1, args.in_flight)} search(es) in flight" + (" + RCCL gather to rank 0 (one collective per search, overlapped with the next search)" if world > 1 else "")),
             "text_bytes_per_gpu": n_per,
             "total_text_bytes": total,
             "pattern_len": m,
             "k": k,
             "profile": args.profile,
+            "searches_in_flight": max(1, args.in_flight),
             "parallelism": f"text sharded x{world}, one process per GPU"
                            + ("" if world == 1 else f", {dist.get_backend()} ({'RCCL' if dist.get_backend() == 'nccl' else 'debug: shared GPU'}) world {dist.get_world_size()}"),
-            "setup": f"{args.tune_searches} untimed searches before the warm-up (geometry tuner of the resident text)",
+            "setup": (f"one cold search (cold_first_search_ms), {args.tune_searches} tuning searches, 50 one-at-a-time searches "
+                      f"(single_search_latency_ms and the roofline object's kernel time), then the W warm-up steps and the K timed steps"),
         },
         "matches": len(matches),
         "matches_per_s": round(len(matches) * args.steps / elapsed, 1),
         "planted_rank0": planted,
         "dominant_kernel_ms": round(dom_ms, 4),
+        "dominant_kernel_ms_in_flight": round(dom_inflight_ms, 4),
         "phases_untimed_ms": {"scan_path": round(phase["scan_path_ms"], 4), "rank_and_trace": round(phase["trace_ms"], 4)},
         "prefilter": {"enabled": filtered, "piece_len": st["piece_len"], "hit_blocks": st["hit_blocks"],
                       "chunks": st["chunks"]},
@@ -317,8 +379,17 @@ def main():
             "traffic_source": traffic_source,
             "kernel": dom_name,
             "algorithmic_bytes_per_launch": n_per,
+            "launch_ms": round(dom_ms, 4),
+            "measured": (f"HIP events around the kernel on the searcher's stream, {n_lat} launches of the one-search-at-a-time "
+                         f"loop of this run" if args.in_flight > 1 else "HIP events around the kernel on the searcher's stream, the timed steps"),
         },
     }
+    # the whole search against the same roofline: text bytes of one GPU / time per step (the kernel figure above
+    # leaves out the chunk DP, traceback, launches and the host's share)
+    out["roofline_search"] = {"bound": "hbm", "achieved": round(n_per / (ms_per_step / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBPS,
+                              "unit": "GB/s", "frac": round(n_per / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
+                              "what": f"text bytes per GPU / ms_per_step, {max(1, args.in_flight)} search(es) in flight",
+                              "frac_single_search": round(n_per / (latency_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)}
     if world == 1 and not args.no_cpu_baseline:
         host = buf[:n_per].cpu().numpy()
         gpu_ends = [(int(e), int(c)) for e, c in zip(matches.array["text_end"], matches.array["cost"])]

@@ -101,6 +101,12 @@ int sassy_hip_set_timing(sassy_SearcherType *s, int level);
  * DP over every block, 1 = prefilter also with short pieces.  All give the same matches; the setting exists so
  * that the paths can be checked against each other (tests) and timed apart. */
 int sassy_hip_set_prefilter(sassy_SearcherType *s, int mode);
+/* On-line tuner of the streaming kernels' lane-chunk length for a resident text (off by default, or
+ * SASSY_HIP_TUNE=1): the first ~36 searches of a (text, filter kind) try neighbouring geometries -- each a
+ * complete, exact search -- and the rest use the fastest.  Worth it for the latency of lone searches on one
+ * text at sizes where the default geometry is unlucky (up to 10 %); with searches in flight it moves the time
+ * per search by 0-2 %. */
+int sassy_hip_set_geometry_tuner(sassy_SearcherType *s, int on);
 /* Count DP word-rows / blocks in the scan kernel (stats.word_rows, stats.blocks); off by default. */
 int sassy_hip_enable_counters(sassy_SearcherType *s, int on);
 
@@ -166,6 +172,27 @@ int sassy_hip_search_shard(sassy_SearcherType *s, const uint8_t *pattern, size_t
                            uint64_t global_offset, uint64_t total_len, size_t k, uint32_t flags,
                            sassy_hip_Result **out);
 uint64_t sassy_hip_required_halo(size_t pattern_len, size_t k);
+
+/* Searches in flight.  A stream of searches over a resident text (many patterns against one genome; the
+ * reference's model is one Searcher per thread fed from a queue, bin/grep.rs:476-503) is pipelined on the
+ * device: sassy_hip_search_shard_begin queues the whole kernel chain of one search (same arguments and rules
+ * as sassy_hip_search_shard) and returns a ticket at once; sassy_hip_search_finish waits for that search and
+ * hands out its result (out = NULL: wait and discard).  Up to 2 searches (sassy_hip_set_pipe_depth, at most 4) may
+ * be in flight per searcher -- begin fails with SASSY_HIP_EINVAL beyond that --; they finish in any order the
+ * caller likes, each result is exactly what sassy_hip_search_shard returns.  The short, latency-bound tail of
+ * search i (chunk list, chunk DP, traceback) then runs underneath the bandwidth-bound prefilter of search
+ * i+1.  The pattern is copied; the text must stay valid and unchanged until the ticket is finished.  Every
+ * ticket must be finished before the searcher is freed (tickets still open then are dropped).  The calls of
+ * one searcher must still come from one thread at a time.  sassy_hip_get_stats describes the search finished last. */
+typedef struct sassy_hip_Ticket sassy_hip_Ticket;
+int sassy_hip_search_shard_begin(sassy_SearcherType *s, const uint8_t *pattern, size_t pattern_len,
+                                 const uint8_t *d_text, uint64_t halo_len, uint64_t shard_len,
+                                 uint64_t global_offset, uint64_t total_len, size_t k, uint32_t flags,
+                                 sassy_hip_Ticket **out);
+int sassy_hip_search_finish(sassy_SearcherType *s, sassy_hip_Ticket *ticket, sassy_hip_Result **out);
+/* How many searches sassy_hip_search_shard_begin keeps in flight (1 .. 4, default 2 or SASSY_HIP_PIPE_DEPTH);
+ * only while none is in flight. */
+int sassy_hip_set_pipe_depth(sassy_SearcherType *s, int depth);
 
 size_t sassy_hip_result_len(const sassy_hip_Result *r);
 const sassy_hip_Match *sassy_hip_result_matches(const sassy_hip_Result *r);

@@ -106,6 +106,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_last_error", "sassy_hip_version", "sassy_hip_device_count",
     "sassy_hip_searcher_new", "sassy_hip_set_stream", "sassy_hip_get_stats",
     "sassy_hip_search", "sassy_hip_search_shard", "sassy_hip_required_halo",
+    "sassy_hip_search_shard_begin", "sassy_hip_search_finish", "sassy_hip_set_pipe_depth", "sassy_hip_set_geometry_tuner",
     "sassy_hip_result_len", "sassy_hip_result_matches", "sassy_hip_result_cigars",
     "sassy_hip_result_cigars_len", "sassy_hip_pack_rows", "sassy_hip_enable_counters", "sassy_hip_set_timing",
     "sassy_hip_set_only_best_match", "sassy_hip_set_max_n_frac", "sassy_hip_search_with_fn",
@@ -181,6 +182,15 @@ def lib():
     L.sassy_hip_search_shard.restype = C.c_int
     L.sassy_hip_search_shard.argtypes = [vp, u8p, sz, vp, C.c_uint64, C.c_uint64, C.c_uint64,
                                          C.c_uint64, sz, C.c_uint32, C.POINTER(vp)]
+    L.sassy_hip_search_shard_begin.restype = C.c_int
+    L.sassy_hip_search_shard_begin.argtypes = [vp, u8p, sz, vp, C.c_uint64, C.c_uint64, C.c_uint64,
+                                               C.c_uint64, sz, C.c_uint32, C.POINTER(vp)]
+    L.sassy_hip_set_geometry_tuner.restype = C.c_int
+    L.sassy_hip_set_geometry_tuner.argtypes = [vp, C.c_int]
+    L.sassy_hip_set_pipe_depth.restype = C.c_int
+    L.sassy_hip_set_pipe_depth.argtypes = [vp, C.c_int]
+    L.sassy_hip_search_finish.restype = C.c_int
+    L.sassy_hip_search_finish.argtypes = [vp, vp, C.POINTER(vp)]
     L.sassy_hip_required_halo.restype = C.c_uint64
     L.sassy_hip_required_halo.argtypes = [sz, sz]
     L.sassy_hip_result_len.restype = sz
@@ -500,6 +510,29 @@ class Searcher:
         _check(lib().sassy_hip_search_shard(self._h, pattern, len(pattern), d_text_ptr, halo_len,
                                             shard_len, global_offset, total_len, k, flags,
                                             C.byref(out)))
+        return Result(out)
+
+    def search_shard_begin(self, pattern: bytes, d_text_ptr: int, halo_len: int, shard_len: int,
+                           global_offset: int, total_len: int, k: int, flags: int = 0) -> int:
+        """Queue one search of a resident shard and return a ticket at once (sassy_hip_search_shard_begin);
+        up to 2 may be in flight.  search_finish(ticket) waits for it and returns its Result."""
+        out = C.c_void_p()
+        pattern = bytes(pattern)
+        _check(lib().sassy_hip_search_shard_begin(self._h, pattern, len(pattern), d_text_ptr, halo_len, shard_len,
+                                                  global_offset, total_len, k, flags, C.byref(out)))
+        return out.value
+
+    def set_geometry_tuner(self, on: bool = True):
+        _check(lib().sassy_hip_set_geometry_tuner(self._h, int(on)))
+        return self
+
+    def set_pipe_depth(self, depth: int):
+        _check(lib().sassy_hip_set_pipe_depth(self._h, int(depth)))
+        return self
+
+    def search_finish(self, ticket: int) -> Result:
+        out = C.c_void_p()
+        _check(lib().sassy_hip_search_finish(self._h, ticket, C.byref(out)))
         return Result(out)
 
     def set_stream(self, hip_stream_handle: int):

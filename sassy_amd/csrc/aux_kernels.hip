@@ -149,32 +149,46 @@ __device__ __forceinline__ bool dilated_bit(const BuildParams& P, uint64_t blk) 
   return (dilated_word(P, (long long)(blk >> 6)) >> (blk & 63)) & 1ull;
 }
 
-// 1024-thread workgroups: the descriptor slots are claimed with ONE atomic per workgroup, and all
-// workgroups hit the same counter, so their number bounds the kernel's duration.
+// 1024-thread workgroups, kBuildWords bitmap words per thread (word j of a thread lies j * 1024 words
+// behind its first one: the loads of a wave stay coalesced).  The descriptor slots are claimed with ONE
+// atomic per workgroup.  What bounds the kernel (23 us for the 5.9 MB bitmap of a 3 GB text) is not the
+// number of those same-address atomics -- 8 words per thread, an eighth of the workgroups and atomics,
+// measured 24 us -- but the latency chain inside a workgroup (bitmap loads, scan, atomic round trip,
+// descriptor stores) at two resident workgroups per CU; one word per thread keeps the most of them in flight.
+// The order of the descriptors does not matter (the list kernels take any lane <-> chunk assignment; the
+// host sorts the chunk table when it needs the seam chain).
 constexpr int kBuildWaves = 16;
+constexpr int kBuildWords = 1;
 __global__ __launch_bounds__(1024) void build_chunks_kernel(const BuildParams P) {
   __shared__ uint32_t wave_sum[kBuildWaves];
   __shared__ uint32_t wave_hits[kBuildWaves];
   __shared__ uint32_t group_base;
-  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  unsigned long long A = 0, prev_top = 0, starts = 0;
-  uint32_t my_hits = 0;
-  if (w < P.n_words) {
-    my_hits = (uint32_t)__popcll(P.hit[w]);
-    A = dilated_word(P, (long long)w);
-    if (A) {
-      prev_top = w > 0 ? (dilated_word(P, (long long)w - 1) >> 63) : 0ull;
-      // maxlen is a power of two >= 64: a cut can only fall on bit 0 of a word
-      const unsigned long long align = ((w * 64) & (uint64_t)(P.maxlen - 1)) == 0 ? 1ull : 0ull;
-      unsigned long long own = ~0ull;  // only blocks >= first_owned are owned (the halo is warm-up)
-      if (w * 64 < P.first_owned) own = (P.first_owned - w * 64 >= 64) ? 0ull : (~0ull << (P.first_owned - w * 64));
-      unsigned long long first_bit = 0;  // the first owned block starts a chunk if it is in A'
-      if (P.first_owned >= w * 64 && P.first_owned < w * 64 + 64) first_bit = 1ull << (P.first_owned - w * 64);
-      starts = A & own & (~((A << 1) | prev_top) | align | first_bit);
+  unsigned long long A[kBuildWords], starts[kBuildWords];
+  uint32_t prev_tops = 0;  // bit j: the block left of word j's first block is in A'
+  uint32_t my_hits = 0, mine = 0;
+#pragma unroll
+  for (int j = 0; j < kBuildWords; ++j) {
+    const uint64_t w = ((uint64_t)blockIdx.x * kBuildWords + j) * blockDim.x + threadIdx.x;
+    A[j] = 0;
+    starts[j] = 0;
+    if (w < P.n_words) {
+      my_hits += (uint32_t)__popcll(P.hit[w]);
+      A[j] = dilated_word(P, (long long)w);
+      if (A[j]) {
+        const unsigned long long prev_top = w > 0 ? (dilated_word(P, (long long)w - 1) >> 63) : 0ull;
+        prev_tops |= (uint32_t)prev_top << j;
+        // maxlen is a power of two >= 64: a cut can only fall on bit 0 of a word
+        const unsigned long long align = ((w * 64) & (uint64_t)(P.maxlen - 1)) == 0 ? 1ull : 0ull;
+        unsigned long long own = ~0ull;  // only blocks >= first_owned are owned (the halo is warm-up)
+        if (w * 64 < P.first_owned) own = (P.first_owned - w * 64 >= 64) ? 0ull : (~0ull << (P.first_owned - w * 64));
+        unsigned long long first_bit = 0;  // the first owned block starts a chunk if it is in A'
+        if (P.first_owned >= w * 64 && P.first_owned < w * 64 + 64) first_bit = 1ull << (P.first_owned - w * 64);
+        starts[j] = A[j] & own & (~((A[j] << 1) | prev_top) | align | first_bit);
+        mine += (uint32_t)__popcll(starts[j]);
+      }
     }
   }
   // one atomic per workgroup: exclusive scan of the per-thread chunk counts
-  const uint32_t mine = (uint32_t)__popcll(starts);
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   uint32_t incl = mine;
 #pragma unroll
@@ -196,41 +210,50 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const BuildParams P)
   uint32_t idx = group_base + (incl - mine);
   for (uint32_t v = 0; v < wv; ++v) idx += wave_sum[v];
 
-  while (starts) {
-    const int i = __ffsll((long long)starts) - 1;
-    starts &= starts - 1;
-    const uint64_t lo = w * 64 + (uint64_t)i;
-    const bool left_in = i > 0 ? ((A >> (i - 1)) & 1ull) : (prev_top != 0);
-    // end of the chunk: first block after lo that is outside A', or the next cut
-    uint64_t j = lo + 1;
-    {
-      unsigned long long rest = (i < 63) ? (A >> (i + 1)) : 0ull;       // A' bits of blocks lo+1 ..
-      int avail = 63 - i;                                               // .. still inside this word
-      uint64_t ww = w;
-      for (;;) {
-        // consecutive A' blocks at the bottom of `rest` (bits past `avail` are zero or ignored)
-        const unsigned long long inv = ~rest;
-        int run = inv ? (__ffsll((long long)inv) - 1) : 64;
-        if (run > avail) run = avail;
-        j += (uint64_t)run;
-        if (run < avail) break;                       // hit a block outside A'
-        ++ww;
-        if (ww * 64 >= P.n_blocks) break;             // end of the buffer
-        if (((ww * 64) & (uint64_t)(P.maxlen - 1)) == 0) break;  // cut at a multiple of maxlen
-        rest = dilated_word(P, (long long)ww);
-        avail = 64;
+#pragma unroll 1
+  for (int j = 0; j < kBuildWords; ++j) {
+    const uint64_t w = ((uint64_t)blockIdx.x * kBuildWords + j) * blockDim.x + threadIdx.x;
+    unsigned long long st = 0, Aj = 0;
+#pragma unroll
+    for (int q = 0; q < kBuildWords; ++q)  // (register arrays: select, do not index)
+      if (q == j) { st = starts[q]; Aj = A[q]; }
+    const bool prev_top = (prev_tops >> j) & 1u;
+    while (st) {
+      const int i = __ffsll((long long)st) - 1;
+      st &= st - 1;
+      const uint64_t lo = w * 64 + (uint64_t)i;
+      const bool left_in = i > 0 ? ((Aj >> (i - 1)) & 1ull) : prev_top;
+      // end of the chunk: first block after lo that is outside A', or the next cut
+      uint64_t e = lo + 1;
+      {
+        unsigned long long rest = (i < 63) ? (Aj >> (i + 1)) : 0ull;      // A' bits of blocks lo+1 ..
+        int avail = 63 - i;                                               // .. still inside this word
+        uint64_t ww = w;
+        for (;;) {
+          // consecutive A' blocks at the bottom of `rest` (bits past `avail` are zero or ignored)
+          const unsigned long long inv = ~rest;
+          int run = inv ? (__ffsll((long long)inv) - 1) : 64;
+          if (run > avail) run = avail;
+          e += (uint64_t)run;
+          if (run < avail) break;                       // hit a block outside A'
+          ++ww;
+          if (ww * 64 >= P.n_blocks) break;             // end of the buffer
+          if (((ww * 64) & (uint64_t)(P.maxlen - 1)) == 0) break;  // cut at a multiple of maxlen
+          rest = dilated_word(P, (long long)ww);
+          avail = 64;
+        }
+        if (e > P.n_blocks) e = P.n_blocks;
       }
-      if (j > P.n_blocks) j = P.n_blocks;
+      if (idx < P.desc_cap) {
+        ChunkDesc d;
+        d.own_lo = (uint32_t)lo;
+        d.own_hi = (uint32_t)e;
+        d.flags = left_in ? 0u : kDescClearBefore;
+        d.pad_ = 0;
+        P.desc[idx] = d;
+      }
+      ++idx;
     }
-    if (idx < P.desc_cap) {
-      ChunkDesc d;
-      d.own_lo = (uint32_t)lo;
-      d.own_hi = (uint32_t)j;
-      d.flags = left_in ? 0u : kDescClearBefore;
-      d.pad_ = 0;
-      P.desc[idx] = d;
-    }
-    ++idx;
   }
 }
 
@@ -441,7 +464,8 @@ hipError_t launch_build_chunks(const unsigned long long* d_hit, uint64_t n_words
   P.hit = d_hit; P.n_words = n_words; P.n_blocks = n_blocks; P.first_owned = first_owned;
   P.wb = wb; P.L = L; P.maxlen = maxlen; P.desc = d_desc; P.desc_count = d_desc_count; P.desc_cap = desc_cap;
   P.hit_count = d_hit_count;
-  hipLaunchKernelGGL(build_chunks_kernel, dim3((uint32_t)((n_words + 1023) / 1024)), dim3(1024), 0, stream, P);
+  const uint64_t per_group = 1024ull * kBuildWords;
+  hipLaunchKernelGGL(build_chunks_kernel, dim3((uint32_t)((n_words + per_group - 1) / per_group)), dim3(1024), 0, stream, P);
   return hipGetLastError();
 }
 

@@ -104,6 +104,7 @@ struct ScanParams {
   // Dna bit-plane filter: per piece, bit j = code bit 0 / code bit 1 of piece row j
   uint32_t piece_planes;      // 1: use filter_dna_kernel (Dna, <= 8 pieces)
   uint32_t lin_steps;         // != 0: filter_dna_linear_kernel, 128-block steps per wave range
+  uint32_t group_offset;      // filter_dna_kernel: first workgroup of this launch (the grid may be split in two launches)
   uint32_t piece_bits[8][2];
   uint32_t piece_rem[8];      // pattern rows behind piece p: a match that contains the piece exactly, ending
                               // at text position e, ends in [e + rem - k, e + rem + k]

@@ -105,6 +105,19 @@ struct sassy_hip_Result {
   int64_t conditional_index = -1;
 };
 
+// One search in flight: everything its ScanJob refers to lives here until sassy_hip_search_finish.
+struct sassy_hip_Ticket {
+  sassy_SearcherType* owner = nullptr;
+  int lane = -1;
+  sassy_hip::PatternPlan plan;
+  std::vector<uint8_t> pat;
+  uint64_t total_len = 0;
+  bool without_trace = false;
+  bool empty_shard = false;
+  double t0 = 0;
+  std::shared_ptr<void> job;     // the ScanJob (defined below)
+};
+
 struct sassy_hip_Encoded {
   Profile profile;
   bool rc;
@@ -309,12 +322,18 @@ struct sassy_SearcherType {
 
   bool want_counters = false;
   int prefilter = -1;            // sassy_hip_set_prefilter: -1 process default, 0 never, 1 also with short pieces
+  // searches in flight (sassy_hip_search_shard_begin / sassy_hip_search_finish): the ticket that owns each lane
+  struct sassy_hip_Ticket* lane_ticket[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
+  int last_begun_lane = -1;
+  int pipe_depth = getenv("SASSY_HIP_PIPE_DEPTH") ? std::max(1, std::min(atoi(getenv("SASSY_HIP_PIPE_DEPTH")), kMaxLanes)) : 2;
   // reporting modes of the reference's Searcher (src/search.rs:442-475)
   float alpha = NAN;             // overhang cost per pattern character (NaN = no overhang), Iupac only
   long max_overhang = -1;        // with_max_overhang(): -1 = none
   bool only_best = false;        // only_best_match(): one match per strand, minimal cost, rightmost end
   float max_n_frac = NAN;        // with_max_n_frac(): NaN = off (the reference's None)
   GeoTuner tuner, tuner_scan;    // prefilter / streaming-DP geometry per resident text
+  // the on-line geometry tuner is opt-in (sassy_hip_set_geometry_tuner, SASSY_HIP_TUNE=1): see stream_geometry
+  bool tune = getenv("SASSY_HIP_TUNE") != nullptr && atoi(getenv("SASSY_HIP_TUNE")) != 0;
   DevBuf<uint64_t> d_tables;     // multi-text buffers: start / len tables (both strands)
   DevBuf<unsigned long long> d_multi_bitmap;  // multi-pattern prefilter: one hit bitmap per pattern of the batch
   DevBuf<uint32_t> d_multi_bits;
@@ -328,6 +347,9 @@ struct sassy_SearcherType {
   sassy_hip_Stats stats{};
 
   ~sassy_SearcherType() {
+    for (ScanLane& l : lanes)  // searches still in flight (tickets never finished): let their kernels drain
+      if (l.stream) (void)hipStreamSynchronize(l.stream);
+    for (sassy_hip_Ticket*& t : lane_ticket) { delete t; t = nullptr; }
     d_text.release(); d_rev.release(); d_rc_bitmap.release();
     free_stage();
     d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
@@ -564,9 +586,12 @@ static int stream_geometry(ScanParams& P, uint64_t owned, uint32_t extra_front, 
   // neighbouring even values during the first searches of a resident text and keeps the fastest;
   // SASSY_HIP_BPL=<n> fixes the value, SASSY_HIP_TUNE=0 keeps the default.
   static const char* env_bpl = getenv("SASSY_HIP_BPL");
-  static const bool env_tune = getenv("SASSY_HIP_TUNE") == nullptr || atoi(getenv("SASSY_HIP_TUNE")) != 0;
+  // (opt-in since round 2: with two searches in flight -- the way a stream of searches runs -- the geometry
+  // moves the time per search by 0-2 %; it still matters for the latency of a lone search at unlucky sizes,
+  // 2.7 GB: 0.80 -> 0.72 ms, which is what SASSY_HIP_TUNE=1 is for; profiles/r02_geometry_sweep.txt)
+  // (the callers pass a tuner only when the searcher asks for one: sassy_hip_set_geometry_tuner / SASSY_HIP_TUNE=1)
   if (env_bpl != nullptr && atoll(env_bpl) > 0) bpl = (uint64_t)atoll(env_bpl);
-  else if (tuner != nullptr && env_tune && env_wpc == 0 && owned * 64 >= (256ull << 20)) {
+  else if (tuner != nullptr && env_wpc == 0 && owned * 64 >= (256ull << 20)) {
     const uint32_t t = tuner->next(tune_text, tune_len, owned, tune_kind, extra_front, (uint32_t)bpl, (uint32_t)(min_bpl + (min_bpl & 1)));
     if (t) bpl = t;
   }
@@ -619,6 +644,9 @@ struct ScanJob {
   uint64_t rev_n = 0;
   hipEvent_t wait_for = nullptr;     // pipelining: the previous sub-shard's "filter done"
   bool signal_filter_done = false;   // pipelining: record L.ev_filter_done behind this filter
+  bool pipelined = false;            // one of several searches in flight (sassy_hip_search_shard_begin): the
+                                     // bit-plane filter takes only half of a CU's wave slots, so that the previous
+                                     // search's small tail kernels find room next to it
 
   static constexpr size_t kCtlHead = 64 + 4 * (size_t)kRankLimit;
   static constexpr uint32_t kTraceWaveMax = 8192;
@@ -932,7 +960,7 @@ int ScanJob::prepare() {
   F = P;           // prefilter launch
   fgrid = 0;
   if (!filtered) {
-    tuned = S->timing >= 1 && !ext_desc;  // (level 1 times the streaming DP when there is no filter)
+    tuned = S->tune && S->timing >= 1 && !ext_desc;  // (level 1 times the streaming DP when there is no filter)
     if (int rc = stream_geometry(P, owned, P.wb, &grid, 16, tuned ? &S->tuner_scan : nullptr, sh.d_text, sh.text_len,
                                  1000u + plan.nwords)) return rc;
     P.lds_per_wave = 4096u * P.stage_blocks + bucket * 512u + plan.nwords * 512u;
@@ -1020,11 +1048,23 @@ int ScanJob::prepare() {
       extra_front = count_w + 1;
     }
     // (timing level >= 1 records the two events around the filter: that is what the tuner learns from)
-    tuned = S->timing >= 1 && !ext_bitmap && !ext_desc;
+    tuned = S->tune && S->timing >= 1 && !ext_bitmap && !ext_desc;
     if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, extra_front, &fgrid, fwpc, tuned ? &S->tuner : nullptr,
                                  sh.d_text, sh.text_len, (uint32_t)fkind * 16u + (rc_marked ? 1u : 0u))) return rc;
     F.lds_per_wave = 4096u * F.stage_blocks + (F.piece_planes ? 0u : 2u * bucket * 512u);
     if (fkind == kFilterCount) F.lds_per_wave = 4096u * F.stage_blocks + 64u * count_w;
+    {
+      // Searches in flight on several lanes: the filter's long-lived workgroups would fill every CU (4 waves
+      // per SIMD x 112 VGPRs leave no room for a list / traceback wave), and the previous search's tail
+      // kernels would only run in the gaps between filter rounds.  Asking for 56 KB of LDS per workgroup
+      // caps the filter at 2 workgroups = 8 waves per CU: two filters in flight still fill the chip, and a
+      // tail kernel always finds registers, LDS and wave slots (measured, 3 GB, two searches in flight:
+      // 0.63 -> 0.585 ms per search; one search alone: 0.745 -> 0.80 ms, hence only when pipelined).
+      // SASSY_HIP_FILTER_LDS_PAD=<bytes per workgroup> overrides (0 = none).
+      static const int env_pad = getenv("SASSY_HIP_FILTER_LDS_PAD") ? atoi(getenv("SASSY_HIP_FILTER_LDS_PAD")) : -1;
+      const uint32_t pad = env_pad >= 0 ? (uint32_t)env_pad : (pipelined ? 24u * 1024u : 0u);
+      if (fkind == kFilterPlanes && pad) F.lds_per_wave += pad / 4u / 16u * 16u;
+    }
     // the bit-plane filter as a linear stream (filter_dna_linear_kernel): every wave owns one contiguous
     // range of 128-block steps; SASSY_HIP_FILTER_LINEAR=<waves> sets how many waves the text is cut into
     F.lin_steps = 0;
@@ -2105,6 +2145,21 @@ int sassy_hip_set_prefilter(sassy_SearcherType* s, int mode) {
   return 0;
 }
 
+int sassy_hip_set_geometry_tuner(sassy_SearcherType* s, int on) {
+  if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
+  s->tune = on != 0;
+  return 0;
+}
+
+int sassy_hip_set_pipe_depth(sassy_SearcherType* s, int depth) {
+  if (!s || depth < 1 || depth > kMaxLanes) return fail(SASSY_HIP_EINVAL, "pipe depth must be 1 .. 4");
+  for (sassy_hip_Ticket* t : s->lane_ticket)
+    if (t) return fail(SASSY_HIP_EINVAL, "searches are in flight");
+  s->pipe_depth = depth;
+  s->last_begun_lane = -1;
+  return 0;
+}
+
 int sassy_hip_set_timing(sassy_SearcherType* s, int level) {
   if (!s || level < 0 || level > 2) return fail(SASSY_HIP_EINVAL, "timing level must be 0, 1 or 2");
   s->timing = level;
@@ -2590,6 +2645,98 @@ int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t
   s->stats.total_ms = now_ms() - t0;
   s->stats.host_post_ms = s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms;
   *out = R;
+  return 0;
+}
+
+// ---- searches in flight: begin / finish ----
+// A stream of searches over a resident text (many patterns against one genome) is pipelined on the device:
+// up to SASSY_HIP_PIPE_DEPTH (default 2, at most 4) searches are in flight, each on a lane (stream + buffers)
+// of its own.  begin() queues the whole kernel chain of one search and returns at once; the filter of
+// search i+1 starts when the filter of search i is done, so that the short, latency-bound tail of search i
+// (chunk list, chunk DP, traceback) runs underneath the bandwidth-bound filter of search i+1.
+int sassy_hip_search_shard_begin(sassy_SearcherType* s, const uint8_t* pattern, size_t pattern_len,
+                                 const uint8_t* d_text, uint64_t halo_len, uint64_t shard_len,
+                                 uint64_t global_offset, uint64_t total_len, size_t k, uint32_t flags,
+                                 sassy_hip_Ticket** out) {
+  if (!s || !pattern || !d_text || !out) return fail(SASSY_HIP_EINVAL, "null argument");
+  if (halo_len % 64 || global_offset % 64) return fail(SASSY_HIP_EINVAL, "halo_len and global_offset must be multiples of 64");
+  if (global_offset < halo_len) return fail(SASSY_HIP_EINVAL, "halo reaches left of the text start");
+  if (global_offset + shard_len > total_len) return fail(SASSY_HIP_EINVAL, "shard exceeds the text");
+  const bool is_first = global_offset == 0, is_last = global_offset + shard_len == total_len;
+  if (!is_last && shard_len % 64) return fail(SASSY_HIP_EINVAL, "inner shard lengths must be multiples of 64");
+  if (!is_first && halo_len < sassy_hip_required_halo(pattern_len, k)) return fail(SASSY_HIP_EINVAL, "halo too short");
+  if (((uintptr_t)d_text & 15) != 0) return fail(SASSY_HIP_EINVAL, "device text pointer must be 16-byte aligned");
+  if (k > 0x7FFFFFFFu) return fail(SASSY_HIP_EINVAL, "k too large");
+  const int depth = s->pipe_depth;
+  int lane = -1;
+  for (int l = 0; l < depth; ++l)
+    if (!s->lane_ticket[(s->last_begun_lane + 1 + l) % depth]) { lane = (s->last_begun_lane + 1 + l) % depth; break; }
+  if (lane < 0) return fail(SASSY_HIP_EINVAL, "too many searches in flight: finish one first (SASSY_HIP_PIPE_DEPTH)");
+  std::unique_ptr<sassy_hip_Ticket> t(new sassy_hip_Ticket());
+  std::string err;
+  if (!make_plan(s->profile, pattern, pattern_len, t->plan, err)) return fail(SASSY_HIP_EINVAL, err);
+  if (int rc = s->ensure_device()) return rc;
+  t->owner = s;
+  t->lane = lane;
+  t->pat.assign(pattern, pattern + pattern_len);
+  t->total_len = total_len;
+  t->without_trace = (flags & SASSY_HIP_WITHOUT_TRACE) != 0;
+  t->t0 = now_ms();
+  t->empty_shard = shard_len == 0;
+  if (!t->empty_shard) {
+    ShardView sh{d_text, halo_len + shard_len, halo_len, global_offset - halo_len, is_first && halo_len == 0, is_last};
+    auto job = std::make_shared<ScanJob>(s, s->lanes[lane], sh, t->plan, (uint32_t)k, (flags & SASSY_HIP_ALL_MINIMA) != 0,
+                                         t->pat.data(), !t->without_trace, total_len);
+    job->pipelined = depth > 1;
+    job->signal_filter_done = true;
+    // The searches in flight run freely side by side.  Two alternatives were measured and dropped (3 GB, two
+    // searches in flight, 0.585 ms per search as it is): every filter waiting for the END of the previous one
+    // (SASSY_HIP_PIPE_CHAIN=1, kept as a switch: 0.64 -- the filters of two searches fill each other's ramp-up and
+    // drain, a strict sequence leaves those bubbles), and the filter as two half launches with the next search
+    // waiting for the event in between (0.65).  Holding back a search that is begun right behind another one
+    // (device-side delay) changed nothing either: the slower first ~20 searches of a stream (0.67 ms) are the
+    // device's clocks coming up, not the phase of the two searches -- 50 searches of any kind in front remove it.
+    static const bool env_chain = getenv("SASSY_HIP_PIPE_CHAIN") && atoi(getenv("SASSY_HIP_PIPE_CHAIN")) != 0;
+    const int prev = s->last_begun_lane;
+    if (env_chain && prev >= 0 && prev != lane && s->lane_ticket[prev] && s->lane_ticket[prev]->job) {
+      ScanJob* pj = static_cast<ScanJob*>(s->lane_ticket[prev]->job.get());
+      if (pj->filtered && !pj->empty && !pj->ext_bitmap && !pj->ext_desc) job->wait_for = s->lanes[prev].ev_filter_done;
+    }
+    int rc = job->prepare();
+    if (rc == 0 && !job->empty) rc = job->enqueue(0);
+    if (rc != 0) {
+      (void)hipStreamSynchronize(s->lanes[lane].stream);
+      return rc;
+    }
+    t->job = job;
+  }
+  s->lane_ticket[lane] = t.get();
+  s->last_begun_lane = lane;
+  *out = t.release();
+  return 0;
+}
+
+int sassy_hip_search_finish(sassy_SearcherType* s, sassy_hip_Ticket* t, sassy_hip_Result** out) {
+  if (!s || !t || t->owner != s) return fail(SASSY_HIP_EINVAL, "not a ticket of this searcher");
+  std::unique_ptr<sassy_hip_Ticket> guard(t);
+  s->lane_ticket[t->lane] = nullptr;
+  reset_stats(s);
+  std::unique_ptr<sassy_hip_Result> R(new sassy_hip_Result());
+  if (t->job) {
+    ScanJob* job = static_cast<ScanJob*>(t->job.get());
+    ScanOut so;
+    if (int rc = job->finish(so)) return rc;
+    if (out) {
+      size_t first = 0;
+      if (int rc = append_matches(so, t->total_len, t->plan, t->without_trace, 0, R.get(), first)) return rc;
+      R->exit_state = so.exit_state;
+      R->conditional_index = so.conditional_index;
+    }
+  }
+  if (R->pool.empty()) R->pool.push_back('\0');
+  s->stats.total_ms = now_ms() - t->t0;
+  s->stats.host_post_ms = std::max(0.0, s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms);
+  if (out) *out = R.release();
   return 0;
 }
 

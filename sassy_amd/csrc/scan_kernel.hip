@@ -35,6 +35,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -232,6 +233,34 @@ __device__ __forceinline__ uint4 load_text16(const ScanParams& P, uint64_t off) 
     return make_uint4(__builtin_bswap32(v.w), __builtin_bswap32(v.z), __builtin_bswap32(v.y), __builtin_bswap32(v.x));
   }
   return load_tail16_rev(P.text, off, P.rev_n);
+}
+
+// The 64 text bytes of block `blk` for a lane of the list kernels (lanes with on = false get 'X').  The
+// lanes of a wave read blocks that lie far apart in a multi-GB buffer: every load is a TLB miss plus an
+// HBM miss, microseconds, and a list kernel has only a few waves per SIMD to hide them behind.  So the
+// common case -- forward text, block inside the buffer, for every lane of the wave -- is four loads in
+// ONE basic block: they are issued back to back and waited for once, where they are used (the caller
+// fetches one block ahead).  A wave with a lane at the buffer's tail, and the Rc strand's backwards
+// reads, take the general path chunk by chunk.
+__device__ __forceinline__ void fetch_block(const ScanParams& P, bool on, uint64_t blk, uint32_t (&dst)[16]) {
+  const uint64_t off = blk * 64;
+  const bool plain = P.rev_n == 0 && off + 64 <= P.text_len;
+  uint4 v0 = make_uint4(0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u), v1 = v0, v2 = v0, v3 = v0;
+  if (__all(!on || plain)) {  // wave-uniform
+    if (on) {
+      const uint4* p = reinterpret_cast<const uint4*>(P.text + off);
+      v0 = p[0]; v1 = p[1]; v2 = p[2]; v3 = p[3];
+    }
+  } else if (on) {
+    v0 = load_text16(P, off);
+    v1 = load_text16(P, off + 16);
+    v2 = load_text16(P, off + 32);
+    v3 = load_text16(P, off + 48);
+  }
+  dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w;
+  dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
+  dst[8] = v2.x; dst[9] = v2.y; dst[10] = v2.z; dst[11] = v2.w;
+  dst[12] = v3.x; dst[13] = v3.y; dst[14] = v3.z; dst[15] = v3.w;
 }
 
 // ------------------------------------------------------------------ the profile, lane-parallel
@@ -900,7 +929,7 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
   const uint32_t wave = threadIdx.x >> 6;
   unsigned char* tile = smem + (size_t)wave * P.lds_per_wave;
 
-  const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * kWavesPerGroup + wave) * kWave;
+  const uint64_t wave_chunk0 = (((uint64_t)blockIdx.x + P.group_offset) * kWavesPerGroup + wave) * kWave;
   if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
   const uint64_t chunk = wave_chunk0 + lane;
   const uint32_t bpl = P.bpl;
@@ -1544,48 +1573,63 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
 
   // the lane's next block is fetched while this one is computed (two or three waves per SIMD do not
   // hide a load that is issued and consumed in the same iteration)
-  auto fetch = [&](uint32_t step, uint32_t (&dst)[16]) {
-    const bool on = step < my_iters;
-    const uint64_t blk = blk0 + step;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const uint64_t off = blk * 64 + (uint64_t)c * 16;
-      uint4 v = make_uint4(0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u);
-      if (on) v = load_text16(P, off);
-      dst[4 * c] = v.x; dst[4 * c + 1] = v.y; dst[4 * c + 2] = v.z; dst[4 * c + 3] = v.w;
-    }
-  };
-  uint32_t xn[16];
-  fetch(0, xn);
-  for (uint32_t it = 0; __any(it < my_iters); ++it) {
-    const bool active = it < my_iters;
-    const uint64_t b = blk0 + it;
-    uint32_t x[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) x[c] = xn[c];
-    fetch(it + 1, xn);
-    {
-      uint2 msk[NS];
-      build_masks<PROFILE, NS>(x, P, msk);
-#pragma unroll
-      for (int s = 0; s < NS; ++s) *reinterpret_cast<uint2*>(mask_bytes + s * 512 + lane * 8) = msk[s];
-    }
-    if ((it & 7u) == 7u && first_rows > 8u && first_rows <= m) first_rows -= 4u;
-    DpWord V;
-    int ds;
-    const bool ran_through = dp_block(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
-                                      !active, first_rows, minus_total, m, P.counters != nullptr && active, cnt_rows);
-    if (active) {
-      if (P.counters) cnt_blocks += 1;
-      if (ran_through && row_maybe_live(ds, V, k)) {
-        const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
-        if (P.counters) cnt_live += 1;
-        st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
+  // Two copies of the block loop, chosen once per wave.  FAST: every block of every lane's chunk lies
+  // whole inside a forward buffer, so the four 16-byte loads of the next block are unconditional,
+  // straight-line code (idle lanes re-read their chunk's first block) and nothing waits for them until
+  // the next iteration uses them: one TLB + HBM miss latency per block, hidden behind the DP of the
+  // current block.  Otherwise (buffer tail, Rc strand read backwards, tiny texts) the general fetch.
+  const bool lane_plain = !has_chunk || (P.rev_n == 0 && own_hi * 64 <= P.text_len);
+  const bool fast_wave = __all(lane_plain) && P.text_len >= 64;
+  auto run = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    auto fetch = [&](uint32_t step, uint32_t (&dst)[16]) {
+      const bool on = step < my_iters;
+      if constexpr (FAST) {
+        const uint64_t blk = on ? blk0 + step : (has_chunk ? blk0 : 0);
+        const uint4* p = reinterpret_cast<const uint4*>(P.text + blk * 64);
+        const uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w;
+        dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
+        dst[8] = v2.x; dst[9] = v2.y; dst[10] = v2.z; dst[11] = v2.w;
+        dst[12] = v3.x; dst[13] = v3.y; dst[14] = v3.z; dst[15] = v3.w;
       } else {
-        st = kStDec;
+        fetch_block(P, on, blk0 + step, dst);
+      }
+    };
+    uint32_t xn[16];
+    fetch(0, xn);
+    for (uint32_t it = 0; __any(it < my_iters); ++it) {
+      const bool active = it < my_iters;
+      const uint64_t b = blk0 + it;
+      uint32_t x[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x[c] = xn[c];
+      fetch(it + 1, xn);
+      {
+        uint2 msk[NS];
+        build_masks<PROFILE, NS>(x, P, msk);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) *reinterpret_cast<uint2*>(mask_bytes + s * 512 + lane * 8) = msk[s];
+      }
+      if ((it & 7u) == 7u && first_rows > 8u && first_rows <= m) first_rows -= 4u;
+      DpWord V;
+      int ds;
+      const bool ran_through = dp_block(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
+                                        !active, first_rows, minus_total, m, P.counters != nullptr && active, cnt_rows);
+      if (active) {
+        if (P.counters) cnt_blocks += 1;
+        if (ran_through && row_maybe_live(ds, V, k)) {
+          const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
+          if (P.counters) cnt_live += 1;
+          st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
+        } else {
+          st = kStDec;
+        }
       }
     }
-  }
+  };
+  if (fast_wave) run(std::true_type{});
+  else run(std::false_type{});
   if (has_chunk) {
     const uint32_t fin = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
     P.chunk_state[di] = (uint8_t)fin;
@@ -1679,13 +1723,7 @@ __global__ __launch_bounds__(256) void list_words_kernel(const ScanParams P) {
   auto fetch = [&](uint32_t step, uint32_t (&dst)[16]) {
     const bool on = has_chunk && step >= w && step - w < my_iters;
     const uint64_t blk = blk0 + (uint64_t)(step - w);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const uint64_t off = blk * 64 + (uint64_t)c * 16;
-      uint4 v = make_uint4(0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u);
-      if (on) v = load_text16(P, off);
-      dst[4 * c] = v.x; dst[4 * c + 1] = v.y; dst[4 * c + 2] = v.z; dst[4 * c + 3] = v.w;
-    }
+    fetch_block(P, on, blk, dst);
   };
   uint32_t xn[16];
   fetch(0, xn);

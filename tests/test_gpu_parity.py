@@ -1246,14 +1246,14 @@ def test_text_beyond_4gib_both_strands(sassy):
 
 @pytest.mark.parametrize("profile,k", [("dna", 3), ("iupac", 3), ("dna", 8)])
 def test_geometry_tuner_trials_are_exact(sassy, profile, k):
-    """The library tries ~20 lane-chunk lengths on a resident text during its first searches (GeoTuner):
+    """With the (opt-in) geometry tuner the library tries ~20 lane-chunk lengths on a resident text during its first searches:
     every trial must return the same matches (bit-plane filter, counting filter, streaming DP at k = 8)."""
     n = 300_000_000
     buf = sassy.DeviceBuffer(n + 4096)
     sassy.generate_dna(buf.ptr, n, 42, 0)
     pat = bytes(oracle.generate_dna(43, 0, 32))
     planted = sassy.plant(buf.ptr, n, 0, n, 42, pat, 3, stride=1 << 20)
-    s = sassy.Searcher(profile, rc=False)
+    s = sassy.Searcher(profile, rc=False).set_geometry_tuner(True)
     first = None
     for it in range(45):
         r = s.search_shard(pat, buf.ptr, 0, n, 0, n, k)
@@ -1325,6 +1325,63 @@ def test_dna_profile_text_with_other_letters(sassy):
             ends = oracle.find_ends(oracle.last_row("dna", pat, text), k)
             assert [(x.text_end, x.cost) for x in wo if x.strand == "+"] == ends, (case, rc)
     assert outcomes["same"] >= 30 and outcomes["both_fail"] >= 10, outcomes
+
+
+# ------------------------------------------------------------------ searches in flight
+def test_searches_in_flight_begin_finish(sassy):
+    """sassy_hip_search_shard_begin / sassy_hip_search_finish: two searches in flight on one searcher give
+    exactly the results of the one-at-a-time calls (different patterns, different k, shards with halos,
+    finished in either order), a third begin is refused, a NULL result pointer discards, and a searcher
+    can be freed with a ticket still open."""
+    rng = random.Random(5)
+    n = (1 << 22) + 777
+    pats = [bytes(oracle.generate_dna(43 + i, 0, m)) for i, m in enumerate([32, 20, 32, 64, 48, 24])]
+    ks = [3, 1, 2, 5, 3, 2]
+    text = bytearray(oracle.generate_dna(42, 0, n).tobytes())
+    for p, k in zip(pats, ks):
+        for _ in range(40):
+            ins = mutate(rng, p, rng.randrange(0, k + 1))
+            at = rng.randrange(0, n - 100)
+            text[at:at + len(ins)] = ins
+    buf = sassy.DeviceBuffer(n + 256)
+    buf.upload(bytes(text[:n]))
+    s = sassy.Searcher("dna", rc=False)
+    ref = sassy.Searcher("dna", rc=False)
+    want = [ref.search_shard(p, buf.ptr, 0, n, 0, n, k).matches for p, k in zip(pats, ks)]
+    assert all(len(w) > 20 for w in want[:3])
+    # a stream of searches, two in flight, finished oldest first
+    got, pending = [], []
+    for p, k in zip(pats, ks):
+        pending.append(s.search_shard_begin(p, buf.ptr, 0, n, 0, n, k))
+        if len(pending) == 2:
+            got.append(s.search_finish(pending.pop(0)).matches)
+    while pending:
+        got.append(s.search_finish(pending.pop(0)).matches)
+    for g, w in zip(got, want):
+        assert_same(g, w)
+    # newest first, and shards with halos
+    halo = sassy.required_halo(64, 5)
+    a = 1 << 21
+    t1 = s.search_shard_begin(pats[0], buf.ptr, 0, a, 0, n, 3)
+    t2 = s.search_shard_begin(pats[3], buf.ptr + a - halo, halo, n - a, a, n, 5)
+    with pytest.raises(sassy.SassyHipError, match="in flight"):
+        s.search_shard_begin(pats[1], buf.ptr, 0, n, 0, n, 1)
+    r2 = s.search_finish(t2)
+    r1 = s.search_finish(t1)
+    assert_same(r1.matches, ref.search_shard(pats[0], buf.ptr, 0, a, 0, n, 3).matches)
+    assert_same(r2.matches, ref.search_shard(pats[3], buf.ptr + a - halo, halo, n - a, a, n, 5).matches)
+    assert (r2.exit_state, r2.conditional_index) == (1, -1)
+    # discard, then the lane is free again; one-at-a-time calls still work on the same searcher
+    L = sassy.lib()
+    t = s.search_shard_begin(pats[2], buf.ptr, 0, n, 0, n, 2)
+    assert L.sassy_hip_search_finish(s._h, t, None) == 0
+    assert_same(s.search_shard(pats[2], buf.ptr, 0, n, 0, n, 2).matches, want[2])
+    # a searcher freed with a ticket still open
+    s2 = sassy.Searcher("dna", rc=False)
+    s2.search_shard_begin(pats[0], buf.ptr, 0, n, 0, n, 3)
+    del s2
+    assert_same(s.search_shard(pats[0], buf.ptr, 0, n, 0, n, 3).matches, want[0])
+    buf.free()
 
 
 # ------------------------------------------------------------------ N > 1 on one GPU
