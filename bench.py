@@ -43,8 +43,9 @@ def cpu_baseline(host_text, pat, k, profile, gpu_ends, min_seconds):
 
     n = host_text.size
     cores = os.cpu_count() or 1
+    usable, why = usable_cpus()
     oracle.lib()  # build / load outside the timed region
-    ends, info = oracle.refstyle_ends_mt(profile, pat, host_text, k, cores, min_seconds)
+    ends, info = oracle.refstyle_ends_mt(profile, pat, host_text, k, usable, min_seconds)
     T = info["shards"]
     gbps = n * info["passes"] / info["seconds"] / 1e9
     # single thread, one search call, on a 2^28-byte slice (comparable to the reference's
@@ -60,7 +61,8 @@ def cpu_baseline(host_text, pat, k, profile, gpu_ends, min_seconds):
         "cores": T,
         "kind": "port",
         "sample": f"{info['passes']} passes ({info['seconds']:.2f} s wall) over the full {n} byte text of this run, "
-                  f"{T} persistent pthreads inside liboracle.so, one shard each with m+k+1 bytes of overlap (whole "
+                  f"{T} persistent pthreads (= the CPUs this container may use: {why}; the host has {cores} hardware threads) "
+                  f"inside liboracle.so, one shard each with m+k+1 bytes of overlap (whole "
                   f"blocks), clock between two barriers (oracle/sassy_refstyle.c rs_scan_mt, gcc -O3 -mavx2 -mbmi2, "
                   f"4x u64 lanes)",
         "single_thread_gbps": round(single, 3),
@@ -68,8 +70,40 @@ def cpu_baseline(host_text, pat, k, profile, gpu_ends, min_seconds):
         "parallel_efficiency": round(gbps / T / single, 3) if single > 0 else None,
         "cpu_seconds": round(info["busy_seconds"], 2),
         "host_cpus": cores,
+        "usable_cpus": usable,
+        "usable_cpus_source": why,
         "ends_equal_gpu": ends == gpu_ends,
     }
+
+
+def usable_cpus():
+    """The CPUs this process may really use: the machine's count, cut down by the affinity mask and by the
+    container's cgroup CPU quota (a 256-thread host that grants 16 CPUs runs 256 busy threads at 1/16 speed
+    each: the baseline would time the scheduler, not the scan)."""
+    n = os.cpu_count() or 1
+    why = "os.cpu_count()"
+    try:
+        aff = len(os.sched_getaffinity(0))
+        if aff < n:
+            n, why = aff, "sched_getaffinity"
+    except (AttributeError, OSError):
+        pass
+    quota = None
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            quota = float(txt[0]) / float(txt[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p_
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, why = max(1, int(quota + 0.5)), f"cgroup cpu quota ({quota:g} CPUs)"
+    return n, why
 
 
 def self_launch(args):

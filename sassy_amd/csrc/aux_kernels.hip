@@ -149,110 +149,140 @@ __device__ __forceinline__ bool dilated_bit(const BuildParams& P, uint64_t blk) 
   return (dilated_word(P, (long long)(blk >> 6)) >> (blk & 63)) & 1ull;
 }
 
-// 1024-thread workgroups, kBuildWords bitmap words per thread (word j of a thread lies j * 1024 words
-// behind its first one: the loads of a wave stay coalesced).  The descriptor slots are claimed with ONE
+// 1024-thread workgroups, one bitmap word (64 blocks) per thread.  The descriptor slots are claimed with ONE
 // atomic per workgroup.  What bounds the kernel (23 us for the 5.9 MB bitmap of a 3 GB text) is not the
 // number of those same-address atomics -- 8 words per thread, an eighth of the workgroups and atomics,
 // measured 24 us -- but the latency chain inside a workgroup (bitmap loads, scan, atomic round trip,
-// descriptor stores) at two resident workgroups per CU; one word per thread keeps the most of them in flight.
-// The order of the descriptors does not matter (the list kernels take any lane <-> chunk assignment; the
-// host sorts the chunk table when it needs the seam chain).
+// descriptor stores) at two resident workgroups per CU.
+//
+// Inside its slot range a workgroup files its chunks BY LENGTH (block visits of the lane that will walk the
+// chunk: owned blocks + warm-up; classes 1 .. 7 and "8 or more"): a wave of the list kernel takes 64
+// consecutive descriptors and runs as long as its longest chunk, so mixing a 6-block chunk among 2-block
+// chunks makes 63 lanes idle for two thirds of the wave's life (config 4: average 2.7 block visits per chunk,
+// 5 per wave).  The order of the descriptors is otherwise free (the list kernels take any lane <-> chunk
+// assignment; the host sorts the chunk table when it needs the seam chain).
 constexpr int kBuildWaves = 16;
-constexpr int kBuildWords = 1;
+constexpr int kLenClasses = 8;
+
+// end (one past the last block) of the chunk that starts at bit i of word w
+__device__ __forceinline__ uint64_t chunk_end(const BuildParams& P, uint64_t w, unsigned long long Aw, int i) {
+  uint64_t e = w * 64 + (uint64_t)i + 1;
+  unsigned long long rest = (i < 63) ? (Aw >> (i + 1)) : 0ull;      // A' bits of the blocks behind the start ..
+  int avail = 63 - i;                                               // .. still inside this word
+  uint64_t ww = w;
+  for (;;) {
+    // consecutive A' blocks at the bottom of `rest` (bits past `avail` are zero or ignored)
+    const unsigned long long inv = ~rest;
+    int run = inv ? (__ffsll((long long)inv) - 1) : 64;
+    if (run > avail) run = avail;
+    e += (uint64_t)run;
+    if (run < avail) break;                       // hit a block outside A'
+    ++ww;
+    if (ww * 64 >= P.n_blocks) break;             // end of the buffer
+    if (((ww * 64) & (uint64_t)(P.maxlen - 1)) == 0) break;  // cut at a multiple of maxlen
+    rest = dilated_word(P, (long long)ww);
+    avail = 64;
+  }
+  return e > P.n_blocks ? P.n_blocks : e;
+}
+
 __global__ __launch_bounds__(1024) void build_chunks_kernel(const BuildParams P) {
-  __shared__ uint32_t wave_sum[kBuildWaves];
+  __shared__ unsigned long long wave_cnt[kBuildWaves][2];  // per wave: chunks per length class, 16 bits each
   __shared__ uint32_t wave_hits[kBuildWaves];
-  __shared__ uint32_t group_base;
-  unsigned long long A[kBuildWords], starts[kBuildWords];
-  uint32_t prev_tops = 0;  // bit j: the block left of word j's first block is in A'
-  uint32_t my_hits = 0, mine = 0;
-#pragma unroll
-  for (int j = 0; j < kBuildWords; ++j) {
-    const uint64_t w = ((uint64_t)blockIdx.x * kBuildWords + j) * blockDim.x + threadIdx.x;
-    A[j] = 0;
-    starts[j] = 0;
-    if (w < P.n_words) {
-      my_hits += (uint32_t)__popcll(P.hit[w]);
-      A[j] = dilated_word(P, (long long)w);
-      if (A[j]) {
-        const unsigned long long prev_top = w > 0 ? (dilated_word(P, (long long)w - 1) >> 63) : 0ull;
-        prev_tops |= (uint32_t)prev_top << j;
-        // maxlen is a power of two >= 64: a cut can only fall on bit 0 of a word
-        const unsigned long long align = ((w * 64) & (uint64_t)(P.maxlen - 1)) == 0 ? 1ull : 0ull;
-        unsigned long long own = ~0ull;  // only blocks >= first_owned are owned (the halo is warm-up)
-        if (w * 64 < P.first_owned) own = (P.first_owned - w * 64 >= 64) ? 0ull : (~0ull << (P.first_owned - w * 64));
-        unsigned long long first_bit = 0;  // the first owned block starts a chunk if it is in A'
-        if (P.first_owned >= w * 64 && P.first_owned < w * 64 + 64) first_bit = 1ull << (P.first_owned - w * 64);
-        starts[j] = A[j] & own & (~((A[j] << 1) | prev_top) | align | first_bit);
-        mine += (uint32_t)__popcll(starts[j]);
-      }
+  __shared__ uint32_t class_base[kLenClasses];             // first slot of each class inside the group's range
+  const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long A = 0, starts = 0;
+  bool prev_top = false;
+  uint32_t my_hits = 0;
+  unsigned long long cnt0 = 0, cnt1 = 0;  // this thread's chunks per class (classes 0-3 | 4-7), 16-bit fields
+  if (w < P.n_words) {
+    my_hits = (uint32_t)__popcll(P.hit[w]);
+    A = dilated_word(P, (long long)w);
+    if (A) {
+      prev_top = w > 0 ? ((dilated_word(P, (long long)w - 1) >> 63) != 0) : false;
+      // maxlen is a power of two >= 64: a cut can only fall on bit 0 of a word
+      const unsigned long long align = ((w * 64) & (uint64_t)(P.maxlen - 1)) == 0 ? 1ull : 0ull;
+      unsigned long long own = ~0ull;  // only blocks >= first_owned are owned (the halo is warm-up)
+      if (w * 64 < P.first_owned) own = (P.first_owned - w * 64 >= 64) ? 0ull : (~0ull << (P.first_owned - w * 64));
+      unsigned long long first_bit = 0;  // the first owned block starts a chunk if it is in A'
+      if (P.first_owned >= w * 64 && P.first_owned < w * 64 + 64) first_bit = 1ull << (P.first_owned - w * 64);
+      starts = A & own & (~((A << 1) | (prev_top ? 1ull : 0ull)) | align | first_bit);
     }
   }
-  // one atomic per workgroup: exclusive scan of the per-thread chunk counts
+  // length class of a chunk: the block visits of its lane, 1 .. 7 -> class 0 .. 6, longer -> class 7
+  auto visits_class = [&](uint64_t lo, uint64_t e, bool left_in) -> uint32_t {
+    uint64_t v = e - lo;
+    if (left_in) v += lo > P.wb ? P.wb : lo;  // a continuation chunk walks its warm-up blocks first
+    return (uint32_t)(v >= kLenClasses ? kLenClasses - 1 : v - 1);
+  };
+  uint64_t e_first = 0, e_second = 0;  // ends of the thread's first two chunks (most threads have at most one):
+  uint32_t seen = 0;                   // the second pass below does not walk their runs again
+  for (unsigned long long st = starts; st; ++seen) {
+    const int i = __ffsll((long long)st) - 1;
+    st &= st - 1;
+    const uint64_t lo = w * 64 + (uint64_t)i;
+    const bool left_in = i > 0 ? ((A >> (i - 1)) & 1ull) : prev_top;
+    const uint64_t e = chunk_end(P, w, A, i);
+    if (seen == 0) e_first = e;
+    if (seen == 1) e_second = e;
+    const uint32_t c = visits_class(lo, e, left_in);
+    if (c < 4) cnt0 += 1ull << (16 * c); else cnt1 += 1ull << (16 * (c - 4));
+  }
+  // exclusive scan of the packed per-class counts over the workgroup (one atomic per workgroup)
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-  uint32_t incl = mine;
+  unsigned long long inc0 = cnt0, inc1 = cnt1;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t up = __shfl_up(incl, d);
-    if (lane >= (uint32_t)d) incl += up;
+    const unsigned long long u0 = __shfl_up(inc0, d), u1 = __shfl_up(inc1, d);
+    if (lane >= (uint32_t)d) { inc0 += u0; inc1 += u1; }
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) my_hits += __shfl_xor(my_hits, d);
-  if (lane == 63) { wave_sum[wv] = incl; wave_hits[wv] = my_hits; }
+  if (lane == 63) { wave_cnt[wv][0] = inc0; wave_cnt[wv][1] = inc1; wave_hits[wv] = my_hits; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    uint32_t total = 0, hits = 0;
-    for (int v = 0; v < kBuildWaves; ++v) { total += wave_sum[v]; hits += wave_hits[v]; }
-    group_base = total ? atomicAdd(P.desc_count, total) : 0u;
+    uint32_t tot[kLenClasses] = {0, 0, 0, 0, 0, 0, 0, 0}, hits = 0, total = 0;
+    for (int v = 0; v < kBuildWaves; ++v) {
+      for (int c = 0; c < kLenClasses; ++c) tot[c] += (uint32_t)((wave_cnt[v][c >> 2] >> (16 * (c & 3))) & 0xFFFFu);
+      hits += wave_hits[v];
+    }
+    for (int c = 0; c < kLenClasses; ++c) total += tot[c];
+    uint32_t base = total ? atomicAdd(P.desc_count, total) : 0u;
+    // the longest chunks first: their waves start first and do not trail behind the kernel's end
+    for (int c = kLenClasses - 1; c >= 0; --c) { class_base[c] = base; base += tot[c]; }
     if (hits) atomicAdd(P.hit_count, (unsigned long long)hits);
   }
   __syncthreads();
-  uint32_t idx = group_base + (incl - mine);
-  for (uint32_t v = 0; v < wv; ++v) idx += wave_sum[v];
-
-#pragma unroll 1
-  for (int j = 0; j < kBuildWords; ++j) {
-    const uint64_t w = ((uint64_t)blockIdx.x * kBuildWords + j) * blockDim.x + threadIdx.x;
-    unsigned long long st = 0, Aj = 0;
+  // this thread's first slot in every class: class base + the waves before it + the lanes before it
+  uint32_t next[kLenClasses];
+  {
+    const unsigned long long ex0 = inc0 - cnt0, ex1 = inc1 - cnt1;
 #pragma unroll
-    for (int q = 0; q < kBuildWords; ++q)  // (register arrays: select, do not index)
-      if (q == j) { st = starts[q]; Aj = A[q]; }
-    const bool prev_top = (prev_tops >> j) & 1u;
-    while (st) {
-      const int i = __ffsll((long long)st) - 1;
-      st &= st - 1;
-      const uint64_t lo = w * 64 + (uint64_t)i;
-      const bool left_in = i > 0 ? ((Aj >> (i - 1)) & 1ull) : prev_top;
-      // end of the chunk: first block after lo that is outside A', or the next cut
-      uint64_t e = lo + 1;
-      {
-        unsigned long long rest = (i < 63) ? (Aj >> (i + 1)) : 0ull;      // A' bits of blocks lo+1 ..
-        int avail = 63 - i;                                               // .. still inside this word
-        uint64_t ww = w;
-        for (;;) {
-          // consecutive A' blocks at the bottom of `rest` (bits past `avail` are zero or ignored)
-          const unsigned long long inv = ~rest;
-          int run = inv ? (__ffsll((long long)inv) - 1) : 64;
-          if (run > avail) run = avail;
-          e += (uint64_t)run;
-          if (run < avail) break;                       // hit a block outside A'
-          ++ww;
-          if (ww * 64 >= P.n_blocks) break;             // end of the buffer
-          if (((ww * 64) & (uint64_t)(P.maxlen - 1)) == 0) break;  // cut at a multiple of maxlen
-          rest = dilated_word(P, (long long)ww);
-          avail = 64;
-        }
-        if (e > P.n_blocks) e = P.n_blocks;
-      }
-      if (idx < P.desc_cap) {
-        ChunkDesc d;
-        d.own_lo = (uint32_t)lo;
-        d.own_hi = (uint32_t)e;
-        d.flags = left_in ? 0u : kDescClearBefore;
-        d.pad_ = 0;
-        P.desc[idx] = d;
-      }
-      ++idx;
+    for (int c = 0; c < kLenClasses; ++c) {
+      uint32_t x = class_base[c] + (uint32_t)(((c < 4 ? ex0 : ex1) >> (16 * (c & 3))) & 0xFFFFu);
+      for (uint32_t v = 0; v < wv; ++v) x += (uint32_t)((wave_cnt[v][c >> 2] >> (16 * (c & 3))) & 0xFFFFu);
+      next[c] = x;
+    }
+  }
+  seen = 0;
+  for (unsigned long long st = starts; st; ++seen) {
+    const int i = __ffsll((long long)st) - 1;
+    st &= st - 1;
+    const uint64_t lo = w * 64 + (uint64_t)i;
+    const bool left_in = i > 0 ? ((A >> (i - 1)) & 1ull) : prev_top;
+    const uint64_t e = seen == 0 ? e_first : seen == 1 ? e_second : chunk_end(P, w, A, i);
+    const uint32_t c = visits_class(lo, e, left_in);
+    uint32_t idx = 0;
+#pragma unroll
+    for (int q = 0; q < kLenClasses; ++q)  // (register array: select, do not index)
+      if ((uint32_t)q == c) { idx = next[q]; next[q] = idx + 1; }
+    if (idx < P.desc_cap) {
+      ChunkDesc d;
+      d.own_lo = (uint32_t)lo;
+      d.own_hi = (uint32_t)e;
+      d.flags = left_in ? 0u : kDescClearBefore;
+      d.pad_ = 0;
+      P.desc[idx] = d;
     }
   }
 }
@@ -464,8 +494,7 @@ hipError_t launch_build_chunks(const unsigned long long* d_hit, uint64_t n_words
   P.hit = d_hit; P.n_words = n_words; P.n_blocks = n_blocks; P.first_owned = first_owned;
   P.wb = wb; P.L = L; P.maxlen = maxlen; P.desc = d_desc; P.desc_count = d_desc_count; P.desc_cap = desc_cap;
   P.hit_count = d_hit_count;
-  const uint64_t per_group = 1024ull * kBuildWords;
-  hipLaunchKernelGGL(build_chunks_kernel, dim3((uint32_t)((n_words + per_group - 1) / per_group)), dim3(1024), 0, stream, P);
+  hipLaunchKernelGGL(build_chunks_kernel, dim3((uint32_t)((n_words + 1023) / 1024)), dim3(1024), 0, stream, P);
   return hipGetLastError();
 }
 
