@@ -225,6 +225,12 @@ int sassy_hip_search_encoded(sassy_SearcherType *s, const sassy_hip_Encoded *e,
  * oracle/sassy_oracle.c:orc_generate_dna / orc_plant_window, checked byte for byte in tests. */
 int sassy_hip_generate_dna(uint8_t *d_text, uint64_t n, uint64_t seed, uint64_t first,
                            void *hip_stream);
+/* A repeat-rich synthetic text (measurement and test input, like sassy_hip_generate_dna): 4 KiB regions of
+ * i.i.d. ACGT (the majority), microsatellites (6 %), copies of 4 interspersed-repeat families with 8 %
+ * divergence (10 %), soft-masked stretches (1 %) and, with with_n != 0, runs of 'N' (2 %); every byte is a pure
+ * function of (seed, first + index).  See sassy_amd/csrc/aux_kernels.hip: genome_like_byte. */
+int sassy_hip_generate_genome_like(uint8_t *d_text, uint64_t n, uint64_t seed, uint64_t first, int with_n,
+                                   void *hip_stream);
 int sassy_hip_plant(uint8_t *d_text, uint64_t n, uint64_t first, uint64_t total_n, uint64_t seed,
                     const uint8_t *pattern, size_t pattern_len, size_t k, uint64_t stride,
                     void *hip_stream, uint64_t *planted);

@@ -114,7 +114,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_search_many", "sassy_hip_tsv_header", "sassy_hip_format_tsv",
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
-    "sassy_hip_generate_dna", "sassy_hip_plant",
+    "sassy_hip_generate_dna", "sassy_hip_generate_genome_like", "sassy_hip_plant",
     "sassy_hip_malloc", "sassy_hip_free", "sassy_hip_memcpy_h2d", "sassy_hip_memcpy_d2h",
 ]
 
@@ -217,6 +217,8 @@ def lib():
     L.sassy_hip_search_encoded.argtypes = [vp, vp, vp, sz, sz, C.c_uint32, C.POINTER(vp)]
     L.sassy_hip_generate_dna.restype = C.c_int
     L.sassy_hip_generate_dna.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, vp]
+    L.sassy_hip_generate_genome_like.restype = C.c_int
+    L.sassy_hip_generate_genome_like.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, vp]
     L.sassy_hip_plant.restype = C.c_int
     L.sassy_hip_plant.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, u8p, sz, sz,
                                   C.c_uint64, vp, C.POINTER(C.c_uint64)]
@@ -581,6 +583,11 @@ def required_halo(pattern_len: int, k: int) -> int:
 def generate_dna(d_ptr: int, n: int, seed: int, first: int = 0, stream: int = 0):
     """Fill device memory [d_ptr, d_ptr+n) with the synthetic ACGT text."""
     _check(lib().sassy_hip_generate_dna(d_ptr, n, seed, first, stream or None))
+
+
+def generate_genome_like(d_ptr: int, n: int, seed: int, first: int = 0, with_n: bool = False, stream: int = 0):
+    """Fill device memory with the repeat-rich synthetic text (microsatellites, repeat families, optional N runs)."""
+    _check(lib().sassy_hip_generate_genome_like(d_ptr, n, seed, first, int(with_n), stream or None))
 
 
 def plant(d_ptr: int, n: int, first: int, total_n: int, seed: int, pattern: bytes, k: int,

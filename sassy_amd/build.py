@@ -28,6 +28,7 @@ UNITS = [
     ("scan_kernel.hip", "scan_iupac.o", ["-DSASSY_SCAN_PROFILE=2"]),
     ("count_filter.hip", "count_filter.o", []),
     ("aux_kernels.hip", "aux_kernels.o", []),
+    ("sort_kernels.hip", "sort_kernels.o", []),
     ("trace_kernel.hip", "trace_kernel.o", []),
     ("host.hip", "host.o", []),
 ]

@@ -52,6 +52,57 @@ __global__ __launch_bounds__(256) void generate_dna_kernel(uint8_t* out, uint64_
   }
 }
 
+// A repeat-rich synthetic text for measuring the path on something less kind than i.i.d. letters (what a
+// real genome does to a prefilter): the text is cut into 4 KiB regions whose kind is drawn from the region
+// index --
+//    6 %  microsatellite: a unit of 1..6 letters repeated through the region, 2 % of the letters substituted;
+//   10 %  interspersed repeat: a copy of one of 4 family consensus sequences (4 KiB each, copy starts at a random
+//         phase), 8 % of the letters substituted;
+//    2 %  (only with `with_n`) a run of 'N' over the whole region; 1 % soft-masked (lower case) random letters;
+//   rest  i.i.d. ACGT as generate_dna_kernel gives them.
+// Every byte is a pure function of (seed, global index): any slice can be regenerated anywhere.
+__device__ __forceinline__ uint8_t genome_like_byte(uint64_t seed, uint64_t g, bool with_n) {
+  const uint64_t region = g >> 12;
+  const uint32_t off = (uint32_t)(g & 4095u);
+  const uint64_t h = splitmix64(seed * 0x9E3779B97F4A7C15ull + 0x5eed0000ull + region);
+  const uint32_t kind = (uint32_t)(h % 100u);
+  const uint64_t hb = splitmix64(seed * 0x9E3779B97F4A7C15ull + (g >> 5));
+  const uint32_t rnd = (uint32_t)(hb >> (2 * (g & 31u))) & 3u;           // the i.i.d. letter of this position
+  const uint64_t hm = splitmix64((seed ^ 0x6d757461ull) * 0x9E3779B97F4A7C15ull + g);  // mutation draw
+  uint32_t code = rnd;
+  bool lower = false;
+  if (kind < 6) {
+    const uint32_t period = 1u + (uint32_t)((h >> 8) % 6u);
+    const uint32_t unit = (uint32_t)(h >> 16);                           // 2 bits per unit letter
+    code = (unit >> (2 * (off % period))) & 3u;
+    if (hm % 100u < 2u) code = (code + 1u + (uint32_t)((hm >> 8) % 3u)) & 3u;
+  } else if (kind < 16) {
+    const uint64_t fam = (h >> 8) & 3u;
+    const uint32_t phase = (uint32_t)((h >> 12) & 4095u);
+    const uint32_t cp = (off + phase) & 4095u;                           // position inside the family consensus
+    const uint64_t hc = splitmix64((0xfa000000ull + fam) * 0x9E3779B97F4A7C15ull + (cp >> 5));
+    code = (uint32_t)(hc >> (2 * (cp & 31u))) & 3u;
+    if (hm % 100u < 8u) code = (code + 1u + (uint32_t)((hm >> 8) % 3u)) & 3u;
+  } else if (kind < 18 && with_n) {
+    return (uint8_t)'N';
+  } else if (kind == 18) {
+    lower = true;
+  }
+  const uint8_t ch = (uint8_t)((0x54474341u >> (8 * code)) & 0xFFu);
+  return lower ? (uint8_t)(ch | 0x20u) : ch;
+}
+__global__ __launch_bounds__(256) void generate_genome_like_kernel(uint8_t* out, uint64_t n, uint64_t seed, uint64_t first,
+                                                                   int with_n) {
+  const uint64_t stride = (uint64_t)gridDim.x * blockDim.x * 4;
+  for (uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
+    uint32_t v = 0;
+    for (int b = 0; b < 4; ++b) v |= (uint32_t)genome_like_byte(seed, first + i + b, with_n != 0) << (8 * b);
+    if (i + 4 <= n && ((uintptr_t)(out + i) & 3) == 0) *reinterpret_cast<uint32_t*>(out + i) = v;
+    else
+      for (int b = 0; b < 4 && i + b < n; ++b) out[i + b] = (uint8_t)(v >> (8 * b));
+  }
+}
+
 // text[pos[i] - first] = val[i] for the planted bytes that fall into [first, first + n)
 __global__ void scatter_bytes_kernel(uint8_t* text, uint64_t n, uint64_t first, const uint64_t* pos,
                                      const uint8_t* val, uint64_t count) {
@@ -183,7 +234,11 @@ __device__ __forceinline__ uint64_t chunk_end(const BuildParams& P, uint64_t w, 
     rest = dilated_word(P, (long long)ww);
     avail = 64;
   }
-  return e > P.n_blocks ? P.n_blocks : e;
+  if (e > P.n_blocks) e = P.n_blocks;
+  // cuts at absolute multiples of maxlen (a power of two): the chunk ends at the first one behind its start
+  const uint64_t lo = w * 64 + (uint64_t)i;
+  const uint64_t cut = (lo / P.maxlen + 1) * (uint64_t)P.maxlen;
+  return e < cut ? e : cut;
 }
 
 __global__ __launch_bounds__(1024) void build_chunks_kernel(const BuildParams P) {
@@ -200,8 +255,13 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const BuildParams P)
     A = dilated_word(P, (long long)w);
     if (A) {
       prev_top = w > 0 ? ((dilated_word(P, (long long)w - 1) >> 63) != 0) : false;
-      // maxlen is a power of two >= 64: a cut can only fall on bit 0 of a word
-      const unsigned long long align = ((w * 64) & (uint64_t)(P.maxlen - 1)) == 0 ? 1ull : 0ull;
+      // a chunk starts at every absolute multiple of maxlen (a power of two >= 8) that lies in A'
+      unsigned long long align;
+      if (P.maxlen >= 64) align = ((w * 64) & (uint64_t)(P.maxlen - 1)) == 0 ? 1ull : 0ull;
+      else {
+        align = 1ull;
+        for (uint32_t sh = P.maxlen; sh < 64; sh <<= 1) align |= align << sh;  // bit 0 repeated every maxlen bits
+      }
       unsigned long long own = ~0ull;  // only blocks >= first_owned are owned (the halo is warm-up)
       if (w * 64 < P.first_owned) own = (P.first_owned - w * 64 >= 64) ? 0ull : (~0ull << (P.first_owned - w * 64));
       unsigned long long first_bit = 0;  // the first owned block starts a chunk if it is in A'
@@ -466,6 +526,15 @@ hipError_t launch_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint6
   uint64_t blocks = (nb + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(generate_dna_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_text, n, seed, first);
+  return hipGetLastError();
+}
+
+hipError_t launch_generate_genome_like(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first, int with_n,
+                                       hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  uint64_t blocks = ((n + 3) / 4 + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  hipLaunchKernelGGL(generate_genome_like_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_text, n, seed, first, with_n);
   return hipGetLastError();
 }
 

@@ -49,6 +49,8 @@ hipError_t launch_build_chunks(const unsigned long long* d_hit, uint64_t n_words
                                ChunkDesc* d_desc, uint32_t* d_desc_count, uint32_t desc_cap,
                                unsigned long long* d_hit_count, hipStream_t stream);
 hipError_t launch_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first, hipStream_t stream);
+hipError_t launch_generate_genome_like(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first, int with_n,
+                                       hipStream_t stream);
 hipError_t launch_scatter_bytes(uint8_t* d_text, uint64_t n, uint64_t first, const uint64_t* d_pos,
                                 const uint8_t* d_val, uint64_t count, hipStream_t stream);
 hipError_t launch_reverse(const uint8_t* d_in, uint8_t* d_out, uint64_t n, hipStream_t stream);
@@ -56,6 +58,10 @@ hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stre
 hipError_t launch_rank(const Candidate* d_cand, const uint32_t* d_count, uint32_t cap, uint32_t* d_rank,
                        Candidate* d_sorted, Candidate* h_sorted, uint32_t host_cap, void* h_ctl,
                        const TextTable& texts, hipStream_t stream);
+
+size_t sort_scratch_bytes(uint32_t count);
+hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, uint32_t count, void* d_scratch,
+                                  size_t scratch_bytes, hipStream_t stream);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -136,7 +142,7 @@ struct ScanLane {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_f = nullptr, ev_filter_done = nullptr;
-  DevBuf<uint8_t> d_state, d_scratch, d_str, d_ctl;
+  DevBuf<uint8_t> d_state, d_scratch, d_str, d_ctl, d_sort;
   DevBuf<Candidate> d_cand, d_sorted;
   DevBuf<MatchOut> d_trace;
   DevBuf<ChunkDesc> d_desc;
@@ -187,6 +193,50 @@ struct ScanLane {
     h_up_used = need;
     return e == hipSuccess ? 0 : hip_fail(e, "hipMemcpyAsync");
   }
+  // Results too large for the device-mapped staging area (dense matches: 10^5 .. 10^6 records) come back with
+  // ordinary copies.  A copy into pageable memory runs at ~5 GB/s; through two pinned 8 MiB buffers, the next
+  // piece in flight while the previous one is moved to its final place, the transfer runs at the speed of the
+  // host memcpy.
+  static constexpr size_t kBulk = 8u << 20;
+  unsigned char* h_bulk[2] = {nullptr, nullptr};
+  int download(void* dst, const void* d_src, size_t bytes) {
+    if (bytes == 0) return 0;
+    for (unsigned char*& b : h_bulk)
+      if (!b && hipHostMalloc(reinterpret_cast<void**>(&b), kBulk, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        b = nullptr;
+      }
+    if (!h_bulk[0] || !h_bulk[1] || bytes < (1u << 20)) {  // small, or no pinned memory to be had
+      hipError_t e = hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      return e == hipSuccess ? 0 : hip_fail(e, "hipMemcpy (results)");
+    }
+    unsigned char* out = static_cast<unsigned char*>(dst);
+    const unsigned char* src = static_cast<const unsigned char*>(d_src);
+    size_t issued = 0, done = 0;
+    int slot = 0;
+    size_t len[2] = {0, 0};
+    // prime one piece, then: wait for piece i, issue piece i+1, move piece i
+    len[0] = std::min(kBulk, bytes);
+    hipError_t e = hipMemcpyAsync(h_bulk[0], src, len[0], hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync (results)");
+    issued = len[0];
+    while (done < bytes) {
+      e = hipStreamSynchronize(stream);
+      if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize (results)");
+      const int cur = slot;
+      slot ^= 1;
+      if (issued < bytes) {
+        len[slot] = std::min(kBulk, bytes - issued);
+        e = hipMemcpyAsync(h_bulk[slot], src + issued, len[slot], hipMemcpyDeviceToHost, stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync (results)");
+        issued += len[slot];
+      }
+      memcpy(out + done, h_bulk[cur], len[cur]);
+      done += len[cur];
+    }
+    return 0;
+  }
   int reserve_pinned(size_t bytes) {
     if (bytes <= h_pin_cap) return 0;
     if (h_pin) (void)hipHostFree(h_pin);
@@ -216,7 +266,8 @@ struct ScanLane {
   void destroy() {
     if (h_up) (void)hipHostFree(h_up);
     h_up = nullptr; h_up_cap = h_up_used = 0;
-    d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release();
+    d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release(); d_sort.release();
+    for (unsigned char*& b : h_bulk) { if (b) (void)hipHostFree(b); b = nullptr; }
     d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release();
     d_pattern.release(); d_table.release(); d_rowoff.release(); d_ovtab.release();
     if (h_pin) (void)hipHostFree(h_pin);
@@ -650,7 +701,11 @@ struct ScanJob {
 
   static constexpr size_t kCtlHead = 64 + 4 * (size_t)kRankLimit;
   static constexpr uint32_t kTraceWaveMax = 8192;
-  static constexpr uint32_t maxlen = 128;  // list mode: longest chunk in blocks (long runs are cut)
+  // list mode: longest chunk in blocks.  Long runs of candidate blocks (N runs under the Iupac profile,
+  // low-complexity stretches) are cut there; every cut costs the next chunk wb warm-up blocks, every uncut run
+  // is one lane walking it alone.  8 * wb blocks keep the warm-up at an eighth of the work (m = 32: 16-block
+  // chunks, a 4 KiB N run is shared by four lanes instead of one).
+  uint32_t maxlen = 128;
   static constexpr uint32_t kSpec = 4096;  // reports the kernels also write into the host buffer
   static constexpr size_t kPinCounts = 0, kPinCounters = 16;
   static constexpr size_t pin_cands = 128;
@@ -1158,6 +1213,8 @@ int ScanJob::enqueue(int attempt) {
     }
     if (time_head && attempt == 0) HIP_TRY(hipEventRecord(L.ev_f, L.stream));
     if (signal_filter_done && attempt == 0) HIP_TRY(hipEventRecord(L.ev_filter_done, L.stream));
+    maxlen = 16;
+    while (maxlen < 8u * P.wb && maxlen < 128u) maxlen <<= 1;
     desc_cap = ext_desc ? ext_ndesc : (uint32_t)std::min<size_t>(L.d_desc.cap, 0x7FFFFFFFu);
     if (int rc = L.d_state.reserve(std::max<uint32_t>(desc_cap, 1))) return rc;
     P.chunk_state = L.d_state.p;
@@ -1233,6 +1290,7 @@ int ScanJob::enqueue(int attempt) {
 int ScanJob::finish(ScanOut& out) {
   out = ScanOut();
   if (empty) return 0;
+  bool sorted_on_device = false;
   for (int attempt = 0;; ++attempt) {
     // the only synchronisation of the call; the kernels have written the results into h_pin
     const double t_sync0 = now_ms();
@@ -1274,7 +1332,17 @@ int ScanJob::finish(ScanOut& out) {
         // many reports: what enqueue() left out -- the ranking kernels (self-ranking mode), then the
         // thread-per-report traceback, or the wave kernel on the ranked list where only it applies
         hipError_t le = hipSuccess;
-        if (self_rank) {
+        if (texts.n == 0) {
+          // more reports than the traceback waves rank for themselves: radix sort on the device
+          // (sort_kernels.hip), then the traceback on the sorted list -- the records arrive in result order,
+          // the host sorts nothing (the counting ranker is quadratic: 27 000 reports took it 0.32 ms, the
+          // host's std::sort 63 ms for 740 000)
+          const size_t need = sort_scratch_bytes(counts[0]);
+          if (int rc = L.d_sort.reserve(need)) return rc;
+          le = launch_sort_candidates(L.d_cand.p, L.d_sorted.p, counts[0], L.d_sort.p, L.d_sort.cap, L.stream);
+          if (le != hipSuccess) return hip_fail(le, "report sort launch");
+          sorted_on_device = true;
+        } else if (self_rank) {
           le = launch_rank(L.d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(L.d_ctl.p + 64), L.d_sorted.p,
                            reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands), std::min<uint32_t>(kSpec, P.cand_cap),
                            L.h_pin_dev + kPinCounts, texts, L.stream);
@@ -1315,13 +1383,14 @@ int ScanJob::finish(ScanOut& out) {
   }
 
   if (count) {
-    const uint32_t have = std::min<uint32_t>(count, kSpec);
+    // (after a device sort the staging area's head holds the unsorted list's records: take everything from the device)
+    const uint32_t have = sorted_on_device ? 0u : std::min<uint32_t>(count, kSpec);
     // (assign, not resize + memcpy: one pass over the memory instead of a zero fill and a copy)
     const Candidate* hc = reinterpret_cast<const Candidate*>(L.h_pin + pin_cands);
     out.cands.assign(hc, hc + have);
     out.cands.resize(count);
     if (count > have)
-      HIP_TRY(hipMemcpy(out.cands.data() + have, L.d_sorted.p + have, (size_t)(count - have) * sizeof(Candidate), hipMemcpyDeviceToHost));
+      if (int rc = L.download(out.cands.data() + have, L.d_sorted.p + have, (size_t)(count - have) * sizeof(Candidate))) return rc;
     if (do_trace) {
       const sassy_hip_Match* hm = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + pin_recs);
       out.matches.assign(hm, hm + have);
@@ -1329,9 +1398,9 @@ int ScanJob::finish(ScanOut& out) {
       out.pool.assign(reinterpret_cast<const char*>(L.h_pin + pin_ops), (size_t)have * T.str_stride);
       out.pool.resize((size_t)count * T.str_stride);
       if (count > have) {
-        HIP_TRY(hipMemcpy(out.matches.data() + have, L.d_trace.p + have, (size_t)(count - have) * sizeof(MatchOut), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(&out.pool[0] + (size_t)have * T.str_stride, L.d_str.p + (size_t)have * T.str_stride,
-                          (size_t)(count - have) * T.str_stride, hipMemcpyDeviceToHost));
+        if (int rc = L.download(out.matches.data() + have, L.d_trace.p + have, (size_t)(count - have) * sizeof(MatchOut))) return rc;
+        if (int rc = L.download(&out.pool[0] + (size_t)have * T.str_stride, L.d_str.p + (size_t)have * T.str_stride,
+                                (size_t)(count - have) * T.str_stride)) return rc;
       }
     }
   }
@@ -1352,8 +1421,9 @@ int ScanJob::finish(ScanOut& out) {
       if (r.pad_[0] == kTraceFailed)
         // the reference asserts both conditions (src/search.rs:1672-1685) and panics in get_trace
         return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
-  if (count > kRankLimit) {
-    // too many reports for the device ranking pass: they arrived in append order, sort here
+  if (count > kRankLimit && !sorted_on_device) {
+    // too many reports for the device ranking pass (and not the single-text traceback path, which sorts on the
+    // device): they arrived in append order, sort here
     std::vector<uint32_t> order(count);
     for (uint32_t i = 0; i < count; ++i) order[i] = i;
     std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return out.cands[x].pos < out.cands[y].pos; });
@@ -2994,6 +3064,14 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
 int sassy_hip_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first, void* hip_stream) {
   if (!d_text && n) return fail(SASSY_HIP_EINVAL, "null argument");
   hipError_t e = launch_generate_dna(d_text, n, seed, first, reinterpret_cast<hipStream_t>(hip_stream));
+  if (e != hipSuccess) return hip_fail(e, "generate kernel launch");
+  HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream)));
+  return 0;
+}
+
+int sassy_hip_generate_genome_like(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first, int with_n, void* hip_stream) {
+  if (!d_text && n) return fail(SASSY_HIP_EINVAL, "null argument");
+  hipError_t e = launch_generate_genome_like(d_text, n, seed, first, with_n, reinterpret_cast<hipStream_t>(hip_stream));
   if (e != hipSuccess) return hip_fail(e, "generate kernel launch");
   HIP_TRY(hipStreamSynchronize(reinterpret_cast<hipStream_t>(hip_stream)));
   return 0;

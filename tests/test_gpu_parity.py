@@ -1327,6 +1327,84 @@ def test_dna_profile_text_with_other_letters(sassy):
     assert outcomes["same"] >= 30 and outcomes["both_fail"] >= 10, outcomes
 
 
+# ------------------------------------------------------------------ texts that are not i.i.d.
+def _check_slices(sassy, buf, n, profile, pat, k, r, starts, SL=1 << 20):
+    """the matches of a whole-text search that lie inside a few slices, against the oracle on each slice"""
+    arr, pool = r.array, r.pool
+    ts, te = arr["text_start"].astype(np.int64), arr["text_end"].astype(np.int64)
+    assert (np.diff(te) > 0).all() and (arr["cost"] <= k).all()
+    compared = 0
+    for a in starts:
+        a = min(max(0, a // 64 * 64), n - SL)
+        sl = buf.download(SL, a)
+        want = [(m.text_start + a, m.text_end + a, m.cost, m.cigar) for m in oracle.search(profile, pat, sl, k)
+                if m.text_start >= 256 and m.text_end <= SL - 256]
+        sel = np.nonzero((ts >= a + 256) & (te <= a + SL - 256))[0]
+        got = [(int(ts[i]), int(te[i]), int(arr["cost"][i]),
+                pool[int(arr["cigar_off"][i]):int(arr["cigar_off"][i]) + int(arr["cigar_len"][i])].decode()) for i in sel]
+        assert got == want, (profile, pat, a, len(got), len(want))
+        compared += len(want)
+    return compared
+
+
+@pytest.mark.parametrize("case", ["dense_plants", "periodic_pattern", "repeats_family", "repeats_microsatellite",
+                                  "repeats_polyA", "repeats_with_N_iupac"])
+def test_texts_that_are_not_iid(sassy, case):
+    """SURVEY 8(d)'s dense-plant variant (a near-match every 4 KiB: the output path), the periodic BASELINE
+    pattern 'ATCG'x8, and the repeat-rich synthetic text (microsatellites, repeat families, soft-masked
+    stretches, N runs) on which a prefilter finds far more candidate blocks than on i.i.d. letters: whole-text
+    search on the device, matches sorted and <= k, and the matches inside 1 MiB slices equal to the oracle's
+    -- through the searches-in-flight entry points as well.  (tools/bench_texts.py times the same cases at 3 GB.)"""
+    n = 160 << 20
+    buf = sassy.DeviceBuffer(n + 4096)
+    rnd32 = bytes(oracle.generate_dna(43, 0, 32))
+    profile, k = "dna", 3
+    if case == "dense_plants":
+        pat = rnd32
+        sassy.generate_dna(buf.ptr, n, 42, 0)
+        planted = sassy.plant(buf.ptr, n, 0, n, 42, pat, k, stride=4096)
+        assert planted == n // 4096
+    elif case == "periodic_pattern":
+        pat = b"ATCG" * 8
+        sassy.generate_dna(buf.ptr, n, 42, 0)
+        buf.upload(b"ATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCGATCG", 5 << 20)  # a plateau of its own
+        buf.upload(b"ATCGATCGATCGATCGTTCGATCGATCGATCG", (40 << 20) + 17)
+    else:
+        sassy.generate_genome_like(buf.ptr, n, 42, 0, with_n=case.endswith("iupac"))
+        first_region = buf.download(1 << 16, 0)
+        if case == "repeats_family":
+            # a 32-mer of the consensus of family 0: read it off a copy in the text itself (the longest exact
+            # repeat between two repeat regions would do; simpler: the generator's rule, restated in the tool)
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+            from bench_texts import consensus_32mer
+            pat = consensus_32mer(0, 1000)
+        elif case == "repeats_microsatellite":
+            pat = b"AC" * 16
+        elif case == "repeats_polyA":
+            pat = b"A" * 32
+        else:
+            profile, pat = "iupac", rnd32
+        assert len(first_region) == 1 << 16
+    s = sassy.Searcher(profile, rc=False)
+    r = s.search_shard(pat, buf.ptr, 0, n, 0, n, k)
+    assert s.stats()["filtered"] != 0 or os.environ.get("SASSY_HIP_PREFILTER") == "0"
+    nm = len(r)
+    expect_min = {"dense_plants": n // 4096, "periodic_pattern": 2, "repeats_family": 200, "repeats_microsatellite": 20000,
+                  "repeats_polyA": 1000, "repeats_with_N_iupac": 500}[case]
+    assert nm >= expect_min, (case, nm)
+    starts = [0, n // 3, n - (1 << 20), 5 << 20, 40 << 20]
+    if nm:
+        starts.append(int(r.array["text_start"][nm // 2]) - (1 << 19))
+    compared = _check_slices(sassy, buf, n, profile, pat, k, r, starts)
+    assert compared >= min(5, expect_min)
+    # the same search as one of two in flight: identical records
+    t1 = s.search_shard_begin(pat, buf.ptr, 0, n, 0, n, k)
+    t2 = s.search_shard_begin(pat, buf.ptr, 0, n, 0, n, k)
+    r1, r2 = s.search_finish(t1), s.search_finish(t2)
+    assert r1.array.tobytes() == r.array.tobytes() == r2.array.tobytes() and r1.pool == r.pool == r2.pool
+    buf.free()
+
+
 # ------------------------------------------------------------------ searches in flight
 def test_searches_in_flight_begin_finish(sassy):
     """sassy_hip_search_shard_begin / sassy_hip_search_finish: two searches in flight on one searcher give
