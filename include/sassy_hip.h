@@ -101,6 +101,13 @@ int sassy_hip_set_timing(sassy_SearcherType *s, int level);
  * DP over every block, 1 = prefilter also with short pieces.  All give the same matches; the setting exists so
  * that the paths can be checked against each other (tests) and timed apart. */
 int sassy_hip_set_prefilter(sassy_SearcherType *s, int mode);
+/* Which reports a search of ONE text returns on low-complexity text (sassy_hip_search, the drop-in search):
+ * 0 (default) = the definition -- one left-to-right pass over the text, independent of any chunking;
+ * 4 / 8 = what the reference binary built for AVX2 / AVX-512 returns: it cuts the text into 4 / 8 lanes that each
+ * start with decreasing = true (src/search.rs:1016-1056, 1202-1240), which adds reports for <=k plateaus that
+ * were entered by an increase left of a lane's start (never on random text).  Process default:
+ * SASSY_HIP_REF_LANES.  Not applied with overhang, nor by search_many / search_shard / search_encoded. */
+int sassy_hip_set_reference_lanes(sassy_SearcherType *s, int lanes);
 /* On-line tuner of the streaming kernels' lane-chunk length for a resident text (off by default, or
  * SASSY_HIP_TUNE=1): the first ~36 searches of a (text, filter kind) try neighbouring geometries -- each a
  * complete, exact search -- and the rest use the fastest.  Worth it for the latency of lone searches on one

@@ -106,7 +106,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_last_error", "sassy_hip_version", "sassy_hip_device_count",
     "sassy_hip_searcher_new", "sassy_hip_set_stream", "sassy_hip_get_stats",
     "sassy_hip_search", "sassy_hip_search_shard", "sassy_hip_required_halo",
-    "sassy_hip_search_shard_begin", "sassy_hip_search_finish", "sassy_hip_set_pipe_depth", "sassy_hip_set_geometry_tuner",
+    "sassy_hip_search_shard_begin", "sassy_hip_search_finish", "sassy_hip_set_pipe_depth", "sassy_hip_set_geometry_tuner", "sassy_hip_set_reference_lanes",
     "sassy_hip_result_len", "sassy_hip_result_matches", "sassy_hip_result_cigars",
     "sassy_hip_result_cigars_len", "sassy_hip_pack_rows", "sassy_hip_enable_counters", "sassy_hip_set_timing",
     "sassy_hip_set_only_best_match", "sassy_hip_set_max_n_frac", "sassy_hip_search_with_fn",
@@ -185,6 +185,8 @@ def lib():
     L.sassy_hip_search_shard_begin.restype = C.c_int
     L.sassy_hip_search_shard_begin.argtypes = [vp, u8p, sz, vp, C.c_uint64, C.c_uint64, C.c_uint64,
                                                C.c_uint64, sz, C.c_uint32, C.POINTER(vp)]
+    L.sassy_hip_set_reference_lanes.restype = C.c_int
+    L.sassy_hip_set_reference_lanes.argtypes = [vp, C.c_int]
     L.sassy_hip_set_geometry_tuner.restype = C.c_int
     L.sassy_hip_set_geometry_tuner.argtypes = [vp, C.c_int]
     L.sassy_hip_set_pipe_depth.restype = C.c_int
@@ -523,6 +525,11 @@ class Searcher:
         _check(lib().sassy_hip_search_shard_begin(self._h, pattern, len(pattern), d_text_ptr, halo_len, shard_len,
                                                   global_offset, total_len, k, flags, C.byref(out)))
         return out.value
+
+    def set_reference_lanes(self, lanes: int):
+        """0 = the definition (default); 4 / 8 = the reports of the reference binary built for AVX2 / AVX-512."""
+        _check(lib().sassy_hip_set_reference_lanes(self._h, int(lanes)))
+        return self
 
     def set_geometry_tuner(self, on: bool = True):
         _check(lib().sassy_hip_set_geometry_tuner(self._h, int(on)))

@@ -373,6 +373,8 @@ struct sassy_SearcherType {
 
   bool want_counters = false;
   int prefilter = -1;            // sassy_hip_set_prefilter: -1 process default, 0 never, 1 also with short pieces
+  // sassy_hip_set_reference_lanes: 0 = the definition (one pass), 4 / 8 = the reference binary's lane reports
+  uint32_t ref_lanes = getenv("SASSY_HIP_REF_LANES") ? (uint32_t)atoi(getenv("SASSY_HIP_REF_LANES")) : 0u;
   // searches in flight (sassy_hip_search_shard_begin / sassy_hip_search_finish): the ticket that owns each lane
   struct sassy_hip_Ticket* lane_ticket[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
   int last_begun_lane = -1;
@@ -1658,6 +1660,55 @@ static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPla
   return 0;
 }
 
+// The reference's lane reports (opt-in: sassy_hip_set_reference_lanes / SASSY_HIP_REF_LANES = 4 | 8).
+// The reference cuts a single text into LANES chunks (4 with AVX2, 8 with AVX-512), lane l walking the blocks
+// [l bpc, l bpc + bpc + overlap) with a FRESH start -- D[j][start] = j and decreasing = true
+// (src/search.rs:1016-1056) -- and keeps of lane l the reports with lane_end[l-1] <= end < lane_end[l]
+// (:1202-1240).  On low-complexity text that yields reports the definition (one left-to-right pass, the
+// default here) does not have: a <=k plateau entered by an INCREASE left of a lane's start looks entered by a
+// decrease to that lane.  This mode reproduces the reference binary's output for a given
+// SIMD width: every lane is searched as a text of its own that starts at the lane's first block (text-start
+// semantics: exactly the fresh start), without the end-of-text rule unless the lane reaches the end of the
+// text (the lane's walk simply stops), and its reports are cut to the lane's range.  Values <= k at or behind
+// lane_end[l-1] >= start + m + k are exact, so only the plateau bookkeeping differs -- as in the reference.
+// (The reference may also stop its overlap blocks early, should_terminate_early :1253-1271, which moves
+// lane_end; it does so only where no lane can still report, so the reports are the same.)
+// Checked against the reference-shaped port oracle/sassy_refstyle.c on periodic fixtures (tests).
+static int run_scan(sassy_SearcherType* S, const ShardView& sh, const PatternPlan& plan, uint32_t k,
+                    bool all_minima, const uint8_t* pat, bool do_trace, uint64_t total_len, ScanOut& out);
+static int run_scan_ref_lanes(sassy_SearcherType* S, const uint8_t* d_text, uint64_t n, const PatternPlan& plan, uint32_t k,
+                              bool all_minima, const uint8_t* pat, bool do_trace, uint32_t lanes, ScanOut& out) {
+  out = ScanOut();
+  const uint64_t overlap = ((uint64_t)plan.m + k + 63) / 64;
+  const uint64_t nblocks = (n + 63) / 64;
+  const uint64_t rest = nblocks > overlap ? nblocks - overlap : 0;
+  const uint64_t bpc = (rest + lanes - 1) / lanes;
+  for (uint32_t l = 0; l < lanes; ++l) {
+    const uint64_t a = (uint64_t)l * bpc * 64;
+    if (a >= n) break;
+    const uint64_t b = std::min<uint64_t>(n, ((uint64_t)l * bpc + bpc + overlap) * 64);
+    const uint64_t lo = l == 0 ? 0 : (((uint64_t)(l - 1)) * bpc + bpc + overlap) * 64;
+    const uint64_t hi = l + 1 == lanes ? UINT64_MAX : ((uint64_t)l * bpc + bpc + overlap) * 64;
+    ShardView sub{d_text + a, b - a, 0, a, true, b == n};
+    ScanOut so;
+    if (int rc = run_scan(S, sub, plan, k, all_minima, pat, do_trace, n, so)) return rc;
+    const size_t base = out.pool.size();
+    if (base + so.pool.size() > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB");
+    out.pool.append(so.pool);
+    for (size_t i = 0; i < so.cands.size(); ++i) {
+      const uint64_t e = so.cands[i].pos;
+      if (e < lo || e >= hi) continue;
+      out.cands.push_back(so.cands[i]);
+      if (do_trace) {
+        sassy_hip_Match r = so.matches[i];
+        r.cigar_off = (uint32_t)(r.cigar_off + base);
+        out.matches.push_back(r);
+      }
+    }
+  }
+  return 0;
+}
+
 // Several independent scans (different patterns over the same resident buffer) in flight, one per
 // lane: while the GPU runs one pattern's kernels the host already queues the next one's and unpacks
 // the previous one's results.  submit() blocks only when every lane is busy; results come back in
@@ -2017,8 +2068,10 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
   // read the forward buffer backwards -- no reversed copy, no second streaming pass.  Needs a filter
   // that can do it (bit-plane / counting) and no option that wants the reversed text as such.
   static const int env_fuse = getenv("SASSY_HIP_RC_FUSED") ? atoi(getenv("SASSY_HIP_RC_FUSED")) : 1;
+  // the reference's lane reports (run_scan_ref_lanes): single texts, no overhang; each strand lane by lane
+  const uint32_t ref_lanes = (S->ref_lanes == 4 || S->ref_lanes == 8) && std::isnan(S->alpha) ? S->ref_lanes : 0u;
   const bool can_fuse = fwd_strand && rc_strand && env_fuse != 0 && !ef.fn && std::isnan(S->max_n_frac) &&
-                        std::isnan(S->alpha) && S->profile != PROFILE_ASCII;
+                        std::isnan(S->alpha) && S->profile != PROFILE_ASCII && ref_lanes == 0;
   bool rc_by_bitmap = false;
 
   if (fwd_strand) {
@@ -2068,7 +2121,9 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
         }
       }
     } else {
-      if (int rc = run_scan(S, sh, plan, (uint32_t)k, all, pattern, !wo, tlen, so)) return rc;
+      if (ref_lanes) {
+        if (int rc = run_scan_ref_lanes(S, d_fwd, tlen, plan, (uint32_t)k, all, pattern, !wo, ref_lanes, so)) return rc;
+      } else if (int rc = run_scan(S, sh, plan, (uint32_t)k, all, pattern, !wo, tlen, so)) return rc;
       if (int rc = post_filter(S, so, plan, pattern, (uint32_t)k, 0, on_dev ? nullptr : text, d_fwd, tlen, !wo, ef)) return rc;
       size_t first = 0;
       if (int rc = append_matches(so, tlen, plan, wo, pattern_idx, R, first)) return rc;
@@ -2091,7 +2146,9 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
     }
     ShardView sh{S->d_rev.p, tlen, 0, 0, true, true};
     ScanOut so;
-    if (int rc = run_scan(S, sh, cplan, (uint32_t)k, all, cp.data(), !wo, tlen, so)) return rc;
+    if (ref_lanes) {
+      if (int rc = run_scan_ref_lanes(S, S->d_rev.p, tlen, cplan, (uint32_t)k, all, cp.data(), !wo, ref_lanes, so)) return rc;
+    } else if (int rc = run_scan(S, sh, cplan, (uint32_t)k, all, cp.data(), !wo, tlen, so)) return rc;
     std::vector<uint8_t> h_rev;  // the callback sees the reversed text, like the reference's
     if (ef.fn && !on_dev) h_rev.assign(std::reverse_iterator<const uint8_t*>(text + tlen),
                                        std::reverse_iterator<const uint8_t*>(text));
@@ -2212,6 +2269,12 @@ int sassy_hip_enable_counters(sassy_SearcherType* s, int on) {
 int sassy_hip_set_prefilter(sassy_SearcherType* s, int mode) {
   if (!s || mode < -1 || mode > 1) return fail(SASSY_HIP_EINVAL, "prefilter mode must be -1, 0 or 1");
   s->prefilter = mode;
+  return 0;
+}
+
+int sassy_hip_set_reference_lanes(sassy_SearcherType* s, int lanes) {
+  if (!s || (lanes != 0 && lanes != 4 && lanes != 8)) return fail(SASSY_HIP_EINVAL, "reference lanes must be 0, 4 or 8");
+  s->ref_lanes = (uint32_t)lanes;
   return 0;
 }
 
@@ -2582,6 +2645,43 @@ int sassy_hip_search_many(sassy_SearcherType* s, const uint8_t* const* patterns,
   if (!handled)
     if (int rc = search_many_batched(s, patterns, pattern_lens, n_patterns, texts, text_lens, n_texts, k, flags, R.get(), handled))
       return rc;
+  // Device-resident texts, forward strand: every (pattern, text) pair is one scan job; several are in flight
+  // on the searcher's lanes (ScanQueue), so the latency-bound tail of one pair runs next to the filter of the
+  // next instead of the host waiting for each pair in turn (reference: search_many spreads the pairs over
+  // threads, src/search.rs:531-603).  Both-strand searchers keep the pair loop below (its one-pass two-strand
+  // path already uses two lanes per pair).
+  if (!handled && (flags & SASSY_HIP_TEXT_ON_DEVICE) && !s->rc && n_patterns * n_texts > 1) {
+    handled = true;
+    const bool all = (flags & SASSY_HIP_ALL_MINIMA) != 0;
+    const bool wo = (flags & SASSY_HIP_WITHOUT_TRACE) != 0;
+    if (k > 0x7FFFFFFFu) return fail(SASSY_HIP_EINVAL, "k too large");
+    for (size_t ti = 0; ti < n_texts; ++ti) {
+      if (!texts[ti] && text_lens[ti]) return fail(SASSY_HIP_EINVAL, "null text");
+      if (text_lens[ti] && ((uintptr_t)texts[ti] & 15) != 0) return fail(SASSY_HIP_EINVAL, "device text pointer must be 16-byte aligned");
+    }
+    sassy_hip_Result* Rp = R.get();
+    ScanQueue queue(s, [&](uint64_t tag, ScanOut& so, const PatternPlan& plan, const uint8_t* pat) -> int {
+      const size_t pi = (size_t)(tag / n_texts), ti = (size_t)(tag % n_texts);
+      if (int rc = post_filter(s, so, plan, pat, (uint32_t)k, 0, nullptr, texts[ti], text_lens[ti], !wo, EndFilter())) return rc;
+      size_t first = 0;
+      if (int rc = append_matches(so, text_lens[ti], plan, wo, pi, Rp, first)) return rc;
+      for (size_t i = first; i < Rp->matches.size(); ++i) Rp->matches[i].text_idx = ti;
+      return 0;
+    });
+    std::string err;
+    for (size_t ti = 0; ti < n_texts; ++ti) {
+      if (text_lens[ti] == 0) continue;  // no reports for an empty text (src/search.rs:1314-1316)
+      for (size_t pi = 0; pi < n_patterns; ++pi) {
+        if (!patterns[pi]) return fail(SASSY_HIP_EINVAL, "null pattern");
+        PatternPlan plan;
+        if (!make_plan(s->profile, patterns[pi], pattern_lens[pi], plan, err)) return fail(SASSY_HIP_EINVAL, err);
+        ShardView sh{texts[ti], text_lens[ti], 0, 0, true, true};
+        if (int rc = queue.submit(plan, patterns[pi], sh, TextTable{}, (uint32_t)k, all, !wo, text_lens[ti],
+                                  (uint64_t)pi * n_texts + ti)) return rc;
+      }
+    }
+    if (int rc = queue.drain_all()) return rc;
+  }
   // otherwise: text-major (each host text is uploaded once), pattern-major in the result
   for (size_t ti = 0; !handled && ti < n_texts; ++ti) {
     const uint8_t* tptr = texts[ti];

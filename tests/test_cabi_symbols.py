@@ -145,3 +145,18 @@ def test_c_client_compiles_and_links_against_the_headers(tmp_path):
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "sassy_amd", "lib")
     assert subprocess.run([str(tmp_path / "hdr")], env=env).returncode == 0
+
+
+def test_rust_shim_declares_only_exported_symbols(sassy):
+    """bindings/rust/src/lib.rs is source only (no rustc in this image); at least every extern "C" function it
+    declares must be a symbol libsassy_hip.so exports and include/sassy_hip.h (or sassy.h) declares."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    block = src[src.index('extern "C" {'):]
+    block = block[:block.index("\n}\n")]
+    names = re.findall(r"fn\s+(sassy_\w+)\s*\(", block)
+    assert len(names) >= 12
+    hdr = open(os.path.join(ROOT, "include", "sassy_hip.h")).read() + open(os.path.join(ROOT, "include", "sassy.h")).read()
+    L = sassy.lib()
+    for n in names:
+        assert hasattr(L, n), n
+        assert re.search(r"\b" + n + r"\s*\(", hdr), n

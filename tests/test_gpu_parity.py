@@ -1327,6 +1327,117 @@ def test_dna_profile_text_with_other_letters(sassy):
     assert outcomes["same"] >= 30 and outcomes["both_fail"] >= 10, outcomes
 
 
+def test_search_many_on_device_resident_texts(sassy):
+    """search_many with texts that already live in HBM (SASSY_HIP_TEXT_ON_DEVICE): forward searchers keep
+    several (pattern, text) pairs in flight on the searcher's lanes; the result is the pair-by-pair answer in
+    the reference's pattern-major order, for every profile, search_all and without_trace, an empty text and
+    texts of very different lengths; both-strand searchers (pair loop) give the oracle's answer too."""
+    rng = random.Random(23)
+    lens = [70_000, 0, 3_000, 1 << 20, 333, 64, 250_000]
+    offs, total = [], 0
+    for ln in lens:
+        offs.append(total)
+        total += (ln + 15) // 16 * 16 + 64
+    buf = sassy.DeviceBuffer(total + 256)
+    pats = [rand_seq(rng, 32), rand_seq(rng, 20), rand_seq(rng, 48)]
+    texts = []
+    for ln, off in zip(lens, offs):
+        t = bytearray(rand_seq(rng, ln))
+        for p in pats:
+            for _ in range(max(1, ln // 40_000)):
+                if ln > len(p) + 10:
+                    at = rng.randrange(0, ln - len(p) - 5)
+                    ins = mutate(rng, p, rng.randrange(0, 3))
+                    t[at:at + len(ins)] = ins
+        t = bytes(t[:ln])
+        texts.append(t)
+        if ln:
+            buf.upload(t, off)
+    dev = [_DevText(buf.ptr + off, ln) for ln, off in zip(lens, offs)]
+    for profile in ("dna", "iupac", "ascii"):
+        s = sassy.Searcher(profile, rc=False)
+        for allm in (False, True):
+            got = s.search_many(pats, dev, 2, all_minima=allm)
+            want = []
+            for pi, p in enumerate(pats):
+                for ti, t in enumerate(texts):
+                    want += [(pi, ti) + key(m)[1:] for m in oracle.search(profile, p, t, 2, all_minima=allm)]
+            assert [(m.pattern_idx, m.text_idx) + key(m)[1:] for m in got] == want, (profile, allm)
+            assert len(want) > 10
+    both = sassy.Searcher("dna", rc=True)
+    got = both.search_many(pats[:2], dev, 2)
+    want = []
+    for pi, p in enumerate(pats[:2]):
+        for ti, t in enumerate(texts):
+            want += [(pi, ti) + key(m)[1:] for m in oracle.search("dna", p, t, 2, rc=True)]
+    assert [(m.pattern_idx, m.text_idx) + key(m)[1:] for m in got] == want
+    buf.free()
+
+
+def test_reference_lane_reports_mode(sassy):
+    """sassy_hip_set_reference_lanes(4): the reports of the reference binary built for AVX2 -- 4 lanes that each
+    start with decreasing = true (src/search.rs:1016-1056, 1202-1240) -- against the reference-shaped port
+    oracle.refstyle_ends (RS_LANES = 4) on the periodic / low-complexity fixtures where they differ from the
+    definition (the documented artefact: A^20, k = 3 -> an extra (953, 1)), on random text (no difference), with
+    traced records equal to the oracle's traceback of every reported end, through the drop-in symbol with
+    SASSY_HIP_REF_LANES semantics set per searcher, and for both strands."""
+    assert oracle.lib().rs_lanes() == 4
+    rng = random.Random(3)
+    s_def = sassy.Searcher("dna", rc=False)
+    s_ref = sassy.Searcher("dna", rc=False).set_reference_lanes(4)
+    # the documented case (tests/test_oracle_diff.py::test_lane_seam_artefact_documented)
+    pat = b"A" * 20
+    text = b"A" * 92 + (b"C" + b"A" * 19) * 43 + b"G" * 51
+    assert [(m.text_end, m.cost) for m in s_def.search(pat, text, 3)] == [(92, 0)]
+    assert [(m.text_end, m.cost) for m in s_ref.search(pat, text, 3)] == [(92, 0), (953, 1)]
+    differ = 0
+    for it in range(400):
+        m = rng.choice([8, 12, 20, 32, 40, 60, 70, 90])
+        k = min(rng.choice([1, 2, 3, 5, 8]), m - 1)
+        style = 0 if it % 2 == 0 else 1 + (it // 2) % 2
+        if style == 0:
+            sep = rng.choice([b"C", b"CG", b"CCC"])
+            per = rng.choice([m - 1, m, m + 1, m // 2, 2 * m])
+            text = b"A" * rng.randrange(0, 200) + (sep + b"A" * per) * rng.randrange(5, 120) + b"G" * rng.randrange(0, 100)
+            pat = b"A" * m
+        elif style == 1:
+            unit = rand_seq(rng, rng.choice([1, 2, 3, 5]))
+            n = rng.choice([100, 257, 1003, 5000])
+            text, pat = (unit * (n // len(unit) + 1))[:n], (unit * (m // len(unit) + 1))[:m]
+        else:
+            pat = rand_seq(rng, m)
+            text = bytearray(rand_seq(rng, rng.choice([64, 500, 3000, 20000])))
+            for _ in range(3):
+                if len(text) > m + 5:
+                    at = rng.randrange(0, len(text) - m)
+                    text[at:at + m] = pat
+            text = bytes(text)
+        want, _ = oracle.refstyle_ends("dna", pat, text, k)
+        got = s_ref.search(pat, text, k)
+        assert [(x.text_end, x.cost) for x in got] == want, (it, m, k, len(text))
+        plain = [(x.text_end, x.cost) for x in s_def.search(pat, text, k)]
+        differ += plain != want
+        # every record is the traceback of its end position, as the definition's oracle traces that end
+        by_end = {x.text_end: x for x in oracle.search("dna", pat, text, k, all_minima=True)}
+        for x in got:
+            w = by_end[x.text_end]
+            assert (x.text_start, x.cost, x.cigar) == (w.text_start, w.cost, w.cigar), (it, x)
+        wo = s_ref.search_without_trace(pat, text, k)
+        assert [(x.text_end, x.cost) for x in wo] == want
+    assert differ >= 5  # the mode is exercised where it matters (about 5 % of the periodic fixtures)
+    # both strands: the Rc strand is the same lane scheme on the reversed text with complement(pattern)
+    both = sassy.Searcher("dna", rc=True).set_reference_lanes(4)
+    text = b"A" * 92 + (b"C" + b"A" * 19) * 43 + b"G" * 51
+    rc_text = oracle.reverse_complement("dna", text)
+    got = both.search(b"A" * 20, rc_text, 3)
+    fw = [(m.text_end, m.cost) for m in got if m.strand == "+"]
+    rc = [(len(rc_text) - m.text_start, m.cost) for m in got if m.strand == "-"]
+    want_fw, _ = oracle.refstyle_ends("dna", b"A" * 20, rc_text, 3)
+    assert fw == want_fw and rc == [(92, 0), (953, 1)]
+    with pytest.raises(sassy.SassyHipError, match="0, 4 or 8"):
+        s_def.set_reference_lanes(5)
+
+
 # ------------------------------------------------------------------ texts that are not i.i.d.
 def _check_slices(sassy, buf, n, profile, pat, k, r, starts, SL=1 << 20):
     """the matches of a whole-text search that lie inside a few slices, against the oracle on each slice"""

@@ -2,23 +2,48 @@
 # tools/refresh_profiles.sh <round-tag> -- ON THE GPU BOX (via gpurun): every measurement profiles/ holds,
 # written under gpurun_out/refresh/ (copy the files into profiles/ afterwards: tools/collect_profiles.sh).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/refresh
+rm -rf $OUT
 mkdir -p $OUT
+# ---- the bench line (two searches in flight) and the driver's short form of it
 python bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_steps20.json 2>> $OUT/bench.err
+# ---- rocprofv3 of the same command: kernel stats + PMC passes, searches in flight / one at a time
 bash tools/prof.sh $TAG > /dev/null 2>&1
 cp gpurun_out/prof_$TAG/summary.txt $OUT/${TAG}_rocprof_summary.txt
-cp gpurun_out/prof_$TAG/hbm_traffic.json $OUT/hbm_traffic.json
 cp $(ls gpurun_out/prof_$TAG/trace/*kernel_stats.csv gpurun_out/prof_$TAG/trace/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_kernel_stats.csv
+bash tools/prof.sh ${TAG}_one --in-flight 1 > /dev/null 2>&1
+cp gpurun_out/prof_${TAG}_one/summary.txt $OUT/${TAG}_rocprof_summary_one_at_a_time.txt
+cp gpurun_out/prof_${TAG}_one/hbm_traffic.json $OUT/hbm_traffic.json
+# ---- the streaming DP (prefilter off): with and without the row cut-off
+SASSY_HIP_PREFILTER=0 bash tools/prof.sh ${TAG}_scan --in-flight 1 > /dev/null 2>&1
+cp gpurun_out/prof_${TAG}_scan/summary.txt $OUT/${TAG}_scan_kernel_rocprof_summary.txt
+SASSY_HIP_PREFILTER=0 SASSY_HIP_ROW_CUT=0 bash tools/prof.sh ${TAG}_scan_nocut --in-flight 1 > /dev/null 2>&1
+cp gpurun_out/prof_${TAG}_scan_nocut/summary.txt $OUT/${TAG}_scan_kernel_all_rows_rocprof_summary.txt
+{ echo "# streaming DP (SASSY_HIP_PREFILTER=0), BASELINE config 2 and config 3 shapes, row cut-off on / off (SASSY_HIP_ROW_CUT=0)";
+  for cut in 1 0; do for shape in "--profile dna --pattern-len 32 --k 3" "--profile iupac --pattern-len 200 --k 20" "--profile dna --pattern-len 64 --k 6"; do
+    echo "ROW_CUT=$cut $shape"; SASSY_HIP_PREFILTER=0 SASSY_HIP_ROW_CUT=$cut python bench.py $shape --steps 30 --warmup 5 --in-flight 1 --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('   ms_per_search', d['ms_per_step'], 'scan_kernel_ms', d['dominant_kernel_ms'], 'roofline_frac', d['roofline']['frac'], 'matches', d['matches'])"; done; done; } > $OUT/${TAG}_streaming_dp.txt 2>&1
+# ---- searches in flight: depth, filter occupancy, chaining
+{ echo "# python bench.py --steps 400 --warmup 50 (3 GB, config 2): ms per search by searches in flight and switches";
+  for v in "--in-flight 1" "--in-flight 2" "--in-flight 3" "--in-flight 4"; do echo "$v: $(python bench.py --steps 400 --warmup 50 --no-cpu-baseline $v 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')"; done;
+  for e in "SASSY_HIP_FILTER_LDS_PAD=0" "SASSY_HIP_FILTER_LDS_PAD=16384" "SASSY_HIP_FILTER_LDS_PAD=40000" "SASSY_HIP_PIPE_CHAIN=1" "SASSY_HIP_FILTER_LINEAR=8192"; do echo "--in-flight 2 $e: $(env $e python bench.py --steps 400 --warmup 50 --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')"; done; } > $OUT/${TAG}_in_flight.txt 2>&1
+# ---- lane-chunk geometry: default vs the opt-in tuner, lone searches and searches in flight, several text sizes
+{ echo "# bench.py --steps 300 --warmup 60 --tune-searches 40: ms per search (in flight 2) | latency of a lone search; SASSY_HIP_TUNE=1 = opt-in tuner";
+  for n in 1000000000 2000000000 2700000000 3000000000 3700000000 5000000000; do for t in 0 1; do
+    echo "text_bytes $n TUNE=$t: $(SASSY_HIP_TUNE=$t python bench.py --steps 300 --warmup 60 --tune-searches 40 --text-bytes $n --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"single_search_latency_ms": [0-9.]*' | tr '\n' ' ')"; done; done; } > $OUT/${TAG}_geometry_sweep.txt 2>&1
+# ---- other configs, shapes, texts
 python tools/bench_configs.py --configs 1,3,4 --patterns 10000 > $OUT/${TAG}_configs.json 2> $OUT/configs.err
 bash tools/prof_configs.sh cfg > /dev/null 2>&1
 cp gpurun_out/prof_cfg/summary.txt $OUT/${TAG}_configs_prof.txt
+python tools/bench_texts.py > $OUT/${TAG}_texts.json 2> $OUT/texts.err
 { python tools/bench_reads.py; python tools/bench_reads.py --reads 330000; python tools/bench_reads.py --overhang 0.5; } > $OUT/${TAG}_reads.json 2> $OUT/reads.err
 { python tools/probe_count.py; python tools/probe_rc.py; } > $OUT/${TAG}_shapes.json 2> $OUT/shapes.err
-mkdir -p tools/ubench/bin
-[ -x tools/ubench/bin/unaligned_read ] || hipcc --offload-arch=gfx950 -O3 -o tools/ubench/bin/unaligned_read tools/ubench/unaligned_read.hip 2> /dev/null
-./tools/ubench/bin/unaligned_read > $OUT/${TAG}_unaligned_read.txt 2>&1
+python tools/cpu_probe.py > $OUT/${TAG}_host_cpus.txt 2>&1
 tail -2 $OUT/*.err
 ls -la $OUT
