@@ -39,7 +39,22 @@ def build(force: bool = False) -> str:
     if force or stale:
         cmd = ["gcc", "-O3", "-mavx2", "-mbmi2", "-shared", "-fPIC", "-pthread", "-o", _SO] + _SRCS + ["-lm"]
         subprocess.check_call(cmd)
+    if srcs_present:
+        _build_lanes8(force)
     return _SO
+
+
+_SO8 = os.path.join(_BUILD, "liboracle_lanes8.so")
+
+
+def _build_lanes8(force: bool = False) -> str:
+    """The same sources with RS_LANES=8 (the reference's AVX-512 lane count) for the reference-shaped port."""
+    os.makedirs(_BUILD, exist_ok=True)
+    stale = (not os.path.exists(_SO8)) or any(os.path.exists(x) and os.path.getmtime(x) > os.path.getmtime(_SO8) for x in _SRCS)
+    if force or stale:
+        subprocess.check_call(["gcc", "-O3", "-mavx2", "-mbmi2", "-DRS_LANES=8", "-shared", "-fPIC", "-pthread", "-o", _SO8]
+                              + _SRCS + ["-lm"])
+    return _SO8
 
 
 class _OrcMatch(C.Structure):
@@ -57,6 +72,24 @@ class _OrcMatch(C.Structure):
 
 
 _lib = None
+_lib8 = None
+
+
+def lib8():
+    """The same oracle library compiled with RS_LANES=8: the reference's AVX-512 lane count (src/lib.rs:177-185)
+    for the reference-shaped port; only rs_scan / rs_lanes / rs_free are used from it."""
+    global _lib8
+    if _lib8 is not None:
+        return _lib8
+    L = C.CDLL(_build_lanes8() if all(os.path.exists(x) for x in _SRCS) else _SO8)
+    L.rs_scan.restype = C.c_size_t
+    L.rs_scan.argtypes = [C.c_int, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int32, C.c_int,
+                          C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]
+    L.rs_free.restype = None
+    L.rs_free.argtypes = [C.c_void_p]
+    L.rs_lanes.restype = C.c_int
+    _lib8 = L
+    return L
 
 
 def lib():
@@ -238,12 +271,13 @@ def reverse_complement(profile, seq: bytes) -> bytes:
     return buf.raw
 
 
-def refstyle_ends(profile, pattern: bytes, text, k: int, all_minima: bool = False):
-    """The reference-shaped LANES-chunk scan.  Returns ([(end_pos, cost)...], stats) where
-    stats = {'word_rows': .., 'blocks': .., 'lanes': ..}.  `text` may be bytes or a numpy
+def refstyle_ends(profile, pattern: bytes, text, k: int, all_minima: bool = False, lanes: int = 4):
+    """The reference-shaped LANES-chunk scan (lanes = 4: AVX2, 8: AVX-512).  Returns ([(end_pos, cost)...], stats)
+    where stats = {'word_rows': .., 'blocks': .., 'lanes': ..}.  `text` may be bytes or a numpy
     uint8 array (no copy)."""
     import numpy as np
-    L = lib()
+    L = lib() if lanes == 4 else lib8()
+    assert L.rs_lanes() == lanes
     if isinstance(text, (bytes, bytearray)):
         arr = np.frombuffer(text, dtype=np.uint8)
     else:
