@@ -265,6 +265,90 @@ def shard_case(rng, searchers):
     return key(allm) == key(want), desc, pat, t, allm, want
 
 
+def inflight_case(rng, searchers):
+    """Searches in flight (sassy_hip_search_shard_begin / _finish): a burst of random searches over one resident
+    text, two or three in flight, finished in a random order, each against the oracle."""
+    profile = rng.choice(["dna", "iupac"])
+    n = rng.choice([5000, 70_000, 400_000])
+    comp = rng.random()
+    if comp < 0.6:
+        t = bytearray(rand_seq(rng, n, b"ACGT"))
+    else:
+        unit = rand_seq(rng, rng.randrange(1, 30), b"ACGT")
+        t = bytearray((unit * (n // len(unit) + 1))[:n])
+        for _ in range(n // 150):
+            t[rng.randrange(n)] = rng.choice(b"ACGT")
+    jobs = []
+    for _ in range(rng.randrange(2, 7)):
+        m = rng.choice([8, 20, 32, 33, 64, 100, 200])
+        k = min(rng.choice([0, 1, 3, 5, 8, 20]), m // 4)
+        pat = rand_seq(rng, m, b"ACGT")
+        if comp >= 0.6 and rng.random() < 0.5:
+            pat = (unit * (m // len(unit) + 1))[:m]
+        for _ in range(rng.randrange(0, 4)):
+            ins = mutate(rng, pat, rng.randrange(0, k + 1))
+            at = rng.randrange(0, n - len(ins))
+            t[at:at + len(ins)] = ins
+        jobs.append((pat, k, rng.random() < 0.2))
+    t = bytes(t)
+    buf = sassy_amd.DeviceBuffer(n + 256)
+    buf.upload(t)
+    depth = rng.choice([2, 3])
+    s = sassy_amd.Searcher(profile, rc=False).set_pipe_depth(depth)
+    got, pending = {}, []
+    for i, (pat, k, allm) in enumerate(jobs):
+        pending.append((i, s.search_shard_begin(pat, buf.ptr, 0, n, 0, n, k, sassy_amd.ALL_MINIMA if allm else 0)))
+        if len(pending) == depth:
+            j, tk = pending.pop(rng.randrange(len(pending)))
+            got[j] = s.search_finish(tk).matches
+    while pending:
+        j, tk = pending.pop(rng.randrange(len(pending)))
+        got[j] = s.search_finish(tk).matches
+    buf.free()
+    ok, nm = True, 0
+    bad = None
+    for i, (pat, k, allm) in enumerate(jobs):
+        want = oracle.search(profile, pat, t, k, all_minima=allm)
+        nm += len(want)
+        if key(got[i]) != key(want):
+            ok, bad = False, (pat, got[i], want)
+    desc = dict(mode="inflight", profile=profile, n=n, jobs=[(len(p), k, a) for p, k, a in jobs], depth=depth,
+                filtered=s.stats()["filtered"], matches=nm)
+    if not ok:
+        return False, desc, bad[0], t, bad[1], bad[2]
+    return True, desc, b"", t, [], []
+
+
+def reflanes_case(rng, searchers):
+    """The reference-lane reports mode against the reference-shaped port (4 and 8 lanes), periodic and random text."""
+    lanes = rng.choice([4, 8])
+    m = rng.choice([8, 12, 20, 32, 40, 60, 70, 90, 130])
+    k = min(rng.choice([0, 1, 2, 3, 5, 8]), m - 1)
+    style = rng.randrange(3)
+    if style == 0:
+        sep = rng.choice([b"C", b"CG", b"CCC"])
+        per = rng.choice([m - 1, m, m + 1, max(1, m // 2), 2 * m])
+        text = b"A" * rng.randrange(0, 200) + (sep + b"A" * per) * rng.randrange(5, 120) + b"G" * rng.randrange(0, 100)
+        pat = b"A" * m
+    elif style == 1:
+        unit = rand_seq(rng, rng.choice([1, 2, 3, 5]), b"ACGT")
+        n = rng.choice([100, 257, 1003, 5000, 30000])
+        text, pat = (unit * (n // len(unit) + 1))[:n], (unit * (m // len(unit) + 1))[:m]
+    else:
+        pat = rand_seq(rng, m, b"ACGT")
+        text = bytearray(rand_seq(rng, rng.choice([64, 500, 3000, 20000, 100000]), b"ACGT"))
+        for _ in range(3):
+            if len(text) > m + 5:
+                at = rng.randrange(0, len(text) - m)
+                text[at:at + m] = pat
+        text = bytes(text)
+    s = sassy_amd.Searcher("dna", rc=False).set_reference_lanes(lanes)
+    got = [(x.text_end, x.cost) for x in s.search(pat, text, k)]
+    want, _ = oracle.refstyle_ends("dna", pat, text, k, lanes=lanes)
+    desc = dict(mode="reflanes", lanes=lanes, m=m, k=k, n=len(text), style=style, filtered=s.stats()["filtered"], matches=len(want))
+    return got == want, desc, pat, text, got, want
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
@@ -280,9 +364,14 @@ def main():
     total_matches = 0
     while time.time() - t0 < args.seconds:
         mode = rng.random()
-        fn = one_case if mode < 0.55 else many_case if mode < 0.7 else encoded_case if mode < 0.85 else shard_case
+        fn = (one_case if mode < 0.5 else many_case if mode < 0.62 else encoded_case if mode < 0.74 else shard_case
+              if mode < 0.84 else inflight_case if mode < 0.93 else reflanes_case)
         if args.focus == "count":
             fn = count_case
+        if args.focus == "inflight":
+            fn = inflight_case
+        if args.focus == "reflanes":
+            fn = reflanes_case
         ok, desc, pat, text, got, want = fn(rng, searchers)
         cases += 1
         kinds[desc["filtered"]] = kinds.get(desc["filtered"], 0) + 1
@@ -290,7 +379,7 @@ def main():
         if not ok:
             print("MISMATCH", desc)
             print("pattern", pat)
-            gk, wk = (key(got), key(want)) if desc.get("mode") in (None, "shard", "count") else (got, want)
+            gk, wk = (key(got), key(want)) if desc.get("mode") in (None, "shard", "count", "inflight") else (got, want)
             print("got", len(gk), "want", len(wk))
             extra = [x for x in gk if x not in set(wk)][:5]
             missing = [x for x in wk if x not in set(gk)][:5]
