@@ -495,13 +495,15 @@ class Searcher:
         return EncodedPatterns(h, len(patterns), plen)
 
     def search_encoded_patterns(self, encoded: EncodedPatterns, text, k: int,
-                                all_minima: bool = False, as_result: bool = False):
+                                all_minima: bool = False, as_result: bool = False, without_trace: bool = False):
         """Searcher::search_encoded_patterns (src/search.rs:415-423).  as_result: hand back the Result
         (numpy record array + cigar pool) instead of a list of Match objects -- for result sets with
-        10^5 and more matches, where a Python object per match costs more than the search."""
+        10^5 and more matches, where a Python object per match costs more than the search.
+        without_trace: end positions and costs only (text_start = pattern_start = usize::MAX, empty cigar)."""
         addr, n, keep, on_dev = _ptr_len(text)
         out = C.c_void_p()
-        flags = (ALL_MINIMA if all_minima else 0) | (TEXT_ON_DEVICE if on_dev else 0)
+        flags = (ALL_MINIMA if all_minima else 0) | (TEXT_ON_DEVICE if on_dev else 0) | \
+            (WITHOUT_TRACE if without_trace else 0)
         _check(lib().sassy_hip_search_encoded(self._h, encoded._h, addr, n, k, flags, C.byref(out)))
         r = Result(out)
         return r if as_result else r.matches

@@ -29,6 +29,7 @@ UNITS = [
     ("count_filter.hip", "count_filter.o", []),
     ("aux_kernels.hip", "aux_kernels.o", []),
     ("sort_kernels.hip", "sort_kernels.o", []),
+    ("tiled_kernel.hip", "tiled_kernel.o", []),
     ("trace_kernel.hip", "trace_kernel.o", []),
     ("host.hip", "host.o", []),
 ]

@@ -155,6 +155,24 @@ struct ScanParams {
   const uint64_t* texts_len;    // device: its length
 };
 
+// The pattern-tiled scan (tiled_kernel.hip; reference v2, src/pattern_tiling/search.rs:326-425).
+struct TiledParams {
+  const uint8_t* text_aligned;    // text - skew: 64-byte aligned (a block load never leaves the text's pages)
+  uint32_t skew;                  // (address of the text) mod 64
+  uint64_t text_len;
+  const unsigned long long* peq;  // device: [classes][npat_padded], bit j of peq[c][p] = row j of pattern p matches class c
+  uint32_t npat, npat_padded;     // patterns; padded to a multiple of 64
+  uint32_t n_groups;              // npat_padded / 64
+  uint32_t m, k;
+  uint32_t classes;               // 4: Dna codes (c >> 1) & 3; 16: Iupac base-set nibbles
+  uint32_t chunk;                 // bytes of the aligned array a wave owns (a multiple of 64)
+  uint32_t warm_blocks;           // 64-byte blocks in front of a chunk: 64 * warm_blocks >= m + k
+  uint64_t n_chunks;              // ceil((skew + text_len) / chunk)
+  Candidate* cand;                // {pos, cost, flags = pattern << kCandTextShift}
+  uint32_t* cand_count;
+  uint32_t cand_cap;
+};
+
 // A finished match record as the trace kernel writes it; same layout as sassy_hip_Match
 // (include/sassy_hip.h).  64 bytes.
 struct MatchOut {
@@ -183,6 +201,8 @@ struct TraceParams {
   uint32_t m, k;
   uint32_t profile;
   const uint8_t* pattern;   // device copy of the (strand-specific) pattern
+  uint32_t pattern_stride;  // != 0: many patterns of m bytes each, pattern_stride bytes apart; a report's pattern is
+                            // flags >> kCandTextShift (single-text buffers only) and goes into its row's pattern_idx
   uint8_t* scratch;         // nthreads * scratch_stride bytes (used when the slices do not fit LDS)
   uint32_t scratch_stride;  // bytes per thread: band | window | ops | cigar text
   uint32_t band_bytes;      // (m+1) * (2k+3) * sizeof(cell), rounded up to 4

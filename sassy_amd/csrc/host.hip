@@ -61,7 +61,11 @@ hipError_t launch_rank(const Candidate* d_cand, const uint32_t* d_count, uint32_
 
 size_t sort_scratch_bytes(uint32_t count);
 hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, uint32_t count, void* d_scratch,
-                                  size_t scratch_bytes, hipStream_t stream);
+                                  size_t scratch_bytes, hipStream_t stream, int by_tag = 0);
+size_t select_scratch_bytes(uint32_t count);
+hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Candidate* d_sel, uint32_t* d_sel_count,
+                                 void* d_scratch, size_t scratch_bytes, hipStream_t stream);
+hipError_t launch_tiled_scan(const TiledParams& P, hipStream_t stream);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -390,6 +394,11 @@ struct sassy_SearcherType {
   DevBuf<uint64_t> d_tables;     // multi-text buffers: start / len tables (both strands)
   DevBuf<unsigned long long> d_multi_bitmap;  // multi-pattern prefilter: one hit bitmap per pattern of the batch
   DevBuf<uint32_t> d_multi_bits;
+  // pattern-tiled search (search_encoded_tiled): match masks, the patterns' bytes, counters, the selected reports
+  DevBuf<unsigned long long> d_tiled_peq;
+  DevBuf<uint8_t> d_tiled_pat;
+  DevBuf<uint32_t> d_tiled_cnt;
+  DevBuf<Candidate> d_tiled_sel;
   hipEvent_t ev_multi = nullptr, ev_multi_a = nullptr;
   hipEvent_t ev_a_multi() { return ev_multi_a; }
   DevBuf<uint64_t> d_range;      // N counting on device-resident text
@@ -406,6 +415,7 @@ struct sassy_SearcherType {
     d_text.release(); d_rev.release(); d_rc_bitmap.release();
     free_stage();
     d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
+    d_tiled_peq.release(); d_tiled_pat.release(); d_tiled_cnt.release(); d_tiled_sel.release();
     if (ev_multi) (void)hipEventDestroy(ev_multi);
     if (ev_multi_a) (void)hipEventDestroy(ev_multi_a);
     for (ScanLane& l : lanes) l.destroy();
@@ -971,7 +981,7 @@ int ScanJob::prepare() {
     const uint64_t pat_bytes = ((uint64_t)plan.m + 15) / 16 * 16;
     static const int env_wave = getenv("SASSY_HIP_TRACE_WAVE") ? atoi(getenv("SASSY_HIP_TRACE_WAVE")) : 1;
     const uint64_t wstride = (raw + 15) / 16 * 16;
-    use_wave = env_wave != 0 && 2ull * k + 3 <= 64 && pat_bytes + 4 * wstride <= 160 * 1024;
+    use_wave = env_wave != 0 && 2ull * k + 3 <= 64 && 4 * pat_bytes + 4 * wstride <= 160 * 1024;
     use_thread = !use_wave || (k <= 6 && !overhang);  // overhang: wave shape or the generic thread shape
     uint64_t stride = raw;
     if ((stride / 4) % 2 == 0) stride += 4;  // odd number of LDS words: conflict-free slices
@@ -2167,6 +2177,214 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
   return 0;
 }
 
+// search_encoded_patterns in ONE pass: the pattern-tiled scan (tiled_kernel.hip; reference v2,
+// src/pattern_tiling/search.rs:326-425 + general.rs:335-404).  All (rc-expanded) patterns advance together over
+// the text, 64 per wavefront; the kernel lists every (pattern, end position) with cost <= k, the device sorts the
+// list by (pattern, position), applies the report rule to each run (sort_kernels.hip: flag_reports_kernel) and
+// traces the reports (trace_wave_kernel with one pattern per report).  *done = false: too many end positions for
+// this shape (k close to m on a long text) -- the caller runs one scan per pattern instead.
+static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
+                                const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
+                                sassy_hip_Result* R, bool* done) {
+  *done = false;
+  ScanLane& L = s->lanes[0];
+  const size_t npat = e->patterns.size();
+  const uint32_t m = (uint32_t)e->plen;
+  std::string err;
+  PatternPlan plan0;
+  for (size_t p = 0; p < npat; ++p) {  // what the reference's encode would reject (tqueries.rs:60-65, iupac.rs:19-24)
+    PatternPlan pl;
+    if (!make_plan(s->profile, e->patterns[p].data(), m, p == 0 ? plan0 : pl, err)) return fail(SASSY_HIP_EINVAL, err);
+  }
+  // ---- match masks: bit j of peq[class][pattern] = row j of the pattern matches a text character of that class ----
+  const uint32_t classes = s->profile == PROFILE_DNA ? 4u : 16u;
+  const uint32_t npad = (uint32_t)((npat + 63) / 64 * 64);
+  std::vector<unsigned long long> peq((size_t)classes * npad, 0ull);
+  std::vector<uint8_t> flat(npat * (size_t)m);
+  for (size_t p = 0; p < npat; ++p) {
+    const uint8_t* pt = e->patterns[p].data();
+    memcpy(&flat[p * m], pt, m);
+    for (uint32_t j = 0; j < m; ++j) {
+      if (classes == 4) {
+        peq[(size_t)((pt[j] >> 1) & 3u) * npad + p] |= 1ull << j;  // src/profiles/dna.rs:19-40
+      } else {
+        const uint32_t set = iupac_code(pt[j]) & 0x0Fu;              // src/profiles/iupac.rs:18-36
+        for (uint32_t c = 1; c < 16; ++c)
+          if (set & c) peq[(size_t)c * npad + p] |= 1ull << j;
+      }
+    }
+  }
+  if (int rc = s->d_tiled_peq.reserve(peq.size())) return rc;
+  if (int rc = s->d_tiled_pat.reserve(flat.size() + 64)) return rc;
+  if (int rc = s->d_tiled_cnt.reserve(16)) return rc;
+  hipStream_t st = s->stream;
+  HIP_TRY(hipMemcpyAsync(s->d_tiled_peq.p, peq.data(), peq.size() * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(s->d_tiled_pat.p, flat.data(), flat.size(), hipMemcpyHostToDevice, st));
+
+  TiledParams P{};
+  P.skew = (uint32_t)((uintptr_t)tptr & 63u);
+  P.text_aligned = tptr - P.skew;
+  P.text_len = text_len;
+  P.peq = s->d_tiled_peq.p;
+  P.npat = (uint32_t)npat;
+  P.npat_padded = npad;
+  P.n_groups = npad / 64;
+  P.m = m;
+  P.k = k;
+  P.classes = classes;
+  P.warm_blocks = (m + k + 63) / 64;
+  {
+    const uint64_t span = (uint64_t)P.skew + text_len;
+    const uint64_t waves_wanted = 16384;
+    const uint64_t chunks_wanted = std::max<uint64_t>(1, waves_wanted / P.n_groups);
+    uint64_t chunk = std::max<uint64_t>(512, (span + chunks_wanted - 1) / chunks_wanted);
+    chunk = std::min<uint64_t>((chunk + 63) / 64 * 64, 1u << 20);
+    P.chunk = (uint32_t)chunk;
+    P.n_chunks = (span + chunk - 1) / chunk;
+  }
+  const uint64_t kMaxList = 1ull << 26;  // 1 GiB of (pattern, position, cost) records: beyond that, per-pattern scans
+  uint32_t counts[2] = {0, 0};
+  for (int attempt = 0;; ++attempt) {
+    if (int rc = L.d_cand.reserve(std::max<size_t>((size_t)1 << 18, (size_t)counts[0] + 1024))) return rc;
+    P.cand = L.d_cand.p;
+    P.cand_cap = (uint32_t)std::min<size_t>(L.d_cand.cap, 0xFFFFFFFFu);
+    P.cand_count = s->d_tiled_cnt.p;
+    HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p, 0, 64, st));
+    HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
+    hipError_t le = launch_tiled_scan(P, st);
+    if (le != hipSuccess) return hip_fail(le, "pattern-tiled scan launch");
+    HIP_TRY(hipEventRecord(s->ev_multi, st));
+    HIP_TRY(hipMemcpyAsync(counts, s->d_tiled_cnt.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
+    s->stats.scan_ms += ms;
+    s->stats.scan_launches += 1;
+    if (counts[0] <= P.cand_cap) break;
+    if (counts[0] > kMaxList || attempt == 2) return 0;  // *done stays false
+  }
+  const uint32_t count = counts[0];
+  s->stats.text_bytes += text_len;
+  s->stats.chunks += P.n_chunks * P.n_groups;
+  s->stats.filtered = 5;
+  s->stats.candidates += count;
+  *done = true;
+  if (count == 0) return 0;
+
+  // ---- (pattern, position) order, then the report rule ----
+  if (int rc = L.d_sorted.reserve(count)) return rc;
+  if (int rc = L.d_sort.reserve(std::max(sort_scratch_bytes(count), select_scratch_bytes(count)))) return rc;
+  hipError_t le = launch_sort_candidates(L.d_cand.p, L.d_sorted.p, count, L.d_sort.p, L.d_sort.cap, st, 1);
+  if (le != hipSuccess) return hip_fail(le, "report sort launch");
+  const Candidate* d_rep = L.d_sorted.p;
+  uint32_t n_rep = count;
+  if (!all) {
+    if (int rc = s->d_tiled_sel.reserve(count)) return rc;
+    le = launch_select_reports(L.d_sorted.p, count, s->d_tiled_sel.p, s->d_tiled_cnt.p + 1, L.d_sort.p, L.d_sort.cap, st);
+    if (le != hipSuccess) return hip_fail(le, "report selection launch");
+    HIP_TRY(hipMemcpyAsync(counts + 1, s->d_tiled_cnt.p + 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    d_rep = s->d_tiled_sel.p;
+    n_rep = counts[1];
+  } else {
+    HIP_TRY(hipMemcpyAsync(s->d_tiled_cnt.p + 1, &count, 4, hipMemcpyHostToDevice, st));
+  }
+  if (n_rep == 0) return 0;
+
+  // ---- traceback: one wavefront per report, the report's pattern comes with it ----
+  std::vector<Candidate> reps(n_rep);
+  std::vector<sassy_hip_Match> rows;
+  std::string pool;
+  uint32_t str_stride = 0;
+  if (!wo) {
+    const uint64_t band = ((uint64_t)(m + 1) * (2ull * k + 3) + 3) / 4 * 4;
+    const uint64_t win = ((uint64_t)m + k + 15 + 15) / 16 * 16;
+    const uint64_t opsb = ((uint64_t)m + k + 1 + 3) / 4 * 4;
+    const uint64_t strb = ((2ull * (m + k + 1) + 2 + 15) / 16 * 16);
+    const uint64_t wstride = (band + win + opsb + strb + 15) / 16 * 16;
+    str_stride = (uint32_t)strb;
+    if ((uint64_t)n_rep * strb > 0xFFFFFFFFull)
+      return fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB");
+    if (int rc = L.d_trace.reserve(n_rep)) return rc;
+    if (int rc = L.d_str.reserve((size_t)n_rep * strb)) return rc;
+    TraceParams T{};
+    T.text = tptr;
+    T.total_len = text_len;
+    T.cand = d_rep;
+    T.cand_count = s->d_tiled_cnt.p + 1;
+    T.cand_cap = n_rep;
+    T.m = m;
+    T.k = k;
+    T.profile = (uint32_t)s->profile;
+    T.pattern = s->d_tiled_pat.p;
+    T.pattern_stride = m;
+    T.scratch_stride = (uint32_t)wstride;
+    T.band_bytes = (uint32_t)band;
+    T.win_bytes = (uint32_t)win;
+    T.out = L.d_trace.p;
+    T.out_str = L.d_str.p;
+    T.str_stride = str_stride;
+    T.ops_bytes = (uint32_t)opsb;
+    T.wave_mode = 1;
+    T.count_min = 0;
+    T.count_max = 0xFFFFFFFFu;
+    T.max_overhang = 0xFFFFFFFFu;
+    HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
+    le = launch_trace(T, (uint32_t)std::min<uint64_t>(1024, ((uint64_t)n_rep + 3) / 4), st);
+    if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
+    HIP_TRY(hipEventRecord(s->ev_multi, st));
+    rows.resize(n_rep);
+    pool.resize((size_t)n_rep * strb);
+    if (int rc = L.download(rows.data(), L.d_trace.p, (size_t)n_rep * sizeof(MatchOut))) return rc;
+    if (int rc = L.download(&pool[0], L.d_str.p, pool.size())) return rc;
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
+    s->stats.trace_ms += ms;
+    for (const sassy_hip_Match& r : rows)
+      if (r.pad_[0] == kTraceFailed)
+        return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
+  }
+  if (int rc = L.download(reps.data(), d_rep, (size_t)n_rep * sizeof(Candidate))) return rc;
+
+  // ---- per pattern: the searcher's report filters, then the records ----
+  const bool filters = !std::isnan(s->max_n_frac) || s->only_best;
+  if (!filters && !wo) {  // the records are finished: adopt them
+    R->matches.swap(rows);
+    R->pool.swap(pool);
+    for (size_t i = 0; i < R->matches.size(); ++i) {
+      sassy_hip_Match& r = R->matches[i];
+      const uint64_t p = r.pattern_idx;
+      r.pattern_idx = p % e->n_original;
+      r.strand = p >= e->n_original ? 1 : 0;
+    }
+    return 0;
+  }
+  size_t i0 = 0;
+  while (i0 < n_rep) {
+    const uint32_t p = reps[i0].flags >> kCandTextShift;
+    size_t i1 = i0;
+    while (i1 < n_rep && (reps[i1].flags >> kCandTextShift) == p) ++i1;
+    ScanOut so;
+    so.cands.assign(reps.begin() + i0, reps.begin() + i1);
+    for (Candidate& c : so.cands) c.flags = 0;
+    if (!wo) {
+      so.matches.assign(rows.begin() + i0, rows.begin() + i1);
+      // the records' cigar offsets point into the whole pool: keep it whole for this pattern's rebase
+      so.pool.assign(pool, (size_t)i0 * str_stride, (size_t)(i1 - i0) * str_stride);
+      for (sassy_hip_Match& r : so.matches) r.cigar_off -= (uint32_t)(i0 * str_stride);
+    }
+    if (int rc = post_filter(s, so, plan0, e->patterns[p].data(), k, 0, h_text, tptr, text_len, !wo, EndFilter())) return rc;
+    size_t first = 0;
+    if (int rc = append_matches(so, text_len, plan0, wo, p % e->n_original, R, first)) return rc;
+    for (size_t i = first; i < R->matches.size(); ++i) {
+      R->matches[i].pattern_idx = p % e->n_original;
+      R->matches[i].strand = p >= e->n_original ? 1 : 0;
+    }
+    i0 = i1;
+  }
+  return 0;
+}
+
 static void reset_stats(sassy_SearcherType* S) { S->stats = sassy_hip_Stats{}; }
 
 }  // namespace sassy_hip
@@ -3065,8 +3283,23 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
     const uint32_t mq = (uint32_t)std::min<size_t>(e->plen / (k + 1), 12);
     const bool multi = s->profile == PROFILE_DNA && std::isnan(s->alpha) && e->patterns.size() >= 8 && k + 1 <= 8 &&
                        mq >= 6 && text_len >= multi_min && (((uintptr_t)tptr) & 15) == 0;
+    // Many patterns, short or medium text: the pattern-tiled scan does all of them in one pass, where one
+    // scan per pattern pays 40-65 us of launches each.  Measured (tools/bench_encoded.py, 20-mers, k = 2): the
+    // tiled kernel advances 3.8e10 (character x group of 64 patterns) per second; 1 000 / 10 000 patterns break
+    // even with the per-pattern paths at ~100 MB of text (SASSY_HIP_TILED=0 / 1 forces the choice).
+    const int env_tiled = getenv("SASSY_HIP_TILED") ? atoi(getenv("SASSY_HIP_TILED")) : -1;  // (read per call: tests flip it)
+    const double tiled_budget = getenv("SASSY_HIP_TILED_BUDGET") ? atof(getenv("SASSY_HIP_TILED_BUDGET")) : 1.5e6;
+    const bool tiled_ok = s->profile != PROFILE_ASCII && std::isnan(s->alpha) && 2 * k + 3 <= 64 &&
+                          e->patterns.size() < (1u << 24) && text_len < (1ull << 40);
+    const uint64_t tiled_groups = (e->patterns.size() + 63) / 64;
+    bool tiled = tiled_ok && e->patterns.size() >= 2 &&
+                 (double)text_len * (double)tiled_groups <= tiled_budget * (double)e->patterns.size();
+    if (env_tiled >= 0) tiled = tiled_ok && env_tiled != 0;
+    bool tiled_done = false;
+    if (tiled)
+      if (int rc = search_encoded_tiled(s, e, tptr, h_text, text_len, (uint32_t)k, all, wo, R, &tiled_done)) return rc;
     const size_t batch = multi ? 64 : 1;
-    for (size_t p0 = 0; p0 < e->patterns.size(); p0 += batch) {
+    for (size_t p0 = 0; p0 < (tiled_done ? 0 : e->patterns.size()); p0 += batch) {
       const size_t nb = std::min(batch, e->patterns.size() - p0);
       unsigned long long* bm_base = nullptr;
       uint64_t bm_stride = 0;

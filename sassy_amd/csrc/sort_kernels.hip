@@ -15,10 +15,39 @@ namespace sassy_hip {
 
 namespace {
 __global__ __launch_bounds__(256) void sort_keys_kernel(const Candidate* __restrict__ cand, uint32_t count,
-                                                        unsigned long long* __restrict__ keys) {
+                                                        unsigned long long* __restrict__ keys, int by_tag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  // multi-text buffers never come here; end positions are unique within one search of one strand
-  if (i < count) keys[i] = cand[i].pos;
+  // multi-text buffers never come here; end positions are unique within one search of one strand.
+  // by_tag (the pattern-tiled search): the flags' upper 24 bits name the pattern -- (pattern, position) order
+  if (i < count)
+    keys[i] = by_tag ? ((unsigned long long)(cand[i].flags >> kCandTextShift) << 40) | cand[i].pos : cand[i].pos;
+}
+
+// The reference's report rule on a complete, (pattern, position)-sorted list of ALL end positions with cost <= k
+// (src/search.rs:1310-1368): inside a run of consecutive positions of one pattern, the rightmost position of
+// every plateau that was entered by a decrease and is left by an increase.  A run starts and ends next to a
+// cost > k, so its first plateau counts as entered by a decrease and its last as left by an increase.
+__global__ __launch_bounds__(256) void flag_reports_kernel(const Candidate* __restrict__ c, uint32_t count,
+                                                           unsigned char* __restrict__ keep) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const Candidate me = c[i];
+  const uint32_t tag = me.flags >> kCandTextShift;
+  bool report = true;
+  if (i + 1 < count) {
+    const Candidate nx = c[i + 1];
+    if ((nx.flags >> kCandTextShift) == tag && nx.pos == me.pos + 1 && nx.cost <= me.cost) report = false;
+  }
+  if (report) {  // walk to the left end of the plateau
+    uint64_t pos = me.pos;
+    for (uint32_t j = i; j > 0; --j) {
+      const Candidate pv = c[j - 1];
+      if ((pv.flags >> kCandTextShift) != tag || pv.pos + 1 != pos) break;  // start of the run
+      if (pv.cost != me.cost) { report = pv.cost > me.cost; break; }
+      pos = pv.pos;
+    }
+  }
+  keep[i] = report ? 1 : 0;
 }
 }  // namespace
 
@@ -31,9 +60,9 @@ size_t sort_scratch_bytes(uint32_t count) {
   return 2 * ((size_t)count * 8 + 256) + temp + 256;
 }
 
-// sorted[0 .. count) = cand[0 .. count) by ascending end position.
+// sorted[0 .. count) = cand[0 .. count) by ascending end position (by_tag: by (flags >> 8, end position)).
 hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, uint32_t count, void* d_scratch,
-                                  size_t scratch_bytes, hipStream_t stream) {
+                                  size_t scratch_bytes, hipStream_t stream, int by_tag) {
   if (count == 0) return hipSuccess;
   const size_t key_bytes = ((size_t)count * 8 + 255) / 256 * 256;
   if (scratch_bytes < 2 * key_bytes) return hipErrorInvalidValue;
@@ -41,10 +70,34 @@ hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, 
   unsigned long long* keys_out = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(d_scratch) + key_bytes);
   void* temp = static_cast<unsigned char*>(d_scratch) + 2 * key_bytes;
   size_t temp_bytes = scratch_bytes - 2 * key_bytes;
-  hipLaunchKernelGGL(sort_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_cand, count, keys_in);
+  hipLaunchKernelGGL(sort_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_cand, count, keys_in, by_tag);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, d_cand, d_sorted, (size_t)count, 0, 64, stream);
+}
+
+// Bytes of scratch launch_select_reports needs.
+size_t select_scratch_bytes(uint32_t count) {
+  size_t temp = 0;
+  (void)rocprim::select(nullptr, temp, static_cast<Candidate*>(nullptr), static_cast<unsigned char*>(nullptr),
+                        static_cast<Candidate*>(nullptr), static_cast<uint32_t*>(nullptr), (size_t)count,
+                        hipStream_t(nullptr));
+  return ((size_t)count + 255) / 256 * 256 + temp + 256;
+}
+
+// sel[0 .. *sel_count) = the reports among sorted[0 .. count) (flag_reports_kernel), order kept.
+hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Candidate* d_sel, uint32_t* d_sel_count,
+                                 void* d_scratch, size_t scratch_bytes, hipStream_t stream) {
+  if (count == 0) return hipMemsetAsync(d_sel_count, 0, 4, stream);
+  const size_t flag_bytes = ((size_t)count + 255) / 256 * 256;
+  if (scratch_bytes < flag_bytes) return hipErrorInvalidValue;
+  unsigned char* keep = static_cast<unsigned char*>(d_scratch);
+  void* temp = keep + flag_bytes;
+  size_t temp_bytes = scratch_bytes - flag_bytes;
+  hipLaunchKernelGGL(flag_reports_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_sorted, count, keep);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return rocprim::select(temp, temp_bytes, d_sorted, keep, d_sel, d_sel_count, (size_t)count, stream);
 }
 
 }  // namespace sassy_hip

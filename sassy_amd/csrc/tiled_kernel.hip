@@ -1,0 +1,158 @@
+// tiled_kernel.hip -- K2: the pattern-tiled scan of search_encoded_patterns (reference "v2":
+// src/pattern_tiling/search.rs:148-175 myers_step, :326-425 search_ranges, tqueries.rs:53-134 peq tables).
+//
+// The reference's v2 turns the DP around: bits run along the PATTERN (<= 64 rows in one word), one pattern per
+// SIMD lane, every lane consumes the same text character per step.  On a wavefront that is: lane = one pattern
+// (64 per wave), the character class of the text byte is wave-uniform, the lane fetches ITS pattern's match mask
+// for that class (peq) from LDS and advances the classic Myers column step; the last-row cost is tracked per
+// lane and every end position with cost <= k is appended as a candidate {pattern, position, cost}.
+//
+// Where the reference walks the whole text with each block of LANES patterns, the grid here is
+// (text chunks) x (groups of 64 patterns): a wave starts m + k characters left of its chunk with the fresh
+// column (Vp = 1^m, cost = m) -- after m + k characters every value <= k is exact -- and owns
+// the end positions inside its chunk.  Runs of positions <= k are complete in the candidate list whatever the
+// chunking (chunks own disjoint position ranges), so the host applies the report rule to each run exactly, with
+// no seam bookkeeping (host.hip: search_encoded_tiled).
+//
+// Used where the pigeonhole prefilter path (filter_dna_multi_kernel: one pass per 64 patterns at HBM speed plus
+// chains per pattern) does not apply or is launch-bound: many patterns on short / medium texts, texts with
+// non-ACGT letters.  Cost: ~30 VALU per (character, 64 patterns) -- integer-VALU bound, no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace sassy_hip {
+
+// IUPAC letter (5 low bits) -> base set nibble; non-letters act as N (reference v1 scan semantics,
+// src/profiles/iupac.rs:281-330), X = 0.
+__constant__ uint8_t kTiledIupacNib[32] = {
+    15, 1, 14, 2, 13, 15, 15, 8, 7, 15, 15, 12, 15, 3, 15, 15,
+    15, 15, 9, 10, 4, 4, 11, 5, 0, 6, 15, 15, 15, 15, 15, 15};
+
+// One text character for the 64 patterns of a wave: the Myers column step with the bits along the pattern
+// (src/pattern_tiling/search.rs:148-175), the last row's cost tracked in `cost`.
+template <typename Word>
+struct TiledState {
+  Word vp, vn;
+  int cost;
+};
+template <typename Word>
+__device__ __forceinline__ void tiled_step(TiledState<Word>& S, const Word eq, const uint32_t top_shift) {
+  const Word sum = (eq & S.vp) + S.vp;
+  const Word xh = (sum ^ S.vp) | eq;
+  const Word mh = S.vp & xh;
+  const Word ph = S.vn | ~(xh | S.vp);
+  // (the top row sits in the upper half of a 64-bit word: WORDS = 2 is used for m > 32 only)
+  const uint32_t pht = sizeof(Word) == 8 ? (uint32_t)((unsigned long long)ph >> 32) : (uint32_t)ph;
+  const uint32_t mht = sizeof(Word) == 8 ? (uint32_t)((unsigned long long)mh >> 32) : (uint32_t)mh;
+  S.cost += (int)__builtin_amdgcn_ubfe(pht, top_shift, 1u) + __builtin_amdgcn_sbfe((int)mht, top_shift, 1u);
+  const Word phs = ph << 1;  // the row above the pattern is free: 0 shifted in
+  S.vp = (mh << 1) | ~(eq | S.vn | phs);
+  S.vn = phs & (eq | S.vn);
+}
+
+__device__ __forceinline__ void tiled_emit(const TiledParams& P, uint64_t pos, int cost, uint32_t pat) {
+  const uint32_t idx = atomicAdd(P.cand_count, 1u);
+  if (idx < P.cand_cap) P.cand[idx] = Candidate{pos, cost, pat << kCandTextShift};
+}
+
+// WORDS = 1: patterns of <= 32 rows (one 32-bit word), 2: 33 .. 64 rows.
+//
+// Coordinates: y = text position + skew indexes the 64-byte-aligned array text_aligned = text - skew, so that
+// every wave step loads one aligned 64-byte block (one byte per lane); the chunks a wave owns are whole blocks
+// of y.  Character y is followed by end position y - skew + 1.
+template <int WORDS>
+__global__ __launch_bounds__(256) void tiled_scan_kernel(const TiledParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tsmem[];
+  typedef typename std::conditional<WORDS == 1, uint32_t, unsigned long long>::type Word;
+  constexpr uint32_t kShift = WORDS == 1 ? 8u : 9u;  // one class = 64 lanes x sizeof(Word) bytes of LDS
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint64_t w = (uint64_t)blockIdx.x * kWavesPerGroup + wave;
+  const uint64_t chunk = w / P.n_groups;
+  const uint32_t group = (uint32_t)(w % P.n_groups);
+  if (chunk >= P.n_chunks) return;  // wave-uniform
+  const uint32_t pat = group * 64u + lane;
+  const bool valid = pat < P.npat;
+  // this wave's match masks: [class][lane]
+  unsigned char* wave_lds = tsmem + ((size_t)wave * P.classes << kShift);
+  Word* peq = reinterpret_cast<Word*>(wave_lds);
+  for (uint32_t c = 0; c < P.classes; ++c) {
+    const unsigned long long v = valid ? P.peq[(size_t)c * P.npat_padded + pat] : 0ull;
+    peq[c * 64u + lane] = (Word)v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned char* lane_lds = wave_lds + lane * sizeof(Word);
+
+  const uint32_t m = P.m;
+  const int kk = valid ? (int)P.k : (int)0x80000000;  // lanes without a pattern never report
+  const uint32_t skew = P.skew;
+  const uint64_t end_y = (uint64_t)skew + P.text_len;
+  const uint64_t own_lo = chunk * (uint64_t)P.chunk;
+  const uint64_t own_hi = own_lo + P.chunk < end_y ? own_lo + P.chunk : end_y;
+  const uint64_t warm = (uint64_t)P.warm_blocks * 64u;
+  const uint64_t first = own_lo > warm ? own_lo - warm : 0;  // first block processed (0: the text starts in it)
+  const uint32_t top_shift = (m - 1u) & 31u;
+  TiledState<Word> S;
+  S.vp = m >= 8 * sizeof(Word) ? (Word)~(Word)0 : (Word)(((Word)1 << m) - 1);
+  S.vn = 0;
+  S.cost = (int)m;
+  if (chunk == 0 && S.cost <= kk) tiled_emit(P, 0ull, S.cost, pat);  // end position 0 (only when m <= k)
+
+  for (uint64_t yb = first; yb < own_hi; yb += 64) {
+    // 64 text bytes, one per lane -> LDS offsets of their character classes
+    const uint32_t ch = P.text_aligned[yb + lane];
+    uint32_t off;
+    if (P.classes == 4) off = ((ch >> 1) & 3u) << kShift;   // Dna code (src/profiles/dna.rs:19-40)
+    else off = (uint32_t)kTiledIupacNib[ch & 31u] << kShift;  // Iupac base set
+    const uint32_t u0 = yb == 0 ? skew : 0u;
+    const uint32_t u1 = end_y - yb < 64 ? (uint32_t)(end_y - yb) : 64u;
+    const bool owned = yb >= own_lo;
+    const uint64_t pos0 = yb - skew + 1;  // end position behind character u = 0 of this block
+    if (u0 == 0 && u1 == 64) {
+      // whole block: eight characters' masks are fetched ahead of the eight (dependent) column steps
+#pragma unroll
+      for (uint32_t g = 0; g < 64; g += 8) {
+        Word eq[8];
+#pragma unroll
+        for (uint32_t i = 0; i < 8; ++i)
+          eq[i] = *reinterpret_cast<const Word*>(lane_lds + (uint32_t)__builtin_amdgcn_readlane((int)off, (int)(g + i)));
+        if (owned) {
+#pragma unroll
+          for (uint32_t i = 0; i < 8; ++i) {
+            tiled_step(S, eq[i], top_shift);
+            if (S.cost <= kk) tiled_emit(P, pos0 + g + i, S.cost, pat);
+          }
+        } else {  // warm-up: nothing is reported
+#pragma unroll
+          for (uint32_t i = 0; i < 8; ++i) tiled_step(S, eq[i], top_shift);
+        }
+      }
+    } else {  // the block the text starts or ends in
+      for (uint32_t u = u0; u < u1; ++u) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)u);
+        tiled_step(S, *reinterpret_cast<const Word*>(lane_lds + o), top_shift);
+        if (owned && S.cost <= kk) tiled_emit(P, pos0 + u, S.cost, pat);
+      }
+    }
+  }
+}
+
+hipError_t launch_tiled_scan(const TiledParams& P, hipStream_t stream) {
+  const uint64_t waves = P.n_chunks * (uint64_t)P.n_groups;
+  const uint64_t groups = (waves + kWavesPerGroup - 1) / kWavesPerGroup;
+  if (groups == 0) return hipSuccess;
+  if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  if (P.m <= 32) {
+    const size_t lds = (size_t)kWavesPerGroup * P.classes * 64u * 4u;
+    hipLaunchKernelGGL((tiled_scan_kernel<1>), dim3((uint32_t)groups), dim3(256), lds, stream, P);
+  } else {
+    const size_t lds = (size_t)kWavesPerGroup * P.classes * 64u * 8u;
+    hipLaunchKernelGGL((tiled_scan_kernel<2>), dim3((uint32_t)groups), dim3(256), lds, stream, P);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace sassy_hip

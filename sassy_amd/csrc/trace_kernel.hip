@@ -138,9 +138,9 @@ __device__ __forceinline__ int ov_left(const TraceParams& P, int j) {
 
 __device__ __forceinline__ MatchOut make_row(const TraceParams& P, uint32_t c, const Window& win, uint64_t text_start,
                                              int cost, uint32_t len, bool ok, uint32_t pattern_start = 0,
-                                             uint32_t pattern_end = 0xFFFFFFFFu) {
+                                             uint32_t pattern_end = 0xFFFFFFFFu, uint32_t pattern_idx = 0) {
   MatchOut r;
-  r.pattern_idx = 0;
+  r.pattern_idx = pattern_idx;
   r.text_idx = win.text_idx;
   r.text_start = text_start - win.base;
   r.text_end = win.we - win.base;
@@ -385,15 +385,19 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
   const int inf = k + 1;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const CharRule rule = char_rule(P.profile);
-  // LDS: pattern codes (shared) | per wave: band rows | window | ops
-  unsigned char* spat = trace_smem;
+  // LDS: per wave: pattern codes | then per wave: band rows | window | ops.  With many patterns
+  // (pattern_stride != 0: the pattern-tiled search) a report brings its own pattern, loaded per report.
   const uint32_t pat_bytes = (P.m + 15u) & ~15u;
-  for (uint32_t x = threadIdx.x; x < P.m; x += blockDim.x) {
-    const uint32_t ch = P.pattern[x];
-    spat[x] = (unsigned char)(rule.iupac ? kIupacCode[ch & 31u] : ch);
-  }
-  __syncthreads();
-  unsigned char* slice = trace_smem + pat_bytes + (size_t)wave * P.scratch_stride;
+  unsigned char* spat = trace_smem + (size_t)wave * pat_bytes;
+  auto load_pattern = [&](const uint8_t* src) {
+    for (uint32_t x = lane; x < P.m; x += 64u) {
+      const uint32_t ch = src[x];
+      spat[x] = (unsigned char)(rule.iupac ? kIupacCode[ch & 31u] : ch);
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  if (P.pattern_stride == 0) load_pattern(P.pattern);
+  unsigned char* slice = trace_smem + 4u * pat_bytes + (size_t)wave * P.scratch_stride;
   Cell* L = reinterpret_cast<Cell*>(slice);
   unsigned char* win = slice + P.band_bytes;
   unsigned char* ops = slice + P.band_bytes + P.win_bytes;
@@ -429,7 +433,14 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
     } else {
       cd = P.cand[c];                                      // wave-uniform
     }
-    const Window W = report_window(P, cd);
+    Window W = report_window(P, cd);
+    uint32_t pattern_idx = 0;
+    if (P.pattern_stride) {  // many patterns, one text: the flags' upper bits name the pattern, not a text
+      pattern_idx = cd.flags >> kCandTextShift;
+      W.text_idx = 0;
+      __builtin_amdgcn_wave_barrier();  // the previous report's walk is done with spat
+      load_pattern(P.pattern + (size_t)pattern_idx * P.pattern_stride);
+    }
     if (W.skip) continue;
     const uint64_t o = W.o, we = W.we;
     const int wl = (int)(we - o);
@@ -555,7 +566,7 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
         if (c < P.host_cap) hstr[x] = v;
       }
       if (lane == 0) {
-        const MatchOut r = make_row(P, c, W, o + (uint64_t)i, cost, w, ok, pattern_start, pattern_end);
+        const MatchOut r = make_row(P, c, W, o + (uint64_t)i, cost, w, ok, pattern_start, pattern_end, pattern_idx);
         P.out[c] = r;
         if (c < P.host_cap) P.host_out[c] = r;
       }
@@ -579,7 +590,7 @@ static void launch_one(const TraceParams& P, uint32_t nblocks, size_t lds, hipSt
 
 hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stream) {
   if (P.wave_mode) {  // one wavefront per report (host checked 2k+3 <= 64 and the LDS budget)
-    const size_t lds = (size_t)((P.m + 15u) & ~15u) + (size_t)4 * P.scratch_stride;
+    const size_t lds = (size_t)4 * ((P.m + 15u) & ~15u) + (size_t)4 * P.scratch_stride;
     if (P.k + 1 <= 255) {
       static bool attr8 = false;
       if (!attr8) {

@@ -189,34 +189,69 @@ def many_case(rng, searchers):
 
 
 def encoded_case(rng, searchers):
-    """search_encoded_patterns (incl. the multi-pattern prefilter when the text is long enough)."""
+    """search_encoded_patterns: the pattern-tiled one-pass scan, or (SASSY_HIP_TILED=0, long texts) one scan per
+    pattern incl. the multi-pattern prefilter."""
     profile = rng.choice(["dna", "iupac"])
     rc = rng.random() < 0.5
-    m = rng.choice([12, 16, 20, 23, 24, 32, 40])
-    k = min(rng.choice([0, 1, 2, 3]), m // 6)
-    npat = rng.choice([1, 3, 8, 9, 40, 70])
-    pats = [rand_seq(rng, m, b"ACGT") for _ in range(npat)]
-    n = rng.choice([200, 3000, 20_000, 60_000])
+    wide = rng.random() < 0.5  # the wider shapes only the one-pass scan sees often enough otherwise
+    m = rng.choice([1, 2, 7, 12, 16, 20, 23, 24, 31, 32, 33, 40, 63, 64]) if wide else rng.choice([12, 16, 20, 23, 24, 32, 40])
+    k = rng.choice([0, 1, 2, 3, 5, 8, 12]) if wide else min(rng.choice([0, 1, 2, 3]), m // 6)
+    if wide and k > m + 2:
+        k = m + 2
+    npat = rng.choice([1, 2, 3, 8, 9, 40, 64, 65, 70, 130, 300])
+    pal = b"ACGT" if profile == "dna" or rng.random() < 0.6 else b"ACGTNRYKMSW"
+    pats = [rand_seq(rng, m, pal) for _ in range(npat)]
+    n = rng.choice([1, 5, 70, 200, 3000, 20_000, 60_000])
+    if wide and k >= m // 2:
+        n = min(n, 3000)  # nearly every position is a report: keep the oracle's work bounded
     t = bytearray(rand_seq(rng, n, b"ACGT"))
     for p in pats[:20]:
-        ins = mutate(rng, p, rng.randrange(0, k + 2))
+        ins = bytearray(mutate(rng, p, rng.randrange(0, k + 2)))
+        for i, c in enumerate(ins):
+            if chr(c) not in "ACGT":
+                ins[i] = rng.choice(b"ACGT")
         if len(ins) < n:
             at = rng.randrange(0, n - len(ins) + 1)
             t[at:at + len(ins)] = ins
     if rng.random() < 0.2:
         for _ in range(20):
             i = rng.randrange(n); t[i] = t[i] | 0x20
-    if profile == "iupac" and rng.random() < 0.2:
-        t[rng.randrange(n)] = ord("N")
+    if rng.random() < 0.3:
+        for _ in range(rng.choice([1, 30])):
+            t[rng.randrange(n)] = rng.choice(b"NRYn-*" if profile == "iupac" else b"NX-n")
     t = bytes(t)
+    allm = wide and rng.random() < 0.3
+    force = rng.choice([None, None, "0", "1"])
+    if force is None:
+        os.environ.pop("SASSY_HIP_TILED", None)
+    else:
+        os.environ["SASSY_HIP_TILED"] = force
     s = searchers[(profile, rc)]
     enc = s.encode_patterns(pats)
-    got = s.search_encoded_patterns(enc, t, k)
-    want = oracle.search_encoded(profile, pats, t, k, rc=rc)
+    # (Dna text with other letters: the scan's 2-bit equality and the traceback's letter equality can disagree;
+    # the reference panics in get_trace, the oracle raises, and so must the library)
+    try:
+        want = oracle.search_encoded(profile, pats, t, k, rc=rc, all_minima=allm)
+    except RuntimeError:
+        want = None
+    try:
+        got = s.search_encoded_patterns(enc, t, k, all_minima=allm)
+    except sassy_amd.SassyHipError as e:
+        got = None
+        if want is not None or "traceback failed" not in str(e):
+            print("FAILED CALL", dict(profile=profile, m=m, k=k, rc=rc, npat=npat, n=n, all_minima=allm, tiled=force))
+            with open(os.path.join(ROOT, "gpurun_out", "fuzz_fail.bin"), "wb") as fh:
+                fh.write(b"|".join(pats) + b"\n" + t)
+            raise
+    os.environ.pop("SASSY_HIP_TILED", None)
+    if want is None or got is None:
+        desc = dict(mode="encoded", profile=profile, m=m, k=k, rc=rc, npat=npat, n=n, all_minima=allm, tiled=force,
+                    filtered=s.stats()["filtered"], matches=0)
+        return want is None and got is None, desc, b"|".join(pats), t, [], []
     kk = lambda m: (m.pattern_idx, m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, m.strand, m.cigar)
     gk, wk = sorted(kk(m) for m in got), sorted(kk(m) for m in want)
-    desc = dict(mode="encoded", profile=profile, m=m, k=k, rc=rc, npat=npat, n=n, filtered=s.stats()["filtered"],
-                matches=len(wk))
+    desc = dict(mode="encoded", profile=profile, m=m, k=k, rc=rc, npat=npat, n=n, all_minima=allm, tiled=force,
+                filtered=s.stats()["filtered"], matches=len(wk))
     return gk == wk, desc, b"|".join(pats), t, gk, wk
 
 
@@ -372,6 +407,8 @@ def main():
             fn = inflight_case
         if args.focus == "reflanes":
             fn = reflanes_case
+        if args.focus == "encoded":
+            fn = encoded_case
         ok, desc, pat, text, got, want = fn(rng, searchers)
         cases += 1
         kinds[desc["filtered"]] = kinds.get(desc["filtered"], 0) + 1

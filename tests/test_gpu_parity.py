@@ -709,6 +709,7 @@ def test_encoded_many_patterns(sassy):
     import os
     rng = random.Random(45)
     pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(12)]
+    os.environ["SASSY_HIP_TILED"] = "0"  # one scan per pattern here; the one-pass path: test_encoded_pattern_tiled
     for variant in ("plain", "lower", "with_n", "plain_multi", "lower_multi"):
         # *_multi: force the multi-pattern prefilter (one filter_dna_multi_kernel pass per batch of
         # patterns) that long texts get by default
@@ -745,6 +746,108 @@ def test_encoded_many_patterns(sassy):
             elif not os.environ.get("SASSY_HIP_PREFILTER"):
                 assert s.stats()["filtered"] in (0, 4)  # 20-mers at k=2: pieces too short (q-gram counting, or the streaming DP)
     os.environ.pop("SASSY_HIP_MULTI_MIN_TEXT", None)
+    os.environ.pop("SASSY_HIP_TILED", None)
+
+
+def test_encoded_pattern_tiled(sassy):
+    """search_encoded_patterns through the pattern-tiled scan (tiled_kernel.hip, the reference's v2 shape: one
+    pattern per lane, all patterns in one pass; src/pattern_tiling/search.rs:326-425) against the oracle:
+    both profiles, both strands, every word shape (m <= 32, m <= 64), k = 0, m <= k, texts shorter than the
+    pattern, IUPAC letters in patterns and text, search_all, without_trace, more than 64 patterns (several
+    groups), chunk seams (texts longer than one wave's chunk)."""
+    import os
+    rng = random.Random(4711)
+    os.environ.pop("SASSY_HIP_TILED", None)
+    shapes = [  # (profile, m, k, npat, n, alphabet of the text, all_minima)
+        ("dna", 20, 2, 12, 30_000, b"ACGT", False),
+        ("dna", 20, 2, 150, 5_000, b"ACGT", False),
+        ("dna", 32, 3, 70, 20_000, b"ACGT", False),
+        ("dna", 33, 4, 9, 20_000, b"ACGT", False),
+        ("dna", 64, 8, 65, 9_000, b"ACGT", False),
+        ("dna", 5, 0, 3, 4_000, b"ACGT", False),
+        ("dna", 3, 3, 4, 300, b"ACGT", False),       # m <= k: every position is a report candidate
+        ("dna", 4, 6, 2, 200, b"ACGT", True),
+        ("dna", 12, 2, 5, 7, b"ACGT", False),        # text shorter than the patterns
+        ("dna", 16, 1, 200, 3_000, b"ACGTN", True),
+        ("iupac", 20, 2, 12, 30_000, b"ACGT", False),
+        ("iupac", 20, 3, 100, 8_000, b"ACGTNRYacgtn-", False),
+        ("iupac", 24, 2, 40, 6_000, b"ACGTN", True),
+        ("iupac", 64, 12, 7, 4_000, b"ACGTRYKM", False),
+        ("iupac", 1, 0, 3, 500, b"ACGTN", False),
+        ("dna", 24, 3, 20, 600_000, b"ACGT", False),  # many chunks per group of patterns
+    ]
+    for (profile, m, k, npat, n, alpha, allm) in shapes:
+        pal = b"ACGT" if profile == "dna" else b"ACGTNRYSWKM"
+        pats = [bytes(rng.choice(pal if rng.random() < 0.3 else b"ACGT") for _ in range(m)) for _ in range(npat)]
+        text = bytearray(rng.choice(alpha) for _ in range(n))
+        for p in pats[:40]:
+            for _ in range(2):
+                ins = mutate(rng, p, rng.randrange(0, k + 1))
+                if profile == "iupac":
+                    ins = bytes(c if chr(c) in "ACGT" else rng.choice(b"ACGT") for c in ins)
+                if rng.random() < 0.5:
+                    ins = oracle.reverse_complement("iupac", ins)
+                if len(ins) < n:
+                    at = rng.randrange(0, n - len(ins))
+                    text[at:at + len(ins)] = ins
+        if n > 100:
+            ins = mutate(rng, pats[0], 0)  # a match that ends at the text end, one at its start
+            text[n - len(ins):] = ins
+            text[:m] = pats[-1]
+        tb = bytes(text)
+        for rc in (False, True):
+            s = sassy.Searcher(profile, rc=rc)
+            enc = s.encode_patterns(pats)
+            got = s.search_encoded_patterns(enc, tb, k, all_minima=allm)
+            st = s.stats()
+            want = oracle.search_encoded(profile, pats, tb, k, rc=rc, all_minima=allm)
+            assert st["filtered"] == 5, (profile, m, k, npat, n, st)  # the pattern-tiled scan took the call
+            assert sorted(key(x) for x in got) == sorted(key(x) for x in want), (profile, m, k, npat, n, rc, allm)
+            assert len(want) >= (1 if n > 100 else 0)
+            got_wo = s.search_encoded_patterns(enc, tb, k, all_minima=allm, without_trace=True)
+            assert sorted((x.pattern_idx, x.text_end, x.cost, x.strand) for x in got_wo) == \
+                sorted((x.pattern_idx, x.text_end, x.cost, x.strand) for x in want)
+    # a device-resident text that does not start on a 64-byte boundary (the kernel loads aligned blocks and
+    # skips the bytes in front of the text; the bytes around it are poison that would match)
+    pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(70)]
+    n = 5_000
+    for off in (16, 48):
+        text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        text[:20] = pats[3]
+        text[n - 20:] = pats[69]
+        text[1000:1020] = pats[5]
+        buf = sassy.DeviceBuffer(n + 256)
+        buf.upload(pats[3] * 3 + pats[3][:4], 0)           # in front of the text: more of pattern 3
+        buf.upload(bytes(text), off)
+        buf.upload(pats[69] * 3, off + n)                   # behind it: more of pattern 69
+        s = sassy.Searcher("dna", rc=False)
+        got = s.search_encoded_patterns(s.encode_patterns(pats), _DevText(buf.ptr + off, n), 1)
+        assert s.stats()["filtered"] == 5
+        want = oracle.search_encoded("dna", pats, bytes(text), 1)
+        assert sorted(key(x) for x in got) == sorted(key(x) for x in want) and len(want) >= 3, off
+    # the searcher's report filters are applied per pattern: equal to the one-scan-per-pattern path
+    pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(30)]
+    text = bytearray(rng.choice(b"ACGTN") for _ in range(20_000))
+    for p in pats:
+        for _ in range(3):
+            ins = mutate(rng, p, rng.randrange(0, 3))
+            at = rng.randrange(0, len(text) - len(ins))
+            text[at:at + len(ins)] = ins
+    tb = bytes(text)
+    for cfg in ("best", "nfrac", "both"):
+        res = []
+        for tiled in ("1", "0"):
+            os.environ["SASSY_HIP_TILED"] = tiled
+            s = sassy.Searcher("iupac", rc=True)
+            if cfg in ("best", "both"):
+                s.only_best_match()
+            if cfg in ("nfrac", "both"):
+                s.with_max_n_frac(0.1)
+            enc = s.encode_patterns(pats)
+            res.append(sorted(key(x) for x in s.search_encoded_patterns(enc, tb, 3)))
+            assert s.stats()["filtered"] == (5 if tiled == "1" else s.stats()["filtered"])
+        assert res[0] == res[1] and len(res[0]) >= 10, cfg
+    os.environ.pop("SASSY_HIP_TILED", None)
 
 
 def test_pack_result_for_gather(sassy):
