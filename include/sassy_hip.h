@@ -68,7 +68,8 @@ typedef struct sassy_hip_Stats {
   uint32_t filtered;     /* 0: DP over every block (scan_kernel); 1: prefilter (filter_kernel) -> chunk list ->
                             DP on the listed chunks; 2: the same with the Dna bit-plane prefilter (filter_dna_kernel);
                             3: q-gram piece table (filter_table_kernel); 4: q-gram counting (filter_count_kernel);
-                            5: the pattern-tiled scan of search_encoded (tiled_kernel: all patterns in one pass) */
+                            5: the pattern-tiled scan of search_encoded (tiled_kernel: all patterns in one pass);
+                            6: the seeded search of search_encoded (seed_kernels: seed table lookups, one lane per hit) */
   double filter_ms;      /* HIP-event time of the prefilter kernel (part of scan_ms) */
   uint64_t hit_blocks;   /* text blocks in which an exact pattern piece ends */
   uint32_t piece_len;    /* rows per pattern piece (k+1 pieces) / q-gram length Q (filtered = 4), 0 when unfiltered */

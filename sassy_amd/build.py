@@ -30,10 +30,11 @@ UNITS = [
     ("aux_kernels.hip", "aux_kernels.o", []),
     ("sort_kernels.hip", "sort_kernels.o", []),
     ("tiled_kernel.hip", "tiled_kernel.o", []),
+    ("seed_kernels.hip", "seed_kernels.o", []),
     ("trace_kernel.hip", "trace_kernel.o", []),
     ("host.hip", "host.o", []),
 ]
-HEADERS = ["common.h", "profiles.h", os.path.join("..", "..", "include", "sassy.h"),
+HEADERS = ["common.h", "profiles.h", "tiled_step.h", os.path.join("..", "..", "include", "sassy.h"),
            os.path.join("..", "..", "include", "sassy_hip.h")]
 
 

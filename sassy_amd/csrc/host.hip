@@ -64,7 +64,9 @@ hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, 
                                   size_t scratch_bytes, hipStream_t stream, int by_tag = 0);
 size_t select_scratch_bytes(uint32_t count);
 hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Candidate* d_sel, uint32_t* d_sel_count,
-                                 void* d_scratch, size_t scratch_bytes, hipStream_t stream);
+                                 void* d_scratch, size_t scratch_bytes, hipStream_t stream, int all_minima = 0);
+hipError_t launch_seed_scan(const SeedParams& P, uint32_t grid, hipStream_t stream);
+hipError_t launch_seed_verify(const VerifyParams& P, hipStream_t stream);
 hipError_t launch_tiled_scan(const TiledParams& P, hipStream_t stream);
 
 static thread_local std::string g_err;
@@ -399,6 +401,9 @@ struct sassy_SearcherType {
   DevBuf<uint8_t> d_tiled_pat;
   DevBuf<uint32_t> d_tiled_cnt;
   DevBuf<Candidate> d_tiled_sel;
+  // seeded search (search_encoded_seeded): piece tables, candidate list and its chunk fill counts
+  DevBuf<uint32_t> d_seed_start[2], d_seed_entries[2], d_seed_fill;
+  DevBuf<unsigned long long> d_seed_cand;
   hipEvent_t ev_multi = nullptr, ev_multi_a = nullptr;
   hipEvent_t ev_a_multi() { return ev_multi_a; }
   DevBuf<uint64_t> d_range;      // N counting on device-resident text
@@ -416,6 +421,8 @@ struct sassy_SearcherType {
     free_stage();
     d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
     d_tiled_peq.release(); d_tiled_pat.release(); d_tiled_cnt.release(); d_tiled_sel.release();
+    for (int t = 0; t < 2; ++t) { d_seed_start[t].release(); d_seed_entries[t].release(); }
+    d_seed_fill.release(); d_seed_cand.release();
     if (ev_multi) (void)hipEventDestroy(ev_multi);
     if (ev_multi_a) (void)hipEventDestroy(ev_multi_a);
     for (ScanLane& l : lanes) l.destroy();
@@ -2177,100 +2184,18 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
   return 0;
 }
 
-// search_encoded_patterns in ONE pass: the pattern-tiled scan (tiled_kernel.hip; reference v2,
-// src/pattern_tiling/search.rs:326-425 + general.rs:335-404).  All (rc-expanded) patterns advance together over
-// the text, 64 per wavefront; the kernel lists every (pattern, end position) with cost <= k, the device sorts the
-// list by (pattern, position), applies the report rule to each run (sort_kernels.hip: flag_reports_kernel) and
-// traces the reports (trace_wave_kernel with one pattern per report).  *done = false: too many end positions for
-// this shape (k close to m on a long text) -- the caller runs one scan per pattern instead.
-static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
-                                const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
-                                sassy_hip_Result* R, bool* done) {
-  *done = false;
+// The tail of the one-pass searches of many patterns (pattern-tiled scan, seeded search): lanes[0].d_cand holds
+// `count` records (pattern, end position, cost) -- EVERY end position with cost <= k of every pattern, in any
+// order, `copies`: possibly several times.  Sort by (pattern, position), apply the report rule to each run
+// (sort_kernels.hip), trace the reports with one wavefront each (the report's pattern comes with it), apply the
+// searcher's report filters per pattern and append the records to R.
+static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, const PatternPlan& plan0,
+                               const uint8_t* tptr, const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all,
+                               bool wo, uint32_t count, bool copies, sassy_hip_Result* R) {
   ScanLane& L = s->lanes[0];
-  const size_t npat = e->patterns.size();
-  const uint32_t m = (uint32_t)e->plen;
-  std::string err;
-  PatternPlan plan0;
-  for (size_t p = 0; p < npat; ++p) {  // what the reference's encode would reject (tqueries.rs:60-65, iupac.rs:19-24)
-    PatternPlan pl;
-    if (!make_plan(s->profile, e->patterns[p].data(), m, p == 0 ? plan0 : pl, err)) return fail(SASSY_HIP_EINVAL, err);
-  }
-  // ---- match masks: bit j of peq[class][pattern] = row j of the pattern matches a text character of that class ----
-  const uint32_t classes = s->profile == PROFILE_DNA ? 4u : 16u;
-  const uint32_t npad = (uint32_t)((npat + 63) / 64 * 64);
-  std::vector<unsigned long long> peq((size_t)classes * npad, 0ull);
-  std::vector<uint8_t> flat(npat * (size_t)m);
-  for (size_t p = 0; p < npat; ++p) {
-    const uint8_t* pt = e->patterns[p].data();
-    memcpy(&flat[p * m], pt, m);
-    for (uint32_t j = 0; j < m; ++j) {
-      if (classes == 4) {
-        peq[(size_t)((pt[j] >> 1) & 3u) * npad + p] |= 1ull << j;  // src/profiles/dna.rs:19-40
-      } else {
-        const uint32_t set = iupac_code(pt[j]) & 0x0Fu;              // src/profiles/iupac.rs:18-36
-        for (uint32_t c = 1; c < 16; ++c)
-          if (set & c) peq[(size_t)c * npad + p] |= 1ull << j;
-      }
-    }
-  }
-  if (int rc = s->d_tiled_peq.reserve(peq.size())) return rc;
-  if (int rc = s->d_tiled_pat.reserve(flat.size() + 64)) return rc;
-  if (int rc = s->d_tiled_cnt.reserve(16)) return rc;
   hipStream_t st = s->stream;
-  HIP_TRY(hipMemcpyAsync(s->d_tiled_peq.p, peq.data(), peq.size() * 8, hipMemcpyHostToDevice, st));
-  HIP_TRY(hipMemcpyAsync(s->d_tiled_pat.p, flat.data(), flat.size(), hipMemcpyHostToDevice, st));
-
-  TiledParams P{};
-  P.skew = (uint32_t)((uintptr_t)tptr & 63u);
-  P.text_aligned = tptr - P.skew;
-  P.text_len = text_len;
-  P.peq = s->d_tiled_peq.p;
-  P.npat = (uint32_t)npat;
-  P.npat_padded = npad;
-  P.n_groups = npad / 64;
-  P.m = m;
-  P.k = k;
-  P.classes = classes;
-  P.warm_blocks = (m + k + 63) / 64;
-  {
-    const uint64_t span = (uint64_t)P.skew + text_len;
-    const uint64_t waves_wanted = 16384;
-    const uint64_t chunks_wanted = std::max<uint64_t>(1, waves_wanted / P.n_groups);
-    uint64_t chunk = std::max<uint64_t>(512, (span + chunks_wanted - 1) / chunks_wanted);
-    chunk = std::min<uint64_t>((chunk + 63) / 64 * 64, 1u << 20);
-    P.chunk = (uint32_t)chunk;
-    P.n_chunks = (span + chunk - 1) / chunk;
-  }
-  const uint64_t kMaxList = 1ull << 26;  // 1 GiB of (pattern, position, cost) records: beyond that, per-pattern scans
-  uint32_t counts[2] = {0, 0};
-  for (int attempt = 0;; ++attempt) {
-    if (int rc = L.d_cand.reserve(std::max<size_t>((size_t)1 << 18, (size_t)counts[0] + 1024))) return rc;
-    P.cand = L.d_cand.p;
-    P.cand_cap = (uint32_t)std::min<size_t>(L.d_cand.cap, 0xFFFFFFFFu);
-    P.cand_count = s->d_tiled_cnt.p;
-    HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p, 0, 64, st));
-    HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
-    hipError_t le = launch_tiled_scan(P, st);
-    if (le != hipSuccess) return hip_fail(le, "pattern-tiled scan launch");
-    HIP_TRY(hipEventRecord(s->ev_multi, st));
-    HIP_TRY(hipMemcpyAsync(counts, s->d_tiled_cnt.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
-    s->stats.scan_ms += ms;
-    s->stats.scan_launches += 1;
-    if (counts[0] <= P.cand_cap) break;
-    if (counts[0] > kMaxList || attempt == 2) return 0;  // *done stays false
-  }
-  const uint32_t count = counts[0];
-  s->stats.text_bytes += text_len;
-  s->stats.chunks += P.n_chunks * P.n_groups;
-  s->stats.filtered = 5;
-  s->stats.candidates += count;
-  *done = true;
-  if (count == 0) return 0;
-
+  const uint32_t m = (uint32_t)e->plen;
+  uint32_t counts[2] = {count, 0};
   // ---- (pattern, position) order, then the report rule ----
   if (int rc = L.d_sorted.reserve(count)) return rc;
   if (int rc = L.d_sort.reserve(std::max(sort_scratch_bytes(count), select_scratch_bytes(count)))) return rc;
@@ -2278,9 +2203,10 @@ static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* 
   if (le != hipSuccess) return hip_fail(le, "report sort launch");
   const Candidate* d_rep = L.d_sorted.p;
   uint32_t n_rep = count;
-  if (!all) {
+  if (!all || copies) {
     if (int rc = s->d_tiled_sel.reserve(count)) return rc;
-    le = launch_select_reports(L.d_sorted.p, count, s->d_tiled_sel.p, s->d_tiled_cnt.p + 1, L.d_sort.p, L.d_sort.cap, st);
+    le = launch_select_reports(L.d_sorted.p, count, s->d_tiled_sel.p, s->d_tiled_cnt.p + 1, L.d_sort.p, L.d_sort.cap, st,
+                               all ? 1 : 0);
     if (le != hipSuccess) return hip_fail(le, "report selection launch");
     HIP_TRY(hipMemcpyAsync(counts + 1, s->d_tiled_cnt.p + 1, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -2383,6 +2309,279 @@ static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* 
     i0 = i1;
   }
   return 0;
+}
+
+// search_encoded_patterns in ONE pass: the pattern-tiled scan (tiled_kernel.hip; reference v2,
+// src/pattern_tiling/search.rs:326-425 + general.rs:335-404).  All (rc-expanded) patterns advance together over
+// the text, 64 per wavefront; the kernel lists every (pattern, end position) with cost <= k, the device sorts the
+// list by (pattern, position), applies the report rule to each run (sort_kernels.hip: flag_reports_kernel) and
+// traces the reports (trace_wave_kernel with one pattern per report).  *done = false: too many end positions for
+// this shape (k close to m on a long text) -- the caller runs one scan per pattern instead.
+static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
+                                const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
+                                sassy_hip_Result* R, bool* done) {
+  *done = false;
+  ScanLane& L = s->lanes[0];
+  const size_t npat = e->patterns.size();
+  const uint32_t m = (uint32_t)e->plen;
+  std::string err;
+  PatternPlan plan0;
+  for (size_t p = 0; p < npat; ++p) {  // what the reference's encode would reject (tqueries.rs:60-65, iupac.rs:19-24)
+    PatternPlan pl;
+    if (!make_plan(s->profile, e->patterns[p].data(), m, p == 0 ? plan0 : pl, err)) return fail(SASSY_HIP_EINVAL, err);
+  }
+  // ---- match masks: bit j of peq[class][pattern] = row j of the pattern matches a text character of that class ----
+  const uint32_t classes = s->profile == PROFILE_DNA ? 4u : 16u;
+  const uint32_t npad = (uint32_t)((npat + 63) / 64 * 64);
+  std::vector<unsigned long long> peq((size_t)classes * npad, 0ull);
+  std::vector<uint8_t> flat(npat * (size_t)m);
+  for (size_t p = 0; p < npat; ++p) {
+    const uint8_t* pt = e->patterns[p].data();
+    memcpy(&flat[p * m], pt, m);
+    for (uint32_t j = 0; j < m; ++j) {
+      if (classes == 4) {
+        peq[(size_t)((pt[j] >> 1) & 3u) * npad + p] |= 1ull << j;  // src/profiles/dna.rs:19-40
+      } else {
+        const uint32_t set = iupac_code(pt[j]) & 0x0Fu;              // src/profiles/iupac.rs:18-36
+        for (uint32_t c = 1; c < 16; ++c)
+          if (set & c) peq[(size_t)c * npad + p] |= 1ull << j;
+      }
+    }
+  }
+  if (int rc = s->d_tiled_peq.reserve(peq.size())) return rc;
+  if (int rc = s->d_tiled_pat.reserve(flat.size() + 64)) return rc;
+  if (int rc = s->d_tiled_cnt.reserve(16)) return rc;
+  hipStream_t st = s->stream;
+  HIP_TRY(hipMemcpyAsync(s->d_tiled_peq.p, peq.data(), peq.size() * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(s->d_tiled_pat.p, flat.data(), flat.size(), hipMemcpyHostToDevice, st));
+
+  TiledParams P{};
+  P.skew = (uint32_t)((uintptr_t)tptr & 63u);
+  P.text_aligned = tptr - P.skew;
+  P.text_len = text_len;
+  P.peq = s->d_tiled_peq.p;
+  P.npat = (uint32_t)npat;
+  P.npat_padded = npad;
+  P.n_groups = npad / 64;
+  P.m = m;
+  P.k = k;
+  P.classes = classes;
+  P.warm_blocks = (m + k + 63) / 64;
+  {
+    const uint64_t span = (uint64_t)P.skew + text_len;
+    const uint64_t waves_wanted = 16384;
+    const uint64_t chunks_wanted = std::max<uint64_t>(1, waves_wanted / P.n_groups);
+    uint64_t chunk = std::max<uint64_t>(512, (span + chunks_wanted - 1) / chunks_wanted);
+    chunk = std::min<uint64_t>((chunk + 63) / 64 * 64, 1u << 20);
+    P.chunk = (uint32_t)chunk;
+    P.n_chunks = (span + chunk - 1) / chunk;
+  }
+  const uint64_t kMaxList = 1ull << 26;  // 1 GiB of (pattern, position, cost) records: beyond that, per-pattern scans
+  uint32_t counts[2] = {0, 0};
+  for (int attempt = 0;; ++attempt) {
+    if (int rc = L.d_cand.reserve(std::max<size_t>((size_t)1 << 18, (size_t)counts[0] + 1024))) return rc;
+    P.cand = L.d_cand.p;
+    P.cand_cap = (uint32_t)std::min<size_t>(L.d_cand.cap, 0xFFFFFFFFu);
+    P.cand_count = s->d_tiled_cnt.p;
+    HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p, 0, 64, st));
+    HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
+    hipError_t le = launch_tiled_scan(P, st);
+    if (le != hipSuccess) return hip_fail(le, "pattern-tiled scan launch");
+    HIP_TRY(hipEventRecord(s->ev_multi, st));
+    HIP_TRY(hipMemcpyAsync(counts, s->d_tiled_cnt.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
+    s->stats.scan_ms += ms;
+    s->stats.scan_launches += 1;
+    if (counts[0] <= P.cand_cap) break;
+    if (counts[0] > kMaxList || attempt == 2) return 0;  // *done stays false
+  }
+  const uint32_t count = counts[0];
+  s->stats.text_bytes += text_len;
+  s->stats.chunks += P.n_chunks * P.n_groups;
+  s->stats.filtered = 5;
+  s->stats.candidates += count;
+  *done = true;
+  if (count == 0) return 0;
+  return finish_pattern_list(s, e, plan0, tptr, h_text, text_len, k, all, wo, count, false, R);
+}
+
+// search_encoded_patterns for many patterns over a long text: seed -> verify -> report (seed_kernels.hip).  One
+// pass over the text looks every L-gram up in a table of all patterns' pigeonhole pieces; one lane per hit runs the
+// pattern over the few dozen characters around it.  Dna codes only (the caller has checked the text is plain ACGT
+// when the searcher is Iupac).  *done = false: not this shape after all (lists too large) -- the caller falls back.
+static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
+                                 const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
+                                 sassy_hip_Result* R, bool* done) {
+  *done = false;
+  ScanLane& L = s->lanes[0];
+  hipStream_t st = s->stream;
+  const size_t npat = e->patterns.size();
+  const uint32_t m = (uint32_t)e->plen;
+  std::string err;
+  PatternPlan plan0;
+  for (size_t p = 0; p < npat; ++p) {
+    PatternPlan pl;
+    if (!make_plan(s->profile, e->patterns[p].data(), m, p == 0 ? plan0 : pl, err)) return fail(SASSY_HIP_EINVAL, err);
+  }
+  // ---- pieces: k+1 of them, the first m mod (k+1) one row longer; a seed is the last <= kSeedMaxLen rows of a piece ----
+  const uint32_t pieces = k + 1, q = m / pieces, spare = m - q * pieces;
+  uint32_t p_end[8], p_len[8], tab_of[8], tab_len[2] = {0, 0};
+  double per_char = 0;  // expected candidates per text character on random text
+  for (uint32_t pc = 0; pc < pieces; ++pc) {
+    const uint32_t len = q + (pc < spare ? 1u : 0u);
+    p_end[pc] = pc * q + std::min(pc, spare) + len;
+    p_len[pc] = std::min(len, kSeedMaxLen);
+    if (tab_len[0] == 0 || tab_len[0] == p_len[pc]) { tab_len[0] = p_len[pc]; tab_of[pc] = 0; }
+    else { tab_len[1] = p_len[pc]; tab_of[pc] = 1; }
+    per_char += (double)npat * std::pow(0.25, (double)p_len[pc]);
+  }
+  // ---- direct-address tables: code of a seed = sum of its characters' Dna codes, first character lowest ----
+  std::vector<uint32_t> start[2], entries[2];
+  for (int t = 0; t < 2; ++t) {
+    if (!tab_len[t]) continue;
+    const size_t size = (size_t)1 << (2 * tab_len[t]);
+    start[t].assign(size + 1, 0u);
+    std::vector<uint32_t> code_of;
+    code_of.reserve(npat * pieces);
+    for (size_t p = 0; p < npat; ++p)
+      for (uint32_t pc = 0; pc < pieces; ++pc) {
+        if (tab_of[pc] != (uint32_t)t) continue;
+        const uint8_t* src = e->patterns[p].data() + p_end[pc] - p_len[pc];
+        uint32_t code = 0;
+        for (uint32_t x = 0; x < p_len[pc]; ++x) code |= (uint32_t)((src[x] >> 1) & 3u) << (2 * x);
+        code_of.push_back(code);
+        start[t][code + 1]++;
+      }
+    for (size_t c = 0; c < size; ++c) start[t][c + 1] += start[t][c];
+    entries[t].resize(code_of.size());
+    std::vector<uint32_t> cursor(start[t].begin(), start[t].end() - 1);
+    size_t x = 0;
+    for (size_t p = 0; p < npat; ++p)
+      for (uint32_t pc = 0; pc < pieces; ++pc) {
+        if (tab_of[pc] != (uint32_t)t) continue;
+        entries[t][cursor[code_of[x++]]++] = (uint32_t)(p << 3) | pc;
+      }
+  }
+  // ---- match masks per Dna code and the patterns' bytes (traceback) ----
+  const bool wide = m > 32;
+  std::vector<unsigned long long> peq(npat * 4, 0ull);
+  std::vector<uint8_t> flat(npat * (size_t)m);
+  for (size_t p = 0; p < npat; ++p) {
+    const uint8_t* pt = e->patterns[p].data();
+    memcpy(&flat[p * m], pt, m);
+    for (uint32_t j = 0; j < m; ++j) {
+      const uint32_t c = (pt[j] >> 1) & 3u;
+      if (wide) peq[p * 4 + c] |= 1ull << j;
+      else reinterpret_cast<uint32_t*>(peq.data())[p * 4 + c] |= 1u << j;
+    }
+  }
+  if (int rc = s->d_tiled_peq.reserve(peq.size())) return rc;
+  if (int rc = s->d_tiled_pat.reserve(flat.size() + 64)) return rc;
+  if (int rc = s->d_tiled_cnt.reserve(16)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->d_tiled_peq.p, peq.data(), (wide ? 8 : 4) * 4 * npat, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(s->d_tiled_pat.p, flat.data(), flat.size(), hipMemcpyHostToDevice, st));
+  for (int t = 0; t < 2; ++t) {
+    if (!tab_len[t]) continue;
+    if (int rc = s->d_seed_start[t].reserve(start[t].size())) return rc;
+    if (int rc = s->d_seed_entries[t].reserve(entries[t].size() + 1)) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_seed_start[t].p, start[t].data(), start[t].size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_seed_entries[t].p, entries[t].data(), entries[t].size() * 4, hipMemcpyHostToDevice, st));
+  }
+  // ---- candidate list: chunks of 16 384, sized for ~1.5x the expectation of a segment ----
+  const uint32_t chunk_entries = 16384;
+  const uint64_t max_entries = (uint64_t)1 << 28;  // 2 GiB of candidates at a time
+  uint64_t seg_len = (text_len + 2047) / 2048 * 2048;
+  const double slack = 1.5;
+  auto entries_for = [&](uint64_t len, uint64_t waves) { return (uint64_t)(slack * per_char * (double)len) + waves * chunk_entries; };
+  auto waves_for = [&](uint64_t len) { return std::min<uint64_t>(4096, std::max<uint64_t>(1, len / 2048)); };
+  while (seg_len > 2048 * 64 && entries_for(seg_len, waves_for(seg_len)) > max_entries) seg_len = (seg_len / 2 + 2047) / 2048 * 2048;
+  uint64_t cap_entries = std::min(max_entries, std::max<uint64_t>(entries_for(seg_len, waves_for(seg_len)), 4 * chunk_entries));
+  uint32_t n_chunks_cap = (uint32_t)((cap_entries + chunk_entries - 1) / chunk_entries);
+  if (int rc = s->d_seed_cand.reserve((size_t)n_chunks_cap * chunk_entries)) return rc;
+  if (int rc = s->d_seed_fill.reserve(n_chunks_cap)) return rc;
+
+  SeedParams SP{};
+  SP.text = tptr;
+  SP.text_len = text_len;
+  for (int t = 0; t < 2; ++t) {
+    SP.len[t] = tab_len[t];
+    SP.start[t] = s->d_seed_start[t].p;
+    SP.entries[t] = s->d_seed_entries[t].p;
+  }
+  SP.cand = s->d_seed_cand.p;
+  SP.chunk_entries = chunk_entries;
+  SP.n_chunks_cap = n_chunks_cap;
+  SP.alloc = s->d_tiled_cnt.p + 4;
+  SP.fill = s->d_seed_fill.p;
+  VerifyParams VP{};
+  VP.text = tptr;
+  VP.text_len = text_len;
+  VP.cand = s->d_seed_cand.p;
+  VP.chunk_entries = chunk_entries;
+  VP.alloc = s->d_tiled_cnt.p + 4;
+  VP.fill = s->d_seed_fill.p;
+  VP.peq = s->d_tiled_peq.p;
+  VP.m = m;
+  VP.k = k;
+  for (uint32_t pc = 0; pc < 8; ++pc) VP.rem[pc] = pc < pieces ? m - p_end[pc] : 0u;
+  VP.out_count = s->d_tiled_cnt.p;
+
+  const uint64_t kMaxList = 1ull << 26;
+  uint32_t out_count = 0;
+  uint64_t n_cand = 0, n_seg = 0;
+  for (int attempt = 0;; ++attempt) {
+    if (int rc = L.d_cand.reserve(std::max<size_t>((size_t)1 << 18, (size_t)out_count + 1024))) return rc;
+    VP.out = L.d_cand.p;
+    VP.out_cap = (uint32_t)std::min<size_t>(L.d_cand.cap, 0xFFFFFFFFu);
+    HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p, 0, 64, st));
+    HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
+    n_cand = 0;
+    n_seg = 0;
+    uint64_t len = seg_len;
+    for (uint64_t lo = 0; lo < text_len;) {
+      const uint64_t hi = std::min<uint64_t>(text_len, lo + len);
+      SP.seg_lo = lo;
+      SP.seg_hi = hi;
+      HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p + 4, 0, 8, st));
+      const uint64_t waves = waves_for(hi - lo);
+      hipError_t le = launch_seed_scan(SP, (uint32_t)((waves + kWavesPerGroup - 1) / kWavesPerGroup), st);
+      if (le != hipSuccess) return hip_fail(le, "seed scan launch");
+      uint32_t al[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(al, s->d_tiled_cnt.p + 4, 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (al[1]) {  // more hits than the list holds (a text far from random): smaller segments
+        if (len <= 2048 * 16) return 0;  // *done stays false
+        len = (len / 4 + 2047) / 2048 * 2048;
+        continue;
+      }
+      VP.n_chunks_cap = std::min(al[0], n_chunks_cap);
+      le = launch_seed_verify(VP, st);
+      if (le != hipSuccess) return hip_fail(le, "seed verification launch");
+      n_cand += (uint64_t)VP.n_chunks_cap * chunk_entries;  // (upper bound: the last chunk of a wave is partly filled)
+      ++n_seg;
+      lo = hi;
+    }
+    HIP_TRY(hipEventRecord(s->ev_multi, st));
+    HIP_TRY(hipMemcpyAsync(&out_count, s->d_tiled_cnt.p, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
+    s->stats.scan_ms += ms;
+    s->stats.scan_launches += 2 * n_seg;
+    if (out_count <= VP.out_cap) break;
+    if (out_count > kMaxList || attempt == 2) return 0;  // *done stays false
+  }
+  s->stats.text_bytes += text_len;
+  s->stats.chunks += n_seg;
+  s->stats.hit_blocks += n_cand;
+  s->stats.piece_len = tab_len[0];
+  s->stats.filtered = 6;
+  s->stats.candidates += out_count;
+  *done = true;
+  if (out_count == 0) return 0;
+  return finish_pattern_list(s, e, plan0, tptr, h_text, text_len, k, all, wo, out_count, true, R);
 }
 
 static void reset_stats(sassy_SearcherType* S) { S->stats = sassy_hip_Stats{}; }
@@ -3295,8 +3494,26 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
     bool tiled = tiled_ok && e->patterns.size() >= 2 &&
                  (double)text_len * (double)tiled_groups <= tiled_budget * (double)e->patterns.size();
     if (env_tiled >= 0) tiled = tiled_ok && env_tiled != 0;
+    // Many patterns, long text, selective pieces: seed -> verify -> report (seed_kernels.hip) reads the text
+    // once for all patterns.  Expected cost per (character, pattern): hit rate x window x ~24 operations, against
+    // 17 for the pattern-tiled scan (SASSY_HIP_SEEDED=0 / 1 forces the choice).
+    const int env_seeded = getenv("SASSY_HIP_SEEDED") ? atoi(getenv("SASSY_HIP_SEEDED")) : -1;
+    bool seeded = false;
+    if (s->profile == PROFILE_DNA && std::isnan(s->alpha) && k + 1 <= 8 && e->plen / (k + 1) >= 5 &&
+        e->plen + 3 * k + 1 <= 4 * kSeedWindowDwords && e->patterns.size() < (1u << 24) && text_len < (1ull << 36) &&
+        (((uintptr_t)tptr) & 15) == 0) {
+      double rate = 0;
+      for (size_t pc = 0; pc < k + 1; ++pc)
+        rate += std::pow(0.25, (double)std::min<size_t>(e->plen / (k + 1) + (pc < e->plen % (k + 1) ? 1 : 0), kSeedMaxLen));
+      seeded = rate * (double)(e->plen + 3 * k + 1) * 24.0 < 8.0 && (double)text_len * (double)e->patterns.size() >= 2e9;
+      if (env_seeded >= 0) seeded = env_seeded != 0;
+    }
     bool tiled_done = false;
-    if (tiled)
+    if (seeded) {
+      if (int rc = search_encoded_seeded(s, e, tptr, h_text, text_len, (uint32_t)k, all, wo, R, &tiled_done)) return rc;
+      if (tiled_done) tiled = false;
+    }
+    if (tiled && !tiled_done)
       if (int rc = search_encoded_tiled(s, e, tptr, h_text, text_len, (uint32_t)k, all, wo, R, &tiled_done)) return rc;
     const size_t batch = multi ? 64 : 1;
     for (size_t p0 = 0; p0 < (tiled_done ? 0 : e->patterns.size()); p0 += batch) {

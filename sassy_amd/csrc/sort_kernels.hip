@@ -27,22 +27,35 @@ __global__ __launch_bounds__(256) void sort_keys_kernel(const Candidate* __restr
 // (src/search.rs:1310-1368): inside a run of consecutive positions of one pattern, the rightmost position of
 // every plateau that was entered by a decrease and is left by an increase.  A run starts and ends next to a
 // cost > k, so its first plateau counts as entered by a decrease and its last as left by an increase.
+// The list may hold an entry several times (the seeded search sees a match through each of its intact pieces):
+// the first copy stands for all.  all_minima: every distinct entry is a report.
 __global__ __launch_bounds__(256) void flag_reports_kernel(const Candidate* __restrict__ c, uint32_t count,
-                                                           unsigned char* __restrict__ keep) {
+                                                           unsigned char* __restrict__ keep, int all_minima) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const Candidate me = c[i];
   const uint32_t tag = me.flags >> kCandTextShift;
   bool report = true;
-  if (i + 1 < count) {
-    const Candidate nx = c[i + 1];
-    if ((nx.flags >> kCandTextShift) == tag && nx.pos == me.pos + 1 && nx.cost <= me.cost) report = false;
+  if (i > 0) {
+    const Candidate pv = c[i - 1];
+    if ((pv.flags >> kCandTextShift) == tag && pv.pos == me.pos) report = false;  // a copy
   }
-  if (report) {  // walk to the left end of the plateau
+  if (report && !all_minima) {
+    for (uint32_t j = i + 1; j < count; ++j) {  // the next distinct entry
+      const Candidate nx = c[j];
+      if ((nx.flags >> kCandTextShift) != tag) break;
+      if (nx.pos == me.pos) continue;
+      if (nx.pos == me.pos + 1 && nx.cost <= me.cost) report = false;
+      break;
+    }
+  }
+  if (report && !all_minima) {  // walk to the left end of the plateau
     uint64_t pos = me.pos;
     for (uint32_t j = i; j > 0; --j) {
       const Candidate pv = c[j - 1];
-      if ((pv.flags >> kCandTextShift) != tag || pv.pos + 1 != pos) break;  // start of the run
+      if ((pv.flags >> kCandTextShift) != tag) break;  // start of the run
+      if (pv.pos == pos) continue;                      // a copy
+      if (pv.pos + 1 != pos) break;                     // start of the run
       if (pv.cost != me.cost) { report = pv.cost > me.cost; break; }
       pos = pv.pos;
     }
@@ -86,15 +99,16 @@ size_t select_scratch_bytes(uint32_t count) {
 }
 
 // sel[0 .. *sel_count) = the reports among sorted[0 .. count) (flag_reports_kernel), order kept.
+// all_minima: the distinct entries.
 hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Candidate* d_sel, uint32_t* d_sel_count,
-                                 void* d_scratch, size_t scratch_bytes, hipStream_t stream) {
+                                 void* d_scratch, size_t scratch_bytes, hipStream_t stream, int all_minima) {
   if (count == 0) return hipMemsetAsync(d_sel_count, 0, 4, stream);
   const size_t flag_bytes = ((size_t)count + 255) / 256 * 256;
   if (scratch_bytes < flag_bytes) return hipErrorInvalidValue;
   unsigned char* keep = static_cast<unsigned char*>(d_scratch);
   void* temp = keep + flag_bytes;
   size_t temp_bytes = scratch_bytes - flag_bytes;
-  hipLaunchKernelGGL(flag_reports_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_sorted, count, keep);
+  hipLaunchKernelGGL(flag_reports_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_sorted, count, keep, all_minima);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return rocprim::select(temp, temp_bytes, d_sorted, keep, d_sel, d_sel_count, (size_t)count, stream);

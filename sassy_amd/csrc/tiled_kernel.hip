@@ -22,6 +22,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "tiled_step.h"
 
 namespace sassy_hip {
 
@@ -30,28 +31,6 @@ namespace sassy_hip {
 __constant__ uint8_t kTiledIupacNib[32] = {
     15, 1, 14, 2, 13, 15, 15, 8, 7, 15, 15, 12, 15, 3, 15, 15,
     15, 15, 9, 10, 4, 4, 11, 5, 0, 6, 15, 15, 15, 15, 15, 15};
-
-// One text character for the 64 patterns of a wave: the Myers column step with the bits along the pattern
-// (src/pattern_tiling/search.rs:148-175), the last row's cost tracked in `cost`.
-template <typename Word>
-struct TiledState {
-  Word vp, vn;
-  int cost;
-};
-template <typename Word>
-__device__ __forceinline__ void tiled_step(TiledState<Word>& S, const Word eq, const uint32_t top_shift) {
-  const Word sum = (eq & S.vp) + S.vp;
-  const Word xh = (sum ^ S.vp) | eq;
-  const Word mh = S.vp & xh;
-  const Word ph = S.vn | ~(xh | S.vp);
-  // (the top row sits in the upper half of a 64-bit word: WORDS = 2 is used for m > 32 only)
-  const uint32_t pht = sizeof(Word) == 8 ? (uint32_t)((unsigned long long)ph >> 32) : (uint32_t)ph;
-  const uint32_t mht = sizeof(Word) == 8 ? (uint32_t)((unsigned long long)mh >> 32) : (uint32_t)mh;
-  S.cost += (int)__builtin_amdgcn_ubfe(pht, top_shift, 1u) + __builtin_amdgcn_sbfe((int)mht, top_shift, 1u);
-  const Word phs = ph << 1;  // the row above the pattern is free: 0 shifted in
-  S.vp = (mh << 1) | ~(eq | S.vn | phs);
-  S.vn = phs & (eq | S.vn);
-}
 
 __device__ __forceinline__ void tiled_emit(const TiledParams& P, uint64_t pos, int cost, uint32_t pat) {
   const uint32_t idx = atomicAdd(P.cand_count, 1u);

@@ -221,10 +221,12 @@ def encoded_case(rng, searchers):
             t[rng.randrange(n)] = rng.choice(b"NRYn-*" if profile == "iupac" else b"NX-n")
     t = bytes(t)
     allm = wide and rng.random() < 0.3
-    force = rng.choice([None, None, "0", "1"])
-    if force is None:
-        os.environ.pop("SASSY_HIP_TILED", None)
-    else:
+    force = rng.choice([None, None, "0", "1", "seed", "seed"])
+    os.environ.pop("SASSY_HIP_TILED", None)
+    os.environ.pop("SASSY_HIP_SEEDED", None)
+    if force == "seed":  # seed -> verify -> report wherever the shape allows it
+        os.environ["SASSY_HIP_SEEDED"] = "1"
+    elif force is not None:
         os.environ["SASSY_HIP_TILED"] = force
     s = searchers[(profile, rc)]
     enc = s.encode_patterns(pats)
@@ -244,6 +246,7 @@ def encoded_case(rng, searchers):
                 fh.write(b"|".join(pats) + b"\n" + t)
             raise
     os.environ.pop("SASSY_HIP_TILED", None)
+    os.environ.pop("SASSY_HIP_SEEDED", None)
     if want is None or got is None:
         desc = dict(mode="encoded", profile=profile, m=m, k=k, rc=rc, npat=npat, n=n, all_minima=allm, tiled=force,
                     filtered=s.stats()["filtered"], matches=0)

@@ -826,8 +826,14 @@ def test_encoded_pattern_tiled(sassy):
         want = oracle.search_encoded("dna", pats, bytes(text), 1)
         assert sorted(key(x) for x in got) == sorted(key(x) for x in want) and len(want) >= 3, off
     # the searcher's report filters are applied per pattern: equal to the one-scan-per-pattern path
+    _encoded_filters_agree(sassy, rng, "SASSY_HIP_TILED", 5)
+
+
+def _encoded_filters_agree(sassy, rng, env, kind):
+    import os
     pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(30)]
-    text = bytearray(rng.choice(b"ACGTN") for _ in range(20_000))
+    # (the seeded search is for Dna codes: no other letters, or the reference's traceback panics)
+    text = bytearray(rng.choice(b"ACGTN" if kind == 5 else b"ACGT") for _ in range(20_000))
     for p in pats:
         for _ in range(3):
             ins = mutate(rng, p, rng.randrange(0, 3))
@@ -836,18 +842,92 @@ def test_encoded_pattern_tiled(sassy):
     tb = bytes(text)
     for cfg in ("best", "nfrac", "both"):
         res = []
-        for tiled in ("1", "0"):
-            os.environ["SASSY_HIP_TILED"] = tiled
-            s = sassy.Searcher("iupac", rc=True)
+        for on in ("1", "0"):
+            os.environ[env] = on
+            os.environ["SASSY_HIP_TILED"] = os.environ.get("SASSY_HIP_TILED", "0")
+            s = sassy.Searcher("iupac" if kind == 5 else "dna", rc=True)
             if cfg in ("best", "both"):
                 s.only_best_match()
             if cfg in ("nfrac", "both"):
                 s.with_max_n_frac(0.1)
             enc = s.encode_patterns(pats)
             res.append(sorted(key(x) for x in s.search_encoded_patterns(enc, tb, 3)))
-            assert s.stats()["filtered"] == (5 if tiled == "1" else s.stats()["filtered"])
+            assert (s.stats()["filtered"] == kind) == (on == "1")
         assert res[0] == res[1] and len(res[0]) >= 10, cfg
+    os.environ.pop(env, None)
     os.environ.pop("SASSY_HIP_TILED", None)
+
+
+def test_encoded_seeded(sassy):
+    """search_encoded_patterns through seed -> verify -> report (seed_kernels.hip: one pass over the text looks every
+    L-gram up in a table of all patterns' pigeonhole pieces, one lane per hit runs the pattern around it) against
+    the oracle.  Shapes: both word widths, seeds of one and of two lengths, seeds cut to 10 rows, 1 .. 7 pieces,
+    matches at both ends of the text, texts shorter than a pattern, lower case, the same pattern twice, both
+    strands, search_all, without_trace, a candidate list that overflows (segments are cut smaller and repeated)."""
+    import os
+    rng = random.Random(99)
+    os.environ["SASSY_HIP_SEEDED"] = "1"
+    os.environ.pop("SASSY_HIP_TILED", None)
+    shapes = [  # (searcher profile, m, k, npat, n, all_minima)
+        ("dna", 20, 2, 300, 40_000, False),
+        ("iupac", 20, 2, 70, 30_000, False),   # plain ACGT patterns and text: the Dna path after the text check
+        ("dna", 32, 3, 100, 50_000, False),
+        ("dna", 24, 1, 64, 30_000, True),
+        ("dna", 40, 2, 30, 20_000, False),      # 64-bit pattern words
+        ("dna", 12, 0, 40, 20_000, False),      # one piece of 12 rows: the seed is its last 10
+        ("dna", 35, 6, 10, 3_000, False),       # seven pieces of 5 rows: many hits
+        ("dna", 60, 1, 9, 8_000, True),         # the longest window: m + 3k + 1 = 64 characters
+        ("dna", 20, 2, 5, 7, False),            # text shorter than the patterns
+        ("dna", 20, 2, 12, 45, False),          # every window leaves the text
+        ("dna", 23, 3, 3000, 6_000, False),
+    ]
+    for (profile, m, k, npat, n, allm) in shapes:
+        pats = [bytes(rng.choice(b"ACGT") for _ in range(m)) for _ in range(npat)]
+        pats[-1] = pats[0]  # the same pattern twice: two entries under every seed
+        text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        for p in pats[:60]:
+            for _ in range(2):
+                ins = mutate(rng, p, rng.randrange(0, k + 1))
+                if rng.random() < 0.5:
+                    ins = oracle.reverse_complement("iupac", ins)
+                if len(ins) < n:
+                    at = rng.randrange(0, n - len(ins))
+                    text[at:at + len(ins)] = ins
+        if n > 100:
+            text[n - m:] = pats[1]
+            text[:m] = pats[2]
+            for _ in range(50):
+                i = rng.randrange(n); text[i] |= 0x20
+        tb = bytes(text)
+        for rc in (False, True):
+            s = sassy.Searcher(profile, rc=rc)
+            enc = s.encode_patterns(pats)
+            got = s.search_encoded_patterns(enc, tb, k, all_minima=allm)
+            st = s.stats()
+            want = oracle.search_encoded(profile, pats, tb, k, rc=rc, all_minima=allm)
+            if n >= 16:
+                assert st["filtered"] == 6, (profile, m, k, npat, n, st)
+            assert sorted(key(x) for x in got) == sorted(key(x) for x in want), (profile, m, k, npat, n, rc, allm)
+            assert len(want) >= (3 if n > 100 else 0)
+            got_wo = s.search_encoded_patterns(enc, tb, k, all_minima=allm, without_trace=True)
+            assert sorted((x.pattern_idx, x.text_end, x.cost, x.strand) for x in got_wo) == \
+                sorted((x.pattern_idx, x.text_end, x.cost, x.strand) for x in want)
+    # a text of one repeated unit: every position hits the seed tables of the patterns cut from it; the candidate
+    # list overflows its expectation-sized capacity and the segments are cut smaller
+    unit = bytes(rng.choice(b"ACGT") for _ in range(37))
+    tb = (unit * 30_000)[:1_000_000]
+    pats = [tb[i:i + 20] for i in range(0, 37)] * 3 + [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(20)]
+    pats = [bytes(mutate(rng, p, rng.randrange(0, 2))[:20].ljust(20, b"A")) for p in pats]
+    s = sassy.Searcher("dna", rc=False)
+    enc = s.encode_patterns(pats)
+    r = s.search_encoded_patterns(enc, tb, 1, as_result=True)
+    assert s.stats()["filtered"] in (6, 5, 0, 2, 4)  # (the library may give up on seeding this text)
+    sub = tb[:20_000]
+    got = [x for x in s.search_encoded_patterns(enc, sub, 1)]
+    want = oracle.search_encoded("dna", pats, sub, 1)
+    assert sorted(key(x) for x in got) == sorted(key(x) for x in want) and len(want) > 1000
+    assert len(r) > 50 * len(want) * 0.5
+    _encoded_filters_agree(sassy, rng, "SASSY_HIP_SEEDED", 6)
 
 
 def test_pack_result_for_gather(sassy):
