@@ -2491,7 +2491,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   }
   // ---- candidate list: chunks of 16 384, sized for ~1.5x the expectation of a segment ----
   const uint32_t chunk_entries = 16384;
-  const uint64_t max_entries = (uint64_t)1 << 28;  // 2 GiB of candidates at a time
+  const uint64_t max_entries = (uint64_t)1 << 30;  // at most 8 GiB of candidates at a time (sized by need)
   uint64_t seg_len = (text_len + 2047) / 2048 * 2048;
   const double slack = 1.5;
   auto entries_for = [&](uint64_t len, uint64_t waves) { return (uint64_t)(slack * per_char * (double)len) + waves * chunk_entries; };

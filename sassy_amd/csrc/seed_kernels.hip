@@ -94,13 +94,12 @@ __global__ __launch_bounds__(256) void seed_scan_kernel(const SeedParams P) {
       if (g + 16 < P.text_len) c2 = pack_codes16(src[1]);
     }
     const unsigned long long q01 = ((unsigned long long)c1 << 32) | c0, q12 = ((unsigned long long)c2 << 32) | c1;
-#pragma unroll 1
-    for (uint32_t j = 0; j < 32 && !dead; ++j) {
+    // table rows of position j: [first, count) of the entry lists (table 0: the longer pieces)
+    auto look_up = [&](uint32_t j, uint32_t& a0, uint32_t& n0, uint32_t& a1, uint32_t& n1) {
       const unsigned long long q = j < 16 ? q01 : q12;
       const uint64_t end = g + j + 1;  // exclusive end of the seeds that end in character j
-      const bool in_seg = end <= P.seg_hi && end <= P.text_len && g + j >= P.seg_lo;
-      // table 0 (longer pieces), table 1: [first, last) of the entry lists
-      uint32_t a0 = 0, n0 = 0, a1 = 0, n1 = 0;
+      const bool in_seg = j < 32 && end <= P.seg_hi && end <= P.text_len;
+      a0 = n0 = a1 = n1 = 0;
       if (P.len[0] && in_seg && end >= P.len[0]) {
         const uint32_t code = (uint32_t)(q >> (2u * (17u + (j & 15u) - P.len[0]))) & mask0;
         a0 = P.start[0][code];
@@ -111,6 +110,14 @@ __global__ __launch_bounds__(256) void seed_scan_kernel(const SeedParams P) {
         a1 = P.start[1][code];
         n1 = P.start[1][code + 1] - a1;
       }
+    };
+    uint32_t a0, n0, a1, n1;
+    look_up(0, a0, n0, a1, n1);
+#pragma unroll 1
+    for (uint32_t j = 0; j < 32 && !dead; ++j) {
+      uint32_t xa0, xn0, xa1, xn1;  // the next position's rows are in flight while this one's hits are written
+      look_up(j + 1, xa0, xn0, xa1, xn1);
+      const uint64_t end = g + j + 1;
       const uint32_t n = n0 + n1;
       for (uint32_t r = 0;; ++r) {
         const bool active = r < n;
@@ -125,6 +132,7 @@ __global__ __launch_bounds__(256) void seed_scan_kernel(const SeedParams P) {
         }
         used += cnt;
       }
+      a0 = xa0; n0 = xn0; a1 = xa1; n1 = xn1;
     }
   }
   close_chunk();
@@ -177,6 +185,10 @@ __device__ __forceinline__ void verify_candidate(const VerifyParams& P, unsigned
 #pragma unroll
   for (int x = 0; x < kSeedWindowDwords; ++x) {
     if (4 * x < T) {  // wave-uniform
+      // The last row's cost falls by at most one per character: a lane whose cost cannot reach k by the last
+      // step is done, and when that holds for every lane of the wave (nearly every candidate is a chance hit of
+      // one piece: the cost hovers around m / 2) the rest of the window is skipped.
+      if (4 * x >= 8 && __all(S.cost - (T - 4 * x) > k)) return;
 #pragma unroll
       for (int y = 0; y < 4; ++y) {
         const int t = 4 * x + y;

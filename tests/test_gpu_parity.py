@@ -1271,7 +1271,8 @@ def test_config4_full_size_10000_patterns_against_the_oracle(sassy):
     r = s.search_encoded_patterns(enc, _DevText(buf.ptr, n), k, as_result=True)
     st = s.stats()
     arr, pool = r.array, r.pool
-    assert st["scan_launches"] == npat and len(arr) > 100_000
+    # (one pass for all patterns: seed -> verify -> report, a pair of launches per text segment -- not one per pattern)
+    assert st["filtered"] == 6 and st["scan_launches"] < 1000 and len(arr) > 100_000
     pidx = arr["pattern_idx"].astype(np.int64)
     # (d) order and ranges
     assert int(pidx.min()) >= 0 and int(pidx.max()) < npat

@@ -78,18 +78,22 @@ def main():
         pats = [dna_bytes(45 + i, 20) for i in range(P)]
         s = sassy_amd.Searcher("iupac", rc=False)
         enc = s.encode_patterns(pats)
-        t0 = time.perf_counter()
-        out = sassy_amd.C.c_void_p()
-        sassy_amd._check(sassy_amd.lib().sassy_hip_search_encoded(s._h, enc._h, buf.ptr, n, 2, sassy_amd.TEXT_ON_DEVICE,
-                                                                  sassy_amd.C.byref(out)))
-        dt = time.perf_counter() - t0
-        r = sassy_amd.Result(out)
+        secs = []
+        for rep in range(args.steps if args.steps < 3 else 3):  # the first call also sizes the device buffers
+            t0 = time.perf_counter()
+            out = sassy_amd.C.c_void_p()
+            sassy_amd._check(sassy_amd.lib().sassy_hip_search_encoded(s._h, enc._h, buf.ptr, n, 2, sassy_amd.TEXT_ON_DEVICE,
+                                                                      sassy_amd.C.byref(out)))
+            secs.append(time.perf_counter() - t0)
+            r = sassy_amd.Result(out)
+        dt = min(secs)
         st = s.stats()
         print(json.dumps({"config": 4, "workload": f"search_encoded_patterns, {P} random 20-mers, k=2, Iupac new_fwd, {n} B random ACGT",
-                          "seconds": round(dt, 3), "text_GB_per_s": round(n / dt / 1e9, 3),
+                          "seconds": round(dt, 3), "seconds_each_call": [round(x, 3) for x in secs],
+                          "text_GB_per_s": round(n / dt / 1e9, 3),
                           "pattern_text_GB_per_s": round(n * P / dt / 1e9, 1), "matches": len(r),
-                          "stats": {k: st[k] for k in ("scan_ms", "filter_ms", "trace_ms", "scan_launches")}}))
-
+                          "stats": {k: st[k] for k in ("scan_ms", "filter_ms", "trace_ms", "scan_launches", "filtered", "chunks",
+                                                       "hit_blocks", "candidates")}}))
 
 if __name__ == "__main__":
     main()
