@@ -180,29 +180,16 @@ constexpr uint32_t kSeedMaxLen = 10;     // longest seed (table of 4^10 entries)
 struct SeedParams {
   const uint8_t* text;            // 16-byte aligned
   uint64_t text_len;
-  uint64_t seg_lo, seg_hi;        // seeds that END in characters [seg_lo, seg_hi) (seg_lo a multiple of 2048)
   uint32_t len[2];                // seed lengths of the two tables (0: unused)
   const uint32_t* start[2];       // 4^len + 1 offsets into entries
   const uint32_t* entries[2];     // (pattern << 3) | piece, grouped by seed code
-  unsigned long long* cand;       // n_chunks_cap * chunk_entries candidates
-  uint32_t chunk_entries;         // a multiple of 64
-  uint32_t n_chunks_cap;
-  uint32_t* alloc;                // [0] chunks handed out, [1] != 0: the list overflowed
-  uint32_t* fill;                 // per chunk: candidates written
-};
-struct VerifyParams {
-  const uint8_t* text;
-  uint64_t text_len;
-  const unsigned long long* cand;
-  uint32_t chunk_entries, n_chunks_cap;
-  const uint32_t* alloc;
-  const uint32_t* fill;
   const void* peq;                // per pattern the match masks of the four Dna codes: 4 x u32 (m <= 32) or 4 x u64
   uint32_t m, k;
   uint32_t rem[8];                // pattern rows behind piece p
-  Candidate* out;                 // every (pattern, end position, cost <= k) in a candidate's range
+  Candidate* out;                 // every (pattern, end position, cost <= k) in a hit's range
   uint32_t* out_count;
   uint32_t out_cap;
+  unsigned long long* hit_count;  // optional: number of table hits verified
 };
 
 // A finished match record as the trace kernel writes it; same layout as sassy_hip_Match

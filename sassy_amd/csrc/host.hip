@@ -65,8 +65,7 @@ hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, 
 size_t select_scratch_bytes(uint32_t count);
 hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Candidate* d_sel, uint32_t* d_sel_count,
                                  void* d_scratch, size_t scratch_bytes, hipStream_t stream, int all_minima = 0);
-hipError_t launch_seed_scan(const SeedParams& P, uint32_t grid, hipStream_t stream);
-hipError_t launch_seed_verify(const VerifyParams& P, hipStream_t stream);
+hipError_t launch_seed_search(const SeedParams& P, uint32_t grid, hipStream_t stream);
 hipError_t launch_tiled_scan(const TiledParams& P, hipStream_t stream);
 
 static thread_local std::string g_err;
@@ -401,9 +400,8 @@ struct sassy_SearcherType {
   DevBuf<uint8_t> d_tiled_pat;
   DevBuf<uint32_t> d_tiled_cnt;
   DevBuf<Candidate> d_tiled_sel;
-  // seeded search (search_encoded_seeded): piece tables, candidate list and its chunk fill counts
-  DevBuf<uint32_t> d_seed_start[2], d_seed_entries[2], d_seed_fill;
-  DevBuf<unsigned long long> d_seed_cand;
+  // seeded search (search_encoded_seeded): the piece tables
+  DevBuf<uint32_t> d_seed_start[2], d_seed_entries[2];
   hipEvent_t ev_multi = nullptr, ev_multi_a = nullptr;
   hipEvent_t ev_a_multi() { return ev_multi_a; }
   DevBuf<uint64_t> d_range;      // N counting on device-resident text
@@ -422,7 +420,6 @@ struct sassy_SearcherType {
     d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
     d_tiled_peq.release(); d_tiled_pat.release(); d_tiled_cnt.release(); d_tiled_sel.release();
     for (int t = 0; t < 2; ++t) { d_seed_start[t].release(); d_seed_entries[t].release(); }
-    d_seed_fill.release(); d_seed_cand.release();
     if (ev_multi) (void)hipEventDestroy(ev_multi);
     if (ev_multi_a) (void)hipEventDestroy(ev_multi_a);
     for (ScanLane& l : lanes) l.destroy();
@@ -2408,8 +2405,8 @@ static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* 
 }
 
 // search_encoded_patterns for many patterns over a long text: seed -> verify -> report (seed_kernels.hip).  One
-// pass over the text looks every L-gram up in a table of all patterns' pigeonhole pieces; one lane per hit runs the
-// pattern over the few dozen characters around it.  Dna codes only (the caller has checked the text is plain ACGT
+// pass over the text -- one launch -- looks every L-gram up in a table of all patterns' pigeonhole pieces; one lane
+// per hit runs the pattern over the few dozen characters around it.  Dna codes only (the caller has checked the text is plain ACGT
 // when the searcher is Iupac).  *done = false: not this shape after all (lists too large) -- the caller falls back.
 static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
                                  const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
@@ -2428,14 +2425,12 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   // ---- pieces: k+1 of them, the first m mod (k+1) one row longer; a seed is the last <= kSeedMaxLen rows of a piece ----
   const uint32_t pieces = k + 1, q = m / pieces, spare = m - q * pieces;
   uint32_t p_end[8], p_len[8], tab_of[8], tab_len[2] = {0, 0};
-  double per_char = 0;  // expected candidates per text character on random text
   for (uint32_t pc = 0; pc < pieces; ++pc) {
     const uint32_t len = q + (pc < spare ? 1u : 0u);
     p_end[pc] = pc * q + std::min(pc, spare) + len;
     p_len[pc] = std::min(len, kSeedMaxLen);
     if (tab_len[0] == 0 || tab_len[0] == p_len[pc]) { tab_len[0] = p_len[pc]; tab_of[pc] = 0; }
     else { tab_len[1] = p_len[pc]; tab_of[pc] = 1; }
-    per_char += (double)npat * std::pow(0.25, (double)p_len[pc]);
   }
   // ---- direct-address tables: code of a seed = sum of its characters' Dna codes, first character lowest ----
   std::vector<uint32_t> start[2], entries[2];
@@ -2489,19 +2484,6 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     HIP_TRY(hipMemcpyAsync(s->d_seed_start[t].p, start[t].data(), start[t].size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->d_seed_entries[t].p, entries[t].data(), entries[t].size() * 4, hipMemcpyHostToDevice, st));
   }
-  // ---- candidate list: chunks of 16 384, sized for ~1.5x the expectation of a segment ----
-  const uint32_t chunk_entries = 16384;
-  const uint64_t max_entries = (uint64_t)1 << 30;  // at most 8 GiB of candidates at a time (sized by need)
-  uint64_t seg_len = (text_len + 2047) / 2048 * 2048;
-  const double slack = 1.5;
-  auto entries_for = [&](uint64_t len, uint64_t waves) { return (uint64_t)(slack * per_char * (double)len) + waves * chunk_entries; };
-  auto waves_for = [&](uint64_t len) { return std::min<uint64_t>(4096, std::max<uint64_t>(1, len / 2048)); };
-  while (seg_len > 2048 * 64 && entries_for(seg_len, waves_for(seg_len)) > max_entries) seg_len = (seg_len / 2 + 2047) / 2048 * 2048;
-  uint64_t cap_entries = std::min(max_entries, std::max<uint64_t>(entries_for(seg_len, waves_for(seg_len)), 4 * chunk_entries));
-  uint32_t n_chunks_cap = (uint32_t)((cap_entries + chunk_entries - 1) / chunk_entries);
-  if (int rc = s->d_seed_cand.reserve((size_t)n_chunks_cap * chunk_entries)) return rc;
-  if (int rc = s->d_seed_fill.reserve(n_chunks_cap)) return rc;
-
   SeedParams SP{};
   SP.text = tptr;
   SP.text_len = text_len;
@@ -2510,72 +2492,44 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     SP.start[t] = s->d_seed_start[t].p;
     SP.entries[t] = s->d_seed_entries[t].p;
   }
-  SP.cand = s->d_seed_cand.p;
-  SP.chunk_entries = chunk_entries;
-  SP.n_chunks_cap = n_chunks_cap;
-  SP.alloc = s->d_tiled_cnt.p + 4;
-  SP.fill = s->d_seed_fill.p;
-  VerifyParams VP{};
-  VP.text = tptr;
-  VP.text_len = text_len;
-  VP.cand = s->d_seed_cand.p;
-  VP.chunk_entries = chunk_entries;
-  VP.alloc = s->d_tiled_cnt.p + 4;
-  VP.fill = s->d_seed_fill.p;
-  VP.peq = s->d_tiled_peq.p;
-  VP.m = m;
-  VP.k = k;
-  for (uint32_t pc = 0; pc < 8; ++pc) VP.rem[pc] = pc < pieces ? m - p_end[pc] : 0u;
-  VP.out_count = s->d_tiled_cnt.p;
+  SP.peq = s->d_tiled_peq.p;
+  SP.m = m;
+  SP.k = k;
+  for (uint32_t pc = 0; pc < 8; ++pc) SP.rem[pc] = pc < pieces ? m - p_end[pc] : 0u;
+  SP.out_count = s->d_tiled_cnt.p;
+  SP.hit_count = reinterpret_cast<unsigned long long*>(s->d_tiled_cnt.p + 4);
+  // 2 KiB of text per wave and step; enough waves for two rounds of the chip, contiguous runs per wave
+  static const uint64_t env_waves = getenv("SASSY_HIP_SEED_WAVES") ? (uint64_t)atoll(getenv("SASSY_HIP_SEED_WAVES")) : 0ull;
+  const uint64_t waves = std::min<uint64_t>(env_waves ? env_waves : 16384, std::max<uint64_t>(1, (text_len + 2047) / 2048));
+  const uint32_t grid = (uint32_t)((waves + kWavesPerGroup - 1) / kWavesPerGroup);
 
   const uint64_t kMaxList = 1ull << 26;
   uint32_t out_count = 0;
-  uint64_t n_cand = 0, n_seg = 0;
+  unsigned long long n_hits = 0;
   for (int attempt = 0;; ++attempt) {
     if (int rc = L.d_cand.reserve(std::max<size_t>((size_t)1 << 18, (size_t)out_count + 1024))) return rc;
-    VP.out = L.d_cand.p;
-    VP.out_cap = (uint32_t)std::min<size_t>(L.d_cand.cap, 0xFFFFFFFFu);
+    SP.out = L.d_cand.p;
+    SP.out_cap = (uint32_t)std::min<size_t>(L.d_cand.cap, 0xFFFFFFFFu);
     HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p, 0, 64, st));
     HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
-    n_cand = 0;
-    n_seg = 0;
-    uint64_t len = seg_len;
-    for (uint64_t lo = 0; lo < text_len;) {
-      const uint64_t hi = std::min<uint64_t>(text_len, lo + len);
-      SP.seg_lo = lo;
-      SP.seg_hi = hi;
-      HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p + 4, 0, 8, st));
-      const uint64_t waves = waves_for(hi - lo);
-      hipError_t le = launch_seed_scan(SP, (uint32_t)((waves + kWavesPerGroup - 1) / kWavesPerGroup), st);
-      if (le != hipSuccess) return hip_fail(le, "seed scan launch");
-      uint32_t al[2] = {0, 0};
-      HIP_TRY(hipMemcpyAsync(al, s->d_tiled_cnt.p + 4, 8, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      if (al[1]) {  // more hits than the list holds (a text far from random): smaller segments
-        if (len <= 2048 * 16) return 0;  // *done stays false
-        len = (len / 4 + 2047) / 2048 * 2048;
-        continue;
-      }
-      VP.n_chunks_cap = std::min(al[0], n_chunks_cap);
-      le = launch_seed_verify(VP, st);
-      if (le != hipSuccess) return hip_fail(le, "seed verification launch");
-      n_cand += (uint64_t)VP.n_chunks_cap * chunk_entries;  // (upper bound: the last chunk of a wave is partly filled)
-      ++n_seg;
-      lo = hi;
-    }
+    hipError_t le = launch_seed_search(SP, grid, st);
+    if (le != hipSuccess) return hip_fail(le, "seeded search launch");
     HIP_TRY(hipEventRecord(s->ev_multi, st));
-    HIP_TRY(hipMemcpyAsync(&out_count, s->d_tiled_cnt.p, 4, hipMemcpyDeviceToHost, st));
+    uint32_t ctl[6] = {0, 0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(ctl, s->d_tiled_cnt.p, sizeof ctl, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    out_count = ctl[0];
+    memcpy(&n_hits, ctl + 4, 8);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
     s->stats.scan_ms += ms;
-    s->stats.scan_launches += 2 * n_seg;
-    if (out_count <= VP.out_cap) break;
+    s->stats.scan_launches += 1;
+    if (out_count <= SP.out_cap) break;
     if (out_count > kMaxList || attempt == 2) return 0;  // *done stays false
   }
   s->stats.text_bytes += text_len;
-  s->stats.chunks += n_seg;
-  s->stats.hit_blocks += n_cand;
+  s->stats.chunks += waves;
+  s->stats.hit_blocks += n_hits;  // (here: table hits verified)
   s->stats.piece_len = tab_len[0];
   s->stats.filtered = 6;
   s->stats.candidates += out_count;
@@ -3505,7 +3459,7 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
       double rate = 0;
       for (size_t pc = 0; pc < k + 1; ++pc)
         rate += std::pow(0.25, (double)std::min<size_t>(e->plen / (k + 1) + (pc < e->plen % (k + 1) ? 1 : 0), kSeedMaxLen));
-      seeded = rate * (double)(e->plen + 3 * k + 1) * 24.0 < 8.0 && (double)text_len * (double)e->patterns.size() >= 2e9;
+      seeded = rate * (double)(e->plen + 3 * k + 1) * 24.0 < 8.0 && (double)text_len * (double)e->patterns.size() >= 1e9;
       if (env_seeded >= 0) seeded = env_seeded != 0;
     }
     bool tiled_done = false;

@@ -6,20 +6,21 @@
 // edits leaves one of k+1 disjoint pattern pieces intact): cut every pattern into k+1 pieces; an end position e
 // with cost <= k has an alignment in which some piece p matches the text exactly, ending at a text position i with
 // e in [i + rem_p - k, i + rem_p + k] (rem_p = pattern rows behind the piece).  So
-//   K-seed   (seed_scan_kernel): ONE pass over the text.  Every lane packs its characters to 2-bit Dna codes, forms
-//            the L-gram ending at each position and looks it up in a direct-address table of all pieces of all
-//            patterns (4^L entries -> list of (pattern, piece)); every hit is appended to a candidate list as
-//            (position, pattern, piece).  The waves write through private chunks of the list (one atomic per
-//            16 384 candidates);
-//   K-verify (seed_verify_kernel): one lane per candidate runs the pattern's Myers column steps (bits along the
-//            pattern, tiled_step.h) over the m + 3k + 1 characters in front of the last end position the candidate
-//            allows, from the fresh column -- exact after m + k characters -- and appends every end position with
-//            cost <= k in its range to the (pattern, position, cost) list;
+//   seed     (seed_search_kernel, first half of its loop): ONE pass over the text.  Every lane packs its characters
+//            to 2-bit Dna codes, forms the L-gram ending at each position and looks it up in a direct-address table
+//            of all pieces of all patterns (4^L entries -> list of (pattern, piece)); every hit goes into the wave's
+//            queue in LDS as (position, pattern, piece);
+//   verify   (same kernel, whenever 64 hits are queued): one lane per hit runs the pattern's Myers column steps (bits
+//            along the pattern, tiled_step.h) over the m + 3k + 1 characters in front of the last end position the
+//            hit allows, from the fresh column -- exact after m + k characters -- and appends every end position
+//            with cost <= k in its range to the (pattern, position, cost) list.  (A first version wrote the hits to
+//            a global list and verified them in a second kernel: 176 GB of traffic and 8 GB of memory at config 4
+//            for nothing -- the hits of a wave are consumed where they are found, the text around them still in L2.)
 //   the list holds ALL positions with cost <= k (some twice: a match seen through two pieces), which is what the
 //   report rule needs: sort, drop duplicates, flag the reports per run (sort_kernels.hip), trace them
 //   (trace_wave_kernel) -- the tail of the pattern-tiled search (host.hip: finish_pattern_list).
 //
-// Cost at config 4: 3.7e-4 candidates per (position, pattern) x 27 characters x ~24 VALU operations against the
+// Cost at config 4: 3.7e-4 hits per (position, pattern) x 27 characters x ~24 VALU operations against the
 // 17 operations per (position, pattern) of the pattern-tiled scan and the ~100 per (row, pattern, two blocks) of
 // the multi-pattern bit-plane filter.  Integer VALU and L2-resident tables; the text is read once.
 #include <hip/hip_runtime.h>
@@ -45,102 +46,9 @@ __device__ __forceinline__ uint32_t pack_codes16(const uint4 v) {
 
 }  // namespace
 
-// One wave walks a contiguous range of the segment, 2 KiB per step: lane l takes the 32 characters
-// [g, g + 32), g = step base + 32 l, plus the 16 in front of them (seeds that end in its characters start there).
-__global__ __launch_bounds__(256) void seed_scan_kernel(const SeedParams P) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerGroup + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const uint64_t n_waves = (uint64_t)gridDim.x * kWavesPerGroup;
-  // the segment in 2 KiB steps, dealt to the waves in contiguous runs
-  const uint64_t steps = (P.seg_hi - P.seg_lo + 2047) / 2048;
-  const uint64_t per_wave = (steps + n_waves - 1) / n_waves;
-  const uint64_t s_lo = wave * per_wave;
-  const uint64_t s_hi = s_lo + per_wave < steps ? s_lo + per_wave : steps;
-  if (s_lo >= s_hi) return;
-
-  // this wave's chunk of the candidate list
-  uint32_t chunk = 0xFFFFFFFFu, used = 0;
-  bool dead = false;
-  auto close_chunk = [&]() {
-    if (chunk != 0xFFFFFFFFu && lane == 0) P.fill[chunk] = used;
-  };
-  auto reserve = [&](uint32_t need) -> bool {  // wave-uniform; false: the list is full
-    if (chunk == 0xFFFFFFFFu || used + need > P.chunk_entries) {
-      close_chunk();
-      uint32_t id = 0;
-      if (lane == 0) id = atomicAdd(P.alloc, 1u);
-      id = (uint32_t)__builtin_amdgcn_readfirstlane((int)id);
-      if (id >= P.n_chunks_cap) {
-        if (lane == 0) P.alloc[1] = 1u;  // overflow: the host repeats the segment in smaller pieces
-        chunk = 0xFFFFFFFFu;
-        return false;
-      }
-      chunk = id;
-      used = 0;
-    }
-    return true;
-  };
-
-  const uint32_t mask0 = P.len[0] ? (uint32_t)((1ull << (2 * P.len[0])) - 1) : 0u;
-  const uint32_t mask1 = P.len[1] ? (uint32_t)((1ull << (2 * P.len[1])) - 1) : 0u;
-  for (uint64_t s = s_lo; s < s_hi && !dead; ++s) {
-    const uint64_t g = P.seg_lo + s * 2048 + 32ull * lane;  // a multiple of 32 (seg_lo is one)
-    // 48 characters as 96 bits of codes; bytes outside the text are never part of an accepted seed
-    uint32_t c0 = 0, c1 = 0, c2 = 0;
-    if (g < P.text_len) {
-      const uint4* src = reinterpret_cast<const uint4*>(P.text + g);
-      if (g >= 16) c0 = pack_codes16(src[-1]);
-      c1 = pack_codes16(src[0]);
-      if (g + 16 < P.text_len) c2 = pack_codes16(src[1]);
-    }
-    const unsigned long long q01 = ((unsigned long long)c1 << 32) | c0, q12 = ((unsigned long long)c2 << 32) | c1;
-    // table rows of position j: [first, count) of the entry lists (table 0: the longer pieces)
-    auto look_up = [&](uint32_t j, uint32_t& a0, uint32_t& n0, uint32_t& a1, uint32_t& n1) {
-      const unsigned long long q = j < 16 ? q01 : q12;
-      const uint64_t end = g + j + 1;  // exclusive end of the seeds that end in character j
-      const bool in_seg = j < 32 && end <= P.seg_hi && end <= P.text_len;
-      a0 = n0 = a1 = n1 = 0;
-      if (P.len[0] && in_seg && end >= P.len[0]) {
-        const uint32_t code = (uint32_t)(q >> (2u * (17u + (j & 15u) - P.len[0]))) & mask0;
-        a0 = P.start[0][code];
-        n0 = P.start[0][code + 1] - a0;
-      }
-      if (P.len[1] && in_seg && end >= P.len[1]) {
-        const uint32_t code = (uint32_t)(q >> (2u * (17u + (j & 15u) - P.len[1]))) & mask1;
-        a1 = P.start[1][code];
-        n1 = P.start[1][code + 1] - a1;
-      }
-    };
-    uint32_t a0, n0, a1, n1;
-    look_up(0, a0, n0, a1, n1);
-#pragma unroll 1
-    for (uint32_t j = 0; j < 32 && !dead; ++j) {
-      uint32_t xa0, xn0, xa1, xn1;  // the next position's rows are in flight while this one's hits are written
-      look_up(j + 1, xa0, xn0, xa1, xn1);
-      const uint64_t end = g + j + 1;
-      const uint32_t n = n0 + n1;
-      for (uint32_t r = 0;; ++r) {
-        const bool active = r < n;
-        const unsigned long long m = __ballot(active);
-        if (m == 0) break;
-        const uint32_t cnt = (uint32_t)__popcll(m);
-        if (!reserve(cnt)) { dead = true; break; }
-        if (active) {
-          const uint32_t e = r < n0 ? P.entries[0][a0 + r] : P.entries[1][a1 + (r - n0)];
-          const uint32_t slot = used + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          P.cand[(uint64_t)chunk * P.chunk_entries + slot] = ((unsigned long long)end << kSeedPosShift) | e;
-        }
-        used += cnt;
-      }
-      a0 = xa0; n0 = xn0; a1 = xa1; n1 = xn1;
-    }
-  }
-  close_chunk();
-}
-
 // One lane per candidate.  EDGE: the candidate's window leaves the text (the first / last few dozen characters).
 template <int WORDS, bool EDGE>
-__device__ __forceinline__ void verify_candidate(const VerifyParams& P, unsigned long long cand) {
+__device__ __forceinline__ void verify_candidate(const SeedParams& P, unsigned long long cand) {
   typedef typename std::conditional<WORDS == 1, uint32_t, unsigned long long>::type Word;
   const uint32_t entry = (uint32_t)cand & ((1u << kSeedPosShift) - 1u);
   const uint32_t pat = entry >> 3, piece = entry & 7u;
@@ -215,45 +123,116 @@ __device__ __forceinline__ void verify_candidate(const VerifyParams& P, unsigned
   }
 }
 
+// One wave walks a contiguous range of the text, 2 KiB per step: lane l takes the 32 characters [g, g + 32),
+// g = step base + 32 l, plus the 16 in front of them (seeds that end in its characters start there).
 template <int WORDS>
-__global__ __launch_bounds__(256) void seed_verify_kernel(const VerifyParams P) {
-  const uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t chunk = (uint32_t)(slot / P.chunk_entries);  // wave-uniform (chunk_entries is a multiple of 64)
-  uint32_t n_chunks = P.alloc[0];
-  if (n_chunks > P.n_chunks_cap) n_chunks = P.n_chunks_cap;
-  if (chunk >= n_chunks) return;
-  const uint32_t within = (uint32_t)(slot % P.chunk_entries);
-  const bool have = within < P.fill[chunk];
-  if (!__any(have)) return;
-  unsigned long long cand = 0;
-  bool edge = false;
-  if (have) {
-    cand = P.cand[slot];
-    const int64_t i = (int64_t)(cand >> kSeedPosShift);
-    const int64_t e_hi = i + (int64_t)P.rem[(uint32_t)cand & 7u] + (int64_t)P.k;
-    const int64_t s0 = e_hi - ((int64_t)P.m + 3 * (int64_t)P.k + 1);
-    edge = s0 < 4 || e_hi + 8 > (int64_t)P.text_len;
+__global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
+  __shared__ unsigned long long queue_mem[kWavesPerGroup][128];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave_in_group = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerGroup + wave_in_group;
+  const uint64_t n_waves = (uint64_t)gridDim.x * kWavesPerGroup;
+  const uint64_t steps = (P.text_len + 2047) / 2048;
+  const uint64_t per_wave = (steps + n_waves - 1) / n_waves;
+  const uint64_t s_lo = wave * per_wave;
+  const uint64_t s_hi = s_lo + per_wave < steps ? s_lo + per_wave : steps;
+  if (s_lo >= s_hi) return;
+  unsigned long long* queue = queue_mem[wave_in_group];
+  uint32_t queued = 0;      // wave-uniform
+  uint64_t n_hits = 0;
+
+  // verify the first `count` queued hits, one per lane (the window of a hit near the text's ends needs range checks)
+  auto verify = [&](uint32_t count) {
+    const bool have = lane < count;
+    unsigned long long cand = 0;
+    bool edge = false;
+    if (have) {
+      cand = queue[lane];
+      const int64_t i = (int64_t)(cand >> kSeedPosShift);
+      const int64_t e_hi = i + (int64_t)P.rem[(uint32_t)cand & 7u] + (int64_t)P.k;
+      const int64_t s0 = e_hi - ((int64_t)P.m + 3 * (int64_t)P.k + 1);
+      edge = s0 < 4 || e_hi + 8 > (int64_t)P.text_len;
+    }
+    if (__any(edge)) {
+      if (have) verify_candidate<WORDS, true>(P, cand);
+    } else {
+      if (have) verify_candidate<WORDS, false>(P, cand);
+    }
+  };
+
+  const uint32_t mask0 = P.len[0] ? (uint32_t)((1ull << (2 * P.len[0])) - 1) : 0u;
+  const uint32_t mask1 = P.len[1] ? (uint32_t)((1ull << (2 * P.len[1])) - 1) : 0u;
+  for (uint64_t s = s_lo; s < s_hi; ++s) {
+    const uint64_t g = s * 2048 + 32ull * lane;
+    // 48 characters as 96 bits of codes; bytes outside the text are never part of an accepted seed
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    if (g < P.text_len) {
+      const uint4* src = reinterpret_cast<const uint4*>(P.text + g);
+      if (g >= 16) c0 = pack_codes16(src[-1]);
+      c1 = pack_codes16(src[0]);
+      if (g + 16 < P.text_len) c2 = pack_codes16(src[1]);
+    }
+    const unsigned long long q01 = ((unsigned long long)c1 << 32) | c0, q12 = ((unsigned long long)c2 << 32) | c1;
+    // table rows of position j: [first, count) of the entry lists (table 0: the longer pieces)
+    auto look_up = [&](uint32_t j, uint32_t& a0, uint32_t& n0, uint32_t& a1, uint32_t& n1) {
+      const unsigned long long q = j < 16 ? q01 : q12;
+      const uint64_t end = g + j + 1;  // exclusive end of the seeds that end in character j
+      const bool in_text = j < 32 && end <= P.text_len;
+      a0 = n0 = a1 = n1 = 0;
+      if (P.len[0] && in_text && end >= P.len[0]) {
+        const uint32_t code = (uint32_t)(q >> (2u * (17u + (j & 15u) - P.len[0]))) & mask0;
+        a0 = P.start[0][code];
+        n0 = P.start[0][code + 1] - a0;
+      }
+      if (P.len[1] && in_text && end >= P.len[1]) {
+        const uint32_t code = (uint32_t)(q >> (2u * (17u + (j & 15u) - P.len[1]))) & mask1;
+        a1 = P.start[1][code];
+        n1 = P.start[1][code + 1] - a1;
+      }
+    };
+    uint32_t a0, n0, a1, n1;
+    look_up(0, a0, n0, a1, n1);
+#pragma unroll 1
+    for (uint32_t j = 0; j < 32; ++j) {
+      uint32_t xa0, xn0, xa1, xn1;  // the next position's rows are in flight while this one's hits are queued
+      look_up(j + 1, xa0, xn0, xa1, xn1);
+      const uint64_t end = g + j + 1;
+      const uint32_t n = n0 + n1;
+      for (uint32_t r = 0;; ++r) {
+        const bool active = r < n;
+        const unsigned long long m = __ballot(active);
+        if (m == 0) break;
+        if (active) {
+          const uint32_t e = r < n0 ? P.entries[0][a0 + r] : P.entries[1][a1 + (r - n0)];
+          const uint32_t slot = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+          queue[slot] = ((unsigned long long)end << kSeedPosShift) | e;
+        }
+        queued += (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+        if (queued >= 64) {
+          verify(64);
+          const uint32_t rest = queued - 64;
+          unsigned long long moved = 0;
+          if (lane < rest) moved = queue[64 + lane];
+          __builtin_amdgcn_wave_barrier();
+          if (lane < rest) queue[lane] = moved;
+          __builtin_amdgcn_wave_barrier();
+          queued = rest;
+          n_hits += 64;
+        }
+      }
+      a0 = xa0; n0 = xn0; a1 = xa1; n1 = xn1;
+    }
   }
-  if (__any(edge)) {
-    if (have) verify_candidate<WORDS, true>(P, cand);
-  } else {
-    if (have) verify_candidate<WORDS, false>(P, cand);
-  }
+  if (queued) verify(queued);
+  n_hits += queued;
+  if (P.hit_count && lane == 0 && n_hits) atomicAdd(P.hit_count, (unsigned long long)n_hits);
 }
 
-hipError_t launch_seed_scan(const SeedParams& P, uint32_t grid, hipStream_t stream) {
-  if (P.seg_hi <= P.seg_lo) return hipSuccess;
-  hipLaunchKernelGGL(seed_scan_kernel, dim3(grid), dim3(256), 0, stream, P);
-  return hipGetLastError();
-}
-
-hipError_t launch_seed_verify(const VerifyParams& P, hipStream_t stream) {
-  const uint64_t slots = (uint64_t)P.n_chunks_cap * P.chunk_entries;
-  const uint64_t groups = (slots + 255) / 256;
-  if (groups == 0) return hipSuccess;
-  if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
-  if (P.m <= 32) hipLaunchKernelGGL((seed_verify_kernel<1>), dim3((uint32_t)groups), dim3(256), 0, stream, P);
-  else hipLaunchKernelGGL((seed_verify_kernel<2>), dim3((uint32_t)groups), dim3(256), 0, stream, P);
+hipError_t launch_seed_search(const SeedParams& P, uint32_t grid, hipStream_t stream) {
+  if (P.text_len == 0 || grid == 0) return hipSuccess;
+  if (P.m <= 32) hipLaunchKernelGGL((seed_search_kernel<1>), dim3(grid), dim3(256), 0, stream, P);
+  else hipLaunchKernelGGL((seed_search_kernel<2>), dim3(grid), dim3(256), 0, stream, P);
   return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
-"""search_encoded_patterns: the pattern-tiled one-pass scan (tiled_kernel.hip) against one scan per pattern,
-over (number of patterns) x (text length).  Device-resident random-ACGT text, random 20-mers, k = 2, Iupac
+"""search_encoded_patterns: seed -> verify -> report (seed_kernels.hip), the pattern-tiled one-pass scan
+(tiled_kernel.hip) and one kernel chain per pattern, over (number of patterns) x (text length).  Device-resident random-ACGT text, random 20-mers, k = 2, Iupac
 searcher as in BASELINE config 4.  Prints one line per shape: ms per call for both paths, and the
 pattern-tiled kernel's rate in (text characters x patterns) per second.
 
@@ -46,18 +46,24 @@ def main():
     buf = sassy_amd.DeviceBuffer(nmax + 4096)
     sassy_amd.generate_dna(buf.ptr, nmax, 7, 0)
     print(f"# m={args.m} k={args.k} profile={args.profile}")
-    print("# npat  text_bytes  tiled_ms  per_pattern_ms  speedup  tiled_kernel_ms  cells/s(kernel)  matches")
+    print("# ms per call (best of 3, device-resident text); kind = what the library picks by itself "
+          "(6 seeded, 5 pattern-tiled, else one chain per pattern)")
+    print("# npat  text_bytes  auto_ms kind  seeded_ms  tiled_ms  per_pattern_ms  tiled_kernel_ms  char*pat/s(tiled kernel)  matches")
+    modes = {"auto": {}, "seeded": {"SASSY_HIP_SEEDED": "1"}, "tiled": {"SASSY_HIP_SEEDED": "0", "SASSY_HIP_TILED": "1"},
+             "chains": {"SASSY_HIP_SEEDED": "0", "SASSY_HIP_TILED": "0"}}
     for npat in (64, 1000, 10000):
         pats = [bytes(rng.choice(b"ACGT") for _ in range(args.m)) for _ in range(npat)]
         for n in (10_000, 1 << 20, 16 << 20, 64 << 20, 256 << 20):
             res = {}
-            for tiled in ("1", "0"):
-                os.environ["SASSY_HIP_TILED"] = tiled
+            for mode, env in modes.items():
+                for key in ("SASSY_HIP_SEEDED", "SASSY_HIP_TILED"):
+                    os.environ.pop(key, None)
+                os.environ.update(env)
                 s = sassy_amd.Searcher(args.profile, rc=False)
                 enc = s.encode_patterns(pats)
-                est = npat * 60e-6 + npat * n / 2e12 if tiled == "0" else 0
+                est = npat * 60e-6 + npat * n / 2e12 if mode == "chains" else (n * npat / 2e12 if mode == "tiled" else 0)
                 if est > args.max_per_pattern_s:
-                    res[tiled] = (float("nan"), 0, 0.0)
+                    res[mode] = (float("nan"), -1, 0.0, -1)
                     continue
                 best = 1e30
                 for rep in range(3):
@@ -65,14 +71,15 @@ def main():
                     r = s.search_encoded_patterns(enc, DevText(buf.ptr, n), args.k, as_result=True)
                     best = min(best, time.perf_counter() - t0)
                 st = s.stats()
-                res[tiled] = (best * 1e3, len(r), st["scan_ms"] if tiled == "1" else 0.0)
-            t_ms, nm, kern_ms = res["1"]
-            p_ms, nm0, _ = res["0"]
-            assert nm0 in (0, nm) or p_ms != p_ms, (nm, nm0)
+                res[mode] = (best * 1e3, len(r), st["scan_ms"], st["filtered"])
+            counts = {v[1] for v in res.values() if v[1] >= 0}
+            assert len(counts) == 1, res
+            kern_ms = res["tiled"][2] if res["tiled"][3] == 5 else 0.0
             rate = (n * npat / (kern_ms * 1e-3)) if kern_ms else 0.0
-            print(f"{npat:6d} {n:11d} {t_ms:9.2f} {p_ms:14.2f} {p_ms / t_ms:8.1f} {kern_ms:10.3f} {rate:12.3e} {nm:8d}",
-                  flush=True)
-    os.environ.pop("SASSY_HIP_TILED", None)
+            print(f"{npat:6d} {n:11d} {res['auto'][0]:8.2f} {res['auto'][3]:4d} {res['seeded'][0]:10.2f} {res['tiled'][0]:9.2f} "
+                  f"{res['chains'][0]:15.2f} {kern_ms:16.3f} {rate:12.3e} {counts.pop():8d}", flush=True)
+    for key in ("SASSY_HIP_SEEDED", "SASSY_HIP_TILED"):
+        os.environ.pop(key, None)
 
 
 if __name__ == "__main__":
