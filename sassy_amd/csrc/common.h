@@ -185,11 +185,22 @@ struct SeedParams {
   const uint32_t* entries[2];     // (pattern << 3) | piece, grouped by seed code
   const void* peq;                // per pattern the match masks of the four Dna codes: 4 x u32 (m <= 32) or 4 x u64
   uint32_t m, k;
-  uint32_t rem[8];                // pattern rows behind piece p
+  uint64_t rem_packed;            // byte p = pattern rows behind piece p (per-lane lookups: no arrays in the arguments)
   Candidate* out;                 // every (pattern, end position, cost <= k) in a hit's range
   uint32_t* out_count;
   uint32_t out_cap;
-  unsigned long long* hit_count;  // optional: number of table hits verified
+  unsigned long long* hit_count;  // optional: [0] table hits, [1] hits that passed the sub-piece test
+  // ---- the sub-piece test in front of the verification (m <= 32; sub == nullptr: off) ----
+  // A hit says piece p is intact at i.  The other rows of the pattern hold at most k edits, so of any k+1 disjoint
+  // sub-pieces of them one is intact too, at most k characters off the seed's diagonal.  sub[8 p + u] = row a |
+  // len << 8 | c0 << 16 | side << 24 of sub-piece u of piece p: rows [a, a + len), len <= 16; side 0: left of the
+  // seed, compared in the window of 32 characters that ends 8 behind the seed's start, side 1: right of it, window
+  // of 32 characters that starts 8 in front of the seed's end; c0 = its character offset in that window on the
+  // seed's diagonal.  len = 0 in sub[8 p]: no test for piece p.
+  const uint32_t* sub;
+  const uint32_t* packed_text;    // 2-bit Dna codes of the text, 16 characters per dword
+  const unsigned long long* packed_pat;  // per pattern: row r at bits 2r
+  uint64_t seed_len_packed;       // byte p = rows of the seed of piece p
 };
 
 // A finished match record as the trace kernel writes it; same layout as sassy_hip_Match

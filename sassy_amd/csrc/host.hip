@@ -66,6 +66,7 @@ size_t select_scratch_bytes(uint32_t count);
 hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Candidate* d_sel, uint32_t* d_sel_count,
                                  void* d_scratch, size_t scratch_bytes, hipStream_t stream, int all_minima = 0);
 hipError_t launch_seed_search(const SeedParams& P, uint32_t grid, hipStream_t stream);
+hipError_t launch_pack_text(const uint8_t* d_text, uint64_t n, uint32_t* d_packed, hipStream_t stream);
 hipError_t launch_tiled_scan(const TiledParams& P, hipStream_t stream);
 
 static thread_local std::string g_err;
@@ -400,8 +401,9 @@ struct sassy_SearcherType {
   DevBuf<uint8_t> d_tiled_pat;
   DevBuf<uint32_t> d_tiled_cnt;
   DevBuf<Candidate> d_tiled_sel;
-  // seeded search (search_encoded_seeded): the piece tables
-  DevBuf<uint32_t> d_seed_start[2], d_seed_entries[2];
+  // seeded search (search_encoded_seeded): the piece tables; sub-piece table, packed text and patterns
+  DevBuf<uint32_t> d_seed_start[2], d_seed_entries[2], d_seed_sub, d_seed_packed;
+  DevBuf<unsigned long long> d_seed_ppk;
   hipEvent_t ev_multi = nullptr, ev_multi_a = nullptr;
   hipEvent_t ev_a_multi() { return ev_multi_a; }
   DevBuf<uint64_t> d_range;      // N counting on device-resident text
@@ -420,6 +422,7 @@ struct sassy_SearcherType {
     d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
     d_tiled_peq.release(); d_tiled_pat.release(); d_tiled_cnt.release(); d_tiled_sel.release();
     for (int t = 0; t < 2; ++t) { d_seed_start[t].release(); d_seed_entries[t].release(); }
+    d_seed_sub.release(); d_seed_packed.release(); d_seed_ppk.release();
     if (ev_multi) (void)hipEventDestroy(ev_multi);
     if (ev_multi_a) (void)hipEventDestroy(ev_multi_a);
     for (ScanLane& l : lanes) l.destroy();
@@ -2495,7 +2498,54 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   SP.peq = s->d_tiled_peq.p;
   SP.m = m;
   SP.k = k;
-  for (uint32_t pc = 0; pc < 8; ++pc) SP.rem[pc] = pc < pieces ? m - p_end[pc] : 0u;
+  for (uint32_t pc = 0; pc < pieces; ++pc) {
+    SP.rem_packed |= (uint64_t)(m - p_end[pc]) << (8 * pc);
+    SP.seed_len_packed |= (uint64_t)p_len[pc] << (8 * pc);
+  }
+  // ---- the sub-piece test in front of the verification (common.h: SeedParams::sub; patterns of <= 32 rows) ----
+  // For a hit of piece p: k+1 disjoint sub-pieces of the rows within 24 - k of the seed, shared out between the two
+  // sides in proportion to the rows there; one of them must be intact within k characters of the seed's diagonal.
+  static const bool env_sub = !(getenv("SASSY_HIP_SEED_SUBTEST") && atoi(getenv("SASSY_HIP_SEED_SUBTEST")) == 0);
+  if (!wide && env_sub) {
+    std::vector<uint32_t> sub(64, 0u);
+    const uint32_t reach = 24 - k;  // (k <= 7)
+    for (uint32_t pc = 0; pc < pieces; ++pc) {
+      const uint32_t sp = p_end[pc] - p_len[pc], pe = p_end[pc];
+      const uint32_t nl = std::min(sp, reach), nr = std::min(m - pe, reach);
+      if (nl + nr < pieces) continue;  // fewer rows than sub-pieces: no test for this piece
+      uint32_t cl = (uint32_t)(((uint64_t)pieces * nl + (nl + nr) / 2) / (nl + nr));
+      cl = std::min(cl, nl);
+      uint32_t cr = pieces - cl;
+      if (cr > nr) { cr = nr; cl = pieces - cr; }
+      uint32_t u = 0;
+      for (uint32_t x = 0; x < cl; ++x) {  // left of the seed: rows [sp - nl, sp) in cl parts
+        const uint32_t a = sp - nl + (uint32_t)((uint64_t)nl * x / cl), b = sp - nl + (uint32_t)((uint64_t)nl * (x + 1) / cl);
+        const uint32_t len = std::min(b - a, 16u);
+        sub[8 * pc + u++] = a | (len << 8) | ((24u - (sp - a)) << 16) | (0u << 24);
+      }
+      for (uint32_t x = 0; x < cr; ++x) {  // right of it: rows [pe, pe + nr) in cr parts
+        const uint32_t a = pe + (uint32_t)((uint64_t)nr * x / cr), b = pe + (uint32_t)((uint64_t)nr * (x + 1) / cr);
+        const uint32_t len = std::min(b - a, 16u);
+        sub[8 * pc + u++] = a | (len << 8) | ((8u + (a - pe)) << 16) | (1u << 24);
+      }
+    }
+    std::vector<unsigned long long> ppk(npat, 0ull);
+    for (size_t p = 0; p < npat; ++p)
+      for (uint32_t j = 0; j < m; ++j) ppk[p] |= (unsigned long long)((e->patterns[p][j] >> 1) & 3u) << (2 * j);
+    const uint64_t n16 = (text_len + 15) / 16;
+    if (int rc = s->d_seed_sub.reserve(64)) return rc;
+    if (int rc = s->d_seed_ppk.reserve(npat)) return rc;
+    if (int rc = s->d_seed_packed.reserve(n16 + 8)) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_seed_sub.p, sub.data(), 64 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_seed_ppk.p, ppk.data(), npat * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(s->d_seed_packed.p + n16, 0, 8 * 4, st));
+    hipError_t pe_ = launch_pack_text(tptr, text_len, s->d_seed_packed.p, st);
+    if (pe_ != hipSuccess) return hip_fail(pe_, "text packing launch");
+    HIP_TRY(hipStreamSynchronize(st));  // (`sub`, `ppk` go out of scope)
+    SP.sub = s->d_seed_sub.p;
+    SP.packed_text = s->d_seed_packed.p;
+    SP.packed_pat = s->d_seed_ppk.p;
+  }
   SP.out_count = s->d_tiled_cnt.p;
   SP.hit_count = reinterpret_cast<unsigned long long*>(s->d_tiled_cnt.p + 4);
   // 2 KiB of text per wave and step; enough waves for two rounds of the chip, contiguous runs per wave
@@ -2505,7 +2555,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
 
   const uint64_t kMaxList = 1ull << 26;
   uint32_t out_count = 0;
-  unsigned long long n_hits = 0;
+  unsigned long long n_hits = 0, n_pass = 0;
   for (int attempt = 0;; ++attempt) {
     if (int rc = L.d_cand.reserve(std::max<size_t>((size_t)1 << 18, (size_t)out_count + 1024))) return rc;
     SP.out = L.d_cand.p;
@@ -2515,11 +2565,12 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     hipError_t le = launch_seed_search(SP, grid, st);
     if (le != hipSuccess) return hip_fail(le, "seeded search launch");
     HIP_TRY(hipEventRecord(s->ev_multi, st));
-    uint32_t ctl[6] = {0, 0, 0, 0, 0, 0};
+    uint32_t ctl[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY(hipMemcpyAsync(ctl, s->d_tiled_cnt.p, sizeof ctl, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     out_count = ctl[0];
     memcpy(&n_hits, ctl + 4, 8);
+    memcpy(&n_pass, ctl + 6, 8);
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
     s->stats.scan_ms += ms;
@@ -2529,7 +2580,8 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   }
   s->stats.text_bytes += text_len;
   s->stats.chunks += waves;
-  s->stats.hit_blocks += n_hits;  // (here: table hits verified)
+  s->stats.hit_blocks += n_hits;   // (here: table hits ...
+  s->stats.live_blocks += n_pass;  //  ... and how many of them passed the sub-piece test)
   s->stats.piece_len = tab_len[0];
   s->stats.filtered = 6;
   s->stats.candidates += out_count;

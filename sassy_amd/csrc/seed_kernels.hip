@@ -25,6 +25,7 @@
 // the multi-pattern bit-plane filter.  Integer VALU and L2-resident tables; the text is read once.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -44,6 +45,56 @@ __device__ __forceinline__ uint32_t pack_codes16(const uint4 v) {
   return d[0] | (d[1] << 8) | (d[2] << 16) | (d[3] << 24);
 }
 
+// 2-bit copy of the text for the sub-piece test: dword x = characters [16 x, 16 x + 16)
+__global__ __launch_bounds__(256) void pack_text_kernel(const uint4* __restrict__ text16, uint64_t n16,
+                                                        uint32_t* __restrict__ packed) {
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x)
+    packed[i] = pack_codes16(text16[i]);
+}
+
+// 64 bits = 32 characters of the packed text from character c on (c >= 0, the dwords exist)
+__device__ __forceinline__ unsigned long long packed_window(const uint32_t* packed, int64_t c) {
+  const uint32_t* src = packed + (c >> 4);
+  const uint32_t sh = 2u * ((uint32_t)c & 15u);
+  const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
+  const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// The sub-piece test (SeedParams::sub): false = no alignment with <= k edits keeps this hit's piece intact.
+__device__ __forceinline__ bool sub_piece_test(const SeedParams& P, unsigned long long cand) {
+  const uint32_t entry = (uint32_t)cand & ((1u << kSeedPosShift) - 1u);
+  const uint32_t pat = entry >> 3, piece = entry & 7u;
+  const int64_t i = (int64_t)(cand >> kSeedPosShift);
+  // everything the test reads, requested at once: the piece's sub-piece row, the pattern, the two text windows
+  const uint4* row = reinterpret_cast<const uint4*>(P.sub + 8u * piece);
+  const uint4 r0 = row[0], r1 = row[1];
+  const unsigned long long pp = P.packed_pat[pat];
+  const int64_t cl = i - (int64_t)((P.seed_len_packed >> (8u * piece)) & 0xFFu) - 24, ch = i - 8;
+  const bool inside = cl >= 0 && ch + 32 <= (int64_t)P.text_len;
+  const unsigned long long lo = packed_window(P.packed_text, inside ? cl : 0),
+                           hi = packed_window(P.packed_text, inside ? ch : 0);
+  if (((r0.x >> 8) & 0xFFu) == 0u || !inside) return true;  // untested
+  const uint32_t ent[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+  const uint32_t k = P.k;
+  bool ok = false;
+#pragma unroll
+  for (uint32_t u = 0; u < 8; ++u) {
+    if (u <= k) {  // wave-uniform
+      const uint32_t a = ent[u] & 0xFFu, len = (ent[u] >> 8) & 0xFFu, c0 = (ent[u] >> 16) & 0xFFu;
+      const uint32_t want = (uint32_t)(pp >> (2u * a));
+      const uint32_t mask = len >= 16u ? 0xFFFFFFFFu : (1u << (2u * len)) - 1u;
+      // the window from the leftmost shift on; every further shift is two bits down
+      unsigned long long w = ((ent[u] >> 24) ? hi : lo) >> (2u * (c0 - k));
+      for (uint32_t d = 0; d <= 2u * k; ++d) {
+        ok = ok || (((uint32_t)w ^ want) & mask) == 0u;
+        w >>= 2;
+      }
+    }
+  }
+  return ok;
+}
+
 }  // namespace
 
 // One lane per candidate.  EDGE: the candidate's window leaves the text (the first / last few dozen characters).
@@ -55,7 +106,7 @@ __device__ __forceinline__ void verify_candidate(const SeedParams& P, unsigned l
   const int64_t i = (int64_t)(cand >> kSeedPosShift);
   const int m = (int)P.m, k = (int)P.k;
   const int T = m + 3 * k + 1;
-  const int64_t e_hi = i + (int64_t)P.rem[piece] + k;  // last end position the seed allows
+  const int64_t e_hi = i + (int64_t)((P.rem_packed >> (8u * piece)) & 0xFFu) + k;  // last end position the seed allows
   const int64_t s0 = e_hi - T;                          // first character of the window
   // the pattern's match masks per Dna code
   Word e[4];
@@ -127,7 +178,7 @@ __device__ __forceinline__ void verify_candidate(const SeedParams& P, unsigned l
 // g = step base + 32 l, plus the 16 in front of them (seeds that end in its characters start there).
 template <int WORDS>
 __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
-  __shared__ unsigned long long queue_mem[kWavesPerGroup][128];
+  __shared__ unsigned long long queue_mem[kWavesPerGroup][128], pass_mem[kWavesPerGroup][128];
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave_in_group = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerGroup + wave_in_group;
@@ -138,18 +189,19 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
   const uint64_t s_hi = s_lo + per_wave < steps ? s_lo + per_wave : steps;
   if (s_lo >= s_hi) return;
   unsigned long long* queue = queue_mem[wave_in_group];
-  uint32_t queued = 0;      // wave-uniform
-  uint64_t n_hits = 0;
+  unsigned long long* passed = pass_mem[wave_in_group];
+  uint32_t queued = 0, n_passed = 0;  // wave-uniform
+  uint64_t n_hits = 0, n_pass = 0;
 
-  // verify the first `count` queued hits, one per lane (the window of a hit near the text's ends needs range checks)
-  auto verify = [&](uint32_t count) {
+  // verify the first `count` hits of `from`, one per lane (the window of a hit near the text's ends needs range checks)
+  auto verify_from = [&](const unsigned long long* from, uint32_t count) __attribute__((always_inline)) {
     const bool have = lane < count;
     unsigned long long cand = 0;
     bool edge = false;
     if (have) {
-      cand = queue[lane];
+      cand = from[lane];
       const int64_t i = (int64_t)(cand >> kSeedPosShift);
-      const int64_t e_hi = i + (int64_t)P.rem[(uint32_t)cand & 7u] + (int64_t)P.k;
+      const int64_t e_hi = i + (int64_t)((P.rem_packed >> (8u * ((uint32_t)cand & 7u))) & 0xFFu) + (int64_t)P.k;
       const int64_t s0 = e_hi - ((int64_t)P.m + 3 * (int64_t)P.k + 1);
       edge = s0 < 4 || e_hi + 8 > (int64_t)P.text_len;
     }
@@ -157,6 +209,36 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
       if (have) verify_candidate<WORDS, true>(P, cand);
     } else {
       if (have) verify_candidate<WORDS, false>(P, cand);
+    }
+  };
+  // drop the first 64 entries of a queue of `have` (< 128) entries
+  auto pop64 = [&](unsigned long long* q, uint32_t have) __attribute__((always_inline)) {
+    const uint32_t rest = have - 64;
+    unsigned long long moved = 0;
+    if (lane < rest) moved = q[64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rest) q[lane] = moved;
+    __builtin_amdgcn_wave_barrier();
+  };
+  // The first `count` queued hits, one per lane: with the sub-piece test (WORDS == 1, P.sub) the few that pass it
+  // collect in a second queue and are verified 64 at a time, else they are verified at once.
+  auto verify = [&](uint32_t count) __attribute__((always_inline)) {
+    if (WORDS != 1 || P.sub == nullptr) { verify_from(queue, count); return; }
+    bool ok = false;
+    unsigned long long cand = 0;
+    if (lane < count) {
+      cand = queue[lane];
+      ok = sub_piece_test(P, cand);
+    }
+    const unsigned long long m = __ballot(ok);
+    if (ok) passed[n_passed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = cand;
+    n_passed += (uint32_t)__popcll(m);
+    n_pass += (uint32_t)__popcll(m);
+    __builtin_amdgcn_wave_barrier();
+    if (n_passed >= 64) {
+      verify_from(passed, 64);
+      pop64(passed, n_passed);
+      n_passed -= 64;
     }
   };
 
@@ -174,7 +256,7 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
     }
     const unsigned long long q01 = ((unsigned long long)c1 << 32) | c0, q12 = ((unsigned long long)c2 << 32) | c1;
     // table rows of position j: [first, count) of the entry lists (table 0: the longer pieces)
-    auto look_up = [&](uint32_t j, uint32_t& a0, uint32_t& n0, uint32_t& a1, uint32_t& n1) {
+    auto look_up = [&](uint32_t j, uint32_t& a0, uint32_t& n0, uint32_t& a1, uint32_t& n1) __attribute__((always_inline)) {
       const unsigned long long q = j < 16 ? q01 : q12;
       const uint64_t end = g + j + 1;  // exclusive end of the seeds that end in character j
       const bool in_text = j < 32 && end <= P.text_len;
@@ -211,13 +293,8 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
         __builtin_amdgcn_wave_barrier();
         if (queued >= 64) {
           verify(64);
-          const uint32_t rest = queued - 64;
-          unsigned long long moved = 0;
-          if (lane < rest) moved = queue[64 + lane];
-          __builtin_amdgcn_wave_barrier();
-          if (lane < rest) queue[lane] = moved;
-          __builtin_amdgcn_wave_barrier();
-          queued = rest;
+          pop64(queue, queued);
+          queued -= 64;
           n_hits += 64;
         }
       }
@@ -226,7 +303,20 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
   }
   if (queued) verify(queued);
   n_hits += queued;
-  if (P.hit_count && lane == 0 && n_hits) atomicAdd(P.hit_count, (unsigned long long)n_hits);
+  if (n_passed) verify_from(passed, n_passed);
+  if (P.hit_count && lane == 0 && n_hits) {
+    atomicAdd(P.hit_count, (unsigned long long)n_hits);
+    atomicAdd(P.hit_count + 1, (unsigned long long)n_pass);
+  }
+}
+
+// packed[0 .. ceil(n / 16)) = the text's Dna codes (the caller pads the buffer with 4 more dwords)
+hipError_t launch_pack_text(const uint8_t* d_text, uint64_t n, uint32_t* d_packed, hipStream_t stream) {
+  const uint64_t n16 = (n + 15) / 16;
+  if (n16 == 0) return hipSuccess;
+  const uint32_t grid = (uint32_t)std::min<uint64_t>(8192, (n16 + 255) / 256);
+  hipLaunchKernelGGL(pack_text_kernel, dim3(grid), dim3(256), 0, stream, reinterpret_cast<const uint4*>(d_text), n16, d_packed);
+  return hipGetLastError();
 }
 
 hipError_t launch_seed_search(const SeedParams& P, uint32_t grid, hipStream_t stream) {

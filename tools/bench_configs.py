@@ -93,7 +93,7 @@ def main():
                           "text_GB_per_s": round(n / dt / 1e9, 3),
                           "pattern_text_GB_per_s": round(n * P / dt / 1e9, 1), "matches": len(r),
                           "stats": {k: st[k] for k in ("scan_ms", "filter_ms", "trace_ms", "scan_launches", "filtered", "chunks",
-                                                       "hit_blocks", "candidates")}}))
+                                                       "hit_blocks", "live_blocks", "candidates")}}))
 
 if __name__ == "__main__":
     main()
