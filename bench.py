@@ -144,6 +144,8 @@ def main():
                     help="wall seconds the CPU baseline's threads keep scanning (at least one pass)")
     ap.add_argument("--in-flight", type=int, default=2,
                     help="searches in flight on the device (1 = every search alone: begin, wait, next)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of BASELINE configs 3 and 4 on the resident text (N = 1, after the timed steps)")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="debugging the N > 1 path on a box with fewer GPUs than ranks: ranks share devices and "
                          "the match exchange goes over gloo; never a valid scaling measurement")
@@ -429,11 +431,47 @@ def main():
         gpu_ends = [(int(e), int(c)) for e, c in zip(matches.array["text_end"], matches.array["cost"])]
         out["cpu_baseline"] = cpu_baseline(host, pat, k, args.profile, gpu_ends, args.cpu_seconds)
         out["h2d_inclusive"] = h2d_inclusive(sassy_amd, args.profile, pat, host, k, len(matches))
+        if not args.no_other_configs:
+            out["other_configs"] = other_configs(sassy_amd, buf[:n_per])
     print(json.dumps(out), flush=True)
     if gather_worker is not None:
         gather_worker.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def other_configs(sassy_amd, text):
+    """BASELINE configs 3 and 4 on the text that is resident anyway (N = 1, after the timed steps; reported next
+    to the bench line, never part of `value`): config 3 = one 200-row Iupac pattern, k = 20; config 4 =
+    search_encoded_patterns with 10 000 pre-encoded 20-mers, k = 2, Iupac searcher.  The text carries the bench
+    pattern's plants (one per MiB), which neither pattern set matches.  Parity of both at this size: tests/."""
+    n = text.numel()
+    res = {}
+    p = bytearray(_dna_bytes(44, 0, 200))
+    p[50], p[100], p[150], p[199] = ord("N"), ord("R"), ord("Y"), ord("W")
+    s3 = sassy_amd.Searcher("iupac", rc=False)
+    r = s3.search_shard(bytes(p), text.data_ptr(), 0, n, 0, n, 20)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        r = s3.search_shard(bytes(p), text.data_ptr(), 0, n, 0, n, 20)
+    dt = (time.perf_counter() - t0) / 5
+    res["3"] = {"workload": f"Iupac new_fwd, |pattern|=200 (N, R, Y, W at 50/100/150/199), k=20, {n} B",
+                "ms_per_search": round(dt * 1e3, 3), "text_GB_per_s": round(n / dt / 1e9, 1), "matches": len(r),
+                "path": s3.stats()["filtered"]}
+    flat = _dna_bytes(45, 0, 20 * 10_000).tobytes()
+    pats = [flat[20 * i:20 * i + 20] for i in range(10_000)]
+    s4 = sassy_amd.Searcher("iupac", rc=False)
+    enc = s4.encode_patterns(pats)
+    secs = []
+    for _ in range(2):  # the first call also sizes the device buffers
+        t0 = time.perf_counter()
+        r = s4.search_encoded_patterns(enc, text, 2, as_result=True)
+        secs.append(time.perf_counter() - t0)
+    res["4"] = {"workload": f"Iupac new_fwd, search_encoded_patterns, 10 000 seeded random 20-mers, k=2, {n} B",
+                "seconds": round(min(secs), 4), "seconds_first_call": round(secs[0], 4),
+                "pattern_text_TB_per_s": round(n * 10_000 / min(secs) / 1e12, 1), "matches": len(r),
+                "path": s4.stats()["filtered"]}
+    return res
 
 
 def h2d_inclusive(sassy_amd, profile, pat, host_text, k, want_matches):
