@@ -192,11 +192,11 @@ struct SeedParams {
   unsigned long long* hit_count;  // optional: [0] table hits, [1] hits that passed the sub-piece test
   // ---- the sub-piece test in front of the verification (m <= 32; sub == nullptr: off) ----
   // A hit says piece p is intact at i.  The other rows of the pattern hold at most k edits, so of any k+1 disjoint
-  // sub-pieces of them one is intact too, at most k characters off the seed's diagonal.  sub[8 p + u] = row a |
-  // len << 8 | c0 << 16 | side << 24 of sub-piece u of piece p: rows [a, a + len), len <= 16; side 0: left of the
-  // seed, compared in the window of 32 characters that ends 8 behind the seed's start, side 1: right of it, window
-  // of 32 characters that starts 8 in front of the seed's end; c0 = its character offset in that window on the
-  // seed's diagonal.  len = 0 in sub[8 p]: no test for piece p.
+  // sub-pieces of them one is intact too, at most k characters off the seed's diagonal.  Sub-piece u of piece p =
+  // rows [a, a + len), len <= 16; side 0: left of the seed, compared in the window of 32 characters that ends 8
+  // behind the seed's start, side 1: right of it, window of 32 characters that starts 8 in front of the seed's end;
+  // c0 = its character offset in that window on the seed's diagonal.  sub[8 p + u] = 2a | (32 - 2 len) << 8 |
+  // 2 (c0 - k) << 16 | side << 24 (the shift amounts the test uses); sub[8 p] = 0xFF in its low byte: no test for piece p.
   const uint32_t* sub;
   const uint32_t* packed_text;    // 2-bit Dna codes of the text, 16 characters per dword
   const unsigned long long* packed_pat;  // per pattern: row r at bits 2r

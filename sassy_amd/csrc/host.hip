@@ -400,7 +400,7 @@ struct sassy_SearcherType {
   DevBuf<unsigned long long> d_tiled_peq;
   DevBuf<uint8_t> d_tiled_pat;
   DevBuf<uint32_t> d_tiled_cnt;
-  DevBuf<Candidate> d_tiled_sel;
+  DevBuf<Candidate> d_tiled_sel, d_tiled_list;  // (the list is not a lane's d_cand: its size must not leak into single searches)
   // seeded search (search_encoded_seeded): the piece tables; sub-piece table, packed text and patterns
   DevBuf<uint32_t> d_seed_start[2], d_seed_entries[2], d_seed_sub, d_seed_packed;
   DevBuf<unsigned long long> d_seed_ppk;
@@ -420,7 +420,7 @@ struct sassy_SearcherType {
     d_text.release(); d_rev.release(); d_rc_bitmap.release();
     free_stage();
     d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
-    d_tiled_peq.release(); d_tiled_pat.release(); d_tiled_cnt.release(); d_tiled_sel.release();
+    d_tiled_peq.release(); d_tiled_pat.release(); d_tiled_cnt.release(); d_tiled_sel.release(); d_tiled_list.release();
     for (int t = 0; t < 2; ++t) { d_seed_start[t].release(); d_seed_entries[t].release(); }
     d_seed_sub.release(); d_seed_packed.release(); d_seed_ppk.release();
     if (ev_multi) (void)hipEventDestroy(ev_multi);
@@ -1193,10 +1193,10 @@ int ScanJob::prepare() {
 int ScanJob::enqueue(int attempt) {
   P.cand = L.d_cand.p;
   P.cand_cap = (uint32_t)std::min<size_t>(L.d_cand.cap, 0xFFFFFFFFu);
+  // (the buffer may be large from an earlier, denser search: the cigar pool of this one holds at most 4 GiB)
+  if (do_trace) P.cand_cap = (uint32_t)std::min<uint64_t>(P.cand_cap, 0xFFFFFFFFull / T.str_stride);
   if (int rc = L.d_sorted.reserve(P.cand_cap)) return rc;
   if (do_trace) {
-    if ((uint64_t)P.cand_cap * T.str_stride > 0xFFFFFFFFull)
-      return fail(SASSY_HIP_EUNSUPPORTED, "too many reports for one cigar pool (> 4 GiB of cigar text)");
     if (int rc = L.d_trace.reserve(P.cand_cap)) return rc;
     if (int rc = L.d_str.reserve((size_t)P.cand_cap * T.str_stride)) return rc;
     T.cand = Tw.cand = L.d_sorted.p;
@@ -1343,6 +1343,8 @@ int ScanJob::finish(ScanOut& out) {
       again = true;
     }
     if (counts[0] > P.cand_cap) {  // more reports than the buffer holds (dense matches)
+      if (do_trace && ((uint64_t)counts[0] + 1024) * T.str_stride > 0xFFFFFFFFull)
+        return fail(SASSY_HIP_EUNSUPPORTED, "too many reports for one cigar pool (> 4 GiB of cigar text)");
       if (int rc = L.d_cand.reserve((size_t)counts[0] + 1024)) return rc;
       again = true;
     }
@@ -2184,7 +2186,7 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
   return 0;
 }
 
-// The tail of the one-pass searches of many patterns (pattern-tiled scan, seeded search): lanes[0].d_cand holds
+// The tail of the one-pass searches of many patterns (pattern-tiled scan, seeded search): d_tiled_list holds
 // `count` records (pattern, end position, cost) -- EVERY end position with cost <= k of every pattern, in any
 // order, `copies`: possibly several times.  Sort by (pattern, position), apply the report rule to each run
 // (sort_kernels.hip), trace the reports with one wavefront each (the report's pattern comes with it), apply the
@@ -2199,7 +2201,7 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
   // ---- (pattern, position) order, then the report rule ----
   if (int rc = L.d_sorted.reserve(count)) return rc;
   if (int rc = L.d_sort.reserve(std::max(sort_scratch_bytes(count), select_scratch_bytes(count)))) return rc;
-  hipError_t le = launch_sort_candidates(L.d_cand.p, L.d_sorted.p, count, L.d_sort.p, L.d_sort.cap, st, 1);
+  hipError_t le = launch_sort_candidates(s->d_tiled_list.p, L.d_sorted.p, count, L.d_sort.p, L.d_sort.cap, st, 1);
   if (le != hipSuccess) return hip_fail(le, "report sort launch");
   const Candidate* d_rep = L.d_sorted.p;
   uint32_t n_rep = count;
@@ -2379,9 +2381,9 @@ static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* 
   const uint64_t kMaxList = 1ull << 26;  // 1 GiB of (pattern, position, cost) records: beyond that, per-pattern scans
   uint32_t counts[2] = {0, 0};
   for (int attempt = 0;; ++attempt) {
-    if (int rc = L.d_cand.reserve(std::max<size_t>((size_t)1 << 18, (size_t)counts[0] + 1024))) return rc;
-    P.cand = L.d_cand.p;
-    P.cand_cap = (uint32_t)std::min<size_t>(L.d_cand.cap, 0xFFFFFFFFu);
+    if (int rc = s->d_tiled_list.reserve(std::max<size_t>((size_t)1 << 18, (size_t)counts[0] + 1024))) return rc;
+    P.cand = s->d_tiled_list.p;
+    P.cand_cap = (uint32_t)std::min<size_t>(s->d_tiled_list.cap, 0xFFFFFFFFu);
     P.cand_count = s->d_tiled_cnt.p;
     HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p, 0, 64, st));
     HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
@@ -2507,7 +2509,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   // sides in proportion to the rows there; one of them must be intact within k characters of the seed's diagonal.
   static const bool env_sub = !(getenv("SASSY_HIP_SEED_SUBTEST") && atoi(getenv("SASSY_HIP_SEED_SUBTEST")) == 0);
   if (!wide && env_sub) {
-    std::vector<uint32_t> sub(64, 0u);
+    std::vector<uint32_t> sub(64, 0xFFu);  // (low byte 0xFF in a piece's first entry: no test for that piece)
     const uint32_t reach = 24 - k;  // (k <= 7)
     for (uint32_t pc = 0; pc < pieces; ++pc) {
       const uint32_t sp = p_end[pc] - p_len[pc], pe = p_end[pc];
@@ -2521,12 +2523,12 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
       for (uint32_t x = 0; x < cl; ++x) {  // left of the seed: rows [sp - nl, sp) in cl parts
         const uint32_t a = sp - nl + (uint32_t)((uint64_t)nl * x / cl), b = sp - nl + (uint32_t)((uint64_t)nl * (x + 1) / cl);
         const uint32_t len = std::min(b - a, 16u);
-        sub[8 * pc + u++] = a | (len << 8) | ((24u - (sp - a)) << 16) | (0u << 24);
+        sub[8 * pc + u++] = (2 * a) | ((32 - 2 * len) << 8) | ((2 * (24u - (sp - a) - k)) << 16) | (0u << 24);
       }
       for (uint32_t x = 0; x < cr; ++x) {  // right of it: rows [pe, pe + nr) in cr parts
         const uint32_t a = pe + (uint32_t)((uint64_t)nr * x / cr), b = pe + (uint32_t)((uint64_t)nr * (x + 1) / cr);
         const uint32_t len = std::min(b - a, 16u);
-        sub[8 * pc + u++] = a | (len << 8) | ((8u + (a - pe)) << 16) | (1u << 24);
+        sub[8 * pc + u++] = (2 * a) | ((32 - 2 * len) << 8) | ((2 * (8u + (a - pe) - k)) << 16) | (1u << 24);
       }
     }
     std::vector<unsigned long long> ppk(npat, 0ull);
@@ -2557,9 +2559,9 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   uint32_t out_count = 0;
   unsigned long long n_hits = 0, n_pass = 0;
   for (int attempt = 0;; ++attempt) {
-    if (int rc = L.d_cand.reserve(std::max<size_t>((size_t)1 << 18, (size_t)out_count + 1024))) return rc;
-    SP.out = L.d_cand.p;
-    SP.out_cap = (uint32_t)std::min<size_t>(L.d_cand.cap, 0xFFFFFFFFu);
+    if (int rc = s->d_tiled_list.reserve(std::max<size_t>((size_t)1 << 18, (size_t)out_count + 1024))) return rc;
+    SP.out = s->d_tiled_list.p;
+    SP.out_cap = (uint32_t)std::min<size_t>(s->d_tiled_list.cap, 0xFFFFFFFFu);
     HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p, 0, 64, st));
     HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
     hipError_t le = launch_seed_search(SP, grid, st);

@@ -62,6 +62,8 @@ __device__ __forceinline__ unsigned long long packed_window(const uint32_t* pack
 }
 
 // The sub-piece test (SeedParams::sub): false = no alignment with <= k edits keeps this hit's piece intact.
+// KT >= 0: k is the compile-time constant KT (the loops over sub-pieces and shifts unroll), KT < 0: any k.
+template <int KT>
 __device__ __forceinline__ bool sub_piece_test(const SeedParams& P, unsigned long long cand) {
   const uint32_t entry = (uint32_t)cand & ((1u << kSeedPosShift) - 1u);
   const uint32_t pat = entry >> 3, piece = entry & 7u;
@@ -74,25 +76,31 @@ __device__ __forceinline__ bool sub_piece_test(const SeedParams& P, unsigned lon
   const bool inside = cl >= 0 && ch + 32 <= (int64_t)P.text_len;
   const unsigned long long lo = packed_window(P.packed_text, inside ? cl : 0),
                            hi = packed_window(P.packed_text, inside ? ch : 0);
-  if (((r0.x >> 8) & 0xFFu) == 0u || !inside) return true;  // untested
+  if ((r0.x & 0xFFu) == 0xFFu || !inside) return true;  // untested
   const uint32_t ent[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
-  const uint32_t k = P.k;
-  bool ok = false;
+  const uint32_t k = KT >= 0 ? (uint32_t)KT : P.k;
+  uint32_t miss = 0xFFFFFFFFu;  // minimum over all (sub-piece, shift) of the differing bits: 0 = one of them is intact
 #pragma unroll
   for (uint32_t u = 0; u < 8; ++u) {
-    if (u <= k) {  // wave-uniform
-      const uint32_t a = ent[u] & 0xFFu, len = (ent[u] >> 8) & 0xFFu, c0 = (ent[u] >> 16) & 0xFFu;
-      const uint32_t want = (uint32_t)(pp >> (2u * a));
-      const uint32_t mask = len >= 16u ? 0xFFFFFFFFu : (1u << (2u * len)) - 1u;
+    if (u <= k) {
+      // row fields (host.hip): 2a | (32 - 2 len) << 8 | 2 (c0 - k) << 16 | side << 24
+      const uint32_t want = (uint32_t)(pp >> (ent[u] & 0xFFu));
+      const uint32_t mask = 0xFFFFFFFFu >> ((ent[u] >> 8) & 0xFFu);
       // the window from the leftmost shift on; every further shift is two bits down
-      unsigned long long w = ((ent[u] >> 24) ? hi : lo) >> (2u * (c0 - k));
-      for (uint32_t d = 0; d <= 2u * k; ++d) {
-        ok = ok || (((uint32_t)w ^ want) & mask) == 0u;
-        w >>= 2;
+      const unsigned long long w = ((ent[u] >> 24) ? hi : lo) >> ((ent[u] >> 16) & 0xFFu);
+      const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+      if (KT >= 0) {
+#pragma unroll
+        for (uint32_t d = 0; d <= 2u * (uint32_t)(KT >= 0 ? KT : 0); ++d) {
+          const uint32_t got = d == 0 ? wl : __builtin_amdgcn_alignbit(wh, wl, 2u * d);
+          miss = min(miss, (got ^ want) & mask);
+        }
+      } else {
+        for (uint32_t d = 0; d <= 2u * k; ++d) miss = min(miss, (__builtin_amdgcn_alignbit(wh, wl, 2u * d) ^ want) & mask);
       }
     }
   }
-  return ok;
+  return miss == 0u;
 }
 
 }  // namespace
@@ -176,7 +184,8 @@ __device__ __forceinline__ void verify_candidate(const SeedParams& P, unsigned l
 
 // One wave walks a contiguous range of the text, 2 KiB per step: lane l takes the 32 characters [g, g + 32),
 // g = step base + 32 l, plus the 16 in front of them (seeds that end in its characters start there).
-template <int WORDS>
+// KT: the sub-piece test's k (>= 0: compile-time, -1: run-time, -2: no test).
+template <int WORDS, int KT>
 __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
   __shared__ unsigned long long queue_mem[kWavesPerGroup][128], pass_mem[kWavesPerGroup][128];
   const uint32_t lane = threadIdx.x & 63u;
@@ -223,12 +232,12 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
   // The first `count` queued hits, one per lane: with the sub-piece test (WORDS == 1, P.sub) the few that pass it
   // collect in a second queue and are verified 64 at a time, else they are verified at once.
   auto verify = [&](uint32_t count) __attribute__((always_inline)) {
-    if (WORDS != 1 || P.sub == nullptr) { verify_from(queue, count); return; }
+    if (KT < -1) { verify_from(queue, count); return; }
     bool ok = false;
     unsigned long long cand = 0;
     if (lane < count) {
       cand = queue[lane];
-      ok = sub_piece_test(P, cand);
+      ok = sub_piece_test<KT>(P, cand);
     }
     const unsigned long long m = __ballot(ok);
     if (ok) passed[n_passed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = cand;
@@ -321,8 +330,14 @@ hipError_t launch_pack_text(const uint8_t* d_text, uint64_t n, uint32_t* d_packe
 
 hipError_t launch_seed_search(const SeedParams& P, uint32_t grid, hipStream_t stream) {
   if (P.text_len == 0 || grid == 0) return hipSuccess;
-  if (P.m <= 32) hipLaunchKernelGGL((seed_search_kernel<1>), dim3(grid), dim3(256), 0, stream, P);
-  else hipLaunchKernelGGL((seed_search_kernel<2>), dim3(grid), dim3(256), 0, stream, P);
+  const dim3 g(grid), b(256);
+  if (P.m > 32) hipLaunchKernelGGL((seed_search_kernel<2, -2>), g, b, 0, stream, P);
+  else if (P.sub == nullptr) hipLaunchKernelGGL((seed_search_kernel<1, -2>), g, b, 0, stream, P);
+  else if (P.k == 0) hipLaunchKernelGGL((seed_search_kernel<1, 0>), g, b, 0, stream, P);
+  else if (P.k == 1) hipLaunchKernelGGL((seed_search_kernel<1, 1>), g, b, 0, stream, P);
+  else if (P.k == 2) hipLaunchKernelGGL((seed_search_kernel<1, 2>), g, b, 0, stream, P);
+  else if (P.k == 3) hipLaunchKernelGGL((seed_search_kernel<1, 3>), g, b, 0, stream, P);
+  else hipLaunchKernelGGL((seed_search_kernel<1, -1>), g, b, 0, stream, P);
   return hipGetLastError();
 }
 

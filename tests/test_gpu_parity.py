@@ -930,6 +930,26 @@ def test_encoded_seeded(sassy):
     _encoded_filters_agree(sassy, rng, "SASSY_HIP_SEEDED", 6)
 
 
+def test_dense_search_then_long_cigars_on_one_searcher(sassy):
+    """A searcher keeps its device buffers across calls: after a search with millions of reports (the report buffer
+    grows with them) a search whose cigars are long must not size its cigar pool by that capacity (2.1 M reports
+    x 2 208 B of cigar text would pass the pool's 4 GiB and used to fail with EUNSUPPORTED)."""
+    rng = random.Random(5)
+    s = sassy.Searcher("dna", rc=False)
+    dense = b"A" * 2_100_000
+    got = s.search_all(b"AAAAAAAA", dense, 0)
+    assert len(got) == len(dense) - 7
+    m, k = 1000, 100
+    pat = rand_seq(rng, m)
+    text = bytearray(rand_seq(rng, 60_000))
+    ins = mutate(rng, pat, 40)
+    text[20_000:20_000 + len(ins)] = ins
+    got = s.search(pat, bytes(text), k)
+    want = oracle.search("dna", pat, bytes(text), k)
+    assert_same(got, want)
+    assert len(want) >= 1
+
+
 def test_pack_result_for_gather(sassy):
     """multigpu.pack_result (vectorised wire format of the match gather) against the per-match packer."""
     from sassy_amd import multigpu
