@@ -3490,17 +3490,21 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
     const uint32_t mq = (uint32_t)std::min<size_t>(e->plen / (k + 1), 12);
     const bool multi = s->profile == PROFILE_DNA && std::isnan(s->alpha) && e->patterns.size() >= 8 && k + 1 <= 8 &&
                        mq >= 6 && text_len >= multi_min && (((uintptr_t)tptr) & 15) == 0;
-    // Many patterns, short or medium text: the pattern-tiled scan does all of them in one pass, where one
-    // scan per pattern pays 40-65 us of launches each.  Measured (tools/bench_encoded.py, 20-mers, k = 2): the
-    // tiled kernel advances 3.8e10 (character x group of 64 patterns) per second; 1 000 / 10 000 patterns break
-    // even with the per-pattern paths at ~100 MB of text (SASSY_HIP_TILED=0 / 1 forces the choice).
+    // Many patterns: the pattern-tiled scan does all of them in one pass, where one scan per pattern pays a kernel
+    // chain each.  Measured (tools/bench_encoded.py, config 4's shape; profiles/r02_encoded_paths.txt): the tiled
+    // kernel advances 3.8e10 (character x group of 64 patterns) per second; a chain costs ~60 us, or 40 us +
+    // 7.8e-14 s per text byte behind the multi-pattern prefilter (long plain-ACGT texts), or 60 us + 5.5e-13 s
+    // per byte with its own filter pass (texts with other letters).  SASSY_HIP_TILED=0 / 1 forces the choice.
     const int env_tiled = getenv("SASSY_HIP_TILED") ? atoi(getenv("SASSY_HIP_TILED")) : -1;  // (read per call: tests flip it)
-    const double tiled_budget = getenv("SASSY_HIP_TILED_BUDGET") ? atof(getenv("SASSY_HIP_TILED_BUDGET")) : 1.5e6;
+    const double tiled_bias = getenv("SASSY_HIP_TILED_BUDGET") ? atof(getenv("SASSY_HIP_TILED_BUDGET")) : 1.0;
     const bool tiled_ok = s->profile != PROFILE_ASCII && std::isnan(s->alpha) && 2 * k + 3 <= 64 &&
                           e->patterns.size() < (1u << 24) && text_len < (1ull << 40);
     const uint64_t tiled_groups = (e->patterns.size() + 63) / 64;
-    bool tiled = tiled_ok && e->patterns.size() >= 2 &&
-                 (double)text_len * (double)tiled_groups <= tiled_budget * (double)e->patterns.size();
+    const double est_tiled = (double)text_len * (double)tiled_groups / 3.8e10 + 1e-4;
+    const double est_chains = (double)e->patterns.size() *
+        (multi ? 40e-6 + 7.8e-14 * (double)text_len
+               : 60e-6 + (text_len >= multi_min ? 5.5e-13 * (double)text_len : 0.0));
+    bool tiled = tiled_ok && e->patterns.size() >= 2 && est_tiled <= tiled_bias * est_chains;
     if (env_tiled >= 0) tiled = tiled_ok && env_tiled != 0;
     // Many patterns, long text, selective pieces: seed -> verify -> report (seed_kernels.hip) reads the text
     // once for all patterns.  Expected cost per (character, pattern): hit rate x window x ~24 operations, against
