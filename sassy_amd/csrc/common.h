@@ -260,6 +260,9 @@ struct TraceParams {
   const Candidate* unsorted;
   Candidate* host_cand;
   uint4* host_ctl;
+  // many patterns over a multi-text buffer (pattern_stride != 0 and texts.n != 0): the flags name the pattern, the
+  // text of report c is report_text[c]
+  const uint32_t* report_text;
 };
 // MatchOut::pad_[0] of a record whose traceback found no ancestor / exceeded the scanned cost
 constexpr uint8_t kTraceFailed = 1;

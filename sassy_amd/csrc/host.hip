@@ -68,6 +68,8 @@ hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Cand
 hipError_t launch_seed_search(const SeedParams& P, uint32_t grid, hipStream_t stream);
 hipError_t launch_pack_text(const uint8_t* d_text, uint64_t n, uint32_t* d_packed, hipStream_t stream);
 hipError_t launch_tiled_scan(const TiledParams& P, hipStream_t stream);
+hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable& texts, uint32_t* d_report_text,
+                               hipStream_t stream);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -399,7 +401,7 @@ struct sassy_SearcherType {
   // pattern-tiled search (search_encoded_tiled): match masks, the patterns' bytes, counters, the selected reports
   DevBuf<unsigned long long> d_tiled_peq;
   DevBuf<uint8_t> d_tiled_pat;
-  DevBuf<uint32_t> d_tiled_cnt;
+  DevBuf<uint32_t> d_tiled_cnt, d_tiled_rtext;
   DevBuf<Candidate> d_tiled_sel, d_tiled_list;  // (the list is not a lane's d_cand: its size must not leak into single searches)
   // seeded search (search_encoded_seeded): the piece tables; sub-piece table, packed text and patterns
   DevBuf<uint32_t> d_seed_start[2], d_seed_entries[2], d_seed_sub, d_seed_packed;
@@ -420,7 +422,7 @@ struct sassy_SearcherType {
     d_text.release(); d_rev.release(); d_rc_bitmap.release();
     free_stage();
     d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
-    d_tiled_peq.release(); d_tiled_pat.release(); d_tiled_cnt.release(); d_tiled_sel.release(); d_tiled_list.release();
+    d_tiled_peq.release(); d_tiled_pat.release(); d_tiled_cnt.release(); d_tiled_sel.release(); d_tiled_list.release(); d_tiled_rtext.release();
     for (int t = 0; t < 2; ++t) { d_seed_start[t].release(); d_seed_entries[t].release(); }
     d_seed_sub.release(); d_seed_packed.release(); d_seed_ppk.release();
     if (ev_multi) (void)hipEventDestroy(ev_multi);
@@ -2191,9 +2193,13 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
 // order, `copies`: possibly several times.  Sort by (pattern, position), apply the report rule to each run
 // (sort_kernels.hip), trace the reports with one wavefront each (the report's pattern comes with it), apply the
 // searcher's report filters per pattern and append the records to R.
+// tt / ht: the buffer holds several texts (device / host tables): a report learns its text from its position,
+// reports inside a separator are moved to their text's end (search_all: dropped), the records carry text-relative
+// coordinates and the text's index in the buffer.
 static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, const PatternPlan& plan0,
                                const uint8_t* tptr, const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all,
-                               bool wo, uint32_t count, bool copies, sassy_hip_Result* R) {
+                               bool wo, uint32_t count, bool copies, sassy_hip_Result* R,
+                               const TextTable* tt = nullptr, const HostTexts* ht = nullptr) {
   ScanLane& L = s->lanes[0];
   hipStream_t st = s->stream;
   const uint32_t m = (uint32_t)e->plen;
@@ -2218,6 +2224,18 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
     HIP_TRY(hipMemcpyAsync(s->d_tiled_cnt.p + 1, &count, 4, hipMemcpyHostToDevice, st));
   }
   if (n_rep == 0) return 0;
+  std::vector<uint32_t> rtext;
+  if (tt) {  // several texts: which one a report belongs to; reports inside separators
+    if (d_rep == L.d_sorted.p) {  // (search_all without copies: the sorted list itself is the report list)
+      if (int rc = s->d_tiled_sel.reserve(n_rep)) return rc;
+      HIP_TRY(hipMemcpyAsync(s->d_tiled_sel.p, L.d_sorted.p, (size_t)n_rep * sizeof(Candidate), hipMemcpyDeviceToDevice, st));
+      d_rep = s->d_tiled_sel.p;
+    }
+    if (int rc = s->d_tiled_rtext.reserve(n_rep)) return rc;
+    le = launch_assign_texts(s->d_tiled_sel.p, n_rep, *tt, s->d_tiled_rtext.p, st);
+    if (le != hipSuccess) return hip_fail(le, "text assignment launch");
+    rtext.resize(n_rep);
+  }
 
   // ---- traceback: one wavefront per report, the report's pattern comes with it ----
   std::vector<Candidate> reps(n_rep);
@@ -2257,6 +2275,10 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
     T.count_min = 0;
     T.count_max = 0xFFFFFFFFu;
     T.max_overhang = 0xFFFFFFFFu;
+    if (tt) {
+      T.texts = *tt;
+      T.report_text = s->d_tiled_rtext.p;
+    }
     HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
     le = launch_trace(T, (uint32_t)std::min<uint64_t>(1024, ((uint64_t)n_rep + 3) / 4), st);
     if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
@@ -2268,22 +2290,47 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
     float ms = 0;
     HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
     s->stats.trace_ms += ms;
+  }
+  if (int rc = L.download(reps.data(), d_rep, (size_t)n_rep * sizeof(Candidate))) return rc;
+  if (tt)
+    if (int rc = L.download(rtext.data(), s->d_tiled_rtext.p, (size_t)n_rep * sizeof(uint32_t))) return rc;
+  if (tt && all) {  // drop the reports that lie in separators (their records were not written)
+    size_t w = 0;
+    for (size_t i = 0; i < n_rep; ++i) {
+      if (reps[i].flags & kCandDrop) continue;
+      reps[w] = reps[i];
+      rtext[w] = rtext[i];
+      if (!wo) rows[w] = rows[i];
+      ++w;
+    }
+    n_rep = (uint32_t)w;
+    reps.resize(w);
+    rtext.resize(w);
+    if (!wo) rows.resize(w);
+  }
+  if (!wo)
     for (const sassy_hip_Match& r : rows)
       if (r.pad_[0] == kTraceFailed)
         return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
-  }
-  if (int rc = L.download(reps.data(), d_rep, (size_t)n_rep * sizeof(Candidate))) return rc;
 
   // ---- per pattern: the searcher's report filters, then the records ----
   const bool filters = !std::isnan(s->max_n_frac) || s->only_best;
-  if (!filters && !wo) {  // the records are finished: adopt them
-    R->matches.swap(rows);
-    R->pool.swap(pool);
-    for (size_t i = 0; i < R->matches.size(); ++i) {
+  if (!filters && !wo) {  // the records are finished: adopt them (or append them behind what R holds already)
+    const size_t first = R->matches.size(), base = R->pool.size();
+    if (first == 0 && base == 0) {
+      R->matches.swap(rows);
+      R->pool.swap(pool);
+    } else {
+      if (base + pool.size() > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB");
+      R->pool.append(pool);
+      R->matches.insert(R->matches.end(), rows.begin(), rows.end());
+    }
+    for (size_t i = first; i < R->matches.size(); ++i) {
       sassy_hip_Match& r = R->matches[i];
       const uint64_t p = r.pattern_idx;
       r.pattern_idx = p % e->n_original;
       r.strand = p >= e->n_original ? 1 : 0;
+      r.cigar_off += (uint32_t)base;
     }
     return 0;
   }
@@ -2294,16 +2341,18 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
     while (i1 < n_rep && (reps[i1].flags >> kCandTextShift) == p) ++i1;
     ScanOut so;
     so.cands.assign(reps.begin() + i0, reps.begin() + i1);
-    for (Candidate& c : so.cands) c.flags = 0;
+    for (size_t i = i0; i < i1; ++i) so.cands[i - i0].flags = tt ? rtext[i] << kCandTextShift : 0u;
     if (!wo) {
       so.matches.assign(rows.begin() + i0, rows.begin() + i1);
-      // the records' cigar offsets point into the whole pool: keep it whole for this pattern's rebase
-      so.pool.assign(pool, (size_t)i0 * str_stride, (size_t)(i1 - i0) * str_stride);
-      for (sassy_hip_Match& r : so.matches) r.cigar_off -= (uint32_t)(i0 * str_stride);
+      // the records' cigar offsets point into the whole pool: this pattern's share is cut out and they are rebased
+      // (after dropped reports the records are no longer consecutive in the pool: take the span they cover)
+      const size_t lo = so.matches.front().cigar_off, hi = (size_t)so.matches.back().cigar_off + str_stride;
+      so.pool.assign(pool, lo, hi - lo);
+      for (sassy_hip_Match& r : so.matches) r.cigar_off -= (uint32_t)lo;
     }
-    if (int rc = post_filter(s, so, plan0, e->patterns[p].data(), k, 0, h_text, tptr, text_len, !wo, EndFilter())) return rc;
+    if (int rc = post_filter(s, so, plan0, e->patterns[p].data(), k, 0, h_text, tptr, text_len, !wo, EndFilter(), ht)) return rc;
     size_t first = 0;
-    if (int rc = append_matches(so, text_len, plan0, wo, p % e->n_original, R, first)) return rc;
+    if (int rc = append_matches(so, text_len, plan0, wo, p % e->n_original, R, first, ht)) return rc;
     for (size_t i = first; i < R->matches.size(); ++i) {
       R->matches[i].pattern_idx = p % e->n_original;
       R->matches[i].strand = p >= e->n_original ? 1 : 0;
@@ -2321,7 +2370,8 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
 // this shape (k close to m on a long text) -- the caller runs one scan per pattern instead.
 static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
                                 const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
-                                sassy_hip_Result* R, bool* done) {
+                                sassy_hip_Result* R, bool* done, const TextTable* tt = nullptr,
+                                const HostTexts* ht = nullptr) {
   *done = false;
   ScanLane& L = s->lanes[0];
   const size_t npat = e->patterns.size();
@@ -2406,7 +2456,7 @@ static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* 
   s->stats.candidates += count;
   *done = true;
   if (count == 0) return 0;
-  return finish_pattern_list(s, e, plan0, tptr, h_text, text_len, k, all, wo, count, false, R);
+  return finish_pattern_list(s, e, plan0, tptr, h_text, text_len, k, all, wo, count, false, R, tt, ht);
 }
 
 // search_encoded_patterns for many patterns over a long text: seed -> verify -> report (seed_kernels.hip).  One
@@ -2777,9 +2827,27 @@ static bool acgt_only(const uint8_t* p, size_t n) {
   return true;
 }
 
+// Patterns of one length (<= 64 rows) can take the pattern-tiled scan over the batch instead of one kernel chain per
+// pattern and strand; many_tiled_wanted() is the shared estimate.  tiled_only: called ahead of search_many_pertext
+// for exactly that -- if the tiled scan does not take the batch after all, nothing is done here (handled = false).
+static bool many_tiled_wanted(const sassy_SearcherType* s, const size_t* pattern_lens, size_t n_patterns, uint64_t total, size_t k) {
+  if (n_patterns == 0 || pattern_lens[0] > 64 || 2 * k + 3 > 64 || n_patterns >= (1u << 24)) return false;
+  for (size_t pi = 1; pi < n_patterns; ++pi)
+    if (pattern_lens[pi] != pattern_lens[0]) return false;
+  const int env_many = getenv("SASSY_HIP_MANY_TILED") ? atoi(getenv("SASSY_HIP_MANY_TILED")) : -1;  // (per call: tests flip it)
+  if (env_many >= 0) return env_many != 0;
+  // Measured with tools/bench_reads.py (96 barcodes of 24 rows, k = 3, both strands, 100 / 330 MB of 1 kb reads): the
+  // tiled scan advances 2.8e10 (character x group of 64 patterns) per second here (16 Iupac classes, the last group
+  // half empty): 14 / 46 ms; the 192 chains take 15 / 38 ms = 25 us + 5.3e-13 s per byte of the batch each.
+  const double strands = s->rc ? 2.0 : 1.0;
+  const double est_tiled = strands * ((double)total * (double)((n_patterns + 63) / 64) / 2.8e10 + 1.5e-4);
+  const double est_chains = strands * (double)n_patterns * (25e-6 + 5.3e-13 * (double)total);
+  return est_tiled < est_chains;
+}
+
 static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patterns, const size_t* pattern_lens,
                                size_t n_patterns, const uint8_t* const* texts, const size_t* text_lens, size_t n_texts,
-                               size_t k, uint32_t flags, sassy_hip_Result* R, bool& handled) {
+                               size_t k, uint32_t flags, sassy_hip_Result* R, bool& handled, bool tiled_only = false) {
   handled = false;
   static const bool off = getenv("SASSY_HIP_BATCH_TEXTS") && atoi(getenv("SASSY_HIP_BATCH_TEXTS")) == 0;
   if (off || n_texts < 2 || n_patterns == 0 || (flags & SASSY_HIP_TEXT_ON_DEVICE) || s->profile == PROFILE_ASCII) return 0;
@@ -2854,6 +2922,54 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
         if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
       }
       std::string err;
+      // Many patterns of one length: the pattern-tiled scan (tiled_kernel.hip) takes all of them over the whole
+      // batch in one pass per strand -- the separators are characters that match nothing, so after m + k + 1 of
+      // them the columns are fresh, as for the scans of one pattern.  SASSY_HIP_MANY_TILED=0 / 1 forces the choice.
+      bool tiled_done = false;
+      {
+        const bool use = many_tiled_wanted(s, pattern_lens, n_patterns, total, k);
+        if (use) {
+          const size_t batch_first = R->matches.size(), pool_first = R->pool.size();
+          tiled_done = true;
+          for (int strand = 0; strand < (s->rc ? 2 : 1) && tiled_done; ++strand) {
+            sassy_hip_Encoded tmp;
+            tmp.profile = s->profile;
+            tmp.rc = false;
+            tmp.plen = pattern_lens[0];
+            tmp.n_original = n_patterns;
+            for (size_t pi = 0; pi < n_patterns; ++pi) {
+              tmp.patterns.emplace_back(patterns[pi], patterns[pi] + pattern_lens[pi]);
+              if (strand)
+                for (uint8_t& c : tmp.patterns.back()) c = complement_char(s->profile, c);
+            }
+            const size_t first = R->matches.size();
+            bool done = false;
+            if (int rc = search_encoded_tiled(s, &tmp, strand ? s->d_rev.p : s->d_text.p, strand ? nullptr : hbuf, total,
+                                              (uint32_t)k, all, wo, R, &done, strand ? &tt_rev : &tt,
+                                              strand ? &ht_rev : &ht)) return rc;
+            if (!done) { tiled_done = false; break; }
+            for (size_t i = first; i < R->matches.size(); ++i) {
+              sassy_hip_Match& m = R->matches[i];
+              if (!strand) { m.text_idx += t0; continue; }
+              // reference: src/search.rs:859-873
+              const size_t t = nt - 1 - (size_t)m.text_idx;
+              const uint64_t len = ht.len[t], rs = m.text_start, re = m.text_end;
+              m.strand = 1;
+              m.text_idx = t0 + t;
+              m.text_start = len - re;
+              m.text_end = wo ? UINT64_MAX : len - rs;
+            }
+          }
+          if (!tiled_done) {  // too many end positions for one list: back to one chain per pattern for this batch
+            R->matches.resize(batch_first);
+            R->pool.resize(pool_first);
+          }
+        }
+        if (tiled_only && !tiled_done && t0 == 0) {  // first batch, nothing appended yet: leave it all to the caller
+          handled = false;
+          return 0;
+        }  // (a later batch that the tiled scan cannot take runs as chains below)
+      }
       // one scan per pattern and strand, several in flight (ScanQueue); tag = 2 * pattern + strand
       ScanQueue queue(s, [&](uint64_t tag, ScanOut& so, const PatternPlan& plan, const uint8_t* pat) -> int {
         const size_t pi = (size_t)(tag >> 1);
@@ -2876,7 +2992,7 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
         }
         return 0;
       });
-      for (size_t pi = 0; pi < n_patterns; ++pi) {
+      for (size_t pi = 0; pi < (tiled_done ? 0 : n_patterns); ++pi) {
         PatternPlan plan;
         if (!make_plan(s->profile, patterns[pi], pattern_lens[pi], plan, err)) return fail(SASSY_HIP_EINVAL, err);
         ShardView sh{s->d_text.p, total, 0, 0, true, true};
@@ -3065,8 +3181,16 @@ int sassy_hip_search_many(sassy_SearcherType* s, const uint8_t* const* patterns,
   if (int rc = s->ensure_device()) return rc;
   std::unique_ptr<sassy_hip_Result> R(new sassy_hip_Result());
   bool handled = false;
-  if (int rc = search_many_pertext(s, patterns, pattern_lens, n_patterns, texts, text_lens, n_texts, k, flags, R.get(), handled))
-    return rc;
+  {  // patterns of one length over many host texts: the pattern-tiled scan over the separator layout, if it pays
+    uint64_t sum = 0;
+    for (size_t ti = 0; ti < n_texts; ++ti) sum += text_lens[ti];
+    if (n_texts >= 2 && many_tiled_wanted(s, pattern_lens, n_patterns, sum, k))
+      if (int rc = search_many_batched(s, patterns, pattern_lens, n_patterns, texts, text_lens, n_texts, k, flags, R.get(),
+                                       handled, true)) return rc;
+  }
+  if (!handled)
+    if (int rc = search_many_pertext(s, patterns, pattern_lens, n_patterns, texts, text_lens, n_texts, k, flags, R.get(), handled))
+      return rc;
   if (!handled)
     if (int rc = search_many_batched(s, patterns, pattern_lens, n_patterns, texts, text_lens, n_texts, k, flags, R.get(), handled))
       return rc;

@@ -62,6 +62,29 @@ __global__ __launch_bounds__(256) void flag_reports_kernel(const Candidate* __re
   }
   keep[i] = report ? 1 : 0;
 }
+
+// Reports of many patterns over a multi-text buffer learn their text (the largest t with start[t] <= position).  A
+// report that ends inside the separator behind text t stands for the end-of-text report of text t and is moved
+// there; in search_all mode such positions do not exist in a single-text search and are dropped (as
+// aux_kernels.hip: rank_scatter_kernel does for the scans of one pattern).
+__global__ __launch_bounds__(256) void assign_texts_kernel(Candidate* __restrict__ rep, uint32_t count, const TextTable T,
+                                                           uint32_t* __restrict__ report_text) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  Candidate v = rep[i];
+  uint32_t lo = 0, hi = T.n;  // invariant: start[lo] <= pos < start[hi]
+  while (lo + 1 < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (T.start[mid] <= v.pos) lo = mid; else hi = mid;
+  }
+  const uint64_t te = T.start[lo] + T.len[lo];
+  if (v.pos > te) {
+    if (T.all_minima) v.flags |= kCandDrop;
+    else v.pos = te;
+    rep[i] = v;
+  }
+  report_text[i] = lo;
+}
 }  // namespace
 
 // Bytes of scratch launch_sort_candidates needs for `count` reports (keys in, keys out, rocPRIM's own).
@@ -112,6 +135,13 @@ hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Cand
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return rocprim::select(temp, temp_bytes, d_sorted, keep, d_sel, d_sel_count, (size_t)count, stream);
+}
+
+hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable& texts, uint32_t* d_report_text,
+                               hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(assign_texts_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_rep, count, texts, d_report_text);
+  return hipGetLastError();
 }
 
 }  // namespace sassy_hip

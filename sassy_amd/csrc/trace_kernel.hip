@@ -109,13 +109,13 @@ struct Window {
   uint32_t text_idx;
   bool skip;
 };
-__device__ __forceinline__ Window report_window(const TraceParams& P, const Candidate& cd) {
+__device__ __forceinline__ Window report_window(const TraceParams& P, const Candidate& cd, uint32_t c = 0) {
   Window w;
   const uint64_t fill = (uint64_t)P.m + P.k;
   const uint64_t e = cd.pos;
   w.skip = (cd.flags & kCandDrop) != 0;
   if (P.texts.n) {
-    w.text_idx = cd.flags >> kCandTextShift;
+    w.text_idx = P.report_text ? P.report_text[c] : cd.flags >> kCandTextShift;
     w.base = P.texts.start[w.text_idx];
     const uint64_t te = w.base + P.texts.len[w.text_idx];
     w.o = e > w.base + fill ? e - fill : w.base;
@@ -433,11 +433,10 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
     } else {
       cd = P.cand[c];                                      // wave-uniform
     }
-    Window W = report_window(P, cd);
+    Window W = report_window(P, cd, c);
     uint32_t pattern_idx = 0;
-    if (P.pattern_stride) {  // many patterns, one text: the flags' upper bits name the pattern, not a text
+    if (P.pattern_stride) {  // many patterns: the flags' upper bits name the pattern, not a text (report_text does)
       pattern_idx = cd.flags >> kCandTextShift;
-      W.text_idx = 0;
       __builtin_amdgcn_wave_barrier();  // the previous report's walk is done with spat
       load_pattern(P.pattern + (size_t)pattern_idx * P.pattern_stride);
     }

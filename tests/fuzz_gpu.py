@@ -156,8 +156,12 @@ def many_case(rng, searchers):
     pal = {"dna": b"ACGT", "iupac": b"ACGTNRY", "ascii": b"ACGTXYZ "}[profile]
     npat = rng.randrange(1, 5)
     pats = []
+    same = rng.random() < 0.5  # patterns of one length (<= 64) can go through the pattern-tiled scan in one pass
+    if same:
+        npat = rng.choice([1, 2, 3, 5, 70])
+    m_same = rng.choice([8, 16, 20, 24, 32, 40, 64])
     for _ in range(npat):
-        m = rng.choice([8, 16, 20, 24, 32, 40, 64, 100])
+        m = m_same if same else rng.choice([8, 16, 20, 24, 32, 40, 64, 100])
         pats.append(rand_seq(rng, m, pal if rng.random() < 0.3 else pal[:4]))
     k = rng.choice([0, 1, 2, 3, 5])
     k = min(k, min(len(p) for p in pats) - 1)
@@ -175,7 +179,13 @@ def many_case(rng, searchers):
             t[rng.randrange(n)] = rng.choice(b"NRYn")
         texts.append(bytes(t))
     s = searchers[(profile, rc)]
+    force = rng.choice([None, "0", "1"])
+    if force is None:
+        os.environ.pop("SASSY_HIP_MANY_TILED", None)
+    else:
+        os.environ["SASSY_HIP_MANY_TILED"] = force
     got = s.search_many(pats, texts, k, all_minima=allm)
+    os.environ.pop("SASSY_HIP_MANY_TILED", None)
     gk = [(m.pattern_idx, m.text_idx, m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, m.strand, m.cigar)
           for m in got]
     wk = []
@@ -183,7 +193,7 @@ def many_case(rng, searchers):
         for ti, t in enumerate(texts):
             for m in oracle.search(profile, p, t, k, rc=rc, all_minima=allm):
                 wk.append((pi, ti, m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, m.strand, m.cigar))
-    desc = dict(mode="many", profile=profile, k=k, rc=rc, all_minima=allm, npat=npat, ntext=len(texts),
+    desc = dict(mode="many", profile=profile, k=k, rc=rc, all_minima=allm, npat=npat, ntext=len(texts), tiled=force,
                 filtered=s.stats()["filtered"], matches=len(wk))
     return sorted(gk) == sorted(wk), desc, b"|".join(pats), b"|".join(texts), gk, wk
 
@@ -412,6 +422,8 @@ def main():
             fn = reflanes_case
         if args.focus == "encoded":
             fn = encoded_case
+        if args.focus == "many":
+            fn = many_case
         ok, desc, pat, text, got, want = fn(rng, searchers)
         cases += 1
         kinds[desc["filtered"]] = kinds.get(desc["filtered"], 0) + 1
