@@ -3641,7 +3641,12 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
       double rate = 0;
       for (size_t pc = 0; pc < k + 1; ++pc)
         rate += std::pow(0.25, (double)std::min<size_t>(e->plen / (k + 1) + (pc < e->plen % (k + 1) ? 1 : 0), kSeedMaxLen));
-      seeded = rate * (double)(e->plen + 3 * k + 1) * 24.0 < 8.0 && (double)text_len * (double)e->patterns.size() >= 1e9;
+      // the seed pass reads the text at ~1.3e11 B/s whatever the number of patterns; a table hit costs ~8 ps with the
+      // sub-piece test (patterns of <= 32 rows), ~16 ps when every hit is verified (tools/bench_configs.py, config 4:
+      // 1.1e10 hits, 103 / 197 ms); ~0.3 ms of tables and launches
+      const double hits = rate * (double)text_len * (double)e->patterns.size();
+      const double est_seeded = 3e-4 + (double)text_len / 1.3e11 + hits * (e->plen <= 32 ? 8e-12 : 16e-12);
+      seeded = est_seeded < est_chains && (!tiled || est_seeded < est_tiled);
       if (env_seeded >= 0) seeded = env_seeded != 0;
     }
     bool tiled_done = false;

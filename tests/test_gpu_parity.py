@@ -709,7 +709,8 @@ def test_encoded_many_patterns(sassy):
     import os
     rng = random.Random(45)
     pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(12)]
-    os.environ["SASSY_HIP_TILED"] = "0"  # one scan per pattern here; the one-pass path: test_encoded_pattern_tiled
+    os.environ["SASSY_HIP_TILED"] = "0"  # one scan per pattern here; the one-pass paths: test_encoded_pattern_tiled,
+    os.environ["SASSY_HIP_SEEDED"] = "0"  # test_encoded_seeded
     for variant in ("plain", "lower", "with_n", "plain_multi", "lower_multi"):
         # *_multi: force the multi-pattern prefilter (one filter_dna_multi_kernel pass per batch of
         # patterns) that long texts get by default
@@ -747,6 +748,7 @@ def test_encoded_many_patterns(sassy):
                 assert s.stats()["filtered"] in (0, 4)  # 20-mers at k=2: pieces too short (q-gram counting, or the streaming DP)
     os.environ.pop("SASSY_HIP_MULTI_MIN_TEXT", None)
     os.environ.pop("SASSY_HIP_TILED", None)
+    os.environ.pop("SASSY_HIP_SEEDED", None)
 
 
 def test_encoded_pattern_tiled(sassy):
@@ -758,6 +760,7 @@ def test_encoded_pattern_tiled(sassy):
     import os
     rng = random.Random(4711)
     os.environ.pop("SASSY_HIP_TILED", None)
+    os.environ["SASSY_HIP_SEEDED"] = "0"  # (the library would seed some of these shapes by itself)
     shapes = [  # (profile, m, k, npat, n, alphabet of the text, all_minima)
         ("dna", 20, 2, 12, 30_000, b"ACGT", False),
         ("dna", 20, 2, 150, 5_000, b"ACGT", False),
@@ -827,6 +830,7 @@ def test_encoded_pattern_tiled(sassy):
         assert sorted(key(x) for x in got) == sorted(key(x) for x in want) and len(want) >= 3, off
     # the searcher's report filters are applied per pattern: equal to the one-scan-per-pattern path
     _encoded_filters_agree(sassy, rng, "SASSY_HIP_TILED", 5)
+    os.environ.pop("SASSY_HIP_SEEDED", None)
 
 
 def _encoded_filters_agree(sassy, rng, env, kind):
