@@ -449,9 +449,10 @@ __global__ __launch_bounds__(256) void reverse_texts_kernel(const uint8_t* __res
 // cheaper (two bit planes instead of a five-plane table lookup), so multi-pattern searches test
 // the text once and then run the Dna kernels.  Same SWAR test as filter_table_kernel: the byte must
 // equal the letter its 2-bit code stands for.
+// allow_x: 'X' bytes (the separators of a multi-text buffer) pass too.
 __global__ __launch_bounds__(256) void acgt_check_kernel(const uint4* __restrict__ text16, uint64_t n16,
                                                          const uint8_t* __restrict__ tail, uint32_t n_tail,
-                                                         uint32_t* __restrict__ flag) {
+                                                         uint32_t* __restrict__ flag, int allow_x) {
   uint32_t bad = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint4 v = text16[i];
@@ -460,12 +461,18 @@ __global__ __launch_bounds__(256) void acgt_check_kernel(const uint4* __restrict
     for (int d = 0; d < 4; ++d) {
       const uint32_t sel = (w[d] >> 1) & 0x03030303u;
       const uint32_t expect = __builtin_amdgcn_perm(0u, 0x47544341u, sel);  // 'A' 'C' 'T' 'G' by code
-      bad |= (w[d] & 0xDFDFDFDFu) ^ expect;
+      uint32_t diff = (w[d] & 0xDFDFDFDFu) ^ expect;
+      if (allow_x) {  // bytes equal to 'X': zero-byte test on w ^ 'XXXX', widened to byte masks
+        const uint32_t z = w[d] ^ 0x58585858u;
+        const uint32_t is_x = (~(((z & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | z) & 0x80808080u) >> 7;  // (exact per byte: no borrows)
+        diff &= ~(is_x * 0xFFu);
+      }
+      bad |= diff;
     }
   }
   if (blockIdx.x == 0 && threadIdx.x < n_tail) {
     const uint32_t c = tail[threadIdx.x] & 0xDFu;
-    bad |= (c != 'A' && c != 'C' && c != 'G' && c != 'T') ? 1u : 0u;
+    bad |= (c != 'A' && c != 'C' && c != 'G' && c != 'T' && !(allow_x && tail[threadIdx.x] == 'X')) ? 1u : 0u;
   }
   if (bad) *flag = 1u;
 }
@@ -491,10 +498,10 @@ hipError_t launch_reverse_texts(const uint8_t* d_src, uint8_t* d_dst, uint64_t n
   return hipGetLastError();
 }
 
-hipError_t launch_acgt_check(const uint8_t* d_text, uint64_t n, uint32_t* d_flag, hipStream_t stream) {
+hipError_t launch_acgt_check(const uint8_t* d_text, uint64_t n, uint32_t* d_flag, hipStream_t stream, int allow_x) {
   const uint64_t n16 = n / 16;
   hipLaunchKernelGGL(acgt_check_kernel, dim3(4096), dim3(256), 0, stream, reinterpret_cast<const uint4*>(d_text), n16,
-                     d_text + n16 * 16, (uint32_t)(n - n16 * 16), d_flag);
+                     d_text + n16 * 16, (uint32_t)(n - n16 * 16), d_flag, allow_x);
   return hipGetLastError();
 }
 

@@ -201,6 +201,7 @@ struct SeedParams {
   const uint32_t* packed_text;    // 2-bit Dna codes of the text, 16 characters per dword
   const unsigned long long* packed_pat;  // per pattern: row r at bits 2r
   uint64_t seed_len_packed;       // byte p = rows of the seed of piece p
+  uint32_t separators;            // 1: a multi-text buffer -- text bytes with bit 3 set ('X', the separator) match no row
 };
 
 // A finished match record as the trace kernel writes it; same layout as sassy_hip_Match

@@ -36,7 +36,7 @@ hipError_t launch_filter_dna_multi(const ScanParams& P, uint32_t grid, hipStream
 hipError_t launch_filter_count(const ScanParams& P, uint32_t grid, hipStream_t stream);
 hipError_t launch_count_n(const uint8_t* d_text, const uint64_t* d_range, uint32_t n, uint32_t* d_count,
                           hipStream_t stream);
-hipError_t launch_acgt_check(const uint8_t* d_text, uint64_t n, uint32_t* d_flag, hipStream_t stream);
+hipError_t launch_acgt_check(const uint8_t* d_text, uint64_t n, uint32_t* d_flag, hipStream_t stream, int allow_x = 0);
 hipError_t launch_reverse_texts(const uint8_t* d_src, uint8_t* d_dst, uint64_t n, const uint32_t* d_blk2text,
                                 const uint64_t* d_start, const uint64_t* d_len, uint32_t pad, hipStream_t stream);
 hipError_t launch_filter_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
@@ -2465,7 +2465,8 @@ static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* 
 // when the searcher is Iupac).  *done = false: not this shape after all (lists too large) -- the caller falls back.
 static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
                                  const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
-                                 sassy_hip_Result* R, bool* done) {
+                                 sassy_hip_Result* R, bool* done, const TextTable* tt = nullptr,
+                                 const HostTexts* ht = nullptr) {
   *done = false;
   ScanLane& L = s->lanes[0];
   hipStream_t st = s->stream;
@@ -2600,6 +2601,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   }
   SP.out_count = s->d_tiled_cnt.p;
   SP.hit_count = reinterpret_cast<unsigned long long*>(s->d_tiled_cnt.p + 4);
+  SP.separators = tt ? 1u : 0u;  // several texts in the buffer: 'X' between them
   // 2 KiB of text per wave and step; enough waves for two rounds of the chip, contiguous runs per wave
   static const uint64_t env_waves = getenv("SASSY_HIP_SEED_WAVES") ? (uint64_t)atoll(getenv("SASSY_HIP_SEED_WAVES")) : 0ull;
   const uint64_t waves = std::min<uint64_t>(env_waves ? env_waves : 16384, std::max<uint64_t>(1, (text_len + 2047) / 2048));
@@ -2639,7 +2641,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   s->stats.candidates += out_count;
   *done = true;
   if (out_count == 0) return 0;
-  return finish_pattern_list(s, e, plan0, tptr, h_text, text_len, k, all, wo, out_count, true, R);
+  return finish_pattern_list(s, e, plan0, tptr, h_text, text_len, k, all, wo, out_count, true, R, tt, ht);
 }
 
 static void reset_stats(sassy_SearcherType* S) { S->stats = sassy_hip_Stats{}; }
@@ -2830,12 +2832,32 @@ static bool acgt_only(const uint8_t* p, size_t n) {
 // Patterns of one length (<= 64 rows) can take the pattern-tiled scan over the batch instead of one kernel chain per
 // pattern and strand; many_tiled_wanted() is the shared estimate.  tiled_only: called ahead of search_many_pertext
 // for exactly that -- if the tiled scan does not take the batch after all, nothing is done here (handled = false).
+// Expected table hits of the seeded search per (character, pattern) on random text; 0: the shape does not allow it.
+static double seeded_hit_rate(size_t m, size_t k) {
+  if (k + 1 > 8 || m / (k + 1) < 5 || m + 3 * k + 1 > 4 * (size_t)kSeedWindowDwords) return 0.0;
+  double rate = 0;
+  for (size_t pc = 0; pc < k + 1; ++pc)
+    rate += std::pow(0.25, (double)std::min<size_t>(m / (k + 1) + (pc < m % (k + 1) ? 1 : 0), kSeedMaxLen));
+  return rate;
+}
+// The seeded search's estimate (search_encoded_seeded): ~0.3 ms of tables and launches, the seed pass at ~1.3e11 B/s
+// whatever the number of patterns, ~8 ps per table hit with the sub-piece test (patterns of <= 32 rows), ~16 ps when
+// every hit is verified (tools/bench_configs.py, config 4: 1.1e10 hits, 103 / 197 ms).
+static double seeded_estimate(size_t m, size_t k, size_t n_patterns, uint64_t text_len) {
+  const double hits = seeded_hit_rate(m, k) * (double)text_len * (double)n_patterns;
+  return 3e-4 + (double)text_len / 1.3e11 + hits * (m <= 32 ? 8e-12 : 16e-12);
+}
+
 static bool many_tiled_wanted(const sassy_SearcherType* s, const size_t* pattern_lens, size_t n_patterns, uint64_t total, size_t k) {
   if (n_patterns == 0 || pattern_lens[0] > 64 || 2 * k + 3 > 64 || n_patterns >= (1u << 24)) return false;
   for (size_t pi = 1; pi < n_patterns; ++pi)
     if (pattern_lens[pi] != pattern_lens[0]) return false;
   const int env_many = getenv("SASSY_HIP_MANY_TILED") ? atoi(getenv("SASSY_HIP_MANY_TILED")) : -1;  // (per call: tests flip it)
   if (env_many >= 0) return env_many != 0;
+  if (seeded_hit_rate(pattern_lens[0], k) > 0 &&
+      (s->rc ? 2.0 : 1.0) * seeded_estimate(pattern_lens[0], k, n_patterns, total) <
+          (s->rc ? 2.0 : 1.0) * (double)n_patterns * (25e-6 + 5.3e-13 * (double)total))
+    return true;  // (the one-pass branch decides between the seeded search and the tiled scan once the batch is on the device)
   // Measured with tools/bench_reads.py (96 barcodes of 24 rows, k = 3, both strands, 100 / 330 MB of 1 kb reads): the
   // tiled scan advances 2.8e10 (character x group of 64 patterns) per second here (16 Iupac classes, the last group
   // half empty): 14 / 46 ms; the 192 chains take 15 / 38 ms = 25 us + 5.3e-13 s per byte of the batch each.
@@ -2928,6 +2950,27 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
       bool tiled_done = false;
       {
         const bool use = many_tiled_wanted(s, pattern_lens, n_patterns, total, k);
+        // ... or the seeded search (seed_kernels.hip: 'X' bytes match nothing there) when the patterns and the
+        // batch are plain ACGT and its estimate is the lower one (SASSY_HIP_MANY_SEEDED=0 / 1 forces the choice)
+        bool seed_batch = false;
+        if (use && seeded_hit_rate(pattern_lens[0], k) > 0 && total < (1ull << 36)) {
+          const int env_seed = getenv("SASSY_HIP_MANY_SEEDED") ? atoi(getenv("SASSY_HIP_MANY_SEEDED")) : -1;
+          const double est_seed = seeded_estimate(pattern_lens[0], k, n_patterns, total);
+          const double est_tile = (double)total * (double)((n_patterns + 63) / 64) / 2.8e10 + 1.5e-4;
+          bool plain = env_seed != 0 && (env_seed > 0 || est_seed < est_tile);
+          for (size_t pi = 0; plain && pi < n_patterns; ++pi) plain = acgt_only(patterns[pi], pattern_lens[pi]);
+          if (plain) {
+            if (int rc = s->d_ncount.reserve(4)) return rc;
+            HIP_TRY(hipMemsetAsync(s->d_ncount.p, 0, 4, s->stream));
+            hipError_t le = launch_acgt_check(s->d_text.p, total, s->d_ncount.p, s->stream, 1);
+            if (le != hipSuccess) return hip_fail(le, "text check kernel launch");
+            uint32_t bad = 1;
+            HIP_TRY(hipMemcpyAsync(&bad, s->d_ncount.p, 4, hipMemcpyDeviceToHost, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            plain = !bad;
+          }
+          seed_batch = plain;
+        }
         if (use) {
           const size_t batch_first = R->matches.size(), pool_first = R->pool.size();
           tiled_done = true;
@@ -2944,9 +2987,14 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
             }
             const size_t first = R->matches.size();
             bool done = false;
-            if (int rc = search_encoded_tiled(s, &tmp, strand ? s->d_rev.p : s->d_text.p, strand ? nullptr : hbuf, total,
-                                              (uint32_t)k, all, wo, R, &done, strand ? &tt_rev : &tt,
-                                              strand ? &ht_rev : &ht)) return rc;
+            if (seed_batch)
+              if (int rc = search_encoded_seeded(s, &tmp, strand ? s->d_rev.p : s->d_text.p, strand ? nullptr : hbuf, total,
+                                                 (uint32_t)k, all, wo, R, &done, strand ? &tt_rev : &tt,
+                                                 strand ? &ht_rev : &ht)) return rc;
+            if (!done)
+              if (int rc = search_encoded_tiled(s, &tmp, strand ? s->d_rev.p : s->d_text.p, strand ? nullptr : hbuf, total,
+                                                (uint32_t)k, all, wo, R, &done, strand ? &tt_rev : &tt,
+                                                strand ? &ht_rev : &ht)) return rc;
             if (!done) { tiled_done = false; break; }
             for (size_t i = first; i < R->matches.size(); ++i) {
               sassy_hip_Match& m = R->matches[i];
@@ -3638,14 +3686,7 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
     if (s->profile == PROFILE_DNA && std::isnan(s->alpha) && k + 1 <= 8 && e->plen / (k + 1) >= 5 &&
         e->plen + 3 * k + 1 <= 4 * kSeedWindowDwords && e->patterns.size() < (1u << 24) && text_len < (1ull << 36) &&
         (((uintptr_t)tptr) & 15) == 0) {
-      double rate = 0;
-      for (size_t pc = 0; pc < k + 1; ++pc)
-        rate += std::pow(0.25, (double)std::min<size_t>(e->plen / (k + 1) + (pc < e->plen % (k + 1) ? 1 : 0), kSeedMaxLen));
-      // the seed pass reads the text at ~1.3e11 B/s whatever the number of patterns; a table hit costs ~8 ps with the
-      // sub-piece test (patterns of <= 32 rows), ~16 ps when every hit is verified (tools/bench_configs.py, config 4:
-      // 1.1e10 hits, 103 / 197 ms); ~0.3 ms of tables and launches
-      const double hits = rate * (double)text_len * (double)e->patterns.size();
-      const double est_seeded = 3e-4 + (double)text_len / 1.3e11 + hits * (e->plen <= 32 ? 8e-12 : 16e-12);
+      const double est_seeded = seeded_estimate(e->plen, k, e->patterns.size(), text_len);
       seeded = est_seeded < est_chains && (!tiled || est_seeded < est_tiled);
       if (env_seeded >= 0) seeded = env_seeded != 0;
     }

@@ -105,7 +105,8 @@ __device__ __forceinline__ bool sub_piece_test(const SeedParams& P, unsigned lon
 
 }  // namespace
 
-// One lane per candidate.  EDGE: the candidate's window leaves the text (the first / last few dozen characters).
+// One lane per candidate.  EDGE: the candidate's window leaves the text (the first / last few dozen characters),
+// or the buffer holds several texts with separators between them.
 template <int WORDS, bool EDGE>
 __device__ __forceinline__ void verify_candidate(const SeedParams& P, unsigned long long cand) {
   typedef typename std::conditional<WORDS == 1, uint32_t, unsigned long long>::type Word;
@@ -167,6 +168,8 @@ __device__ __forceinline__ void verify_candidate(const SeedParams& P, unsigned l
           if (EDGE) {
             const int64_t c = s0 + t;
             if (c < 0 || c >= (int64_t)P.text_len) eq = 0;  // outside the text: the fresh column stays fresh
+            // multi-text buffers: the separator 'X' (and any text 'X': the empty IUPAC set) matches nothing
+            if (P.separators && ((win[x] >> (8 * y + 3)) & 1u)) eq = 0;
           }
           tiled_step(S, eq, top_shift);
           if (t >= emit_from && S.cost <= k) {
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
       const int64_t i = (int64_t)(cand >> kSeedPosShift);
       const int64_t e_hi = i + (int64_t)((P.rem_packed >> (8u * ((uint32_t)cand & 7u))) & 0xFFu) + (int64_t)P.k;
       const int64_t s0 = e_hi - ((int64_t)P.m + 3 * (int64_t)P.k + 1);
-      edge = s0 < 4 || e_hi + 8 > (int64_t)P.text_len;
+      edge = s0 < 4 || e_hi + 8 > (int64_t)P.text_len || P.separators != 0u;  // (separators: the checked copy of the loop)
     }
     if (__any(edge)) {
       if (have) verify_candidate<WORDS, true>(P, cand);

@@ -184,8 +184,14 @@ def many_case(rng, searchers):
         os.environ.pop("SASSY_HIP_MANY_TILED", None)
     else:
         os.environ["SASSY_HIP_MANY_TILED"] = force
+    seed = rng.choice([None, "0", "1"])
+    if seed is None:
+        os.environ.pop("SASSY_HIP_MANY_SEEDED", None)
+    else:
+        os.environ["SASSY_HIP_MANY_SEEDED"] = seed
     got = s.search_many(pats, texts, k, all_minima=allm)
     os.environ.pop("SASSY_HIP_MANY_TILED", None)
+    os.environ.pop("SASSY_HIP_MANY_SEEDED", None)
     gk = [(m.pattern_idx, m.text_idx, m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, m.strand, m.cigar)
           for m in got]
     wk = []

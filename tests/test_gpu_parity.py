@@ -1536,48 +1536,54 @@ def test_dna_profile_text_with_other_letters(sassy):
 
 
 def test_search_many_pattern_tiled(sassy):
-    """search_many with patterns of one length through the pattern-tiled scan over the whole batch of texts
-    (SASSY_HIP_MANY_TILED=1; host.hip: search_many_batched + finish_pattern_list with text tables) against one
-    oracle search per (pattern, text) pair: both strands (the Rc strand runs complement(pattern) over the reversed
-    batch, coordinates mapped back), matches at the first and last characters of a text, empty and one-character
-    texts, search_all (reports inside separators are dropped, else moved to the text end)."""
+    """search_many with patterns of one length through the one-pass kernels over the whole batch of texts --
+    the pattern-tiled scan (SASSY_HIP_MANY_TILED=1) and, for plain-ACGT patterns and texts, the seeded search
+    (SASSY_HIP_MANY_SEEDED=1; host.hip: search_many_batched + finish_pattern_list with text tables) -- against
+    one oracle search per (pattern, text) pair: both strands (the Rc strand runs complement(pattern) over the
+    reversed batch, coordinates mapped back), matches at the first and last characters of a text, empty and
+    one-character texts, search_all (reports inside separators are dropped, else moved to the text end)."""
     import os
     rng = random.Random(17)
     os.environ["SASSY_HIP_MANY_TILED"] = "1"
     try:
-        for (profile, m, k, npat, allm) in [("iupac", 20, 2, 70, False), ("dna", 24, 3, 5, False), ("iupac", 16, 1, 3, True),
-                                            ("iupac", 64, 5, 2, False)]:
-            pats = [rand_seq(rng, m) for _ in range(npat)]
-            if profile == "iupac":
-                pats[0] = pats[0][:3] + b"N" + pats[0][4:7] + b"R" + pats[0][8:]
-            texts = []
-            for t in range(120):
-                n = rng.choice([0, 1, m - 1, m, m + 3, 100, 333, 1000])
-                tx = bytearray(rand_seq(rng, n))
-                if n >= m + 3:
-                    p = bytes(c if c in b"ACGT" else 65 for c in rng.choice(pats))
-                    ins = mutate(rng, p, rng.randrange(0, k + 1))
-                    if rng.random() < 0.5:
-                        ins = oracle.reverse_complement("iupac", ins)
-                    if len(ins) <= n:
-                        at = rng.choice([0, n - len(ins), rng.randrange(0, n - len(ins) + 1)])
-                        tx[at:at + len(ins)] = ins
-                texts.append(bytes(tx))
-            for rc in (False, True):
-                s = sassy.Searcher(profile, rc=rc)
-                got = s.search_many(pats, texts, k, all_minima=allm)
-                assert s.stats()["filtered"] == 5, s.stats()
-                gk = sorted((x.pattern_idx, x.text_idx, x.text_start, x.text_end, x.pattern_start, x.pattern_end, x.cost,
-                             x.strand, x.cigar) for x in got)
-                wk = []
-                for pi, p in enumerate(pats):
-                    for ti, tx in enumerate(texts):
-                        for x in oracle.search(profile, p, tx, k, rc=rc, all_minima=allm):
-                            wk.append((pi, ti, x.text_start, x.text_end, x.pattern_start, x.pattern_end, x.cost, x.strand, x.cigar))
-                assert gk == sorted(wk), (profile, m, k, npat, allm, rc, len(gk), len(wk))
-                assert len(wk) >= 15
+        for mode in ("tiled", "seeded"):
+            os.environ["SASSY_HIP_MANY_SEEDED"] = "1" if mode == "seeded" else "0"
+            for (profile, m, k, npat, allm) in [("iupac", 20, 2, 70, False), ("dna", 24, 3, 5, False),
+                                                ("iupac", 16, 1, 3, True), ("iupac", 64, 5, 2, False)]:
+                pats = [rand_seq(rng, m) for _ in range(npat)]
+                pats[-1] = b"A" * m  # (its pieces also "occur" in the separators, whose bytes read as code A)
+                if profile == "iupac" and mode == "tiled":
+                    pats[0] = pats[0][:3] + b"N" + pats[0][4:7] + b"R" + pats[0][8:]
+                texts = []
+                for t in range(120):
+                    n = rng.choice([0, 1, m - 1, m, m + 3, 100, 333, 1000])
+                    tx = bytearray(rand_seq(rng, n))
+                    if n >= m + 3:
+                        p = bytes(c if c in b"ACGT" else 65 for c in rng.choice(pats))
+                        ins = mutate(rng, p, rng.randrange(0, k + 1))
+                        if rng.random() < 0.5:
+                            ins = oracle.reverse_complement("iupac", ins)
+                        if len(ins) <= n:
+                            at = rng.choice([0, n - len(ins), rng.randrange(0, n - len(ins) + 1)])
+                            tx[at:at + len(ins)] = ins
+                    texts.append(bytes(tx))
+                for rc in (False, True):
+                    s = sassy.Searcher(profile, rc=rc)
+                    got = s.search_many(pats, texts, k, all_minima=allm)
+                    seedable = mode == "seeded" and m + 3 * k + 1 <= 64
+                    assert s.stats()["filtered"] == (6 if seedable else 5), (mode, m, k, s.stats())
+                    gk = sorted((x.pattern_idx, x.text_idx, x.text_start, x.text_end, x.pattern_start, x.pattern_end, x.cost,
+                                 x.strand, x.cigar) for x in got)
+                    wk = []
+                    for pi, p in enumerate(pats):
+                        for ti, tx in enumerate(texts):
+                            for x in oracle.search(profile, p, tx, k, rc=rc, all_minima=allm):
+                                wk.append((pi, ti, x.text_start, x.text_end, x.pattern_start, x.pattern_end, x.cost, x.strand, x.cigar))
+                    assert gk == sorted(wk), (mode, profile, m, k, npat, allm, rc, len(gk), len(wk))
+                    assert len(wk) >= 15
     finally:
         os.environ.pop("SASSY_HIP_MANY_TILED", None)
+        os.environ.pop("SASSY_HIP_MANY_SEEDED", None)
 
 
 def test_search_many_on_device_resident_texts(sassy):
