@@ -201,6 +201,9 @@ struct SeedParams {
   const uint32_t* packed_text;    // 2-bit Dna codes of the text, 16 characters per dword
   const unsigned long long* packed_pat;  // per pattern: row r at bits 2r
   uint64_t seed_len_packed;       // byte p = rows of the seed of piece p
+  const uint32_t* seed_bits;      // bit c of table t's part (offset bits_off[t] words): some seed of table t ends with the
+                                  // min(len, 8) characters c -- staged in LDS, tested before the tables are read
+  uint32_t bits_off[2];
   uint32_t separators;            // 1: a multi-text buffer -- text bytes with bit 3 set ('X', the separator) match no row
 };
 

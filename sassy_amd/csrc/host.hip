@@ -404,7 +404,7 @@ struct sassy_SearcherType {
   DevBuf<uint32_t> d_tiled_cnt, d_tiled_rtext;
   DevBuf<Candidate> d_tiled_sel, d_tiled_list;  // (the list is not a lane's d_cand: its size must not leak into single searches)
   // seeded search (search_encoded_seeded): the piece tables; sub-piece table, packed text and patterns
-  DevBuf<uint32_t> d_seed_start[2], d_seed_entries[2], d_seed_sub, d_seed_packed;
+  DevBuf<uint32_t> d_seed_start[2], d_seed_entries[2], d_seed_sub, d_seed_packed, d_seed_bits;
   DevBuf<unsigned long long> d_seed_ppk;
   hipEvent_t ev_multi = nullptr, ev_multi_a = nullptr;
   hipEvent_t ev_a_multi() { return ev_multi_a; }
@@ -424,7 +424,7 @@ struct sassy_SearcherType {
     d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
     d_tiled_peq.release(); d_tiled_pat.release(); d_tiled_cnt.release(); d_tiled_sel.release(); d_tiled_list.release(); d_tiled_rtext.release();
     for (int t = 0; t < 2; ++t) { d_seed_start[t].release(); d_seed_entries[t].release(); }
-    d_seed_sub.release(); d_seed_packed.release(); d_seed_ppk.release();
+    d_seed_sub.release(); d_seed_packed.release(); d_seed_ppk.release(); d_seed_bits.release();
     if (ev_multi) (void)hipEventDestroy(ev_multi);
     if (ev_multi_a) (void)hipEventDestroy(ev_multi_a);
     for (ScanLane& l : lanes) l.destroy();
@@ -2488,6 +2488,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     if (tab_len[0] == 0 || tab_len[0] == p_len[pc]) { tab_len[0] = p_len[pc]; tab_of[pc] = 0; }
     else { tab_len[1] = p_len[pc]; tab_of[pc] = 1; }
   }
+  uint32_t seed_bits_off[2] = {0, 0};
   // ---- direct-address tables: code of a seed = sum of its characters' Dna codes, first character lowest ----
   std::vector<uint32_t> start[2], entries[2];
   for (int t = 0; t < 2; ++t) {
@@ -2533,6 +2534,23 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   if (int rc = s->d_tiled_cnt.reserve(16)) return rc;
   HIP_TRY(hipMemcpyAsync(s->d_tiled_peq.p, peq.data(), (wide ? 8 : 4) * 4 * npat, hipMemcpyHostToDevice, st));
   HIP_TRY(hipMemcpyAsync(s->d_tiled_pat.p, flat.data(), flat.size(), hipMemcpyHostToDevice, st));
+  {  // one bit per min(len, 8)-gram a seed of the table ends with (staged in LDS by the kernel)
+    std::vector<uint32_t> bits;
+    uint32_t off[2] = {0, 0};
+    for (int t = 0; t < 2; ++t) {
+      off[t] = (uint32_t)bits.size();
+      if (!tab_len[t]) continue;
+      const uint32_t l8 = std::min(tab_len[t], 8u), cut = 2 * (tab_len[t] - l8);
+      bits.resize(bits.size() + std::max<size_t>(1, ((size_t)1 << (2 * l8)) / 32), 0u);
+      for (size_t c = 0; c + 1 < start[t].size(); ++c)
+        if (start[t][c + 1] != start[t][c]) bits[off[t] + ((c >> cut) >> 5)] |= 1u << ((c >> cut) & 31);
+    }
+    if (int rc = s->d_seed_bits.reserve(bits.size())) return rc;
+    HIP_TRY(hipMemcpyAsync(s->d_seed_bits.p, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // (`bits` goes out of scope)
+    seed_bits_off[0] = off[0];
+    seed_bits_off[1] = off[1];
+  }
   for (int t = 0; t < 2; ++t) {
     if (!tab_len[t]) continue;
     if (int rc = s->d_seed_start[t].reserve(start[t].size())) return rc;
@@ -2601,6 +2619,9 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   }
   SP.out_count = s->d_tiled_cnt.p;
   SP.hit_count = reinterpret_cast<unsigned long long*>(s->d_tiled_cnt.p + 4);
+  SP.seed_bits = s->d_seed_bits.p;
+  SP.bits_off[0] = seed_bits_off[0];
+  SP.bits_off[1] = seed_bits_off[1];
   SP.separators = tt ? 1u : 0u;  // several texts in the buffer: 'X' between them
   // 2 KiB of text per wave and step; enough waves for two rounds of the chip, contiguous runs per wave
   static const uint64_t env_waves = getenv("SASSY_HIP_SEED_WAVES") ? (uint64_t)atoll(getenv("SASSY_HIP_SEED_WAVES")) : 0ull;
@@ -2840,12 +2861,13 @@ static double seeded_hit_rate(size_t m, size_t k) {
     rate += std::pow(0.25, (double)std::min<size_t>(m / (k + 1) + (pc < m % (k + 1) ? 1 : 0), kSeedMaxLen));
   return rate;
 }
-// The seeded search's estimate (search_encoded_seeded): ~0.3 ms of tables and launches, the seed pass at ~1.3e11 B/s
-// whatever the number of patterns, ~8 ps per table hit with the sub-piece test (patterns of <= 32 rows), ~16 ps when
-// every hit is verified (tools/bench_configs.py, config 4: 1.1e10 hits, 103 / 197 ms).
+// The seeded search's estimate (search_encoded_seeded): ~0.3 ms of tables and launches, the seed pass at ~3e11 B/s
+// whatever the number of patterns (tools/bench_encoded.py: 64 patterns over 256 MB in 1.2 ms), ~8 ps per table hit
+// with the sub-piece test (patterns of <= 32 rows), ~16 ps when every hit is verified (tools/bench_configs.py,
+// config 4: 1.1e10 hits, 95 / 197 ms).
 static double seeded_estimate(size_t m, size_t k, size_t n_patterns, uint64_t text_len) {
   const double hits = seeded_hit_rate(m, k) * (double)text_len * (double)n_patterns;
-  return 3e-4 + (double)text_len / 1.3e11 + hits * (m <= 32 ? 8e-12 : 16e-12);
+  return 3e-4 + (double)text_len / 3e11 + hits * (m <= 32 ? 8e-12 : 16e-12);
 }
 
 static bool many_tiled_wanted(const sassy_SearcherType* s, const size_t* pattern_lens, size_t n_patterns, uint64_t total, size_t k) {

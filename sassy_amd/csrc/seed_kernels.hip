@@ -191,6 +191,12 @@ __device__ __forceinline__ void verify_candidate(const SeedParams& P, unsigned l
 template <int WORDS, int KT>
 __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
   __shared__ unsigned long long queue_mem[kWavesPerGroup][128], pass_mem[kWavesPerGroup][128];
+  // "does any pattern have a seed that ends like this?" -- one bit per min(len, 8)-gram and table (<= 2 x 8 KiB): with
+  // few patterns nearly every position fails it and never reads the tables in global memory
+  __shared__ uint32_t bits_lds[2 * 2048];
+  for (uint32_t x = threadIdx.x; x < P.bits_off[1] + (P.len[1] ? (1u << (2 * (P.len[1] < 8 ? P.len[1] : 8))) / 32 : 0); x += blockDim.x)
+    bits_lds[x] = P.seed_bits[x];
+  __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave_in_group = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint64_t wave = (uint64_t)blockIdx.x * kWavesPerGroup + wave_in_group;
@@ -256,6 +262,7 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
 
   const uint32_t mask0 = P.len[0] ? (uint32_t)((1ull << (2 * P.len[0])) - 1) : 0u;
   const uint32_t mask1 = P.len[1] ? (uint32_t)((1ull << (2 * P.len[1])) - 1) : 0u;
+  const uint32_t cut0 = P.len[0] > 8 ? 2 * (P.len[0] - 8) : 0u, cut1 = P.len[1] > 8 ? 2 * (P.len[1] - 8) : 0u;
   for (uint64_t s = s_lo; s < s_hi; ++s) {
     const uint64_t g = s * 2048 + 32ull * lane;
     // 48 characters as 96 bits of codes; bytes outside the text are never part of an accepted seed
@@ -275,13 +282,19 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
       a0 = n0 = a1 = n1 = 0;
       if (P.len[0] && in_text && end >= P.len[0]) {
         const uint32_t code = (uint32_t)(q >> (2u * (17u + (j & 15u) - P.len[0]))) & mask0;
-        a0 = P.start[0][code];
-        n0 = P.start[0][code + 1] - a0;
+        const uint32_t c8 = code >> cut0;  // the seed's last min(len, 8) characters
+        if ((bits_lds[c8 >> 5] >> (c8 & 31u)) & 1u) {
+          a0 = P.start[0][code];
+          n0 = P.start[0][code + 1] - a0;
+        }
       }
       if (P.len[1] && in_text && end >= P.len[1]) {
         const uint32_t code = (uint32_t)(q >> (2u * (17u + (j & 15u) - P.len[1]))) & mask1;
-        a1 = P.start[1][code];
-        n1 = P.start[1][code + 1] - a1;
+        const uint32_t c8 = code >> cut1;
+        if ((bits_lds[P.bits_off[1] + (c8 >> 5)] >> (c8 & 31u)) & 1u) {
+          a1 = P.start[1][code];
+          n1 = P.start[1][code + 1] - a1;
+        }
       }
     };
     uint32_t a0, n0, a1, n1;
