@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/prof_configs.sh <tag> -- rocprofv3 kernel stats + VALU / HBM counters for BASELINE configs 3 and 4
-# (tools/bench_configs.py; config 4 on 20 patterns).  Counters in their own runs, never mixed with
+# (tools/bench_configs.py; config 4 on $PATTERNS patterns, default 20: one chain per pattern; PATTERNS=10000 CONFIGS=4
+# profiles the seeded search).  Counters in their own runs, never mixed with
 # API tracing.  Output: gpurun_out/prof_<tag>/summary.txt
 set -u
 TAG=${1:-cfg}
@@ -8,7 +9,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-CMD="python tools/bench_configs.py --configs 3,4 --patterns 20 --steps 3"
+CMD="python tools/bench_configs.py --configs ${CONFIGS:-3,4} --patterns ${PATTERNS:-20} --steps 3"
 rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- $CMD > $OUT/bench.json 2> $OUT/trace.err
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES GRBM_GUI_ACTIVE -f csv -d $OUT/pmc_a -o p -- $CMD > /dev/null 2> $OUT/pmc_a.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/pmc_d -o p -- $CMD > /dev/null 2> $OUT/pmc_d.err

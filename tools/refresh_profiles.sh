@@ -41,6 +41,11 @@ print('   ms_per_search', d['ms_per_step'], 'scan_kernel_ms', d['dominant_kernel
 python tools/bench_configs.py --configs 1,3,4 --patterns 10000 > $OUT/${TAG}_configs.json 2> $OUT/configs.err
 bash tools/prof_configs.sh cfg > /dev/null 2>&1
 cp gpurun_out/prof_cfg/summary.txt $OUT/${TAG}_configs_prof.txt
+# config 4 at its own size: the seeded search (kernel stats + VALU / HBM counters), and the three many-pattern paths
+PATTERNS=10000 CONFIGS=4 bash tools/prof_configs.sh cfg10k > /dev/null 2>&1
+cp gpurun_out/prof_cfg10k/summary.txt $OUT/${TAG}_config4_seeded_prof.txt
+cp $(ls gpurun_out/prof_cfg10k/trace/*kernel_stats.csv gpurun_out/prof_cfg10k/trace/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_config4_seeded_kernel_stats.csv
+python tools/bench_encoded.py > $OUT/${TAG}_encoded_paths.txt 2> $OUT/encoded.err
 python tools/bench_texts.py > $OUT/${TAG}_texts.json 2> $OUT/texts.err
 { python tools/bench_reads.py; python tools/bench_reads.py --reads 330000; python tools/bench_reads.py --overhang 0.5; } > $OUT/${TAG}_reads.json 2> $OUT/reads.err
 { python tools/probe_count.py; python tools/probe_rc.py; } > $OUT/${TAG}_shapes.json 2> $OUT/shapes.err
