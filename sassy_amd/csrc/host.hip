@@ -2373,7 +2373,6 @@ static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* 
                                 sassy_hip_Result* R, bool* done, const TextTable* tt = nullptr,
                                 const HostTexts* ht = nullptr) {
   *done = false;
-  ScanLane& L = s->lanes[0];
   const size_t npat = e->patterns.size();
   const uint32_t m = (uint32_t)e->plen;
   std::string err;
@@ -2468,7 +2467,6 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
                                  sassy_hip_Result* R, bool* done, const TextTable* tt = nullptr,
                                  const HostTexts* ht = nullptr) {
   *done = false;
-  ScanLane& L = s->lanes[0];
   hipStream_t st = s->stream;
   const size_t npat = e->patterns.size();
   const uint32_t m = (uint32_t)e->plen;
