@@ -199,7 +199,9 @@ struct SeedParams {
   // 2 (c0 - k) << 16 | side << 24 (the shift amounts the test uses); sub[8 p] = 0xFF in its low byte: no test for piece p.
   const uint32_t* sub;
   const uint32_t* packed_text;    // 2-bit Dna codes of the text, 16 characters per dword
-  const unsigned long long* packed_pat;  // per pattern: row r at bits 2r
+  const unsigned long long* packed_pat;  // per pattern: row r at bits 2r; pat_care: two words per pattern, the second
+                                         // one = 11 at the rows the test may compare (concrete bases), 00 elsewhere
+  uint32_t pat_care;
   uint64_t seed_len_packed;       // byte p = rows of the seed of piece p
   const uint32_t* seed_bits;      // bit c of table t's part (offset bits_off[t] words): some seed of table t ends with the
                                   // min(len, 8) characters c -- staged in LDS, tested before the tables are read

@@ -2488,31 +2488,44 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   }
   uint32_t seed_bits_off[2] = {0, 0};
   // ---- direct-address tables: code of a seed = sum of its characters' Dna codes, first character lowest ----
+  // Iupac searcher (plain-ACGT text, patterns with ambiguity letters -- a CRISPR guide with its NGG): a seed with such
+  // letters stands for every concrete string it matches and gets one table entry per string (A, C, T, G = codes
+  // 0..3 = bits 0..3 of the letter's base set).  More than kSeedMaxExpand strings in one seed: not this path.
+  const bool iupac_pats = s->profile == PROFILE_IUPAC;
+  auto base_set = [&](uint8_t c) -> uint32_t { return iupac_pats ? (uint32_t)(iupac_code(c) & 0x0Fu) : 1u << ((c >> 1) & 3u); };
+  constexpr size_t kSeedMaxExpand = 256;
   std::vector<uint32_t> start[2], entries[2];
   for (int t = 0; t < 2; ++t) {
     if (!tab_len[t]) continue;
     const size_t size = (size_t)1 << (2 * tab_len[t]);
     start[t].assign(size + 1, 0u);
-    std::vector<uint32_t> code_of;
-    code_of.reserve(npat * pieces);
+    std::vector<std::pair<uint32_t, uint32_t>> code_entry;  // (code, (pattern << 3) | piece)
+    code_entry.reserve(npat * pieces);
+    std::vector<uint32_t> codes, next;
     for (size_t p = 0; p < npat; ++p)
       for (uint32_t pc = 0; pc < pieces; ++pc) {
         if (tab_of[pc] != (uint32_t)t) continue;
         const uint8_t* src = e->patterns[p].data() + p_end[pc] - p_len[pc];
-        uint32_t code = 0;
-        for (uint32_t x = 0; x < p_len[pc]; ++x) code |= (uint32_t)((src[x] >> 1) & 3u) << (2 * x);
-        code_of.push_back(code);
-        start[t][code + 1]++;
+        codes.assign(1, 0u);
+        for (uint32_t x = 0; x < p_len[pc]; ++x) {
+          const uint32_t set = base_set(src[x]);
+          if (set == 0) { codes.clear(); break; }  // (X: matches nothing -- the piece is never intact)
+          next.clear();
+          for (uint32_t c : codes)
+            for (uint32_t b = 0; b < 4; ++b)
+              if (set & (1u << b)) next.push_back(c | (b << (2 * x)));
+          if (next.size() > kSeedMaxExpand) return 0;  // *done stays false
+          codes.swap(next);
+        }
+        for (uint32_t c : codes) {
+          code_entry.emplace_back(c, (uint32_t)(p << 3) | pc);
+          start[t][c + 1]++;
+        }
       }
     for (size_t c = 0; c < size; ++c) start[t][c + 1] += start[t][c];
-    entries[t].resize(code_of.size());
+    entries[t].resize(code_entry.size());
     std::vector<uint32_t> cursor(start[t].begin(), start[t].end() - 1);
-    size_t x = 0;
-    for (size_t p = 0; p < npat; ++p)
-      for (uint32_t pc = 0; pc < pieces; ++pc) {
-        if (tab_of[pc] != (uint32_t)t) continue;
-        entries[t][cursor[code_of[x++]]++] = (uint32_t)(p << 3) | pc;
-      }
+    for (const auto& ce : code_entry) entries[t][cursor[ce.first]++] = ce.second;
   }
   // ---- match masks per Dna code and the patterns' bytes (traceback) ----
   const bool wide = m > 32;
@@ -2522,9 +2535,12 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     const uint8_t* pt = e->patterns[p].data();
     memcpy(&flat[p * m], pt, m);
     for (uint32_t j = 0; j < m; ++j) {
-      const uint32_t c = (pt[j] >> 1) & 3u;
-      if (wide) peq[p * 4 + c] |= 1ull << j;
-      else reinterpret_cast<uint32_t*>(peq.data())[p * 4 + c] |= 1u << j;
+      const uint32_t set = base_set(pt[j]);
+      for (uint32_t c = 0; c < 4; ++c) {
+        if (!(set & (1u << c))) continue;
+        if (wide) peq[p * 4 + c] |= 1ull << j;
+        else reinterpret_cast<uint32_t*>(peq.data())[p * 4 + c] |= 1u << j;
+      }
     }
   }
   if (int rc = s->d_tiled_peq.reserve(peq.size())) return rc;
@@ -2598,15 +2614,27 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
         sub[8 * pc + u++] = (2 * a) | ((32 - 2 * len) << 8) | ((2 * (8u + (a - pe) - k)) << 16) | (1u << 24);
       }
     }
-    std::vector<unsigned long long> ppk(npat, 0ull);
+    // packed patterns: row j at bits 2j; with ambiguity letters a second word per pattern says which rows the test
+    // may compare (11: a concrete base, 00: a letter that stands for several -- such a row matches any character here)
+    std::vector<unsigned long long> ppk(npat * (iupac_pats ? 2 : 1), 0ull);
     for (size_t p = 0; p < npat; ++p)
-      for (uint32_t j = 0; j < m; ++j) ppk[p] |= (unsigned long long)((e->patterns[p][j] >> 1) & 3u) << (2 * j);
+      for (uint32_t j = 0; j < m; ++j) {
+        const uint32_t set = base_set(e->patterns[p][j]);
+        const bool one = set && !(set & (set - 1));
+        const uint32_t code = one ? (set == 1 ? 0u : set == 2 ? 1u : set == 4 ? 2u : 3u) : 0u;
+        if (iupac_pats) {
+          ppk[2 * p] |= (unsigned long long)code << (2 * j);
+          if (one) ppk[2 * p + 1] |= 3ull << (2 * j);
+        } else {
+          ppk[p] |= (unsigned long long)code << (2 * j);
+        }
+      }
     const uint64_t n16 = (text_len + 15) / 16;
     if (int rc = s->d_seed_sub.reserve(64)) return rc;
-    if (int rc = s->d_seed_ppk.reserve(npat)) return rc;
+    if (int rc = s->d_seed_ppk.reserve(ppk.size())) return rc;
     if (int rc = s->d_seed_packed.reserve(n16 + 8)) return rc;
     HIP_TRY(hipMemcpyAsync(s->d_seed_sub.p, sub.data(), 64 * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_seed_ppk.p, ppk.data(), npat * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_seed_ppk.p, ppk.data(), ppk.size() * 8, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->d_seed_packed.p + n16, 0, 8 * 4, st));
     hipError_t pe_ = launch_pack_text(tptr, text_len, s->d_seed_packed.p, st);
     if (pe_ != hipSuccess) return hip_fail(pe_, "text packing launch");
@@ -2614,6 +2642,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     SP.sub = s->d_seed_sub.p;
     SP.packed_text = s->d_seed_packed.p;
     SP.packed_pat = s->d_seed_ppk.p;
+    SP.pat_care = iupac_pats ? 1u : 0u;
   }
   SP.out_count = s->d_tiled_cnt.p;
   SP.hit_count = reinterpret_cast<unsigned long long*>(s->d_tiled_cnt.p + 4);
@@ -3645,11 +3674,14 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
     sassy_SearcherType* s; Profile saved;
     ~ProfileGuard() { s->profile = saved; }
   } pguard{s, s->profile};
+  // (patterns with ambiguity letters -- guides with their NGG -- stay Iupac, but on a plain text the seeded search
+  // takes them too: its seeds and masks are built from the letters' base sets)
+  bool text_plain = false;
   if (s->profile == PROFILE_IUPAC && std::isnan(s->alpha) && e->patterns.size() >= 4 && text_len >= 16 &&
       ((uintptr_t)tptr & 15) == 0) {
     bool plain = true;
     for (const auto& p : e->patterns) plain = plain && acgt_only(p.data(), p.size());
-    if (plain) {
+    if (plain || seeded_hit_rate(e->plen, k) > 0) {
       if (int rc = s->d_ncount.reserve(4)) return rc;
       HIP_TRY(hipMemsetAsync(s->d_ncount.p, 0, 4, s->stream));
       hipError_t le = launch_acgt_check(tptr, text_len, s->d_ncount.p, s->stream);
@@ -3657,7 +3689,8 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
       uint32_t bad = 1;
       HIP_TRY(hipMemcpyAsync(&bad, s->d_ncount.p, 4, hipMemcpyDeviceToHost, s->stream));
       HIP_TRY(hipStreamSynchronize(s->stream));
-      if (!bad) s->profile = PROFILE_DNA;
+      text_plain = !bad;
+      if (plain && text_plain) s->profile = PROFILE_DNA;
     }
   }
   (void)f;
@@ -3703,7 +3736,8 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
     // 17 for the pattern-tiled scan (SASSY_HIP_SEEDED=0 / 1 forces the choice).
     const int env_seeded = getenv("SASSY_HIP_SEEDED") ? atoi(getenv("SASSY_HIP_SEEDED")) : -1;
     bool seeded = false;
-    if (s->profile == PROFILE_DNA && std::isnan(s->alpha) && k + 1 <= 8 && e->plen / (k + 1) >= 5 &&
+    if ((s->profile == PROFILE_DNA || (s->profile == PROFILE_IUPAC && text_plain)) && std::isnan(s->alpha) && k + 1 <= 8 &&
+        e->plen / (k + 1) >= 5 &&
         e->plen + 3 * k + 1 <= 4 * kSeedWindowDwords && e->patterns.size() < (1u << 24) && text_len < (1ull << 36) &&
         (((uintptr_t)tptr) & 15) == 0) {
       const double est_seeded = seeded_estimate(e->plen, k, e->patterns.size(), text_len);

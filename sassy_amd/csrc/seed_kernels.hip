@@ -71,7 +71,8 @@ __device__ __forceinline__ bool sub_piece_test(const SeedParams& P, unsigned lon
   // everything the test reads, requested at once: the piece's sub-piece row, the pattern, the two text windows
   const uint4* row = reinterpret_cast<const uint4*>(P.sub + 8u * piece);
   const uint4 r0 = row[0], r1 = row[1];
-  const unsigned long long pp = P.packed_pat[pat];
+  const unsigned long long pp = P.packed_pat[P.pat_care ? 2u * pat : pat];
+  const unsigned long long care = P.pat_care ? P.packed_pat[2u * pat + 1u] : ~0ull;  // (wave-uniform branch)
   const int64_t cl = i - (int64_t)((P.seed_len_packed >> (8u * piece)) & 0xFFu) - 24, ch = i - 8;
   const bool inside = cl >= 0 && ch + 32 <= (int64_t)P.text_len;
   const unsigned long long lo = packed_window(P.packed_text, inside ? cl : 0),
@@ -85,7 +86,7 @@ __device__ __forceinline__ bool sub_piece_test(const SeedParams& P, unsigned lon
     if (u <= k) {
       // row fields (host.hip): 2a | (32 - 2 len) << 8 | 2 (c0 - k) << 16 | side << 24
       const uint32_t want = (uint32_t)(pp >> (ent[u] & 0xFFu));
-      const uint32_t mask = 0xFFFFFFFFu >> ((ent[u] >> 8) & 0xFFu);
+      const uint32_t mask = (0xFFFFFFFFu >> ((ent[u] >> 8) & 0xFFu)) & (uint32_t)(care >> (ent[u] & 0xFFu));
       // the window from the leftmost shift on; every further shift is two bits down
       const unsigned long long w = ((ent[u] >> 24) ? hi : lo) >> ((ent[u] >> 16) & 0xFFu);
       const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);

@@ -916,6 +916,38 @@ def test_encoded_seeded(sassy):
             got_wo = s.search_encoded_patterns(enc, tb, k, all_minima=allm, without_trace=True)
             assert sorted((x.pattern_idx, x.text_end, x.cost, x.strand) for x in got_wo) == \
                 sorted((x.pattern_idx, x.text_end, x.cost, x.strand) for x in want)
+    # patterns with ambiguity letters on a plain-ACGT text (Iupac searcher): CRISPR guides with their NGG, letters that
+    # stand for two or three bases inside seeds and sub-pieces, an X (matches nothing); a seed with such letters has one
+    # table entry per concrete string it matches
+    for (m, k, npat, n) in [(23, 3, 120, 60_000), (20, 2, 40, 30_000), (32, 3, 20, 30_000)]:
+        pats = []
+        for i in range(npat):
+            p = bytearray(rng.choice(b"ACGT") for _ in range(m))
+            if m == 23:
+                p[20:23] = b"NGG"
+            else:
+                for _ in range(rng.randrange(0, 4)):
+                    p[rng.randrange(m)] = rng.choice(b"NRYKMSWBDHV")
+            pats.append(bytes(p))
+        pats[1] = pats[1][:5] + b"X" + pats[1][6:]
+        text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        for p in pats[:60]:
+            conc = bytes(c if c in b"ACGT" else rng.choice(b"ACGT") for c in p)
+            for _ in range(2):
+                ins = mutate(rng, conc, rng.randrange(0, k + 1))
+                if rng.random() < 0.5:
+                    ins = oracle.reverse_complement("iupac", ins)
+                at = rng.randrange(0, n - len(ins))
+                text[at:at + len(ins)] = ins
+        tb = bytes(text)
+        for rc in (False, True):
+            s = sassy.Searcher("iupac", rc=rc)
+            enc = s.encode_patterns(pats)
+            got = s.search_encoded_patterns(enc, tb, k)
+            assert s.stats()["filtered"] == 6, (m, k, s.stats())
+            want = oracle.search_encoded("iupac", pats, tb, k, rc=rc)
+            assert sorted(key(x) for x in got) == sorted(key(x) for x in want), (m, k, npat, rc, len(got), len(want))
+            assert len(want) >= 10
     # a text of one repeated unit: every position hits the seed tables of the patterns cut from it; the candidate
     # list overflows its expectation-sized capacity and the segments are cut smaller
     unit = bytes(rng.choice(b"ACGT") for _ in range(37))
