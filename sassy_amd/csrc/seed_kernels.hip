@@ -191,6 +191,7 @@ __device__ __forceinline__ void verify_candidate(const SeedParams& P, unsigned l
 // KT: the sub-piece test's k (>= 0: compile-time, -1: run-time, -2: no test).
 template <int WORDS, int KT>
 __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
+  constexpr uint32_t kTurn = 4;
   __shared__ unsigned long long queue_mem[kWavesPerGroup][128], pass_mem[kWavesPerGroup][128];
   // "does any pattern have a seed that ends like this?" -- one bit per min(len, 8)-gram and table (<= 2 x 8 KiB): with
   // few patterns nearly every position fails it and never reads the tables in global memory
@@ -275,18 +276,19 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
       if (g + 16 < P.text_len) c2 = pack_codes16(src[1]);
     }
     const unsigned long long q01 = ((unsigned long long)c1 << 32) | c0, q12 = ((unsigned long long)c2 << 32) | c1;
-    // table rows of position j: [first, count) of the entry lists (table 0: the longer pieces)
-    auto look_up = [&](uint32_t j, uint32_t& a0, uint32_t& n0, uint32_t& a1, uint32_t& n1) __attribute__((always_inline)) {
+    // table rows of position j: [first, last) of the entry lists (table 0: the longer pieces).  The loads are left
+    // in flight: the caller subtracts when it gets to the position.
+    auto look_up = [&](uint32_t j, uint32_t& a0, uint32_t& b0, uint32_t& a1, uint32_t& b1) __attribute__((always_inline)) {
       const unsigned long long q = j < 16 ? q01 : q12;
       const uint64_t end = g + j + 1;  // exclusive end of the seeds that end in character j
       const bool in_text = j < 32 && end <= P.text_len;
-      a0 = n0 = a1 = n1 = 0;
+      a0 = b0 = a1 = b1 = 0;
       if (P.len[0] && in_text && end >= P.len[0]) {
         const uint32_t code = (uint32_t)(q >> (2u * (17u + (j & 15u) - P.len[0]))) & mask0;
         const uint32_t c8 = code >> cut0;  // the seed's last min(len, 8) characters
         if ((bits_lds[c8 >> 5] >> (c8 & 31u)) & 1u) {
           a0 = P.start[0][code];
-          n0 = P.start[0][code + 1] - a0;
+          b0 = P.start[0][code + 1];
         }
       }
       if (P.len[1] && in_text && end >= P.len[1]) {
@@ -294,37 +296,47 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
         const uint32_t c8 = code >> cut1;
         if ((bits_lds[P.bits_off[1] + (c8 >> 5)] >> (c8 & 31u)) & 1u) {
           a1 = P.start[1][code];
-          n1 = P.start[1][code + 1] - a1;
+          b1 = P.start[1][code + 1];
         }
       }
     };
-    uint32_t a0, n0, a1, n1;
-    look_up(0, a0, n0, a1, n1);
+    uint32_t a0, b0, a1, b1;
+    look_up(0, a0, b0, a1, b1);
 #pragma unroll 1
     for (uint32_t j = 0; j < 32; ++j) {
-      uint32_t xa0, xn0, xa1, xn1;  // the next position's rows are in flight while this one's hits are queued
-      look_up(j + 1, xa0, xn0, xa1, xn1);
+      uint32_t xa0, xb0, xa1, xb1;  // the next position's rows are in flight while this one's hits are queued
+      look_up(j + 1, xa0, xb0, xa1, xb1);
       const uint64_t end = g + j + 1;
-      const uint32_t n = n0 + n1;
-      for (uint32_t r = 0;; ++r) {
-        const bool active = r < n;
-        const unsigned long long m = __ballot(active);
-        if (m == 0) break;
-        if (active) {
-          const uint32_t e = r < n0 ? P.entries[0][a0 + r] : P.entries[1][a1 + (r - n0)];
-          const uint32_t slot = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-          queue[slot] = ((unsigned long long)end << kSeedPosShift) | e;
+      const uint32_t n0 = b0 - a0, n = n0 + (b1 - a1);
+      // the hits of this position, kTurn per lane and turn: their entry loads are in flight together
+      for (uint32_t r0 = 0; __ballot(r0 < n) != 0; r0 += kTurn) {
+        uint32_t ent[kTurn];
+#pragma unroll
+        for (uint32_t x = 0; x < kTurn; ++x) {
+          const uint32_t r = r0 + x;
+          ent[x] = 0;
+          if (r < n) ent[x] = r < n0 ? P.entries[0][a0 + r] : P.entries[1][a1 + (r - n0)];
         }
-        queued += (uint32_t)__popcll(m);
-        __builtin_amdgcn_wave_barrier();
-        if (queued >= 64) {
-          verify(64);
-          pop64(queue, queued);
-          queued -= 64;
-          n_hits += 64;
+#pragma unroll
+        for (uint32_t x = 0; x < kTurn; ++x) {
+          const bool active = r0 + x < n;
+          const unsigned long long m = __ballot(active);
+          if (m == 0) break;
+          if (active) {
+            const uint32_t slot = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            queue[slot] = ((unsigned long long)end << kSeedPosShift) | ent[x];
+          }
+          queued += (uint32_t)__popcll(m);
+          __builtin_amdgcn_wave_barrier();
+          if (queued >= 64) {
+            verify(64);
+            pop64(queue, queued);
+            queued -= 64;
+            n_hits += 64;
+          }
         }
       }
-      a0 = xa0; n0 = xn0; a1 = xa1; n1 = xn1;
+      a0 = xa0; b0 = xb0; a1 = xa1; b1 = xb1;
     }
   }
   if (queued) verify(queued);
