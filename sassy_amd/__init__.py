@@ -272,6 +272,15 @@ def match_dtype():
                      ("cigar_off", "<u4"), ("cigar_len", "<u4")])
 
 
+def _bytes_at(addr, size: int) -> bytes:
+    """`size` bytes at a C address (ctypes.string_at takes an int-sized length: results above 2 GiB need the array form)."""
+    if not size:
+        return b""
+    if size < (1 << 31):
+        return C.string_at(addr, size)
+    return bytes((C.c_char * size).from_address(addr if isinstance(addr, int) else C.cast(addr, C.c_void_p).value))
+
+
 class Result:
     """Matches of one call plus the shard bookkeeping (see include/sassy_hip.h).
 
@@ -300,11 +309,11 @@ class Result:
         try:
             n = self._n
             ptr = L.sassy_hip_result_matches(h)
-            raw = C.string_at(ptr, n * 64) if n else b""
+            raw = _bytes_at(ptr, n * 64)
             self._array = np.frombuffer(raw, dtype=match_dtype())
             plen = L.sassy_hip_result_cigars_len(h)
             pool = L.sassy_hip_result_cigars(h)
-            self._pool = C.string_at(pool, plen) if plen else b""
+            self._pool = _bytes_at(pool, plen)
         finally:
             L.sassy_hip_result_free(h)
 

@@ -21,6 +21,8 @@ constexpr int kCtlTailWord = 12;
 // candidate flags
 constexpr uint32_t kCandCond = 1u;     // report depends on the plateau-entry direction left of the chunk
 constexpr uint32_t kCandDrop = 2u;     // multi-text buffers: the report lies in a separator, not in a text
+constexpr uint32_t kCandCont = 4u;     // lists of all end positions <= k: the cost stays the same over a stretch of
+                                       // positions left out behind this one (the inside of a long run of N): not a plateau's end
 constexpr int kCandTextShift = 8;      // multi-text buffers: bits 8..31 = index of the text (< 2^24)
 
 // Several texts in one device buffer (search_texts / search_many on many short texts): text t

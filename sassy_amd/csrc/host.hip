@@ -67,6 +67,16 @@ hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Cand
                                  void* d_scratch, size_t scratch_bytes, hipStream_t stream, int all_minima = 0);
 hipError_t launch_seed_search(const SeedParams& P, uint32_t grid, hipStream_t stream);
 hipError_t launch_pack_text(const uint8_t* d_text, uint64_t n, uint32_t* d_packed, hipStream_t stream);
+hipError_t launch_dirty_scan(const uint8_t* d_text, uint64_t n, unsigned long long* d_starts, unsigned long long* d_ends,
+                             unsigned long long* d_hard, uint32_t cap, uint32_t* d_counts, hipStream_t stream);
+hipError_t launch_gather_zones(const uint8_t* d_text, uint8_t* d_dst, const unsigned long long* d_seg, uint32_t n_seg,
+                               hipStream_t stream);
+hipError_t launch_map_zone_list(const Candidate* d_in, uint32_t count, const unsigned long long* d_zone, uint32_t n_zones,
+                                Candidate* d_out, uint32_t* d_out_count, uint32_t out_cap, hipStream_t stream);
+hipError_t launch_drop_excluded(const Candidate* d_in, uint32_t count, const unsigned long long* d_excl, uint32_t n_excl,
+                                unsigned char* d_keep, hipStream_t stream);
+hipError_t launch_compact_candidates(const Candidate* d_in, uint32_t count, const unsigned char* d_keep, Candidate* d_out,
+                                     uint32_t* d_out_count, void* d_scratch, size_t scratch_bytes, hipStream_t stream);
 hipError_t launch_tiled_scan(const TiledParams& P, hipStream_t stream);
 hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable& texts, uint32_t* d_report_text,
                                hipStream_t stream);
@@ -406,6 +416,10 @@ struct sassy_SearcherType {
   // seeded search (search_encoded_seeded): the piece tables; sub-piece table, packed text and patterns
   DevBuf<uint32_t> d_seed_start[2], d_seed_entries[2], d_seed_sub, d_seed_packed, d_seed_bits;
   DevBuf<unsigned long long> d_seed_ppk;
+  // ... on texts with other letters (seeded_dirty_zones): run lists / tables, the gathered neighbourhoods, their scan
+  DevBuf<unsigned long long> d_zone_u64, d_zone_tab, d_zone_peq;
+  DevBuf<uint8_t> d_zone_text;
+  DevBuf<Candidate> d_zone_list;
   hipEvent_t ev_multi = nullptr, ev_multi_a = nullptr;
   hipEvent_t ev_a_multi() { return ev_multi_a; }
   DevBuf<uint64_t> d_range;      // N counting on device-resident text
@@ -425,6 +439,7 @@ struct sassy_SearcherType {
     d_tiled_peq.release(); d_tiled_pat.release(); d_tiled_cnt.release(); d_tiled_sel.release(); d_tiled_list.release(); d_tiled_rtext.release();
     for (int t = 0; t < 2; ++t) { d_seed_start[t].release(); d_seed_entries[t].release(); }
     d_seed_sub.release(); d_seed_packed.release(); d_seed_ppk.release(); d_seed_bits.release();
+    d_zone_u64.release(); d_zone_tab.release(); d_zone_peq.release(); d_zone_text.release(); d_zone_list.release();
     if (ev_multi) (void)hipEventDestroy(ev_multi);
     if (ev_multi_a) (void)hipEventDestroy(ev_multi_a);
     for (ScanLane& l : lanes) l.destroy();
@@ -2362,6 +2377,86 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
   return 0;
 }
 
+// The pattern-tiled kernel over one device buffer: every (pattern, end position, cost <= k) into `list` (grown on
+// demand; the counter is the device word d_count).  *ok = false: more than 2^26 of them.  classes: 4 (Dna codes) or
+// 16 (Iupac base sets; 'X' matches nothing).
+static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* buf, uint64_t len, uint32_t k,
+                           uint32_t classes, DevBuf<unsigned long long>& d_peq, DevBuf<Candidate>& list, uint32_t* d_count,
+                           uint32_t* count, bool* ok, uint64_t* n_waves) {
+  *ok = false;
+  *count = 0;
+  const size_t npat = e->patterns.size();
+  const uint32_t m = (uint32_t)e->plen;
+  hipStream_t st = s->stream;
+  // ---- match masks: bit j of peq[class][pattern] = row j of the pattern matches a text character of that class ----
+  const uint32_t npad = (uint32_t)((npat + 63) / 64 * 64);
+  std::vector<unsigned long long> peq((size_t)classes * npad, 0ull);
+  for (size_t p = 0; p < npat; ++p) {
+    const uint8_t* pt = e->patterns[p].data();
+    for (uint32_t j = 0; j < m; ++j) {
+      if (classes == 4) {
+        peq[(size_t)((pt[j] >> 1) & 3u) * npad + p] |= 1ull << j;  // src/profiles/dna.rs:19-40
+      } else {
+        const uint32_t set = iupac_code(pt[j]) & 0x0Fu;              // src/profiles/iupac.rs:18-36
+        for (uint32_t c = 1; c < 16; ++c)
+          if (set & c) peq[(size_t)c * npad + p] |= 1ull << j;
+      }
+    }
+  }
+  if (int rc = d_peq.reserve(peq.size())) return rc;
+  HIP_TRY(hipMemcpyAsync(d_peq.p, peq.data(), peq.size() * 8, hipMemcpyHostToDevice, st));
+
+  TiledParams P{};
+  P.skew = (uint32_t)((uintptr_t)buf & 63u);
+  P.text_aligned = buf - P.skew;
+  P.text_len = len;
+  P.peq = d_peq.p;
+  P.npat = (uint32_t)npat;
+  P.npat_padded = npad;
+  P.n_groups = npad / 64;
+  P.m = m;
+  P.k = k;
+  P.classes = classes;
+  P.warm_blocks = (m + k + 63) / 64;
+  {
+    const uint64_t span = (uint64_t)P.skew + len;
+    const uint64_t waves_wanted = 16384;
+    const uint64_t chunks_wanted = std::max<uint64_t>(1, waves_wanted / P.n_groups);
+    uint64_t chunk = std::max<uint64_t>(512, (span + chunks_wanted - 1) / chunks_wanted);
+    chunk = std::min<uint64_t>((chunk + 63) / 64 * 64, 1u << 20);
+    P.chunk = (uint32_t)chunk;
+    P.n_chunks = (span + chunk - 1) / chunk;
+  }
+  *n_waves = P.n_chunks * P.n_groups;
+  const uint64_t kMaxList = 1ull << 28;  // 4 GiB of (pattern, position, cost) records: beyond that, per-pattern scans
+  uint32_t got = 0;
+  for (int attempt = 0;; ++attempt) {
+    if (int rc = list.reserve(std::max<size_t>((size_t)1 << 18, (size_t)got + 1024))) return rc;
+    P.cand = list.p;
+    P.cand_cap = (uint32_t)std::min<size_t>(list.cap, 0xFFFFFFFFu);
+    P.cand_count = d_count;
+    HIP_TRY(hipMemsetAsync(d_count, 0, 4, st));
+    HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
+    hipError_t le = launch_tiled_scan(P, st);
+    if (le != hipSuccess) return hip_fail(le, "pattern-tiled scan launch");
+    HIP_TRY(hipEventRecord(s->ev_multi, st));
+    HIP_TRY(hipMemcpyAsync(&got, d_count, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));  // (`peq` stays alive until here)
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
+    s->stats.scan_ms += ms;
+    s->stats.scan_launches += 1;
+    if (got <= P.cand_cap) break;
+    if (got > kMaxList || attempt == 2) {
+      if (getenv("SASSY_HIP_DEBUG_ZONES")) fprintf(stderr, "[tiled] list of %u records (attempt %d, capacity %u): too many\n", got, attempt, P.cand_cap);
+      return 0;  // *ok stays false
+    }
+  }
+  *count = got;
+  *ok = true;
+  return 0;
+}
+
 // search_encoded_patterns in ONE pass: the pattern-tiled scan (tiled_kernel.hip; reference v2,
 // src/pattern_tiling/search.rs:326-425 + general.rs:335-404).  All (rc-expanded) patterns advance together over
 // the text, 64 per wavefront; the kernel lists every (pattern, end position) with cost <= k, the device sorts the
@@ -2381,81 +2476,167 @@ static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* 
     PatternPlan pl;
     if (!make_plan(s->profile, e->patterns[p].data(), m, p == 0 ? plan0 : pl, err)) return fail(SASSY_HIP_EINVAL, err);
   }
-  // ---- match masks: bit j of peq[class][pattern] = row j of the pattern matches a text character of that class ----
-  const uint32_t classes = s->profile == PROFILE_DNA ? 4u : 16u;
-  const uint32_t npad = (uint32_t)((npat + 63) / 64 * 64);
-  std::vector<unsigned long long> peq((size_t)classes * npad, 0ull);
   std::vector<uint8_t> flat(npat * (size_t)m);
-  for (size_t p = 0; p < npat; ++p) {
-    const uint8_t* pt = e->patterns[p].data();
-    memcpy(&flat[p * m], pt, m);
-    for (uint32_t j = 0; j < m; ++j) {
-      if (classes == 4) {
-        peq[(size_t)((pt[j] >> 1) & 3u) * npad + p] |= 1ull << j;  // src/profiles/dna.rs:19-40
-      } else {
-        const uint32_t set = iupac_code(pt[j]) & 0x0Fu;              // src/profiles/iupac.rs:18-36
-        for (uint32_t c = 1; c < 16; ++c)
-          if (set & c) peq[(size_t)c * npad + p] |= 1ull << j;
-      }
-    }
-  }
-  if (int rc = s->d_tiled_peq.reserve(peq.size())) return rc;
+  for (size_t p = 0; p < npat; ++p) memcpy(&flat[p * m], e->patterns[p].data(), m);
   if (int rc = s->d_tiled_pat.reserve(flat.size() + 64)) return rc;
   if (int rc = s->d_tiled_cnt.reserve(16)) return rc;
   hipStream_t st = s->stream;
-  HIP_TRY(hipMemcpyAsync(s->d_tiled_peq.p, peq.data(), peq.size() * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p, 0, 64, st));
   HIP_TRY(hipMemcpyAsync(s->d_tiled_pat.p, flat.data(), flat.size(), hipMemcpyHostToDevice, st));
-
-  TiledParams P{};
-  P.skew = (uint32_t)((uintptr_t)tptr & 63u);
-  P.text_aligned = tptr - P.skew;
-  P.text_len = text_len;
-  P.peq = s->d_tiled_peq.p;
-  P.npat = (uint32_t)npat;
-  P.npat_padded = npad;
-  P.n_groups = npad / 64;
-  P.m = m;
-  P.k = k;
-  P.classes = classes;
-  P.warm_blocks = (m + k + 63) / 64;
-  {
-    const uint64_t span = (uint64_t)P.skew + text_len;
-    const uint64_t waves_wanted = 16384;
-    const uint64_t chunks_wanted = std::max<uint64_t>(1, waves_wanted / P.n_groups);
-    uint64_t chunk = std::max<uint64_t>(512, (span + chunks_wanted - 1) / chunks_wanted);
-    chunk = std::min<uint64_t>((chunk + 63) / 64 * 64, 1u << 20);
-    P.chunk = (uint32_t)chunk;
-    P.n_chunks = (span + chunk - 1) / chunk;
-  }
-  const uint64_t kMaxList = 1ull << 26;  // 1 GiB of (pattern, position, cost) records: beyond that, per-pattern scans
-  uint32_t counts[2] = {0, 0};
-  for (int attempt = 0;; ++attempt) {
-    if (int rc = s->d_tiled_list.reserve(std::max<size_t>((size_t)1 << 18, (size_t)counts[0] + 1024))) return rc;
-    P.cand = s->d_tiled_list.p;
-    P.cand_cap = (uint32_t)std::min<size_t>(s->d_tiled_list.cap, 0xFFFFFFFFu);
-    P.cand_count = s->d_tiled_cnt.p;
-    HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p, 0, 64, st));
-    HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
-    hipError_t le = launch_tiled_scan(P, st);
-    if (le != hipSuccess) return hip_fail(le, "pattern-tiled scan launch");
-    HIP_TRY(hipEventRecord(s->ev_multi, st));
-    HIP_TRY(hipMemcpyAsync(counts, s->d_tiled_cnt.p, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    float ms = 0;
-    HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
-    s->stats.scan_ms += ms;
-    s->stats.scan_launches += 1;
-    if (counts[0] <= P.cand_cap) break;
-    if (counts[0] > kMaxList || attempt == 2) return 0;  // *done stays false
-  }
-  const uint32_t count = counts[0];
+  uint32_t count = 0;
+  uint64_t n_waves = 0;
+  bool ok = false;
+  if (int rc = tiled_scan_list(s, e, tptr, text_len, k, s->profile == PROFILE_DNA ? 4u : 16u, s->d_tiled_peq, s->d_tiled_list,
+                               s->d_tiled_cnt.p, &count, &ok, &n_waves)) return rc;
+  if (!ok) return 0;  // *done stays false
   s->stats.text_bytes += text_len;
-  s->stats.chunks += P.n_chunks * P.n_groups;
+  s->stats.chunks += n_waves;
   s->stats.filtered = 5;
   s->stats.candidates += count;
   *done = true;
   if (count == 0) return 0;
   return finish_pattern_list(s, e, plan0, tptr, h_text, text_len, k, all, wo, count, false, R, tt, ht);
+}
+
+// The seeded search on a text with other letters than ACGT (Iupac searcher; seed_kernels.hip, second half).  The
+// seeded pass has filled d_tiled_list with *list_count records that are exact wherever the m + k characters in front
+// of the end position are plain.  Here: find the runs of other letters, drop the records whose window touches one,
+// and put in their place what the pattern-tiled scan (16 Iupac classes) finds on a gathered copy of the runs'
+// neighbourhoods.  A run of full wildcards (N, non-letters) of more than m + 1 characters is not copied
+// whole: inside it every pattern's cost is constant, so the list leaves those positions out and marks the last one
+// in front of them (kCandCont) -- the report rule then sees one plateau (search_all needs every position: no cut).
+// *ok = false: too many runs / too much text around them -- the caller takes another way.
+static int seeded_dirty_zones(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr, uint64_t n, uint32_t k,
+                              bool all, uint32_t* list_count, bool* ok) {
+  *ok = false;
+  ScanLane& L = s->lanes[0];
+  hipStream_t st = s->stream;
+  const uint64_t C = (uint64_t)e->plen + k;
+  const uint32_t cap = 1u << 20;  // runs of other letters (a human genome has ~10^3; this synthetic one 10^5)
+  uint32_t* d_cnt = s->d_tiled_cnt.p + 8;  // words 8..10: runs' starts, ends, hard letters; 12, 13: list counters
+  if (int rc = s->d_zone_u64.reserve(3 * (size_t)cap)) return rc;
+  HIP_TRY(hipMemsetAsync(d_cnt, 0, 32, st));
+  hipError_t le = launch_dirty_scan(tptr, n, s->d_zone_u64.p, s->d_zone_u64.p + cap, s->d_zone_u64.p + 2 * cap, cap, d_cnt, st);
+  if (le != hipSuccess) return hip_fail(le, "letter run scan launch");
+  uint32_t cnt[3] = {0, 0, 0};
+  HIP_TRY(hipMemcpyAsync(cnt, d_cnt, 12, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  static const bool dbg = getenv("SASSY_HIP_DEBUG_ZONES") != nullptr;
+  if (dbg) fprintf(stderr, "[zones] runs %u ends %u hard %u\n", cnt[0], cnt[1], cnt[2]);
+  if (cnt[0] > cap || cnt[1] > cap || cnt[2] > cap) return 0;
+  if (cnt[0] != cnt[1]) return fail(SASSY_HIP_EINVAL, "letter run scan: unpaired run ends (internal error)");
+  std::vector<unsigned long long> starts(cnt[0]), ends(cnt[1]), hard(cnt[2]);
+  if (cnt[0]) {
+    HIP_TRY(hipMemcpyAsync(starts.data(), s->d_zone_u64.p, cnt[0] * 8ull, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(ends.data(), s->d_zone_u64.p + cap, cnt[1] * 8ull, hipMemcpyDeviceToHost, st));
+  }
+  if (cnt[2]) HIP_TRY(hipMemcpyAsync(hard.data(), s->d_zone_u64.p + 2 * cap, cnt[2] * 8ull, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  std::sort(starts.begin(), starts.end());
+  std::sort(ends.begin(), ends.end());
+  const size_t n_runs = starts.size();
+  std::vector<char> run_hard(n_runs, 0);
+  for (unsigned long long h : hard) {
+    const size_t r = (size_t)(std::upper_bound(starts.begin(), starts.end(), h) - starts.begin()) - 1;
+    run_hard[r] = 1;
+  }
+  // ---- where the zones are responsible (end positions), what they keep, what they copy ----
+  struct Keep { uint64_t lo, hi; bool cont; };
+  std::vector<Keep> keep;
+  std::vector<unsigned long long> excl;  // pairs
+  auto add_keep = [&](uint64_t lo, uint64_t hi, bool cont) {
+    if (!keep.empty() && !keep.back().cont && lo <= keep.back().hi + 1) {
+      keep.back().hi = std::max(keep.back().hi, hi);
+      keep.back().cont = cont;
+    } else {
+      keep.push_back(Keep{lo, hi, cont});
+    }
+  };
+  for (size_t r = 0; r < n_runs; ++r) {
+    const uint64_t rs = starts[r], re = ends[r];
+    const uint64_t lo = rs + 1, hi = std::min<uint64_t>(n, re + C);
+    if (!excl.empty() && lo <= excl.back() + 1) excl.back() = std::max<unsigned long long>(excl.back(), hi);
+    else { excl.push_back(lo); excl.push_back(hi); }
+    // A run of full wildcards longer than the pattern: from end position rs + m (the last m characters are wildcards)
+    // to re every pattern's cost is one constant -- the list holds the way down to it (kept up to rs + m, marked) and
+    // picks up at re, the last position of the stretch.
+    // (the way down may be longer when the interval in front reaches into this run: it is merged with it)
+    uint64_t left_hi = rs + e->plen;
+    if (!keep.empty() && !keep.back().cont && lo <= keep.back().hi + 1) left_hi = std::max(left_hi, keep.back().hi);
+    const bool cut = !all && !run_hard[r] && re - rs >= (uint64_t)e->plen + 2 && left_hi + 1 < re;
+    if (cut) {
+      add_keep(lo, left_hi, true);
+      add_keep(re, hi, false);
+    } else {
+      add_keep(lo, hi, false);
+    }
+  }
+  const size_t n_zones = keep.size();
+  std::vector<unsigned long long> tab;  // zones (6 words each), then the segments (4 words each), then excl
+  tab.reserve(10 * n_zones + excl.size());
+  uint64_t Z = C + 1;
+  for (const Keep& kp : keep) {
+    // (m + k characters of context: the scan starts fresh behind the separator, exact from the first kept position on)
+    const uint64_t a = kp.lo - 1 > C ? kp.lo - 1 - C : 0;
+    tab.insert(tab.end(), {(unsigned long long)Z, (unsigned long long)a, (unsigned long long)kp.lo, (unsigned long long)kp.hi,
+                           kp.cont ? 1ull : 0ull, 0ull});
+    Z += (kp.hi - a) + C + 1;
+  }
+  // (the tiled scan of the zones at 3.8e10 character x group of 64 patterns per second: at most ~0.2 s of it)
+  if (dbg) fprintf(stderr, "[zones] %zu zones, %llu bytes\n", n_zones, (unsigned long long)Z);
+  if (Z > (1ull << 30) || (double)Z * (double)((e->patterns.size() + 63) / 64) > 8e9) return 0;
+  const size_t seg_at = tab.size();
+  for (size_t z = 0; z < n_zones; ++z)
+    tab.insert(tab.end(), {tab[6 * z + 1], tab[6 * z], tab[6 * z + 3] - tab[6 * z + 1], 0ull});
+  const size_t excl_at = tab.size();
+  tab.insert(tab.end(), excl.begin(), excl.end());
+  if (int rc = s->d_zone_tab.reserve(tab.size() + 8)) return rc;
+  if (int rc = s->d_zone_text.reserve(Z + 128)) return rc;
+  HIP_TRY(hipMemcpyAsync(s->d_zone_tab.p, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemsetAsync(s->d_zone_text.p, 'X', Z + 64, st));
+  le = launch_gather_zones(tptr, s->d_zone_text.p, s->d_zone_tab.p + seg_at, (uint32_t)n_zones, st);
+  if (le != hipSuccess) return hip_fail(le, "zone gather launch");
+  // ---- the neighbourhoods through the pattern-tiled scan ----
+  uint32_t zc = 0;
+  uint64_t waves = 0;
+  bool zok = n_zones == 0;
+  if (n_zones)
+    if (int rc = tiled_scan_list(s, e, s->d_zone_text.p, Z, k, 16u, s->d_zone_peq, s->d_zone_list, d_cnt + 4, &zc, &zok, &waves))
+      return rc;
+  if (dbg) fprintf(stderr, "[zones] tiled scan ok=%d records %u\n", (int)zok, zc);
+  if (!zok) return 0;
+  // ---- the seeded pass's records outside the zones' intervals, then the zones' records behind them ----
+  const uint32_t have = *list_count;
+  uint32_t kept = 0;
+  if (have) {
+    if (int rc = L.d_sorted.reserve(have)) return rc;
+    if (int rc = L.d_sort.reserve(select_scratch_bytes(have))) return rc;
+    const size_t flag_bytes = ((size_t)have + 255) / 256 * 256;
+    unsigned char* d_keep = L.d_sort.p;
+    le = launch_drop_excluded(s->d_tiled_list.p, have, s->d_zone_tab.p + excl_at, (uint32_t)(excl.size() / 2), d_keep, st);
+    if (le != hipSuccess) return hip_fail(le, "record filter launch");
+    le = launch_compact_candidates(s->d_tiled_list.p, have, d_keep, L.d_sorted.p, d_cnt + 5, L.d_sort.p + flag_bytes,
+                                   L.d_sort.cap - flag_bytes, st);
+    if (le != hipSuccess) return hip_fail(le, "record compaction launch");
+    HIP_TRY(hipMemcpyAsync(&kept, d_cnt + 5, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  } else {
+    HIP_TRY(hipStreamSynchronize(st));  // (`tab` goes out of scope)
+  }
+  if ((uint64_t)kept + zc > (1ull << 28) + (1ull << 27)) return 0;
+  if (int rc = s->d_tiled_list.reserve((size_t)kept + zc + 1024)) return rc;  // (may move the buffer: its records are in d_sorted)
+  if (kept) HIP_TRY(hipMemcpyAsync(s->d_tiled_list.p, L.d_sorted.p, (size_t)kept * sizeof(Candidate), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipMemcpyAsync(d_cnt + 5, &kept, 4, hipMemcpyHostToDevice, st));
+  le = launch_map_zone_list(s->d_zone_list.p, zc, s->d_zone_tab.p, (uint32_t)n_zones, s->d_tiled_list.p, d_cnt + 5,
+                            (uint32_t)std::min<size_t>(s->d_tiled_list.cap, 0xFFFFFFFFu), st);
+  if (le != hipSuccess) return hip_fail(le, "zone record mapping launch");
+  uint32_t total = kept;
+  HIP_TRY(hipMemcpyAsync(&total, d_cnt + 5, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *list_count = total;
+  s->stats.cond_resolved += n_zones;  // (here: neighbourhoods of other letters that went through the tiled scan)
+  *ok = true;
+  return 0;
 }
 
 // search_encoded_patterns for many patterns over a long text: seed -> verify -> report (seed_kernels.hip).  One
@@ -2465,7 +2646,7 @@ static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* 
 static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
                                  const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
                                  sassy_hip_Result* R, bool* done, const TextTable* tt = nullptr,
-                                 const HostTexts* ht = nullptr) {
+                                 const HostTexts* ht = nullptr, bool dirty_text = false) {
   *done = false;
   hipStream_t st = s->stream;
   const size_t npat = e->patterns.size();
@@ -2679,6 +2860,11 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     s->stats.scan_launches += 1;
     if (out_count <= SP.out_cap) break;
     if (out_count > kMaxList || attempt == 2) return 0;  // *done stays false
+  }
+  if (dirty_text) {  // other letters than ACGT in the text: their neighbourhoods come from the pattern-tiled scan
+    bool zones_ok = false;
+    if (int rc = seeded_dirty_zones(s, e, tptr, text_len, k, all, &out_count, &zones_ok)) return rc;
+    if (!zones_ok) return 0;  // *done stays false
   }
   s->stats.text_bytes += text_len;
   s->stats.chunks += waves;
@@ -3676,7 +3862,7 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
   } pguard{s, s->profile};
   // (patterns with ambiguity letters -- guides with their NGG -- stay Iupac, but on a plain text the seeded search
   // takes them too: its seeds and masks are built from the letters' base sets)
-  bool text_plain = false;
+  bool text_plain = false, text_checked = false;
   if (s->profile == PROFILE_IUPAC && std::isnan(s->alpha) && e->patterns.size() >= 4 && text_len >= 16 &&
       ((uintptr_t)tptr & 15) == 0) {
     bool plain = true;
@@ -3690,6 +3876,7 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
       HIP_TRY(hipMemcpyAsync(&bad, s->d_ncount.p, 4, hipMemcpyDeviceToHost, s->stream));
       HIP_TRY(hipStreamSynchronize(s->stream));
       text_plain = !bad;
+      text_checked = true;
       if (plain && text_plain) s->profile = PROFILE_DNA;
     }
   }
@@ -3736,7 +3923,12 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
     // 17 for the pattern-tiled scan (SASSY_HIP_SEEDED=0 / 1 forces the choice).
     const int env_seeded = getenv("SASSY_HIP_SEEDED") ? atoi(getenv("SASSY_HIP_SEEDED")) : -1;
     bool seeded = false;
-    if ((s->profile == PROFILE_DNA || (s->profile == PROFILE_IUPAC && text_plain)) && std::isnan(s->alpha) && k + 1 <= 8 &&
+    // (an Iupac searcher's text with other letters: the seeded search plus the pattern-tiled scan around those letters,
+    // search_encoded_seeded / seeded_dirty_zones; SASSY_HIP_SEEDED_DIRTY=0: not for such texts)
+    static const bool env_dirty = !(getenv("SASSY_HIP_SEEDED_DIRTY") && atoi(getenv("SASSY_HIP_SEEDED_DIRTY")) == 0);
+    const bool dirty_text = s->profile == PROFILE_IUPAC && text_checked && !text_plain;
+    if ((s->profile == PROFILE_DNA || (s->profile == PROFILE_IUPAC && text_checked && (text_plain || env_dirty))) &&
+        std::isnan(s->alpha) && k + 1 <= 8 &&
         e->plen / (k + 1) >= 5 &&
         e->plen + 3 * k + 1 <= 4 * kSeedWindowDwords && e->patterns.size() < (1u << 24) && text_len < (1ull << 36) &&
         (((uintptr_t)tptr) & 15) == 0) {
@@ -3746,7 +3938,8 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
     }
     bool tiled_done = false;
     if (seeded) {
-      if (int rc = search_encoded_seeded(s, e, tptr, h_text, text_len, (uint32_t)k, all, wo, R, &tiled_done)) return rc;
+      if (int rc = search_encoded_seeded(s, e, tptr, h_text, text_len, (uint32_t)k, all, wo, R, &tiled_done, nullptr, nullptr,
+                                         dirty_text)) return rc;
       if (tiled_done) tiled = false;
     }
     if (tiled && !tiled_done)

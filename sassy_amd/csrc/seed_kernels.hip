@@ -348,6 +348,146 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
   }
 }
 
+// ---------------------------------------------------------------- texts with other letters than ACGT (Iupac searcher)
+// The seeded search reads Dna codes, so it is exact only where the m + k characters in front of an end position are
+// plain.  Around every run of other letters ("dirty": N, R, Y, ..., non-letters) the end positions are computed by
+// the pattern-tiled scan on a gathered copy of those neighbourhoods instead (host.hip: search_encoded_seeded):
+//   dirty_scan_kernel      finds the runs: their first positions, their end positions, and the positions of dirty
+//                          letters that are not full wildcards (a run of full wildcards -- N, non-letters -- longer
+//                          than m + 1 is cut out of the gathered copy: every pattern's cost is constant inside);
+//   gather_zones_kernel    copies the neighbourhoods ("zones") into one buffer, 'X' separators between them;
+//   map_zone_list_kernel   turns the tiled scan's (pattern, position in the zone buffer, cost) records into text
+//                          positions, keeps those a zone is responsible for and marks the last one in front of a
+//                          cut-out stretch (kCandCont);
+//   drop_excluded_kernel   flags the seeded search's records that lie where a zone is responsible.
+namespace {
+__device__ __forceinline__ bool dirty_byte(uint32_t c) {
+  const uint32_t u = c & 0xDFu;
+  return !(u == 'A' || u == 'C' || u == 'G' || u == 'T');
+}
+// dirty letters that do not match every base.  The Iupac profile looks a text byte up by its five low bits
+// (src/profiles/iupac.rs:281-330): 15 = every base (N, and every byte whose low bits are no IUPAC letter's),
+// anything else a proper subset -- also for bytes that are no letters ('-' reads as M).
+__device__ __forceinline__ bool hard_byte(uint32_t c) {
+  // bit i = the letter with low bits i stands for a proper subset: A B C D G H K M R S T U V W X Y
+  constexpr uint32_t kProper = (1u << 1) | (1u << 2) | (1u << 3) | (1u << 4) | (1u << 7) | (1u << 8) | (1u << 11) | (1u << 13) |
+                               (1u << 18) | (1u << 19) | (1u << 20) | (1u << 21) | (1u << 22) | (1u << 23) | (1u << 24) | (1u << 25);
+  return (kProper >> (c & 31u)) & 1u;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void dirty_scan_kernel(const uint8_t* __restrict__ text, uint64_t n,
+                                                         unsigned long long* __restrict__ starts,
+                                                         unsigned long long* __restrict__ ends,
+                                                         unsigned long long* __restrict__ hard, uint32_t cap,
+                                                         uint32_t* __restrict__ counts) {
+  const uint64_t n16 = (n + 15) / 16;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint4 v = reinterpret_cast<const uint4*>(text)[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t bad = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const uint32_t sel = (w[d] >> 1) & 0x03030303u;
+      bad |= (w[d] & 0xDFDFDFDFu) ^ __builtin_amdgcn_perm(0u, 0x47544341u, sel);  // (as acgt_check_kernel)
+    }
+    if (!bad) continue;  // sixteen plain characters (a run cannot start or end inside: their neighbours see to it)
+    for (uint32_t j = 0; j < 16; ++j) {
+      const uint64_t x = i * 16 + j;
+      if (x >= n) break;
+      const uint32_t c = (w[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+      if (!dirty_byte(c)) continue;
+      const bool prev_dirty = x > 0 && dirty_byte(text[x - 1]);
+      const bool next_dirty = x + 1 < n && dirty_byte(text[x + 1]);
+      if (!prev_dirty) { const uint32_t k = atomicAdd(counts + 0, 1u); if (k < cap) starts[k] = x; }
+      if (!next_dirty) { const uint32_t k = atomicAdd(counts + 1, 1u); if (k < cap) ends[k] = x + 1; }
+      if (hard_byte(c)) { const uint32_t k = atomicAdd(counts + 2, 1u); if (k < cap) hard[k] = x; }
+    }
+  }
+}
+
+// seg[4 g .. 4 g + 3] = source offset in the text, destination offset in the zone buffer, length, unused; the bytes
+// the segments do not cover (the separators) are filled by the caller.
+__global__ __launch_bounds__(256) void gather_zones_kernel(const uint8_t* __restrict__ text, uint8_t* __restrict__ dst,
+                                                           const unsigned long long* __restrict__ seg, uint32_t n_seg) {
+  for (uint32_t g = blockIdx.y; g < n_seg; g += gridDim.y) {
+    const unsigned long long src = seg[4 * g], to = seg[4 * g + 1], len = seg[4 * g + 2];
+    for (uint64_t x = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; x < len; x += (uint64_t)gridDim.x * blockDim.x)
+      dst[to + x] = text[src + x];
+  }
+}
+
+// zone[6 z .. 6 z + 5] = first byte of the zone in the zone buffer, text position of that byte, first and last end
+// position (in the text) the zone is responsible for, 1 if a cut-out stretch follows the last one, unused.  Sorted by
+// the first field.
+__global__ __launch_bounds__(256) void map_zone_list_kernel(const Candidate* __restrict__ in, uint32_t count,
+                                                            const unsigned long long* __restrict__ zone, uint32_t n_zones,
+                                                            Candidate* __restrict__ out, uint32_t* __restrict__ out_count,
+                                                            uint32_t out_cap) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const Candidate c = in[i];
+  if (c.pos == 0) return;
+  uint32_t lo = 0, hi = n_zones;  // the zone whose bytes hold character c.pos - 1: largest z with dst[z] <= c.pos - 1
+  while (lo + 1 < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (zone[6 * mid] <= c.pos - 1) lo = mid; else hi = mid;
+  }
+  if (zone[6 * lo] > c.pos - 1) return;  // in the separator in front of the first zone
+  const unsigned long long p = zone[6 * lo + 1] + (c.pos - zone[6 * lo]);  // end position in the text
+  if (p < zone[6 * lo + 2] || p > zone[6 * lo + 3]) return;                 // context, or the separator behind the zone
+  const uint32_t k = atomicAdd(out_count, 1u);
+  if (k < out_cap) out[k] = Candidate{p, c.cost, c.flags | ((p == zone[6 * lo + 3] && zone[6 * lo + 4]) ? kCandCont : 0u)};
+}
+
+// excl[2 x], excl[2 x + 1]: first and last end position of an interval where the zones are responsible (sorted,
+// disjoint).  keep[i] = 0 for the records inside one.
+__global__ __launch_bounds__(256) void drop_excluded_kernel(const Candidate* __restrict__ in, uint32_t count,
+                                                            const unsigned long long* __restrict__ excl, uint32_t n_excl,
+                                                            unsigned char* __restrict__ keep) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const unsigned long long p = in[i].pos;
+  uint32_t lo = 0, hi = n_excl;
+  bool inside = false;
+  if (n_excl && excl[0] <= p) {
+    while (lo + 1 < hi) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (excl[2 * mid] <= p) lo = mid; else hi = mid;
+    }
+    inside = p <= excl[2 * lo + 1];
+  }
+  keep[i] = inside ? 0 : 1;
+}
+
+hipError_t launch_dirty_scan(const uint8_t* d_text, uint64_t n, unsigned long long* d_starts, unsigned long long* d_ends,
+                             unsigned long long* d_hard, uint32_t cap, uint32_t* d_counts, hipStream_t stream) {
+  if (n == 0) return hipSuccess;
+  const uint64_t n16 = (n + 15) / 16;
+  hipLaunchKernelGGL(dirty_scan_kernel, dim3((uint32_t)std::min<uint64_t>(8192, (n16 + 255) / 256)), dim3(256), 0, stream,
+                     d_text, n, d_starts, d_ends, d_hard, cap, d_counts);
+  return hipGetLastError();
+}
+hipError_t launch_gather_zones(const uint8_t* d_text, uint8_t* d_dst, const unsigned long long* d_seg, uint32_t n_seg,
+                               hipStream_t stream) {
+  if (n_seg == 0) return hipSuccess;
+  hipLaunchKernelGGL(gather_zones_kernel, dim3(8, std::min<uint32_t>(n_seg, 4096)), dim3(256), 0, stream, d_text, d_dst, d_seg, n_seg);
+  return hipGetLastError();
+}
+hipError_t launch_map_zone_list(const Candidate* d_in, uint32_t count, const unsigned long long* d_zone, uint32_t n_zones,
+                                Candidate* d_out, uint32_t* d_out_count, uint32_t out_cap, hipStream_t stream) {
+  if (count == 0 || n_zones == 0) return hipSuccess;
+  hipLaunchKernelGGL(map_zone_list_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_in, count, d_zone, n_zones, d_out,
+                     d_out_count, out_cap);
+  return hipGetLastError();
+}
+hipError_t launch_drop_excluded(const Candidate* d_in, uint32_t count, const unsigned long long* d_excl, uint32_t n_excl,
+                                unsigned char* d_keep, hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(drop_excluded_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_in, count, d_excl, n_excl, d_keep);
+  return hipGetLastError();
+}
+
 // packed[0 .. ceil(n / 16)) = the text's Dna codes (the caller pads the buffer with 4 more dwords)
 hipError_t launch_pack_text(const uint8_t* d_text, uint64_t n, uint32_t* d_packed, hipStream_t stream) {
   const uint64_t n16 = (n + 15) / 16;

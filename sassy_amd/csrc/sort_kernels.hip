@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void flag_reports_kernel(const Candidate* __re
     const Candidate pv = c[i - 1];
     if ((pv.flags >> kCandTextShift) == tag && pv.pos == me.pos) report = false;  // a copy
   }
+  if (me.flags & kCandCont) report = all_minima != 0;  // its plateau goes on over positions the list leaves out
   if (report && !all_minima) {
     for (uint32_t j = i + 1; j < count; ++j) {  // the next distinct entry
       const Candidate nx = c[j];
@@ -135,6 +136,13 @@ hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Cand
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   return rocprim::select(temp, temp_bytes, d_sorted, keep, d_sel, d_sel_count, (size_t)count, stream);
+}
+
+// out[0 .. *out_count) = the records of in[0 .. count) whose keep byte is set, order kept (scratch: select_scratch_bytes).
+hipError_t launch_compact_candidates(const Candidate* d_in, uint32_t count, const unsigned char* d_keep, Candidate* d_out,
+                                     uint32_t* d_out_count, void* d_scratch, size_t scratch_bytes, hipStream_t stream) {
+  if (count == 0) return hipMemsetAsync(d_out_count, 0, 4, stream);
+  return rocprim::select(d_scratch, scratch_bytes, d_in, d_keep, d_out, d_out_count, (size_t)count, stream);
 }
 
 hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable& texts, uint32_t* d_report_text,

@@ -948,6 +948,46 @@ def test_encoded_seeded(sassy):
             want = oracle.search_encoded("iupac", pats, tb, k, rc=rc)
             assert sorted(key(x) for x in got) == sorted(key(x) for x in want), (m, k, npat, rc, len(got), len(want))
             assert len(want) >= 10
+    # texts with other letters than ACGT (Iupac searcher): the seeded pass is exact where the window in front of an
+    # end position is plain; around every run of other letters the pattern-tiled scan fills in, and a long run of N
+    # is left out of its copy (every cost is constant inside) -- runs of all lengths around that threshold
+    # m + 2, at both ends of the text, close to each other, with a letter inside that is not a wildcard
+    for (m, k, npat, allm) in [(20, 2, 60, False), (23, 3, 40, False), (20, 2, 30, True), (32, 3, 25, False)]:
+        C = m + k
+        pats = [bytes(rng.choice(b"ACGT") for _ in range(m)) for _ in range(npat)]
+        pats[0] = pats[0][:4] + b"N" + pats[0][5:]
+        pats[1] = pats[1][:9] + b"X" + pats[1][10:]
+        n = 40_000
+        text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+        for p in pats:
+            conc = bytes(c if c in b"ACGT" else 65 for c in p)
+            for _ in range(3):
+                ins = mutate(rng, conc, rng.randrange(0, k + 1))
+                at = rng.randrange(0, n - len(ins))
+                text[at:at + len(ins)] = ins
+        at = 0
+        for ln in [5, 1, m, m + 1, m + 2, m + 3, 2 * C + 2, 3 * C, 500, 4000, 7, m + 2]:
+            text[at:at + ln] = b"N" * ln
+            at += ln + rng.choice([1, 3, C - 1, C, C + 1, 2 * C, 900, 2500])
+        text[at + 100:at + 100 + 300] = b"N" * 300
+        text[at + 250] = ord("R")            # not a wildcard: this run is copied whole
+        for _ in range(40):
+            text[rng.randrange(n)] = rng.choice(b"NRYKMSWn-*x")
+        text[n - 3 * C:] = b"N" * (3 * C)    # the text ends inside a run
+        for p in pats[:10]:                  # matches that lean into runs
+            conc = bytes(c if c in b"ACGT" else 65 for c in p)
+            i = bytes(text).find(b"N" * 50)
+            text[i - m // 2:i] = conc[:m // 2]
+        tb = bytes(text)
+        for rc in (False, True):
+            s = sassy.Searcher("iupac", rc=rc)
+            enc = s.encode_patterns(pats)
+            got = s.search_encoded_patterns(enc, tb, k, all_minima=allm)
+            st = s.stats()
+            assert st["filtered"] == 6 and st["cond_resolved"] >= 10, (m, k, st)
+            want = oracle.search_encoded("iupac", pats, tb, k, rc=rc, all_minima=allm)
+            assert sorted(key(x) for x in got) == sorted(key(x) for x in want), (m, k, npat, rc, allm, len(got), len(want))
+            assert len(want) >= 100
     # a text of one repeated unit: every position hits the seed tables of the patterns cut from it; the candidate
     # list overflows its expectation-sized capacity and the segments are cut smaller
     unit = bytes(rng.choice(b"ACGT") for _ in range(37))

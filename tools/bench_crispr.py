@@ -22,11 +22,17 @@ def main():
     ap.add_argument("--guides", type=int, default=312)
     ap.add_argument("--text-bytes", type=int, default=3_000_000_000)
     ap.add_argument("--k", type=int, default=3)
+    ap.add_argument("--genome-like", action="store_true",
+                    help="repeat-rich text with runs of N and scattered IUPAC letters (generate_genome_like) instead of "
+                         "i.i.d. ACGT: the seeded search runs with the pattern-tiled scan around the other letters")
     args = ap.parse_args()
     rng = random.Random(11)
     n = args.text_bytes
     buf = sassy_amd.DeviceBuffer(n + 4096)
-    sassy_amd.generate_dna(buf.ptr, n, 42, 0)
+    if args.genome_like:
+        sassy_amd.generate_genome_like(buf.ptr, n, 42, 0, with_n=True)
+    else:
+        sassy_amd.generate_dna(buf.ptr, n, 42, 0)
     pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) + b"NGG" for _ in range(args.guides)]
     for rc in (False, True):
         s = sassy_amd.Searcher("iupac", rc=rc)
@@ -39,10 +45,12 @@ def main():
         st = s.stats()
         npat = len(pats) * (2 if rc else 1)
         print(json.dumps({"workload": f"{args.guides} guides (20 bases + NGG), k={args.k}, Iupac searcher, "
-                                      f"{'both strands' if rc else 'forward strand'}, {n} B random ACGT resident in HBM",
+                                      f"{'both strands' if rc else 'forward strand'}, {n} B "
+                                      f"{'genome-like text with N runs' if args.genome_like else 'random ACGT'} resident in HBM",
                           "seconds": round(min(secs), 4), "seconds_each_call": [round(x, 4) for x in secs],
                           "pattern_text_GB_per_s": round(n * npat / min(secs) / 1e9, 1), "matches": len(r),
                           "path": st["filtered"], "table_hits": st["hit_blocks"], "verified": st["live_blocks"],
+                          "zones": st["cond_resolved"],
                           "kernel_ms": round(st["scan_ms"], 2)}), flush=True)
 
 
