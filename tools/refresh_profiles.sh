@@ -47,6 +47,7 @@ cp gpurun_out/prof_cfg10k/summary.txt $OUT/${TAG}_config4_seeded_prof.txt
 cp $(ls gpurun_out/prof_cfg10k/trace/*kernel_stats.csv gpurun_out/prof_cfg10k/trace/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_config4_seeded_kernel_stats.csv
 python tools/bench_encoded.py > $OUT/${TAG}_encoded_paths.txt 2> $OUT/encoded.err
 python tools/bench_crispr.py > $OUT/${TAG}_crispr.json 2> $OUT/crispr.err
+python tools/bench_crispr.py --genome-like >> $OUT/${TAG}_crispr.json 2>> $OUT/crispr.err
 python tools/bench_texts.py > $OUT/${TAG}_texts.json 2> $OUT/texts.err
 { python tools/bench_reads.py; python tools/bench_reads.py --reads 330000; python tools/bench_reads.py --overhang 0.5; } > $OUT/${TAG}_reads.json 2> $OUT/reads.err
 { python tools/probe_count.py; python tools/probe_rc.py; } > $OUT/${TAG}_shapes.json 2> $OUT/shapes.err
