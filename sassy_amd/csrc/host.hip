@@ -2687,6 +2687,20 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
       for (uint32_t pc = 0; pc < pieces; ++pc) {
         if (tab_of[pc] != (uint32_t)t) continue;
         const uint8_t* src = e->patterns[p].data() + p_end[pc] - p_len[pc];
+        {  // the common case, every letter one base: one code, no lists
+          uint32_t code = 0;
+          bool concrete = true;
+          for (uint32_t x = 0; x < p_len[pc] && concrete; ++x) {
+            const uint32_t set = base_set(src[x]);
+            concrete = set && !(set & (set - 1));
+            code |= (set == 1 ? 0u : set == 2 ? 1u : set == 4 ? 2u : 3u) << (2 * x);
+          }
+          if (concrete) {
+            code_entry.emplace_back(code, (uint32_t)(p << 3) | pc);
+            start[t][code + 1]++;
+            continue;
+          }
+        }
         codes.assign(1, 0u);
         for (uint32_t x = 0; x < p_len[pc]; ++x) {
           const uint32_t set = base_set(src[x]);
@@ -2715,12 +2729,19 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   for (size_t p = 0; p < npat; ++p) {
     const uint8_t* pt = e->patterns[p].data();
     memcpy(&flat[p * m], pt, m);
+    uint32_t* peq32 = reinterpret_cast<uint32_t*>(peq.data());
     for (uint32_t j = 0; j < m; ++j) {
+      if (!iupac_pats) {  // one base per letter: its Dna code
+        const uint32_t c = (pt[j] >> 1) & 3u;
+        if (wide) peq[p * 4 + c] |= 1ull << j;
+        else peq32[p * 4 + c] |= 1u << j;
+        continue;
+      }
       const uint32_t set = base_set(pt[j]);
       for (uint32_t c = 0; c < 4; ++c) {
         if (!(set & (1u << c))) continue;
         if (wide) peq[p * 4 + c] |= 1ull << j;
-        else reinterpret_cast<uint32_t*>(peq.data())[p * 4 + c] |= 1u << j;
+        else peq32[p * 4 + c] |= 1u << j;
       }
     }
   }
@@ -2800,6 +2821,10 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     std::vector<unsigned long long> ppk(npat * (iupac_pats ? 2 : 1), 0ull);
     for (size_t p = 0; p < npat; ++p)
       for (uint32_t j = 0; j < m; ++j) {
+        if (!iupac_pats) {
+          ppk[p] |= (unsigned long long)((e->patterns[p][j] >> 1) & 3u) << (2 * j);
+          continue;
+        }
         const uint32_t set = base_set(e->patterns[p][j]);
         const bool one = set && !(set & (set - 1));
         const uint32_t code = one ? (set == 1 ? 0u : set == 2 ? 1u : set == 4 ? 2u : 3u) : 0u;
