@@ -173,6 +173,7 @@ struct TiledParams {
   Candidate* cand;                // {pos, cost, flags = pattern << kCandTextShift}
   uint32_t* cand_count;
   uint32_t cand_cap;
+  const uint32_t* keep_bits;      // optional: bit p = end position p is wanted (others are computed, not listed)
 };
 
 // The seeded search of many patterns over a long text (seed_kernels.hip).

@@ -2382,7 +2382,7 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
 // 16 (Iupac base sets; 'X' matches nothing).
 static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* buf, uint64_t len, uint32_t k,
                            uint32_t classes, DevBuf<unsigned long long>& d_peq, DevBuf<Candidate>& list, uint32_t* d_count,
-                           uint32_t* count, bool* ok, uint64_t* n_waves) {
+                           uint32_t* count, bool* ok, uint64_t* n_waves, const uint32_t* d_keep_bits = nullptr) {
   *ok = false;
   *count = 0;
   const size_t npat = e->patterns.size();
@@ -2418,6 +2418,7 @@ static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, co
   P.k = k;
   P.classes = classes;
   P.warm_blocks = (m + k + 63) / 64;
+  P.keep_bits = d_keep_bits;
   {
     const uint64_t span = (uint64_t)P.skew + len;
     const uint64_t waves_wanted = 16384;
@@ -2596,12 +2597,21 @@ static int seeded_dirty_zones(sassy_SearcherType* s, const sassy_hip_Encoded* e,
   HIP_TRY(hipMemsetAsync(s->d_zone_text.p, 'X', Z + 64, st));
   le = launch_gather_zones(tptr, s->d_zone_text.p, s->d_zone_tab.p + seg_at, (uint32_t)n_zones, st);
   if (le != hipSuccess) return hip_fail(le, "zone gather launch");
+  // (one bit per end position of the zone buffer: only the positions a zone is responsible for are listed)
+  std::vector<uint32_t> bits((size_t)(Z + 64) / 32 + 2, 0u);
+  for (size_t z = 0; z < n_zones; ++z) {
+    const uint64_t q0 = tab[6 * z] + (tab[6 * z + 2] - tab[6 * z + 1]), q1 = tab[6 * z] + (tab[6 * z + 3] - tab[6 * z + 1]);
+    for (uint64_t q = q0; q <= q1; ++q) bits[q >> 5] |= 1u << (q & 31);
+  }
+  if (int rc = s->d_seed_packed.reserve(bits.size())) return rc;  // (free here: the seeded pass is over)
+  HIP_TRY(hipMemcpyAsync(s->d_seed_packed.p, bits.data(), bits.size() * 4, hipMemcpyHostToDevice, st));
   // ---- the neighbourhoods through the pattern-tiled scan ----
   uint32_t zc = 0;
   uint64_t waves = 0;
   bool zok = n_zones == 0;
   if (n_zones)
-    if (int rc = tiled_scan_list(s, e, s->d_zone_text.p, Z, k, 16u, s->d_zone_peq, s->d_zone_list, d_cnt + 4, &zc, &zok, &waves))
+    if (int rc = tiled_scan_list(s, e, s->d_zone_text.p, Z, k, 16u, s->d_zone_peq, s->d_zone_list, d_cnt + 4, &zc, &zok, &waves,
+                                 s->d_seed_packed.p))
       return rc;
   if (dbg) fprintf(stderr, "[zones] tiled scan ok=%d records %u\n", (int)zok, zc);
   if (!zok) return 0;
@@ -4049,14 +4059,23 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
   // sorts by this key before comparing (pattern_tiling/search.rs:748-757).
   if (R->pool.empty()) R->pool.push_back('\0');
   const char* pool = R->pool.c_str();
-  std::sort(R->matches.begin(), R->matches.end(), [pool](const sassy_hip_Match& a, const sassy_hip_Match& b) {
+  auto before = [pool](const sassy_hip_Match& a, const sassy_hip_Match& b) {
     if (a.pattern_idx != b.pattern_idx) return a.pattern_idx < b.pattern_idx;
     if (a.text_start != b.text_start) return a.text_start < b.text_start;
     if (a.text_end != b.text_end) return a.text_end < b.text_end;
     if (a.cost != b.cost) return a.cost < b.cost;
     if (a.strand != b.strand) return a.strand < b.strand;
     return strcmp(pool + a.cigar_off, pool + b.cigar_off) < 0;
-  });
+  };
+  // (the one-pass paths deliver the records pattern by pattern in position order, the Rc strand's behind the forward
+  // strand's: already in this order, or two runs that are -- one linear merge instead of a sort of millions of records)
+  {
+    auto mid = std::is_sorted_until(R->matches.begin(), R->matches.end(), before);
+    if (mid != R->matches.end()) {
+      if (std::is_sorted(mid, R->matches.end(), before)) std::inplace_merge(R->matches.begin(), mid, R->matches.end(), before);
+      else std::sort(R->matches.begin(), R->matches.end(), before);
+    }
+  }
   guard.release();
   s->stats.total_ms = now_ms() - t0;
   s->stats.host_post_ms = s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms;

@@ -33,6 +33,7 @@ __constant__ uint8_t kTiledIupacNib[32] = {
     15, 15, 9, 10, 4, 4, 11, 5, 0, 6, 15, 15, 15, 15, 15, 15};
 
 __device__ __forceinline__ void tiled_emit(const TiledParams& P, uint64_t pos, int cost, uint32_t pat) {
+  if (P.keep_bits && !((P.keep_bits[pos >> 5] >> (pos & 31u)) & 1u)) return;  // (a gathered buffer: context, separators)
   const uint32_t idx = atomicAdd(P.cand_count, 1u);
   if (idx < P.cand_cap) P.cand[idx] = Candidate{pos, cost, pat << kCandTextShift};
 }
