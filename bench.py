@@ -142,8 +142,9 @@ def main():
                          "geometry tuner settles within 36 searches); the default run has none")
     ap.add_argument("--cpu-seconds", type=float, default=2.0,
                     help="wall seconds the CPU baseline's threads keep scanning (at least one pass)")
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="searches in flight on the device (1 = every search alone: begin, wait, next)")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="searches in flight on the device (1 = every search alone: begin, wait, next; 3 measured best: "
+                         "profiles/r02_in_flight.txt)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short runs of BASELINE configs 3 and 4 on the resident text (N = 1, after the timed steps)")
     ap.add_argument("--allow-shared-gpu", action="store_true",
@@ -218,7 +219,7 @@ def main():
         gather_worker = multigpu.GatherWorker(multigpu.MatchGather(
             torch, dist, coll_device, capacity_rows=1024, cigar_bytes=multigpu.cigar_bytes_for(m, k)))
 
-    # A stream of searches over the resident text keeps `--in-flight` (default 2) of them in flight on the
+    # A stream of searches over the resident text keeps `--in-flight` (default 3) of them in flight on the
     # device (include/sassy_hip.h: sassy_hip_search_shard_begin / sassy_hip_search_finish): step i queues
     # search i and then waits for search i-1, whose chunk DP / traceback tail ran underneath search i's
     # prefilter.  Every step is one complete search with its Match records on the host; all K searches of
