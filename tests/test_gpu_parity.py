@@ -1438,6 +1438,8 @@ def test_config4_full_size_10000_patterns_against_the_oracle(sassy):
     sub = pats[:600]
     enc2 = s.encode_patterns(sub)
     r2 = s.search_encoded_patterns(enc2, _DevText(buf.ptr, n), k, as_result=True)
+    st2 = s.stats()  # (the seeded search again, with the pattern-tiled scan around the 40 patches of other letters)
+    assert st2["filtered"] == 6 and 20 <= st2["cond_resolved"] <= 80, st2
     arr2, pool2 = r2.array, r2.pool
     pidx2 = arr2["pattern_idx"].astype(np.int64)
     first2 = np.searchsorted(pidx2, np.arange(len(sub) + 1))
