@@ -73,7 +73,8 @@ typedef struct sassy_hip_Stats {
   double filter_ms;      /* HIP-event time of the prefilter kernel (part of scan_ms) */
   uint64_t hit_blocks;   /* text blocks in which an exact pattern piece ends */
   uint32_t piece_len;    /* rows per pattern piece (k+1 pieces) / q-gram length Q (filtered = 4), 0 when unfiltered */
-  uint32_t pad_;
+  uint32_t fused;        /* 1: the bit-plane prefilter ran the chunk DP of what it found itself (one launch for
+                            filter + chunk list + DP; sassy_hip_set_fused) */
   double host_enqueue_ms; /* host wall time spent queueing work on the stream */
   double host_wait_ms;    /* host wall time blocked in the stream synchronisation */
   double host_post_ms;    /* host wall time after it: sort, seams, cigar strings, result records */
@@ -103,6 +104,11 @@ int sassy_hip_set_timing(sassy_SearcherType *s, int level);
  * DP over every block, 1 = prefilter also with short pieces.  All give the same matches; the setting exists so
  * that the paths can be checked against each other (tests) and timed apart. */
 int sassy_hip_set_prefilter(sassy_SearcherType *s, int mode);
+/* The bit-plane prefilter (Dna, <= 8 pieces, one strand, one text) can finish the scan in its own launch: every
+ * wavefront runs the chunk DP over the match-end blocks it found itself when it has streamed its text range
+ * (no hit bitmap, no chunk-list kernel, no list kernel).  on = 1 (default; process-wide: SASSY_HIP_FUSED=0 turns it
+ * off), 0 = always the classic chain.  Same matches either way; stats.fused tells which one ran. */
+int sassy_hip_set_fused(sassy_SearcherType *s, int on);
 /* Which reports a search of ONE text returns on low-complexity text (sassy_hip_search, the drop-in search):
  * 0 (default) = the definition -- one left-to-right pass over the text, independent of any chunking;
  * 4 / 8 = what the reference binary built for AVX2 / AVX-512 returns: it cuts the text into 4 / 8 lanes that each

@@ -89,7 +89,7 @@ class Stats(C.Structure):
         ("filter_ms", C.c_double),
         ("hit_blocks", C.c_uint64),
         ("piece_len", C.c_uint32),
-        ("pad_", C.c_uint32),
+        ("fused", C.c_uint32),
         ("host_enqueue_ms", C.c_double),
         ("host_wait_ms", C.c_double),
         ("host_post_ms", C.c_double),
@@ -110,7 +110,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_result_len", "sassy_hip_result_matches", "sassy_hip_result_cigars",
     "sassy_hip_result_cigars_len", "sassy_hip_pack_rows", "sassy_hip_enable_counters", "sassy_hip_set_timing",
     "sassy_hip_set_only_best_match", "sassy_hip_set_max_n_frac", "sassy_hip_search_with_fn",
-    "sassy_hip_set_max_overhang", "sassy_hip_set_prefilter",
+    "sassy_hip_set_max_overhang", "sassy_hip_set_prefilter", "sassy_hip_set_fused",
     "sassy_hip_search_many", "sassy_hip_tsv_header", "sassy_hip_format_tsv",
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
@@ -159,6 +159,8 @@ def lib():
     L.sassy_hip_set_timing.argtypes = [vp, C.c_int]
     L.sassy_hip_set_prefilter.restype = C.c_int
     L.sassy_hip_set_prefilter.argtypes = [vp, C.c_int]
+    L.sassy_hip_set_fused.restype = C.c_int
+    L.sassy_hip_set_fused.argtypes = [vp, C.c_int]
     L.sassy_hip_set_only_best_match.restype = C.c_int
     L.sassy_hip_set_only_best_match.argtypes = [vp, C.c_int]
     L.sassy_hip_set_max_overhang.restype = C.c_int
@@ -565,6 +567,11 @@ class Searcher:
     def set_prefilter(self, mode: int):
         """-1 = the library's choice, 0 = streaming DP over every block, 1 = prefilter also with short pieces."""
         _check(lib().sassy_hip_set_prefilter(self._h, int(mode)))
+        return self
+
+    def set_fused(self, on: bool = True):
+        """The bit-plane prefilter finishes the scan in its own launch (default) / always the classic kernel chain."""
+        _check(lib().sassy_hip_set_fused(self._h, int(bool(on))))
         return self
 
     def enable_counters(self, on: bool = True):

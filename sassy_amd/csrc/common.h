@@ -17,6 +17,11 @@ constexpr int kMaxSlots = 64;          // profile slots (distinct pattern letter
 // counters | words 12..15 (tail): the chunk that ends the buffer -- own_lo, exit state, descriptor
 // flags, found -- written by the scan / list kernel for the shard seam protocol.
 constexpr int kCtlTailWord = 12;
+// u32 [2] of the control block: the fused filter (filter_dna_kernel<.., FUSED>) could not finish the search on
+// its own -- bit 0: a wave found more chunks than its LDS queue holds.  The host then runs the classic chain
+// (bitmap -> chunk list -> list kernel) for this search.
+constexpr int kCtlFuseWord = 2;
+constexpr uint32_t kFuseOverflow = 1u;
 
 // candidate flags
 constexpr uint32_t kCandCond = 1u;     // report depends on the plateau-entry direction left of the chunk
@@ -108,6 +113,13 @@ struct ScanParams {
   uint32_t lin_steps;         // != 0: filter_dna_linear_kernel, 128-block steps per wave range
   uint32_t group_offset;      // filter_dna_kernel: first workgroup of this launch (the grid may be split in two launches)
   uint32_t piece_bits[8][2];
+  // fused mode of filter_dna_kernel (one launch: filter, then the chunk DP of what the wave itself found):
+  // fused = 1; dp_first_owned = first block whose end positions this launch reports (first_owned_block is the
+  // filter's, which also looks at the last halo blocks); a piece occurrence in block b marks match-end blocks in
+  // [b - fuse_reach_left, b + fuse_reach_right]; fuse_queue_cap = chunks a wave's LDS queue holds
+  uint32_t fused;
+  uint32_t fuse_reach_left, fuse_reach_right, fuse_queue_cap;
+  uint64_t dp_first_owned;
   uint32_t piece_rem[8];      // pattern rows behind piece p: a match that contains the piece exactly, ending
                               // at text position e, ends in [e + rem - k, e + rem + k]
   // multi-pattern bit-plane filter (filter_dna_multi_kernel): multi_n patterns of equal length and
@@ -267,6 +279,8 @@ struct TraceParams {
   // the append-order list, `cand` the sorted one it fills; host_cand / host_ctl: the host copies the
   // rank kernels would have written (sorted head of the list, 64-byte control block)
   const Candidate* unsorted;
+  uint32_t dedup;           // self-ranking: the list may hold a report twice (fused filter: two lanes' chunks share a
+                            // block); the later copy becomes a kCandDrop record in the slot behind its twin
   Candidate* host_cand;
   uint4* host_ctl;
   // many patterns over a multi-text buffer (pattern_stride != 0 and texts.n != 0): the flags name the pattern, the

@@ -174,6 +174,7 @@ struct ScanLane {
   int up_profile = -1, table_profile = -1;
   uint32_t table_q = 0, table_k = 0, table_r = 0;   // table_r: 0 = piece bit table, else the counting table's R
   bool table_rc = false;                            // the counting table also holds the Rc strand's q-grams
+  uint32_t fuse_backoff = 0;                        // searches this lane still runs unfused after a fused one overflowed
   double table_density = 0;
   // pinned host staging area: control block and the first kSpec reports of a scan are written into
   // it by the kernels themselves; one stream synchronisation makes them readable
@@ -391,6 +392,9 @@ struct sassy_SearcherType {
 
   bool want_counters = false;
   int prefilter = -1;            // sassy_hip_set_prefilter: -1 process default, 0 never, 1 also with short pieces
+  // sassy_hip_set_fused / SASSY_HIP_FUSED: the bit-plane filter runs the chunk DP of what it finds itself (one launch
+  // instead of filter -> chunk list -> list kernel); 0 = always the classic chain
+  bool fuse = !(getenv("SASSY_HIP_FUSED") && atoi(getenv("SASSY_HIP_FUSED")) == 0);
   // sassy_hip_set_reference_lanes: 0 = the definition (one pass), 4 / 8 = the reference binary's lane reports
   uint32_t ref_lanes = getenv("SASSY_HIP_REF_LANES") ? (uint32_t)atoi(getenv("SASSY_HIP_REF_LANES")) : 0u;
   // searches in flight (sassy_hip_search_shard_begin / sassy_hip_search_finish): the ticket that owns each lane
@@ -763,6 +767,9 @@ struct ScanJob {
   TraceParams T{}, Tw{};
   uint32_t trace_blocks = 0, wave_blocks = 0, grid = 0, fgrid = 0, desc_cap = 0;
   bool use_wave = false, use_thread = false, ev_scan = false, self_rank = false, tuned = false;
+  // fused: the bit-plane filter also runs the chunk DP (filter_dna_kernel<.., FUSED>): no bitmap, no chunk list, no
+  // list kernel; no_fuse: this job already fell back to the classic chain
+  bool fused = false, no_fuse = false;
   uint32_t counts[2] = {0, 0};  // reports, chunk descriptors
   int timing = 1;
 
@@ -773,6 +780,7 @@ struct ScanJob {
   int prepare();
   int enqueue(int attempt);
   int finish(ScanOut& out);
+  int finish_once(ScanOut& out, bool& redo);
 };
 
 int ScanJob::prepare() {
@@ -1046,6 +1054,15 @@ int ScanJob::prepare() {
     Tw.count_max = use_thread ? kTraceWaveMax : 0xFFFFFFFFu;
   }
 
+  // ---- one launch for filter + chunk DP?  (bit-plane filter, one strand, one text, reports ranked by the
+  // traceback waves themselves; the chunk DP's masks and carries must fit the filter's 8 KiB tile)
+  static const int env_selfrank0 = getenv("SASSY_HIP_SELF_RANK") ? atoi(getenv("SASSY_HIP_SELF_RANK")) : 1;
+  static const int env_lin0 = getenv("SASSY_HIP_FILTER_LINEAR") ? atoi(getenv("SASSY_HIP_FILTER_LINEAR")) : 0;
+  fused = filtered && fkind == kFilterPlanes && !ext_bitmap && !ext_desc && rc_bitmap == nullptr && rev_n == 0 &&
+          S->fuse && !no_fuse && L.fuse_backoff == 0 && env_lin0 <= 0 && env_selfrank0 != 0 && do_trace && use_wave &&
+          texts.n == 0 && plan.nwords <= 8 && n_blocks < 0x7FFFFFFFull && !S->want_counters;
+  if (L.fuse_backoff && !no_fuse) --L.fuse_backoff;
+
   // ---- geometry of the streaming kernel (full DP, or the prefilter) ----
   grid = 0;
   F = P;           // prefilter launch
@@ -1142,8 +1159,21 @@ int ScanJob::prepare() {
     tuned = S->tune && S->timing >= 1 && !ext_bitmap && !ext_desc;
     if (int rc = stream_geometry(F, n_blocks - F.first_owned_block, extra_front, &fgrid, fwpc, tuned ? &S->tuner : nullptr,
                                  sh.d_text, sh.text_len, (uint32_t)fkind * 16u + (rc_marked ? 1u : 0u))) return rc;
+    if (fkind == kFilterPlanes) F.stage_blocks = 2;  // (the bit-plane kernel stages whole 128-byte lines only)
     F.lds_per_wave = 4096u * F.stage_blocks + (F.piece_planes ? 0u : 2u * bucket * 512u);
     if (fkind == kFilterCount) F.lds_per_wave = 4096u * F.stage_blocks + 64u * count_w;
+    F.fused = 0;
+    if (fused) {
+      // a piece occurrence in block b marks match-end blocks in [b - reach_left, b + reach_right] (mark_piece_ends):
+      // columns e + rem - k .. e + rem + k + 1 for an occurrence that ends at e in (64 b, 64 b + 64]
+      const uint32_t max_rem = plan.m - q, min_rem = plan.m - (k + 1) * q;
+      F.fused = 1;
+      F.fuse_reach_right = 1u + (max_rem + k) / 64u;
+      F.fuse_reach_left = k > min_rem ? (k - min_rem + 63u) / 64u : 0u;
+      F.dp_first_owned = first_owned;
+      F.fuse_queue_cap = 160;  // chunks per wave (config 2: ~22 expected); 4 workgroups per CU still fit the LDS
+      F.lds_per_wave += F.fuse_queue_cap * 8u + 16u;
+    }
     {
       // Searches in flight on several lanes: the filter's long-lived workgroups would fill every CU (4 waves
       // per SIMD x 112 VGPRs leave no room for a list / traceback wave), and the previous search's tail
@@ -1222,7 +1252,8 @@ int ScanJob::enqueue(int attempt) {
     T.out_str = Tw.out_str = L.d_str.p;
   }
   // control block, rank counters and (first attempt: the filter runs once) the hit bitmap
-  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, kCtlHead + (filtered && !ext_bitmap && !ext_desc && attempt == 0 ? (n_words + 2) * 8 : 0), L.stream));
+  // (fused: no bitmap -- and the rank counters behind the control block are not used either)
+  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, fused ? 64 : kCtlHead + (filtered && !ext_bitmap && !ext_desc && attempt == 0 ? (n_words + 2) * 8 : 0), L.stream));
   if (ext_wait && attempt == 0) HIP_TRY(hipStreamWaitEvent(L.stream, ext_wait, 0));
   // pipelined sub-shards: this lane's filter starts when the previous sub-shard's filter is done,
   // so that the previous lane's DP / rank / traceback kernels overlap this bandwidth-bound one
@@ -1235,7 +1266,15 @@ int ScanJob::enqueue(int attempt) {
     le = launch_scan_any(S->profile, P, grid, (size_t)kWavesPerGroup * P.lds_per_wave, L.stream);
     if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
   } else {
-    if (attempt == 0 && !ext_bitmap && !ext_desc) {  // the hit bitmap does not depend on buffer sizes: build it once
+    if (fused) {  // the filter appends the reports itself: it needs the list (every attempt runs the whole launch)
+      F.cand = P.cand;
+      F.cand_cap = P.cand_cap;
+      F.cand_count = P.cand_count;
+      F.counters = nullptr;
+      F.row_tab = P.row_tab;
+      le = launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, L.stream);
+      if (le != hipSuccess) return hip_fail(le, "fused filter kernel launch");
+    } else if (attempt == 0 && !ext_bitmap && !ext_desc) {  // the hit bitmap does not depend on buffer sizes: build it once
       if (rc_marked) HIP_TRY(hipMemsetAsync(rc_bitmap, 0, (n_words + 2) * 8, L.stream));
       if (rc_second_pass) {
         le = launch_filter_any(S->profile, F2, fgrid, 1024 + (size_t)kWavesPerGroup * F2.lds_per_wave, L.stream);
@@ -1249,6 +1288,7 @@ int ScanJob::enqueue(int attempt) {
     }
     if (time_head && attempt == 0) HIP_TRY(hipEventRecord(L.ev_f, L.stream));
     if (signal_filter_done && attempt == 0) HIP_TRY(hipEventRecord(L.ev_filter_done, L.stream));
+    if (!fused) {
     maxlen = 16;
     while (maxlen < 8u * P.wb && maxlen < 128u) maxlen <<= 1;
     desc_cap = ext_desc ? ext_ndesc : (uint32_t)std::min<size_t>(L.d_desc.cap, 0x7FFFFFFFu);
@@ -1281,6 +1321,7 @@ int ScanJob::enqueue(int attempt) {
     const uint32_t lgrid = (desc_cap + 255) / 256;
     le = launch_list_any(S->profile, P, lgrid, (size_t)kWavesPerGroup * P.lds_per_wave, L.stream);
     if (le != hipSuccess) return hip_fail(le, "list kernel launch");
+    }
   }
   ev_scan = timing >= 2 || (timing == 1 && !filtered);
   if (ev_scan) HIP_TRY(hipEventRecord(L.ev_b, L.stream));
@@ -1307,6 +1348,7 @@ int ScanJob::enqueue(int attempt) {
     Tw.host_cand = reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands);
     Tw.host_ctl = reinterpret_cast<uint4*>(L.h_pin_dev + kPinCounts);
     if (self_rank) Tw.count_max = kTraceWaveMax;
+    Tw.dedup = fused ? 1u : 0u;
     if (use_wave) {
       le = launch_trace(Tw, wave_blocks, L.stream);
       if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
@@ -1323,7 +1365,23 @@ int ScanJob::enqueue(int attempt) {
   return 0;
 }
 
+// finish_once() may find that the fused launch could not complete the search (a wave's chunk queue overflowed, a
+// report hangs on a chunk seam, the shard's exit state needs the chunk chain): the job then runs again as the
+// classic chain, which resolves all of that.
 int ScanJob::finish(ScanOut& out) {
+  bool redo = false;
+  if (int rc = finish_once(out, redo)) return rc;
+  if (!redo) return 0;
+  no_fuse = true;
+  L.fuse_backoff = 16;  // and so do the lane's next searches: a text that overflows the queue once does it again
+  if (int rc = prepare()) return rc;
+  if (!empty)
+    if (int rc = enqueue(0)) return rc;
+  return finish_once(out, redo);
+}
+
+int ScanJob::finish_once(ScanOut& out, bool& redo) {
+  redo = false;
   out = ScanOut();
   if (empty) return 0;
   bool sorted_on_device = false;
@@ -1354,8 +1412,13 @@ int ScanJob::finish(ScanOut& out) {
       S->stats.trace_ms += ms;
     }
     g_marks.mark("event times");
+    if (fused) {
+      uint32_t fw = 0;
+      memcpy(&fw, L.h_pin + kPinCounts + 4 * kCtlFuseWord, sizeof fw);
+      if (fw != 0) { redo = true; return 0; }
+    }
     bool again = false;
-    if (filtered && counts[1] > desc_cap) {  // more chunks than descriptors fit: grow, rebuild
+    if (filtered && !fused && counts[1] > desc_cap) {  // more chunks than descriptors fit: grow, rebuild
       if (int rc = L.d_desc.reserve((size_t)counts[1] + 1024)) return rc;
       again = true;
     }
@@ -1411,6 +1474,7 @@ int ScanJob::finish(ScanOut& out) {
   S->stats.text_bytes += sh.text_len - sh.halo_len;
   S->stats.filtered = filtered ? (uint32_t)fkind : 0u;
   S->stats.piece_len = q;
+  S->stats.fused = fused ? 1u : 0u;
   {
     unsigned long long c[4];
     memcpy(c, L.h_pin + kPinCounters, sizeof c);
@@ -1454,6 +1518,34 @@ int ScanJob::finish(ScanOut& out) {
     out.cands.resize(w);
     if (do_trace) out.matches.resize(w);
   }
+  if (fused && !sorted_on_device) {  // a report two chunks made: the second copy came back as a kCandDrop record
+    size_t w = 0;
+    for (size_t i = 0; i < out.cands.size(); ++i) {
+      if (out.cands[i].flags & kCandDrop) continue;
+      if (w != i) {
+        out.cands[w] = out.cands[i];
+        if (do_trace) out.matches[w] = out.matches[i];
+      }
+      ++w;
+    }
+    out.cands.resize(w);
+    if (do_trace) out.matches.resize(w);
+  } else if (fused) {  // sorted on the device (more reports than the traceback waves rank): copies are neighbours
+    size_t w = 0;
+    for (size_t i = 0; i < out.cands.size(); ++i) {
+      if (w > 0 && out.cands[i].pos == out.cands[w - 1].pos) {
+        if (out.cands[i].flags & kCandCond) out.cands[w - 1].flags |= kCandCond;
+        continue;
+      }
+      if (w != i) {
+        out.cands[w] = out.cands[i];
+        if (do_trace) out.matches[w] = out.matches[i];
+      }
+      ++w;
+    }
+    out.cands.resize(w);
+    if (do_trace) out.matches.resize(w);
+  }
   if (do_trace)
     for (const sassy_hip_Match& r : out.matches)
       if (r.pad_[0] == kTraceFailed)
@@ -1480,6 +1572,7 @@ int ScanJob::finish(ScanOut& out) {
   // ---- seams: reports that depend on how a plateau was entered left of their chunk ----
   bool any_cond = false;
   for (const Candidate& c : out.cands) any_cond |= (c.flags & kCandCond) != 0;
+  if (fused && any_cond) { redo = true; return 0; }  // the chunk chain that resolves it exists only in the classic path
   bool need_state = any_cond || !sh.text_end;  // non-final shards publish their exit state
   if (need_state && !any_cond) {
     // common case: no report hangs on a chunk seam, only the exit state is wanted, and the chunk that
@@ -1490,6 +1583,7 @@ int ScanJob::finish(ScanOut& out) {
     else if (tail[1] != kStatePass) { out.exit_state = (int)tail[1]; need_state = false; }
     else if (tail[2] & kDescClearBefore) { out.exit_state = kStateDecTrue; need_state = false; }
     // else: one plateau from the chunk's start to the buffer end -- walk the chain below
+    if (need_state && fused) { redo = true; return 0; }
   }
   // chunk table in text order: [own_lo, own_hi), exit state, "its left edge is known to be > k"
   struct ChunkInfo { uint64_t lo, hi; uint8_t state; bool clear_before; };
@@ -3015,6 +3109,12 @@ int sassy_hip_enable_counters(sassy_SearcherType* s, int on) {
 int sassy_hip_set_prefilter(sassy_SearcherType* s, int mode) {
   if (!s || mode < -1 || mode > 1) return fail(SASSY_HIP_EINVAL, "prefilter mode must be -1, 0 or 1");
   s->prefilter = mode;
+  return 0;
+}
+
+int sassy_hip_set_fused(sassy_SearcherType* s, int on) {
+  if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
+  s->fuse = on != 0;
   return 0;
 }
 

@@ -886,8 +886,9 @@ __global__ __launch_bounds__(256) void filter_kernel(const ScanParams P) {
 // edits, a match that contains the occurrence ending at text position e ends in
 // [e + rem - k, e + rem + k].  The blocks of those columns and of the one behind them are marked
 // (not the block of the occurrence); K0b adds the warm-up in front.
-__device__ __noinline__ void mark_piece_ends(unsigned long long* bitmap, uint64_t bits, uint64_t b, int64_t mirror_n_plus_q,
-                                             int64_t rem, int64_t k, uint64_t n_blocks) {
+// blocks [x, y] in which a match around the occurrences `bits` of a piece can end (see above)
+__device__ __forceinline__ uint2 piece_end_blocks(uint64_t bits, uint64_t b, int64_t mirror_n_plus_q, int64_t rem, int64_t k,
+                                                  uint64_t n_blocks) {
   int64_t e_lo = (int64_t)(b * 64) + __ffsll((long long)bits);        // first end position
   int64_t e_hi = (int64_t)(b * 64) + 64 - __clzll((long long)bits);   // last end position
   if (mirror_n_plus_q >= 0) {
@@ -903,160 +904,12 @@ __device__ __noinline__ void mark_piece_ends(unsigned long long* bitmap, uint64_
   if (c_lo < 1) c_lo = 1;
   uint64_t blo = (uint64_t)(c_lo - 1) >> 6, bhi = (uint64_t)(c_hi - 1) >> 6;
   if (bhi >= n_blocks) bhi = n_blocks - 1;
-  for (uint64_t x = blo; x <= bhi; ++x) atomicOr(&bitmap[x >> 6], 1ull << (x & 63));
+  return make_uint2((uint32_t)blo, (uint32_t)bhi);
 }
-
-// ====================================================================== K0 for Dna: bit planes only
-// The Dna code of a text byte is two bits ((c >> 1) & 3), so "text char i equals pattern char p"
-// is  (T0 ^ ~P0) & (T1 ^ ~P1)  on the two code bit planes T0, T1 of the block with P0, P1 the
-// replicated code bits of p -- wave-uniform values.  A piece occurrence ending at text bit i is the
-// AND over its rows j of that term taken at bit i - (q-1-j).  The planes are shifted once per
-// distance d = q-1-j (funnel shift with the previous block's planes, which this lane computed in
-// its previous iteration and keeps in registers) and shared by all pieces; every term is then two
-// v_bitop3_b32 (acc & (plane ^ scalar)) per 32-bit half.  No slot masks, no LDS besides the
-// staging tile: per 64-byte block about 130 VALU ops for the planes + 4 * q for the shifts +
-// 4 * (k+1) * q for the terms, which leaves the kernel bound by the HBM stream.
-// NPG: 1 / 2 = up to 4 / 8 pieces (missing pieces repeat piece 0).
-template <int SB, int NPG>
-__global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr uint32_t kRowBytes = 64u * SB;
-  constexpr uint32_t kSlots = 4u * SB;
-  constexpr uint32_t kOwnersPerInstr = 64u / kSlots;
-  constexpr int kStageInstr = 4 * SB;
-  constexpr int NP = 4 * NPG;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = threadIdx.x >> 6;
-  unsigned char* tile = smem + (size_t)wave * P.lds_per_wave;
-
-  const uint64_t wave_chunk0 = (((uint64_t)blockIdx.x + P.group_offset) * kWavesPerGroup + wave) * kWave;
-  if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
-  const uint64_t chunk = wave_chunk0 + lane;
-  const uint32_t bpl = P.bpl;
-  const uint64_t first_owned = P.first_owned_block;
-  const uint32_t back = 1u + (uint32_t)((first_owned + 1u) & 1u);  // previous block + evenness
-  const uint64_t own_lo = first_owned + chunk * (uint64_t)bpl;
-  uint64_t own_hi = own_lo + bpl;
-  if (own_hi > P.n_blocks) own_hi = P.n_blocks;
-  const bool has_chunk = chunk < P.n_chunks && own_lo < P.n_blocks;
-  const uint64_t blk0 = chunk_blk0(first_owned, bpl, back, chunk);
-
-  const uint64_t wave_blk0 = chunk_blk0(first_owned, bpl, back, wave_chunk0);
-  const uint8_t* text_base = P.text + wave_blk0 * 64;
-  uint32_t soff[kStageInstr];
-#pragma unroll
-  for (int i = 0; i < kStageInstr; ++i) {
-    const uint32_t owner = (uint32_t)i * kOwnersPerInstr + lane / kSlots;
-    const uint32_t slot = lane % kSlots;
-    const uint32_t j = slot ^ (SB == 2 ? ((owner >> 1) & 7u) : ((owner >> 2) & 3u));
-    soff[i] = (uint32_t)((chunk_blk0(first_owned, bpl, back, wave_chunk0 + owner) - wave_blk0) * 64) + j * 16u;
-  }
-  const uint64_t wave_last = chunk_blk0(first_owned, bpl, back, wave_chunk0 + 63) + P.n_iter + 2;
-  const bool interior = wave_last * 64 <= P.text_len;
-  const uint32_t fsw = SB == 2 ? ((lane >> 1) & 7u) : ((lane >> 2) & 3u);
-  uint32_t rc[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) rc[c] = lane * kRowBytes + (((uint32_t)c ^ (fsw & 3u)) << 4);
-
-  const uint32_t q = P.piece_len;
-  // ~P0 / ~P1 of every piece row as bit masks (bit j = row j of the piece), wave-uniform
-  uint32_t nb0[NP], nb1[NP];
-#pragma unroll
-  for (int pp = 0; pp < NP; ++pp) {
-    nb0[pp] = ~P.piece_bits[pp][0];
-    nb1[pp] = ~P.piece_bits[pp][1];
-  }
-  uint32_t prev0 = 0, prev1 = 0;  // high halves of the previous block's planes
-
-  // software pipeline: the loads of the next staging step are in flight while this one is processed
-  uint4 nxt[kStageInstr];
-#pragma unroll
-  for (int i = 0; i < kStageInstr; ++i) {
-    nxt[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (interior) nxt[i] = *reinterpret_cast<const uint4*>(text_base + soff[i]);
-  }
-
-  for (uint32_t it = 0; it < P.n_iter; ++it) {
-    const uint32_t sub = SB == 2 ? (it & 1u) : 0u;
-    if (sub == 0) {
-      if (interior) {
-#pragma unroll
-        for (int i = 0; i < kStageInstr; ++i) *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = nxt[i];
-        if (it + SB < P.n_iter) {
-#pragma unroll
-          for (int i = 0; i < kStageInstr; ++i)
-            nxt[i] = *reinterpret_cast<const uint4*>(text_base + (uint64_t)(it + SB) * 64 + soff[i]);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < kStageInstr; ++i) {
-          const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
-          uint4 v;
-          if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
-          else v = load_tail16(P.text, off, P.text_len);
-          *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
-        }
-      }
-    }
-    uint2 t0, t1;
-    {
-      const uint32_t hs = SB == 2 ? (((sub << 2) ^ (fsw & 4u)) << 4) : 0u;
-      uint32_t x[16];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const uint4 v = *reinterpret_cast<const uint4*>(tile + rc[c] + hs);
-        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
-      }
-      t0 = bit_plane<1>(x);  // code bit 0
-      t1 = bit_plane<2>(x);  // code bit 1
-    }
-    uint32_t al[NP], ah[NP];
-#pragma unroll
-    for (int pp = 0; pp < NP; ++pp) { al[pp] = 0xFFFFFFFFu; ah[pp] = 0xFFFFFFFFu; }
-#pragma unroll
-    for (int d = 0; d < 12; ++d) {
-      if ((uint32_t)d < q) {  // wave-uniform
-        uint32_t s0l, s0h, s1l, s1h;
-        if (d == 0) {
-          s0l = t0.x; s0h = t0.y; s1l = t1.x; s1h = t1.y;
-        } else {
-          s0l = __builtin_amdgcn_alignbit(t0.x, prev0, 32 - d);
-          s0h = __builtin_amdgcn_alignbit(t0.y, t0.x, 32 - d);
-          s1l = __builtin_amdgcn_alignbit(t1.x, prev1, 32 - d);
-          s1h = __builtin_amdgcn_alignbit(t1.y, t1.x, 32 - d);
-        }
-        const uint32_t j = q - 1u - (uint32_t)d;  // the piece row whose char sits d bits left of the end
-#pragma unroll
-        for (int pp = 0; pp < NP; ++pp) {
-          const uint32_t n0 = 0u - ((nb0[pp] >> j) & 1u);
-          const uint32_t n1 = 0u - ((nb1[pp] >> j) & 1u);
-          al[pp] = bitop3<0x60>(al[pp], s0l, n0);  // a & (b ^ c)
-          ah[pp] = bitop3<0x60>(ah[pp], s0h, n0);
-          al[pp] = bitop3<0x60>(al[pp], s1l, n1);
-          ah[pp] = bitop3<0x60>(ah[pp], s1h, n1);
-        }
-      }
-    }
-    prev0 = t0.y;
-    prev1 = t1.y;
-    uint32_t hit = 0;
-#pragma unroll
-    for (int pp = 0; pp < NP; ++pp) hit |= al[pp] | ah[pp];
-    const uint64_t b = blk0 + it;
-    const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
-    if (evaluate && hit != 0) {
-#pragma unroll
-      for (int pp = 0; pp < NP; ++pp) {
-        const uint64_t bits = ((uint64_t)ah[pp] << 32) | al[pp];
-        if (bits != 0) {
-          const bool mirror = (P.piece_mirror >> pp) & 1u;
-          mark_piece_ends(mirror ? P.hit_bitmap_rc : P.hit_bitmap, bits, b,
-                          mirror ? (int64_t)P.text_len + (int64_t)q : (int64_t)-1, (int64_t)P.piece_rem[pp], (int64_t)P.k,
-                          P.n_blocks);
-        }
-      }
-    }
-  }
+__device__ __noinline__ void mark_piece_ends(unsigned long long* bitmap, uint64_t bits, uint64_t b, int64_t mirror_n_plus_q,
+                                             int64_t rem, int64_t k, uint64_t n_blocks) {
+  const uint2 r = piece_end_blocks(bits, b, mirror_n_plus_q, rem, k, n_blocks);
+  for (uint64_t x = r.x; x <= (uint64_t)r.y; ++x) atomicOr(&bitmap[x >> 6], 1ull << (x & 63));
 }
 
 // ====================================================================== K0 for Dna, linear streaming
@@ -1498,25 +1351,13 @@ __global__ __launch_bounds__(256) void filter_table_kernel(const ScanParams P) {
 // Same DP, same report rule, same seam bookkeeping as scan_kernel, but every lane takes its chunk
 // (first block, end block, flags) from a descriptor list built from the prefilter's hit bitmap.
 // The chunks are few and short, so each lane simply reads its own 64 bytes per block.
+// The DP of one chunk per lane (descriptor d; lanes without one idle along): shared by list_kernel and by
+// the fused filter (filter_dna_kernel<.., FUSED>), which runs it on the chunks its own wave has found.
+// di: index of the lane's chunk in P.chunk_state (kNoStateSlot: the exit state is not recorded).
+constexpr uint32_t kNoStateSlot = 0xFFFFFFFFu;
 template <int PROFILE, int NS>
-__global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = threadIdx.x >> 6;
-  unsigned char* wbase = smem + (size_t)wave * P.lds_per_wave;
-  unsigned char* mask_bytes = wbase;                                        // [NS][64] u64
-  uint32_t* carry = reinterpret_cast<uint32_t*>(wbase + NS * 512);          // [word][hp|hm][lane]
-
-  uint32_t n_desc = *P.desc_count;
-  if (n_desc > P.desc_cap) n_desc = P.desc_cap;
-  const uint32_t wave_first = (blockIdx.x * kWavesPerGroup + wave) * kWave;
-  if (wave_first >= n_desc) return;  // wave-uniform
-  if (n_desc <= P.list_words_max) return;  // few chunks of a multi-word pattern: list_words_kernel runs them
-  const uint32_t di = wave_first + lane;
-  const bool has_chunk = di < n_desc;
-  ChunkDesc d;
-  d.own_lo = d.own_hi = d.flags = d.pad_ = 0;
-  if (has_chunk) d = P.desc[di];
+__device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* mask_bytes, uint32_t* carry, uint32_t lane,
+                                           bool has_chunk, const ChunkDesc d, uint32_t di) {
   const uint64_t own_lo = d.own_lo, own_hi = d.own_hi;
   const bool clear_before = (d.flags & kDescClearBefore) != 0;
   // a chunk whose left neighbour block holds no cell <= k starts fresh at its own first block;
@@ -1632,7 +1473,7 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   else run(std::false_type{});
   if (has_chunk) {
     const uint32_t fin = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
-    P.chunk_state[di] = (uint8_t)fin;
+    if (di != kNoStateSlot) P.chunk_state[di] = (uint8_t)fin;
     // the chunk that reaches the end of the buffer publishes what a following shard needs
     if (own_hi == P.n_blocks) {
       uint32_t* tail = P.cand_count + kCtlTailWord;
@@ -1643,6 +1484,361 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
     atomicAdd(&P.counters[0], cnt_rows);
     atomicAdd(&P.counters[1], cnt_blocks);
     atomicAdd(&P.counters[3], cnt_live);
+  }
+}
+
+template <int PROFILE, int NS>
+__global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  unsigned char* wbase = smem + (size_t)wave * P.lds_per_wave;
+  unsigned char* mask_bytes = wbase;                                        // [NS][64] u64
+  uint32_t* carry = reinterpret_cast<uint32_t*>(wbase + NS * 512);          // [word][hp|hm][lane]
+
+  uint32_t n_desc = *P.desc_count;
+  if (n_desc > P.desc_cap) n_desc = P.desc_cap;
+  const uint32_t wave_first = (blockIdx.x * kWavesPerGroup + wave) * kWave;
+  if (wave_first >= n_desc) return;  // wave-uniform
+  if (n_desc <= P.list_words_max) return;  // few chunks of a multi-word pattern: list_words_kernel runs them
+  const uint32_t di = wave_first + lane;
+  const bool has_chunk = di < n_desc;
+  ChunkDesc d;
+  d.own_lo = d.own_hi = d.flags = d.pad_ = 0;
+  if (has_chunk) d = P.desc[di];
+  list_lanes<PROFILE, NS>(P, mask_bytes, carry, lane, has_chunk, d, di);
+}
+
+// Rare paths of the fused filter_dna_kernel, out of line like mark_piece_ends (inlined they cost the streaming
+// loop 40 VGPRs = one wave per SIMD).
+__device__ __noinline__ uint2 piece_end_range(uint64_t bits, uint64_t b, int64_t rem, int64_t k, uint64_t n_blocks) {
+  return piece_end_blocks(bits, b, (int64_t)-1, rem, k, n_blocks);
+}
+// The run of match-end blocks a lane is collecting: x = first block (kRunNone: none), y = last block,
+// z = end (one past the last block) of the last run the lane queued.
+constexpr uint32_t kRunNone = 0xFFFFFFFFu;
+struct FuseCtx {
+  uint2* queue;        // the wave's chunk queue in LDS: {own_lo, own_hi | clear << 31}
+  uint32_t* qcount;
+  uint32_t* fuse_word; // control block word kCtlFuseWord
+  uint32_t cap;
+  uint32_t wb, reach_left, reach_right;
+  uint32_t no_left;    // the lane starts the text: no neighbour on its left
+  uint64_t dp_first, own_lo, own_hi;
+};
+// `now`: the block whose occurrences are being added (the lane's own_hi when it is done): this lane's later
+// occurrences mark blocks >= now + 1 - reach_left
+__device__ __forceinline__ uint4 fuse_flush(const FuseCtx& c, uint4 st, uint64_t now) {
+  if (st.x == kRunNone) return st;
+  // fresh start wb blocks in front of the run?  Those blocks must hold no cell <= k: behind this lane's previous
+  // run, inside the launch's owned range, out of reach of the neighbour lanes' occurrences and of this lane's later ones
+  bool clear = st.x >= c.wb;
+  const uint32_t from = clear ? st.x - c.wb : 0u;
+  clear = clear && from >= st.z && (uint64_t)from >= c.dp_first &&
+          (c.no_left || (uint64_t)from >= c.own_lo + c.reach_right) && (uint64_t)st.x + c.reach_left <= c.own_hi &&
+          (uint64_t)st.x + c.reach_left <= now + 1;
+  const uint32_t idx = atomicAdd(c.qcount, 1u);
+  if (idx < c.cap) c.queue[idx] = make_uint2(clear ? from : st.x, (st.y + 1u) | (clear ? 0x80000000u : 0u));
+  st.z = st.y + 1u;
+  st.x = kRunNone;
+  return st;
+}
+// adds the blocks [lo, hi] (lo = kRunNone: nothing to add, only queue the pending run)
+__device__ __noinline__ uint4 fuse_add_range(const FuseCtx c, uint4 st, uint32_t lo, uint32_t hi, uint64_t now) {
+  if (lo == kRunNone) return fuse_flush(c, st, now);
+  if ((uint64_t)lo < c.dp_first) lo = (uint32_t)c.dp_first;  // the halo's end positions are not ours
+  if (lo > hi) return st;
+  if (lo < st.z) {
+    // blocks in front of the end of a run that is already queued (possible only when an occurrence's marks reach
+    // more than two blocks: long patterns): the runs would no longer be disjoint -- the classic chain takes the search
+    atomicOr(c.fuse_word, kFuseOverflow);
+    return st;
+  }
+  if (st.x != kRunNone && lo <= st.y + 1u) {
+    st.x = min(st.x, lo);
+    st.y = max(st.y, hi);
+    return st;
+  }
+  st = fuse_flush(c, st, now);
+  st.x = lo;
+  st.y = hi;
+  return st;
+}
+
+// ====================================================================== K0 for Dna: bit planes only
+// The Dna code of a text byte is two bits ((c >> 1) & 3), so "text char i equals pattern char p"
+// is  (T0 ^ ~P0) & (T1 ^ ~P1)  on the two code bit planes T0, T1 of the block with P0, P1 the
+// replicated code bits of p -- wave-uniform values.  A piece occurrence ending at text bit i is the
+// AND over its rows j of that term taken at bit i - (q-1-j).  The planes are shifted once per
+// distance d = q-1-j (funnel shift with the previous block's planes, which this lane computed in
+// its previous iteration and keeps in registers) and shared by all pieces; every term is then two
+// v_bitop3_b32 (acc & (plane ^ scalar)) per 32-bit half.  No slot masks, no LDS besides the
+// staging tile: per 64-byte block about 130 VALU ops for the planes + 4 * q for the shifts +
+// 4 * (k+1) * q for the terms, which leaves the kernel bound by the HBM stream.
+// Q: piece length (compile time: the shifts and the bit positions of the piece rows are immediates, the
+// per-term scalars -- all-ones or zero -- come from one s_bfe_i32 each, issued next to the VALU work; as run-time
+// values the compiler hoisted all 2 * Q * pieces of them out of the loop and spilled them: 80 v_readlane per block).
+// NPG: 1 / 2 = up to 4 / 8 pieces (missing pieces repeat piece 0).
+//
+// FUSED: the whole scan in this one launch.  A lane that finds a piece occurrence knows the blocks a match
+// around it can end in; instead of marking them in a global bitmap for a chunk builder and a list kernel to
+// pick up (two more launches, each a latency chain of its own), it merges them into runs and queues the runs
+// in its wave's LDS; when the wave has streamed its text range it runs the chunk DP (list_lanes: the list
+// kernel's code) over what it queued, 64 chunks at a time, and appends the reports.  A run [lo, hi] becomes the
+// chunk [lo - wb, hi] with a fresh start when the wb blocks in front of it are known to hold no cell <= k --
+// unmarked by this lane and out of reach of the neighbour lanes' occurrences -- and otherwise the chunk [lo, hi]
+// that warms up on the wb blocks in front (the list kernel's continuation chunk; a report whose plateau entry
+// stays ambiguous carries kCandCond and sends the search to the classic chain).  Runs are per lane: the marks of
+// an occurrence in a lane's first or last blocks can fall into the neighbour's range, and when the neighbour
+// marks the same block both chunks report its end positions -- identical records, dropped where the reports
+// are ranked (trace_wave_kernel).
+template <int Q, int NPG, bool FUSED>
+__global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int SB = 2;
+  constexpr uint32_t kRowBytes = 64u * SB;
+  constexpr uint32_t kSlots = 4u * SB;
+  constexpr uint32_t kOwnersPerInstr = 64u / kSlots;
+  constexpr int kStageInstr = 4 * SB;
+  constexpr int NP = 4 * NPG;
+  constexpr uint32_t kTile = 64u * kRowBytes;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  unsigned char* tile = smem + (size_t)wave * P.lds_per_wave;
+  // FUSED: the wave's chunk queue behind the tile: fuse_queue_cap entries {own_lo, own_hi | clear << 31}, then the count
+  uint2* queue = reinterpret_cast<uint2*>(tile + kTile);
+  uint32_t* qcount = reinterpret_cast<uint32_t*>(tile + kTile + (size_t)P.fuse_queue_cap * 8u);
+
+  const uint64_t wave_chunk0 = (((uint64_t)blockIdx.x + P.group_offset) * kWavesPerGroup + wave) * kWave;
+  if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
+  if constexpr (FUSED) {
+    if (lane == 0) *qcount = 0;
+  }
+  const uint64_t chunk = wave_chunk0 + lane;
+  const uint32_t bpl = P.bpl;
+  const uint64_t first_owned = P.first_owned_block;
+  const uint32_t back = 1u + (uint32_t)((first_owned + 1u) & 1u);  // previous block + evenness
+  const uint64_t own_lo = first_owned + chunk * (uint64_t)bpl;
+  uint64_t own_hi = own_lo + bpl;
+  if (own_hi > P.n_blocks) own_hi = P.n_blocks;
+  const bool has_chunk = chunk < P.n_chunks && own_lo < P.n_blocks;
+  const uint64_t blk0 = chunk_blk0(first_owned, bpl, back, chunk);
+
+  const uint64_t wave_blk0 = chunk_blk0(first_owned, bpl, back, wave_chunk0);
+  const uint8_t* text_base = P.text + wave_blk0 * 64;
+  uint32_t soff[kStageInstr];
+#pragma unroll
+  for (int i = 0; i < kStageInstr; ++i) {
+    const uint32_t owner = (uint32_t)i * kOwnersPerInstr + lane / kSlots;
+    const uint32_t slot = lane % kSlots;
+    const uint32_t j = slot ^ ((owner >> 1) & 7u);
+    soff[i] = (uint32_t)((chunk_blk0(first_owned, bpl, back, wave_chunk0 + owner) - wave_blk0) * 64) + j * 16u;
+  }
+  const uint64_t wave_last = chunk_blk0(first_owned, bpl, back, wave_chunk0 + 63) + P.n_iter + 2;
+  const bool interior = wave_last * 64 <= P.text_len;
+  const uint32_t fsw = (lane >> 1) & 7u;
+  uint32_t rc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rc[c] = lane * kRowBytes + (((uint32_t)c ^ (fsw & 3u)) << 4);
+
+  // ~P0 / ~P1 of every piece row as bit masks (bit j = row j of the piece), wave-uniform
+  uint32_t nb0[NP], nb1[NP];
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp) {
+    nb0[pp] = ~P.piece_bits[pp][0];
+    nb1[pp] = ~P.piece_bits[pp][1];
+  }
+  uint32_t prev0 = 0, prev1 = 0;  // high halves of the previous block's planes
+
+  // FUSED: the run of match-end blocks this lane is collecting, and the end of the last one it queued
+  uint4 run = make_uint4(kRunNone, 0u, 0u, 0u);
+
+  // software pipeline: the loads of the next staging step are in flight while this one is processed
+  uint4 nxt[kStageInstr];
+#pragma unroll
+  for (int i = 0; i < kStageInstr; ++i) {
+    nxt[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (interior) nxt[i] = *reinterpret_cast<const uint4*>(text_base + soff[i]);
+  }
+
+  for (uint32_t it = 0; it < P.n_iter; ++it) {
+    const uint32_t sub = it & 1u;
+    if (sub == 0) {
+      if (interior) {
+#pragma unroll
+        for (int i = 0; i < kStageInstr; ++i) *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = nxt[i];
+        if (it + SB < P.n_iter) {
+#pragma unroll
+          for (int i = 0; i < kStageInstr; ++i)
+            nxt[i] = *reinterpret_cast<const uint4*>(text_base + (uint64_t)(it + SB) * 64 + soff[i]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < kStageInstr; ++i) {
+          const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
+          uint4 v;
+          if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
+          else v = load_tail16(P.text, off, P.text_len);
+          *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+        }
+      }
+    }
+    uint2 t0, t1;
+    {
+      const uint32_t hs = (((sub << 2) ^ (fsw & 4u)) << 4);
+      uint32_t x[16];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const uint4 v = *reinterpret_cast<const uint4*>(tile + rc[c] + hs);
+        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+      }
+      t0 = bit_plane<1>(x);  // code bit 0
+      t1 = bit_plane<2>(x);  // code bit 1
+    }
+    // the piece rows' bits, opaque to the optimiser inside the loop: what is derived from them below (one scalar
+    // per term) is computed here, per iteration, on the scalar unit, instead of living in 2 * Q * pieces registers
+    uint32_t b0[NP], b1[NP];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) {
+      b0[pp] = nb0[pp];
+      b1[pp] = nb1[pp];
+      asm volatile("" : "+s"(b0[pp]), "+s"(b1[pp]));
+    }
+    uint32_t al[NP], ah[NP];
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) { al[pp] = 0xFFFFFFFFu; ah[pp] = 0xFFFFFFFFu; }
+#pragma unroll
+    for (int d = 0; d < Q; ++d) {
+      uint32_t s0l, s0h, s1l, s1h;
+      if (d == 0) {
+        s0l = t0.x; s0h = t0.y; s1l = t1.x; s1h = t1.y;
+      } else {
+        s0l = __builtin_amdgcn_alignbit(t0.x, prev0, 32 - d);
+        s0h = __builtin_amdgcn_alignbit(t0.y, t0.x, 32 - d);
+        s1l = __builtin_amdgcn_alignbit(t1.x, prev1, 32 - d);
+        s1h = __builtin_amdgcn_alignbit(t1.y, t1.x, 32 - d);
+      }
+      const int j = Q - 1 - d;  // the piece row whose char sits d bits left of the end
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        const uint32_t n0 = (uint32_t)__builtin_amdgcn_sbfe((int)b0[pp], j, 1);  // all ones iff bit j is set
+        const uint32_t n1 = (uint32_t)__builtin_amdgcn_sbfe((int)b1[pp], j, 1);
+        al[pp] = bitop3<0x60>(al[pp], s0l, n0);  // a & (b ^ c)
+        ah[pp] = bitop3<0x60>(ah[pp], s0h, n0);
+        al[pp] = bitop3<0x60>(al[pp], s1l, n1);
+        ah[pp] = bitop3<0x60>(ah[pp], s1h, n1);
+      }
+    }
+    prev0 = t0.y;
+    prev1 = t1.y;
+    uint32_t hit = 0;
+#pragma unroll
+    for (int pp = 0; pp < NP; ++pp) hit |= al[pp] | ah[pp];
+    const uint64_t b = blk0 + it;
+    const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
+    if (evaluate && hit != 0) {
+      if constexpr (FUSED) {
+        uint32_t lo = kRunNone, hi = 0;
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+          const uint64_t bits = ((uint64_t)ah[pp] << 32) | al[pp];
+          if (bits != 0) {
+            const uint2 r = piece_end_range(bits, b, (int64_t)P.piece_rem[pp], (int64_t)P.k, P.n_blocks);
+            lo = min(lo, r.x);
+            hi = max(hi, r.y);
+          }
+        }
+        FuseCtx fc;
+        fc.queue = queue; fc.qcount = qcount; fc.cap = P.fuse_queue_cap;
+        fc.wb = P.wb; fc.reach_left = P.fuse_reach_left; fc.reach_right = P.fuse_reach_right;
+        fc.no_left = (own_lo == 0 && (P.flags & kScanTextStart)) ? 1u : 0u;
+        fc.dp_first = P.dp_first_owned; fc.own_lo = own_lo; fc.own_hi = own_hi;
+        fc.fuse_word = P.cand_count + kCtlFuseWord;
+        run = fuse_add_range(fc, run, lo, hi, b);
+      } else {
+#pragma unroll
+        for (int pp = 0; pp < NP; ++pp) {
+          const uint64_t bits = ((uint64_t)ah[pp] << 32) | al[pp];
+          if (bits != 0) {
+            const bool mirror = (P.piece_mirror >> pp) & 1u;
+            mark_piece_ends(mirror ? P.hit_bitmap_rc : P.hit_bitmap, bits, b,
+                            mirror ? (int64_t)P.text_len + (int64_t)Q : (int64_t)-1, (int64_t)P.piece_rem[pp], (int64_t)P.k,
+                            P.n_blocks);
+          }
+        }
+      }
+    }
+  }
+
+  if constexpr (FUSED) {
+    if (run.x != kRunNone) {
+      FuseCtx fc;
+      fc.queue = queue; fc.qcount = qcount; fc.cap = P.fuse_queue_cap;
+      fc.wb = P.wb; fc.reach_left = P.fuse_reach_left; fc.reach_right = P.fuse_reach_right;
+      fc.no_left = (own_lo == 0 && (P.flags & kScanTextStart)) ? 1u : 0u;
+      fc.dp_first = P.dp_first_owned; fc.own_lo = own_lo; fc.own_hi = own_hi;
+      fc.fuse_word = P.cand_count + kCtlFuseWord;
+      run = fuse_add_range(fc, run, kRunNone, 0u, own_hi);
+    }
+    // (one wave: its LDS operations complete in order; the fence keeps the compiler from moving the read up)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t nq = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(qcount));
+    if (nq == 0) return;
+    if (nq > P.fuse_queue_cap) {  // more chunks than the queue holds: the classic chain takes this search
+      if (lane == 0) atomicOr(&P.cand_count[kCtlFuseWord], kFuseOverflow);
+      return;
+    }
+    // What the DP needs of the launch parameters is read HERE, through a pointer the optimiser cannot see
+    // through: read from P they would be loaded at the top of the kernel and held (or spilled to VGPR lanes and
+    // read back inside the streaming loop) for the whole life of the wave.
+    typedef const ScanParams __attribute__((address_space(4)))* kparams_ptr;
+    kparams_ptr kp = (kparams_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    ScanParams L;
+    L.text = kp->text;
+    L.text_len = kp->text_len;
+    L.n_blocks = kp->n_blocks;
+    L.global_offset = kp->global_offset;
+    L.wb = kp->wb;
+    L.m = kp->m;
+    L.k = kp->k;
+    L.nwords = kp->nwords;
+    L.flags = kp->flags;
+    L.cand_cap = kp->cand_cap;
+    L.row_tab = kp->row_tab;
+    L.cand = kp->cand;
+    L.cand_count = kp->cand_count;
+    L.counters = kp->counters;
+    L.rev_n = 0;
+    L.alpha = 0.0f;
+    L.ov_steps = 0;
+    L.ov_tab = nullptr;
+    L.chunk_state = nullptr;
+    L.texts_start = nullptr;
+    L.texts_len = nullptr;
+    // (the same for everything the DP derives from the thread index -- LDS addresses per lane, word, slot:
+    // computed from an opaque copy, they cannot be hoisted in front of the streaming loop and held in VGPRs there)
+    uint32_t tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const uint32_t dlane = tid & 63u;
+    unsigned char* dtile = smem + (size_t)(tid >> 6) * kp->lds_per_wave;
+    const uint2* dqueue = reinterpret_cast<const uint2*>(dtile + kTile);
+    if (dlane == 0) atomicAdd(&L.cand_count[1], nq);  // statistics: chunks
+    // the DP's LDS -- slot masks, per-row carries -- takes the place of the text tile
+    unsigned char* mask_bytes = dtile;
+    uint32_t* carry = reinterpret_cast<uint32_t*>(dtile + 4 * 512);
+    for (uint32_t base = 0; base < nq; base += 64u) {
+      const bool has = base + dlane < nq;
+      uint2 e = make_uint2(0u, 0u);
+      if (has) e = dqueue[base + dlane];
+      ChunkDesc dsc;
+      dsc.own_lo = e.x;
+      dsc.own_hi = e.y & 0x7FFFFFFFu;
+      dsc.flags = (e.y >> 31) ? kDescClearBefore : 0u;
+      dsc.pad_ = 0;
+      list_lanes<PROFILE_DNA, 4>(L, mask_bytes, carry, dlane, has, dsc, kNoStateSlot);
+    }
   }
 }
 
@@ -1846,11 +2042,29 @@ static hipError_t launch_list_one(const ScanParams& P, uint32_t grid, size_t sme
 hipError_t launch_scan_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
   return launch_one<PROFILE_DNA, 4>(P, grid, smem, stream);
 }
-template <int SB, int NPG>
-static hipError_t launch_filter_planes(const ScanParams& P, uint32_t grid, hipStream_t stream) {
-  hipLaunchKernelGGL((filter_dna_kernel<SB, NPG>), dim3(grid), dim3(256), (size_t)kWavesPerGroup * P.lds_per_wave,
-                     stream, P);
+template <int Q, int NPG>
+static hipError_t launch_filter_planes_q(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  const size_t smem = (size_t)kWavesPerGroup * P.lds_per_wave;
+  if (P.fused) hipLaunchKernelGGL((filter_dna_kernel<Q, NPG, true>), dim3(grid), dim3(256), smem, stream, P);
+  else hipLaunchKernelGGL((filter_dna_kernel<Q, NPG, false>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
+}
+template <int NPG>
+static hipError_t launch_filter_planes(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  switch (P.piece_len) {  // 7 .. 12 by default; shorter pieces with SASSY_HIP_PREFILTER=1 / sassy_hip_set_prefilter(s, 1)
+    case 2: return launch_filter_planes_q<2, NPG>(P, grid, stream);
+    case 3: return launch_filter_planes_q<3, NPG>(P, grid, stream);
+    case 4: return launch_filter_planes_q<4, NPG>(P, grid, stream);
+    case 5: return launch_filter_planes_q<5, NPG>(P, grid, stream);
+    case 6: return launch_filter_planes_q<6, NPG>(P, grid, stream);
+    case 7: return launch_filter_planes_q<7, NPG>(P, grid, stream);
+    case 8: return launch_filter_planes_q<8, NPG>(P, grid, stream);
+    case 9: return launch_filter_planes_q<9, NPG>(P, grid, stream);
+    case 10: return launch_filter_planes_q<10, NPG>(P, grid, stream);
+    case 11: return launch_filter_planes_q<11, NPG>(P, grid, stream);
+    case 12: return launch_filter_planes_q<12, NPG>(P, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
 }
 template <int Q>
 static hipError_t launch_filter_table_q(const ScanParams& P, uint32_t grid, hipStream_t stream) {
@@ -1893,11 +2107,8 @@ hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hi
       hipLaunchKernelGGL((filter_dna_linear_kernel<2>), dim3(grid), dim3(256), (size_t)kWavesPerGroup * 8192u, stream, P);
     return hipGetLastError();
   }
-  if (P.piece_planes) {  // <= 8 pieces: the bit-plane kernel (lds_per_wave = the staging tile only)
-    if (P.stage_blocks == 1)
-      return P.piece_groups == 1 ? launch_filter_planes<1, 1>(P, grid, stream) : launch_filter_planes<1, 2>(P, grid, stream);
-    return P.piece_groups == 1 ? launch_filter_planes<2, 1>(P, grid, stream) : launch_filter_planes<2, 2>(P, grid, stream);
-  }
+  if (P.piece_planes)  // <= 8 pieces: the bit-plane kernel (lds_per_wave = the staging tile, + the chunk queue when fused)
+    return P.piece_groups == 1 ? launch_filter_planes<1>(P, grid, stream) : launch_filter_planes<2>(P, grid, stream);
   return launch_filter_one<PROFILE_DNA, 4>(P, grid, smem, stream);
 }
 hipError_t launch_list_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {

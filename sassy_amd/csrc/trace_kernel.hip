@@ -412,6 +412,8 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
       // it (64 lanes over the list, which sits in L2) and files the report, and everything it
       // derives from it, under that rank -- no ranking kernels, two launches fewer per search.
       cd = P.unsorted[u];
+      // rank = reports with a smaller end position + (dedup) earlier copies of this very report: copies of one
+      // position then fill consecutive slots, and every copy but the first is a kCandDrop record the host skips
       uint32_t r = 0;
       {
         // four independent loads in flight per lane (the list is L2 resident; the loop is latency bound)
@@ -420,16 +422,27 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
           const uint64_t p0 = P.unsorted[v].pos, p1 = P.unsorted[v + 64].pos, p2 = P.unsorted[v + 128].pos,
                          p3 = P.unsorted[v + 192].pos;
           r += (p0 < cd.pos ? 1u : 0u) + (p1 < cd.pos ? 1u : 0u) + (p2 < cd.pos ? 1u : 0u) + (p3 < cd.pos ? 1u : 0u);
+          if (P.dedup)
+            r += ((p0 == cd.pos && v < u) ? 0x10000u : 0u) + ((p1 == cd.pos && v + 64 < u) ? 0x10000u : 0u) +
+                 ((p2 == cd.pos && v + 128 < u) ? 0x10000u : 0u) + ((p3 == cd.pos && v + 192 < u) ? 0x10000u : 0u);
         }
-        for (; v < count; v += 64) r += P.unsorted[v].pos < cd.pos ? 1u : 0u;
+        for (; v < count; v += 64) {
+          const uint64_t p0 = P.unsorted[v].pos;
+          r += p0 < cd.pos ? 1u : 0u;
+          if (P.dedup) r += (p0 == cd.pos && v < u) ? 0x10000u : 0u;
+        }
       }
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) r += __shfl_xor(r, d);
-      c = r;
+      // (count <= kTraceWaveMax = 8192 here: the two 16-bit fields cannot overflow)
+      const uint32_t twins = r >> 16;
+      c = (r & 0xFFFFu) + twins;
+      if (twins) cd.flags |= kCandDrop;
       if (lane == 0) {
         const_cast<Candidate*>(P.cand)[c] = cd;
         if (c < P.host_cap && P.host_cand) P.host_cand[c] = cd;
       }
+      if (twins) continue;
     } else {
       cd = P.cand[c];                                      // wave-uniform
     }

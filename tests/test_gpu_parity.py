@@ -2001,3 +2001,195 @@ def test_compiled_c_client_links_and_runs(sassy, tmp_path):
             assert got.get((t, q), []) == want, (t, q)
             total += len(want)
     assert total >= 20
+
+
+# ------------------------------------------------------------------ the fused filter (one launch: filter + chunk DP)
+def _fused_cases(rng):
+    """(pattern, text, k) for which the Dna bit-plane prefilter applies (k + 1 <= 8 pieces of >= 7 rows)."""
+    cases = []
+    for it in range(60):
+        k = rng.choice([0, 1, 2, 3, 3, 3, 4, 5, 7])
+        m = rng.choice([7 * (k + 1), 8 * (k + 1), 8 * (k + 1) + 3, 12 * (k + 1), 12 * (k + 1) + 40, 32 if k <= 3 else 9 * (k + 1)])
+        n = rng.choice([64, 100, 1000, 4096, 4097, 30_000, 70_000, 300_000])
+        pat = rand_seq(rng, m)
+        t = bytearray(rand_seq(rng, n))
+        dense = rng.random() < 0.3
+        for _ in range(n // 300 if dense else rng.randrange(12)):
+            ins = mutate(rng, pat, rng.randrange(k + 2))
+            if len(ins) < n:
+                at = rng.randrange(0, n - len(ins) + 1)
+                t[at:at + len(ins)] = ins
+        if rng.random() < 0.2:  # a low-complexity stretch: plateaus, long runs of candidate blocks
+            ln = min(n // 2, rng.choice([100, 1000, 5000]))
+            at = rng.randrange(0, n - ln + 1)
+            t[at:at + ln] = (pat[:rng.randrange(1, 5)] * ln)[:ln]
+        cases.append((pat, bytes(t[:n]), k))
+    # plants right at the ends of the text, and a pattern made of one letter (every block is a candidate)
+    p = rand_seq(rng, 32)
+    cases.append((p, p + rand_seq(rng, 5000) + p, 3))
+    cases.append((p, rand_seq(rng, 63) + p[:31], 3))
+    cases.append((b"A" * 32, b"A" * 20_000, 3))
+    cases.append((b"AC" * 16, b"AC" * 9000 + b"G" * 77 + b"CA" * 3000, 2))
+    return cases
+
+
+def _env_allows_fusing():
+    """False in the forced-path processes whose switches take the fused launch out of the picture."""
+    e = os.environ
+    return not (e.get("SASSY_HIP_FUSED") == "0" or e.get("SASSY_HIP_PREFILTER") == "0" or e.get("SASSY_HIP_FILTER_KIND", "2") != "2" or
+                e.get("SASSY_HIP_FILTER_LINEAR") or e.get("SASSY_HIP_SELF_RANK") == "0" or e.get("SASSY_HIP_TRACE_WAVE") == "0" or
+                e.get("SASSY_HIP_LANES"))
+
+
+def test_fused_filter_equals_classic_chain_and_oracle(sassy):
+    """filter_dna_kernel<.., FUSED> (filter + chunk DP in one launch, reports deduplicated where they are ranked)
+    against the classic chain (hit bitmap -> chunk list -> list kernel) and the oracle: whole texts, search_all,
+    shards with halos (exit states), searches in flight."""
+    rng = random.Random(77)
+    can_fuse = _env_allows_fusing()
+    fused = sassy.Searcher("dna", rc=False).set_fused(True)
+    classic = sassy.Searcher("dna", rc=False).set_fused(False)
+    ran_fused = 0
+    for i, (pat, text, k) in enumerate(_fused_cases(rng)):
+        want = oracle.search("dna", pat, text, k)
+        got = fused.search(pat, text, k)
+        st = fused.stats()
+        ran_fused += st["fused"]
+        assert_same(got, want, ("fused", i, len(pat), k, len(text), st["filtered"], st["fused"]))
+        got = classic.search(pat, text, k)
+        assert classic.stats()["fused"] == 0
+        assert_same(got, want, ("classic", i, len(pat), k, len(text)))
+        if i % 4 == 0:
+            assert_same(fused.search_all(pat, text[:3000], k), oracle.search("dna", pat, text[:3000], k, all_minima=True), ("all", i))
+    assert ran_fused >= 30 or not can_fuse, ran_fused
+    # shards with halos over a resident text; plants across the seams; both searchers give the same shard results
+    pat = bytes(oracle.generate_dna(43, 0, 32))
+    n = (1 << 21) + 333
+    text = bytearray(oracle.generate_dna(42, 0, n).tobytes())
+    bounds = [0, 64 * 1000, 64 * 1001, 1 << 20, n]
+    for b in bounds[1:-1]:
+        for off in (-40, -3, 10):
+            ins = mutate(rng, pat, rng.randrange(3))
+            text[b + off:b + off + len(ins)] = ins
+    for _ in range(200):
+        ins = mutate(rng, pat, rng.randrange(4))
+        at = rng.randrange(0, n - 64)
+        text[at:at + len(ins)] = ins
+    text = bytes(text[:n])
+    buf = sassy.DeviceBuffer(n + 256)
+    buf.upload(text)
+    want = oracle.search("dna", pat, text, 3)
+    halo = sassy.required_halo(len(pat), 3)
+    for s in (fused, classic):
+        allm = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            h = 0 if a == 0 else halo
+            r = s.search_shard(pat, buf.ptr + a - h, h, b - a, a, n, 3)
+            assert r.conditional_index == -1 and r.exit_state == 1
+            allm += r.matches
+        assert_same(allm, want, "shards")
+    assert fused.stats()["fused"] == 1 or not can_fuse
+    t1 = fused.search_shard_begin(pat, buf.ptr, 0, n, 0, n, 3)
+    t2 = fused.search_shard_begin(pat, buf.ptr, 0, n, 0, n, 2)
+    assert_same(fused.search_finish(t2).matches, oracle.search("dna", pat, text, 2), "in flight k=2")
+    assert_same(fused.search_finish(t1).matches, want, "in flight k=3")
+    buf.free()
+
+
+def test_fused_filter_falls_back_when_a_wave_queue_overflows(sassy):
+    """More candidate runs than a wave's LDS queue holds (a near-match every 192 bytes), and plateaus that cross
+    chunk seams (conditional reports): the fused launch flags it, the classic chain takes the search, the lane backs
+    off for its next searches, and the results are the oracle's."""
+    rng = random.Random(78)
+    pat = rand_seq(rng, 32)
+    n = 400_000
+    t = bytearray(rand_seq(rng, n))
+    for at in range(0, n - 64, 192):
+        ins = mutate(rng, pat, rng.randrange(3))
+        t[at:at + len(ins)] = ins
+    text = bytes(t[:n])
+    s = sassy.Searcher("dna", rc=False)
+    got = s.search(pat, text, 3)
+    assert s.stats()["fused"] == 0 and s.stats()["filtered"] == 2
+    want = oracle.search("dna", pat, text, 3)
+    assert len(want) > 1500
+    assert_same(got, want)
+    # the lane stays unfused for a while, then fuses again
+    sparse = bytes(rand_seq(rng, 100_000))
+    seen = []
+    for _ in range(20):
+        assert s.search(pat, sparse, 3) == []
+        seen.append(s.stats()["fused"])
+    assert seen[0] == 0 and seen[-1] == 1, seen
+    # a plateau over a chunk seam: conditional report -> classic chain
+    p2, t2 = b"A" * 28, b"G" * 5000 + b"A" * 40_000 + b"G" * 5000
+    assert_same(s.search(p2, t2, 3), oracle.search("dna", p2, t2, 3))
+
+
+# ------------------------------------------------------------------ fuzz failures, replayed
+@pytest.mark.parametrize("name", sorted(os.listdir(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_regressions"))))
+def test_fuzz_regressions(sassy, name):
+    """Every case tests/fuzz_gpu.py ever failed on, kept as data: description line, patterns joined by '|', text."""
+    import ast
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_regressions", name), "rb") as fh:
+        head, pats, text = fh.read().split(b"\n", 2)
+    d = ast.literal_eval(head.decode())
+    pats = pats.split(b"|")
+    assert d["mode"] == "encoded" and len(pats) == d["npat"] and len(text) == d["n"]
+    want = sorted(key(m) for m in oracle.search_encoded(d["profile"], pats, text, d["k"], rc=d["rc"], all_minima=d["all_minima"]))
+    assert len(want) == d["matches"]
+    for env in ({"SASSY_HIP_SEEDED": "1"}, {"SASSY_HIP_SEEDED": "0", "SASSY_HIP_TILED": "1"}, {"SASSY_HIP_SEEDED": "0", "SASSY_HIP_TILED": "0"}, {}):
+        os.environ.update(env)
+        try:
+            s = sassy.Searcher(d["profile"], rc=d["rc"])
+            got = s.search_encoded_patterns(s.encode_patterns(pats), text, d["k"], all_minima=d["all_minima"])
+            assert sorted(key(m) for m in got) == want, (env, s.stats()["filtered"], len(got), len(want))
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+
+
+# ------------------------------------------------------------------ every kernel path, forced
+_CORE = ("test_fuzz_small_texts or test_low_complexity_and_seams or test_long_pattern_iupac_config3_shape or "
+         "test_traceback_variants or test_dna_profile_text_with_other_letters or test_device_resident_search_and_shards or "
+         "test_shard_seam_plateau_chain or test_fused_filter_equals_classic_chain_and_oracle or test_dense_reports or "
+         "test_qgram_count_filter_worst_case_edits or test_searches_in_flight_begin_finish")
+_FORCED = [
+    {"SASSY_HIP_PREFILTER": "0"},                    # streaming DP over every block (scan_kernel), also multi-word
+    {"SASSY_HIP_PREFILTER": "0", "SASSY_HIP_ROW_CUT": "0"},   # ... every row of every block
+    {"SASSY_HIP_PREFILTER": "0", "SASSY_HIP_STAGE_BLOCKS": "2"},
+    {"SASSY_HIP_PREFILTER": "1"},                    # prefilter even with 2-row pieces
+    {"SASSY_HIP_PREFILTER": "1", "SASSY_HIP_FUSED": "0"},
+    {"SASSY_HIP_FILTER_KIND": "1"},                  # filter_kernel (slot masks in LDS)
+    {"SASSY_HIP_FILTER_KIND": "3"},                  # filter_table_kernel
+    {"SASSY_HIP_FILTER_KIND": "4"},                  # filter_count_kernel
+    {"SASSY_HIP_FILTER_KIND": "4", "SASSY_HIP_COUNT_STAGE_BLOCKS": "2"},
+    {"SASSY_HIP_ROW_CUT": "0"},                      # list kernels without bounded rows
+    {"SASSY_HIP_FUSED": "0"},                        # classic chain: bitmap -> chunk list -> list kernel
+    {"SASSY_HIP_FILTER_LINEAR": "64"},               # filter_dna_linear_kernel
+    {"SASSY_HIP_TRACE_WAVE": "0"},                   # thread-per-report traceback only
+    {"SASSY_HIP_SELF_RANK": "0"},                    # rank_count / rank_scatter kernels
+    {"SASSY_HIP_RC_FUSED": "0"},                     # Rc strand from a reversed copy
+    {"SASSY_HIP_LIST_WORDS": "0"},                   # multi-word chunk DP by the lane-per-chunk kernel
+    {"SASSY_HIP_LANES": "3", "SASSY_HIP_SUBSHARD_MIN": "2048"},  # one search cut into sub-shards on several streams
+]
+
+
+@pytest.mark.parametrize("env", _FORCED, ids=lambda e: ",".join(f"{k[10:]}={v}" for k, v in e.items()))
+def test_forced_kernel_paths(sassy, env):
+    """The environment switches of DESIGN 5.7 are read once per process, so each forced configuration runs the core
+    differential tests (oracle comparisons: fuzz, seams, long patterns, tracebacks, shards, in flight) in a
+    process of its own -- inside the one `pytest -m gpu` run the driver makes."""
+    import subprocess
+    e = dict(os.environ)
+    for k_ in list(e):
+        if k_.startswith("SASSY_HIP_"):
+            del e[k_]
+    e.update(env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                        "-p", "no:cacheprovider", "-k", _CORE], env=e, cwd=root, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout[-3000:] + r.stderr[-1500:])
+    assert r.returncode == 0, (env, tail)
+    assert " passed" in r.stdout and "failed" not in r.stdout, (env, tail)
+    print(env, r.stdout.strip().splitlines()[-1])
