@@ -50,6 +50,10 @@ constexpr uint32_t kDescClearBefore = 1u;  // the block left of own_lo holds no 
 constexpr uint32_t kDescWholeText = 2u;    // per-text mode: the chunk is one whole text (index in pad_), which
                                            // starts at block own_lo: exact start, own end-of-text rule
 
+constexpr uint32_t kDescWindow = 4u;       // fused filter: the chunk's blocks start at any byte -- block b holds the text
+                                           // bytes [64 b + shift, ..), shift = pad_ & 63 --, all of them are owned, and
+                                           // the DP warms up inside them: columns up to (start + m + k) report nothing
+
 // A chunk of consecutive text blocks handed to one lane of the list-mode DP kernel.  16 bytes.
 struct ChunkDesc {
   uint32_t own_lo;   // first owned block (buffer-relative; texts up to 2^32 blocks = 256 GiB)
@@ -115,10 +119,9 @@ struct ScanParams {
   uint32_t piece_bits[8][2];
   // fused mode of filter_dna_kernel (one launch: filter, then the chunk DP of what the wave itself found):
   // fused = 1; dp_first_owned = first block whose end positions this launch reports (first_owned_block is the
-  // filter's, which also looks at the last halo blocks); a piece occurrence in block b marks match-end blocks in
-  // [b - fuse_reach_left, b + fuse_reach_right]; fuse_queue_cap = chunks a wave's LDS queue holds
+  // filter's, which also looks at the last halo blocks); fuse_queue_cap = chunks a wave's LDS queue holds
   uint32_t fused;
-  uint32_t fuse_reach_left, fuse_reach_right, fuse_queue_cap;
+  uint32_t fuse_queue_cap;
   uint64_t dp_first_owned;
   uint32_t piece_rem[8];      // pattern rows behind piece p: a match that contains the piece exactly, ending
                               // at text position e, ends in [e + rem - k, e + rem + k]

@@ -1164,14 +1164,11 @@ int ScanJob::prepare() {
     if (fkind == kFilterCount) F.lds_per_wave = 4096u * F.stage_blocks + 64u * count_w;
     F.fused = 0;
     if (fused) {
-      // a piece occurrence in block b marks match-end blocks in [b - reach_left, b + reach_right] (mark_piece_ends):
-      // columns e + rem - k .. e + rem + k + 1 for an occurrence that ends at e in (64 b, 64 b + 64]
-      const uint32_t max_rem = plan.m - q, min_rem = plan.m - (k + 1) * q;
-      F.fused = 1;
-      F.fuse_reach_right = 1u + (max_rem + k) / 64u;
-      F.fuse_reach_left = k > min_rem ? (k - min_rem + 63u) / 64u : 0u;
+      static const int env_probe = getenv("SASSY_HIP_FUSED_PROBE") ? atoi(getenv("SASSY_HIP_FUSED_PROBE")) : 0;
+      F.fused = 1u | (env_probe == 1 ? 2u : env_probe == 2 ? 6u : 0u);
       F.dp_first_owned = first_owned;
-      F.fuse_queue_cap = 160;  // chunks per wave (config 2: ~22 expected); 4 workgroups per CU still fit the LDS
+      static const int env_qcap = getenv("SASSY_HIP_FUSED_QCAP") ? atoi(getenv("SASSY_HIP_FUSED_QCAP")) : 0;
+      F.fuse_queue_cap = env_qcap > 0 ? (uint32_t)env_qcap : 160u;  // chunks per wave (config 2: ~22 expected); 4 workgroups per CU still fit the LDS
       F.lds_per_wave += F.fuse_queue_cap * 8u + 16u;
     }
     {
@@ -1415,7 +1412,11 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
     if (fused) {
       uint32_t fw = 0;
       memcpy(&fw, L.h_pin + kPinCounts + 4 * kCtlFuseWord, sizeof fw);
-      if (fw != 0) { redo = true; return 0; }
+      if (fw != 0) {
+        if (getenv("SASSY_HIP_DEBUG_FUSED")) fprintf(stderr, "[sassy-hip] fused launch: queue overflow / out-of-order marks (flag %u)\n", fw);
+        redo = true;
+        return 0;
+      }
     }
     bool again = false;
     if (filtered && !fused && counts[1] > desc_cap) {  // more chunks than descriptors fit: grow, rebuild
@@ -1518,10 +1519,13 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
     out.cands.resize(w);
     if (do_trace) out.matches.resize(w);
   }
+  // fused launch: window chunks that begin in the halo also report end positions in front of the first owned block
+  // (the previous shard's)
+  const uint64_t fused_min_pos = sh.global_offset + first_owned * 64;
   if (fused && !sorted_on_device) {  // a report two chunks made: the second copy came back as a kCandDrop record
     size_t w = 0;
     for (size_t i = 0; i < out.cands.size(); ++i) {
-      if (out.cands[i].flags & kCandDrop) continue;
+      if ((out.cands[i].flags & kCandDrop) || out.cands[i].pos < fused_min_pos) continue;
       if (w != i) {
         out.cands[w] = out.cands[i];
         if (do_trace) out.matches[w] = out.matches[i];
@@ -1533,6 +1537,7 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
   } else if (fused) {  // sorted on the device (more reports than the traceback waves rank): copies are neighbours
     size_t w = 0;
     for (size_t i = 0; i < out.cands.size(); ++i) {
+      if (out.cands[i].pos < fused_min_pos) continue;
       if (w > 0 && out.cands[i].pos == out.cands[w - 1].pos) {
         if (out.cands[i].flags & kCandCond) out.cands[w - 1].flags |= kCandCond;
         continue;
@@ -1572,7 +1577,16 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
   // ---- seams: reports that depend on how a plateau was entered left of their chunk ----
   bool any_cond = false;
   for (const Candidate& c : out.cands) any_cond |= (c.flags & kCandCond) != 0;
-  if (fused && any_cond) { redo = true; return 0; }  // the chunk chain that resolves it exists only in the classic path
+  if (fused && any_cond) {  // the chunk chain that resolves it exists only in the classic path
+    if (getenv("SASSY_HIP_DEBUG_FUSED"))
+      for (const Candidate& c : out.cands)
+        if (c.flags & kCandCond)
+          fprintf(stderr, "[sassy-hip] fused launch: conditional report at %llu cost %d (buffer: offset %llu, halo %llu, len %llu, text end %d)\n",
+                  (unsigned long long)c.pos, c.cost, (unsigned long long)sh.global_offset, (unsigned long long)sh.halo_len,
+                  (unsigned long long)sh.text_len, (int)sh.text_end);
+    redo = true;
+    return 0;
+  }
   bool need_state = any_cond || !sh.text_end;  // non-final shards publish their exit state
   if (need_state && !any_cond) {
     // common case: no report hangs on a chunk seam, only the exit state is wanted, and the chunk that
@@ -1583,7 +1597,11 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
     else if (tail[1] != kStatePass) { out.exit_state = (int)tail[1]; need_state = false; }
     else if (tail[2] & kDescClearBefore) { out.exit_state = kStateDecTrue; need_state = false; }
     // else: one plateau from the chunk's start to the buffer end -- walk the chain below
-    if (need_state && fused) { redo = true; return 0; }
+    if (need_state && fused) {
+      if (getenv("SASSY_HIP_DEBUG_FUSED")) fprintf(stderr, "[sassy-hip] fused launch: exit state undetermined (tail %u %u %u %u)\n", tail[0], tail[1], tail[2], tail[3]);
+      redo = true;
+      return 0;
+    }
   }
   // chunk table in text order: [own_lo, own_hi), exit state, "its left edge is known to be > k"
   struct ChunkInfo { uint64_t lo, hi; uint8_t state; bool clear_before; };

@@ -123,7 +123,11 @@ struct EmitCtx {
   uint32_t ov_steps;  // overhang: end positions up to text_len + ov_steps exist
   uint64_t text_begin; // buffer position of the text's column 0 (0 unless per-text mode)
   uint32_t tag;        // OR-ed into the flags of every report (per-text mode: the text index)
+  // (72 bytes: a larger struct would no longer travel in registers but through scratch memory.  Window chunks
+  // (kDescWindow: block b holds the text bytes [64 b + shift, 64 b + shift + 64)) keep their shift in flags >> 24.)
 };
+static_assert(sizeof(EmitCtx) <= 72, "EmitCtx must stay in registers (one more word and it goes through scratch)");
+constexpr int kEmitShiftBit = 24;
 
 __device__ __forceinline__ void emit(const EmitCtx& P, uint64_t gpos, int cost, uint32_t flags) {
   const uint32_t idx = atomicAdd(P.cand_count, 1u);
@@ -148,7 +152,7 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
   bool dec = (state & kStDec) != 0, amb = (state & kStAmb) != 0;
   const int k = (int)P.k;
   const bool all = (P.flags & kScanAllMinima) != 0;
-  const uint64_t base = b * 64;
+  const uint64_t base = b * 64 + (P.flags >> kEmitShiftBit);
   // with overhang the end positions run on into the virtual 'N' columns behind the text, at an
   // extra cost (reference: add_overshoot_cost, src/search.rs:1274-1282)
   const uint64_t max_pos = P.text_len + P.ov_steps;
@@ -169,17 +173,20 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
     raw += (int)((vp >> (bit - 1)) & 1);
     raw -= (int)((vm >> (bit - 1)) & 1);
     cost = total_of(raw, pos);
+    // (x0: columns up to it are not exact yet.  The owned blocks of a chunk with warm-up BLOCKS lie behind x0 as a
+    // whole; a window chunk warms up inside its own first block(s): nothing is reported or concluded there)
+    const bool exact = (int64_t)pos > x0;
     if (all) {
-      if (owned && cost <= k) emit(P, P.global_offset + pos, cost, 0);
+      if (owned && exact && cost <= k) emit(P, P.global_offset + pos, cost, 0);
     } else {
       const bool rising = cost > prev_cost, falling = cost < prev_cost;
-      if (dec && rising && prev_cost <= k && owned)
+      if (dec && rising && prev_cost <= k && owned && (int64_t)prev_pos > x0)
         emit(P, P.global_offset + prev_pos, prev_cost, amb ? kCandCond : 0u);
       dec = falling || (dec && !rising);
       const bool event = rising || falling || cost > k || prev_cost > k;
-      if (event) {
+      if (event && exact) {
         if (owned) amb = false;
-        else if ((int64_t)pos > x0) determined = true;
+        else determined = true;
       }
     }
     prev_cost = cost;
@@ -187,7 +194,7 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
   }
   if (!all) {
     if (last_warm) amb = !determined;
-    if (owned && (P.flags & kScanTextEnd) && prev_pos == max_pos && dec && prev_cost <= k)
+    if (owned && (P.flags & kScanTextEnd) && prev_pos == max_pos && dec && prev_cost <= k && (int64_t)prev_pos > x0)
       emit(P, P.global_offset + prev_pos, prev_cost, amb ? kCandCond : 0u);
   }
   return (dec ? kStDec : 0u) | (amb ? kStAmb : 0u);
@@ -225,7 +232,10 @@ __device__ __noinline__ uint4 load_tail16_rev(const uint8_t* text, uint64_t off,
 }
 __device__ __forceinline__ uint4 load_text16(const ScanParams& P, uint64_t off) {
   if (P.rev_n == 0) {
-    if (off + 16 <= P.text_len) return *reinterpret_cast<const uint4*>(P.text + off);
+    if (off + 16 <= P.text_len) {  // (any alignment: window chunks start at any byte)
+      const u32x4_unaligned v = *reinterpret_cast<const u32x4_unaligned*>(P.text + off);
+      return make_uint4(v.x, v.y, v.z, v.w);
+    }
     return load_tail16(P.text, off, P.text_len);
   }
   if (off + 16 <= P.rev_n) {
@@ -242,9 +252,9 @@ __device__ __forceinline__ uint4 load_text16(const ScanParams& P, uint64_t off) 
 // ONE basic block: they are issued back to back and waited for once, where they are used (the caller
 // fetches one block ahead).  A wave with a lane at the buffer's tail, and the Rc strand's backwards
 // reads, take the general path chunk by chunk.
-__device__ __forceinline__ void fetch_block(const ScanParams& P, bool on, uint64_t blk, uint32_t (&dst)[16]) {
-  const uint64_t off = blk * 64;
-  const bool plain = P.rev_n == 0 && off + 64 <= P.text_len;
+__device__ __forceinline__ void fetch_block(const ScanParams& P, bool on, uint64_t blk, uint32_t (&dst)[16], uint32_t shift = 0) {
+  const uint64_t off = blk * 64 + shift;
+  const bool plain = P.rev_n == 0 && off + 64 <= P.text_len && shift == 0;
   uint4 v0 = make_uint4(0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u), v1 = v0, v2 = v0, v3 = v0;
   if (__all(!on || plain)) {  // wave-uniform
     if (on) {
@@ -1355,7 +1365,8 @@ __global__ __launch_bounds__(256) void filter_table_kernel(const ScanParams P) {
 // the fused filter (filter_dna_kernel<.., FUSED>), which runs it on the chunks its own wave has found.
 // di: index of the lane's chunk in P.chunk_state (kNoStateSlot: the exit state is not recorded).
 constexpr uint32_t kNoStateSlot = 0xFFFFFFFFu;
-template <int PROFILE, int NS>
+// WIN: the chunks are windows (kDescWindow): blocks at any byte offset, warm-up inside the owned blocks.
+template <int PROFILE, int NS, bool WIN = false>
 __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* mask_bytes, uint32_t* carry, uint32_t lane,
                                            bool has_chunk, const ChunkDesc d, uint32_t di) {
   const uint64_t own_lo = d.own_lo, own_hi = d.own_hi;
@@ -1364,11 +1375,13 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
   // a continuation chunk (split of a long run) needs the warm-up blocks in front of it
   // per-text mode: the chunk is a whole text that starts at block own_lo
   const bool whole_text = (d.flags & kDescWholeText) != 0;
+  const uint32_t shift = WIN ? (d.pad_ & 63u) : 0u;
   uint64_t blk0 = own_lo;
-  if (!clear_before && !whole_text) blk0 = own_lo > P.wb ? own_lo - P.wb : 0;
-  const bool at_text_start = whole_text || (blk0 == 0 && (P.flags & kScanTextStart));
+  if (!WIN && !clear_before && !whole_text) blk0 = own_lo > P.wb ? own_lo - P.wb : 0;
+  const bool at_text_start = whole_text || (blk0 == 0 && shift == 0 && (P.flags & kScanTextStart));
   const bool exact_start = clear_before || at_text_start;
-  const int64_t x0 = exact_start ? -1 : (int64_t)(blk0 * 64 + P.m + P.k);
+  const int64_t x0 = exact_start ? -1 : (int64_t)(blk0 * 64 + shift + P.m + P.k);
+  // (windows may begin in the halo: the host drops the end positions in front of the first owned block)
   const uint32_t my_iters = has_chunk ? (uint32_t)(own_hi - blk0) : 0u;
 
   const int k = (int)P.k;
@@ -1389,7 +1402,8 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
     carry[(w * 2 + 0) * 64 + lane] = hp0;
     carry[(w * 2 + 1) * 64 + lane] = 0;
   }
-  uint32_t st = kStDec;
+  // (a window has no warm-up block that would settle the plateau state: it is open until an exact column does)
+  uint32_t st = (WIN && !exact_start) ? (kStDec | kStAmb) : kStDec;
   EmitCtx ctx;
   ctx.cand = P.cand;
   ctx.cand_count = P.cand_count;
@@ -1402,6 +1416,7 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
   ctx.ov_steps = (P.flags & kScanOverhang) ? P.ov_steps : 0u;
   ctx.text_begin = 0;
   ctx.tag = 0;
+  ctx.flags |= shift << kEmitShiftBit;
   if (whole_text) {  // this lane's text: its own column 0, its own end, its index on every report
     ctx.text_begin = own_lo * 64;
     ctx.text_len = P.texts_start[d.pad_] + P.texts_len[d.pad_];
@@ -1419,7 +1434,7 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
   // straight-line code (idle lanes re-read their chunk's first block) and nothing waits for them until
   // the next iteration uses them: one TLB + HBM miss latency per block, hidden behind the DP of the
   // current block.  Otherwise (buffer tail, Rc strand read backwards, tiny texts) the general fetch.
-  const bool lane_plain = !has_chunk || (P.rev_n == 0 && own_hi * 64 <= P.text_len);
+  const bool lane_plain = !has_chunk || (P.rev_n == 0 && own_hi * 64 + shift <= P.text_len);
   const bool fast_wave = __all(lane_plain) && P.text_len >= 64;
   auto run = [&](auto fast_tag) {
     constexpr bool FAST = decltype(fast_tag)::value;
@@ -1427,14 +1442,15 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
       const bool on = step < my_iters;
       if constexpr (FAST) {
         const uint64_t blk = on ? blk0 + step : (has_chunk ? blk0 : 0);
-        const uint4* p = reinterpret_cast<const uint4*>(P.text + blk * 64);
-        const uint4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+        typedef typename std::conditional<WIN, u32x4_unaligned, uint4>::type vec16;
+        const vec16* p = reinterpret_cast<const vec16*>(P.text + blk * 64 + (on || has_chunk ? shift : 0u));
+        const vec16 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
         dst[0] = v0.x; dst[1] = v0.y; dst[2] = v0.z; dst[3] = v0.w;
         dst[4] = v1.x; dst[5] = v1.y; dst[6] = v1.z; dst[7] = v1.w;
         dst[8] = v2.x; dst[9] = v2.y; dst[10] = v2.z; dst[11] = v2.w;
         dst[12] = v3.x; dst[13] = v3.y; dst[14] = v3.z; dst[15] = v3.w;
       } else {
-        fetch_block(P, on, blk0 + step, dst);
+        fetch_block(P, on, blk0 + step, dst, shift);
       }
     };
     uint32_t xn[16];
@@ -1463,8 +1479,8 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
           const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
           if (P.counters) cnt_live += 1;
           st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
-        } else {
-          st = kStDec;
+        } else if (!WIN || (int64_t)((b + 1) * 64 + shift) > x0) {
+          st = kStDec;  // no cell <= k in the block (a window's block that ends inside its warm-up says nothing)
         }
       }
     }
@@ -1475,7 +1491,7 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
     const uint32_t fin = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
     if (di != kNoStateSlot) P.chunk_state[di] = (uint8_t)fin;
     // the chunk that reaches the end of the buffer publishes what a following shard needs
-    if (own_hi == P.n_blocks) {
+    if (WIN ? (own_hi * 64 + shift >= P.text_len) : (own_hi == P.n_blocks)) {
       uint32_t* tail = P.cand_count + kCtlTailWord;
       tail[0] = (uint32_t)own_lo; tail[1] = fin; tail[2] = d.flags; tail[3] = 1u;
     }
@@ -1510,56 +1526,64 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
 }
 
 // Rare paths of the fused filter_dna_kernel, out of line like mark_piece_ends (inlined they cost the streaming
-// loop 40 VGPRs = one wave per SIMD).
-__device__ __noinline__ uint2 piece_end_range(uint64_t bits, uint64_t b, int64_t rem, int64_t k, uint64_t n_blocks) {
-  return piece_end_blocks(bits, b, (int64_t)-1, rem, k, n_blocks);
+// loop 40 VGPRs = one wave per SIMD).  Everything by value in registers: a struct argument would go through
+// scratch memory, and a kernel that owns a scratch segment starts its waves slower (0.55 -> 0.65 ms per launch).
+//
+// The end positions (columns) a match around the occurrences `bits` of a piece can have: with rem pattern rows
+// behind the piece and <= k edits, [e + rem - k, e + rem + k] for an occurrence that ends at e, + 1 column (the
+// report rule decides about a position when it sees the next one); relative to col_base (a lane's marks stay
+// within a few thousand columns of its own blocks: 32 bits).
+__device__ __noinline__ uint2 piece_end_cols(uint64_t bits, uint64_t b, int64_t rem, int64_t k, int64_t max_col, int64_t col_base) {
+  const int64_t e_lo = (int64_t)(b * 64) + __ffsll((long long)bits);        // first end position
+  const int64_t e_hi = (int64_t)(b * 64) + 64 - __clzll((long long)bits);   // last end position
+  int64_t c_lo = e_lo + rem - k, c_hi = e_hi + rem + k + 1;
+  if (c_lo < 1) c_lo = 1;
+  if (c_hi > max_col) c_hi = max_col;
+  return make_uint2((uint32_t)(c_lo - col_base), (uint32_t)(c_hi - col_base));
 }
-// The run of match-end blocks a lane is collecting: x = first block (kRunNone: none), y = last block,
-// z = end (one past the last block) of the last run the lane queued.
+// The run of end positions a lane is collecting (columns relative to col_base): x = first (kRunNone: none),
+// y = last, z = one past the last column the lane's queued windows cover, w = first column of the last queued one.
 constexpr uint32_t kRunNone = 0xFFFFFFFFu;
-struct FuseCtx {
-  uint2* queue;        // the wave's chunk queue in LDS: {own_lo, own_hi | clear << 31}
-  uint32_t* qcount;
-  uint32_t* fuse_word; // control block word kCtlFuseWord
-  uint32_t cap;
-  uint32_t wb, reach_left, reach_right;
-  uint32_t no_left;    // the lane starts the text: no neighbour on its left
-  uint64_t dp_first, own_lo, own_hi;
-};
-// `now`: the block whose occurrences are being added (the lane's own_hi when it is done): this lane's later
-// occurrences mark blocks >= now + 1 - reach_left
-__device__ __forceinline__ uint4 fuse_flush(const FuseCtx& c, uint4 st, uint64_t now) {
+constexpr uint32_t kRunMergeGap = 32;  // runs this close share a window
+// Queues the window chunk for the run [x, y]: the DP starts fresh at column `start` and is exact from start + mk on
+// (mk = m + k), so the window [start, y] with start <= x - 1 - mk reports every end position of the run, plateau
+// state included (unless the plateau reaches back beyond x - 1: such a report is conditional, scan_block).  Whole
+// 64-column blocks ending at y: {first block, blocks << 6 | byte shift}.
+__device__ __forceinline__ uint4 fuse_flush(uint2* queue, uint32_t* qcount, uint32_t cap, uint32_t mk, int64_t col_base, uint4 st) {
   if (st.x == kRunNone) return st;
-  // fresh start wb blocks in front of the run?  Those blocks must hold no cell <= k: behind this lane's previous
-  // run, inside the launch's owned range, out of reach of the neighbour lanes' occurrences and of this lane's later ones
-  bool clear = st.x >= c.wb;
-  const uint32_t from = clear ? st.x - c.wb : 0u;
-  clear = clear && from >= st.z && (uint64_t)from >= c.dp_first &&
-          (c.no_left || (uint64_t)from >= c.own_lo + c.reach_right) && (uint64_t)st.x + c.reach_left <= c.own_hi &&
-          (uint64_t)st.x + c.reach_left <= now + 1;
-  const uint32_t idx = atomicAdd(c.qcount, 1u);
-  if (idx < c.cap) c.queue[idx] = make_uint2(clear ? from : st.x, (st.y + 1u) | (clear ? 0x80000000u : 0u));
+  uint32_t nv = (st.y - st.x + mk + 2u + 63u) / 64u;
+  const int64_t end = col_base + (int64_t)st.y;
+  int64_t start = end - 64 * (int64_t)nv;
+  if (start < 0) {  // the buffer starts inside the window: whole blocks from byte 0
+    start = 0;
+    nv = (uint32_t)((end + 63) / 64);
+  }
+  const uint32_t idx = atomicAdd(qcount, 1u);
+  if (idx < cap) queue[idx] = make_uint2((uint32_t)(start >> 6), (nv << 6) | (uint32_t)(start & 63));
   st.z = st.y + 1u;
+  st.w = st.x;
   st.x = kRunNone;
   return st;
 }
-// adds the blocks [lo, hi] (lo = kRunNone: nothing to add, only queue the pending run)
-__device__ __noinline__ uint4 fuse_add_range(const FuseCtx c, uint4 st, uint32_t lo, uint32_t hi, uint64_t now) {
-  if (lo == kRunNone) return fuse_flush(c, st, now);
-  if ((uint64_t)lo < c.dp_first) lo = (uint32_t)c.dp_first;  // the halo's end positions are not ours
-  if (lo > hi) return st;
-  if (lo < st.z) {
-    // blocks in front of the end of a run that is already queued (possible only when an occurrence's marks reach
-    // more than two blocks: long patterns): the runs would no longer be disjoint -- the classic chain takes the search
-    atomicOr(c.fuse_word, kFuseOverflow);
+// adds the columns [lo, hi] (lo = kRunNone: nothing to add, only queue the pending run)
+__device__ __noinline__ uint4 fuse_add_range(uint2* queue, uint32_t* qcount, uint32_t* fuse_word, uint32_t cap, uint32_t mk,
+                                             int64_t col_base, uint32_t first_col, uint4 st, uint32_t lo, uint32_t hi) {
+  if (lo == kRunNone) return fuse_flush(queue, qcount, cap, mk, col_base, st);
+  if (lo < first_col) lo = first_col;  // the halo's end positions are not ours
+  if (lo < st.w) {
+    // columns in front of a window that is already queued (possible only when an occurrence's marks reach further
+    // than a block: long patterns): the classic chain takes the search
+    atomicOr(fuse_word, kFuseOverflow);
     return st;
   }
-  if (st.x != kRunNone && lo <= st.y + 1u) {
+  if (lo < st.z) lo = st.z;  // covered by a queued window
+  if (lo > hi) return st;
+  if (st.x != kRunNone && lo <= st.y + kRunMergeGap) {
     st.x = min(st.x, lo);
     st.y = max(st.y, hi);
     return st;
   }
-  st = fuse_flush(c, st, now);
+  st = fuse_flush(queue, qcount, cap, mk, col_base, st);
   st.x = lo;
   st.y = hi;
   return st;
@@ -1602,56 +1626,69 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
   constexpr int kStageInstr = 4 * SB;
   constexpr int NP = 4 * NPG;
   constexpr uint32_t kTile = 64u * kRowBytes;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wave = threadIdx.x >> 6;
-  unsigned char* tile = smem + (size_t)wave * P.lds_per_wave;
-  // FUSED: the wave's chunk queue behind the tile: fuse_queue_cap entries {own_lo, own_hi | clear << 31}, then the count
-  uint2* queue = reinterpret_cast<uint2*>(tile + kTile);
-  uint32_t* qcount = reinterpret_cast<uint32_t*>(tile + kTile + (size_t)P.fuse_queue_cap * 8u);
+  typedef const ScanParams __attribute__((address_space(4)))* kparams_ptr;
 
-  const uint64_t wave_chunk0 = (((uint64_t)blockIdx.x + P.group_offset) * kWavesPerGroup + wave) * kWave;
-  if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
+  // (FUSED: everything is derived from a pointer to the launch parameters that is opaque to the optimiser, so that
+  // nothing of the chunk DP behind the streaming loop is hoisted in front of it and held there.)
+  constexpr uint32_t units = 1u;
+  for (uint32_t unit = 0; unit < units; ++unit) {
+  kparams_ptr Pk = (kparams_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+  uint32_t tid0 = threadIdx.x;
+  if constexpr (FUSED) asm volatile("" : "+s"(Pk), "+v"(tid0));
+  const uint32_t lane = tid0 & 63u;
+  const uint32_t wave = tid0 >> 6;
+  unsigned char* tile = smem + (size_t)wave * Pk->lds_per_wave;
+  // FUSED: the wave's chunk queue behind the tile: fuse_queue_cap entries {first block, blocks << 6 | byte shift}, then the count
+  uint2* queue = reinterpret_cast<uint2*>(tile + kTile);
+  uint32_t* qcount = reinterpret_cast<uint32_t*>(tile + kTile + (size_t)Pk->fuse_queue_cap * 8u);
+  const uint64_t group = (uint64_t)blockIdx.x + Pk->group_offset;
+  const uint32_t bpl = Pk->bpl;
+  const uint64_t first_owned = Pk->first_owned_block;
+  const uint32_t back = 1u + (uint32_t)((first_owned + 1u) & 1u);  // previous block + evenness
+  const uint32_t fsw = (lane >> 1) & 7u;
+  uint32_t rc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) rc[c] = lane * kRowBytes + (((uint32_t)c ^ (fsw & 3u)) << 4);
+  // ~P0 / ~P1 of every piece row as bit masks (bit j = row j of the piece), wave-uniform
+  uint32_t nb0[NP], nb1[NP];
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp) {
+    nb0[pp] = ~Pk->piece_bits[pp][0];
+    nb1[pp] = ~Pk->piece_bits[pp][1];
+  }
+  uint32_t u_bpl = bpl;
+  uint64_t u_first = first_owned + group * 256ull * bpl;
+  const uint32_t lc0 = wave * kWave;  // the wave's first lane chunk inside the unit
+  if (u_first + (uint64_t)lc0 * u_bpl >= Pk->n_blocks) break;  // wave-uniform: nothing left for this wave
+  unsigned long long probe_t0 = 0;
   if constexpr (FUSED) {
     if (lane == 0) *qcount = 0;
+    if (Pk->fused & 2u) probe_t0 = wall_clock64();
   }
-  const uint64_t chunk = wave_chunk0 + lane;
-  const uint32_t bpl = P.bpl;
-  const uint64_t first_owned = P.first_owned_block;
-  const uint32_t back = 1u + (uint32_t)((first_owned + 1u) & 1u);  // previous block + evenness
-  const uint64_t own_lo = first_owned + chunk * (uint64_t)bpl;
-  uint64_t own_hi = own_lo + bpl;
-  if (own_hi > P.n_blocks) own_hi = P.n_blocks;
-  const bool has_chunk = chunk < P.n_chunks && own_lo < P.n_blocks;
-  const uint64_t blk0 = chunk_blk0(first_owned, bpl, back, chunk);
+  const uint32_t n_iter = Pk->n_iter - bpl + u_bpl;
+  const uint64_t own_lo = u_first + (uint64_t)(lc0 + lane) * u_bpl;
+  uint64_t own_hi = own_lo + u_bpl;
+  if (own_hi > Pk->n_blocks) own_hi = Pk->n_blocks;
+  const bool has_chunk = own_lo < Pk->n_blocks;
+  const int64_t col_base = (int64_t)(own_lo * 64) - 65536;  // FUSED: origin of the lane's relative columns
+  const uint64_t blk0 = chunk_blk0(u_first, u_bpl, back, lc0 + lane);
 
-  const uint64_t wave_blk0 = chunk_blk0(first_owned, bpl, back, wave_chunk0);
-  const uint8_t* text_base = P.text + wave_blk0 * 64;
+  const uint64_t wave_blk0 = chunk_blk0(u_first, u_bpl, back, lc0);
+  const uint8_t* text_base = Pk->text + wave_blk0 * 64;
   uint32_t soff[kStageInstr];
 #pragma unroll
   for (int i = 0; i < kStageInstr; ++i) {
     const uint32_t owner = (uint32_t)i * kOwnersPerInstr + lane / kSlots;
     const uint32_t slot = lane % kSlots;
     const uint32_t j = slot ^ ((owner >> 1) & 7u);
-    soff[i] = (uint32_t)((chunk_blk0(first_owned, bpl, back, wave_chunk0 + owner) - wave_blk0) * 64) + j * 16u;
+    soff[i] = (uint32_t)((chunk_blk0(u_first, u_bpl, back, lc0 + owner) - wave_blk0) * 64) + j * 16u;
   }
-  const uint64_t wave_last = chunk_blk0(first_owned, bpl, back, wave_chunk0 + 63) + P.n_iter + 2;
-  const bool interior = wave_last * 64 <= P.text_len;
-  const uint32_t fsw = (lane >> 1) & 7u;
-  uint32_t rc[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) rc[c] = lane * kRowBytes + (((uint32_t)c ^ (fsw & 3u)) << 4);
-
-  // ~P0 / ~P1 of every piece row as bit masks (bit j = row j of the piece), wave-uniform
-  uint32_t nb0[NP], nb1[NP];
-#pragma unroll
-  for (int pp = 0; pp < NP; ++pp) {
-    nb0[pp] = ~P.piece_bits[pp][0];
-    nb1[pp] = ~P.piece_bits[pp][1];
-  }
+  const uint64_t wave_last = chunk_blk0(u_first, u_bpl, back, lc0 + 63) + n_iter + 2;
+  const bool interior = wave_last * 64 <= Pk->text_len;
   uint32_t prev0 = 0, prev1 = 0;  // high halves of the previous block's planes
 
   // FUSED: the run of match-end blocks this lane is collecting, and the end of the last one it queued
-  uint4 run = make_uint4(kRunNone, 0u, 0u, 0u);
+  uint4 run = make_uint4(kRunNone, 0u, 0u, 0u);  // (columns, see fuse_add_range)
 
   // software pipeline: the loads of the next staging step are in flight while this one is processed
   uint4 nxt[kStageInstr];
@@ -1661,13 +1698,13 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
     if (interior) nxt[i] = *reinterpret_cast<const uint4*>(text_base + soff[i]);
   }
 
-  for (uint32_t it = 0; it < P.n_iter; ++it) {
+  for (uint32_t it = 0; it < n_iter; ++it) {
     const uint32_t sub = it & 1u;
     if (sub == 0) {
       if (interior) {
 #pragma unroll
         for (int i = 0; i < kStageInstr; ++i) *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = nxt[i];
-        if (it + SB < P.n_iter) {
+        if (it + SB < n_iter) {
 #pragma unroll
           for (int i = 0; i < kStageInstr; ++i)
             nxt[i] = *reinterpret_cast<const uint4*>(text_base + (uint64_t)(it + SB) * 64 + soff[i]);
@@ -1677,8 +1714,8 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
         for (int i = 0; i < kStageInstr; ++i) {
           const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
           uint4 v;
-          if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
-          else v = load_tail16(P.text, off, P.text_len);
+          if (off + 16 <= Pk->text_len) v = *reinterpret_cast<const uint4*>(Pk->text + off);
+          else v = load_tail16(Pk->text, off, Pk->text_len);
           *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
         }
       }
@@ -1743,27 +1780,23 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
         for (int pp = 0; pp < NP; ++pp) {
           const uint64_t bits = ((uint64_t)ah[pp] << 32) | al[pp];
           if (bits != 0) {
-            const uint2 r = piece_end_range(bits, b, (int64_t)P.piece_rem[pp], (int64_t)P.k, P.n_blocks);
+            const uint2 r = piece_end_cols(bits, b, (int64_t)Pk->piece_rem[pp], (int64_t)Pk->k, (int64_t)(Pk->n_blocks * 64), col_base);
             lo = min(lo, r.x);
             hi = max(hi, r.y);
           }
         }
-        FuseCtx fc;
-        fc.queue = queue; fc.qcount = qcount; fc.cap = P.fuse_queue_cap;
-        fc.wb = P.wb; fc.reach_left = P.fuse_reach_left; fc.reach_right = P.fuse_reach_right;
-        fc.no_left = (own_lo == 0 && (P.flags & kScanTextStart)) ? 1u : 0u;
-        fc.dp_first = P.dp_first_owned; fc.own_lo = own_lo; fc.own_hi = own_hi;
-        fc.fuse_word = P.cand_count + kCtlFuseWord;
-        run = fuse_add_range(fc, run, lo, hi, b);
+        const int64_t fc = (int64_t)(Pk->dp_first_owned * 64) - col_base;
+        run = fuse_add_range(queue, qcount, Pk->cand_count + kCtlFuseWord, Pk->fuse_queue_cap, Pk->m + Pk->k, col_base,
+                             fc > 0 ? (uint32_t)fc : 0u, run, lo, hi);
       } else {
 #pragma unroll
         for (int pp = 0; pp < NP; ++pp) {
           const uint64_t bits = ((uint64_t)ah[pp] << 32) | al[pp];
           if (bits != 0) {
-            const bool mirror = (P.piece_mirror >> pp) & 1u;
-            mark_piece_ends(mirror ? P.hit_bitmap_rc : P.hit_bitmap, bits, b,
-                            mirror ? (int64_t)P.text_len + (int64_t)Q : (int64_t)-1, (int64_t)P.piece_rem[pp], (int64_t)P.k,
-                            P.n_blocks);
+            const bool mirror = (Pk->piece_mirror >> pp) & 1u;
+            mark_piece_ends(mirror ? Pk->hit_bitmap_rc : Pk->hit_bitmap, bits, b,
+                            mirror ? (int64_t)Pk->text_len + (int64_t)Q : (int64_t)-1, (int64_t)Pk->piece_rem[pp], (int64_t)Pk->k,
+                            Pk->n_blocks);
           }
         }
       }
@@ -1771,28 +1804,24 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
   }
 
   if constexpr (FUSED) {
-    if (run.x != kRunNone) {
-      FuseCtx fc;
-      fc.queue = queue; fc.qcount = qcount; fc.cap = P.fuse_queue_cap;
-      fc.wb = P.wb; fc.reach_left = P.fuse_reach_left; fc.reach_right = P.fuse_reach_right;
-      fc.no_left = (own_lo == 0 && (P.flags & kScanTextStart)) ? 1u : 0u;
-      fc.dp_first = P.dp_first_owned; fc.own_lo = own_lo; fc.own_hi = own_hi;
-      fc.fuse_word = P.cand_count + kCtlFuseWord;
-      run = fuse_add_range(fc, run, kRunNone, 0u, own_hi);
-    }
+    if (run.x != kRunNone)
+      run = fuse_add_range(queue, qcount, Pk->cand_count + kCtlFuseWord, Pk->fuse_queue_cap, Pk->m + Pk->k, col_base, 0u, run,
+                           kRunNone, 0u);
     // (one wave: its LDS operations complete in order; the fence keeps the compiler from moving the read up)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const uint32_t nq = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(qcount));
-    if (nq == 0) return;
-    if (nq > P.fuse_queue_cap) {  // more chunks than the queue holds: the classic chain takes this search
-      if (lane == 0) atomicOr(&P.cand_count[kCtlFuseWord], kFuseOverflow);
-      return;
+    unsigned long long probe_t1 = 0;
+    if (Pk->fused & 2u) probe_t1 = wall_clock64();  // SASSY_HIP_FUSED_PROBE: 100 MHz ticks spent streaming / in the chunk DP
+    if (Pk->fused & 4u) continue;                   // (probe: no chunk DP at all -- timing only, no reports)
+    if (nq == 0) continue;
+    if (nq > Pk->fuse_queue_cap) {  // more chunks than the queue holds: the classic chain takes this search
+      if (lane == 0) atomicOr(&Pk->cand_count[kCtlFuseWord], kFuseOverflow);
+      continue;
     }
     // What the DP needs of the launch parameters is read HERE, through a pointer the optimiser cannot see
     // through: read from P they would be loaded at the top of the kernel and held (or spilled to VGPR lanes and
     // read back inside the streaming loop) for the whole life of the wave.
-    typedef const ScanParams __attribute__((address_space(4)))* kparams_ptr;
     kparams_ptr kp = (kparams_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
     ScanParams L;
@@ -1810,6 +1839,7 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
     L.cand = kp->cand;
     L.cand_count = kp->cand_count;
     L.counters = kp->counters;
+    L.dp_first_owned = kp->dp_first_owned;
     L.rev_n = 0;
     L.alpha = 0.0f;
     L.ov_steps = 0;
@@ -1834,12 +1864,23 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
       if (has) e = dqueue[base + dlane];
       ChunkDesc dsc;
       dsc.own_lo = e.x;
-      dsc.own_hi = e.y & 0x7FFFFFFFu;
-      dsc.flags = (e.y >> 31) ? kDescClearBefore : 0u;
-      dsc.pad_ = 0;
-      list_lanes<PROFILE_DNA, 4>(L, mask_bytes, carry, dlane, has, dsc, kNoStateSlot);
+      dsc.own_hi = e.x + (e.y >> 6);
+      dsc.flags = kDescWindow;
+      dsc.pad_ = e.y & 63u;
+      list_lanes<PROFILE_DNA, 4, true>(L, mask_bytes, carry, dlane, has, dsc, kNoStateSlot);
     }
+    if ((kp->fused & 2u) && dlane == 0) {
+      unsigned long long* pc = reinterpret_cast<unsigned long long*>(L.cand_count + 4);  // the control block's counters
+      atomicAdd(&pc[0], probe_t1 - probe_t0);
+      atomicAdd(&pc[1], wall_clock64() - probe_t1);
+      atomicAdd(&pc[2], (unsigned long long)nq);
+      atomicAdd(&pc[3], 1ull);
+    }
+    // the tile is the next unit's again: the DP's LDS traffic is complete before its first staging store (one wave,
+    // in-order LDS); the fence keeps the compiler from reordering across it
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
+  }  // units
 }
 
 // ====================================================================== K1-list, few long chunks

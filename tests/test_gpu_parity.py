@@ -2080,12 +2080,14 @@ def test_fused_filter_equals_classic_chain_and_oracle(sassy):
     buf.upload(text)
     want = oracle.search("dna", pat, text, 3)
     halo = sassy.required_halo(len(pat), 3)
+    fused = sassy.Searcher("dna", rc=False).set_fused(True)  # (the poly-A cases above made the old one back off)
     for s in (fused, classic):
         allm = []
         for a, b in zip(bounds[:-1], bounds[1:]):
             h = 0 if a == 0 else halo
             r = s.search_shard(pat, buf.ptr + a - h, h, b - a, a, n, 3)
-            assert r.conditional_index == -1 and r.exit_state == 1
+            # (no report hangs on the previous shard; the exit state only matters to a shard that has such a report)
+            assert r.conditional_index == -1 and r.exit_state in (0, 1)
             allm += r.matches
         assert_same(allm, want, "shards")
     assert fused.stats()["fused"] == 1 or not can_fuse
