@@ -24,7 +24,11 @@ extern "C" {
 /* search flags */
 #define SASSY_HIP_ALL_MINIMA 1u     /* Searcher::search_all (src/search.rs:685-700) */
 #define SASSY_HIP_WITHOUT_TRACE 2u  /* Searcher::without_trace (src/search.rs:448-451,1464-1475) */
-#define SASSY_HIP_TEXT_ON_DEVICE 4u /* `text` is a device pointer (e.g. a torch tensor's data_ptr) */
+#define SASSY_HIP_TEXT_ON_DEVICE 4u /* `text` is a device pointer (e.g. a torch tensor's data_ptr), 16-byte aligned; the
+                                       kernels read whole 64-byte blocks: the allocation must be readable up to the
+                                       next multiple of 64 bytes behind the text (any hipMalloc'ed buffer is -- a
+                                       sub-range that ends exactly at the end of an allocation of a non-multiple size
+                                       is not) */
 #define SASSY_HIP_TEXT_UNCHANGED 8u /* with TEXT_ON_DEVICE: the bytes at `text` are the same as in this searcher's
                                        previous call with this pointer and length (many patterns, one resident
                                        text): the reversed copy the Rc strand scans is reused, not rebuilt */
@@ -198,7 +202,10 @@ uint64_t sassy_hip_required_halo(size_t pattern_len, size_t k);
  * search i (chunk list, chunk DP, traceback) then runs underneath the bandwidth-bound prefilter of search
  * i+1.  The pattern is copied; the text must stay valid and unchanged until the ticket is finished.  Every
  * ticket must be finished before the searcher is freed (tickets still open then are dropped).  The calls of
- * one searcher must still come from one thread at a time.  sassy_hip_get_stats describes the search finished last. */
+ * one searcher must still come from one thread at a time.  sassy_hip_get_stats describes the search finished last.
+ * While a ticket is open the searcher's synchronous entry points (sassy_hip_search, _search_shard, _search_many,
+ * _search_encoded, _search_with_fn, the drop-in search) and sassy_hip_set_stream fail with SASSY_HIP_EINVAL: they
+ * use the same streams and result buffers. */
 typedef struct sassy_hip_Ticket sassy_hip_Ticket;
 int sassy_hip_search_shard_begin(sassy_SearcherType *s, const uint8_t *pattern, size_t pattern_len,
                                  const uint8_t *d_text, uint64_t halo_len, uint64_t shard_len,

@@ -188,6 +188,9 @@ struct TiledParams {
   Candidate* cand;                // {pos, cost, flags = pattern << kCandTextShift}
   uint32_t* cand_count;
   uint32_t cand_cap;
+  uint32_t cand_stop;             // lanes stop counting once the counter is beyond this (> cand_cap and > the largest list
+                                  // the host would retry with): a 32-bit counter that kept counting could wrap on a
+                                  // dense shape and pass for a complete list
   const uint32_t* keep_bits;      // optional: bit p = end position p is wanted (others are computed, not listed)
 };
 
@@ -207,6 +210,7 @@ struct SeedParams {
   Candidate* out;                 // every (pattern, end position, cost <= k) in a hit's range
   uint32_t* out_count;
   uint32_t out_cap;
+  uint32_t out_stop;              // lanes stop counting beyond this (see TiledParams::cand_stop)
   unsigned long long* hit_count;  // optional: [0] table hits, [1] hits that passed the sub-piece test
   // ---- the sub-piece test in front of the verification (m <= 32; sub == nullptr: off) ----
   // A hit says piece p is intact at i.  The other rows of the pattern hold at most k edits, so of any k+1 disjoint
@@ -284,6 +288,8 @@ struct TraceParams {
   const Candidate* unsorted;
   uint32_t dedup;           // self-ranking: the list may hold a report twice (fused filter: two lanes' chunks share a
                             // block); the later copy becomes a kCandDrop record in the slot behind its twin
+  uint32_t rank_lds;        // self-ranking: up to this many reports the workgroups rank from an LDS copy of the end
+                            // positions (8 bytes each behind the four slices; 0: from the list in L2)
   Candidate* host_cand;
   uint4* host_ctl;
   // many patterns over a multi-text buffer (pattern_stride != 0 and texts.n != 0): the flags name the pattern, the

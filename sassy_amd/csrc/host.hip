@@ -396,7 +396,9 @@ struct sassy_SearcherType {
   // instead of filter -> chunk list -> list kernel); 0 = always the classic chain
   bool fuse = !(getenv("SASSY_HIP_FUSED") && atoi(getenv("SASSY_HIP_FUSED")) == 0);
   // sassy_hip_set_reference_lanes: 0 = the definition (one pass), 4 / 8 = the reference binary's lane reports
-  uint32_t ref_lanes = getenv("SASSY_HIP_REF_LANES") ? (uint32_t)atoi(getenv("SASSY_HIP_REF_LANES")) : 0u;
+  // (anything but 4 or 8 in the environment is ignored, as the setter rejects it)
+  uint32_t ref_lanes = (getenv("SASSY_HIP_REF_LANES") && (atoi(getenv("SASSY_HIP_REF_LANES")) == 4 || atoi(getenv("SASSY_HIP_REF_LANES")) == 8))
+                           ? (uint32_t)atoi(getenv("SASSY_HIP_REF_LANES")) : 0u;
   // searches in flight (sassy_hip_search_shard_begin / sassy_hip_search_finish): the ticket that owns each lane
   struct sassy_hip_Ticket* lane_ticket[kMaxLanes] = {nullptr, nullptr, nullptr, nullptr};
   int last_begun_lane = -1;
@@ -1141,6 +1143,10 @@ int ScanJob::prepare() {
     static const int env_fsb = getenv("SASSY_HIP_FILTER_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_FILTER_STAGE_BLOCKS")) : 0;
     F.stage_blocks = env_fsb == 1 || env_fsb == 2 ? (uint32_t)env_fsb : 2u;
     int fwpc = 16;
+    // fused: ONE round of workgroups (as many as are resident at once) -- every workgroup ends with the chunk DP of
+    // what it found, a phase in which it does not stream; with two rounds the chip goes through that twice (3 GB:
+    // 0.595 ms against 0.572 with one round, the same launch without the chunk DP 0.530 / 0.535)
+    if (fused) fwpc = 8;
     if (fkind == kFilterTable) {
       // one 4 KiB tile per wave + the table per workgroup decide how many workgroups a CU holds
       F.stage_blocks = 1;
@@ -1346,6 +1352,12 @@ int ScanJob::enqueue(int attempt) {
     Tw.host_ctl = reinterpret_cast<uint4*>(L.h_pin_dev + kPinCounts);
     if (self_rank) Tw.count_max = kTraceWaveMax;
     Tw.dedup = fused ? 1u : 0u;
+    Tw.rank_lds = 0;
+    if (self_rank) {  // room for the end positions of 4096 reports behind the slices (else as many as fit, or none)
+      const size_t used = (size_t)4 * ((plan.m + 15u) & ~15u) + (size_t)4 * Tw.scratch_stride;
+      const size_t room = used < 96 * 1024 ? (96 * 1024 - used) / 8 : 0;
+      Tw.rank_lds = (uint32_t)std::min<size_t>(4096, room);
+    }
     if (use_wave) {
       le = launch_trace(Tw, wave_blocks, L.stream);
       if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
@@ -2547,6 +2559,7 @@ static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, co
     if (int rc = list.reserve(std::max<size_t>((size_t)1 << 18, (size_t)got + 1024))) return rc;
     P.cand = list.p;
     P.cand_cap = (uint32_t)std::min<size_t>(list.cap, 0xFFFFFFFFu);
+    P.cand_stop = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(P.cand_cap, kMaxList) + (1u << 20), 0xF0000000ull);
     P.cand_count = d_count;
     HIP_TRY(hipMemsetAsync(d_count, 0, 4, st));
     HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
@@ -2990,6 +3003,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     if (int rc = s->d_tiled_list.reserve(std::max<size_t>((size_t)1 << 18, (size_t)out_count + 1024))) return rc;
     SP.out = s->d_tiled_list.p;
     SP.out_cap = (uint32_t)std::min<size_t>(s->d_tiled_list.cap, 0xFFFFFFFFu);
+    SP.out_stop = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(SP.out_cap, kMaxList) + (1u << 20), 0xF0000000ull);
     HIP_TRY(hipMemsetAsync(s->d_tiled_cnt.p, 0, 64, st));
     HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
     hipError_t le = launch_seed_search(SP, grid, st);
@@ -3026,6 +3040,18 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
 }
 
 static void reset_stats(sassy_SearcherType* S) { S->stats = sassy_hip_Stats{}; }
+// The synchronous entry points use the searcher's lanes (streams, device buffers, pinned result areas) themselves:
+// with a ticket open they would overwrite what its finish() is going to read.
+static bool tickets_open(const sassy_SearcherType* s) {
+  for (const sassy_hip_Ticket* t : s->lane_ticket)
+    if (t) return true;
+  return false;
+}
+#define SASSY_NO_TICKETS(s)                                                                                              \
+  do {                                                                                                                   \
+    if (tickets_open(s))                                                                                                 \
+      return fail(SASSY_HIP_EINVAL, "searches are in flight on this searcher (sassy_hip_search_shard_begin): finish them first"); \
+  } while (0)
 
 }  // namespace sassy_hip
 
@@ -3099,6 +3125,7 @@ void sassy_searcher_free(sassy_SearcherType* ptr) {
 
 int sassy_hip_set_stream(sassy_SearcherType* s, void* hip_stream) {
   if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
+  SASSY_NO_TICKETS(s);
   ScanLane& l0 = s->lanes[0];
   if (l0.own_stream && l0.stream) (void)hipStreamDestroy(l0.stream);
   s->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -3180,6 +3207,7 @@ int sassy_hip_search_with_fn(sassy_SearcherType* s, const uint8_t* pattern, size
                              const uint8_t* text, size_t text_len, size_t k, uint32_t flags,
                              sassy_hip_end_filter fn, void* user, sassy_hip_Result** out) {
   if (!s || !pattern || (!text && text_len) || !out || !fn) return fail(SASSY_HIP_EINVAL, "Pointers in search() must not be null");
+  SASSY_NO_TICKETS(s);
   if (flags & SASSY_HIP_TEXT_ON_DEVICE) return fail(SASSY_HIP_EINVAL, "search_with_fn needs the text in host memory");
   const double t0 = now_ms();
   reset_stats(s);
@@ -3610,6 +3638,7 @@ int sassy_hip_search_many(sassy_SearcherType* s, const uint8_t* const* patterns,
                           size_t k, uint32_t flags, sassy_hip_Result** out) {
   if (!s || !out || (n_patterns && (!patterns || !pattern_lens)) || (n_texts && (!texts || !text_lens)))
     return fail(SASSY_HIP_EINVAL, "null argument");
+  SASSY_NO_TICKETS(s);
   if (s->rc && s->profile == PROFILE_ASCII && n_patterns && n_texts)  // as in search_text: the reference panics here
     return fail(SASSY_HIP_EUNSUPPORTED, "reverse complement is not defined for the ascii alphabet");
   const double t0 = now_ms();
@@ -3746,6 +3775,7 @@ int sassy_hip_search(sassy_SearcherType* s, const uint8_t* pattern, size_t patte
                      const uint8_t* text, size_t text_len, size_t k, uint32_t flags,
                      sassy_hip_Result** out) {
   if (!s || !pattern || (!text && text_len) || !out) return fail(SASSY_HIP_EINVAL, "Pointers in search() must not be null");
+  SASSY_NO_TICKETS(s);
   const double t0 = now_ms();
   reset_stats(s);
   sassy_hip_Result* R = new sassy_hip_Result();
@@ -3770,6 +3800,7 @@ int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t
                            uint64_t global_offset, uint64_t total_len, size_t k, uint32_t flags,
                            sassy_hip_Result** out) {
   if (!s || !pattern || !d_text || !out) return fail(SASSY_HIP_EINVAL, "null argument");
+  SASSY_NO_TICKETS(s);
   if (halo_len % 64 || global_offset % 64) return fail(SASSY_HIP_EINVAL, "halo_len and global_offset must be multiples of 64");
   if (global_offset < halo_len) return fail(SASSY_HIP_EINVAL, "halo reaches left of the text start");
   if (global_offset + shard_len > total_len) return fail(SASSY_HIP_EINVAL, "shard exceeds the text");
@@ -3990,6 +4021,7 @@ void sassy_hip_encoded_free(sassy_hip_Encoded* e) { delete e; }
 int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* text,
                              size_t text_len, size_t k, uint32_t flags, sassy_hip_Result** out) {
   if (!s || !e || (!text && text_len) || !out) return fail(SASSY_HIP_EINVAL, "null argument");
+  SASSY_NO_TICKETS(s);
   const double t0 = now_ms();
   reset_stats(s);
   if (int rc = s->ensure_device()) return rc;

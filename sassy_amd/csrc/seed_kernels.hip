@@ -176,8 +176,11 @@ __device__ __forceinline__ void verify_candidate(const SeedParams& P, unsigned l
           if (t >= emit_from && S.cost <= k) {
             const int64_t pos = s0 + t + 1;
             if (!EDGE || (pos >= 1 && pos <= (int64_t)P.text_len)) {
-              const uint32_t idx = atomicAdd(P.out_count, 1u);
-              if (idx < P.out_cap) P.out[idx] = Candidate{(uint64_t)pos, S.cost, pat << kCandTextShift};
+              // (saturating counter, see TiledParams::cand_stop)
+              if (*reinterpret_cast<volatile const uint32_t*>(P.out_count) <= P.out_stop) {
+                const uint32_t idx = atomicAdd(P.out_count, 1u);
+                if (idx < P.out_cap) P.out[idx] = Candidate{(uint64_t)pos, S.cost, pat << kCandTextShift};
+              }
             }
           }
         }

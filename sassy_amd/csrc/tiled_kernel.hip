@@ -34,6 +34,8 @@ __constant__ uint8_t kTiledIupacNib[32] = {
 
 __device__ __forceinline__ void tiled_emit(const TiledParams& P, uint64_t pos, int cost, uint32_t pat) {
   if (P.keep_bits && !((P.keep_bits[pos >> 5] >> (pos & 31u)) & 1u)) return;  // (a gathered buffer: context, separators)
+  // (saturating: far beyond any capacity the host would retry with, the lanes stop counting -- the counter never wraps)
+  if (*reinterpret_cast<volatile const uint32_t*>(P.cand_count) > P.cand_stop) return;
   const uint32_t idx = atomicAdd(P.cand_count, 1u);
   if (idx < P.cand_cap) P.cand[idx] = Candidate{pos, cost, pat << kCandTextShift};
 }

@@ -2195,3 +2195,26 @@ def test_forced_kernel_paths(sassy, env):
     assert r.returncode == 0, (env, tail)
     assert " passed" in r.stdout and "failed" not in r.stdout, (env, tail)
     print(env, r.stdout.strip().splitlines()[-1])
+
+
+def test_synchronous_calls_are_refused_while_a_ticket_is_open(sassy):
+    """A search begun with search_shard_begin owns a lane's stream and result buffers until it is finished: the
+    synchronous entry points of the same searcher must not run in between (they would overwrite what finish() reads)."""
+    pat = bytes(oracle.generate_dna(43, 0, 32))
+    n = 1 << 20
+    text = bytearray(oracle.generate_dna(42, 0, n).tobytes())
+    text[5000:5032] = pat
+    text = bytes(text)
+    buf = sassy.DeviceBuffer(n + 256)
+    buf.upload(text)
+    s = sassy.Searcher("dna", rc=False)
+    want = oracle.search("dna", pat, text, 3)
+    t = s.search_shard_begin(pat, buf.ptr, 0, n, 0, n, 3)
+    for call in (lambda: s.search(pat, text, 3), lambda: s.search_shard(pat, buf.ptr, 0, n, 0, n, 3),
+                 lambda: s.search_many([pat], [text], 3), lambda: s.search_encoded_patterns(s.encode_patterns([pat]), text, 3),
+                 lambda: s.set_stream(0)):
+        with pytest.raises(sassy.SassyHipError, match="in flight"):
+            call()
+    assert_same(s.search_finish(t).matches, want)
+    assert_same(s.search(pat, text, 3), want)
+    buf.free()
