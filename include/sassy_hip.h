@@ -46,7 +46,8 @@ typedef struct sassy_hip_Match {
   int32_t cost;
   uint8_t strand; /* 0 = Fwd, 1 = Rc */
   uint8_t pad_[3];
-  uint32_t cigar_off; /* offset of the NUL-terminated cigar string in the pool */
+  uint32_t cigar_off; /* offset of the NUL-terminated cigar string in the pool (the pool's bytes between the strings
+                         are unspecified) */
   uint32_t cigar_len;
 } sassy_hip_Match;
 

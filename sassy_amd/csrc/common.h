@@ -68,9 +68,21 @@ constexpr uint32_t kScanTextStart = 2u;  // buffer byte 0 is the true start of t
 constexpr uint32_t kScanTextEnd = 4u;    // buffer end is the true end of the text
 constexpr uint32_t kScanPerText = 16u;   // list mode over whole texts: one lane per text of a block-aligned
                                          // multi-text buffer (ScanParams::texts), no prefilter
+constexpr uint32_t kScanStash = 64u;     // fused filter: a block that reports keeps its 64 text bytes for the traceback (TextStash)
 constexpr uint32_t kScanNoRowCut = 32u;  // DP kernels: compute every pattern row of every block (SASSY_HIP_ROW_CUT=0)
 constexpr uint32_t kScanOverhang = 8u;   // overhang (alpha): special left edge at the text start, virtual
                                          // 'N' columns and an extra cost past the text end
+
+// The text under a report, kept by the lane that made it (fused filter: the block is in its registers, and the
+// traceback would otherwise fetch the window from a random place of a multi-GB text -- a page walk per report,
+// 20 of the traceback kernel's 40 us).  Slot s belongs to the reports whose flags carry (s + 1) << kCandTextShift
+// (single-text buffers only: the field is the text index otherwise); the control block's word 3 counts the slots.
+struct TextStash {
+  uint64_t base;      // buffer offset of text[0]
+  uint64_t pad_;
+  uint32_t text[16];  // 64 bytes
+};
+constexpr int kCtlStashWord = 3;
 
 // One (end position, cost) report of the scan kernel.  16 bytes.
 struct Candidate {
@@ -123,6 +135,8 @@ struct ScanParams {
   uint32_t fused;
   uint32_t fuse_queue_cap;
   uint64_t dp_first_owned;
+  TextStash* stash;           // fused: the text under the reports (stash_cap slots), or null
+  uint32_t stash_cap;
   uint32_t piece_rem[8];      // pattern rows behind piece p: a match that contains the piece exactly, ending
                               // at text position e, ends in [e + rem - k, e + rem + k]
   // multi-pattern bit-plane filter (filter_dna_multi_kernel): multi_n patterns of equal length and
@@ -288,10 +302,18 @@ struct TraceParams {
   const Candidate* unsorted;
   uint32_t dedup;           // self-ranking: the list may hold a report twice (fused filter: two lanes' chunks share a
                             // block); the later copy becomes a kCandDrop record in the slot behind its twin
+  const TextStash* stash;   // single text: reports whose flags name a slot (< stash_cap) find their window there
+  uint32_t stash_cap;
+  unsigned long long* probe;  // debugging (SASSY_HIP_TRACE_PROBE): 8 counters, 100 MHz ticks per phase summed over the waves
   uint32_t rank_lds;        // self-ranking: up to this many reports the workgroups rank from an LDS copy of the end
                             // positions (8 bytes each behind the four slices; 0: from the list in L2)
   Candidate* host_cand;
   uint4* host_ctl;
+  // host_flags (pinned, zeroed by the host before the launch): bit 0 a traceback failed, bit 1 a report is
+  // conditional (kCandCond), bit 2 a record was dropped (duplicate / in front of min_pos) -- with none of them set the
+  // host takes the records as they lie in the pinned block
+  uint32_t* host_flags;
+  uint64_t min_pos;         // self-ranking with dedup: reports in front of this end position are not this launch's
   // many patterns over a multi-text buffer (pattern_stride != 0 and texts.n != 0): the flags name the pattern, the
   // text of report c is report_text[c]
   const uint32_t* report_text;

@@ -12,6 +12,7 @@
 #include <functional>
 #include <iterator>
 #include <memory>
+#include <mutex>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -122,11 +123,57 @@ struct DevBuf {
 
 using namespace sassy_hip;
 
+// Pinned, device-mapped host blocks: the kernels write a search's control block, reports, match rows and cigar
+// strings straight into one (ScanLane::h_pin).  A result that needs no host-side editing ADOPTS the block instead of
+// copying 0.5 MB out of it (17 us of a 0.64 ms search); the lane takes another block from this pool, and
+// sassy_hip_result_free puts the adopted one back.
+struct PinBlock {
+  unsigned char* h = nullptr;
+  unsigned char* d = nullptr;  // device address of h
+  size_t cap = 0;
+  int dev = -1;
+};
+struct PinPool {
+  std::mutex mu;
+  std::vector<PinBlock> blocks;
+  static constexpr size_t kKeep = 12;
+  bool take(size_t bytes, int dev, PinBlock& out) {
+    std::lock_guard<std::mutex> g(mu);
+    for (size_t i = 0; i < blocks.size(); ++i)
+      if (blocks[i].dev == dev && blocks[i].cap >= bytes && blocks[i].cap <= 2 * bytes + (1u << 20)) {
+        out = blocks[i];
+        blocks.erase(blocks.begin() + (long)i);
+        return true;
+      }
+    return false;
+  }
+  void give(const PinBlock& b) {
+    if (!b.h) return;
+    {
+      std::lock_guard<std::mutex> g(mu);
+      if (blocks.size() < kKeep) { blocks.push_back(b); return; }
+    }
+    (void)hipHostFree(b.h);
+  }
+};
+static PinPool g_pin_pool;
+
 struct sassy_hip_Result {
   std::vector<sassy_hip_Match> matches;
   std::string pool;
   int exit_state = kStateDecTrue;
   int64_t conditional_index = -1;
+  // adopted pinned block (pin.h != nullptr): the rows and the cigar pool live in it, the vectors above are empty
+  PinBlock pin;
+  const sassy_hip_Match* ext_matches = nullptr;
+  size_t ext_n = 0;
+  const char* ext_pool = nullptr;
+  size_t ext_pool_len = 0;
+  size_t size() const { return pin.h ? ext_n : matches.size(); }
+  const sassy_hip_Match* data() const { return pin.h ? ext_matches : matches.data(); }
+  const char* pool_data() const { return pin.h ? ext_pool : pool.c_str(); }
+  size_t pool_size() const { return pin.h ? ext_pool_len : pool.size(); }
+  ~sassy_hip_Result() { g_pin_pool.give(pin); }
 };
 
 // One search in flight: everything its ScanJob refers to lives here until sassy_hip_search_finish.
@@ -168,6 +215,8 @@ struct ScanLane {
   // (uploads are skipped when the pattern repeats); per lane, so that scans of different patterns
   // can be in flight on different lanes
   DevBuf<uint8_t> d_pattern, d_table;
+  DevBuf<TextStash> d_stash;   // fused filter: the text under the reports, for the traceback
+  DevBuf<unsigned long long> d_probe;  // SASSY_HIP_TRACE_PROBE
   DevBuf<uint32_t> d_rowoff, d_ovtab;
   std::vector<uint8_t> up_pattern, h_table, table_pattern;
   std::vector<uint32_t> up_rowtab, up_ovtab;
@@ -256,17 +305,33 @@ struct ScanLane {
     }
     return 0;
   }
+  int h_pin_device = -1;
   int reserve_pinned(size_t bytes) {
     if (bytes <= h_pin_cap) return 0;
-    if (h_pin) (void)hipHostFree(h_pin);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (h_pin) g_pin_pool.give(PinBlock{h_pin, h_pin_dev, h_pin_cap, h_pin_device});
     h_pin = nullptr;
     h_pin_cap = 0;
+    PinBlock b;
+    if (g_pin_pool.take(bytes, dev, b)) {
+      h_pin = b.h; h_pin_dev = b.d; h_pin_cap = b.cap; h_pin_device = b.dev;
+      return 0;
+    }
     hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&h_pin), bytes, hipHostMallocMapped);
     if (e != hipSuccess) return hip_fail(e, "hipHostMalloc");
     e = hipHostGetDevicePointer(reinterpret_cast<void**>(&h_pin_dev), h_pin, 0);
     if (e != hipSuccess) return hip_fail(e, "hipHostGetDevicePointer");
     h_pin_cap = bytes;
+    h_pin_device = dev;
     return 0;
+  }
+  // hands the block to a result; the next search reserves another one (from the pool)
+  PinBlock take_pin() {
+    PinBlock b{h_pin, h_pin_dev, h_pin_cap, h_pin_device};
+    h_pin = h_pin_dev = nullptr;
+    h_pin_cap = 0;
+    return b;
   }
   int init() {
     if (ready) return 0;
@@ -288,8 +353,9 @@ struct ScanLane {
     d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release(); d_sort.release();
     for (unsigned char*& b : h_bulk) { if (b) (void)hipHostFree(b); b = nullptr; }
     d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release();
-    d_pattern.release(); d_table.release(); d_rowoff.release(); d_ovtab.release();
-    if (h_pin) (void)hipHostFree(h_pin);
+    d_pattern.release(); d_table.release(); d_rowoff.release(); d_ovtab.release(); d_stash.release();
+    if (h_pin) g_pin_pool.give(PinBlock{h_pin, h_pin_dev, h_pin_cap, h_pin_device});
+    h_pin = nullptr;
     for (hipEvent_t e : {ev_a, ev_b, ev_c, ev_f, ev_filter_done})
       if (e) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -504,6 +570,8 @@ struct ShardView {
   uint64_t global_offset;  // global position of d_text[0]
   bool text_start;         // buffer byte 0 is column 0 of the whole text
   bool text_end;           // buffer end is the end of the whole text
+  bool adopt_ok = false;   // the caller takes the result as it comes (no reporting modes, no strand merge): it may
+                           // stay in the pinned block the kernels wrote it into (ScanOut::pin)
 };
 
 struct ScanOut {
@@ -515,6 +583,27 @@ struct ScanOut {
   // same order, whose cigar_off points into `pool`
   std::vector<sassy_hip_Match> matches;
   std::string pool;
+  // ... or, adopted (pin.h != nullptr; cands / matches / pool above stay empty), in the pinned block itself
+  PinBlock pin;
+  ScanOut() = default;
+  ScanOut(const ScanOut&) = delete;
+  ScanOut& operator=(const ScanOut&) = delete;
+  ScanOut(ScanOut&& o) noexcept { *this = std::move(o); }
+  ScanOut& operator=(ScanOut&& o) noexcept {
+    if (this != &o) {
+      g_pin_pool.give(pin);
+      cands = std::move(o.cands); conditional_index = o.conditional_index; exit_state = o.exit_state; cond_seen = o.cond_seen;
+      matches = std::move(o.matches); pool = std::move(o.pool);
+      pin = o.pin; o.pin = PinBlock{};
+      ext_matches = o.ext_matches; ext_n = o.ext_n; ext_pool = o.ext_pool; ext_pool_len = o.ext_pool_len;
+    }
+    return *this;
+  }
+  ~ScanOut() { g_pin_pool.give(pin); }
+  const sassy_hip_Match* ext_matches = nullptr;
+  size_t ext_n = 0;
+  const char* ext_pool = nullptr;
+  size_t ext_pool_len = 0;
 };
 static_assert(sizeof(MatchOut) == sizeof(sassy_hip_Match) && sizeof(MatchOut) == 64, "record layout");
 
@@ -749,7 +838,7 @@ struct ScanJob {
   // chunks, a 4 KiB N run is shared by four lanes instead of one).
   uint32_t maxlen = 128;
   static constexpr uint32_t kSpec = 4096;  // reports the kernels also write into the host buffer
-  static constexpr size_t kPinCounts = 0, kPinCounters = 16;
+  static constexpr size_t kPinCounts = 0, kPinCounters = 16, kPinFlags = 64;
   static constexpr size_t pin_cands = 128;
   static constexpr size_t pin_recs = pin_cands + (size_t)kSpec * sizeof(Candidate);
   static constexpr size_t pin_ops = pin_recs + (size_t)kSpec * sizeof(MatchOut);
@@ -1273,6 +1362,9 @@ int ScanJob::enqueue(int attempt) {
       F.cand = P.cand;
       F.cand_cap = P.cand_cap;
       F.cand_count = P.cand_count;
+      if (int rc = L.d_stash.reserve(std::min<size_t>(P.cand_cap, 1u << 18))) return rc;
+      F.stash = L.d_stash.p;
+      F.stash_cap = (uint32_t)std::min<size_t>(L.d_stash.cap, 0xFFFFFEu);
       F.counters = nullptr;
       F.row_tab = P.row_tab;
       le = launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, L.stream);
@@ -1350,8 +1442,22 @@ int ScanJob::enqueue(int attempt) {
     Tw.unsorted = self_rank ? L.d_cand.p : nullptr;
     Tw.host_cand = reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands);
     Tw.host_ctl = reinterpret_cast<uint4*>(L.h_pin_dev + kPinCounts);
+    // (the traceback waves tell the host whether any record needs its attention: see finish_once, adoption)
+    *reinterpret_cast<volatile uint32_t*>(L.h_pin + kPinFlags) = 0u;
+    Tw.host_flags = self_rank ? reinterpret_cast<uint32_t*>(L.h_pin_dev + kPinFlags) : nullptr;
+    Tw.min_pos = sh.global_offset + first_owned * 64;
+    T.host_flags = nullptr;
     if (self_rank) Tw.count_max = kTraceWaveMax;
     Tw.dedup = fused ? 1u : 0u;
+    Tw.stash = fused ? L.d_stash.p : nullptr;
+    Tw.stash_cap = fused ? (uint32_t)std::min<size_t>(L.d_stash.cap, 0xFFFFFEu) : 0u;
+    Tw.probe = nullptr;
+    static const bool env_tprobe = getenv("SASSY_HIP_TRACE_PROBE") != nullptr;
+    if (env_tprobe) {  // eight counters per traceback wave
+      if (int rc = L.d_probe.reserve((size_t)wave_blocks * 4 * 8)) return rc;
+      Tw.probe = L.d_probe.p;
+      HIP_TRY(hipMemsetAsync(L.d_probe.p, 0, (size_t)wave_blocks * 4 * 8 * 8, L.stream));
+    }
     Tw.rank_lds = 0;
     if (self_rank) {  // room for the end positions of 4096 reports behind the slices (else as many as fit, or none)
       const size_t used = (size_t)4 * ((plan.m + 15u) & ~15u) + (size_t)4 * Tw.scratch_stride;
@@ -1421,6 +1527,15 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
       S->stats.trace_ms += ms;
     }
     g_marks.mark("event times");
+    if (getenv("SASSY_HIP_TRACE_PROBE") && do_trace) {
+      std::vector<unsigned long long> all((size_t)wave_blocks * 4 * 8);
+      HIP_TRY(hipMemcpy(all.data(), L.d_probe.p, all.size() * 8, hipMemcpyDeviceToHost));
+      unsigned long long pr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (size_t i = 0; i < all.size(); ++i) pr[i & 7] += all[i];
+      const double nrep = (double)std::max<unsigned long long>(1, pr[7]);
+      fprintf(stderr, "[sassy-hip] trace waves (us per report): rank %.2f window %.2f fill %.2f walk %.2f out %.2f (%llu reports)\n",
+              pr[0] / nrep / 100, pr[1] / nrep / 100, pr[2] / nrep / 100, pr[3] / nrep / 100, pr[4] / nrep / 100, pr[7]);
+    }
     if (fused) {
       uint32_t fw = 0;
       memcpy(&fw, L.h_pin + kPinCounts + 4 * kCtlFuseWord, sizeof fw);
@@ -1497,7 +1612,20 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
     S->stats.live_blocks += c[3];
   }
 
-  if (count) {
+  // Nothing for the host to edit -- every report ranked and traced by the traceback waves, no duplicate, no
+  // conditional report, no failed traceback (the waves would have said so in the flag word) -- and a caller that takes
+  // the records as they are: the result keeps the pinned block, the lane gets another one.
+  uint32_t host_flags = 0;
+  memcpy(&host_flags, L.h_pin + kPinFlags, sizeof host_flags);
+  static const bool env_noadopt = getenv("SASSY_HIP_ADOPT") && atoi(getenv("SASSY_HIP_ADOPT")) == 0;
+  const bool adopt = sh.adopt_ok && !env_noadopt && do_trace && self_rank && !sorted_on_device && count != 0 && count <= kSpec &&
+                     count <= kTraceWaveMax && texts.n == 0 && host_flags == 0;
+  if (adopt) {
+    out.ext_matches = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + pin_recs);
+    out.ext_n = count;
+    out.ext_pool = reinterpret_cast<const char*>(L.h_pin + pin_ops);
+    out.ext_pool_len = (size_t)count * T.str_stride;
+  } else if (count) {
     // (after a device sort the staging area's head holds the unsorted list's records: take everything from the device)
     const uint32_t have = sorted_on_device ? 0u : std::min<uint32_t>(count, kSpec);
     // (assign, not resize + memcpy: one pass over the memory instead of a zero fill and a copy)
@@ -1699,6 +1827,7 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
   }
   S->stats.cond_resolved += out.cond_seen;
   g_marks.mark("seams");
+  if (adopt) out.pin = L.take_pin();  // (the lane reserves another block in its next prepare())
   return 0;
 }
 
@@ -2030,6 +2159,16 @@ static int append_matches(ScanOut& so, uint64_t total_len, const PatternPlan& pl
     }
     if (R->pool.empty()) R->pool.push_back('\0');
     for (size_t i = first; i < R->matches.size(); ++i) R->matches[i].cigar_off = 0;
+    return 0;
+  }
+  if (so.pin.h) {  // the records stay where the kernels wrote them (ScanOut::pin): the result owns the block now
+    if (first != 0 || !R->pool.empty() || R->pin.h) return fail(SASSY_HIP_EINVAL, "internal: adopted block into a non-empty result");
+    R->pin = so.pin;
+    so.pin = PinBlock{};
+    R->ext_matches = so.ext_matches;
+    R->ext_n = so.ext_n;
+    R->ext_pool = so.ext_pool;
+    R->ext_pool_len = so.ext_pool_len;
     return 0;
   }
   if (first == 0 && R->pool.empty()) {  // the common single-scan case: adopt the buffers
@@ -3818,6 +3957,7 @@ int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t
   if (shard_len > 0) {
     ShardView sh{d_text, halo_len + shard_len, halo_len, global_offset - halo_len,
                  is_first && halo_len == 0, is_last};
+    sh.adopt_ok = true;  // (search_shard applies no reporting modes: the records are final as the kernels write them)
     ScanOut so;
     const bool wo = (flags & SASSY_HIP_WITHOUT_TRACE) != 0;
     if (int rc = run_scan(s, sh, plan, (uint32_t)k, (flags & SASSY_HIP_ALL_MINIMA) != 0, pattern, !wo,
@@ -3871,6 +4011,7 @@ int sassy_hip_search_shard_begin(sassy_SearcherType* s, const uint8_t* pattern, 
   t->empty_shard = shard_len == 0;
   if (!t->empty_shard) {
     ShardView sh{d_text, halo_len + shard_len, halo_len, global_offset - halo_len, is_first && halo_len == 0, is_last};
+    sh.adopt_ok = true;
     auto job = std::make_shared<ScanJob>(s, s->lanes[lane], sh, t->plan, (uint32_t)k, (flags & SASSY_HIP_ALL_MINIMA) != 0,
                                          t->pat.data(), !t->without_trace, total_len);
     job->pipelined = depth > 1;
@@ -3926,10 +4067,10 @@ int sassy_hip_search_finish(sassy_SearcherType* s, sassy_hip_Ticket* t, sassy_hi
   return 0;
 }
 
-size_t sassy_hip_result_len(const sassy_hip_Result* r) { return r ? r->matches.size() : 0; }
-const sassy_hip_Match* sassy_hip_result_matches(const sassy_hip_Result* r) { return r ? r->matches.data() : nullptr; }
-const char* sassy_hip_result_cigars(const sassy_hip_Result* r) { return r ? r->pool.c_str() : nullptr; }
-size_t sassy_hip_result_cigars_len(const sassy_hip_Result* r) { return r ? r->pool.size() : 0; }
+size_t sassy_hip_result_len(const sassy_hip_Result* r) { return r ? r->size() : 0; }
+const sassy_hip_Match* sassy_hip_result_matches(const sassy_hip_Result* r) { return r ? r->data() : nullptr; }
+const char* sassy_hip_result_cigars(const sassy_hip_Result* r) { return r ? r->pool_data() : nullptr; }
+size_t sassy_hip_result_cigars_len(const sassy_hip_Result* r) { return r ? r->pool_size() : 0; }
 
 int sassy_hip_pack_rows(const sassy_hip_Match* matches, size_t n, const char* cigars, size_t cigars_len, int64_t* rows,
                         size_t cigar_bytes) {

@@ -152,6 +152,16 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
   bool dec = (state & kStDec) != 0, amb = (state & kStAmb) != 0;
   const int k = (int)P.k;
   const bool all = (P.flags & kScanAllMinima) != 0;
+  // kScanStash: the first report of this block takes a TextStash slot (control word kCtlStashWord counts them); all
+  // reports of the block carry it in their flags, the caller -- who has the block's text -- fills it (return value)
+  uint32_t slot_tag = 0;
+  auto tag_of = [&]() -> uint32_t {
+    if ((P.flags & kScanStash) && slot_tag == 0) {
+      const uint32_t sl = atomicAdd(P.cand_count + kCtlStashWord, 1u);
+      slot_tag = sl < 0xFFFFFEu ? sl + 1u : 0xFFFFFFu;
+    }
+    return slot_tag == 0xFFFFFFu ? 0u : slot_tag << kCandTextShift;
+  };
   const uint64_t base = b * 64 + (P.flags >> kEmitShiftBit);
   // with overhang the end positions run on into the virtual 'N' columns behind the text, at an
   // extra cost (reference: add_overshoot_cost, src/search.rs:1274-1282)
@@ -165,7 +175,7 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
   int cost = total_of(raw, base), prev_cost = cost;
   uint64_t prev_pos = base;
   if (all && owned && cost <= k && base == P.text_begin && P.global_offset == 0 && (P.flags & kScanTextStart))
-    emit(P, base, cost, 0);
+    emit(P, base, cost, tag_of());
   bool determined = (x0 < 0);
   for (int bit = 1; bit <= 64; ++bit) {
     const uint64_t pos = base + (uint64_t)bit;
@@ -177,11 +187,11 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
     // whole; a window chunk warms up inside its own first block(s): nothing is reported or concluded there)
     const bool exact = (int64_t)pos > x0;
     if (all) {
-      if (owned && exact && cost <= k) emit(P, P.global_offset + pos, cost, 0);
+      if (owned && exact && cost <= k) emit(P, P.global_offset + pos, cost, tag_of());
     } else {
       const bool rising = cost > prev_cost, falling = cost < prev_cost;
       if (dec && rising && prev_cost <= k && owned && (int64_t)prev_pos > x0)
-        emit(P, P.global_offset + prev_pos, prev_cost, amb ? kCandCond : 0u);
+        emit(P, P.global_offset + prev_pos, prev_cost, (amb ? kCandCond : 0u) | tag_of());
       dec = falling || (dec && !rising);
       const bool event = rising || falling || cost > k || prev_cost > k;
       if (event && exact) {
@@ -195,9 +205,9 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
   if (!all) {
     if (last_warm) amb = !determined;
     if (owned && (P.flags & kScanTextEnd) && prev_pos == max_pos && dec && prev_cost <= k && (int64_t)prev_pos > x0)
-      emit(P, P.global_offset + prev_pos, prev_cost, amb ? kCandCond : 0u);
+      emit(P, P.global_offset + prev_pos, prev_cost, (amb ? kCandCond : 0u) | tag_of());
   }
-  return (dec ? kStDec : 0u) | (amb ? kStAmb : 0u);
+  return (dec ? kStDec : 0u) | (amb ? kStAmb : 0u) | (slot_tag << kCandTextShift);
 }
 
 // 16 text bytes that straddle or lie past the end of the buffer (cold path): bytes past the end
@@ -1417,6 +1427,7 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
   ctx.text_begin = 0;
   ctx.tag = 0;
   ctx.flags |= shift << kEmitShiftBit;
+  if (WIN && P.stash != nullptr && !whole_text) ctx.flags |= kScanStash;
   if (whole_text) {  // this lane's text: its own column 0, its own end, its index on every report
     ctx.text_begin = own_lo * 64;
     ctx.text_len = P.texts_start[d.pad_] + P.texts_len[d.pad_];
@@ -1479,6 +1490,19 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
           const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
           if (P.counters) cnt_live += 1;
           st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
+          if constexpr (WIN) {  // the block reported: its text goes with the reports (TextStash)
+            const uint32_t slot1 = st >> kCandTextShift;
+            st &= 0xFFu;
+            if (slot1 != 0 && slot1 != 0xFFFFFFu && slot1 <= P.stash_cap) {
+              TextStash* ts = P.stash + (slot1 - 1u);
+              ts->base = b * 64 + shift;
+              uint4* tt = reinterpret_cast<uint4*>(ts->text);
+              tt[0] = make_uint4(x[0], x[1], x[2], x[3]);
+              tt[1] = make_uint4(x[4], x[5], x[6], x[7]);
+              tt[2] = make_uint4(x[8], x[9], x[10], x[11]);
+              tt[3] = make_uint4(x[12], x[13], x[14], x[15]);
+            }
+          }
         } else if (!WIN || (int64_t)((b + 1) * 64 + shift) > x0) {
           st = kStDec;  // no cell <= k in the block (a window's block that ends inside its warm-up says nothing)
         }
@@ -1840,6 +1864,8 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
     L.cand_count = kp->cand_count;
     L.counters = kp->counters;
     L.dp_first_owned = kp->dp_first_owned;
+    L.stash = kp->stash;
+    L.stash_cap = kp->stash_cap;
     L.rev_n = 0;
     L.alpha = 0.0f;
     L.ov_steps = 0;

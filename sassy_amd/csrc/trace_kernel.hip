@@ -411,6 +411,14 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
     __syncthreads();
   }
 
+  unsigned long long tp0 = P.probe ? wall_clock64() : 0ull;
+  auto tick = [&](int slot) {
+    if (P.probe) {
+      const unsigned long long t = wall_clock64();
+      if (lane == 0) P.probe[(size_t)(blockIdx.x * 4 + wave) * 8 + slot] += t - tp0;  // (the wave's own row)
+      tp0 = t;
+    }
+  };
   for (uint32_t u = blockIdx.x * 4 + wave; u < count; u += n_waves) {
     uint32_t c = u;
     Candidate cd;
@@ -425,8 +433,19 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
       if (P.texts.n == 0 && P.rev_n == 0) {  // (the window does not depend on the rank)
         const Window Wp = report_window(P, cd, 0);
         const int wlp = (int)(Wp.we - Wp.o);
-        if ((int)lane < wlp) wpre = P.text[Wp.o - P.global_offset + lane];
-        have_wpre = true;
+        // the lane that made the report kept the block under it (TextStash): no walk through the page tables of a
+        // multi-GB text for 40 bytes
+        const uint8_t* src0 = P.text + (Wp.o - P.global_offset);
+        const uint32_t slot1 = (P.stash != nullptr && P.pattern_stride == 0) ? (cd.flags >> kCandTextShift) : 0u;
+        if (slot1 != 0 && slot1 <= P.stash_cap) {
+          const TextStash* ts = P.stash + (slot1 - 1u);
+          const uint64_t base = ts->base, orel = Wp.o - P.global_offset;
+          // (a window may begin in front of the buffer -- reference-lane searches hand in a pointer into a larger text)
+          if (Wp.o >= P.global_offset && orel >= base && orel + (uint64_t)wlp <= base + 64)
+            src0 = reinterpret_cast<const uint8_t*>(ts->text) + (orel - base);
+        }
+        if ((int)lane < wlp) wpre = src0[lane];
+        have_wpre = wlp <= 64;
       }
       // rank = reports with a smaller end position + (dedup) earlier copies of this very report: copies of one
       // position then fill consecutive slots, and every copy but the first is a kCandDrop record the host skips
@@ -459,15 +478,19 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
       // (count <= kTraceWaveMax = 8192 here: the two 16-bit fields cannot overflow)
       const uint32_t twins = r >> 16;
       c = (r & 0xFFFFu) + twins;
-      if (twins) cd.flags |= kCandDrop;
+      const bool drop = twins != 0 || (P.dedup && cd.pos < P.min_pos);
+      if (drop) cd.flags |= kCandDrop;
       if (lane == 0) {
         const_cast<Candidate*>(P.cand)[c] = cd;
         if (c < P.host_cap && P.host_cand) P.host_cand[c] = cd;
+        const uint32_t hf = (drop ? 4u : 0u) | ((cd.flags & kCandCond) ? 2u : 0u);
+        if (hf && P.host_flags) __hip_atomic_fetch_or(P.host_flags, hf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
-      if (twins) continue;
+      if (drop) continue;
     } else {
       cd = P.cand[c];                                      // wave-uniform
     }
+    tick(0);  // prologue (pattern, positions into LDS) + ranking
     Window W = report_window(P, cd, c);
     uint32_t pattern_idx = 0;
     if (P.pattern_stride) {  // many patterns: the flags' upper bits name the pattern, not a text (report_text does)
@@ -490,6 +513,7 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
       }
     }
     __builtin_amdgcn_wave_barrier();
+    tick(1);  // window
     const int dend = iend - m, dlo = dend - k - 1;
     const int b = (int)lane;
     const bool in_band = b < bw;
@@ -539,6 +563,7 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
     // make the band and the window visible to every lane (same wave: LDS ops are in order, this
     // only keeps the compiler from reordering)
     __builtin_amdgcn_wave_barrier();
+    tick(2);  // band fill
     // ---- greedy walk from (m, iend), wave-uniform ----
     int j = m, i = iend;
     int g = (int)L[(size_t)m * bw + (k + 1)];
@@ -584,6 +609,7 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
     if (ok && g != 0) ok = false;
     if (cost > cd.cost) ok = false;  // src/search.rs:1672-1685
     __builtin_amdgcn_wave_barrier();
+    tick(3);  // walk
     unsigned char* sbuf = ops + P.ops_bytes;
     uint32_t w = 0;
     if (lane == 0) w = rle_text(ops, nops, ok, sbuf);
@@ -603,9 +629,12 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
         const MatchOut r = make_row(P, c, W, o + (uint64_t)i, cost, w, ok, pattern_start, pattern_end, pattern_idx);
         P.out[c] = r;
         if (c < P.host_cap) P.host_out[c] = r;
+        if (!ok && P.host_flags) __hip_atomic_fetch_or(P.host_flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
     }
     __builtin_amdgcn_wave_barrier();  // the slice is reused by the next report
+    tick(4);  // cigar text + rows out
+    if (P.probe && lane == 0) P.probe[(size_t)(blockIdx.x * 4 + wave) * 8 + 7] += 1ull;
   }
 }
 
