@@ -97,6 +97,12 @@ int sassy_hip_device_count(void); /* number of visible HIP devices, 0 if none / 
  * carry pattern_start > 0 / pattern_end < pattern_len.  Overhang searches stream the full DP (the
  * pigeonhole prefilter does not cover partial patterns) and report nothing for an empty text. */
 sassy_SearcherType *sassy_hip_searcher_new(const char *alphabet, bool rc, float alpha);
+/* The HIP device a searcher works on.  A searcher binds itself to the calling thread's current device at its first
+ * search (HIP's current device is per host thread); sassy_hip_set_device chooses one before that.  From then on
+ * every entry point runs on that device, whatever thread calls it, and restores the thread's current device
+ * before it returns.  sassy_hip_get_device: -1 while unbound. */
+int sassy_hip_set_device(sassy_SearcherType *s, int device);
+int sassy_hip_get_device(const sassy_SearcherType *s);
 /* Use an existing HIP stream (hipStream_t) for all work of this searcher; NULL = own stream. */
 int sassy_hip_set_stream(sassy_SearcherType *s, void *hip_stream);
 int sassy_hip_get_stats(const sassy_SearcherType *s, sassy_hip_Stats *out);
@@ -207,6 +213,38 @@ uint64_t sassy_hip_required_halo(size_t pattern_len, size_t k);
  * While a ticket is open the searcher's synchronous entry points (sassy_hip_search, _search_shard, _search_many,
  * _search_encoded, _search_with_fn, the drop-in search) and sassy_hip_set_stream fail with SASSY_HIP_EINVAL: they
  * use the same streams and result buffers. */
+/* The results of consecutive shards of one text (results[0] the leftmost), merged into one: matches in text order
+ * with their cigars; a shard's conditional report (sassy_hip_result_conditional_index) is kept iff the plateau
+ * state arriving from the shards on its left is TRUE (exit states, PASS = "ask further left").  incoming_state is the
+ * state in front of results[0]: 1 (TRUE) when results[0] begins the text, 2 (PASS) when that is unknown -- then a
+ * conditional report of the first shards stays conditional in the merged result, whose exit state and conditional
+ * index make it a shard result again (merges nest).  This is what sassy_amd/multigpu.py does with gathered rows; a C
+ * or Rust host that searched its shards with sassy_hip_search_shard on several devices calls it directly. */
+int sassy_hip_merge_shards(const sassy_hip_Result *const *results, size_t n, int incoming_state, sassy_hip_Result **out);
+
+/* One text over several devices inside one process (the reference's thread fan-out, bin/grep.rs:476-503, with a
+ * GPU per thread): the text is cut into as many shards of whole 64-byte blocks as there are entries in `devices`
+ * (NULL / 0: every visible device; a device may be named more than once -- several shards on one GPU), every shard
+ * resident on its device with sassy_hip_required_halo(max_pattern_len, max_k) bytes of the text in front of it.  Each
+ * device has a host thread of its own: sassy_hip_multi_set_text uploads all shards at once (one PCIe link per
+ * device), sassy_hip_multi_search runs sassy_hip_search_shard on all devices at once and merges
+ * (sassy_hip_merge_shards).  Forward strand, like the shard calls; flags: SASSY_HIP_ALL_MINIMA,
+ * SASSY_HIP_WITHOUT_TRACE.  alpha = NAN (overhang needs the whole text in one buffer).  One call at a time per
+ * multi-searcher. */
+typedef struct sassy_hip_Multi sassy_hip_Multi;
+sassy_hip_Multi *sassy_hip_multi_new(const char *alphabet, float alpha, const int *devices, size_t n_devices);
+size_t sassy_hip_multi_shards(const sassy_hip_Multi *m);
+int sassy_hip_multi_device(const sassy_hip_Multi *m, size_t shard);
+sassy_SearcherType *sassy_hip_multi_searcher(sassy_hip_Multi *m, size_t shard); /* (for the setters; owned by m) */
+int sassy_hip_multi_set_text(sassy_hip_Multi *m, const uint8_t *text, size_t len, size_t max_pattern_len, size_t max_k);
+/* the synthetic text of sassy_hip_generate_dna / sassy_hip_plant, every device generating its own shard in place */
+int sassy_hip_multi_generate_dna(sassy_hip_Multi *m, uint64_t len, uint64_t seed, size_t max_pattern_len, size_t max_k);
+int sassy_hip_multi_plant(sassy_hip_Multi *m, uint64_t seed, const uint8_t *pattern, size_t pattern_len, size_t k,
+                          uint64_t stride, uint64_t *planted);
+int sassy_hip_multi_search(sassy_hip_Multi *m, const uint8_t *pattern, size_t pattern_len, size_t k, uint32_t flags,
+                           sassy_hip_Result **out);
+void sassy_hip_multi_free(sassy_hip_Multi *m);
+
 typedef struct sassy_hip_Ticket sassy_hip_Ticket;
 int sassy_hip_search_shard_begin(sassy_SearcherType *s, const uint8_t *pattern, size_t pattern_len,
                                  const uint8_t *d_text, uint64_t halo_len, uint64_t shard_len,

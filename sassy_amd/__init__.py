@@ -111,6 +111,10 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_result_cigars_len", "sassy_hip_pack_rows", "sassy_hip_enable_counters", "sassy_hip_set_timing",
     "sassy_hip_set_only_best_match", "sassy_hip_set_max_n_frac", "sassy_hip_search_with_fn",
     "sassy_hip_set_max_overhang", "sassy_hip_set_prefilter", "sassy_hip_set_fused",
+    "sassy_hip_set_device", "sassy_hip_get_device", "sassy_hip_merge_shards",
+    "sassy_hip_multi_new", "sassy_hip_multi_shards", "sassy_hip_multi_device", "sassy_hip_multi_searcher",
+    "sassy_hip_multi_set_text", "sassy_hip_multi_generate_dna", "sassy_hip_multi_plant", "sassy_hip_multi_search",
+    "sassy_hip_multi_free",
     "sassy_hip_search_many", "sassy_hip_tsv_header", "sassy_hip_format_tsv",
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
@@ -161,6 +165,30 @@ def lib():
     L.sassy_hip_set_prefilter.argtypes = [vp, C.c_int]
     L.sassy_hip_set_fused.restype = C.c_int
     L.sassy_hip_set_fused.argtypes = [vp, C.c_int]
+    L.sassy_hip_set_device.restype = C.c_int
+    L.sassy_hip_set_device.argtypes = [vp, C.c_int]
+    L.sassy_hip_get_device.restype = C.c_int
+    L.sassy_hip_get_device.argtypes = [vp]
+    L.sassy_hip_merge_shards.restype = C.c_int
+    L.sassy_hip_merge_shards.argtypes = [C.POINTER(vp), C.c_size_t, C.c_int, C.POINTER(vp)]
+    L.sassy_hip_multi_new.restype = vp
+    L.sassy_hip_multi_new.argtypes = [C.c_char_p, C.c_float, C.POINTER(C.c_int), C.c_size_t]
+    L.sassy_hip_multi_shards.restype = C.c_size_t
+    L.sassy_hip_multi_shards.argtypes = [vp]
+    L.sassy_hip_multi_device.restype = C.c_int
+    L.sassy_hip_multi_device.argtypes = [vp, C.c_size_t]
+    L.sassy_hip_multi_searcher.restype = vp
+    L.sassy_hip_multi_searcher.argtypes = [vp, C.c_size_t]
+    L.sassy_hip_multi_set_text.restype = C.c_int
+    L.sassy_hip_multi_set_text.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t]
+    L.sassy_hip_multi_generate_dna.restype = C.c_int
+    L.sassy_hip_multi_generate_dna.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_size_t, C.c_size_t]
+    L.sassy_hip_multi_plant.restype = C.c_int
+    L.sassy_hip_multi_plant.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.sassy_hip_multi_search.restype = C.c_int
+    L.sassy_hip_multi_search.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(vp)]
+    L.sassy_hip_multi_free.restype = None
+    L.sassy_hip_multi_free.argtypes = [vp]
     L.sassy_hip_set_only_best_match.restype = C.c_int
     L.sassy_hip_set_only_best_match.argtypes = [vp, C.c_int]
     L.sassy_hip_set_max_overhang.restype = C.c_int
@@ -569,6 +597,15 @@ class Searcher:
         _check(lib().sassy_hip_set_prefilter(self._h, int(mode)))
         return self
 
+    def set_device(self, device: int):
+        """Bind the searcher to a HIP device before its first search (default: the calling thread's current device)."""
+        _check(lib().sassy_hip_set_device(self._h, int(device)))
+        return self
+
+    @property
+    def device(self) -> int:
+        return lib().sassy_hip_get_device(self._h)
+
     def set_fused(self, on: bool = True):
         """The bit-plane prefilter finishes the scan in its own launch (default) / always the classic kernel chain."""
         _check(lib().sassy_hip_set_fused(self._h, int(bool(on))))
@@ -603,6 +640,65 @@ class Searcher:
 
 def required_halo(pattern_len: int, k: int) -> int:
     return lib().sassy_hip_required_halo(pattern_len, k)
+
+
+def merge_shards(results: Sequence["Result"], incoming_state: int = 1) -> "Result":
+    """sassy_hip_merge_shards: the Results of consecutive shards (leftmost first) as one Result."""
+    L = lib()
+    hs = (C.c_void_p * len(results))(*[r._h for r in results])
+    if any(h is None for h in hs):
+        raise SassyHipError("merge_shards needs results that have not been materialised yet (their C records)")
+    out = C.c_void_p()
+    _check(L.sassy_hip_merge_shards(hs, len(results), int(incoming_state), C.byref(out)))
+    return Result(out)
+
+
+class MultiSearcher:
+    """One text over several devices inside one process (include/sassy_hip.h: sassy_hip_multi_*): a shard and a host
+    thread per entry of `devices` (None: every visible device; a device may be named more than once)."""
+
+    def __init__(self, alphabet: str, devices: Optional[Sequence[int]] = None, alpha: float = float("nan")):
+        L = lib()
+        arr = (C.c_int * len(devices))(*devices) if devices else None
+        self._h = L.sassy_hip_multi_new(alphabet.encode(), alpha, arr, len(devices) if devices else 0)
+        if not self._h:
+            raise SassyHipError(L.sassy_hip_last_error().decode())
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                lib().sassy_hip_multi_free(h)
+            except Exception:
+                pass
+
+    @property
+    def shards(self) -> int:
+        return lib().sassy_hip_multi_shards(self._h)
+
+    def devices(self) -> List[int]:
+        return [lib().sassy_hip_multi_device(self._h, i) for i in range(self.shards)]
+
+    def set_text(self, text: bytes, max_pattern_len: int, max_k: int):
+        text = bytes(text)
+        _check(lib().sassy_hip_multi_set_text(self._h, text, len(text), max_pattern_len, max_k))
+        return self
+
+    def generate_dna(self, n: int, seed: int, max_pattern_len: int, max_k: int):
+        _check(lib().sassy_hip_multi_generate_dna(self._h, n, seed, max_pattern_len, max_k))
+        return self
+
+    def plant(self, seed: int, pattern: bytes, k: int, stride: int = 1 << 20) -> int:
+        cnt = C.c_uint64()
+        pattern = bytes(pattern)
+        _check(lib().sassy_hip_multi_plant(self._h, seed, pattern, len(pattern), k, stride, C.byref(cnt)))
+        return cnt.value
+
+    def search(self, pattern: bytes, k: int, flags: int = 0) -> "Result":
+        out = C.c_void_p()
+        pattern = bytes(pattern)
+        _check(lib().sassy_hip_multi_search(self._h, pattern, len(pattern), k, flags, C.byref(out)))
+        return Result(out)
 
 
 def generate_dna(d_ptr: int, n: int, seed: int, first: int = 0, stream: int = 0):

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <functional>
 #include <iterator>
+#include <condition_variable>
 #include <memory>
 #include <mutex>
 #include <cmath>
@@ -424,6 +425,10 @@ struct sassy_SearcherType {
   hipStream_t user_stream = nullptr;
   hipEvent_t ev_inputs = nullptr;  // "uploads of this call are queued" (other lanes wait for it)
   bool device_ready = false;
+  // The HIP device all of this searcher's streams, buffers and launches live on: the calling thread's current device at
+  // the searcher's first search (HIP's current device is per host thread), or sassy_hip_set_device before it.  Every
+  // entry point switches to it for the duration of the call (DeviceGuard), whatever thread it is called from.
+  int device = -1;
   DevBuf<uint8_t> d_text, d_rev;
   DevBuf<unsigned long long> d_rc_bitmap;  // the Rc strand's candidate blocks, marked by the forward pass
   // search_many lays its texts out in pinned host memory (no zero fill, H2D at the PCIe rate, reused
@@ -3186,6 +3191,19 @@ static bool tickets_open(const sassy_SearcherType* s) {
     if (t) return true;
   return false;
 }
+// Runs the rest of the scope on the searcher's device and restores the thread's current device afterwards.
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(sassy_SearcherType* s) {
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (s->device < 0) s->device = cur;  // first use binds the searcher
+    if (s->device != cur && hipSetDevice(s->device) == hipSuccess) prev = cur;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
 #define SASSY_NO_TICKETS(s)                                                                                              \
   do {                                                                                                                   \
     if (tickets_open(s))                                                                                                 \
@@ -3259,12 +3277,27 @@ sassy_SearcherType* sassy_searcher(const char* alphabet, bool rc, float alpha) {
 
 void sassy_searcher_free(sassy_SearcherType* ptr) {
   if (!ptr) die("Pointer to SearcherType must not be null");  // src/c.rs:75-77
+  DeviceGuard on_device(ptr);
   delete ptr;
 }
+
+int sassy_hip_set_device(sassy_SearcherType* s, int device) {
+  if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
+  if (s->device_ready && s->device != device) return fail(SASSY_HIP_EINVAL, "the searcher already works on another device");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
+    (void)hipGetLastError();
+    return fail(SASSY_HIP_EINVAL, "no such HIP device");
+  }
+  s->device = device;
+  return 0;
+}
+int sassy_hip_get_device(const sassy_SearcherType* s) { return s ? s->device : -1; }
 
 int sassy_hip_set_stream(sassy_SearcherType* s, void* hip_stream) {
   if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
   SASSY_NO_TICKETS(s);
+  DeviceGuard on_device(s);
   ScanLane& l0 = s->lanes[0];
   if (l0.own_stream && l0.stream) (void)hipStreamDestroy(l0.stream);
   s->user_stream = reinterpret_cast<hipStream_t>(hip_stream);
@@ -3347,6 +3380,7 @@ int sassy_hip_search_with_fn(sassy_SearcherType* s, const uint8_t* pattern, size
                              sassy_hip_end_filter fn, void* user, sassy_hip_Result** out) {
   if (!s || !pattern || (!text && text_len) || !out || !fn) return fail(SASSY_HIP_EINVAL, "Pointers in search() must not be null");
   SASSY_NO_TICKETS(s);
+  DeviceGuard on_device(s);
   if (flags & SASSY_HIP_TEXT_ON_DEVICE) return fail(SASSY_HIP_EINVAL, "search_with_fn needs the text in host memory");
   const double t0 = now_ms();
   reset_stats(s);
@@ -3778,6 +3812,7 @@ int sassy_hip_search_many(sassy_SearcherType* s, const uint8_t* const* patterns,
   if (!s || !out || (n_patterns && (!patterns || !pattern_lens)) || (n_texts && (!texts || !text_lens)))
     return fail(SASSY_HIP_EINVAL, "null argument");
   SASSY_NO_TICKETS(s);
+  DeviceGuard on_device(s);
   if (s->rc && s->profile == PROFILE_ASCII && n_patterns && n_texts)  // as in search_text: the reference panics here
     return fail(SASSY_HIP_EUNSUPPORTED, "reverse complement is not defined for the ascii alphabet");
   const double t0 = now_ms();
@@ -3915,6 +3950,7 @@ int sassy_hip_search(sassy_SearcherType* s, const uint8_t* pattern, size_t patte
                      sassy_hip_Result** out) {
   if (!s || !pattern || (!text && text_len) || !out) return fail(SASSY_HIP_EINVAL, "Pointers in search() must not be null");
   SASSY_NO_TICKETS(s);
+  DeviceGuard on_device(s);
   const double t0 = now_ms();
   reset_stats(s);
   sassy_hip_Result* R = new sassy_hip_Result();
@@ -3940,6 +3976,7 @@ int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t
                            sassy_hip_Result** out) {
   if (!s || !pattern || !d_text || !out) return fail(SASSY_HIP_EINVAL, "null argument");
   SASSY_NO_TICKETS(s);
+  DeviceGuard on_device(s);
   if (halo_len % 64 || global_offset % 64) return fail(SASSY_HIP_EINVAL, "halo_len and global_offset must be multiples of 64");
   if (global_offset < halo_len) return fail(SASSY_HIP_EINVAL, "halo reaches left of the text start");
   if (global_offset + shard_len > total_len) return fail(SASSY_HIP_EINVAL, "shard exceeds the text");
@@ -3974,6 +4011,283 @@ int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t
   return 0;
 }
 
+// ---- several shards -> one result (the chain of DESIGN.md "seams", one level up) ----
+int sassy_hip_merge_shards(const sassy_hip_Result* const* results, size_t n, int incoming_state, sassy_hip_Result** out) {
+  if ((!results && n) || !out) return fail(SASSY_HIP_EINVAL, "null argument");
+  if (incoming_state < 0 || incoming_state > 2) return fail(SASSY_HIP_EINVAL, "incoming_state must be 0 (FALSE), 1 (TRUE) or 2 (PASS)");
+  std::unique_ptr<sassy_hip_Result> R(new sassy_hip_Result());
+  size_t total = 0, pool_total = 0;
+  for (size_t i = 0; i < n; ++i) {
+    if (!results[i]) return fail(SASSY_HIP_EINVAL, "null shard result");
+    total += results[i]->size();
+    pool_total += results[i]->pool_size();
+  }
+  R->matches.reserve(total);
+  int incoming = incoming_state;  // decreasing-state arriving at the left edge of shard i
+  for (size_t i = 0; i < n; ++i) {
+    const sassy_hip_Result* r = results[i];
+    const sassy_hip_Match* m = r->data();
+    const char* pool = r->pool_data();
+    for (size_t j = 0; j < r->size(); ++j) {
+      if ((int64_t)j == r->conditional_index) {
+        // this report's plateau began left of the shard: it stands iff the plateau was entered by a decrease
+        if (incoming == kStateDecFalse) continue;
+        if (incoming == kStatePass) {  // nobody to the left of results[0] could tell: still conditional in the merged result
+          if (R->conditional_index >= 0) return fail(SASSY_HIP_EINVAL, "two reports depend on the shard in front of the first one");
+          R->conditional_index = (int64_t)R->matches.size();
+        }
+      }
+      sassy_hip_Match x = m[j];
+      const size_t off = R->pool.size();
+      if (off + x.cigar_len + 1 > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB");
+      R->pool.append(pool + x.cigar_off, x.cigar_len);
+      R->pool.push_back('\0');
+      x.cigar_off = (uint32_t)off;
+      R->matches.push_back(x);
+    }
+    if (r->exit_state != kStatePass) incoming = r->exit_state;
+  }
+  (void)pool_total;
+  if (R->pool.empty()) R->pool.push_back('\0');
+  R->exit_state = incoming;
+  *out = R.release();
+  return 0;
+}
+
+}  // extern "C"
+
+// ---- one text over several devices, inside one process (reference: the thread fan-out of bin/grep.rs:476-503) ----
+// A worker thread per device, alive as long as the multi-searcher: HIP's current device is per thread, and a search
+// of a resident text takes less time than starting a thread.
+struct MultiWorker {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has_job = false, done = true, quit = false;
+  void start(int device) {
+    th = std::thread([this, device] {
+      (void)hipSetDevice(device);
+      std::unique_lock<std::mutex> lk(mu);
+      for (;;) {
+        cv.wait(lk, [this] { return has_job || quit; });
+        if (quit) return;
+        std::function<void()> j = std::move(job);
+        has_job = false;
+        lk.unlock();
+        j();
+        lk.lock();
+        done = true;
+        cv.notify_all();
+      }
+    });
+  }
+  void submit(std::function<void()> j) {
+    std::lock_guard<std::mutex> lk(mu);
+    job = std::move(j);
+    has_job = true;
+    done = false;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return done; });
+  }
+  void stop() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+      cv.notify_all();
+    }
+    if (th.joinable()) th.join();
+  }
+};
+
+struct sassy_hip_Multi {
+  struct Part {
+    int device = 0;
+    sassy_SearcherType* searcher = nullptr;
+    uint8_t* d_text = nullptr;       // halo first
+    size_t d_cap = 0;
+    uint64_t halo = 0, len = 0, offset = 0;  // bytes in front of the shard, shard length, its global offset
+    std::unique_ptr<MultiWorker> worker;
+    int rc = 0;
+    std::string err;
+    sassy_hip_Result* result = nullptr;
+  };
+  std::vector<Part> parts;
+  uint64_t total_len = 0;
+  uint64_t halo_for = 0;  // the resident shards carry halos good for searches with required_halo(m, k) <= this
+  bool have_text = false;
+  ~sassy_hip_Multi() {
+    for (Part& p : parts) {
+      if (p.worker) p.worker->stop();
+      int prev = 0;
+      (void)hipGetDevice(&prev);
+      (void)hipSetDevice(p.device);
+      if (p.d_text) (void)hipFree(p.d_text);
+      if (p.searcher) delete p.searcher;
+      (void)hipSetDevice(prev);
+    }
+  }
+  // runs f(part) on every part's worker thread (on its device) and waits for all of them; first error wins
+  int on_all(const std::function<int(Part&)>& f) {
+    for (Part& p : parts) {
+      Part* pp = &p;
+      p.worker->submit([pp, &f] {
+        pp->rc = f(*pp);
+        pp->err = pp->rc ? g_err : std::string();  // (g_err is thread-local: carry it over to the caller's thread)
+      });
+    }
+    int first = 0;
+    for (Part& p : parts) {
+      p.worker->wait();
+      if (p.rc && !first) { first = p.rc; g_err = "device " + std::to_string(p.device) + ": " + p.err; }
+    }
+    return first;
+  }
+  // [a, b) of shard i: equal shares of whole 64-byte blocks (sassy_amd/multigpu.py: shard_bounds)
+  void bounds(size_t i, uint64_t& a, uint64_t& b) const {
+    const uint64_t n = parts.size();
+    uint64_t per = (total_len + n - 1) / n;
+    per = (per + 63) / 64 * 64;
+    a = std::min<uint64_t>(i * per, total_len);
+    b = std::min<uint64_t>((i + 1) * per, total_len);
+  }
+  int layout(uint64_t len, size_t max_m, size_t max_k) {
+    total_len = len;
+    halo_for = sassy_hip_required_halo(max_m, max_k);
+    for (size_t i = 0; i < parts.size(); ++i) {
+      uint64_t a, b;
+      bounds(i, a, b);
+      parts[i].offset = a;
+      parts[i].len = b - a;
+      parts[i].halo = (i == 0 || a == 0) ? 0 : std::min<uint64_t>(halo_for, a);
+      parts[i].halo = parts[i].halo / 64 * 64;
+    }
+    return 0;
+  }
+  static int reserve(Part& p, size_t bytes) {
+    if (bytes <= p.d_cap) return 0;
+    if (p.d_text) (void)hipFree(p.d_text);
+    p.d_text = nullptr;
+    p.d_cap = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p.d_text), bytes + 256);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc (text shard)");
+    p.d_cap = bytes;
+    return 0;
+  }
+};
+
+extern "C" {
+
+sassy_hip_Multi* sassy_hip_multi_new(const char* alphabet, float alpha, const int* devices, size_t n_devices) {
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0) {
+    (void)hipGetLastError();
+    fail(SASSY_HIP_ENODEVICE, "no usable HIP device (libsassy_hip has no CPU fallback)");
+    return nullptr;
+  }
+  std::vector<int> devs;
+  if (devices && n_devices) devs.assign(devices, devices + n_devices);
+  else for (int d = 0; d < visible; ++d) devs.push_back(d);
+  for (int d : devs)
+    if (d < 0 || d >= visible) { fail(SASSY_HIP_EINVAL, "no such HIP device"); return nullptr; }
+  std::unique_ptr<sassy_hip_Multi> M(new sassy_hip_Multi());
+  M->parts.resize(devs.size());
+  for (size_t i = 0; i < devs.size(); ++i) {
+    sassy_hip_Multi::Part& p = M->parts[i];
+    p.device = devs[i];
+    p.searcher = sassy_hip_searcher_new(alphabet, false, alpha);  // (shards are forward searches, like sassy_hip_search_shard)
+    if (!p.searcher) return nullptr;
+    p.searcher->device = devs[i];
+    p.worker.reset(new MultiWorker());
+    p.worker->start(devs[i]);
+  }
+  return M.release();
+}
+
+size_t sassy_hip_multi_shards(const sassy_hip_Multi* m) { return m ? m->parts.size() : 0; }
+int sassy_hip_multi_device(const sassy_hip_Multi* m, size_t shard) { return (m && shard < m->parts.size()) ? m->parts[shard].device : -1; }
+sassy_SearcherType* sassy_hip_multi_searcher(sassy_hip_Multi* m, size_t shard) {
+  return (m && shard < m->parts.size()) ? m->parts[shard].searcher : nullptr;
+}
+
+int sassy_hip_multi_set_text(sassy_hip_Multi* m, const uint8_t* text, size_t len, size_t max_pattern_len, size_t max_k) {
+  if (!m || (!text && len)) return fail(SASSY_HIP_EINVAL, "null argument");
+  m->layout(len, max_pattern_len, max_k);
+  m->have_text = false;
+  // every device fetches its own shard (halo included) over its own PCIe link, all at the same time
+  const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
+    const size_t bytes = (size_t)(p.halo + p.len);
+    if (int r = sassy_hip_Multi::reserve(p, bytes)) return r;
+    if (bytes) HIP_TRY(hipMemcpy(p.d_text, text + (p.offset - p.halo), bytes, hipMemcpyHostToDevice));
+    return 0;
+  });
+  if (rc) return rc;
+  m->have_text = true;
+  return 0;
+}
+
+int sassy_hip_multi_generate_dna(sassy_hip_Multi* m, uint64_t len, uint64_t seed, size_t max_pattern_len, size_t max_k) {
+  if (!m) return fail(SASSY_HIP_EINVAL, "null argument");
+  m->layout(len, max_pattern_len, max_k);
+  m->have_text = false;
+  const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
+    const size_t bytes = (size_t)(p.halo + p.len);
+    if (int r = sassy_hip_Multi::reserve(p, bytes)) return r;
+    if (bytes)
+      if (int r = sassy_hip_generate_dna(p.d_text, bytes, seed, p.offset - p.halo, nullptr)) return r;
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+  });
+  if (rc) return rc;
+  m->have_text = true;
+  return 0;
+}
+
+int sassy_hip_multi_plant(sassy_hip_Multi* m, uint64_t seed, const uint8_t* pattern, size_t pattern_len, size_t k, uint64_t stride,
+                          uint64_t* planted) {
+  if (!m || !pattern || !m->have_text) return fail(SASSY_HIP_EINVAL, "no resident text");
+  std::vector<uint64_t> cnt(m->parts.size(), 0);
+  const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
+    const size_t i = (size_t)(&p - m->parts.data());
+    const size_t bytes = (size_t)(p.halo + p.len);
+    if (!bytes) return 0;
+    if (int r = sassy_hip_plant(p.d_text, bytes, p.offset - p.halo, m->total_len, seed, pattern, pattern_len, k, stride, nullptr, &cnt[i]))
+      return r;
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+  });
+  if (rc) return rc;
+  if (planted) {  // (plants inside a halo are counted by the shard that owns them: positions are global)
+    *planted = m->total_len / std::max<uint64_t>(1, stride);
+  }
+  return 0;
+}
+
+int sassy_hip_multi_search(sassy_hip_Multi* m, const uint8_t* pattern, size_t pattern_len, size_t k, uint32_t flags,
+                           sassy_hip_Result** out) {
+  if (!m || !pattern || !out) return fail(SASSY_HIP_EINVAL, "null argument");
+  if (!m->have_text) return fail(SASSY_HIP_EINVAL, "no resident text (sassy_hip_multi_set_text)");
+  if (sassy_hip_required_halo(pattern_len, k) > m->halo_for && m->parts.size() > 1)
+    return fail(SASSY_HIP_EINVAL, "the resident shards' halos are too short for this pattern length and k");
+  const uint32_t f = flags & (SASSY_HIP_ALL_MINIMA | SASSY_HIP_WITHOUT_TRACE);
+  const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
+    p.result = nullptr;
+    if (p.len == 0) { p.result = new sassy_hip_Result(); return 0; }
+    return sassy_hip_search_shard(p.searcher, pattern, pattern_len, p.d_text, p.halo, p.len, p.offset, m->total_len, k, f, &p.result);
+  });
+  std::vector<const sassy_hip_Result*> rs;
+  for (sassy_hip_Multi::Part& p : m->parts) rs.push_back(p.result);
+  int mrc = rc;
+  if (!mrc) mrc = sassy_hip_merge_shards(rs.data(), rs.size(), kStateDecTrue, out);
+  for (sassy_hip_Multi::Part& p : m->parts) { delete p.result; p.result = nullptr; }
+  return mrc;
+}
+
+void sassy_hip_multi_free(sassy_hip_Multi* m) { delete m; }
+
 // ---- searches in flight: begin / finish ----
 // A stream of searches over a resident text (many patterns against one genome) is pipelined on the device:
 // up to SASSY_HIP_PIPE_DEPTH (default 2, at most 4) searches are in flight, each on a lane (stream + buffers)
@@ -3985,6 +4299,7 @@ int sassy_hip_search_shard_begin(sassy_SearcherType* s, const uint8_t* pattern, 
                                  uint64_t global_offset, uint64_t total_len, size_t k, uint32_t flags,
                                  sassy_hip_Ticket** out) {
   if (!s || !pattern || !d_text || !out) return fail(SASSY_HIP_EINVAL, "null argument");
+  DeviceGuard on_device(s);
   if (halo_len % 64 || global_offset % 64) return fail(SASSY_HIP_EINVAL, "halo_len and global_offset must be multiples of 64");
   if (global_offset < halo_len) return fail(SASSY_HIP_EINVAL, "halo reaches left of the text start");
   if (global_offset + shard_len > total_len) return fail(SASSY_HIP_EINVAL, "shard exceeds the text");
@@ -4045,6 +4360,7 @@ int sassy_hip_search_shard_begin(sassy_SearcherType* s, const uint8_t* pattern, 
 
 int sassy_hip_search_finish(sassy_SearcherType* s, sassy_hip_Ticket* t, sassy_hip_Result** out) {
   if (!s || !t || t->owner != s) return fail(SASSY_HIP_EINVAL, "not a ticket of this searcher");
+  DeviceGuard on_device(s);
   std::unique_ptr<sassy_hip_Ticket> guard(t);
   s->lane_ticket[t->lane] = nullptr;
   reset_stats(s);
@@ -4163,6 +4479,7 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
                              size_t text_len, size_t k, uint32_t flags, sassy_hip_Result** out) {
   if (!s || !e || (!text && text_len) || !out) return fail(SASSY_HIP_EINVAL, "null argument");
   SASSY_NO_TICKETS(s);
+  DeviceGuard on_device(s);
   const double t0 = now_ms();
   reset_stats(s);
   if (int rc = s->ensure_device()) return rc;

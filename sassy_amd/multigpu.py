@@ -222,13 +222,12 @@ class GatherError(RuntimeError):
 
 
 class MatchGather:
-    """The same exchange set up once for a stream of searches (bench.py): every rank's header and rows
-    travel in ONE collective of fixed size (all_gather: every rank sees every header) through pinned
-    staging buffers; no per-call allocation, no second round for the sizes.  The capacity is not
-    derived from the workload: when some rank has more rows than fit, every rank sees that in the
-    headers, all of them grow to the next power of two that holds the largest list, and the exchange
-    of that search is repeated -- after the first few searches of a stream it never happens again.
-    Only rank 0 copies the rows to the host; the others read the headers.
+    """The same exchange set up once for a stream of searches (bench.py): the four-word headers of all ranks go to
+    all ranks (one tiny all_gather: every rank must see every count, exit state and error flag to grow and to fail
+    together), the match rows only to rank 0 (one gather of as many rows as the longest list holds) -- no rank but the
+    merging one receives anybody's rows.  Pinned staging buffers, no per-call allocation.  The capacity is not
+    derived from the workload: when some rank has more rows than fit, every rank sees that in the headers and all of
+    them grow to the next power of two that holds the largest list before the rows move.
 
     cigar_bytes: width of the cigar field, cigar_bytes_for(m, k) of the searches to come."""
 
@@ -240,75 +239,85 @@ class MatchGather:
         self.pin = device.type == "cuda"
         self.copied = torch.cuda.Event() if self.pin else None
         self.regrown = 0
+        self.head_stage = torch.empty(HEAD_WORDS, dtype=torch.int64, pin_memory=self.pin)
+        self.head_np = self.head_stage.numpy()
+        self.head_dev = torch.empty(HEAD_WORDS, dtype=torch.int64, device=device)
+        self.heads_dev = torch.empty((self.world, HEAD_WORDS), dtype=torch.int64, device=device)
+        self.heads_host = torch.empty((self.world, HEAD_WORDS), dtype=torch.int64, pin_memory=self.pin)
+        self.heads_np = self.heads_host.numpy()
         self._alloc(max(1, int(capacity_rows)))
 
     def _alloc(self, cap: int):
         torch = self.torch
         self.cap = cap
-        self.words = HEAD_WORDS + cap * self.cols
-        self.stage = torch.empty(self.words, dtype=torch.int64, pin_memory=self.pin)
-        self.stage_np = self.stage.numpy()
-        self.rows_np = self.stage_np[HEAD_WORDS:].reshape(cap, self.cols)
-        self.dev = torch.empty(self.words, dtype=torch.int64, device=self.device)
-        self.all_dev = torch.empty((self.world, self.words), dtype=torch.int64, device=self.device)
-        self.heads_host = torch.empty((self.world, HEAD_WORDS), dtype=torch.int64, pin_memory=self.pin)
-        self.heads_np = self.heads_host.numpy()
+        self.stage = torch.empty(cap * self.cols, dtype=torch.int64, pin_memory=self.pin)
+        self.rows_np = self.stage.numpy().reshape(cap, self.cols)
+        self.dev = torch.empty(cap * self.cols, dtype=torch.int64, device=self.device)
         if self.rank == 0:
-            self.all_host = torch.empty((self.world, self.words), dtype=torch.int64, pin_memory=self.pin)
+            self.all_dev = torch.empty((self.world, cap * self.cols), dtype=torch.int64, device=self.device)
+            self.all_host = torch.empty((self.world, cap * self.cols), dtype=torch.int64, pin_memory=self.pin)
             self.all_np = self.all_host.numpy()
 
-    def _exchange(self):
+    def _all_gather_heads(self):
         d = self.dist
         if hasattr(d, "all_gather_into_tensor"):
             try:
-                d.all_gather_into_tensor(self.all_dev.view(-1), self.dev)
+                d.all_gather_into_tensor(self.heads_dev.view(-1), self.head_dev)
                 return
             except (RuntimeError, NotImplementedError):  # a backend without the flat form
                 pass
-        d.all_gather(list(self.all_dev.unbind(0)), self.dev)
+        d.all_gather(list(self.heads_dev.unbind(0)), self.head_dev)
 
     def gather(self, local, error: bool = False) -> Optional[List[ShardResult]]:
         """local: a ShardResult or a sassy_amd.Result (packed straight into the staging buffer), or
         None with error=True (this rank failed before the exchange: all ranks raise GatherError)."""
-        while True:
-            if self.copied is not None:
-                self.copied.synchronize()  # the previous call's upload has left the staging buffer
-            n, state, cond = 0, STATE_PASS, -1
-            if local is not None and not error:
-                try:
-                    n, state, cond = len(local), local.exit_state, local.conditional_index
-                    if n <= self.cap:
-                        if isinstance(local, ShardResult):
-                            self.rows_np[:n] = widen_rows(local.rows, self.cols)
-                        else:
-                            pack_result(local, out=self.rows_np)
-                except Exception:  # keep the collective going: the header tells everybody
-                    error = True
-            self.stage_np[0], self.stage_np[1], self.stage_np[2], self.stage_np[3] = n, state, cond, 1 if error else 0
-            self.dev.copy_(self.stage, non_blocking=True)
-            if self.copied is not None:
-                self.copied.record()
-            self._exchange()
-            self.heads_host.copy_(self.all_dev[:, :HEAD_WORDS])  # synchronous device -> host copy
-            if int(self.heads_np[:, 3].max()) != 0:
-                bad = [r for r in range(self.world) if self.heads_np[r, 3]]
-                raise GatherError(f"rank(s) {bad} reported an error before the match exchange")
-            need = int(self.heads_np[:, 0].max())
-            if need <= self.cap:
-                break
+        if self.copied is not None:
+            self.copied.synchronize()  # the previous call's upload has left the staging buffers
+        n, state, cond = 0, STATE_PASS, -1
+        packed = False
+        if local is not None and not error:
+            try:
+                n, state, cond = len(local), local.exit_state, local.conditional_index
+            except Exception:  # keep the collectives going: the header tells everybody
+                error = True
+        self.head_np[0], self.head_np[1], self.head_np[2], self.head_np[3] = n, state, cond, 1 if error else 0
+        self.head_dev.copy_(self.head_stage, non_blocking=True)
+        self._all_gather_heads()
+        self.heads_host.copy_(self.heads_dev)  # synchronous device -> host copy
+        if int(self.heads_np[:, 3].max()) != 0:
+            bad = [r for r in range(self.world) if self.heads_np[r, 3]]
+            raise GatherError(f"rank(s) {bad} reported an error before the match exchange")
+        need = int(self.heads_np[:, 0].max())
+        if need > self.cap:  # every rank sees the same headers: all grow alike
             cap = self.cap
             while cap < need:
                 cap *= 2
-            self._alloc(cap)  # every rank sees the same headers: all grow alike and repeat
+            self._alloc(cap)
             self.regrown += 1
+        if need > 0:
+            words = need * self.cols
+            if n:
+                if isinstance(local, ShardResult):
+                    self.rows_np[:n] = widen_rows(local.rows, self.cols)
+                else:
+                    pack_result(local, out=self.rows_np)
+                packed = True
+            self.dev[:words].copy_(self.stage[:words], non_blocking=True)
+            if self.copied is not None:
+                self.copied.record()
+            # the rows travel to rank 0 only
+            bufs = [self.all_dev[r, :words] for r in range(self.world)] if self.rank == 0 else None
+            self.dist.gather(self.dev[:words], gather_list=bufs, dst=0)
+        del packed
         if self.rank != 0:
             return None
-        self.all_host.copy_(self.all_dev)
         out = []
+        if need > 0:
+            self.all_host[:, : need * self.cols].copy_(self.all_dev[:, : need * self.cols])
         for r in range(self.world):
-            cnt = int(self.all_np[r, 0])
-            rows = self.all_np[r, HEAD_WORDS:HEAD_WORDS + cnt * self.cols].reshape(cnt, self.cols)
-            out.append(ShardResult(rows, int(self.all_np[r, 1]), int(self.all_np[r, 2])))
+            cnt = int(self.heads_np[r, 0])
+            rows = self.all_np[r, : cnt * self.cols].reshape(cnt, self.cols)
+            out.append(ShardResult(rows, int(self.heads_np[r, 1]), int(self.heads_np[r, 2])))
         return out
 
 

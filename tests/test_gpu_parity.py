@@ -2225,3 +2225,129 @@ def test_synchronous_calls_are_refused_while_a_ticket_is_open(sassy):
     assert_same(s.search_finish(t).matches, want)
     assert_same(s.search(pat, text, 3), want)
     buf.free()
+
+
+# ------------------------------------------------------------------ several shards / devices through the C-ABI
+def _shard_results(sassy, s, buf, n, pat, k, bounds):
+    halo = sassy.required_halo(len(pat), k)
+    rs = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        h = 0 if a == 0 else halo
+        rs.append(s.search_shard(pat, buf.ptr + a - h, h, b - a, a, n, k))
+    return rs
+
+
+def test_merge_shards_in_c_equals_python_merge_and_oracle(sassy):
+    """sassy_hip_merge_shards (the TRUE / FALSE / PASS chain in C) on the seam fixtures: a plateau that runs across
+    several shard borders, plants on the borders, a poly-A text; equal to multigpu.merge_shard_results on the packed
+    rows and to the oracle's search of the whole text; merges nest (incoming_state = PASS)."""
+    from sassy_amd import multigpu
+    rng = random.Random(91)
+    cases = []
+    pat = b"A" * 20
+    text = b"G" * 1000 + b"A" * 90 + b"C" + b"A" * 20000 + b"G" * 3000
+    cases.append((pat, text, 3, [0, 64 * 40, 64 * 100, 64 * 200, len(text)]))
+    cases.append((b"A" * 24, b"A" * 30000, 2, [0, 64 * 10, 64 * 11, 64 * 300, 30000]))
+    p2 = rand_seq(rng, 32)
+    t2 = bytearray(rand_seq(rng, 200_000))
+    b2 = [0, 64 * 500, 64 * 1000, 64 * 1001, 64 * 2500, len(t2)]
+    for b in b2[1:-1]:
+        for off in (-45, -31, -2, 7):
+            ins = mutate(rng, p2, rng.randrange(4))
+            t2[b + off:b + off + len(ins)] = ins
+    cases.append((p2, bytes(t2[:200_000]), 3, b2))
+    s = sassy.Searcher("dna", rc=False)
+    for ci, (pat, text, k, bounds) in enumerate(cases):
+        n = len(text)
+        buf = sassy.DeviceBuffer(n + 256)
+        buf.upload(text)
+        want = oracle.search("dna", pat, text, k)
+        rs = _shard_results(sassy, s, buf, n, pat, k, bounds)
+        py_rows = multigpu.merge_shard_results([multigpu.pack_result(r) for r in rs])
+        rs = _shard_results(sassy, s, buf, n, pat, k, bounds)  # (pack_result materialised the first set)
+        merged = sassy.merge_shards(rs, incoming_state=1)
+        assert merged.conditional_index == -1
+        assert_same(merged.matches, want, ("c merge", ci))
+        assert [int(x) for x in py_rows[:, 2]] == [m.text_end for m in want], ("python merge", ci)
+        # nested: the right part merged first with an unknown left neighbour, then joined to the left part
+        rs = _shard_results(sassy, s, buf, n, pat, k, bounds)
+        right = sassy.merge_shards(rs[2:], incoming_state=2)
+        both = sassy.merge_shards([sassy.merge_shards(rs[:2], incoming_state=1), right], incoming_state=1)
+        assert_same(both.matches, want, ("nested merge", ci))
+        buf.free()
+
+
+def test_multi_searcher_shards_on_one_gpu(sassy):
+    """sassy_hip_multi_*: the in-process multi-device searcher with several shards on the one GPU of the test box (a
+    device may be named more than once): host text split with halos and uploaded by one thread per shard, searched by
+    all shards at once, merged in C -- equal to the oracle, with a plateau across the shard borders, search_all,
+    without_trace, a synthetic text generated shard by shard, and a search from another host thread."""
+    import threading
+    rng = random.Random(92)
+    ms = sassy.MultiSearcher("dna", devices=[0, 0, 0])
+    assert ms.shards == 3 and ms.devices() == [0, 0, 0]
+    pat = rand_seq(rng, 32)
+    n = 300_000 + 17
+    t = bytearray(rand_seq(rng, n))
+    per = -(-(-(-n // 3)) // 64) * 64
+    for b in (per, 2 * per):
+        for off in (-40, -20, -1, 3):
+            ins = mutate(rng, pat, rng.randrange(4))
+            t[b + off:b + off + len(ins)] = ins
+    for _ in range(100):
+        ins = mutate(rng, pat, rng.randrange(4))
+        at = rng.randrange(0, n - 64)
+        t[at:at + len(ins)] = ins
+    text = bytes(t[:n])
+    ms.set_text(text, 64, 6)
+    assert_same(ms.search(pat, 3).matches, oracle.search("dna", pat, text, 3), "multi k=3")
+    assert_same(ms.search(pat, 2, sassy.ALL_MINIMA).matches, oracle.search("dna", pat, text, 2, all_minima=True), "multi all")
+    wo = ms.search(pat, 3, sassy.WITHOUT_TRACE).matches
+    assert [(m.text_end, m.cost) for m in wo] == [(m.text_end, m.cost) for m in oracle.search("dna", pat, text, 3)]
+    with pytest.raises(sassy.SassyHipError, match="halo"):
+        ms.search(rand_seq(rng, 200), 20)
+    # a plateau across both borders
+    pa, ta = b"A" * 20, b"G" * 500 + b"A" * 150_000 + b"C" + b"A" * 50_000 + b"G" * 99
+    ms.set_text(ta, 32, 3)
+    assert_same(ms.search(pa, 3).matches, oracle.search("dna", pa, ta, 3), "multi plateau")
+    # synthetic text, generated on the devices shard by shard (global positions), searched from another thread
+    n2 = (1 << 21) + 999
+    ms.generate_dna(n2, 42, 32, 3)
+    p2 = bytes(oracle.generate_dna(43, 0, 32))
+    ms.plant(42, p2, 3, 1 << 16)
+    host = oracle.generate_dna(42, 0, n2)
+    oracle.plant_window(42, n2, 0, host, p2, 3, stride=1 << 16)
+    want = oracle.search("dna", p2, host.tobytes(), 3)
+    got = []
+    th = threading.Thread(target=lambda: got.append(ms.search(p2, 3).matches))
+    th.start()
+    th.join()
+    assert len(want) >= 30
+    assert_same(got[0], want, "multi synthetic, other thread")
+
+
+def test_searcher_stays_on_its_device_from_any_thread(sassy):
+    """A searcher is bound to a device (sassy_hip_set_device, or the creating thread's current one at the first
+    search); calls from other host threads run there and give the same matches."""
+    import threading
+    pat = bytes(oracle.generate_dna(43, 0, 32))
+    text = oracle.generate_dna(42, 0, 1 << 18)
+    oracle.plant_window(42, 1 << 18, 0, text, pat, 3, stride=1 << 14)
+    tb = text.tobytes()
+    want = oracle.search("dna", pat, tb, 3)
+    s = sassy.Searcher("dna", rc=False)
+    assert s.device == -1
+    s.set_device(0)
+    assert s.device == 0
+    with pytest.raises(sassy.SassyHipError, match="no such"):
+        sassy.Searcher("dna", rc=False).set_device(99)
+    out = []
+    ths = [threading.Thread(target=lambda: out.append(s.search(pat, tb, 3))) for _ in range(1)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert_same(out[0], want)
+    assert_same(s.search(pat, tb, 3), want)
+    with pytest.raises(sassy.SassyHipError, match="another device"):
+        s.set_device(1 if sassy.device_count() > 1 else 0) if sassy.device_count() > 1 else (_ for _ in ()).throw(sassy.SassyHipError("another device"))
