@@ -5,6 +5,10 @@
 namespace sassy_hip {
 
 enum Profile : uint32_t { PROFILE_ASCII = 0, PROFILE_DNA = 1, PROFILE_IUPAC = 2 };
+// Kernel-side only (ScanParams::profile, template argument): Ascii patterns with more than kMaxSlots distinct bytes.
+// No mask per distinct byte: the block's 8 bit planes are the "slots", a row's Eq word is computed from them and the
+// row's pattern byte (the row table then holds the bytes themselves): 16 VALU more per row, any pattern.
+constexpr uint32_t PROFILE_ASCII_BYTES = 3;
 
 constexpr int kWave = 64;              // gfx950 wavefront
 constexpr int kWavesPerGroup = 4;      // 256-thread workgroups, every wave works alone
@@ -106,6 +110,8 @@ struct ScanParams {
   uint32_t flags;
   uint32_t profile;           // Profile enum
   uint32_t lds_per_wave;      // bytes
+  uint32_t waves_per_group;   // scan_kernel / list_kernel: wavefronts per workgroup (4; fewer when a long pattern's
+                              // per-row carries -- 64 bytes per 32 rows and lane -- would not fit four waves' LDS)
   uint32_t cand_cap;
   uint32_t n_iter;            // iterations of the block loop
   uint32_t stage_blocks;      // 1 or 2: text blocks per lane chunk fetched per staging step

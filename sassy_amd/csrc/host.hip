@@ -911,7 +911,7 @@ int ScanJob::prepare() {
   P.k = k;
   P.nwords = plan.nwords;
   P.nslots = plan.nslots;
-  P.profile = (uint32_t)S->profile;
+  P.profile = plan.bytes ? PROFILE_ASCII_BYTES : (uint32_t)S->profile;
   P.wb = warmup_blocks(plan.m, k);
   P.flags = (all_minima ? kScanAllMinima : 0u) | (sh.text_start ? kScanTextStart : 0u) |
             (sh.text_end ? kScanTextEnd : 0u) | (overhang ? kScanOverhang : 0u);
@@ -928,8 +928,9 @@ int ScanJob::prepare() {
   // a match that hangs over an end of the text contains only part of the pattern: the pigeonhole
   // argument of the prefilter does not cover it, so overhang searches stream the full DP
   if (overhang) q = 0;
-  // Ascii patterns with more than 16 distinct bytes: only the DP kernels carry that many slot masks
-  if (plan.nslots > 16) q = 0;
+  // Ascii patterns with more than 16 distinct bytes: only the DP kernels carry that many slot masks (or, byte mode,
+  // compare bytes instead of looking slots up)
+  if (plan.nslots > 16 || plan.bytes) q = 0;
   if (ext_bitmap) q = ext_q;
   if (ext_desc) q = 1;  // list mode without a filter
   // which prefilter kernel (SASSY_HIP_FILTER_KIND=1|2|3|4 forces one where it applies)
@@ -1168,8 +1169,12 @@ int ScanJob::prepare() {
     if (int rc = stream_geometry(P, owned, P.wb, &grid, 16, tuned ? &S->tuner_scan : nullptr, sh.d_text, sh.text_len,
                                  1000u + plan.nwords)) return rc;
     P.lds_per_wave = 4096u * P.stage_blocks + bucket * 512u + plan.nwords * 512u;
-    if ((size_t)kWavesPerGroup * P.lds_per_wave > 160 * 1024)
-      return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
+    // long patterns: the per-row carries (64 bytes per 32 rows and lane) of four waves no longer fit a workgroup's
+    // 160 KiB of LDS -- fewer waves per workgroup then (m <= ~9 800 with one)
+    P.waves_per_group = (uint32_t)std::min<size_t>(kWavesPerGroup, (160 * 1024) / P.lds_per_wave);
+    if (P.waves_per_group == 0)
+      return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store (about 9 800 rows)");
+    grid = (uint32_t)((P.n_chunks + 64ull * P.waves_per_group - 1) / (64ull * P.waves_per_group));
     if (int rc = L.d_state.reserve(P.n_chunks)) return rc;
     P.chunk_state = L.d_state.p;
   } else {
@@ -1322,8 +1327,9 @@ int ScanJob::prepare() {
       }
     }
     P.lds_per_wave = bucket * 512u + plan.nwords * 512u;
-    if ((size_t)kWavesPerGroup * P.lds_per_wave > 160 * 1024)
-      return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store");
+    P.waves_per_group = (uint32_t)std::min<size_t>(kWavesPerGroup, (160 * 1024) / P.lds_per_wave);
+    if (P.waves_per_group == 0)
+      return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store (about 10 000 rows)");
   }
 
   t_mark = t_enter;
@@ -1360,7 +1366,7 @@ int ScanJob::enqueue(int attempt) {
   if (time_head) HIP_TRY(hipEventRecord(L.ev_a, L.stream));
   hipError_t le;
   if (!filtered) {
-    le = launch_scan_any(S->profile, P, grid, (size_t)kWavesPerGroup * P.lds_per_wave, L.stream);
+    le = launch_scan_any(S->profile, P, grid, (size_t)P.waves_per_group * P.lds_per_wave, L.stream);
     if (le != hipSuccess) return hip_fail(le, "scan kernel launch");
   } else {
     if (fused) {  // the filter appends the reports itself: it needs the list (every attempt runs the whole launch)
@@ -1418,8 +1424,8 @@ int ScanJob::enqueue(int attempt) {
       P.list_words_max = (8192u * 64u) >> glog;
     }
     // the descriptor count lives on the device: launch for the capacity, idle waves exit at once
-    const uint32_t lgrid = (desc_cap + 255) / 256;
-    le = launch_list_any(S->profile, P, lgrid, (size_t)kWavesPerGroup * P.lds_per_wave, L.stream);
+    const uint32_t lgrid = (desc_cap + 64u * P.waves_per_group - 1) / (64u * P.waves_per_group);
+    le = launch_list_any(S->profile, P, lgrid, (size_t)P.waves_per_group * P.lds_per_wave, L.stream);
     if (le != hipSuccess) return hip_fail(le, "list kernel launch");
     }
   }

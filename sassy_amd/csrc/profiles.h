@@ -82,6 +82,8 @@ struct PatternPlan {
   uint8_t slot_val[kMaxSlots] = {};  // Dna: 2-bit code; Iupac: base-set nibble; Ascii: byte
   std::vector<uint32_t> row_tab;     // one byte per row = 2 * its profile slot, 4 rows per word,
                                      // 8 words per 32 rows (padded with slot 0)
+  bool bytes = false;                // Ascii with more than kMaxSlots distinct bytes (PROFILE_ASCII_BYTES): nslots = 8
+                                     // (the bit planes), the row table holds the pattern bytes themselves
 };
 
 // Profile::encode_pattern (dna.rs:19-23, iupac.rs:18-36, ascii.rs:18-29).
@@ -116,12 +118,18 @@ inline bool make_plan(Profile pr, const uint8_t* pat, size_t m, PatternPlan& pla
   }
   // Iupac: the reference's profile holds 16 masks and asserts (iupac.rs:69).  Ascii: 256 slots in the
   // reference (ascii.rs:13-29); here every distinct pattern byte takes one LDS mask slot per lane, up to
-  // 64 of them (documented limit, DESIGN.md: a pattern with more distinct bytes is binary data, not text).
-  const size_t limit = pr == PROFILE_IUPAC ? 16 : (size_t)kMaxSlots;
-  if (letters.size() > limit) {
-    err = pr == PROFILE_IUPAC ? "pattern uses more than 16 distinct letters"
-                              : "pattern uses more than 64 distinct bytes";
+  // 64 of them; patterns with more distinct bytes run in byte mode (below).
+  if (pr == PROFILE_IUPAC && letters.size() > 16) {
+    err = "pattern uses more than 16 distinct letters";
     return false;
+  }
+  if (letters.size() > (size_t)kMaxSlots) {
+    // Ascii, more distinct bytes than mask slots (the reference's profile has 256, ascii.rs:13-29): byte mode
+    plan.bytes = true;
+    plan.nslots = 8;
+    plan.row_tab.assign((size_t)plan.nwords * 8, 0u);
+    for (size_t j = 0; j < m; ++j) plan.row_tab[j >> 2] |= (uint32_t)pat[j] << (8 * (j & 3));
+    return true;
   }
   plan.nslots = (uint32_t)letters.size();
   for (size_t s = 0; s < letters.size(); ++s)

@@ -363,6 +363,11 @@ __device__ __forceinline__ void build_masks(const uint32_t (&x)[16], const ScanP
       }
       m[s] = r;
     }
+  } else if constexpr (PROFILE == (int)PROFILE_ASCII_BYTES) {
+    // byte mode: the eight bit planes themselves (dp_word compares them with the row's pattern byte)
+    static_assert(NS == 8, "byte mode keeps eight planes");
+    m[0] = bit_plane<0>(x); m[1] = bit_plane<1>(x); m[2] = bit_plane<2>(x); m[3] = bit_plane<3>(x);
+    m[4] = bit_plane<4>(x); m[5] = bit_plane<5>(x); m[6] = bit_plane<6>(x); m[7] = bit_plane<7>(x);
   } else {
     // Ascii: byte equality with the slot's pattern byte (reference: src/profiles/ascii.rs:75-90)
     uint2 pl[8];
@@ -427,7 +432,9 @@ struct CutCtx {
 // false: every lane works on its own word (list_words_kernel).
 // CUT: bounded rows (see CutCtx).  Returns 0 when all rows of the word were computed, else the number of
 // rows (4 .. 32) after which the wave stopped (nhp / nhm then hold (+1, 0) for the skipped rows).
-template <bool SCALAR_PK = true, bool CUT = false>
+// BYTES (PROFILE_ASCII_BYTES): pk_in holds the rows' pattern bytes, my_masks the block's eight bit planes; a row's
+// Eq word = AND over the bits b of (plane b XNOR bit b of the row's byte).
+template <bool SCALAR_PK = true, bool CUT = false, bool BYTES = false>
 __device__ __forceinline__ uint32_t dp_word(DpWord& V, const unsigned char* my_masks, uint32_t ohp, uint32_t ohm,
                                             const uint32_t (&pk_in)[8], uint32_t rows, uint32_t& nhp_out,
                                             uint32_t& nhm_out, const CutCtx* cut = nullptr) {
@@ -441,9 +448,28 @@ __device__ __forceinline__ uint32_t dp_word(DpWord& V, const unsigned char* my_m
   }
   uint32_t nhp = 0, nhm = 0, done = 0;
   bool stopped = false;  // wave-uniform
+  uint2 planes[BYTES ? 8 : 1];
+  if constexpr (BYTES) {
+#pragma unroll
+    for (int b = 0; b < 8; ++b) planes[b] = *reinterpret_cast<const uint2*>(my_masks + b * 512);
+  }
+  auto eq_of_byte = [&](uint32_t pb) -> uint2 {  // pb: the row's pattern byte (bits above 7 ignored)
+    uint2 e = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const uint32_t n = ~(uint32_t)__builtin_amdgcn_sbfe((int)pb, b, 1);  // all ones iff bit b of the byte is 0
+      e.x = bitop3<0x60>(e.x, planes[BYTES ? b : 0].x, n);  // a & (b ^ c)
+      e.y = bitop3<0x60>(e.y, planes[BYTES ? b : 0].y, n);
+    }
+    return e;
+  };
+  auto row_byte = [&](int r) -> uint32_t { return pk[r >> 2] >> (8 * (r & 3)); };
   uint2 eqn[4];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) eqn[u] = *reinterpret_cast<const uint2*>(my_masks + row_mask_off(pk, u));
+  for (int u = 0; u < 4; ++u) {
+    if constexpr (BYTES) eqn[u] = eq_of_byte(row_byte(u));
+    else eqn[u] = *reinterpret_cast<const uint2*>(my_masks + row_mask_off(pk, u));
+  }
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
     if (!stopped && 4u * g + 4u <= rows) {
@@ -452,8 +478,10 @@ __device__ __forceinline__ uint32_t dp_word(DpWord& V, const unsigned char* my_m
       for (int u = 0; u < 4; ++u) eqc[u] = eqn[u];
       if (g < 7) {  // prefetch the next group's Eq words while this group computes
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-          eqn[u] = *reinterpret_cast<const uint2*>(my_masks + row_mask_off(pk, 4 * g + 4 + u));
+        for (int u = 0; u < 4; ++u) {
+          if constexpr (BYTES) eqn[u] = eq_of_byte(row_byte(4 * g + 4 + u));
+          else eqn[u] = *reinterpret_cast<const uint2*>(my_masks + row_mask_off(pk, 4 * g + 4 + u));
+        }
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -479,7 +507,9 @@ __device__ __forceinline__ uint32_t dp_word(DpWord& V, const unsigned char* my_m
       const uint32_t pw = q == 0 ? pk[0] : q == 1 ? pk[1] : q == 2 ? pk[2] : q == 3 ? pk[3]
                         : q == 4 ? pk[4] : q == 5 ? pk[5] : q == 6 ? pk[6] : pk[7];
       for (uint32_t r = done; r < rows; ++r) {
-        const uint2 eq = *reinterpret_cast<const uint2*>(my_masks + (((pw >> (8 * (r & 3))) & 0xFFu) << 8));
+        uint2 eq;
+        if constexpr (BYTES) eq = eq_of_byte(pw >> (8 * (r & 3)));
+        else eq = *reinterpret_cast<const uint2*>(my_masks + (((pw >> (8 * (r & 3))) & 0xFFu) << 8));
         dp_row(V, eq, (ohp >> (31 - r)) & 1u, (ohm >> (31 - r)) & 1u, nhp, nhm);
       }
     }
@@ -504,6 +534,7 @@ __device__ __forceinline__ uint32_t dp_word(DpWord& V, const unsigned char* my_m
 // first_rows (wave-uniform, in/out): the row count from which this wave tests; it follows the text --
 // down to four rows before the last stop, up by four after a block that ran through.
 // minus_total (per lane, in/out): -1 vertical deltas on the block's left edge over all words.
+template <bool BYTES = false>
 __device__ __forceinline__ bool dp_block(DpWord& V, int& ds, const unsigned char* my_masks, uint32_t* carry, uint32_t lane,
                                          const_u32_ptr row_tab, const uint32_t (&pkw0)[8], uint32_t nwords, uint32_t last_rows,
                                          uint32_t last_word_init, int k, bool idle, uint32_t& first_rows, int& minus_total,
@@ -539,7 +570,7 @@ __device__ __forceinline__ bool dp_block(DpWord& V, int& ds, const unsigned char
     cc.more_words = !last;
     cc.idle = idle;
     uint32_t nhp, nhm;
-    const uint32_t cut_at = dp_word<true, true>(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm, &cc);
+    const uint32_t cut_at = dp_word<true, true, BYTES>(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm, &cc);
     ds += (int)__popc(ohp) - (int)__popc(ohm);
     carry[(w * 2 + 0) * 64 + lane] = nhp;
     carry[(w * 2 + 1) * 64 + lane] = nhm;
@@ -573,7 +604,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   unsigned char* mask_bytes = wbase + kTile;                                 // [NS][64] u64
   uint32_t* carry = reinterpret_cast<uint32_t*>(wbase + kTile + NS * 512);  // [word][hp|hm][lane]
 
-  const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * kWavesPerGroup + wave) * kWave;
+  const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave) * kWave;  // (1 .. 4 waves per workgroup)
   if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
   const uint64_t chunk = wave_chunk0 + lane;
 
@@ -700,7 +731,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
     if ((it & 7u) == 7u && first_rows > 8u && first_rows <= m) first_rows -= 4u;  // now and then try an earlier row again
     DpWord V;
     int ds;  // cost at the block's left edge in the last row
-    const bool ran_through = dp_block(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
+    const bool ran_through = dp_block<PROFILE == (int)PROFILE_ASCII_BYTES>(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
                                       !active, first_rows, minus_total, m, P.counters != nullptr && active, cnt_rows);
 
     // ---- last row of the block: anything <= k ? ----
@@ -1482,7 +1513,7 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
       if ((it & 7u) == 7u && first_rows > 8u && first_rows <= m) first_rows -= 4u;
       DpWord V;
       int ds;
-      const bool ran_through = dp_block(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
+      const bool ran_through = dp_block<PROFILE == (int)PROFILE_ASCII_BYTES>(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
                                         !active, first_rows, minus_total, m, P.counters != nullptr && active, cnt_rows);
       if (active) {
         if (P.counters) cnt_blocks += 1;
@@ -1538,7 +1569,7 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
 
   uint32_t n_desc = *P.desc_count;
   if (n_desc > P.desc_cap) n_desc = P.desc_cap;
-  const uint32_t wave_first = (blockIdx.x * kWavesPerGroup + wave) * kWave;
+  const uint32_t wave_first = (blockIdx.x * (blockDim.x >> 6) + wave) * kWave;  // (1 .. 4 waves per workgroup)
   if (wave_first >= n_desc) return;  // wave-uniform
   if (n_desc <= P.list_words_max) return;  // few chunks of a multi-word pattern: list_words_kernel runs them
   const uint32_t di = wave_first + lane;
@@ -2013,7 +2044,7 @@ __global__ __launch_bounds__(256) void list_words_kernel(const ScanParams P) {
     if (w == 0) { V.vpl = V.vph = V.vml = V.vmh = 0; ds = 0; }
     ds += __popc(ohp) - __popc(ohm);
     uint32_t nhp, nhm;
-    dp_word<false>(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm);
+    dp_word<false, false, PROFILE == (int)PROFILE_ASCII_BYTES>(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm);
     if (active) {
       ohp = nhp;
       ohm = nhm;
@@ -2049,7 +2080,7 @@ static hipError_t launch_sb(const ScanParams& P, uint32_t grid, size_t smem, hip
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((scan_kernel<PROFILE, NS, SB>), dim3(grid), dim3(256), smem, stream, P);
+  hipLaunchKernelGGL((scan_kernel<PROFILE, NS, SB>), dim3(grid), dim3(64u * (P.waves_per_group ? P.waves_per_group : 4u)), smem, stream, P);
   return hipGetLastError();
 }
 template <int PROFILE, int NS>
@@ -2096,7 +2127,7 @@ static hipError_t launch_list_one(const ScanParams& P, uint32_t grid, size_t sme
     hipLaunchKernelGGL((list_words_kernel<PROFILE, NS>), dim3(wgrid), dim3(256), (size_t)kWavesPerGroup * NS * 512u,
                        stream, P);
   }
-  hipLaunchKernelGGL((list_kernel<PROFILE, NS>), dim3(grid), dim3(256), smem, stream, P);
+  hipLaunchKernelGGL((list_kernel<PROFILE, NS>), dim3(grid), dim3(64u * (P.waves_per_group ? P.waves_per_group : 4u)), smem, stream, P);
   return hipGetLastError();
 }
 
@@ -2189,6 +2220,9 @@ hipError_t launch_scan_iupac(const ScanParams& P, uint32_t grid, size_t smem, hi
 hipError_t launch_scan_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
   constexpr int PR = PROFILE_ASCII;
 #endif
+#if SASSY_SCAN_PROFILE == 0
+  if (P.profile == PROFILE_ASCII_BYTES) return launch_one<(int)PROFILE_ASCII_BYTES, 8>(P, grid, smem, stream);
+#endif
   if (P.nslots <= 4) return launch_one<PR, 4>(P, grid, smem, stream);
   if (P.nslots <= 8) return launch_one<PR, 8>(P, grid, smem, stream);
   if (P.nslots <= 16) return launch_one<PR, 16>(P, grid, smem, stream);
@@ -2217,6 +2251,9 @@ hipError_t launch_list_iupac(const ScanParams& P, uint32_t grid, size_t smem, hi
 #else
 hipError_t launch_list_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
   constexpr int PR3 = PROFILE_ASCII;
+#endif
+#if SASSY_SCAN_PROFILE == 0
+  if (P.profile == PROFILE_ASCII_BYTES) return launch_list_one<(int)PROFILE_ASCII_BYTES, 8>(P, grid, smem, stream);
 #endif
   if (P.nslots <= 4) return launch_list_one<PR3, 4>(P, grid, smem, stream);
   if (P.nslots <= 8) return launch_list_one<PR3, 8>(P, grid, smem, stream);

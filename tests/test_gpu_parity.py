@@ -1152,8 +1152,8 @@ def test_ascii_profile(sassy):
 def test_ascii_many_distinct_bytes(sassy):
     """The reference's Ascii profile has 256 slots (src/profiles/ascii.rs:13-29): ordinary text patterns
     with more than 16 distinct bytes must search, not abort -- here 17 .. 64 distinct pattern bytes
-    (32- and 64-slot kernels), one text and many texts (per-text lanes), against the oracle; more than
-    64 distinct bytes is the documented limit and fails with a message."""
+    (32- and 64-slot kernels), one text and many texts (per-text lanes), against the oracle (more than 64 distinct
+    bytes: test_ascii_binary_patterns_and_very_long_patterns)."""
     rng = random.Random(31)
     sent = b"The quick brown fox jumps over the lazy dog, 1234567890 times; WHY? (because: it_can!)"
     assert len(set(sent)) > 32
@@ -1188,8 +1188,55 @@ def test_ascii_many_distinct_bytes(sassy):
             want += [(pi, ti, m.text_start, m.text_end, m.cost, m.cigar) for m in oracle.search("ascii", pat, t, 4)]
     assert [(m.pattern_idx, m.text_idx, m.text_start, m.text_end, m.cost, m.cigar) for m in got] == want
     assert len(want) >= 3
-    with pytest.raises(sassy.SassyHipError, match="more than 64 distinct bytes"):
-        s.search(bytes(range(40, 140)), text, 3)
+
+
+def test_ascii_binary_patterns_and_very_long_patterns(sassy):
+    """The two cliffs the drop-in search() fell off: Ascii patterns with more than 64 distinct bytes (the reference's
+    profile has 256 slots, src/profiles/ascii.rs:13-29: byte mode here -- bit planes compared with the row's byte)
+    and patterns whose per-row carries exceed four waves' LDS (m = 2 500 .. 4 096: fewer waves per workgroup).
+    Against the oracle, single and many texts, and through the drop-in symbol."""
+    rng = random.Random(33)
+    n = 40_000
+    text = bytearray(rng.randrange(256) for _ in range(n))
+    pats = [bytes(range(40, 140)), bytes(rng.sample(range(256), 200)), bytes(range(256)), bytes(rng.randrange(256) for _ in range(300))]
+    for i, p in enumerate(pats):
+        for e in (0, 3, 9):
+            ins = mutate(rng, p, e)
+            at = 1000 + 9000 * i + 2000 * (e % 4)
+            text[at:at + len(ins)] = ins
+    text = bytes(text[:n])
+    s = sassy.Searcher("ascii", rc=False)
+    for p, k in zip(pats, (3, 10, 5, 12)):
+        assert len(set(p)) > 64
+        want = oracle.search("ascii", p, text, k)
+        assert len(want) >= 2, (len(p), k)
+        assert_same(s.search(p, text, k), want, ("bytes", len(p), k))
+        assert_same(s.search_all(p, text[:12000], 2), oracle.search("ascii", p, text[:12000], 2, all_minima=True), ("bytes all", len(p)))
+    texts = [text[i:i + 3000] for i in range(0, n, 2900)]
+    got = s.search_many([pats[0]], texts, 3)
+    want = [(ti, m.text_start, m.text_end, m.cost, m.cigar) for ti, t in enumerate(texts) for m in oracle.search("ascii", pats[0], t, 3)]
+    assert [(m.text_idx, m.text_start, m.text_end, m.cost, m.cigar) for m in got] == want and len(want) >= 1
+    L = sassy.lib()
+    h = L.sassy_searcher(b"ascii", False, float("nan"))
+    out = C.POINTER(sassy.CMatch)()
+    cnt = L.search(h, pats[2], len(pats[2]), text, len(text), 5, C.byref(out))
+    want = oracle.search("ascii", pats[2], text, 5)
+    assert [(out[i].text_start, out[i].text_end, out[i].cost) for i in range(cnt)] == [(m.text_start, m.text_end, m.cost) for m in want]
+    L.sassy_matches_free(out, cnt)
+    L.sassy_searcher_free(h)
+    # very long patterns: Dna / Iupac, with and without a prefilter
+    for profile, m, k, pre in (("dna", 2500, 5, -1), ("dna", 4096, 12, -1), ("iupac", 3000, 30, -1), ("dna", 4096, 12, 0), ("ascii", 2600, 4, -1)):
+        pat = rand_seq(rng, m) if profile != "ascii" else bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz ") for _ in range(m))
+        nt = 60_000
+        t = bytearray(rand_seq(rng, nt) if profile != "ascii" else bytes(rng.choice(b"abcdefghijklmnopqrstuvwxyz ") for _ in range(nt)))
+        for at, e in ((100, 0), (20_000, k // 2), (45_000, k)):
+            ins = mutate(rng, pat, e)
+            t[at:at + len(ins)] = ins
+        t = bytes(t[:nt])
+        sl = sassy.Searcher(profile, rc=False).set_prefilter(pre)
+        want = oracle.search(profile, pat, t, k)
+        assert len(want) >= 2, (profile, m, k)
+        assert_same(sl.search(pat, t, k), want, ("long", profile, m, k, pre))
 
 
 # ------------------------------------------------------------------ device-resident text
