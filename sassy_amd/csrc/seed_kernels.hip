@@ -108,13 +108,27 @@ __device__ __forceinline__ bool sub_piece_test(const SeedParams& P, unsigned lon
 
 // One lane per candidate.  EDGE: the candidate's window leaves the text (the first / last few dozen characters),
 // or the buffer holds several texts with separators between them.
+// (the launch parameters the verification reads, by value: it is called out of line -- its 64 unrolled column steps,
+// inlined three times, kept 280 scalars of the seed pass spilled)
+struct VerifyArgs {
+  const uint8_t* text;
+  uint64_t text_len;
+  const void* peq;
+  Candidate* out;
+  uint32_t* out_count;
+  uint64_t rem_packed;
+  uint32_t mks;  // m | k << 8 | separators << 16  (64 bytes in all: a larger struct would travel through scratch memory)
+  uint32_t out_cap, out_stop;
+};
+static_assert(sizeof(VerifyArgs) <= 64, "VerifyArgs must travel in registers");
 template <int WORDS, bool EDGE>
-__device__ __forceinline__ void verify_candidate(const SeedParams& P, unsigned long long cand) {
+__device__ __noinline__ void verify_candidate(const VerifyArgs P, unsigned long long cand) {
   typedef typename std::conditional<WORDS == 1, uint32_t, unsigned long long>::type Word;
   const uint32_t entry = (uint32_t)cand & ((1u << kSeedPosShift) - 1u);
   const uint32_t pat = entry >> 3, piece = entry & 7u;
   const int64_t i = (int64_t)(cand >> kSeedPosShift);
-  const int m = (int)P.m, k = (int)P.k;
+  const int m = (int)(P.mks & 0xFFu), k = (int)((P.mks >> 8) & 0xFFu);
+  const bool separators = (P.mks >> 16) != 0;
   const int T = m + 3 * k + 1;
   const int64_t e_hi = i + (int64_t)((P.rem_packed >> (8u * piece)) & 0xFFu) + k;  // last end position the seed allows
   const int64_t s0 = e_hi - T;                          // first character of the window
@@ -170,7 +184,7 @@ __device__ __forceinline__ void verify_candidate(const SeedParams& P, unsigned l
             const int64_t c = s0 + t;
             if (c < 0 || c >= (int64_t)P.text_len) eq = 0;  // outside the text: the fresh column stays fresh
             // multi-text buffers: the separator 'X' (and any text 'X': the empty IUPAC set) matches nothing
-            if (P.separators && ((win[x] >> (8 * y + 3)) & 1u)) eq = 0;
+            if (separators && ((win[x] >> (8 * y + 3)) & 1u)) eq = 0;
           }
           tiled_step(S, eq, top_shift);
           if (t >= emit_from && S.cost <= k) {
@@ -228,10 +242,14 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
       const int64_t s0 = e_hi - ((int64_t)P.m + 3 * (int64_t)P.k + 1);
       edge = s0 < 4 || e_hi + 8 > (int64_t)P.text_len || P.separators != 0u;  // (separators: the checked copy of the loop)
     }
+    VerifyArgs va;
+    va.text = P.text; va.text_len = P.text_len; va.peq = P.peq; va.out = P.out; va.out_count = P.out_count;
+    va.rem_packed = P.rem_packed; va.mks = P.m | (P.k << 8) | (P.separators ? 1u << 16 : 0u);
+    va.out_cap = P.out_cap; va.out_stop = P.out_stop;
     if (__any(edge)) {
-      if (have) verify_candidate<WORDS, true>(P, cand);
+      if (have) verify_candidate<WORDS, true>(va, cand);
     } else {
-      if (have) verify_candidate<WORDS, false>(P, cand);
+      if (have) verify_candidate<WORDS, false>(va, cand);
     }
   };
   // drop the first 64 entries of a queue of `have` (< 128) entries
