@@ -64,6 +64,51 @@ extern "C" {
     fn sassy_hip_result_free(r: *mut RawResult);
     fn sassy_hip_set_only_best_match(s: *mut RawSearcher, on: c_int) -> c_int;
     fn sassy_hip_set_max_n_frac(s: *mut RawSearcher, f: f32) -> c_int;
+    fn sassy_hip_set_device(s: *mut RawSearcher, device: c_int) -> c_int;
+    fn sassy_hip_merge_shards(results: *const *const RawResult, n: usize, incoming_state: c_int,
+                              out: *mut *mut RawResult) -> c_int;
+    fn sassy_hip_multi_new(alphabet: *const c_char, alpha: f32, devices: *const c_int, n_devices: usize) -> *mut RawMulti;
+    fn sassy_hip_multi_set_text(m: *mut RawMulti, text: *const u8, len: usize, max_pattern_len: usize, max_k: usize) -> c_int;
+    fn sassy_hip_multi_search(m: *mut RawMulti, pattern: *const u8, pattern_len: usize, k: usize, flags: u32,
+                              out: *mut *mut RawResult) -> c_int;
+    fn sassy_hip_multi_free(m: *mut RawMulti);
+}
+
+#[repr(C)]
+pub struct RawMulti {
+    _p: [u8; 0],
+}
+
+/// One text over several GPUs inside one process (include/sassy_hip.h: sassy_hip_multi_*): the reference's thread
+/// fan-out (bin/grep.rs:476-503) with a device per thread.  Forward strand, like the shard calls.
+pub struct MultiSearcher {
+    raw: *mut RawMulti,
+}
+
+impl MultiSearcher {
+    /// `devices`: empty = every visible device.
+    pub fn new(alphabet: &str, devices: &[i32]) -> Self {
+        let a = std::ffi::CString::new(alphabet).unwrap();
+        let raw = unsafe { sassy_hip_multi_new(a.as_ptr(), f32::NAN, if devices.is_empty() { std::ptr::null() } else { devices.as_ptr() }, devices.len()) };
+        assert!(!raw.is_null(), "{}", last_error());
+        MultiSearcher { raw }
+    }
+    pub fn set_text(&mut self, text: &[u8], max_pattern_len: usize, max_k: usize) {
+        let rc = unsafe { sassy_hip_multi_set_text(self.raw, text.as_ptr(), text.len(), max_pattern_len, max_k) };
+        assert_eq!(rc, 0, "{}", last_error());
+    }
+    pub fn search(&mut self, pattern: &[u8], k: usize) -> Vec<Match> {
+        let mut res = std::ptr::null_mut();
+        let rc = unsafe { sassy_hip_multi_search(self.raw, pattern.as_ptr(), pattern.len(), k, 0, &mut res) };
+        assert_eq!(rc, 0, "{}", last_error());
+        unsafe { collect(res) }
+    }
+}
+
+impl Drop for MultiSearcher {
+    fn drop(&mut self) {
+        unsafe { sassy_hip_multi_free(self.raw) }
+    }
 }
 
 /// The reference's `Strand` (src/search.rs:107-119).

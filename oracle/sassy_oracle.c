@@ -26,8 +26,11 @@
  *     pattern, plus one forward search of rc(pattern) tagged Rc when the searcher is rc
  *       src/pattern_tiling/search.rs:690-848 (the reference's own differential test states this)
  *
+ * Also here (SURVEY 8f rows the library implements): overhang (alpha, max_overhang; orc_search_overhang,
+ * src/search.rs:347-356, 1274-1308, 1695-1748, src/trace.rs:36-47); max_n_frac (src/n_filter.rs:8-60) is restated
+ * in oracle/__init__.py on top of these searches.
  * Deliberately NOT restated here: SIMD lanes, bounded rows, chunking (see sassy_refstyle.c for
- * the reference-shaped algorithm); overhang (alpha) and max_n_frac (out of scope).
+ * the reference-shaped algorithm).
  */
 #include <stdint.h>
 #include <stdlib.h>

@@ -18,6 +18,15 @@ cp $(ls gpurun_out/prof_$TAG/trace/*kernel_stats.csv gpurun_out/prof_$TAG/trace/
 bash tools/prof.sh ${TAG}_one --in-flight 1 > /dev/null 2>&1
 cp gpurun_out/prof_${TAG}_one/summary.txt $OUT/${TAG}_rocprof_summary_one_at_a_time.txt
 cp gpurun_out/prof_${TAG}_one/hbm_traffic.json $OUT/hbm_traffic.json
+# ---- one search at a time: kernel durations, the gaps between them, the host's turnaround (fused launch / classic chain)
+rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_${TAG}_lone -o t -- python tools/probe_fused.py > $OUT/lone_fused.json 2>> $OUT/bench.err
+SASSY_HIP_FUSED=0 rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_${TAG}_lone_classic -o t -- python tools/probe_fused.py > $OUT/lone_classic.json 2>> $OUT/bench.err
+{ echo "# a lone search of BASELINE config 2 (3 GB, |P| = 32, k = 3), tools/probe_fused.py under rocprofv3 --kernel-trace; tools/timeline.py";
+  echo "## fused launch (default)"; tail -1 $OUT/lone_fused.json; python tools/timeline.py gpurun_out/prof_${TAG}_lone;
+  echo "## classic chain (SASSY_HIP_FUSED=0)"; tail -1 $OUT/lone_classic.json; python tools/timeline.py gpurun_out/prof_${TAG}_lone_classic;
+  echo "## where the fused launch's waves spend their time (SASSY_HIP_FUSED_PROBE=1: streaming / chunk DP, 100 MHz ticks; =2: no chunk DP at all)";
+  SASSY_HIP_FUSED_PROBE=1 python tools/probe_fused.py 2>/dev/null | tail -1; SASSY_HIP_FUSED_PROBE=2 python tools/probe_fused.py 2>/dev/null | tail -1;
+  echo "## traceback waves, microseconds per report and phase (SASSY_HIP_TRACE_PROBE=1)"; SASSY_HIP_TRACE_PROBE=1 python tools/probe_fused.py 2>&1 | grep "trace waves" | tail -2; } > $OUT/${TAG}_lone_search_timeline.txt 2>&1
 # ---- the streaming DP (prefilter off): with and without the row cut-off
 SASSY_HIP_PREFILTER=0 bash tools/prof.sh ${TAG}_scan --in-flight 1 > /dev/null 2>&1
 cp gpurun_out/prof_${TAG}_scan/summary.txt $OUT/${TAG}_scan_kernel_rocprof_summary.txt
