@@ -1,11 +1,7 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r3b
-timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r3b/bench_g.json 2> gpurun_out/r3b/bench_g.err
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/r3b/bench_g.json'))
-print({k:d[k] for k in ['value','ms_per_step','single_search_latency_ms','single_search_roofline_frac','dominant_kernel_ms']})
-print(d.get('other_configs'))
-print(d.get('cpu_baseline'))
-print(d.get('h2d_inclusive'))
-PY
+for rep in 1 2; do
+for f in 2 3; do
+for pad in default 0 8192 12288 16384 24576; do
+  if [ $pad = default ]; then e=""; else e="SASSY_HIP_FILTER_LDS_PAD=$pad"; fi
+  echo "rep $rep in-flight $f pad $pad: $(env $e python bench.py --steps 300 --warmup 50 --no-cpu-baseline --in-flight $f 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')"
+done; done; done
