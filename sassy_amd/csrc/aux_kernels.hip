@@ -183,14 +183,39 @@ struct BuildParams {
   unsigned long long* hit_count;  // statistics: number of hit blocks (one atomic per workgroup)
 };
 
+// (long patterns: the reach of a hit -- L blocks to the right, wb to the left -- exceeds a bitmap word; rare, and then
+// the chunk builder's time does not matter: bit by bit over the words in reach)
+__device__ __noinline__ unsigned long long dilated_word_far(const unsigned long long* hit, uint64_t n_words, uint32_t L, uint32_t wb, long long w) {
+  unsigned long long a = 0;
+  const long long lo = w * 64 - (long long)L, hi = w * 64 + 63 + (long long)wb;  // marked blocks that reach word w
+  for (long long s = (lo < 0 ? 0 : lo) >> 6; s <= (hi >> 6) && (uint64_t)s < n_words; ++s) {
+    unsigned long long h = hit[s];
+    while (h) {
+      const long long b = s * 64 + (__ffsll((long long)h) - 1);
+      h &= h - 1;
+      // block b makes [b - wb, b + L] part of A'
+      long long x0 = b - (long long)wb - w * 64, x1 = b + (long long)L - w * 64;
+      if (x1 < 0 || x0 > 63) continue;
+      if (x0 < 0) x0 = 0;
+      if (x1 > 63) x1 = 63;
+      a |= (x1 - x0 == 63) ? ~0ull : (((1ull << (x1 - x0 + 1)) - 1ull) << x0);
+    }
+  }
+  return a;
+}
 __device__ __forceinline__ unsigned long long dilated_word(const BuildParams& P, long long w) {
   if (w < 0 || (uint64_t)w >= P.n_words) return 0ull;
-  const unsigned long long cur = P.hit[w];
-  const unsigned long long prev = w > 0 ? P.hit[w - 1] : 0ull;
-  const unsigned long long next = (uint64_t)(w + 1) < P.n_words ? P.hit[w + 1] : 0ull;
-  unsigned long long a = cur;
-  for (uint32_t d = 1; d <= P.L; ++d) a |= (cur << d) | (prev >> (64 - d));    // h -> h + d
-  for (uint32_t d = 1; d <= P.wb; ++d) a |= (cur >> d) | (next << (64 - d));   // h -> h - d (warm-up)
+  unsigned long long a;
+  if (P.L >= 64 || P.wb >= 64) {
+    a = dilated_word_far(P.hit, P.n_words, P.L, P.wb, w);
+  } else {
+    const unsigned long long cur = P.hit[w];
+    const unsigned long long prev = w > 0 ? P.hit[w - 1] : 0ull;
+    const unsigned long long next = (uint64_t)(w + 1) < P.n_words ? P.hit[w + 1] : 0ull;
+    a = cur;
+    for (uint32_t d = 1; d <= P.L; ++d) a |= (cur << d) | (prev >> (64 - d));    // h -> h + d
+    for (uint32_t d = 1; d <= P.wb; ++d) a |= (cur >> d) | (next << (64 - d));   // h -> h - d (warm-up)
+  }
   // blocks past the end of the buffer do not exist
   const uint64_t base = (uint64_t)w * 64;
   if (base + 64 > P.n_blocks) a &= (P.n_blocks > base) ? (~0ull >> (64 - (P.n_blocks - base))) : 0ull;

@@ -111,6 +111,98 @@ def one_case(rng, searchers):
     return ok, desc, pat, text, got, want
 
 
+def fused_case(rng, searchers):
+    """Dna, forward strand, k + 1 <= 8 pieces of >= 7 rows: the bit-plane filter's fused launch (window chunks, duplicate
+    reports, text stash, adopted result blocks) -- larger texts, dense plants, stretches of pattern pieces, whole
+    texts and shards."""
+    k = rng.choice([0, 1, 2, 3, 3, 4, 5, 6, 7])
+    q = rng.choice([7, 8, 9, 12])
+    m = q * (k + 1) + rng.choice([0, 0, 1, 3, 17, 60])
+    n = rng.choice([200, 3_000, 50_000, 300_000, 1_000_000])
+    if m > 120:
+        n = min(n, 300_000)
+    pat = rand_seq(rng, m, b"ACGT")
+    if rng.random() < 0.1:
+        unit = rand_seq(rng, rng.randrange(1, 6), b"ACGT")
+        pat = (unit * (m // len(unit) + 1))[:m]
+    text = bytearray(rand_seq(rng, n, b"ACGT"))
+    style = rng.random()
+    plants = rng.randrange(0, 10) if style < 0.6 else n // rng.choice([200, 400, 1500])
+    for _ in range(plants):
+        ins = mutate(rng, pat, rng.randrange(0, k + 2), spaced=rng.choice([0, 0, 5, max(1, m // (k + 1))]))
+        if len(ins) + 2 >= n:
+            continue
+        at = rng.choice([0, n - len(ins), rng.randrange(0, n - len(ins))])
+        text[at:at + len(ins)] = ins
+    if style > 0.85:  # pieces of the pattern back to back: many occurrences, few matches
+        at = rng.randrange(0, max(1, n - 5000))
+        junk = bytearray()
+        while len(junk) < min(5000, n - at):
+            a = rng.randrange(m)
+            junk += pat[a:a + rng.randrange(q, 2 * q + 1)]
+        text[at:at + len(junk)] = junk[:len(text) - at]
+    text = bytes(text[:n])
+    s = searchers[("dna", False)]
+    allm = rng.random() < 0.2
+    desc = dict(mode="fused", profile="dna", m=m, k=k, n=n, rc=False, all_minima=allm)
+    if rng.random() < 0.3 and n >= 3000 and not allm:  # as shards over a resident text
+        buf = sassy_amd.DeviceBuffer(n + 256)
+        buf.upload(text)
+        halo = sassy_amd.required_halo(m, k)
+        cuts = sorted(set([0, n] + [min(n, 64 * rng.randrange(1, max(2, n // 64))) for _ in range(rng.randrange(1, 4))]))
+        rs = []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            h = 0 if a == 0 else min(halo, a) // 64 * 64
+            if a != 0 and h < halo:
+                rs = None
+                break
+            rs.append(s.search_shard(pat, buf.ptr + a - h, h, b - a, a, n, k))
+        if rs is None:
+            got = s.search(pat, text, k)
+        else:
+            got = sassy_amd.merge_shards(rs, 1).matches
+            desc["shards"] = len(cuts) - 1
+        buf.free()
+    else:
+        got = s.search_all(pat, text, k) if allm else s.search(pat, text, k)
+    want = oracle.search("dna", pat, text, k, all_minima=allm)
+    st = s.stats()
+    desc["filtered"] = st["filtered"] * 10 + st["fused"]
+    desc["matches"] = len(want)
+    return key(got) == key(want), desc, pat, text, got, want
+
+
+def bytes_long_case(rng, searchers):
+    """The cliffs of round 2: Ascii patterns with more than 64 distinct bytes (byte mode) and patterns of 1 800 .. 5 000
+    rows (fewer waves per workgroup)."""
+    if rng.random() < 0.5:
+        m = rng.choice([70, 100, 200, 256, 300])
+        pat = bytes(rng.sample(range(256), min(m, 256))) + bytes(rng.randrange(256) for _ in range(max(0, m - 256)))
+        k = rng.choice([0, 2, 5, 12])
+        n = rng.choice([300, 5_000, 40_000])
+        text = bytearray(rng.randrange(256) for _ in range(n))
+        profile = "ascii"
+    else:
+        m = rng.choice([1800, 2048, 2500, 3333, 4096, 5000])
+        profile = rng.choice(["dna", "iupac"])
+        pat = rand_seq(rng, m, b"ACGT")
+        k = rng.choice([0, 3, 10, 25, 40])
+        n = rng.choice([m + 50, 20_000, 50_000])
+        text = bytearray(rand_seq(rng, n, b"ACGT"))
+    for _ in range(rng.randrange(0, 4)):
+        ins = mutate(rng, pat, rng.randrange(0, k + 2))
+        if len(ins) + 2 < n:
+            at = rng.choice([0, n - len(ins), rng.randrange(0, n - len(ins))])
+            text[at:at + len(ins)] = ins
+    text = bytes(text[:n])
+    s = searchers[(profile, False)]
+    got = s.search(pat, text, k)
+    want = oracle.search(profile, pat, text, k)
+    desc = dict(mode="bytes_long", profile=profile, m=m, k=k, n=n, rc=False, all_minima=False, filtered=s.stats()["filtered"],
+                matches=len(want))
+    return key(got) == key(want), desc, pat, text, got, want
+
+
 def count_case(rng, searchers):
     """The q-gram counting filter and the one-pass two-strand marks on larger texts: patterns with
     ambiguity letters, stray non-ACGT text letters (forced windows), both strands."""
@@ -426,8 +518,9 @@ def main():
     total_matches = 0
     while time.time() - t0 < args.seconds:
         mode = rng.random()
-        fn = (one_case if mode < 0.5 else many_case if mode < 0.62 else encoded_case if mode < 0.74 else shard_case
-              if mode < 0.84 else inflight_case if mode < 0.93 else reflanes_case)
+        fn = (one_case if mode < 0.4 else fused_case if mode < 0.52 else bytes_long_case if mode < 0.56 else many_case
+              if mode < 0.66 else encoded_case if mode < 0.76 else shard_case if mode < 0.85 else inflight_case
+              if mode < 0.93 else reflanes_case)
         if args.focus == "count":
             fn = count_case
         if args.focus == "inflight":
@@ -438,6 +531,10 @@ def main():
             fn = encoded_case
         if args.focus == "many":
             fn = many_case
+        if args.focus == "fused":
+            fn = fused_case
+        if args.focus == "bytes_long":
+            fn = bytes_long_case
         ok, desc, pat, text, got, want = fn(rng, searchers)
         cases += 1
         kinds[desc["filtered"]] = kinds.get(desc["filtered"], 0) + 1
@@ -445,7 +542,7 @@ def main():
         if not ok:
             print("MISMATCH", desc)
             print("pattern", pat)
-            gk, wk = (key(got), key(want)) if desc.get("mode") in (None, "shard", "count", "inflight") else (got, want)
+            gk, wk = (key(got), key(want)) if desc.get("mode") in (None, "shard", "count", "inflight", "fused", "bytes_long") else (got, want)
             print("got", len(gk), "want", len(wk))
             extra = [x for x in gk if x not in set(wk)][:5]
             missing = [x for x in wk if x not in set(gk)][:5]

@@ -2190,6 +2190,15 @@ def test_fuzz_regressions(sassy, name):
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fuzz_regressions", name), "rb") as fh:
         head, pats, text = fh.read().split(b"\n", 2)
     d = ast.literal_eval(head.decode())
+    if d["mode"] in ("bytes_long", "fused"):  # one pattern, one text, forward search
+        assert len(pats) == d["m"] and len(text) == d["n"]
+        want = oracle.search(d["profile"], pats, text, d["k"], all_minima=d["all_minima"])
+        assert len(want) == d["matches"]
+        for pre in (-1, 0):
+            s = sassy.Searcher(d["profile"], rc=False).set_prefilter(pre)
+            got = s.search_all(pats, text, d["k"]) if d["all_minima"] else s.search(pats, text, d["k"])
+            assert_same(got, want, (name, pre, s.stats()["filtered"]))
+        return
     pats = pats.split(b"|")
     assert d["mode"] == "encoded" and len(pats) == d["npat"] and len(text) == d["n"]
     want = sorted(key(m) for m in oracle.search_encoded(d["profile"], pats, text, d["k"], rc=d["rc"], all_minima=d["all_minima"]))

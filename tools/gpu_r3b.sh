@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do
-for f in 2 3; do
-for pad in default 0 8192 12288 16384 24576; do
-  if [ $pad = default ]; then e=""; else e="SASSY_HIP_FILTER_LDS_PAD=$pad"; fi
-  echo "rep $rep in-flight $f pad $pad: $(env $e python bench.py --steps 300 --warmup 50 --no-cpu-baseline --in-flight $f 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')"
-done; done; done
+mkdir -p gpurun_out/r3d
+timeout 600 python tests/fuzz_gpu.py --seconds 200 --seed 32 --focus bytes_long > gpurun_out/r3d/fuzz_bytes.log 2>&1; tail -3 gpurun_out/r3d/fuzz_bytes.log | cut -c1-400
+timeout 900 python tests/fuzz_gpu.py --seconds 500 --seed 33 > gpurun_out/r3d/fuzz_all.log 2>&1; tail -3 gpurun_out/r3d/fuzz_all.log | cut -c1-400
+timeout 900 python tests/fuzz_gpu.py --seconds 200 --seed 34 --focus fused > gpurun_out/r3d/fuzz_fused2.log 2>&1; tail -3 gpurun_out/r3d/fuzz_fused2.log | cut -c1-400
