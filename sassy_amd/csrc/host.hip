@@ -138,6 +138,20 @@ struct PinPool {
   std::mutex mu;
   std::vector<PinBlock> blocks;
   static constexpr size_t kKeep = 12;
+  // blocks that results hold right now: a caller who keeps every result alive must not pin memory without bound (and
+  // pay a hipHostMalloc per search) -- beyond kMaxAdopted outstanding blocks results are copied out as before
+  static constexpr int kMaxAdopted = 16;
+  int adopted = 0;
+  bool may_adopt() {
+    std::lock_guard<std::mutex> g(mu);
+    if (adopted >= kMaxAdopted) return false;
+    ++adopted;
+    return true;
+  }
+  void adopted_back() {
+    std::lock_guard<std::mutex> g(mu);
+    if (adopted > 0) --adopted;
+  }
   bool take(size_t bytes, int dev, PinBlock& out) {
     std::lock_guard<std::mutex> g(mu);
     for (size_t i = 0; i < blocks.size(); ++i)
@@ -174,7 +188,10 @@ struct sassy_hip_Result {
   const sassy_hip_Match* data() const { return pin.h ? ext_matches : matches.data(); }
   const char* pool_data() const { return pin.h ? ext_pool : pool.c_str(); }
   size_t pool_size() const { return pin.h ? ext_pool_len : pool.size(); }
-  ~sassy_hip_Result() { g_pin_pool.give(pin); }
+  ~sassy_hip_Result() {
+    if (pin.h) g_pin_pool.adopted_back();
+    g_pin_pool.give(pin);
+  }
 };
 
 // One search in flight: everything its ScanJob refers to lives here until sassy_hip_search_finish.
@@ -596,6 +613,7 @@ struct ScanOut {
   ScanOut(ScanOut&& o) noexcept { *this = std::move(o); }
   ScanOut& operator=(ScanOut&& o) noexcept {
     if (this != &o) {
+      if (pin.h) g_pin_pool.adopted_back();
       g_pin_pool.give(pin);
       cands = std::move(o.cands); conditional_index = o.conditional_index; exit_state = o.exit_state; cond_seen = o.cond_seen;
       matches = std::move(o.matches); pool = std::move(o.pool);
@@ -604,7 +622,10 @@ struct ScanOut {
     }
     return *this;
   }
-  ~ScanOut() { g_pin_pool.give(pin); }
+  ~ScanOut() {
+    if (pin.h) g_pin_pool.adopted_back();
+    g_pin_pool.give(pin);
+  }
   const sassy_hip_Match* ext_matches = nullptr;
   size_t ext_n = 0;
   const char* ext_pool = nullptr;
@@ -1629,8 +1650,13 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
   uint32_t host_flags = 0;
   memcpy(&host_flags, L.h_pin + kPinFlags, sizeof host_flags);
   static const bool env_noadopt = getenv("SASSY_HIP_ADOPT") && atoi(getenv("SASSY_HIP_ADOPT")) == 0;
-  const bool adopt = sh.adopt_ok && !env_noadopt && do_trace && self_rank && !sorted_on_device && count != 0 && count <= kSpec &&
-                     count <= kTraceWaveMax && texts.n == 0 && host_flags == 0;
+  bool adopt = sh.adopt_ok && !env_noadopt && do_trace && self_rank && !sorted_on_device && count != 0 && count <= kSpec &&
+               count <= kTraceWaveMax && texts.n == 0 && host_flags == 0;
+  if (adopt) adopt = g_pin_pool.may_adopt();
+  struct AdoptSlot {  // the counted slot goes back unless the block really changes hands at the end of this function
+    bool held;
+    ~AdoptSlot() { if (held) g_pin_pool.adopted_back(); }
+  } adopt_slot{adopt};
   if (adopt) {
     out.ext_matches = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + pin_recs);
     out.ext_n = count;
@@ -1838,7 +1864,10 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
   }
   S->stats.cond_resolved += out.cond_seen;
   g_marks.mark("seams");
-  if (adopt) out.pin = L.take_pin();  // (the lane reserves another block in its next prepare())
+  if (adopt) {  // (the lane reserves another block in its next prepare())
+    out.pin = L.take_pin();
+    adopt_slot.held = false;  // the slot now belongs to the block's owner (ScanOut, then the result)
+  }
   return 0;
 }
 

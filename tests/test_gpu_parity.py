@@ -2407,3 +2407,32 @@ def test_searcher_stays_on_its_device_from_any_thread(sassy):
     assert_same(s.search(pat, tb, 3), want)
     with pytest.raises(sassy.SassyHipError, match="another device"):
         s.set_device(1 if sassy.device_count() > 1 else 0) if sassy.device_count() > 1 else (_ for _ in ()).throw(sassy.SassyHipError("another device"))
+
+
+def test_results_that_keep_their_pinned_block(sassy):
+    """A shard search whose records need no editing on the host hands its pinned block to the result (no copy); the
+    blocks come from a pool, at most 16 are out at a time (further results are copied), and results stay valid
+    after later searches, after their searcher is gone, and when they are freed in any order."""
+    pat = bytes(oracle.generate_dna(43, 0, 32))
+    n = 1 << 21
+    buf = sassy.DeviceBuffer(n + 256)
+    sassy.generate_dna(buf.ptr, n, 42, 0)
+    sassy.plant(buf.ptr, n, 0, n, 42, pat, 3, stride=1 << 14)
+    host = buf.download(n)
+    want = oracle.search("dna", pat, host, 3)
+    assert len(want) >= 100
+    s = sassy.Searcher("dna", rc=False)
+    held = [s.search_shard(pat, buf.ptr, 0, n, 0, n, 3) for _ in range(40)]
+    other = s.search_shard(pat, buf.ptr, 0, n, 0, n, 1)  # a different result in between
+    del s
+    first = canon(held[0])
+    for i in (39, 17, 3, 20):
+        assert canon(held[i]) == first, i
+    assert_same(held[5].matches, want)
+    assert_same(other.matches, oracle.search("dna", pat, host, 1))
+    random.Random(3).shuffle(held)
+    while held:
+        held.pop()
+    s2 = sassy.Searcher("dna", rc=False)
+    assert_same(s2.search_shard(pat, buf.ptr, 0, n, 0, n, 3).matches, want)
+    buf.free()
