@@ -20,6 +20,7 @@ SO = os.path.join(LIBDIR, "libsassy_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 CFLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+CFLAGS += os.environ.get("SASSY_EXTRA_CFLAGS", "").split()  # experiments (e.g. -DSASSY_NT_LOADS); build with --force
 
 # (source, object name, extra flags): the scan kernel is compiled once per alphabet profile
 UNITS = [

@@ -327,4 +327,37 @@ struct TraceParams {
 // MatchOut::pad_[0] of a record whose traceback found no ancestor / exceeded the scanned cost
 constexpr uint8_t kTraceFailed = 1;
 
+#if defined(__HIPCC__)
+// 16 text bytes of a streaming kernel.  NT: as a non-temporal load (global_load_dwordx4 ... nt) -- the text is read
+// once, and lines that do not linger in L2 / the Infinity Cache leave the HBM stream 10 % faster (bit-plane filter,
+// 3 GB: 0.565 -> 0.506 ms).  Only where a lane takes whole 128-byte lines per step: a kernel that comes back for the
+// other half of a line one step later must find it in L2.
+template <bool NT>
+__device__ __forceinline__ uint4 stream_load16(const uint8_t* p) {
+  if constexpr (NT) {
+    typedef uint32_t u32x4_nt __attribute__((ext_vector_type(4)));
+    const u32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+  } else {
+    return *reinterpret_cast<const uint4*>(p);
+  }
+}
+#endif
+// which streaming kernels read the text with non-temporal loads (measured per kernel)
+#ifndef SASSY_NT_DNA
+#define SASSY_NT_DNA 1
+#endif
+#ifndef SASSY_NT_SCAN
+#define SASSY_NT_SCAN 0    // (the streaming DP is VALU-bound and stages half lines: 1.07 -> 1.16 ms with it)
+#endif
+#ifndef SASSY_NT_COUNT
+#define SASSY_NT_COUNT 1   // (with two blocks per staging step, the default since: 0.64 -> 0.57-0.61 ms; with one 0.87)
+#endif
+#ifndef SASSY_NT_TABLE
+#define SASSY_NT_TABLE 0
+#endif
+#ifndef SASSY_NT_GENERIC
+#define SASSY_NT_GENERIC 1
+#endif
+
 }  // namespace sassy_hip

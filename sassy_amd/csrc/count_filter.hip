@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void filter_count_kernel(const ScanParams P) {
 #pragma unroll
   for (int i = 0; i < kStageInstr; ++i) {
     nxt[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (interior) nxt[i] = *reinterpret_cast<const uint4*>(text_base + soff[i]);
+    if (interior) nxt[i] = stream_load16<SASSY_NT_COUNT>(text_base + soff[i]);
   }
 
   for (uint32_t it = 0; it < P.n_iter; ++it) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void filter_count_kernel(const ScanParams P) {
         if (it + SB < P.n_iter) {
 #pragma unroll
           for (int i = 0; i < kStageInstr; ++i)
-            nxt[i] = *reinterpret_cast<const uint4*>(text_base + (uint64_t)(it + SB) * 64 + soff[i]);
+            nxt[i] = stream_load16<SASSY_NT_COUNT>(text_base + (uint64_t)(it + SB) * 64 + soff[i]);
         }
       } else {
 #pragma unroll

@@ -1276,7 +1276,7 @@ int ScanJob::prepare() {
     uint32_t extra_front = 1;
     if (fkind == kFilterCount) {
       static const int env_csb = getenv("SASSY_HIP_COUNT_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_COUNT_STAGE_BLOCKS")) : 0;
-      F.stage_blocks = env_csb == 2 ? 2u : 1u;
+      F.stage_blocks = env_csb == 1 ? 1u : 2u;  // (whole 128-byte lines per lane and step: read with non-temporal loads)
       const uint32_t wg_lds = (1u << (2 * (q + count_r - 1))) + 4 * (4096u * F.stage_blocks + 64u * count_w);
       fwpc = 4 * (int)std::min<uint32_t>(8, (160u * 1024u) / wg_lds);
       extra_front = count_w + 1;

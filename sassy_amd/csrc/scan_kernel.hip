@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
       if (interior) {
 #pragma unroll
         for (int i = 0; i < kStageInstr; ++i) {
-          const uint4 v = *reinterpret_cast<const uint4*>(text_base + (uint64_t)it * 64 + soff[i]);
+          const uint4 v = stream_load16<SASSY_NT_SCAN>(text_base + (uint64_t)it * 64 + soff[i]);
           *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
         }
       } else {
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const ScanParams P) {
       if (interior) {
 #pragma unroll
         for (int i = 0; i < kStageInstr; ++i) {
-          const uint4 v = *reinterpret_cast<const uint4*>(text_base + (uint64_t)it * 64 + soff[i]);
+          const uint4 v = stream_load16<SASSY_NT_GENERIC>(text_base + (uint64_t)it * 64 + soff[i]);
           *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
         }
       } else {
@@ -1021,7 +1021,7 @@ __global__ __launch_bounds__(256) void filter_dna_linear_kernel(const ScanParams
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     nxt[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (interior) nxt[i] = *reinterpret_cast<const uint4*>(text_base + soff[i]);
+    if (interior) nxt[i] = stream_load16<SASSY_NT_DNA>(text_base + soff[i]);
   }
   for (uint32_t st = 0; st < n_steps; ++st) {
     const uint64_t base = base0 + 128ull * st;
@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(256) void filter_dna_linear_kernel(const ScanParams
       if (st + 1 < n_steps) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
-          nxt[i] = *reinterpret_cast<const uint4*>(text_base + (uint64_t)(st + 1) * 8192 + soff[i]);
+          nxt[i] = stream_load16<SASSY_NT_DNA>(text_base + (uint64_t)(st + 1) * 8192 + soff[i]);
       }
     } else {
 #pragma unroll
@@ -1175,7 +1175,7 @@ __global__ __launch_bounds__(256) void filter_dna_multi_kernel(const ScanParams 
     for (int i = 0; i < kStageInstr; ++i) {
       const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
       uint4 v;
-      if (interior) v = *reinterpret_cast<const uint4*>(text_base + (uint64_t)it * 64 + soff[i]);
+      if (interior) v = stream_load16<SASSY_NT_DNA>(text_base + (uint64_t)it * 64 + soff[i]);
       else if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
       else v = load_tail16(P.text, off, P.text_len);
       *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(256) void filter_table_kernel(const ScanParams P) {
 #pragma unroll
   for (int i = 0; i < kStageInstr; ++i) {
     nxt[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (interior) nxt[i] = *reinterpret_cast<const uint4*>(text_base + soff[i]);
+    if (interior) nxt[i] = stream_load16<SASSY_NT_TABLE>(text_base + soff[i]);
   }
 
   for (uint32_t it = 0; it < P.n_iter; ++it) {
@@ -1352,7 +1352,7 @@ __global__ __launch_bounds__(256) void filter_table_kernel(const ScanParams P) {
       if (it + 1 < P.n_iter) {
 #pragma unroll
         for (int i = 0; i < kStageInstr; ++i)
-          nxt[i] = *reinterpret_cast<const uint4*>(text_base + (uint64_t)(it + 1) * 64 + soff[i]);
+          nxt[i] = stream_load16<SASSY_NT_TABLE>(text_base + (uint64_t)(it + 1) * 64 + soff[i]);
       }
     } else {
 #pragma unroll
@@ -1750,7 +1750,7 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
 #pragma unroll
   for (int i = 0; i < kStageInstr; ++i) {
     nxt[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (interior) nxt[i] = *reinterpret_cast<const uint4*>(text_base + soff[i]);
+    if (interior) nxt[i] = stream_load16<SASSY_NT_DNA>(text_base + soff[i]);
   }
 
   for (uint32_t it = 0; it < n_iter; ++it) {
@@ -1762,7 +1762,7 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
         if (it + SB < n_iter) {
 #pragma unroll
           for (int i = 0; i < kStageInstr; ++i)
-            nxt[i] = *reinterpret_cast<const uint4*>(text_base + (uint64_t)(it + SB) * 64 + soff[i]);
+            nxt[i] = stream_load16<SASSY_NT_DNA>(text_base + (uint64_t)(it + SB) * 64 + soff[i]);
         }
       } else {
 #pragma unroll
