@@ -1491,9 +1491,12 @@ int ScanJob::enqueue(int attempt) {
       HIP_TRY(hipMemsetAsync(L.d_probe.p, 0, (size_t)wave_blocks * 4 * 8 * 8, L.stream));
     }
     Tw.rank_lds = 0;
-    if (self_rank) {  // room for the end positions of 4096 reports behind the slices (else as many as fit, or none)
+    if (self_rank) {
+      // room for the end positions of up to 4096 reports behind the slices, as long as four workgroups still fit a CU
+      // (wide bands -- config 3: 38 KB of slices per workgroup -- rank from the list in L2: with half the waves
+      // resident the traceback of 2 900 reports took 258 instead of 140 us)
       const size_t used = (size_t)4 * ((plan.m + 15u) & ~15u) + (size_t)4 * Tw.scratch_stride;
-      const size_t room = used < 96 * 1024 ? (96 * 1024 - used) / 8 : 0;
+      const size_t room = used < 39 * 1024 ? (39 * 1024 - used) / 8 : 0;
       Tw.rank_lds = (uint32_t)std::min<size_t>(4096, room);
     }
     if (use_wave) {

@@ -2228,7 +2228,7 @@ _FORCED = [
     {"SASSY_HIP_FILTER_KIND": "1"},                  # filter_kernel (slot masks in LDS)
     {"SASSY_HIP_FILTER_KIND": "3"},                  # filter_table_kernel
     {"SASSY_HIP_FILTER_KIND": "4"},                  # filter_count_kernel
-    {"SASSY_HIP_FILTER_KIND": "4", "SASSY_HIP_COUNT_STAGE_BLOCKS": "2"},
+    {"SASSY_HIP_FILTER_KIND": "4", "SASSY_HIP_COUNT_STAGE_BLOCKS": "1"},  # (half lines per step; the default is whole lines)
     {"SASSY_HIP_ROW_CUT": "0"},                      # list kernels without bounded rows
     {"SASSY_HIP_FUSED": "0"},                        # classic chain: bitmap -> chunk list -> list kernel
     {"SASSY_HIP_FILTER_LINEAR": "64"},               # filter_dna_linear_kernel

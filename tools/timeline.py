@@ -12,7 +12,7 @@ rows = []
 for f in files:
     with open(f) as fh:
         for r in csv.DictReader(fh):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("sassy_hip::", "")[:48]))
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("sassy_hip::", "")[:48]))
 rows.sort()
 # searches = runs of kernels that start with first_key
 starts = [i for i, r in enumerate(rows) if first_key in r[2]]
