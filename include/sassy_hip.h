@@ -274,7 +274,12 @@ int64_t sassy_hip_result_conditional_index(const sassy_hip_Result *r); /* -1 if 
 void sassy_hip_result_free(sassy_hip_Result *r);
 
 /* Searcher::encode_patterns / search_encoded_patterns (src/search.rs:404-423):
- * npat patterns of equal length plen (<= 64) stored back to back. */
+ * npat patterns of equal length plen (<= 64) stored back to back.
+ * Limits of the many-pattern calls (this one and sassy_hip_search_many): the reports are the definition's (one
+ * left-to-right pass per pattern and text) -- sassy_hip_set_reference_lanes is not applied to them; with an overhang
+ * searcher (alpha) the one-pass kernels (seeded search, pattern-tiled scan) are not used: the patterns then run
+ * one kernel chain each, correct but at the speed of single searches (the reference's v2 scans overhang in its
+ * tiled loop, src/pattern_tiling/search.rs:222-323). */
 sassy_hip_Encoded *sassy_hip_encode_patterns(sassy_SearcherType *s, const uint8_t *patterns,
                                              size_t npat, size_t plen);
 void sassy_hip_encoded_free(sassy_hip_Encoded *e);
