@@ -63,25 +63,35 @@ struct DpWord {
 // src/bitpacking.rs:63-85).  eq = columns whose text char matches the row's
 // pattern char; hp0/hm0 = vertical delta on the block's left edge in this row (0/1 each);
 // the right-edge vertical delta is shifted into nhp/nhm (first row ends up in the top bit).
+// (a << SH) + b on 64-bit register pairs: one full-rate VALU instruction on gfx950 (the compiler splits a
+// 64-bit shift by one into three instructions when left to itself)
+template <int SH>
+__device__ __forceinline__ uint64_t lshl_add_u64(uint64_t a, uint64_t b) {
+  uint64_t r;
+  asm("v_lshl_add_u64 %0, %1, %3, %2" : "=&v"(r) : "v"(a), "v"(b), "n"(SH));
+  return r;
+}
+__device__ __forceinline__ uint64_t pair64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+
+// zz: two registers holding 0, one per carry (each sits behind its carry bit in a 64-bit register pair; two, so
+// that neither has to be copied into place row after row).
 __device__ __forceinline__ void dp_row(DpWord& V, uint2 eq, uint32_t hp0, uint32_t hm0,
-                                       uint32_t& nhp, uint32_t& nhm) {
+                                       uint32_t& nhp, uint32_t& nhm, uint2 zz = make_uint2(0u, 0u)) {
   const uint32_t vxl = eq.x | V.vml, vxh = eq.y | V.vmh;
   const uint32_t e2l = eq.x | hm0, e2h = eq.y;
-  const uint64_t t = ((uint64_t)(e2h & V.vph) << 32) | (e2l & V.vpl);
-  const uint64_t vp64 = ((uint64_t)V.vph << 32) | V.vpl;
-  const uint64_t sum = t + vp64;
-  const uint32_t hxl = ((uint32_t)sum ^ V.vpl) | e2l;
-  const uint32_t hxh = ((uint32_t)(sum >> 32) ^ V.vph) | e2h;
-  const uint32_t Hpl = V.vml | ~(hxl | V.vpl), Hph = V.vmh | ~(hxh | V.vph);
+  const uint64_t sum = lshl_add_u64<0>(pair64(e2l & V.vpl, e2h & V.vph), pair64(V.vpl, V.vph));
+  const uint32_t hxl = bitop3<0xBE>(lo32(sum), V.vpl, e2l);  // (a ^ b) | c
+  const uint32_t hxh = bitop3<0xBE>(hi32(sum), V.vph, e2h);
+  const uint32_t Hpl = bitop3<0xF1>(V.vml, hxl, V.vpl), Hph = bitop3<0xF1>(V.vmh, hxh, V.vph);  // a | ~(b | c)
   const uint32_t Hml = V.vpl & hxl, Hmh = V.vph & hxh;
   nhp = __builtin_amdgcn_alignbit(nhp, Hph, 31);  // (nhp << 1) | (Hph >> 31)
   nhm = __builtin_amdgcn_alignbit(nhm, Hmh, 31);
-  const uint32_t Hp2h = __builtin_amdgcn_alignbit(Hph, Hpl, 31), Hp2l = (Hpl << 1) | hp0;
-  const uint32_t Hm2h = __builtin_amdgcn_alignbit(Hmh, Hml, 31), Hm2l = (Hml << 1) | hm0;
-  V.vpl = Hm2l | ~(vxl | Hp2l);
-  V.vph = Hm2h | ~(vxh | Hp2h);
-  V.vml = Hp2l & vxl;
-  V.vmh = Hp2h & vxh;
+  const uint64_t Hp2 = lshl_add_u64<1>(pair64(Hpl, Hph), pair64(hp0, zz.x));
+  const uint64_t Hm2 = lshl_add_u64<1>(pair64(Hml, Hmh), pair64(hm0, zz.y));
+  V.vpl = bitop3<0xF1>(lo32(Hm2), vxl, lo32(Hp2));
+  V.vph = bitop3<0xF1>(hi32(Hm2), vxh, hi32(Hp2));
+  V.vml = lo32(Hp2) & vxl;
+  V.vmh = hi32(Hp2) & vxh;
 }
 
 // Lower bound on the minimum of the 65 cells of a row: cell b = ds + P_b - M_b with P_b / M_b the
@@ -448,6 +458,8 @@ __device__ __forceinline__ uint32_t dp_word(DpWord& V, const unsigned char* my_m
   }
   uint32_t nhp = 0, nhm = 0, done = 0;
   bool stopped = false;  // wave-uniform
+  uint2 zz = make_uint2(0u, 0u);
+  asm volatile("" : "+v"(zz.x), "+v"(zz.y));
   uint2 planes[BYTES ? 8 : 1];
   if constexpr (BYTES) {
 #pragma unroll
@@ -470,32 +482,35 @@ __device__ __forceinline__ uint32_t dp_word(DpWord& V, const unsigned char* my_m
     if constexpr (BYTES) eqn[u] = eq_of_byte(row_byte(u));
     else eqn[u] = *reinterpret_cast<const uint2*>(my_masks + row_mask_off(pk, u));
   }
+  // (straight-line flow with early exits: nothing but the exit merges register values, so the Eq words of the next
+  // group are loaded into fresh registers instead of being copied into place)
 #pragma unroll
   for (int g = 0; g < 8; ++g) {
-    if (!stopped && 4u * g + 4u <= rows) {
-      uint2 eqc[4];
+    if (4u * g + 4u > rows) break;  // wave-uniform
+    uint2 eqc[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) eqc[u] = eqn[u];
-      if (g < 7) {  // prefetch the next group's Eq words while this group computes
+    for (int u = 0; u < 4; ++u) eqc[u] = eqn[u];
+    if (g < 7) {  // prefetch the next group's Eq words while this group computes
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if constexpr (BYTES) eqn[u] = eq_of_byte(row_byte(4 * g + 4 + u));
-          else eqn[u] = *reinterpret_cast<const uint2*>(my_masks + row_mask_off(pk, 4 * g + 4 + u));
-        }
+      for (int u = 0; u < 4; ++u) {
+        if constexpr (BYTES) eqn[u] = eq_of_byte(row_byte(4 * g + 4 + u));
+        else eqn[u] = *reinterpret_cast<const uint2*>(my_masks + row_mask_off(pk, 4 * g + 4 + u));
       }
+    }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        dp_row(V, eqc[u], (ohp >> (31 - (4 * g + u))) & 1u, (ohm >> (31 - (4 * g + u))) & 1u, nhp, nhm);
-      done = 4u * g + 4u;
-      if constexpr (CUT) {
-        if (done >= cut->first_test && (done < rows || cut->more_words)) {  // wave-uniform
-          const uint32_t top = 0xFFFFFFFFu << (28 - 4 * g);  // rows 0 .. done-1 of the word (compile-time: g is unrolled)
-          // (HIP's __popc returns unsigned: keep the arithmetic signed, the bound is often negative)
-          const int here = cut->ds_word + (int)__popc(ohp & top) - (int)__popc(ohm & top);
-          const bool below_dead = here - (int)__popc(ohm & ~top) - cut->minus_below > cut->k;
-          const bool dead = cut->idle || (below_dead && !row_maybe_live(here, V, cut->k));
-          stopped = __all(dead);
-        }
+    for (int u = 0; u < 4; ++u)
+      dp_row(V, eqc[u], (ohp >> (31 - (4 * g + u))) & 1u, (ohm >> (31 - (4 * g + u))) & 1u, nhp, nhm, zz);
+    done = 4u * g + 4u;
+    if constexpr (CUT) {
+      if (done >= cut->first_test && (done < rows || cut->more_words)) {  // wave-uniform
+        const uint32_t top = 0xFFFFFFFFu << (28 - 4 * g);  // rows 0 .. done-1 of the word (compile-time: g is unrolled)
+        // (HIP's __popc returns unsigned: keep the arithmetic signed, the bound is often negative)
+        const int here = cut->ds_word + (int)__popc(ohp & top) - (int)__popc(ohm & top);
+        const bool below_dead = here - (int)__popc(ohm & ~top) - cut->minus_below > cut->k;
+        // two votes: the cheap left-edge condition first (a lane whose left edge is still <= k further down keeps
+        // the whole wave going whatever this row looks like), the row's own cells only when it holds everywhere
+        if (__all(cut->idle || below_dead)) stopped = __all(cut->idle || !row_maybe_live(here, V, cut->k));
+        if (stopped) break;
       }
     }
   }
@@ -510,7 +525,7 @@ __device__ __forceinline__ uint32_t dp_word(DpWord& V, const unsigned char* my_m
         uint2 eq;
         if constexpr (BYTES) eq = eq_of_byte(pw >> (8 * (r & 3)));
         else eq = *reinterpret_cast<const uint2*>(my_masks + (((pw >> (8 * (r & 3))) & 0xFFu) << 8));
-        dp_row(V, eq, (ohp >> (31 - r)) & 1u, (ohm >> (31 - r)) & 1u, nhp, nhm);
+        dp_row(V, eq, (ohp >> (31 - r)) & 1u, (ohm >> (31 - r)) & 1u, nhp, nhm, zz);
       }
     }
     if (rows < 32) { nhp <<= (32 - rows); nhm <<= (32 - rows); }

@@ -34,4 +34,12 @@ if os.environ.get("SASSY_HIP_FUSED_PROBE"):
     w = max(1, st["live_blocks"])
     out["probe"] = {"waves_with_chunks": st["live_blocks"], "stream_us_per_wave": round(st["word_rows"] / w / 100, 2),
                     "dp_us_per_wave": round(st["blocks"] / w / 100, 2), "chunks_per_wave": round(st["hit_blocks"] / w, 2)}
+if os.environ.get("PROBE_COUNTERS"):  # rows the streaming DP computed per block (wave-voted cut-off)
+    c0 = s.stats()
+    s.enable_counters(True)
+    s.search_shard(pat, buf.ptr, 0, n, 0, n, k)
+    c = s.stats()
+    d = {x: c[x] - c0[x] for x in ("word_rows", "blocks", "live_blocks")}
+    out["rows_per_block"] = round(d["word_rows"] / max(1, d["blocks"]), 2)
+    out["live_frac"] = round(d["live_blocks"] / max(1, d["blocks"]), 5)
 print(json.dumps(out), flush=True)
