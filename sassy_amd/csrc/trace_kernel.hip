@@ -370,6 +370,16 @@ __device__ __forceinline__ int dpp_min_scan(int x) {
   return x;
 }
 
+// the same within the first 16 lanes (one DPP row): enough for a band of <= 16 columns
+__device__ __forceinline__ int dpp_min_scan16(int x) {
+  constexpr int kId = 0x7FFFFFFF;
+  x = min(x, __builtin_amdgcn_update_dpp(kId, x, 0x111, 0xF, 0xF, false));  // row_shr:1
+  x = min(x, __builtin_amdgcn_update_dpp(kId, x, 0x112, 0xF, 0xF, false));  // row_shr:2
+  x = min(x, __builtin_amdgcn_update_dpp(kId, x, 0x114, 0xF, 0xF, false));  // row_shr:4
+  x = min(x, __builtin_amdgcn_update_dpp(kId, x, 0x118, 0xF, 0xF, false));  // row_shr:8
+  return x;
+}
+
 // ALPHA: overhang (use_alpha) -- the common searches get a fill loop without its branches
 template <typename Cell, bool ALPHA>
 __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
@@ -524,14 +534,14 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
       prev = (!in_band || i < 0 || i > iend) ? inf : 0;
       if (in_band) L[b] = (Cell)prev;
     }
-    for (int j = 1; j <= m; ++j) {
-      const uint32_t pc = spat[j - 1];
-      const int i = j + dlo + b;
-      const bool valid = in_band && i >= 0 && i <= iend;
-      // upper neighbour (j-1, i) = band column b+1 of the previous row
-      const int up = __builtin_amdgcn_update_dpp(inf, prev, 0x130, 0xF, 0xF, false);  // wave_shl:1
-      int t = inf;
-      if constexpr (ALPHA) {
+    if constexpr (ALPHA) {
+      for (int j = 1; j <= m; ++j) {
+        const uint32_t pc = spat[j - 1];
+        const int i = j + dlo + b;
+        const bool valid = in_band && i >= 0 && i <= iend;
+        // upper neighbour (j-1, i) = band column b+1 of the previous row
+        const int up = __builtin_amdgcn_update_dpp(inf, prev, 0x130, 0xF, 0xF, false);  // wave_shl:1
+        int t = inf;
         if (valid) {
           if (i == 0) {
             const int lc = ov_left(P, j);
@@ -543,30 +553,56 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
             t = dg < u ? dg : u;
           }
         }
-      } else {
-        // branch-free: the byte index is clamped into the window, cells that do not use it are overwritten
-        int ci = i - 1;
-        ci = ci < 0 ? 0 : (ci > iend ? iend : ci);
-        const uint32_t tc = win[ci];
+        // left dependency: v[b] = b + min_{b' <= b} (t[b'] - b'); invalid cells carry a large value
+        int v = dpp_min_scan(valid ? t - b : 0x3FFFFFFF) + b;
+        v = (valid && v < inf) ? v : inf;
+        if (in_band) L[(size_t)j * bw + b] = (Cell)v;
+        prev = v;
+      }
+    } else {
+      // Branch-free rows.  The reports of a call run side by side (about three waves per SIMD), so a row costs what
+      // it issues: its two LDS reads are requested one row ahead, the band column's first / last row inside the
+      // window are per-lane constants, and a band of <= 16 columns (k <= 6) scans within one 16-lane row.
+      const int lo_j = -(dlo + b);      // the row in which this band column is window column 0
+      const int hi_j = iend - dlo - b;  // the last row in which it lies inside the window
+      const bool narrow = bw <= 16;     // wave-uniform
+      // the text byte under cell (j, i) is win[i - 1] = wp[j - 1].  No clamping: a cell outside the window reads some
+      // other byte of the wave's own slice (the band lies in front of the window, ops and text behind it, and
+      // |dlo + b| stays below either size) and is overwritten.
+      const unsigned char* wp = win + (dlo + b);
+      uint32_t pcn = spat[0], tcn = wp[0];
+#pragma unroll 2
+      for (int j = 1; j <= m; ++j) {
+        const uint32_t pc = pcn, tc = tcn;
+        if (j < m) {
+          pcn = spat[j];
+          tcn = wp[j];
+        }
+        const int up = __builtin_amdgcn_update_dpp(inf, prev, 0x130, 0xF, 0xF, false);  // wave_shl:1
+        const bool valid = in_band && j >= lo_j && j <= hi_j;
         const int dg = prev + (rule_hit(rule, pc, tc, rule.emask) ? 0 : 1);
         const int u = up + 1;
-        t = dg < u ? dg : u;
-        t = i == 0 ? (j < inf ? j : inf) : t;
-        t = valid ? t : inf;
+        int t = dg < u ? dg : u;
+        t = j == lo_j ? (j < inf ? j : inf) : t;
+        const int x = valid ? t - b : 0x3FFFFFFF;
+        int v = (narrow ? dpp_min_scan16(x) : dpp_min_scan(x)) + b;
+        v = (valid && v < inf) ? v : inf;
+        if (in_band) L[(size_t)j * bw + b] = (Cell)v;
+        prev = v;
       }
-      // left dependency: v[b] = b + min_{b' <= b} (t[b'] - b'); invalid cells carry a large value
-      int v = dpp_min_scan(valid ? t - b : 0x3FFFFFFF) + b;
-      v = (valid && v < inf) ? v : inf;
-      if (in_band) L[(size_t)j * bw + b] = (Cell)v;
-      prev = v;
     }
     // make the band and the window visible to every lane (same wave: LDS ops are in order, this
     // only keeps the compiler from reordering)
     __builtin_amdgcn_wave_barrier();
     tick(2);  // band fill
-    // ---- greedy walk from (m, iend), wave-uniform ----
-    int j = m, i = iend;
-    int g = (int)L[(size_t)m * bw + (k + 1)];
+    // ---- greedy walk from (m, iend) ----
+    // Every lane follows the same path, so the state lives in scalars (readfirstlane: the compiler cannot know that
+    // the report is the same for the whole wave) and the branches are scalar branches.  Most steps are '=' along a
+    // diagonal: lane t tests the step t cells further up, a ballot gives the length of the run and the wave takes it
+    // in one round -- about 2k + 1 rounds of one LDS round trip each instead of m + k dependent steps.
+    int j = __builtin_amdgcn_readfirstlane(m), i = __builtin_amdgcn_readfirstlane(iend);
+    const int dlo_s = __builtin_amdgcn_readfirstlane(dlo);
+    int g = __builtin_amdgcn_readfirstlane((int)L[(size_t)m * bw + (k + 1)]);
     int cost = g;
     uint32_t pattern_start = 0, pattern_end = P.m;
     const uint32_t max_ops = P.m + P.k + 1;
@@ -589,31 +625,81 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
         break;
       }
       if (nops >= max_ops) { ok = false; break; }
-      const int bb = i - j - dlo;
-      const Cell* row = L + (size_t)j * bw;
-      const Cell* prow = row - bw;
-      const int diag = i > 0 ? (int)prow[bb] : inf;
-      if (diag == g && rule_hit(rule, spat[j - 1], win[i - 1], rule.mmask)) {
-        if (lane == 0) ops[nops] = '=';
-        ++nops; --j; --i; continue;
+      const int bb = i - j - dlo_s;
+      const int t = (int)lane;
+      const bool can = t < j && t < i;  // lane 0: i > 0
+      const int tt = can ? t : 0;
+      const int cell = can ? (int)L[(size_t)(j - 1 - tt) * bw + bb] : -1;
+      const uint32_t pc = spat[j - 1 - tt], tc = win[i > 0 ? i - 1 - tt : 0];
+      // the other two neighbours of (j, i), for the step that ends the run (same LDS round trip)
+      const int lft_v = (i > 0 && bb > 0) ? (int)L[(size_t)j * bw + bb - 1] : inf;
+      const int up_v = (bb + 1 < bw) ? (int)L[(size_t)(j - 1) * bw + bb + 1] : inf;
+      const bool hit = can && cell == g && rule_hit(rule, pc, tc, rule.mmask);
+      const unsigned long long bal = __ballot(hit);
+      const uint32_t run = bal == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~bal);
+      if (run) {
+        if (nops + run > max_ops) { ok = false; break; }
+        if (lane < run) ops[nops + lane] = '=';
+        nops += run; j -= (int)run; i -= (int)run;
+        continue;
       }
       g -= 1;
       if (g < 0) { ok = false; break; }
-      if (diag == g) { if (lane == 0) ops[nops] = 'X'; ++nops; --j; --i; continue; }
-      const int lft = (i > 0 && bb > 0) ? (int)row[bb - 1] : inf;
-      if (lft == g) { if (lane == 0) ops[nops] = 'D'; ++nops; --i; continue; }
-      const int up = (bb + 1 < bw) ? (int)prow[bb + 1] : inf;
-      if (up == g) { if (lane == 0) ops[nops] = 'I'; ++nops; --j; continue; }
-      ok = false;  // the reference panics here ("Trace failed! No ancestor found")
+      const int diag = i > 0 ? __builtin_amdgcn_readfirstlane(cell) : inf;
+      unsigned char op;
+      if (diag == g) { op = 'X'; --j; --i; }
+      else if (__builtin_amdgcn_readfirstlane(lft_v) == g) { op = 'D'; --i; }
+      else if (__builtin_amdgcn_readfirstlane(up_v) == g) { op = 'I'; --j; }
+      else { ok = false; break; }  // the reference panics here ("Trace failed! No ancestor found")
+      if (lane == 0) ops[nops] = op;
+      ++nops;
     }
     if (ok && g != 0) ok = false;
     if (cost > cd.cost) ok = false;  // src/search.rs:1672-1685
     __builtin_amdgcn_wave_barrier();
     tick(3);  // walk
+    // ---- cigar text: run-length encoded, start -> end (the ops were recorded end -> start), by the whole wave:
+    // run starts by ballot into the band's memory (the walk is done with it), then one lane per run ----
     unsigned char* sbuf = ops + P.ops_bytes;
     uint32_t w = 0;
-    if (lane == 0) w = rle_text(ops, nops, ok, sbuf);
-    w = __builtin_amdgcn_readfirstlane(w);
+    if (ok && nops) {
+      uint16_t* starts = reinterpret_cast<uint16_t*>(slice);
+      uint32_t nruns = 0;
+      for (uint32_t x0 = 0; x0 < nops; x0 += 64u) {
+        const uint32_t x = x0 + lane;
+        const bool valid = x < nops;
+        const uint32_t cur = valid ? ops[nops - 1u - x] : 0u;
+        const uint32_t prv = (valid && x > 0) ? ops[nops - x] : 0x100u;
+        const bool is_start = valid && cur != prv;
+        const unsigned long long sb = __ballot(is_start);
+        if (is_start) starts[nruns + (uint32_t)__popcll(sb & ((1ull << lane) - 1ull))] = (uint16_t)x;
+        nruns += (uint32_t)__popcll(sb);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t r0 = 0; r0 < nruns; r0 += 64u) {
+        const uint32_t r = r0 + lane;
+        const bool valid = r < nruns;
+        const uint32_t s0 = valid ? starts[r] : 0u;
+        const uint32_t e0 = valid ? (r + 1u < nruns ? (uint32_t)starts[r + 1u] : nops) : 0u;
+        uint32_t len = e0 - s0;
+        const unsigned char op = valid ? ops[nops - 1u - s0] : (unsigned char)0;
+        const uint32_t nd = len >= 10000u ? 5u : len >= 1000u ? 4u : len >= 100u ? 3u : len >= 10u ? 2u : 1u;
+        const uint32_t tl = valid ? nd + 1u : 0u;
+        uint32_t incl = tl;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const uint32_t v = __shfl_up(incl, d);
+          if ((int)lane >= d) incl += v;
+        }
+        const uint32_t off = w + incl - tl;
+        if (valid) {
+          for (int q = (int)nd - 1; q >= 0; --q) { sbuf[off + q] = (unsigned char)('0' + len % 10u); len /= 10u; }
+          sbuf[off + nd] = op;
+        }
+        w += __builtin_amdgcn_readlane(incl, 63);
+      }
+    }
+    if (lane == 0) { sbuf[w] = 0; sbuf[w + 1] = 0; sbuf[w + 2] = 0; sbuf[w + 3] = 0; }
     __builtin_amdgcn_wave_barrier();
     {
       const uint32_t ndw = w / 4 + 1;
