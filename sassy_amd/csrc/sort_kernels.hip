@@ -5,6 +5,7 @@
 // allows for library primitives) does the same in a fraction of a millisecond.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>  // (rocprim's texture iterator uses memset without including it)
 
 #include <rocprim/rocprim.hpp>
@@ -29,8 +30,29 @@ __global__ __launch_bounds__(256) void sort_keys_kernel(const Candidate* __restr
 // cost > k, so its first plateau counts as entered by a decrease and its last as left by an increase.
 // The list may hold an entry several times (the seeded search sees a match through each of its intact pieces):
 // the first copy stands for all.  all_minima: every distinct entry is a report.
+//
+// "entered by a decrease" needs the entry in front of the plateau.  A plateau can be as long as the list (poly-A,
+// microsatellites, runs of N: 2^26 .. 2^28 entries), so no thread walks it: plateau_heads_kernel marks every entry
+// that begins a plateau (not a copy of, and not the same-cost right neighbour of, the entry in front of it), an
+// inclusive max-scan hands every entry the index of its plateau's first entry, and the rule looks at that one's
+// predecessor.
+__global__ __launch_bounds__(256) void plateau_heads_kernel(const Candidate* __restrict__ c, uint32_t count,
+                                                            uint32_t* __restrict__ head) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  uint32_t h = 0;
+  if (i > 0) {
+    const Candidate me = c[i], pv = c[i - 1];
+    const bool same_plateau = (pv.flags >> kCandTextShift) == (me.flags >> kCandTextShift) &&
+                              (pv.pos == me.pos || (pv.pos + 1 == me.pos && pv.cost == me.cost));
+    h = same_plateau ? 0u : i;
+  }
+  head[i] = h;
+}
+
 __global__ __launch_bounds__(256) void flag_reports_kernel(const Candidate* __restrict__ c, uint32_t count,
-                                                           unsigned char* __restrict__ keep, int all_minima) {
+                                                           unsigned char* __restrict__ keep, int all_minima,
+                                                           const uint32_t* __restrict__ head) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= count) return;
   const Candidate me = c[i];
@@ -42,7 +64,8 @@ __global__ __launch_bounds__(256) void flag_reports_kernel(const Candidate* __re
   }
   if (me.flags & kCandCont) report = all_minima != 0;  // its plateau goes on over positions the list leaves out
   if (report && !all_minima) {
-    for (uint32_t j = i + 1; j < count; ++j) {  // the next distinct entry
+    // the next distinct entry (copies are few: the seeded search lists an entry at most once per pattern piece, k + 1 <= 8)
+    for (uint32_t j = i + 1; j < count; ++j) {
       const Candidate nx = c[j];
       if ((nx.flags >> kCandTextShift) != tag) break;
       if (nx.pos == me.pos) continue;
@@ -50,15 +73,11 @@ __global__ __launch_bounds__(256) void flag_reports_kernel(const Candidate* __re
       break;
     }
   }
-  if (report && !all_minima) {  // walk to the left end of the plateau
-    uint64_t pos = me.pos;
-    for (uint32_t j = i; j > 0; --j) {
-      const Candidate pv = c[j - 1];
-      if ((pv.flags >> kCandTextShift) != tag) break;  // start of the run
-      if (pv.pos == pos) continue;                      // a copy
-      if (pv.pos + 1 != pos) break;                     // start of the run
-      if (pv.cost != me.cost) { report = pv.cost > me.cost; break; }
-      pos = pv.pos;
+  if (report && !all_minima) {  // the entry in front of the plateau: higher cost, or the run starts here
+    const uint32_t h = head[i];
+    if (h > 0) {
+      const Candidate first = c[h], pv = c[h - 1];
+      if ((pv.flags >> kCandTextShift) == tag && pv.pos + 1 == first.pos) report = pv.cost > me.cost;
     }
   }
   keep[i] = report ? 1 : 0;
@@ -113,13 +132,17 @@ hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, 
   return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, d_cand, d_sorted, (size_t)count, 0, 64, stream);
 }
 
-// Bytes of scratch launch_select_reports needs.
+// Bytes of scratch launch_select_reports needs: keep flags, plateau heads (marks, scanned), rocPRIM's own for the
+// larger of its two calls.
+static size_t heads_bytes(uint32_t count) { return ((size_t)count * 4 + 255) / 256 * 256; }
 size_t select_scratch_bytes(uint32_t count) {
-  size_t temp = 0;
+  size_t temp = 0, temp2 = 0;
   (void)rocprim::select(nullptr, temp, static_cast<Candidate*>(nullptr), static_cast<unsigned char*>(nullptr),
                         static_cast<Candidate*>(nullptr), static_cast<uint32_t*>(nullptr), (size_t)count,
                         hipStream_t(nullptr));
-  return ((size_t)count + 255) / 256 * 256 + temp + 256;
+  (void)rocprim::inclusive_scan(nullptr, temp2, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                                (size_t)count, rocprim::maximum<uint32_t>(), hipStream_t(nullptr));
+  return ((size_t)count + 255) / 256 * 256 + 2 * heads_bytes(count) + std::max(temp, temp2) + 256;
 }
 
 // sel[0 .. *sel_count) = the reports among sorted[0 .. count) (flag_reports_kernel), order kept.
@@ -128,12 +151,23 @@ hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Cand
                                  void* d_scratch, size_t scratch_bytes, hipStream_t stream, int all_minima) {
   if (count == 0) return hipMemsetAsync(d_sel_count, 0, 4, stream);
   const size_t flag_bytes = ((size_t)count + 255) / 256 * 256;
-  if (scratch_bytes < flag_bytes) return hipErrorInvalidValue;
+  const size_t hb = heads_bytes(count);
+  if (scratch_bytes < flag_bytes + 2 * hb) return hipErrorInvalidValue;
   unsigned char* keep = static_cast<unsigned char*>(d_scratch);
-  void* temp = keep + flag_bytes;
-  size_t temp_bytes = scratch_bytes - flag_bytes;
-  hipLaunchKernelGGL(flag_reports_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_sorted, count, keep, all_minima);
-  hipError_t e = hipGetLastError();
+  uint32_t* marks = reinterpret_cast<uint32_t*>(keep + flag_bytes);
+  uint32_t* heads = reinterpret_cast<uint32_t*>(keep + flag_bytes + hb);
+  void* temp = keep + flag_bytes + 2 * hb;
+  size_t temp_bytes = scratch_bytes - flag_bytes - 2 * hb;
+  hipError_t e;
+  if (!all_minima) {
+    hipLaunchKernelGGL(plateau_heads_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_sorted, count, marks);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    e = rocprim::inclusive_scan(temp, temp_bytes, marks, heads, (size_t)count, rocprim::maximum<uint32_t>(), stream);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(flag_reports_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_sorted, count, keep, all_minima,
+                     all_minima ? nullptr : heads);
+  e = hipGetLastError();
   if (e != hipSuccess) return e;
   return rocprim::select(temp, temp_bytes, d_sorted, keep, d_sel, d_sel_count, (size_t)count, stream);
 }

@@ -1013,6 +1013,39 @@ def test_encoded_seeded(sassy):
     _encoded_filters_agree(sassy, rng, "SASSY_HIP_SEEDED", 6)
 
 
+def test_encoded_patterns_on_long_plateaus(sassy):
+    """The report rule on the sorted list of all end positions (sort_kernels.hip): a plateau of 300 000 equal costs
+    (poly-A text, patterns cut from it or one edit away) has ONE report, decided by the entry in front of the plateau
+    -- found by a scan over the list, not by a thread that walks it.  Seeded and pattern-tiled search, both strands,
+    against the oracle."""
+    import os
+    rng = random.Random(17)
+    flank = lambda n: bytes(rng.choice(b"ACGT") for _ in range(n))
+    tb = flank(3_000) + b"A" * 300_000 + flank(2_000) + b"AC" * 40_000 + flank(3_000) + b"T" * 50_000
+    pats = [b"A" * 20, b"A" * 19 + b"C", b"C" + b"A" * 19, b"AC" * 10, b"CA" * 10, b"A" * 10 + b"G" + b"A" * 9,
+            b"T" * 20, flank(20), flank(20)]
+    try:
+        for env in ("SASSY_HIP_SEEDED", "SASSY_HIP_TILED"):
+            os.environ.pop("SASSY_HIP_SEEDED", None)
+            os.environ.pop("SASSY_HIP_TILED", None)
+            os.environ[env] = "1"
+            for rc in (False, True):
+                for allm in (False, True):
+                    if allm and rc:
+                        continue
+                    s = sassy.Searcher("dna", rc=rc)
+                    enc = s.encode_patterns(pats)
+                    got = s.search_encoded_patterns(enc, tb, 2, all_minima=allm, without_trace=True)
+                    want = oracle.search_encoded("dna", pats, tb, 2, rc=rc, all_minima=allm)
+                    a = sorted((x.pattern_idx, x.text_end, x.cost, x.strand) for x in got)
+                    b = sorted((x.pattern_idx, x.text_end, x.cost, x.strand) for x in want)
+                    assert a == b, (env, rc, allm, len(a), len(b))
+                    assert len(b) >= (300_000 if allm else 10)
+    finally:
+        os.environ.pop("SASSY_HIP_SEEDED", None)
+        os.environ.pop("SASSY_HIP_TILED", None)
+
+
 def test_dense_search_then_long_cigars_on_one_searcher(sassy):
     """A searcher keeps its device buffers across calls: after a search with millions of reports (the report buffer
     grows with them) a search whose cigars are long must not size its cigar pool by that capacity (2.1 M reports
