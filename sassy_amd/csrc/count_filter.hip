@@ -48,8 +48,10 @@ __device__ __noinline__ uint4 tail16(const uint8_t* text, uint64_t off, uint64_t
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <int Q, int R, int SB>
-__global__ __launch_bounds__(256) void filter_count_kernel(const ScanParams P) {
+// WPG: waves per workgroup.  The q-gram table is per workgroup: sixteen waves around one copy leave room for sixteen
+// waves per CU (four around each of three copies: twelve).
+template <int Q, int R, int SB, int WPG>
+__global__ __launch_bounds__(64 * WPG) void filter_count_kernel(const ScanParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr uint32_t kTableBytes = 1u << (2 * (Q + R - 1));
   constexpr uint32_t kRowBytes = 64u * SB;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void filter_count_kernel(const ScanParams P) {
   for (uint32_t s = 0; s < W; ++s) ring[s * 64] = 0;
   __syncthreads();
 
-  const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * kWavesPerGroup + wave) * kWave;
+  const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * WPG + wave) * kWave;
   if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
   const uint64_t chunk = wave_chunk0 + lane;
   const uint32_t bpl = P.bpl;
@@ -204,22 +206,23 @@ __global__ __launch_bounds__(256) void filter_count_kernel(const ScanParams P) {
   }
 }
 
-template <int Q, int R, int SB>
+template <int Q, int R, int SB, int WPG>
 hipError_t launch_qr(const ScanParams& P, uint32_t grid, hipStream_t stream) {
-  const size_t smem = ((size_t)1 << (2 * (Q + R - 1))) + (size_t)kWavesPerGroup * P.lds_per_wave;
+  const size_t smem = ((size_t)1 << (2 * (Q + R - 1))) + (size_t)WPG * P.lds_per_wave;
   static bool attr_set = false;  // LDS beyond the 64 KiB default needs an explicit opt-in
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_count_kernel<Q, R, SB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_count_kernel<Q, R, SB, WPG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((filter_count_kernel<Q, R, SB>), dim3(grid), dim3(256), smem, stream, P);
+  hipLaunchKernelGGL((filter_count_kernel<Q, R, SB, WPG>), dim3(grid), dim3(64 * WPG), smem, stream, P);
   return hipGetLastError();
 }
 template <int Q, int R>
 hipError_t launch_sb(const ScanParams& P, uint32_t grid, hipStream_t stream) {
-  return P.stage_blocks == 2 ? launch_qr<Q, R, 2>(P, grid, stream) : launch_qr<Q, R, 1>(P, grid, stream);
+  if (P.waves_per_group == 16) return P.stage_blocks == 2 ? launch_qr<Q, R, 2, 16>(P, grid, stream) : launch_qr<Q, R, 1, 16>(P, grid, stream);
+  return P.stage_blocks == 2 ? launch_qr<Q, R, 2, 4>(P, grid, stream) : launch_qr<Q, R, 1, 4>(P, grid, stream);
 }
 
 }  // namespace

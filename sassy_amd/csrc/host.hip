@@ -876,7 +876,7 @@ struct ScanJob {
   uint32_t bucket = 4, q = 0;
   bool filtered = false;
   FilterKind fkind = kFilterGeneric;
-  uint32_t count_r = 0, count_w = 0, count_t = 0;  // counting filter: R, window blocks, threshold
+  uint32_t count_r = 0, count_w = 0, count_t = 0, count_wpg = 4;  // counting filter: R, window blocks, threshold, waves per workgroup
   double count_tail = 0;                           // ... and the expected fraction of candidate blocks
   unsigned long long* d_bitmap = nullptr;
   uint32_t* d_counts = nullptr;
@@ -1277,8 +1277,12 @@ int ScanJob::prepare() {
     if (fkind == kFilterCount) {
       static const int env_csb = getenv("SASSY_HIP_COUNT_STAGE_BLOCKS") ? atoi(getenv("SASSY_HIP_COUNT_STAGE_BLOCKS")) : 0;
       F.stage_blocks = env_csb == 1 ? 1u : 2u;  // (whole 128-byte lines per lane and step: read with non-temporal loads)
-      const uint32_t wg_lds = (1u << (2 * (q + count_r - 1))) + 4 * (4096u * F.stage_blocks + 64u * count_w);
-      fwpc = 4 * (int)std::min<uint32_t>(8, (160u * 1024u) / wg_lds);
+      const uint32_t per_wave = 4096u * F.stage_blocks + 64u * count_w, table = 1u << (2 * (q + count_r - 1));
+      // the table is per workgroup: sixteen waves around one copy where that fits a CU's LDS, else four
+      static const int env_wpg = getenv("SASSY_HIP_COUNT_WPG") ? atoi(getenv("SASSY_HIP_COUNT_WPG")) : 0;
+      count_wpg = (env_wpg == 4 || env_wpg == 16) ? (uint32_t)env_wpg : 16u;
+      if (table + 16u * per_wave > 160u * 1024u) count_wpg = 4;
+      fwpc = count_wpg == 16 ? 16 : 4 * (int)std::min<uint32_t>(8, (160u * 1024u) / (table + 4 * per_wave));
       extra_front = count_w + 1;
     }
     // (timing level >= 1 records the two events around the filter: that is what the tuner learns from)
@@ -1287,7 +1291,11 @@ int ScanJob::prepare() {
                                  sh.d_text, sh.text_len, (uint32_t)fkind * 16u + (rc_marked ? 1u : 0u))) return rc;
     if (fkind == kFilterPlanes) F.stage_blocks = 2;  // (the bit-plane kernel stages whole 128-byte lines only)
     F.lds_per_wave = 4096u * F.stage_blocks + (F.piece_planes ? 0u : 2u * bucket * 512u);
-    if (fkind == kFilterCount) F.lds_per_wave = 4096u * F.stage_blocks + 64u * count_w;
+    if (fkind == kFilterCount) {
+      F.lds_per_wave = 4096u * F.stage_blocks + 64u * count_w;
+      F.waves_per_group = count_wpg;
+      fgrid = (uint32_t)((F.n_chunks + 64ull * count_wpg - 1) / (64ull * count_wpg));
+    }
     F.fused = 0;
     if (fused) {
       static const int env_probe = getenv("SASSY_HIP_FUSED_PROBE") ? atoi(getenv("SASSY_HIP_FUSED_PROBE")) : 0;

@@ -12,7 +12,7 @@ pat = bytes(_dna_bytes(43, 0, m))
 buf = sassy_amd.DeviceBuffer(n + 4096)
 sassy_amd.generate_dna(buf.ptr, n, 42, 0)
 sassy_amd.plant(buf.ptr, n, 0, n, 42, pat, k, 1 << 20)
-s = sassy_amd.Searcher(os.environ.get("PROBE_PROFILE", "dna"), rc=False)
+s = sassy_amd.Searcher(os.environ.get("PROBE_PROFILE", "dna"), rc=bool(int(os.environ.get("PROBE_RC", "0"))))
 for _ in range(60):
     r = s.search_shard(pat, buf.ptr, 0, n, 0, n, k)
 f = 0.0
