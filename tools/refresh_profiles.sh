@@ -33,6 +33,7 @@ cp gpurun_out/prof_${TAG}_scan/summary.txt $OUT/${TAG}_scan_kernel_rocprof_summa
 SASSY_HIP_PREFILTER=0 SASSY_HIP_ROW_CUT=0 bash tools/prof.sh ${TAG}_scan_nocut --in-flight 1 > /dev/null 2>&1
 cp gpurun_out/prof_${TAG}_scan_nocut/summary.txt $OUT/${TAG}_scan_kernel_all_rows_rocprof_summary.txt
 { echo "# streaming DP (SASSY_HIP_PREFILTER=0), BASELINE config 2 and config 3 shapes, row cut-off on / off (SASSY_HIP_ROW_CUT=0)";
+  echo "# rows the wave-voted cut-off computes per block: $(for mk in '32 3' '200 20'; do set -- $mk; SASSY_HIP_PREFILTER=0 PROBE_COUNTERS=1 PROBE_M=$1 PROBE_K=$2 python tools/probe_fused.py 2>/dev/null | tail -1 | grep -o '"rows_per_block": [0-9.]*' | sed "s/^/m=$1 k=$2 /"; done | tr '\n' ' ')";
   for cut in 1 0; do for shape in "--profile dna --pattern-len 32 --k 3" "--profile iupac --pattern-len 200 --k 20" "--profile dna --pattern-len 64 --k 6"; do
     echo "ROW_CUT=$cut $shape"; SASSY_HIP_PREFILTER=0 SASSY_HIP_ROW_CUT=$cut python bench.py $shape --steps 30 --warmup 5 --in-flight 1 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
@@ -46,6 +47,18 @@ print('   ms_per_search', d['ms_per_step'], 'scan_kernel_ms', d['dominant_kernel
 { echo "# bench.py --steps 300 --warmup 60 --tune-searches 40: ms per search (in flight 2) | latency of a lone search; SASSY_HIP_TUNE=1 = opt-in tuner";
   for n in 1000000000 2000000000 2700000000 3000000000 3700000000 5000000000; do for t in 0 1; do
     echo "text_bytes $n TUNE=$t: $(SASSY_HIP_TUNE=$t python bench.py --steps 300 --warmup 60 --tune-searches 40 --text-bytes $n --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*\|"single_search_latency_ms": [0-9.]*' | tr '\n' ' ')"; done; done; } > $OUT/${TAG}_geometry_sweep.txt 2>&1
+# ---- the counting filter (Iupac, long patterns): waves per workgroup around one table copy; the config-3 shape as a lone search
+{ echo "# filter_count_kernel on 3 GB, tools/probe_fused.py (lone search, kernel_ms = the filter): four / sixteen waves per workgroup";
+  echo "# (one-off builds, round 3: half the look-ups 0.578-0.592 ms, no look-ups 0.537 ms, no look-ups + Iupac text check 0.562 ms; WPG=4: 0.593-0.600)";
+  for shape in "iupac 200 20" "iupac 32 3" "dna 100 10"; do set -- $shape; for w in 4 16; do
+    echo "profile $1 m $2 k $3 SASSY_HIP_COUNT_WPG=$w: $(PROBE_PROFILE=$1 PROBE_M=$2 PROBE_K=$3 SASSY_HIP_FILTER_KIND=4 SASSY_HIP_COUNT_WPG=$w python tools/probe_fused.py 2>/dev/null | tail -1 | cut -c1-200)"; done; done;
+  echo "## the config-3 shape (Iupac, m=200, k=20) as a lone search: kernel timeline";
+  PROBE_PROFILE=iupac PROBE_M=200 PROBE_K=20 rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_${TAG}_c3 -o t -- python tools/probe_fused.py 2>/dev/null | tail -1 | cut -c1-200;
+  python tools/timeline.py gpurun_out/prof_${TAG}_c3 filter_count;
+  echo "## its traceback waves, microseconds per report and phase"; PROBE_PROFILE=iupac PROBE_M=200 PROBE_K=20 SASSY_HIP_TRACE_PROBE=1 python tools/probe_fused.py 2>&1 | grep "trace waves" | tail -1; } > $OUT/${TAG}_count_filter.txt 2>&1
+# ---- does gfx950 skip masked 16-lane quarters of a VALU instruction?  (sub-wave groups for the streaming DP: no)
+{ echo "# tools/ubench/exec_skip.hip: 4096 x 128 dependent v_bitop3_b32 per wave, 8 waves per SIMD, by EXEC mask";
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/exec_skip tools/ubench/exec_skip.hip 2>/dev/null && /tmp/exec_skip; } > $OUT/${TAG}_exec_mask_ubench.txt 2>&1
 # ---- other configs, shapes, texts
 python tools/bench_configs.py --configs 1,3,4 --patterns 10000 > $OUT/${TAG}_configs.json 2> $OUT/configs.err
 bash tools/prof_configs.sh cfg > /dev/null 2>&1
