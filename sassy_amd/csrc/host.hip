@@ -242,6 +242,8 @@ struct ScanLane {
   uint32_t table_q = 0, table_k = 0, table_r = 0;   // table_r: 0 = piece bit table, else the counting table's R
   bool table_rc = false;                            // the counting table also holds the Rc strand's q-grams
   uint32_t fuse_backoff = 0;                        // searches this lane still runs unfused after a fused one overflowed
+  const uint8_t* dirty_text = nullptr;              // the text on which the Iupac bit-plane filter last gave up (letters other than
+  uint64_t dirty_len = 0;                           //  A C G T in long runs): not tried again while searches stay on it
   double table_density = 0;
   // pinned host staging area: control block and the first kSpec reports of a scan are written into
   // it by the kernels themselves; one stream synchronisation makes them readable
@@ -965,7 +967,34 @@ int ScanJob::prepare() {
     P.texts_len = texts.len;
   }
   const uint32_t pieces = k + 1;
-  const bool can_planes = q > 0 && S->profile == PROFILE_DNA && pieces <= 8;
+  // The fused launch (filter + chunk DP in one kernel, see below) takes one strand of one text whose reports the
+  // traceback waves rank themselves.  (trace_wave_ok mirrors use_wave of the traceback set-up further down.)
+  static const int env_selfrank0 = getenv("SASSY_HIP_SELF_RANK") ? atoi(getenv("SASSY_HIP_SELF_RANK")) : 1;
+  static const int env_lin0 = getenv("SASSY_HIP_FILTER_LINEAR") ? atoi(getenv("SASSY_HIP_FILTER_LINEAR")) : 0;
+  static const int env_wave0 = getenv("SASSY_HIP_TRACE_WAVE") ? atoi(getenv("SASSY_HIP_TRACE_WAVE")) : 1;
+  const bool trace_wave_ok = [&] {
+    const uint64_t cell = (k + 1 <= 255) ? 1 : 2;
+    const uint64_t band = ((uint64_t)(plan.m + 1) * (2ull * k + 3) * cell + 3) / 4 * 4;
+    const uint64_t raw = band + ((uint64_t)plan.m + k + 15 + 15) / 16 * 16 + ((uint64_t)plan.m + k + 1 + 3) / 4 * 4 +
+                         ((2ull * (plan.m + k + 1) + 2 + 15) / 16 * 16);
+    return env_wave0 != 0 && 2ull * k + 3 <= 64 && 4 * (((uint64_t)plan.m + 15) / 16 * 16) + 4 * ((raw + 15) / 16 * 16) <= 160 * 1024;
+  }();
+  const bool fuse_ok = !ext_bitmap && !ext_desc && rc_bitmap == nullptr && rev_n == 0 && S->fuse && !no_fuse &&
+                       L.fuse_backoff == 0 && env_lin0 <= 0 && env_selfrank0 != 0 && do_trace && trace_wave_ok &&
+                       texts.n == 0 && plan.nwords <= 8 && n_blocks < 0x7FFFFFFFull && !S->want_counters;
+  // Iupac searcher, pattern of plain A C G T, <= 4 pieces: the Dna bit-plane filter and chunk DP with a check of the
+  // text (filter_dna_kernel, CHECK) -- as the fused launch only, on a whole text (a shard's halo in front of the first
+  // owned block belongs to no lane's checked range), and not on a text that sent the last such search to the classic
+  // chain (it holds other letters).
+  static const int env_iupac_planes = getenv("SASSY_HIP_IUPAC_PLANES") ? atoi(getenv("SASSY_HIP_IUPAC_PLANES")) : 1;
+  bool plain_pattern = S->profile == PROFILE_IUPAC && env_iupac_planes != 0 && !overhang;
+  for (uint32_t j = 0; plain_pattern && j < plan.m; ++j) {
+    const uint8_t u = pat[j] & 0xDFu;
+    plain_pattern = u == 'A' || u == 'C' || u == 'G' || u == 'T';
+  }
+  const bool iupac_planes = plain_pattern && fuse_ok && q >= 6 && q <= 12 && pieces <= 4 && plan.nslots <= 4 &&
+                            sh.halo_len == 0 && !(L.dirty_text == sh.d_text && L.dirty_len == sh.text_len);
+  const bool can_planes = q > 0 && pieces <= 8 && (S->profile == PROFILE_DNA || iupac_planes);
   // q-gram counting (count_filter.hip): per (Q, R) variant the threshold t = m + 1 - (k+1) Q, the
   // window W, and how often a window of random text reaches t by chance (the pattern's q-grams,
   // ambiguity letters expanded, against 4^Q; Poisson tail).  Taken when that beats the expected
@@ -1174,11 +1203,9 @@ int ScanJob::prepare() {
 
   // ---- one launch for filter + chunk DP?  (bit-plane filter, one strand, one text, reports ranked by the
   // traceback waves themselves; the chunk DP's masks and carries must fit the filter's 8 KiB tile)
-  static const int env_selfrank0 = getenv("SASSY_HIP_SELF_RANK") ? atoi(getenv("SASSY_HIP_SELF_RANK")) : 1;
-  static const int env_lin0 = getenv("SASSY_HIP_FILTER_LINEAR") ? atoi(getenv("SASSY_HIP_FILTER_LINEAR")) : 0;
-  fused = filtered && fkind == kFilterPlanes && !ext_bitmap && !ext_desc && rc_bitmap == nullptr && rev_n == 0 &&
-          S->fuse && !no_fuse && L.fuse_backoff == 0 && env_lin0 <= 0 && env_selfrank0 != 0 && do_trace && use_wave &&
-          texts.n == 0 && plan.nwords <= 8 && n_blocks < 0x7FFFFFFFull && !S->want_counters;
+  fused = filtered && fkind == kFilterPlanes && fuse_ok && use_wave;
+  if (S->profile == PROFILE_IUPAC && fkind == kFilterPlanes && !fused && !ext_bitmap && !ext_desc)
+    return fail(SASSY_HIP_EUNSUPPORTED, "internal: the Iupac bit-plane filter exists as the fused launch only");
   if (L.fuse_backoff && !no_fuse) --L.fuse_backoff;
 
   // ---- geometry of the streaming kernel (full DP, or the prefilter) ----
@@ -1532,6 +1559,10 @@ int ScanJob::finish(ScanOut& out) {
   if (!redo) return 0;
   no_fuse = true;
   L.fuse_backoff = 16;  // and so do the lane's next searches: a text that overflows the queue once does it again
+  if (S->profile == PROFILE_IUPAC) {  // (the bit-plane filter with its text check: not again on this text)
+    L.dirty_text = sh.d_text;
+    L.dirty_len = sh.text_len;
+  }
   if (int rc = prepare()) return rc;
   if (!empty)
     if (int rc = enqueue(0)) return rc;

@@ -1619,9 +1619,12 @@ constexpr uint32_t kRunMergeGap = 32;  // runs this close share a window
 // (mk = m + k), so the window [start, y] with start <= x - 1 - mk reports every end position of the run, plateau
 // state included (unless the plateau reaches back beyond x - 1: such a report is conditional, scan_block).  Whole
 // 64-column blocks ending at y: {first block, blocks << 6 | byte shift}.
-__device__ __forceinline__ uint4 fuse_flush(uint2* queue, uint32_t* qcount, uint32_t cap, uint32_t mk, int64_t col_base, uint4 st) {
+constexpr uint32_t kFuseMaxBlocks = 96;  // a longer window (dense repeats, a run of N under Iupac) is no work for one lane
+__device__ __forceinline__ uint4 fuse_flush(uint2* queue, uint32_t* qcount, uint32_t* fuse_word, uint32_t cap, uint32_t mk,
+                                            int64_t col_base, uint4 st) {
   if (st.x == kRunNone) return st;
   uint32_t nv = (st.y - st.x + mk + 2u + 63u) / 64u;
+  if (nv > kFuseMaxBlocks) atomicOr(fuse_word, kFuseOverflow);  // the classic chain cuts such runs into chunks
   const int64_t end = col_base + (int64_t)st.y;
   int64_t start = end - 64 * (int64_t)nv;
   if (start < 0) {  // the buffer starts inside the window: whole blocks from byte 0
@@ -1638,7 +1641,7 @@ __device__ __forceinline__ uint4 fuse_flush(uint2* queue, uint32_t* qcount, uint
 // adds the columns [lo, hi] (lo = kRunNone: nothing to add, only queue the pending run)
 __device__ __noinline__ uint4 fuse_add_range(uint2* queue, uint32_t* qcount, uint32_t* fuse_word, uint32_t cap, uint32_t mk,
                                              int64_t col_base, uint32_t first_col, uint4 st, uint32_t lo, uint32_t hi) {
-  if (lo == kRunNone) return fuse_flush(queue, qcount, cap, mk, col_base, st);
+  if (lo == kRunNone) return fuse_flush(queue, qcount, fuse_word, cap, mk, col_base, st);
   if (lo < first_col) lo = first_col;  // the halo's end positions are not ours
   if (lo < st.w) {
     // columns in front of a window that is already queued (possible only when an occurrence's marks reach further
@@ -1653,7 +1656,7 @@ __device__ __noinline__ uint4 fuse_add_range(uint2* queue, uint32_t* qcount, uin
     st.y = max(st.y, hi);
     return st;
   }
-  st = fuse_flush(queue, qcount, cap, mk, col_base, st);
+  st = fuse_flush(queue, qcount, fuse_word, cap, mk, col_base, st);
   st.x = lo;
   st.y = hi;
   return st;
@@ -1686,8 +1689,29 @@ __device__ __noinline__ uint4 fuse_add_range(uint2* queue, uint32_t* qcount, uin
 // an occurrence in a lane's first or last blocks can fall into the neighbour's range, and when the neighbour
 // marks the same block both chunks report its end positions -- identical records, dropped where the reports
 // are ranked (trace_wave_kernel).
-template <int Q, int NPG, bool FUSED>
-__global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
+//
+// CHECK (fused only): an Iupac search whose PATTERN holds plain A C G T only, on a text that holds nothing else
+// either.  There the profile's "sets intersect" is equality of the Dna codes: filter and chunk DP are the Dna ones.
+// Every staged byte is checked on its way into the tile (one v_sad_u8 per dword against the letter its code stands
+// for; U counts as other); one other byte anywhere sets the fuse flag and the classic Iupac chain takes the search
+// (the host does not try again on that text).
+// (CHECK) do these 16 text bytes hold anything but plain bases?  The letter a byte's code stands for
+// (v_perm selectors 0 / 2 / 4 / 6 = twice the code -> A C T G) against the byte without its case bit, summed by v_sad_u8.
+__device__ __forceinline__ bool other_letters16(const uint4 v) {
+  const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+  uint32_t diff = 0;
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const uint32_t want = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, w4[d] & 0x06060606u);
+    diff = __builtin_amdgcn_sad_u8(w4[d] & 0xDFDFDFDFu, want, diff);
+  }
+  return diff != 0u;
+}
+
+template <int Q, int NPG, bool FUSED, bool CHECK = false>
+// (CHECK: four waves per SIMD are asked for -- left to itself the compiler settles for three, 0.59 instead of 0.52 ms)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 : 1))) void filter_dna_kernel(const ScanParams P) {
+  static_assert(!CHECK || FUSED, "the text check exists in the fused launch only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int SB = 2;
   constexpr uint32_t kRowBytes = 64u * SB;
@@ -1735,6 +1759,15 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
     if (lane == 0) *qcount = 0;
     if (Pk->fused & 2u) probe_t0 = wall_clock64();
   }
+  bool other_seen = false;  // (CHECK) this lane staged a byte that is not a plain base
+  if constexpr (CHECK) {
+    if (blockIdx.x == 0 && tid0 == 0) {  // the text's last, partial 16-byte piece (the staging steps check whole pieces)
+      for (uint64_t q2 = Pk->text_len & ~15ull; q2 < Pk->text_len; ++q2) {
+        const uint32_t u = Pk->text[q2] & 0xDFu;
+        other_seen |= !(u == 'A' || u == 'C' || u == 'G' || u == 'T');
+      }
+    }
+  }
   const uint32_t n_iter = Pk->n_iter - bpl + u_bpl;
   const uint64_t own_lo = u_first + (uint64_t)(lc0 + lane) * u_bpl;
   uint64_t own_hi = own_lo + u_bpl;
@@ -1773,7 +1806,13 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
     if (sub == 0) {
       if (interior) {
 #pragma unroll
-        for (int i = 0; i < kStageInstr; ++i) *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = nxt[i];
+        for (int i = 0; i < kStageInstr; ++i) {
+          *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = nxt[i];
+          if constexpr (CHECK) other_seen |= other_letters16(nxt[i]);
+        }
+        // (the next loads go into the registers the check has just read: scheduled in front of it they would need
+        // 32 more)
+        if constexpr (CHECK) __builtin_amdgcn_sched_barrier(0);
         if (it + SB < n_iter) {
 #pragma unroll
           for (int i = 0; i < kStageInstr; ++i)
@@ -1787,6 +1826,8 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
           if (off + 16 <= Pk->text_len) v = *reinterpret_cast<const uint4*>(Pk->text + off);
           else v = load_tail16(Pk->text, off, Pk->text_len);
           *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
+          // (the one piece that straddles the end of the text is checked by the launch's first lane, below)
+          if constexpr (CHECK) other_seen |= off + 16 <= Pk->text_len && other_letters16(v);
         }
       }
     }
@@ -1873,6 +1914,12 @@ __global__ __launch_bounds__(256) void filter_dna_kernel(const ScanParams P) {
     }
   }
 
+  if constexpr (CHECK) {
+    if (__any(other_seen)) {  // not a plain text: the Iupac profile's own chain takes the search
+      if (lane == 0) atomicOr(&Pk->cand_count[kCtlFuseWord], kFuseOverflow);
+      continue;
+    }
+  }
   if constexpr (FUSED) {
     if (run.x != kRunNone)
       run = fuse_add_range(queue, qcount, Pk->cand_count + kCtlFuseWord, Pk->fuse_queue_cap, Pk->m + Pk->k, col_base, 0u, run,
@@ -2249,8 +2296,29 @@ hipError_t launch_scan_ascii(const ScanParams& P, uint32_t grid, size_t smem, hi
   return hipErrorInvalidValue;
 }
 #if SASSY_SCAN_PROFILE == 2
+// plain patterns under the Iupac profile: the fused bit-plane launch with the text check (filter_dna_kernel, CHECK)
+template <int Q>
+static hipError_t launch_filter_planes_iupac_q(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  const size_t smem = (size_t)kWavesPerGroup * P.lds_per_wave;
+  if (P.piece_groups != 1) return hipErrorInvalidValue;  // (eight pieces + the check do not fit 128 VGPRs: the host asks for <= 4)
+  hipLaunchKernelGGL((filter_dna_kernel<Q, 1, true, true>), dim3(grid), dim3(256), smem, stream, P);
+  return hipGetLastError();
+}
+static hipError_t launch_filter_planes_iupac(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  switch (P.piece_len) {
+    case 6: return launch_filter_planes_iupac_q<6>(P, grid, stream);
+    case 7: return launch_filter_planes_iupac_q<7>(P, grid, stream);
+    case 8: return launch_filter_planes_iupac_q<8>(P, grid, stream);
+    case 9: return launch_filter_planes_iupac_q<9>(P, grid, stream);
+    case 10: return launch_filter_planes_iupac_q<10>(P, grid, stream);
+    case 11: return launch_filter_planes_iupac_q<11>(P, grid, stream);
+    case 12: return launch_filter_planes_iupac_q<12>(P, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
 hipError_t launch_filter_iupac(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
   constexpr int PR2 = PROFILE_IUPAC;
+  if (P.piece_planes) return P.fused ? launch_filter_planes_iupac(P, grid, stream) : hipErrorInvalidValue;
 #else
 hipError_t launch_filter_ascii(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
   constexpr int PR2 = PROFILE_ASCII;

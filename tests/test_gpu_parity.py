@@ -357,7 +357,9 @@ def test_qgram_count_filter_worst_case_edits(sassy):
         assert_same(s.search(pat, tb, k), want)
         assert_same(s.search_all(pat, tb, k), oracle.search(profile, pat, tb, k, all_minima=True))
         if os.environ.get("SASSY_HIP_PREFILTER") is None and not os.environ.get("SASSY_HIP_FILTER_KIND"):
-            assert s.stats()["filtered"] in (3, 4), (profile, m, k, s.stats()["filtered"])
+            # (2: the Dna launch with its text check, taken by Iupac searches with plain patterns of <= 4 pieces on plain
+            # text; the counting filter has these shapes under SASSY_HIP_IUPAC_PLANES=0 and FILTER_KIND=4)
+            assert s.stats()["filtered"] in (2, 3, 4), (profile, m, k, s.stats()["filtered"])
 
 
 def test_many_pieces_without_a_filter_stream(sassy):
@@ -2185,6 +2187,55 @@ def test_fused_filter_equals_classic_chain_and_oracle(sassy):
     buf.free()
 
 
+def test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_plain_text_only(sassy):
+    """An Iupac searcher whose pattern holds A C G T only runs the fused Dna launch with a check of the text
+    (filter_dna_kernel<.., CHECK>): exact while the text is plain (either case); ONE other letter anywhere -- inside a
+    match, where N matches every base, in the text's last partial 16-byte piece, in its first block -- sends the
+    search to the Iupac profile's own chain, and the searcher does not try again on that text."""
+    rng = random.Random(123)
+    can_fuse = _env_allows_fusing() and os.environ.get("SASSY_HIP_IUPAC_PLANES", "1") != "0"
+    pat = rand_seq(rng, 32)
+    k = 3
+    for n in (70_001, 300_000, 4096, 2_000_003):
+        base = bytearray(rand_seq(rng, n))
+        for _ in range(25):
+            ins = mutate(rng, pat, rng.randrange(k + 1))
+            at = rng.randrange(0, n - len(ins))
+            base[at:at + len(ins)] = ins
+        for i in range(0, n, 97):
+            base[i] |= 0x20  # lower case is plain
+        plant = n // 2
+        base[plant:plant + 32] = pat
+        variants = {"plain": bytes(base)}
+        t = bytearray(base); t[plant + 10] = ord("N"); t[plant + 11] = ord("N"); t[plant + 12] = ord("R"); t[plant + 13] = ord("n")
+        variants["N inside a match"] = bytes(t)
+        t = bytearray(base); t[n - 1] = ord("N")
+        variants["N as the last byte"] = bytes(t)
+        t = bytearray(base); t[0] = ord("-")
+        variants["a non-letter as the first byte"] = bytes(t)
+        t = bytearray(base); t[n - 40] = ord("U")
+        variants["U near the end"] = bytes(t)
+        for name, text in variants.items():
+            s = sassy.Searcher("iupac", rc=False)
+            want = oracle.search("iupac", pat, text, k)
+            for rep in range(3):
+                got = s.search(pat, text, k)
+                st = s.stats()
+                assert_same(got, want, (name, n, rep, st["fused"], st["filtered"]))
+                if can_fuse and n > 4096:
+                    # plain: fused every time; else: tried once (rep 0 falls back inside the call), then not again
+                    assert st["fused"] == (1 if name == "plain" else 0), (name, n, rep, st)
+            # a pattern with an ambiguity letter never takes that launch
+            pat2 = pat[:7] + b"N" + pat[8:]
+            assert_same(s.search(pat2, text, k), oracle.search("iupac", pat2, text, k), (name, n, "N in the pattern"))
+    # device-resident text, searches in flight
+    n = 1 << 21
+    text = bytes(oracle.generate_dna(42, 0, n).tobytes())
+    s = sassy.Searcher("iupac", rc=False)
+    want = oracle.search("iupac", pat, text, k)
+    assert_same(s.search(pat, text, k), want, "resident")
+
+
 def test_fused_filter_falls_back_when_a_wave_queue_overflows(sassy):
     """More candidate runs than a wave's LDS queue holds (a near-match every 192 bytes), and plateaus that cross
     chunk seams (conditional reports): the fused launch flags it, the classic chain takes the search, the lane backs
@@ -2251,7 +2302,8 @@ def test_fuzz_regressions(sassy, name):
 _CORE = ("test_fuzz_small_texts or test_low_complexity_and_seams or test_long_pattern_iupac_config3_shape or "
          "test_traceback_variants or test_dna_profile_text_with_other_letters or test_device_resident_search_and_shards or "
          "test_shard_seam_plateau_chain or test_fused_filter_equals_classic_chain_and_oracle or test_dense_reports or "
-         "test_qgram_count_filter_worst_case_edits or test_searches_in_flight_begin_finish")
+         "test_qgram_count_filter_worst_case_edits or test_searches_in_flight_begin_finish or "
+         "test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_plain_text_only")
 _FORCED = [
     {"SASSY_HIP_PREFILTER": "0"},                    # streaming DP over every block (scan_kernel), also multi-word
     {"SASSY_HIP_PREFILTER": "0", "SASSY_HIP_ROW_CUT": "0"},   # ... every row of every block
@@ -2270,6 +2322,8 @@ _FORCED = [
     {"SASSY_HIP_RC_FUSED": "0"},                     # Rc strand from a reversed copy
     {"SASSY_HIP_LIST_WORDS": "0"},                   # multi-word chunk DP by the lane-per-chunk kernel
     {"SASSY_HIP_LANES": "3", "SASSY_HIP_SUBSHARD_MIN": "2048"},  # one search cut into sub-shards on several streams
+    {"SASSY_HIP_IUPAC_PLANES": "0"},                 # Iupac searches with plain patterns through the Iupac chain only
+    {"SASSY_HIP_FILTER_KIND": "4", "SASSY_HIP_COUNT_WPG": "4"},  # the counting filter with four waves per workgroup
 ]
 
 
