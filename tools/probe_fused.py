@@ -9,9 +9,13 @@ from bench import _dna_bytes
 n = int(float(os.environ.get("PROBE_N", "3e9"))) // 64 * 64
 m, k = int(os.environ.get("PROBE_M", "32")), int(os.environ.get("PROBE_K", "3"))
 pat = bytes(_dna_bytes(43, 0, m))
+plain = pat
+if os.environ.get("PROBE_C3"):  # BASELINE config 3: N, R, Y, W at 50 / 100 / 150 / 199 (planted with a base they contain)
+    p3 = bytearray(pat); p3[50], p3[100], p3[150], p3[199] = b"NRYW"
+    plain = bytes({78: 65, 82: 65, 89: 67, 87: 65}.get(c, c) for c in p3); pat = bytes(p3)
 buf = sassy_amd.DeviceBuffer(n + 4096)
 sassy_amd.generate_dna(buf.ptr, n, 42, 0)
-sassy_amd.plant(buf.ptr, n, 0, n, 42, pat, k, 1 << 20)
+sassy_amd.plant(buf.ptr, n, 0, n, 42, plain, k, 1 << 20)
 s = sassy_amd.Searcher(os.environ.get("PROBE_PROFILE", "dna"), rc=bool(int(os.environ.get("PROBE_RC", "0"))))
 for _ in range(60):
     r = s.search_shard(pat, buf.ptr, 0, n, 0, n, k)
