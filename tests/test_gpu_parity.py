@@ -7,6 +7,7 @@ import json
 import os
 import random
 import sys
+import time
 
 import numpy as np
 import pytest
@@ -2467,6 +2468,51 @@ def test_multi_searcher_shards_on_one_gpu(sassy):
     th.join()
     assert len(want) >= 30
     assert_same(got[0], want, "multi synthetic, other thread")
+
+
+def test_config5_shape_24gb_in_eight_shards_on_one_gpu(sassy):
+    """BASELINE config 5's data path at its own size, on the ONE GPU of the test box: 24e9 bytes of the synthetic text
+    in eight shards with halos (the in-process multi-device searcher with device 0 named eight times: generated shard
+    by shard at global positions, planted, searched by eight host threads, merged in C).  Size-independent properties:
+    every plant is found where it was planted, in order, across all seven seams; and around every seam, and around a
+    few other places, the merged result equals the oracle on a window of the same text rebuilt on the host."""
+    n = 24_000_000_000
+    pat = bytes(oracle.generate_dna(43, 0, 32))
+    try:
+        ms = sassy.MultiSearcher("dna", devices=[0] * 8)
+        ms.generate_dna(n, 42, 32, 3)
+    except sassy.SassyHipError as e:
+        pytest.skip(f"cannot hold 24 GB on this device: {e}")
+    planted = ms.plant(42, pat, 3, 1 << 20)
+    assert planted == n // (1 << 20)
+    t0 = time.perf_counter()
+    res = ms.search(pat, 3)
+    dt = time.perf_counter() - t0
+    got = res.matches
+    assert planted <= len(got) <= planted + planted // 20, (planted, len(got))
+    ends = [m.text_end for m in got]
+    assert ends == sorted(ends)
+    seen = set()
+    for m in got:
+        q = m.text_start >> 20
+        assert abs(m.text_start - (q * (1 << 20) + (1 << 19))) <= 6, m
+        assert m.cost <= 3 and 26 <= m.text_end - m.text_start <= 38
+        seen.add(q)
+    assert len(seen) == planted
+    # windows of the same text on the host: the seven seams (shards of n / 8 bytes, rounded up to 64) and others
+    per = -(-(n // 8) // 64) * 64
+    wlen = 1 << 21
+    starts = [b * per - wlen // 2 for b in range(1, 8)] + [0, n - wlen, 12_345_678_848, 3 * per + (1 << 19) - 4096]
+    for w0 in starts:
+        host = oracle.generate_dna(42, w0, wlen)
+        oracle.plant_window(42, n, w0, host, pat, 3, stride=1 << 20)
+        want = oracle.search("dna", pat, host.tobytes(), 3)
+        lo = 0 if w0 == 0 else 64  # (a window that starts inside the text: the first m + k columns are not exact)
+        sub = [m for m in got if w0 + lo <= m.text_start and m.text_end <= w0 + wlen]
+        assert [(m.text_start - w0, m.text_end - w0, m.cost, m.cigar) for m in sub] == \
+               [(m.text_start, m.text_end, m.cost, m.cigar) for m in want if m.text_start >= lo], w0
+        assert len(sub) >= 1
+    print(f"config 5 shape on one GPU: {n} B in 8 shards, {len(got)} matches, {dt * 1e3:.1f} ms for the search")
 
 
 def test_searcher_stays_on_its_device_from_any_thread(sassy):

@@ -4,7 +4,7 @@ bench.py measures config 2 (the configuration the metric is quoted on) under the
 this script reports the other single-GPU configurations with the same synthetic text so
 that DESIGN.md can state where they stand.  One JSON line per config.
 
-    python tools/bench_configs.py [--configs 1,3,4] [--text-bytes N] [--patterns P] [--steps K]
+    python tools/bench_configs.py [--configs 1,3,4,5] [--text-bytes N] [--patterns P] [--steps K]
 """
 import argparse
 import json
@@ -94,6 +94,24 @@ def main():
                           "pattern_text_GB_per_s": round(n * P / dt / 1e9, 1), "matches": len(r),
                           "stats": {k: st[k] for k in ("scan_ms", "filter_ms", "trace_ms", "scan_launches", "filtered", "chunks",
                                                        "hit_blocks", "live_blocks", "candidates")}}))
+
+    if 5 in todo:
+        # config 5's DATA PATH on ONE GPU (no scaling claim): 24e9 bytes in eight shards with halos through the
+        # in-process multi-device searcher, device 0 named eight times -- eight host threads, eight resident shards,
+        # eight searches on the same GPU, merged in C.  What eight GPUs would each do once, this GPU does eight times.
+        buf.free()
+        n5 = 24_000_000_000
+        ms = sassy_amd.MultiSearcher("dna", devices=[0] * 8)
+        ms.generate_dna(n5, 42, 32, 3)
+        from bench import _dna_bytes
+        pat = bytes(_dna_bytes(43, 0, 32))
+        planted = ms.plant(42, pat, 3, 1 << 20)
+        dt, r = timed(lambda: ms.search(pat, 3), max(args.steps, 10))
+        print(json.dumps({"config": 5, "workload": f"Dna new_fwd, |pattern|=32, k=3, {n5} B in 8 shards ON ONE GPU (sassy_hip_multi_*, device 0 x 8)",
+                          "ms_per_search": round(dt * 1e3, 3), "text_GB_per_s_one_gpu": round(n5 / dt / 1e9, 1),
+                          "matches": len(r), "planted": int(planted),
+                          "note": "eight shards share one GPU: the time is eight shard searches, not a scaling measurement"}))
+
 
 if __name__ == "__main__":
     main()

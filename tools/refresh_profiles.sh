@@ -60,7 +60,7 @@ print('   ms_per_search', d['ms_per_step'], 'scan_kernel_ms', d['dominant_kernel
 { echo "# tools/ubench/exec_skip.hip: 4096 x 128 dependent v_bitop3_b32 per wave, 8 waves per SIMD, by EXEC mask";
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/exec_skip tools/ubench/exec_skip.hip 2>/dev/null && /tmp/exec_skip; } > $OUT/${TAG}_exec_mask_ubench.txt 2>&1
 # ---- other configs, shapes, texts
-python tools/bench_configs.py --configs 1,3,4 --patterns 10000 > $OUT/${TAG}_configs.json 2> $OUT/configs.err
+python tools/bench_configs.py --configs 1,3,4,5 --patterns 10000 > $OUT/${TAG}_configs.json 2> $OUT/configs.err
 bash tools/prof_configs.sh cfg > /dev/null 2>&1
 cp gpurun_out/prof_cfg/summary.txt $OUT/${TAG}_configs_prof.txt
 # config 4 at its own size: the seeded search (kernel stats + VALU / HBM counters), and the three many-pattern paths
