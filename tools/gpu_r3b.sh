@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -s -k "config5_shape" 2>&1 | tail -5
-timeout 600 python tools/bench_configs.py --configs 5 2>&1 | tail -2
+PROBE_STEPS=40 python tools/probe_steps2.py 2>&1 | tail -2
