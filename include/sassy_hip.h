@@ -125,7 +125,9 @@ int sassy_hip_set_fused(sassy_SearcherType *s, int on);
  * 4 / 8 = what the reference binary built for AVX2 / AVX-512 returns: it cuts the text into 4 / 8 lanes that each
  * start with decreasing = true (src/search.rs:1016-1056, 1202-1240), which adds reports for <=k plateaus that
  * were entered by an increase left of a lane's start (never on random text).  Process default:
- * SASSY_HIP_REF_LANES.  Not applied with overhang, nor by search_many / search_shard / search_encoded. */
+ * SASSY_HIP_REF_LANES.  Not applied with overhang, nor to shards.  search_many / search_encoded need no such
+ * mode: with several patterns or texts the reference gives every lane a whole text (chunk_offset_blocks = 0,
+ * src/search.rs:1034-1048; the v2 scan keeps a pattern per lane), so its reports ARE the definition's there. */
 int sassy_hip_set_reference_lanes(sassy_SearcherType *s, int lanes);
 /* On-line tuner of the streaming kernels' lane-chunk length for a resident text (off by default, or
  * SASSY_HIP_TUNE=1): the first ~36 searches of a (text, filter kind) try neighbouring geometries -- each a
@@ -275,8 +277,9 @@ void sassy_hip_result_free(sassy_hip_Result *r);
 
 /* Searcher::encode_patterns / search_encoded_patterns (src/search.rs:404-423):
  * npat patterns of equal length plen (<= 64) stored back to back.
- * Limits of the many-pattern calls (this one and sassy_hip_search_many): the reports are the definition's (one
- * left-to-right pass per pattern and text) -- sassy_hip_set_reference_lanes is not applied to them; with an overhang
+ * The many-pattern calls (this one and sassy_hip_search_many): the reports are the definition's (one left-to-right
+ * pass per pattern and text) -- as in the reference, whose lanes hold whole texts / patterns there (no lane seams:
+ * sassy_hip_set_reference_lanes has nothing to reproduce).  Limit: with an overhang
  * searcher (alpha) the one-pass kernels (seeded search, pattern-tiled scan) are not used: the patterns then run
  * one kernel chain each, correct but at the speed of single searches (the reference's v2 scans overhang in its
  * tiled loop, src/pattern_tiling/search.rs:222-323). */

@@ -1,2 +1,5 @@
 cd $GRAFT_REPO_ROOT
-PROBE_STEPS=40 python tools/probe_steps2.py 2>&1 | tail -2
+mkdir -p gpurun_out/r3e
+for f in "" fused count encoded many inflight bytes_long reflanes; do
+  timeout 200 python tests/fuzz_gpu.py --seconds 100 --seed 4$RANDOM ${f:+--focus $f} 2>&1 | tail -1
+done
