@@ -1309,6 +1309,7 @@ int ScanJob::prepare() {
       static const int env_wpg = getenv("SASSY_HIP_COUNT_WPG") ? atoi(getenv("SASSY_HIP_COUNT_WPG")) : 0;
       count_wpg = (env_wpg == 4 || env_wpg == 16) ? (uint32_t)env_wpg : 16u;
       if (table + 16u * per_wave > 160u * 1024u) count_wpg = 4;
+      if (count_r == 1 && env_wpg != 16) count_wpg = 4;  // (the R = 1 variants need 157 VGPRs: 1024 threads would spill)
       fwpc = count_wpg == 16 ? 16 : 4 * (int)std::min<uint32_t>(8, (160u * 1024u) / (table + 4 * per_wave));
       extra_front = count_w + 1;
     }
