@@ -2229,12 +2229,35 @@ def test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_plain_text_only(sa
             # a pattern with an ambiguity letter never takes that launch
             pat2 = pat[:7] + b"N" + pat[8:]
             assert_same(s.search(pat2, text, k), oracle.search("iupac", pat2, text, k), (name, n, "N in the pattern"))
-    # device-resident text, searches in flight
-    n = 1 << 21
-    text = bytes(oracle.generate_dna(42, 0, n).tobytes())
+    # device-resident texts, searches in flight: a plain text and one with a letter that is no base, alternating -- the
+    # fall-back happens inside search_finish, on the ticket's own lane
+    n = (1 << 21) + 17
+    clean = bytearray(oracle.generate_dna(42, 0, n).tobytes())
+    for _ in range(30):
+        ins = mutate(rng, pat, rng.randrange(k + 1))
+        at = rng.randrange(0, n - 64)
+        clean[at:at + len(ins)] = ins
+    dirty = bytearray(clean)
+    dirty[n // 3] = ord("N")
+    bufs = []
+    for t in (clean, dirty):
+        b = sassy.DeviceBuffer(n + 256)
+        b.upload(bytes(t))
+        bufs.append(b)
+    wants = [oracle.search("iupac", pat, bytes(clean), k), oracle.search("iupac", pat, bytes(dirty), k)]
     s = sassy.Searcher("iupac", rc=False)
-    want = oracle.search("iupac", pat, text, k)
-    assert_same(s.search(pat, text, k), want, "resident")
+    pending, got = [], []
+    for i in range(8):
+        pending.append((i & 1, s.search_shard_begin(pat, bufs[i & 1].ptr, 0, n, 0, n, k)))
+        if len(pending) == 2:
+            which, t = pending.pop(0)
+            got.append((which, s.search_finish(t).matches))
+    while pending:
+        which, t = pending.pop(0)
+        got.append((which, s.search_finish(t).matches))
+    assert len(got) == 8
+    for which, g in got:
+        assert_same(g, wants[which], ("in flight", which))
 
 
 def test_fused_filter_falls_back_when_a_wave_queue_overflows(sassy):
