@@ -2069,10 +2069,29 @@ __global__ __launch_bounds__(256) void list_words_kernel(const ScanParams P) {
   ctx.ov_steps = 0u;
   ctx.text_begin = 0;
   ctx.tag = 0;
-  const unsigned char* my_masks = mask_bytes + lane * 8;
+  const unsigned char* my_masks = mask_bytes + lane * 8;  // (coop: set every step)
   DpWord Vout;
   Vout.vpl = Vout.vph = Vout.vml = Vout.vmh = 0;
   int ds_out = 0;
+
+  // Eight lanes per chunk (5 .. 8 pattern words), Dna / Iupac, forward text inside the buffer: the lanes of a group
+  // BUILD THE MASKS OF A BLOCK TOGETHER, once -- lane q its bytes 8q .. 8q+7, one byte of every slot's mask each, into
+  // a ring of eight blocks per group (entry = group * 8 + step % 8 in place of the lane's own entry) -- instead of
+  // every word's lane building the whole block again when the block reaches it (the masks were a third of a step).
+  constexpr bool kCoopProfile = PROFILE == (int)PROFILE_DNA || PROFILE == (int)PROFILE_IUPAC;
+  const bool chunk_here = di < n_desc;
+  const uint32_t chunk_iters = chunk_here ? (uint32_t)(own_hi - blk0) : 0u;  // (also for the group's lane without a word)
+  const bool coop = kCoopProfile && glog == 3u && P.rev_n == 0 && __all(!chunk_here || own_hi * 64 <= P.text_len);
+  const uint32_t grp8 = (lane >> 3) * 8u;
+  auto fetch8 = [&](uint32_t step) -> uint2 {
+    uint2 v = make_uint2(0x58585858u, 0x58585858u);
+    if (step < chunk_iters) v = *reinterpret_cast<const uint2*>(P.text + (blk0 + step) * 64 + 8u * w);
+    return v;
+  };
+  auto plane8 = [&](const uint2 v, uint32_t sel, int bit) -> uint32_t {  // bit `bit` of the eight bytes
+    const uint32_t a = __builtin_amdgcn_udot4(v.x & sel, 0x08040201u, 0u, false);
+    return (__builtin_amdgcn_udot4(v.y & sel, 0x80402010u, a, false) >> bit) & 0xFFu;
+  };
 
   // the text of the lane's next block is fetched one step ahead (a lone wave per SIMD cannot hide
   // the load latency behind other waves)
@@ -2082,10 +2101,44 @@ __global__ __launch_bounds__(256) void list_words_kernel(const ScanParams P) {
     fetch_block(P, on, blk, dst);
   };
   uint32_t xn[16];
-  fetch(0, xn);
+  uint2 x8n = make_uint2(0u, 0u);
+  if (coop) x8n = fetch8(0);
+  else fetch(0, xn);
   for (uint32_t s = 0; __any(s < my_iters + nwords - 1u && my_iters != 0); ++s) {
     const bool active = has_chunk && s >= w && s - w < my_iters;
     const uint64_t b = blk0 + (uint64_t)(s - w);
+    if (coop) {
+      if constexpr (kCoopProfile) {
+        const uint2 v = x8n;
+        x8n = fetch8(s + 1);
+        uint32_t mk[NS];
+        if constexpr (PROFILE == (int)PROFILE_DNA) {
+          const uint32_t p1 = plane8(v, 0x02020202u, 1), p2 = plane8(v, 0x04040404u, 2);
+          mk[0] = ~(p1 | p2) & 0xFFu; mk[1] = p1 & ~p2; mk[2] = ~p1 & p2; mk[3] = p1 & p2;
+        } else {
+          const uint32_t b0 = plane8(v, 0x01010101u, 0), b1 = plane8(v, 0x02020202u, 1), b2 = plane8(v, 0x04040404u, 2),
+                         b3 = plane8(v, 0x08080808u, 3), b4 = plane8(v, 0x10101010u, 4);
+          const uint32_t base[4] = {iupac_base_plane<0>(b0, b1, b2, b3, b4), iupac_base_plane<1>(b0, b1, b2, b3, b4),
+                                    iupac_base_plane<2>(b0, b1, b2, b3, b4), iupac_base_plane<3>(b0, b1, b2, b3, b4)};
+#pragma unroll
+          for (int q = 0; q < NS; ++q) {
+            const uint32_t sv = P.slot_val[q];  // wave-uniform; unused slots hold 0 -> empty mask
+            uint32_t r = 0;
+#pragma unroll
+            for (int o = 0; o < 4; ++o) r |= base[o] & (((sv >> o) & 1u) ? 0xFFu : 0u);
+            mk[q] = r;
+          }
+        }
+        if (s < chunk_iters) {
+          unsigned char* dst = mask_bytes + (grp8 + (s & 7u)) * 8u + w;
+#pragma unroll
+          for (int q = 0; q < NS; ++q) dst[q * 512] = (unsigned char)mk[q];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        my_masks = mask_bytes + (grp8 + ((s - w) & 7u)) * 8u;  // the block this lane's word works on now
+      }
+    } else {
     uint32_t x[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) x[c] = xn[c];
@@ -2095,6 +2148,7 @@ __global__ __launch_bounds__(256) void list_words_kernel(const ScanParams P) {
       build_masks<PROFILE, NS>(x, P, msk);
 #pragma unroll
       for (int q = 0; q < NS; ++q) *reinterpret_cast<uint2*>(mask_bytes + q * 512 + lane * 8) = msk[q];
+    }
     }
     // the row above this word: what the lane of word w-1 left for this block one step ago
     DpWord V;
