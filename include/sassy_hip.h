@@ -118,7 +118,10 @@ int sassy_hip_set_prefilter(sassy_SearcherType *s, int mode);
 /* The bit-plane prefilter (Dna, <= 8 pieces, one strand, one text) can finish the scan in its own launch: every
  * wavefront runs the chunk DP over the match-end blocks it found itself when it has streamed its text range
  * (no hit bitmap, no chunk-list kernel, no list kernel).  on = 1 (default; process-wide: SASSY_HIP_FUSED=0 turns it
- * off), 0 = always the classic chain.  Same matches either way; stats.fused tells which one ran. */
+ * off), 0 = always the classic chain.  Same matches either way; stats.fused tells which one ran.
+ * An Iupac searcher takes the same launch when its pattern holds plain A C G T only (<= 4 pieces) and the text does
+ * too: the launch checks every text byte, and one other letter sends the search to the Iupac chain (and the searcher
+ * does not try again on that text; SASSY_HIP_IUPAC_PLANES=0 turns the attempt off). */
 int sassy_hip_set_fused(sassy_SearcherType *s, int on);
 /* Which reports a search of ONE text returns on low-complexity text (sassy_hip_search, the drop-in search):
  * 0 (default) = the definition -- one left-to-right pass over the text, independent of any chunking;
