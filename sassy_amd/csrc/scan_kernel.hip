@@ -139,53 +139,48 @@ struct EmitCtx {
 static_assert(sizeof(EmitCtx) <= 72, "EmitCtx must stay in registers (one more word and it goes through scratch)");
 constexpr int kEmitShiftBit = 24;
 
-__device__ __forceinline__ void emit(const EmitCtx& P, uint64_t gpos, int cost, uint32_t flags) {
-  const uint32_t idx = atomicAdd(P.cand_count, 1u);
-  if (idx < P.cand_cap) {
-    Candidate c;
-    c.pos = gpos;
-    c.cost = cost;
-    c.flags = flags | P.tag;
-    P.cand[idx] = c;
-  }
-}
-
 // Exact walk over the 64 columns of a block whose last row may contain a cell <= k.
 // Same decisions as the reference's find_minima_with_overhang with alpha = None
 // (reference: src/search.rs:1286-1369), plus the seam bookkeeping.
 //   b: block index inside the buffer; owned: the block belongs to this lane's chunk (reports are
-//   emitted) or is warm-up (state only); x0: first local column whose <=k values are exact
+//   made) or is warm-up (state only); x0: first local column whose <=k values are exact
 //   (-1: all); last_warm: this is the block right before the chunk's first owned block.
-__device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64_t vm, int ds,
-                                            uint64_t b, bool owned, bool last_warm, int64_t x0,
-                                            uint32_t state) {
+// The walk only DECIDES: it returns the block's reports as a bit mask -- x / y: bit i-1 = end position base + i
+// (i = 1 .. 64), z: bits 0..7 the lane state, bits 8..15 how many of the reports (in position order) are
+// conditional (kCandCond: they are the first ones, `amb` only ever goes from true to false), bit 16 = a report
+// at `base` itself.  emit_reports() then appends them for the whole wave with ONE atomic (a report each used to
+// take its own: one address for the whole chip, ~10 ns apiece -- 743 000 reports cost the list kernel 7.8 ms).
+constexpr uint32_t kRepBase = 1u << 16;
+typedef uint32_t rep4 __attribute__((ext_vector_type(4)));  // (a native vector travels in registers; HIP's uint4 struct went through scratch)
+__device__ __forceinline__ rep4 make_rep4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { rep4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+__device__ __noinline__ rep4 scan_block(const EmitCtx P, uint64_t vp, uint64_t vm, int ds, uint64_t b, bool owned,
+                                         bool last_warm, int64_t x0, uint32_t state) {
   bool dec = (state & kStDec) != 0, amb = (state & kStAmb) != 0;
   const int k = (int)P.k;
   const bool all = (P.flags & kScanAllMinima) != 0;
-  // kScanStash: the first report of this block takes a TextStash slot (control word kCtlStashWord counts them); all
-  // reports of the block carry it in their flags, the caller -- who has the block's text -- fills it (return value)
-  uint32_t slot_tag = 0;
-  auto tag_of = [&]() -> uint32_t {
-    if ((P.flags & kScanStash) && slot_tag == 0) {
-      const uint32_t sl = atomicAdd(P.cand_count + kCtlStashWord, 1u);
-      slot_tag = sl < 0xFFFFFEu ? sl + 1u : 0xFFFFFFu;
-    }
-    return slot_tag == 0xFFFFFFu ? 0u : slot_tag << kCandTextShift;
-  };
+  uint64_t rep = 0;
+  uint32_t n_rep = 0, n_cond = 0, rep_base = 0;
   const uint64_t base = b * 64 + (P.flags >> kEmitShiftBit);
   // with overhang the end positions run on into the virtual 'N' columns behind the text, at an
   // extra cost (reference: add_overshoot_cost, src/search.rs:1274-1282)
   const uint64_t max_pos = P.text_len + P.ov_steps;
-  if (base >= max_pos) return state;
+  if (base >= max_pos) return make_rep4(0u, 0u, state & 0xFFu, 0u);
   const bool ov = P.ov_steps != 0;
   auto total_of = [&](int c, uint64_t pos) -> int {
     return (ov && pos > P.text_len) ? c + __float2int_rd(P.alpha * (float)(pos - P.text_len)) : c;
+  };
+  // report at base + i (i = 0 .. 64); reports are made in position order
+  auto report = [&](uint32_t i, bool cond) {
+    if (i == 0) rep_base = kRepBase;
+    else rep |= 1ull << (i - 1);
+    if (cond) n_cond = n_rep + 1;  // (conditional reports come first)
+    ++n_rep;
   };
   int raw = ds;                        // cost without the overshoot part
   int cost = total_of(raw, base), prev_cost = cost;
   uint64_t prev_pos = base;
   if (all && owned && cost <= k && base == P.text_begin && P.global_offset == 0 && (P.flags & kScanTextStart))
-    emit(P, base, cost, tag_of());
+    report(0, false);
   bool determined = (x0 < 0);
   for (int bit = 1; bit <= 64; ++bit) {
     const uint64_t pos = base + (uint64_t)bit;
@@ -197,13 +192,15 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
     // whole; a window chunk warms up inside its own first block(s): nothing is reported or concluded there)
     const bool exact = (int64_t)pos > x0;
     if (all) {
-      if (owned && exact && cost <= k) emit(P, P.global_offset + pos, cost, tag_of());
+      if (owned && exact && cost <= k) report((uint32_t)bit, false);
     } else {
       const bool rising = cost > prev_cost, falling = cost < prev_cost;
-      if (dec && rising && prev_cost <= k && owned && (int64_t)prev_pos > x0)
-        emit(P, P.global_offset + prev_pos, prev_cost, (amb ? kCandCond : 0u) | tag_of());
+      if (dec && rising && prev_cost <= k && owned && (int64_t)prev_pos > x0) report((uint32_t)bit - 1u, amb);
       dec = falling || (dec && !rising);
-      const bool event = rising || falling || cost > k || prev_cost > k;
+      // An exact cell of cost 0 settles the plateau state as well: costs are >= 0, so the last change in front of it
+      // was no increase -- `dec` is true there in the one-pass definition whatever lies left of this chunk (long
+      // runs of N under Iupac, poly-A against poly-A: plateaus of cost 0 that no window sees the beginning of).
+      const bool event = rising || falling || cost > k || prev_cost > k || cost == 0;
       if (event && exact) {
         if (owned) amb = false;
         else determined = true;
@@ -215,9 +212,67 @@ __device__ __noinline__ uint32_t scan_block(const EmitCtx P, uint64_t vp, uint64
   if (!all) {
     if (last_warm) amb = !determined;
     if (owned && (P.flags & kScanTextEnd) && prev_pos == max_pos && dec && prev_cost <= k && (int64_t)prev_pos > x0)
-      emit(P, P.global_offset + prev_pos, prev_cost, (amb ? kCandCond : 0u) | tag_of());
+      report((uint32_t)(prev_pos - base), amb);
   }
-  return (dec ? kStDec : 0u) | (amb ? kStAmb : 0u) | (slot_tag << kCandTextShift);
+  return make_rep4((uint32_t)rep, (uint32_t)(rep >> 32), (dec ? kStDec : 0u) | (amb ? kStAmb : 0u) | (n_cond << 8) | rep_base, 0u);
+}
+
+// Appends the reports scan_block() decided on, for all lanes of the wave at once: called in wave-uniform control
+// flow (every lane of the wave, lanes without a report pass r = 0), one atomic on the report counter per call
+// (and one on the TextStash counter with kScanStash: a slot per reporting block).  vp / vm / ds / b: the block's last
+// row, as scan_block got them (a report's cost is re-derived from them).  Returns the lane's TextStash slot + 1
+// (0: none, 0xFFFFFF: out of slots), which the caller -- who has the block's text -- fills.
+__device__ __noinline__ uint32_t emit_reports(const EmitCtx P, rep4 r, uint64_t vp, uint64_t vm, int ds, uint64_t b) {
+  uint64_t rep = ((uint64_t)r.y << 32) | r.x;
+  const uint32_t rep_base = (r.z & kRepBase) ? 1u : 0u;
+  const uint32_t cnt = (uint32_t)__popcll(rep) + rep_base;
+  const uint32_t lane = __lane_id();
+  uint32_t inc = cnt;  // inclusive prefix sum over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= (uint32_t)d) inc += t;
+  }
+  const uint32_t total = __shfl(inc, 63, 64);
+  if (total == 0) return 0u;
+  uint32_t first = 0;
+  if (lane == 0) first = atomicAdd(P.cand_count, total);
+  first = __shfl(first, 0, 64);
+  uint32_t idx = first + inc - cnt;
+  uint32_t slot_tag = 0;
+  if (P.flags & kScanStash) {
+    const uint64_t who = __ballot(cnt != 0);
+    uint32_t sfirst = 0;
+    if (lane == 0) sfirst = atomicAdd(P.cand_count + kCtlStashWord, (uint32_t)__popcll(who));
+    sfirst = __shfl(sfirst, 0, 64);
+    const uint32_t sl = sfirst + (uint32_t)__popcll(who & ((1ull << lane) - 1ull));
+    if (cnt != 0) slot_tag = sl < 0xFFFFFEu ? sl + 1u : 0xFFFFFFu;
+  }
+  if (cnt == 0) return 0u;
+  const uint32_t tagbits = ((slot_tag == 0xFFFFFFu ? 0u : slot_tag << kCandTextShift)) | P.tag;
+  uint32_t n_cond = (r.z >> 8) & 0xFFu;
+  const uint64_t base = b * 64 + (P.flags >> kEmitShiftBit);
+  const bool ov = P.ov_steps != 0;
+  auto put = [&](uint64_t pos, int raw) {
+    const int cost = (ov && pos > P.text_len) ? raw + __float2int_rd(P.alpha * (float)(pos - P.text_len)) : raw;
+    if (idx < P.cand_cap) {
+      Candidate c;
+      c.pos = P.global_offset + pos;
+      c.cost = cost;
+      c.flags = tagbits | (n_cond ? kCandCond : 0u);
+      P.cand[idx] = c;
+    }
+    if (n_cond) --n_cond;
+    ++idx;
+  };
+  if (rep_base) put(base, ds);
+  while (rep) {
+    const int i = __ffsll((long long)rep);  // 1-based bit = column offset
+    rep &= rep - 1;
+    const uint64_t low = i == 64 ? ~0ull : ((1ull << i) - 1ull);
+    put(base + (uint64_t)i, ds + (int)__popcll(vp & low) - (int)__popcll(vm & low));
+  }
+  return slot_tag;
 }
 
 // 16 text bytes that straddle or lie past the end of the buffer (cold path): bytes past the end
@@ -750,16 +805,20 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
                                       !active, first_rows, minus_total, m, P.counters != nullptr && active, cnt_rows);
 
     // ---- last row of the block: anything <= k ? ----
+    rep4 rr = make_rep4(0u, 0u, 0u, 0u);
+    const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
     if (active) {
       if (P.counters) cnt_blocks += 1;
       if (ran_through && row_maybe_live(ds, V, k)) {
-        const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
         if (P.counters) cnt_live += 1;
-        st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
+        rr = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
+        st = rr.z & (kStDec | kStAmb);
       } else {
         st = kStDec;  // dec = true: a later <=k run can only be entered by a decrease; amb = false
       }
     }
+    // (wave-uniform: the reports of all lanes go out with one atomic)
+    if (__any((rr.x | rr.y | (rr.z & kRepBase)) != 0u)) (void)emit_reports(ctx, rr, vp, vm, ds, b);
   }
 
   if (chunk < P.n_chunks) {
@@ -1530,27 +1589,31 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
       int ds;
       const bool ran_through = dp_block<PROFILE == (int)PROFILE_ASCII_BYTES>(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
                                         !active, first_rows, minus_total, m, P.counters != nullptr && active, cnt_rows);
+      rep4 rr = make_rep4(0u, 0u, 0u, 0u);
+      const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
       if (active) {
         if (P.counters) cnt_blocks += 1;
         if (ran_through && row_maybe_live(ds, V, k)) {
-          const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
           if (P.counters) cnt_live += 1;
-          st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
-          if constexpr (WIN) {  // the block reported: its text goes with the reports (TextStash)
-            const uint32_t slot1 = st >> kCandTextShift;
-            st &= 0xFFu;
-            if (slot1 != 0 && slot1 != 0xFFFFFFu && slot1 <= P.stash_cap) {
-              TextStash* ts = P.stash + (slot1 - 1u);
-              ts->base = b * 64 + shift;
-              uint4* tt = reinterpret_cast<uint4*>(ts->text);
-              tt[0] = make_uint4(x[0], x[1], x[2], x[3]);
-              tt[1] = make_uint4(x[4], x[5], x[6], x[7]);
-              tt[2] = make_uint4(x[8], x[9], x[10], x[11]);
-              tt[3] = make_uint4(x[12], x[13], x[14], x[15]);
-            }
-          }
+          rr = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
+          st = rr.z & (kStDec | kStAmb);
         } else if (!WIN || (int64_t)((b + 1) * 64 + shift) > x0) {
           st = kStDec;  // no cell <= k in the block (a window's block that ends inside its warm-up says nothing)
+        }
+      }
+      // (wave-uniform: the reports of all lanes go out with one atomic)
+      if (__any((rr.x | rr.y | (rr.z & kRepBase)) != 0u)) {
+        const uint32_t slot1 = emit_reports(ctx, rr, vp, vm, ds, b);
+        if constexpr (WIN) {  // the block reported: its text goes with the reports (TextStash)
+          if (slot1 != 0 && slot1 != 0xFFFFFFu && slot1 <= P.stash_cap) {
+            TextStash* ts = P.stash + (slot1 - 1u);
+            ts->base = b * 64 + shift;
+            uint4* tt = reinterpret_cast<uint4*>(ts->text);
+            tt[0] = make_uint4(x[0], x[1], x[2], x[3]);
+            tt[1] = make_uint4(x[4], x[5], x[6], x[7]);
+            tt[2] = make_uint4(x[8], x[9], x[10], x[11]);
+            tt[3] = make_uint4(x[12], x[13], x[14], x[15]);
+          }
         }
       }
     }
@@ -2161,6 +2224,8 @@ __global__ __launch_bounds__(256) void list_words_kernel(const ScanParams P) {
     ds += __popc(ohp) - __popc(ohm);
     uint32_t nhp, nhm;
     dp_word<false, false, PROFILE == (int)PROFILE_ASCII_BYTES>(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm);
+    rep4 rr = make_rep4(0u, 0u, 0u, 0u);
+    const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
     if (active) {
       ohp = nhp;
       ohm = nhm;
@@ -2168,13 +2233,14 @@ __global__ __launch_bounds__(256) void list_words_kernel(const ScanParams P) {
       ds_out = ds;
       if (last_word) {
         if (row_maybe_live(ds, V, k)) {
-          const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
-          st = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
+          rr = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
+          st = rr.z & (kStDec | kStAmb);
         } else {
           st = kStDec;
         }
       }
     }
+    if (__any((rr.x | rr.y | (rr.z & kRepBase)) != 0u)) (void)emit_reports(ctx, rr, vp, vm, ds, b);
   }
   if (has_chunk && last_word) {
     const uint32_t fin = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
