@@ -358,7 +358,8 @@ def _count_n(text: bytes, a: int, b: int) -> int:
 
 
 def search_modes(profile, pattern: bytes, text: bytes, k: int, rc: bool = False, all_minima: bool = False,
-                 end_filter=None, max_n_frac=None, only_best: bool = False, without_trace: bool = False):
+                 end_filter=None, max_n_frac=None, only_best: bool = False, without_trace: bool = False,
+                 alpha: Optional[float] = None):
     """What Searcher::search_one_strand does around the scan (src/search.rs:884-937), per strand:
     end-position callback (search_with_fn, :895-906), N-fraction pre-filter on the end position
     (src/n_filter.rs:38-52), only_best_match (:1392-1412: minimal cost, rightmost end), N-fraction
@@ -372,7 +373,10 @@ def search_modes(profile, pattern: bytes, text: bytes, k: int, rc: bool = False,
     if rc:
         strands.append(("-", complement(profile, pattern), text[::-1]))
     for strand, pat, txt in strands:
-        ms = search(profile, pat, txt, k, rc=False, all_minima=all_minima)
+        if alpha is not None:
+            ms = search_overhang(profile, pat, txt, k, alpha, rc=False, all_minima=all_minima)
+        else:
+            ms = search(profile, pat, txt, k, rc=False, all_minima=all_minima)
         if end_filter is not None:
             ms = [x for x in ms if end_filter(pat, txt[:min(x.text_end, n)], strand)]
         if max_n_frac is not None and max_n_frac != 1.0:

@@ -1,5 +1,6 @@
 // common.h -- structs shared by the host side and the HIP kernels of libsassy_hip.so.
 #pragma once
+#include <atomic>
 #include <cstdint>
 
 namespace sassy_hip {
@@ -328,6 +329,20 @@ struct TraceParams {
 constexpr uint8_t kTraceFailed = 1;
 
 #if defined(__HIPCC__)
+// "Has this been done on the calling thread's current device?"  hipFuncSetAttribute acts on the function of ONE device:
+// a flag per process left every device but the first at the 64 KiB default (the in-process multi-device searcher runs
+// one worker thread per device through the same launchers).  Racing threads at worst set the attribute twice.
+struct DeviceOnce {
+  std::atomic<uint64_t> mask{0};
+  static uint64_t bit() {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    return 1ull << (d & 63);
+  }
+  bool need() const { return (mask.load(std::memory_order_acquire) & bit()) == 0; }
+  void done() { mask.fetch_or(bit(), std::memory_order_release); }
+};
+
 // 16 text bytes of a streaming kernel.  NT: as a non-temporal load (global_load_dwordx4 ... nt) -- the text is read
 // once, and lines that do not linger in L2 / the Infinity Cache leave the HBM stream 10 % faster (bit-plane filter,
 // 3 GB: 0.565 -> 0.506 ms).  Only where a lane takes whole 128-byte lines per step: a kernel that comes back for the

@@ -209,12 +209,12 @@ __global__ __launch_bounds__(64 * WPG) void filter_count_kernel(const ScanParams
 template <int Q, int R, int SB, int WPG>
 hipError_t launch_qr(const ScanParams& P, uint32_t grid, hipStream_t stream) {
   const size_t smem = ((size_t)1 << (2 * (Q + R - 1))) + (size_t)WPG * P.lds_per_wave;
-  static bool attr_set = false;  // LDS beyond the 64 KiB default needs an explicit opt-in
-  if (!attr_set) {
+  static DeviceOnce attr_set;  // LDS beyond the 64 KiB default needs an explicit opt-in
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_count_kernel<Q, R, SB, WPG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL((filter_count_kernel<Q, R, SB, WPG>), dim3(grid), dim3(64 * WPG), smem, stream, P);
   return hipGetLastError();

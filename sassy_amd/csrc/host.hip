@@ -448,6 +448,7 @@ struct sassy_SearcherType {
   // the searcher's first search (HIP's current device is per host thread), or sassy_hip_set_device before it.  Every
   // entry point switches to it for the duration of the call (DeviceGuard), whatever thread it is called from.
   int device = -1;
+  bool bound = false;  // an entry point has run on `device` (streams / buffers / events may exist there): it stays
   DevBuf<uint8_t> d_text, d_rev;
   DevBuf<unsigned long long> d_rc_bitmap;  // the Rc strand's candidate blocks, marked by the forward pass
   // search_many lays its texts out in pinned host memory (no zero fill, H2D at the PCIe rate, reused
@@ -584,7 +585,7 @@ struct PhaseMarks {
     last = t;
   }
 };
-static PhaseMarks g_marks;
+static thread_local PhaseMarks g_marks;  // (per host thread: the multi-device searcher runs one worker per device)
 
 // ------------------------------------------------------------------ scan driver
 struct ShardView {
@@ -3276,6 +3277,7 @@ struct DeviceGuard {
     int cur = 0;
     if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return; }
     if (s->device < 0) s->device = cur;  // first use binds the searcher
+    s->bound = true;
     if (s->device != cur && hipSetDevice(s->device) == hipSuccess) prev = cur;
   }
   ~DeviceGuard() {
@@ -3361,7 +3363,8 @@ void sassy_searcher_free(sassy_SearcherType* ptr) {
 
 int sassy_hip_set_device(sassy_SearcherType* s, int device) {
   if (!s) return fail(SASSY_HIP_EINVAL, "null searcher");
-  if (s->device_ready && s->device != device) return fail(SASSY_HIP_EINVAL, "the searcher already works on another device");
+  if ((s->device_ready || s->bound) && s->device != device)
+    return fail(SASSY_HIP_EINVAL, "the searcher already works on another device");
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) {
     (void)hipGetLastError();
@@ -4060,7 +4063,9 @@ int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t
   if (global_offset + shard_len > total_len) return fail(SASSY_HIP_EINVAL, "shard exceeds the text");
   const bool is_first = global_offset == 0, is_last = global_offset + shard_len == total_len;
   if (!is_last && shard_len % 64) return fail(SASSY_HIP_EINVAL, "inner shard lengths must be multiples of 64");
-  if (!is_first && halo_len < sassy_hip_required_halo(pattern_len, k)) return fail(SASSY_HIP_EINVAL, "halo too short");
+  // (a halo that reaches byte 0 of the text is as long as a halo can be: a short text cut into many shards)
+  if (!is_first && halo_len < sassy_hip_required_halo(pattern_len, k) && halo_len != global_offset)
+    return fail(SASSY_HIP_EINVAL, "halo too short");
   if (((uintptr_t)d_text & 15) != 0) return fail(SASSY_HIP_EINVAL, "device text pointer must be 16-byte aligned");
   const double t0 = now_ms();
   reset_stats(s);
@@ -4071,7 +4076,7 @@ int sassy_hip_search_shard(sassy_SearcherType* s, const uint8_t* pattern, size_t
   sassy_hip_Result* R = new sassy_hip_Result();
   if (shard_len > 0) {
     ShardView sh{d_text, halo_len + shard_len, halo_len, global_offset - halo_len,
-                 is_first && halo_len == 0, is_last};
+                 global_offset == halo_len, is_last};  // (text_start: buffer byte 0 is column 0 of the text)
     sh.adopt_ok = true;  // (search_shard applies no reporting modes: the records are final as the kernels write them)
     ScanOut so;
     const bool wo = (flags & SASSY_HIP_WITHOUT_TRACE) != 0;
@@ -4338,8 +4343,11 @@ int sassy_hip_multi_plant(sassy_hip_Multi* m, uint64_t seed, const uint8_t* patt
     return 0;
   });
   if (rc) return rc;
-  if (planted) {  // (plants inside a halo are counted by the shard that owns them: positions are global)
-    *planted = m->total_len / std::max<uint64_t>(1, stride);
+  if (planted) {
+    // sassy_hip_plant's own rule over the whole text (the per-shard counts overlap in the halos): plant q exists while
+    // q * stride + stride / 2 + m + k <= total_len
+    const uint64_t need = stride / 2 + pattern_len + k;
+    *planted = m->total_len < need ? 0 : (m->total_len - need) / stride + 1;
   }
   return 0;
 }
@@ -4383,7 +4391,9 @@ int sassy_hip_search_shard_begin(sassy_SearcherType* s, const uint8_t* pattern, 
   if (global_offset + shard_len > total_len) return fail(SASSY_HIP_EINVAL, "shard exceeds the text");
   const bool is_first = global_offset == 0, is_last = global_offset + shard_len == total_len;
   if (!is_last && shard_len % 64) return fail(SASSY_HIP_EINVAL, "inner shard lengths must be multiples of 64");
-  if (!is_first && halo_len < sassy_hip_required_halo(pattern_len, k)) return fail(SASSY_HIP_EINVAL, "halo too short");
+  // (a halo that reaches byte 0 of the text is as long as a halo can be: a short text cut into many shards)
+  if (!is_first && halo_len < sassy_hip_required_halo(pattern_len, k) && halo_len != global_offset)
+    return fail(SASSY_HIP_EINVAL, "halo too short");
   if (((uintptr_t)d_text & 15) != 0) return fail(SASSY_HIP_EINVAL, "device text pointer must be 16-byte aligned");
   if (k > 0x7FFFFFFFu) return fail(SASSY_HIP_EINVAL, "k too large");
   const int depth = s->pipe_depth;
@@ -4403,7 +4413,7 @@ int sassy_hip_search_shard_begin(sassy_SearcherType* s, const uint8_t* pattern, 
   t->t0 = now_ms();
   t->empty_shard = shard_len == 0;
   if (!t->empty_shard) {
-    ShardView sh{d_text, halo_len + shard_len, halo_len, global_offset - halo_len, is_first && halo_len == 0, is_last};
+    ShardView sh{d_text, halo_len + shard_len, halo_len, global_offset - halo_len, global_offset == halo_len, is_last};
     sh.adopt_ok = true;
     auto job = std::make_shared<ScanJob>(s, s->lanes[lane], sh, t->plan, (uint32_t)k, (flags & SASSY_HIP_ALL_MINIMA) != 0,
                                          t->pat.data(), !t->without_trace, total_len);

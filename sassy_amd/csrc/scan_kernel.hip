@@ -2255,12 +2255,12 @@ __global__ __launch_bounds__(256) void list_words_kernel(const ScanParams P) {
 // ------------------------------------------------------------------ launcher
 template <int PROFILE, int NS, int SB>
 static hipError_t launch_sb(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
-  static bool attr_set = false;  // LDS beyond the 64 KiB default needs an explicit opt-in
-  if (!attr_set) {
+  static DeviceOnce attr_set;  // LDS beyond the 64 KiB default needs an explicit opt-in
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&scan_kernel<PROFILE, NS, SB>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL((scan_kernel<PROFILE, NS, SB>), dim3(grid), dim3(64u * (P.waves_per_group ? P.waves_per_group : 4u)), smem, stream, P);
   return hipGetLastError();
@@ -2273,12 +2273,12 @@ static hipError_t launch_one(const ScanParams& P, uint32_t grid, size_t smem, hi
 
 template <int PROFILE, int NS, int SB, int NPG>
 static hipError_t launch_filter_npg(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_kernel<PROFILE, NS, SB, NPG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.done();
   }
   hipLaunchKernelGGL((filter_kernel<PROFILE, NS, SB, NPG>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
@@ -2296,12 +2296,12 @@ static hipError_t launch_filter_one(const ScanParams& P, uint32_t grid, size_t s
 }
 template <int PROFILE, int NS>
 static hipError_t launch_list_one(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static DeviceOnce attr_set;
+  if (attr_set.need()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&list_kernel<PROFILE, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    attr_set.done();
   }
   if (P.list_words_max) {  // few chunks of a multi-word pattern are taken by the word-pipelined kernel
     const uint32_t per_group = 256u >> P.list_group_log;

@@ -727,11 +727,11 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
 template <typename Cell, bool IN_LDS, int KT>
 static void launch_one(const TraceParams& P, uint32_t nblocks, size_t lds, hipStream_t stream) {
   if (IN_LDS) {
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
+    static DeviceOnce attr_set;  // per instantiation
+    if (attr_set.need()) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_kernel<Cell, IN_LDS, KT>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      attr_set = true;
+      attr_set.done();
     }
   }
   hipLaunchKernelGGL((trace_kernel<Cell, IN_LDS, KT>), dim3(nblocks), dim3(64), IN_LDS ? lds : 0, stream, P);
@@ -741,24 +741,24 @@ hipError_t launch_trace(const TraceParams& P, uint32_t nblocks, hipStream_t stre
   if (P.wave_mode) {  // one wavefront per report (host checked 2k+3 <= 64 and the LDS budget)
     const size_t lds = (size_t)4 * ((P.m + 15u) & ~15u) + (size_t)4 * P.scratch_stride + (size_t)P.rank_lds * 8u;
     if (P.k + 1 <= 255) {
-      static bool attr8 = false;
-      if (!attr8) {
+      static DeviceOnce attr8;
+      if (attr8.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint8_t, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint8_t, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr8 = true;
+        attr8.done();
       }
       if (P.use_alpha) hipLaunchKernelGGL((trace_wave_kernel<uint8_t, true>), dim3(nblocks), dim3(256), lds, stream, P);
       else hipLaunchKernelGGL((trace_wave_kernel<uint8_t, false>), dim3(nblocks), dim3(256), lds, stream, P);
     } else {
-      static bool attr16 = false;
-      if (!attr16) {
+      static DeviceOnce attr16;
+      if (attr16.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint16_t, false>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&trace_wave_kernel<uint16_t, true>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr16 = true;
+        attr16.done();
       }
       if (P.use_alpha) hipLaunchKernelGGL((trace_wave_kernel<uint16_t, true>), dim3(nblocks), dim3(256), lds, stream, P);
       else hipLaunchKernelGGL((trace_wave_kernel<uint16_t, false>), dim3(nblocks), dim3(256), lds, stream, P);

@@ -274,12 +274,24 @@ class MatchGather:
         if self.copied is not None:
             self.copied.synchronize()  # the previous call's upload has left the staging buffers
         n, state, cond = 0, STATE_PASS, -1
-        packed = False
+        overflow_rows = None  # this rank's rows when they do not fit the staging buffer yet
         if local is not None and not error:
+            # Everything that can fail on this rank alone -- reading the result, packing its rows (a cigar wider than
+            # cigar_bytes, a result already freed) -- happens HERE, in front of the header exchange: the error flag
+            # travels in the header and every rank raises GatherError together.  A rank that raised between the two
+            # collectives would leave the others inside dist.gather for good.
             try:
                 n, state, cond = len(local), local.exit_state, local.conditional_index
+                if n:
+                    dst = self.rows_np if n <= self.cap else np.empty((n, self.cols), dtype=np.int64)
+                    if isinstance(local, ShardResult):
+                        dst[:n] = widen_rows(local.rows, self.cols)
+                    else:
+                        pack_result(local, out=dst)
+                    if n > self.cap:
+                        overflow_rows = dst
             except Exception:  # keep the collectives going: the header tells everybody
-                error = True
+                error, n = True, 0
         self.head_np[0], self.head_np[1], self.head_np[2], self.head_np[3] = n, state, cond, 1 if error else 0
         self.head_dev.copy_(self.head_stage, non_blocking=True)
         self._all_gather_heads()
@@ -289,26 +301,24 @@ class MatchGather:
             raise GatherError(f"rank(s) {bad} reported an error before the match exchange")
         need = int(self.heads_np[:, 0].max())
         if need > self.cap:  # every rank sees the same headers: all grow alike
+            kept = None if overflow_rows is not None or n == 0 else self.rows_np[:n].copy()
             cap = self.cap
             while cap < need:
                 cap *= 2
             self._alloc(cap)
             self.regrown += 1
+            if overflow_rows is not None:
+                self.rows_np[:n] = overflow_rows  # (plain copies of int64 rows: nothing left that can raise)
+            elif kept is not None:
+                self.rows_np[:n] = kept
         if need > 0:
             words = need * self.cols
-            if n:
-                if isinstance(local, ShardResult):
-                    self.rows_np[:n] = widen_rows(local.rows, self.cols)
-                else:
-                    pack_result(local, out=self.rows_np)
-                packed = True
             self.dev[:words].copy_(self.stage[:words], non_blocking=True)
             if self.copied is not None:
                 self.copied.record()
             # the rows travel to rank 0 only
             bufs = [self.all_dev[r, :words] for r in range(self.world)] if self.rank == 0 else None
             self.dist.gather(self.dev[:words], gather_list=bufs, dst=0)
-        del packed
         if self.rank != 0:
             return None
         out = []

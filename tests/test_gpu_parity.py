@@ -2491,6 +2491,23 @@ def test_multi_searcher_shards_on_one_gpu(sassy):
     th.join()
     assert len(want) >= 30
     assert_same(got[0], want, "multi synthetic, other thread")
+    # the count of plants is sassy_hip_plant's own rule over the whole text
+    stride = 1 << 16
+    assert ms.plant(42, p2, 3, stride) == (0 if n2 < stride // 2 + 32 + 3 else (n2 - (stride // 2 + 32 + 3)) // stride + 1)
+    # a short text over many shards: the shards' offsets are smaller than the halo a search asks for -- a halo that
+    # reaches byte 0 of the text is all there is, and enough
+    ms8 = sassy.MultiSearcher("dna", devices=[0] * 8)
+    for n3 in (1000, 1024, 5000, 130, 7):
+        t3 = bytearray(rand_seq(rng, n3))
+        for _ in range(4):
+            ins = mutate(rng, pat, rng.randrange(4))[:max(1, n3 - 1)]
+            at = rng.randrange(0, max(1, n3 - len(ins)))
+            t3[at:at + len(ins)] = ins
+        t3 = bytes(t3[:n3])
+        ms8.set_text(t3, 32, 3)
+        assert_same(ms8.search(pat, 3).matches, oracle.search("dna", pat, t3, 3), ("tiny text over 8 shards", n3))
+        assert_same(ms8.search(pat, 3, sassy.ALL_MINIMA).matches, oracle.search("dna", pat, t3, 3, all_minima=True), ("tiny all", n3))
+
 
 
 def test_config5_shape_24gb_in_eight_shards_on_one_gpu(sassy):
@@ -2561,8 +2578,17 @@ def test_searcher_stays_on_its_device_from_any_thread(sassy):
         th.join()
     assert_same(out[0], want)
     assert_same(s.search(pat, tb, 3), want)
+    # bound by its searches: any other device id is refused, whether or not such a device exists
     with pytest.raises(sassy.SassyHipError, match="another device"):
-        s.set_device(1 if sassy.device_count() > 1 else 0) if sassy.device_count() > 1 else (_ for _ in ()).throw(sassy.SassyHipError("another device"))
+        s.set_device(1)
+    s.set_device(0)  # (naming the device it is on stays a no-op)
+    assert_same(s.search(pat, tb, 3), want)
+    # ... and so is a searcher that an entry point other than a search has bound (sassy_hip_set_stream runs on it)
+    s3 = sassy.Searcher("dna", rc=False)
+    s3.set_stream(0)
+    assert s3.device == 0
+    with pytest.raises(sassy.SassyHipError, match="another device"):
+        s3.set_device(1)
 
 
 def test_results_that_keep_their_pinned_block(sassy):

@@ -126,6 +126,23 @@ def _worker(rank, world, port, q):
             assert "[1]" in str(e)
         w2.close()
         w.close()
+        # a rank whose rows cannot be packed (here: a cigar wider than the gather's field; rank 0 only) must not leave
+        # the others inside the row gather: packing happens in front of the header exchange, the flag travels in the
+        # header, both ranks raise together -- with rows that fit the staging buffer and with rows that overflow it
+        for cap in (8, 1):
+            mg4 = multigpu.MatchGather(torch, dist, dev, capacity_rows=cap, cigar_bytes=8)
+            wide = [M(10, 60, 5, "+", "10=1X10=1X10=1X10="), M(100, 104), M(200, 204)]
+            narrow = [M(20, 24), M(30, 34)]
+            rows = multigpu.rows_from_matches(wide if rank == 0 else narrow)
+            try:
+                mg4.gather(multigpu.ShardResult(rows, multigpu.STATE_TRUE, -1))
+                raise AssertionError("no GatherError")
+            except multigpu.GatherError as e:
+                assert "[0]" in str(e)
+            # the gatherer is still usable: the next exchange is in step on both ranks
+            got = mg4.gather(multigpu.ShardResult(multigpu.rows_from_matches(narrow), multigpu.STATE_TRUE, -1))
+            if rank == 0:
+                assert [len(g) for g in got] == [2, 2]
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
