@@ -63,7 +63,12 @@ hipError_t launch_rank(const Candidate* d_cand, const uint32_t* d_count, uint32_
 
 size_t sort_scratch_bytes(uint32_t count);
 hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, uint32_t count, void* d_scratch,
-                                  size_t scratch_bytes, hipStream_t stream, int by_tag = 0);
+                                  size_t scratch_bytes, hipStream_t stream, int by_tag = 0, int key_bits = 64);
+hipError_t launch_report_flags(const Candidate* d_list, uint32_t max_count, const uint32_t* d_count, uint64_t min_pos,
+                               uint32_t* d_flags, hipStream_t stream);
+size_t unique_scratch_bytes(uint32_t count);
+hipError_t launch_unique_reports(Candidate* d_sorted, uint32_t count, uint64_t min_pos, Candidate* d_out, uint32_t* d_out_count,
+                                 void* d_scratch, size_t scratch_bytes, hipStream_t stream);
 size_t select_scratch_bytes(uint32_t count);
 hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Candidate* d_sel, uint32_t* d_sel_count,
                                  void* d_scratch, size_t scratch_bytes, hipStream_t stream, int all_minima = 0);
@@ -138,19 +143,25 @@ struct PinPool {
   std::mutex mu;
   std::vector<PinBlock> blocks;
   static constexpr size_t kKeep = 12;
+  static constexpr size_t kKeepBytes = (size_t)2 << 30;  // idle blocks kept for reuse (dense results hold 100 MB and more each)
   // blocks that results hold right now: a caller who keeps every result alive must not pin memory without bound (and
-  // pay a hipHostMalloc per search) -- beyond kMaxAdopted outstanding blocks results are copied out as before
+  // pay a hipHostMalloc per search) -- beyond kMaxAdopted outstanding blocks (or kMaxAdoptedBytes) results are copied
+  // out as before
   static constexpr int kMaxAdopted = 16;
+  static constexpr size_t kMaxAdoptedBytes = (size_t)4 << 30;
   int adopted = 0;
-  bool may_adopt() {
+  size_t adopted_bytes = 0;
+  bool may_adopt(size_t bytes) {
     std::lock_guard<std::mutex> g(mu);
-    if (adopted >= kMaxAdopted) return false;
+    if (adopted >= kMaxAdopted || adopted_bytes + bytes > kMaxAdoptedBytes) return false;
     ++adopted;
+    adopted_bytes += bytes;
     return true;
   }
-  void adopted_back() {
+  void adopted_back(size_t bytes) {
     std::lock_guard<std::mutex> g(mu);
     if (adopted > 0) --adopted;
+    adopted_bytes -= std::min(adopted_bytes, bytes);
   }
   bool take(size_t bytes, int dev, PinBlock& out) {
     std::lock_guard<std::mutex> g(mu);
@@ -166,7 +177,9 @@ struct PinPool {
     if (!b.h) return;
     {
       std::lock_guard<std::mutex> g(mu);
-      if (blocks.size() < kKeep) { blocks.push_back(b); return; }
+      size_t kept = 0;
+      for (const PinBlock& x : blocks) kept += x.cap;
+      if (blocks.size() < kKeep && kept + b.cap <= kKeepBytes) { blocks.push_back(b); return; }
     }
     (void)hipHostFree(b.h);
   }
@@ -189,7 +202,7 @@ struct sassy_hip_Result {
   const char* pool_data() const { return pin.h ? ext_pool : pool.c_str(); }
   size_t pool_size() const { return pin.h ? ext_pool_len : pool.size(); }
   ~sassy_hip_Result() {
-    if (pin.h) g_pin_pool.adopted_back();
+    if (pin.h) g_pin_pool.adopted_back(pin.cap);
     g_pin_pool.give(pin);
   }
 };
@@ -226,6 +239,7 @@ struct ScanLane {
   bool own_stream = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_f = nullptr, ev_filter_done = nullptr;
   DevBuf<uint8_t> d_state, d_scratch, d_str, d_ctl, d_sort;
+  DevBuf<uint32_t> d_flags;     // dense results: "does any record need the host's attention" (report_flags_kernel)
   DevBuf<Candidate> d_cand, d_sorted;
   DevBuf<MatchOut> d_trace;
   DevBuf<ChunkDesc> d_desc;
@@ -370,7 +384,7 @@ struct ScanLane {
   void destroy() {
     if (h_up) (void)hipHostFree(h_up);
     h_up = nullptr; h_up_cap = h_up_used = 0;
-    d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release(); d_sort.release();
+    d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release(); d_sort.release(); d_flags.release();
     for (unsigned char*& b : h_bulk) { if (b) (void)hipHostFree(b); b = nullptr; }
     d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release();
     d_pattern.release(); d_table.release(); d_rowoff.release(); d_ovtab.release(); d_stash.release();
@@ -616,7 +630,7 @@ struct ScanOut {
   ScanOut(ScanOut&& o) noexcept { *this = std::move(o); }
   ScanOut& operator=(ScanOut&& o) noexcept {
     if (this != &o) {
-      if (pin.h) g_pin_pool.adopted_back();
+      if (pin.h) g_pin_pool.adopted_back(pin.cap);
       g_pin_pool.give(pin);
       cands = std::move(o.cands); conditional_index = o.conditional_index; exit_state = o.exit_state; cond_seen = o.cond_seen;
       matches = std::move(o.matches); pool = std::move(o.pool);
@@ -626,7 +640,7 @@ struct ScanOut {
     return *this;
   }
   ~ScanOut() {
-    if (pin.h) g_pin_pool.adopted_back();
+    if (pin.h) g_pin_pool.adopted_back(pin.cap);
     g_pin_pool.give(pin);
   }
   const sassy_hip_Match* ext_matches = nullptr;
@@ -868,6 +882,7 @@ struct ScanJob {
   uint32_t maxlen = 128;
   static constexpr uint32_t kSpec = 4096;  // reports the kernels also write into the host buffer
   static constexpr size_t kPinCounts = 0, kPinCounters = 16, kPinFlags = 64;
+  static constexpr size_t kPinFlags2 = 68, kPinCount2 = 72;  // dense results: the device's flag word and the count behind the dedup
   static constexpr size_t pin_cands = 128;
   static constexpr size_t pin_recs = pin_cands + (size_t)kSpec * sizeof(Candidate);
   static constexpr size_t pin_ops = pin_recs + (size_t)kSpec * sizeof(MatchOut);
@@ -1514,7 +1529,9 @@ int ScanJob::enqueue(int attempt) {
     // (the traceback waves tell the host whether any record needs its attention: see finish_once, adoption)
     *reinterpret_cast<volatile uint32_t*>(L.h_pin + kPinFlags) = 0u;
     Tw.host_flags = self_rank ? reinterpret_cast<uint32_t*>(L.h_pin_dev + kPinFlags) : nullptr;
-    Tw.min_pos = sh.global_offset + first_owned * 64;
+    // (the end position ON a shard border, first_owned * 64: under the report rule it is decided by whoever sees the
+    // column behind it -- this shard; a list of ALL end positions <= k has it from the shard on the left already)
+    Tw.min_pos = sh.global_offset + first_owned * 64 + (first_owned && all_minima ? 1 : 0);
     T.host_flags = nullptr;
     if (self_rank) Tw.count_max = kTraceWaveMax;
     Tw.dedup = fused ? 1u : 0u;
@@ -1576,6 +1593,9 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
   out = ScanOut();
   if (empty) return 0;
   bool sorted_on_device = false;
+  bool big = false;  // the result's rows and strings lie in the lane's pinned block at these offsets (dense results)
+  size_t big_rows_off = 0, big_strs_off = 0, big_cands_off = 0;
+  const Candidate* big_list = nullptr;  // ... and the (sorted, deduplicated) reports they belong to on the device
   for (int attempt = 0;; ++attempt) {
     // the only synchronisation of the call; the kernels have written the results into h_pin
     const double t_sync0 = now_ms();
@@ -1642,27 +1662,84 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
           // (sort_kernels.hip), then the traceback on the sorted list -- the records arrive in result order,
           // the host sorts nothing (the counting ranker is quadratic: 27 000 reports took it 0.32 ms, the
           // host's std::sort 63 ms for 740 000)
-          const size_t need = sort_scratch_bytes(counts[0]);
+          const size_t need = std::max(sort_scratch_bytes(counts[0]), unique_scratch_bytes(counts[0]));
           if (int rc = L.d_sort.reserve(need)) return rc;
-          le = launch_sort_candidates(L.d_cand.p, L.d_sorted.p, counts[0], L.d_sort.p, L.d_sort.cap, L.stream);
+          if (int rc = L.d_flags.reserve(64)) return rc;
+          int key_bits = 8;  // (a radix pass per 8 bits of the largest end position)
+          while (key_bits < 64 && ((sh.global_offset + sh.text_len + plan.m + 64) >> key_bits) != 0) key_bits += 8;
+          le = launch_sort_candidates(L.d_cand.p, L.d_sorted.p, counts[0], L.d_sort.p, L.d_sort.cap, L.stream, 0, key_bits);
           if (le != hipSuccess) return hip_fail(le, "report sort launch");
           sorted_on_device = true;
+          // Dense results (10^4 .. 10^6 rows): rows and cigar strings go, with two DMA copies behind the traceback, into
+          // ONE pinned block sized for this result; a result that needs no editing keeps it (as the small ones keep the
+          // lane's block) -- the host used to move 160 bytes per match through bounce buffers, vectors and loops,
+          // 26 ms for 743 000 matches.  What would need editing (a conditional report, a copy, a failed traceback) is
+          // found on the device (report_flags_kernel, the traceback kernels) and told in the block's flag word.
+          static const bool env_nobig = getenv("SASSY_HIP_BIG_PIN") && atoi(getenv("SASSY_HIP_BIG_PIN")) == 0;
+          const size_t cnt = counts[0];
+          big_rows_off = 256;
+          big_strs_off = (big_rows_off + cnt * sizeof(MatchOut) + 255) / 256 * 256;
+          big_cands_off = (big_strs_off + cnt * T.str_stride + 255) / 256 * 256;
+          const size_t big_bytes = big_cands_off + cnt * sizeof(Candidate) + 256;
+          if (!env_nobig && do_trace) {
+            unsigned char ctl_save[128];
+            memcpy(ctl_save, L.h_pin, sizeof ctl_save);
+            if (L.reserve_pinned(big_bytes) == 0) {
+              memcpy(L.h_pin, ctl_save, sizeof ctl_save);  // (the block may be another one now)
+              big = true;
+            } else {
+              (void)hipGetLastError();
+              if (L.reserve_pinned(pin_ops + (size_t)kSpec * T.str_stride + 64)) return fail(SASSY_HIP_ENOMEM, "no pinned memory");
+              memcpy(L.h_pin, ctl_save, sizeof ctl_save);
+            }
+          }
         } else if (self_rank) {
           le = launch_rank(L.d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(L.d_ctl.p + 64), L.d_sorted.p,
                            reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands), std::min<uint32_t>(kSpec, P.cand_cap),
                            L.h_pin_dev + kPinCounts, texts, L.stream);
           if (le != hipSuccess) return hip_fail(le, "rank kernel launch");
         }
-        if (use_thread) {
-          le = launch_trace(T, trace_blocks, L.stream);
-        } else {
-          TraceParams Tall = Tw;
+        TraceParams Tall = use_thread ? T : Tw;
+        if (!use_thread) {
           Tall.unsorted = nullptr;
           Tall.count_max = 0xFFFFFFFFu;
-          le = launch_trace(Tall, wave_blocks, L.stream);
         }
+        if (big) {
+          big_list = L.d_sorted.p;
+          if (fused) {
+            // the fused filter's overlapping windows report some positions twice, windows that begin in the halo report
+            // the previous shard's: the list loses them here (the count in the control block follows), not on the host
+            le = launch_unique_reports(L.d_sorted.p, counts[0], Tw.min_pos, L.d_cand.p, d_counts, L.d_sort.p, L.d_sort.cap, L.stream);
+            if (le != hipSuccess) return hip_fail(le, "report dedup launch");
+            big_list = L.d_cand.p;
+          }
+          *reinterpret_cast<volatile uint32_t*>(L.h_pin + kPinFlags) = 0u;
+          Tall.cand = big_list;
+          Tall.host_flags = reinterpret_cast<uint32_t*>(L.h_pin_dev + kPinFlags);  // (failed tracebacks: rare, straight to the host)
+          Tall.host_cap = 0;  // (no second copy of the head of the list: everything travels by DMA)
+          HIP_TRY(hipMemsetAsync(L.d_flags.p, 0, 4, L.stream));
+          le = launch_report_flags(big_list, counts[0], d_counts, 0, L.d_flags.p, L.stream);
+          if (le != hipSuccess) return hip_fail(le, "report flags launch");
+        } else if (sorted_on_device) {
+          Tall.host_flags = nullptr;
+        }
+        le = launch_trace(Tall, use_thread ? trace_blocks : wave_blocks, L.stream);
         if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
+        if (big) {
+          HIP_TRY(hipMemcpyAsync(L.h_pin + kPinFlags2, L.d_flags.p, 4, hipMemcpyDeviceToHost, L.stream));
+          HIP_TRY(hipMemcpyAsync(L.h_pin + kPinCount2, d_counts, 4, hipMemcpyDeviceToHost, L.stream));
+          HIP_TRY(hipMemcpyAsync(L.h_pin + big_rows_off, L.d_trace.p, (size_t)counts[0] * sizeof(MatchOut), hipMemcpyDeviceToHost, L.stream));
+          HIP_TRY(hipMemcpyAsync(L.h_pin + big_strs_off, L.d_str.p, (size_t)counts[0] * T.str_stride, hipMemcpyDeviceToHost, L.stream));
+          if (!sh.adopt_ok)  // (a caller that edits the list wants the reports themselves as well)
+            HIP_TRY(hipMemcpyAsync(L.h_pin + big_cands_off, big_list, (size_t)counts[0] * sizeof(Candidate), hipMemcpyDeviceToHost, L.stream));
+        }
         HIP_TRY(hipStreamSynchronize(L.stream));
+        if (big) {
+          uint32_t c2 = 0;
+          memcpy(&c2, L.h_pin + kPinCount2, sizeof c2);
+          if (c2 > counts[0]) return fail(SASSY_HIP_EINVAL, "internal: report count grew in the dedup");
+          counts[0] = c2;
+        }
       }
       break;
     }
@@ -1693,19 +1770,34 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
   // the records as they are: the result keeps the pinned block, the lane gets another one.
   uint32_t host_flags = 0;
   memcpy(&host_flags, L.h_pin + kPinFlags, sizeof host_flags);
+  if (big) {
+    uint32_t f2 = 0;
+    memcpy(&f2, L.h_pin + kPinFlags2, sizeof f2);
+    host_flags |= f2;
+  }
   static const bool env_noadopt = getenv("SASSY_HIP_ADOPT") && atoi(getenv("SASSY_HIP_ADOPT")) == 0;
   bool adopt = sh.adopt_ok && !env_noadopt && do_trace && self_rank && !sorted_on_device && count != 0 && count <= kSpec &&
                count <= kTraceWaveMax && texts.n == 0 && host_flags == 0;
-  if (adopt) adopt = g_pin_pool.may_adopt();
+  if (big) adopt = sh.adopt_ok && !env_noadopt && host_flags == 0 && count != 0;
+  if (adopt) adopt = g_pin_pool.may_adopt(L.h_pin_cap);
   struct AdoptSlot {  // the counted slot goes back unless the block really changes hands at the end of this function
     bool held;
-    ~AdoptSlot() { if (held) g_pin_pool.adopted_back(); }
-  } adopt_slot{adopt};
+    size_t bytes;
+    ~AdoptSlot() { if (held) g_pin_pool.adopted_back(bytes); }
+  } adopt_slot{adopt, L.h_pin_cap};
   if (adopt) {
-    out.ext_matches = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + pin_recs);
+    out.ext_matches = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + (big ? big_rows_off : pin_recs));
     out.ext_n = count;
-    out.ext_pool = reinterpret_cast<const char*>(L.h_pin + pin_ops);
+    out.ext_pool = reinterpret_cast<const char*>(L.h_pin + (big ? big_strs_off : pin_ops));
     out.ext_pool_len = (size_t)count * T.str_stride;
+  } else if (big) {
+    // (host -> host copies out of the pinned block; the reports themselves came along unless the caller was expected to adopt)
+    out.cands.resize(count);
+    if (!sh.adopt_ok) memcpy(out.cands.data(), L.h_pin + big_cands_off, (size_t)count * sizeof(Candidate));
+    else if (int rc = L.download(out.cands.data(), big_list, (size_t)count * sizeof(Candidate))) return rc;
+    const sassy_hip_Match* hm = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + big_rows_off);
+    out.matches.assign(hm, hm + count);
+    out.pool.assign(reinterpret_cast<const char*>(L.h_pin + big_strs_off), (size_t)count * T.str_stride);
   } else if (count) {
     // (after a device sort the staging area's head holds the unsorted list's records: take everything from the device)
     const uint32_t have = sorted_on_device ? 0u : std::min<uint32_t>(count, kSpec);
@@ -1742,7 +1834,7 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
   }
   // fused launch: window chunks that begin in the halo also report end positions in front of the first owned block
   // (the previous shard's)
-  const uint64_t fused_min_pos = sh.global_offset + first_owned * 64;
+  const uint64_t fused_min_pos = sh.global_offset + first_owned * 64 + (first_owned && all_minima ? 1 : 0);
   if (fused && !sorted_on_device) {  // a report two chunks made: the second copy came back as a kCandDrop record
     size_t w = 0;
     for (size_t i = 0; i < out.cands.size(); ++i) {

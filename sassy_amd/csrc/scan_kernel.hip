@@ -1675,20 +1675,29 @@ __device__ __noinline__ uint2 piece_end_cols(uint64_t bits, uint64_t b, int64_t 
   return make_uint2((uint32_t)(c_lo - col_base), (uint32_t)(c_hi - col_base));
 }
 // The run of end positions a lane is collecting (columns relative to col_base): x = first (kRunNone: none),
-// y = last, z = one past the last column the lane's queued windows cover, w = first column of the last queued one.
+// y = last, z = one past the last column the lane's queued windows cover, w = first column of the last queued one
+// (bit 31 of w: kRunPressure -- the wave's queue is filling up, see below).
 constexpr uint32_t kRunNone = 0xFFFFFFFFu;
+constexpr uint32_t kRunPressure = 0x80000000u;
 constexpr uint32_t kRunMergeGap = 32;  // runs this close share a window
-// Queues the window chunk for the run [x, y]: the DP starts fresh at column `start` and is exact from start + mk on
+// Queues the window chunk for the columns [x, y]: the DP starts fresh at column `start` and is exact from start + mk on
 // (mk = m + k), so the window [start, y] with start <= x - 1 - mk reports every end position of the run, plateau
-// state included (unless the plateau reaches back beyond x - 1: such a report is conditional, scan_block).  Whole
-// 64-column blocks ending at y: {first block, blocks << 6 | byte shift}.
-constexpr uint32_t kFuseMaxBlocks = 96;  // a longer window (dense repeats, a run of N under Iupac) is no work for one lane
-__device__ __forceinline__ uint4 fuse_flush(uint2* queue, uint32_t* qcount, uint32_t* fuse_word, uint32_t cap, uint32_t mk,
-                                            int64_t col_base, uint4 st) {
-  if (st.x == kRunNone) return st;
-  uint32_t nv = (st.y - st.x + mk + 2u + 63u) / 64u;
-  if (nv > kFuseMaxBlocks) atomicOr(fuse_word, kFuseOverflow);  // the classic chain cuts such runs into chunks
-  const int64_t end = col_base + (int64_t)st.y;
+// state included (unless the plateau reaches back beyond x - 1 without an exact cell of cost 0: such a report is
+// conditional, scan_block).  Whole 64-column blocks ending at y: {first block, blocks << 6 | byte shift}.
+// A long run -- a run of N under Iupac, poly-A against poly-A, a microsatellite -- is no work for one lane: it leaves
+// the lane in windows of kFuseSplitBlocks blocks of end positions each, as it grows (fuse_add_range), every window
+// with its own warm-up; neighbouring windows share up to 63 exact columns, and what both report is dropped where the
+// reports are ranked.
+constexpr uint32_t kFuseSplitBlocks = 32;
+constexpr uint32_t kFuseMaxBlocks = kFuseSplitBlocks + 16;  // (no window is longer: split length + the widest single range + warm-up)
+// press_at: a lane whose entry gets this index or a later one raises kRunPressure -- the wave then runs the chunk DP
+// over its queue at the next block pair instead of at the end of its text range (the queue never overflows: between
+// two looks at the flag every lane adds at most two entries).
+__device__ __forceinline__ rep4 fuse_emit(uint2* queue, uint32_t* qcount, uint32_t* fuse_word, uint32_t cap, uint32_t press_at,
+                                          uint32_t mk, int64_t col_base, rep4 st, uint32_t x, uint32_t y) {
+  uint32_t nv = (y - x + mk + 2u + 63u) / 64u;
+  if (nv > kFuseMaxBlocks) atomicOr(fuse_word, kFuseOverflow);  // (cannot happen: runs are split before they get there)
+  const int64_t end = col_base + (int64_t)y;
   int64_t start = end - 64 * (int64_t)nv;
   if (start < 0) {  // the buffer starts inside the window: whole blocks from byte 0
     start = 0;
@@ -1696,17 +1705,23 @@ __device__ __forceinline__ uint4 fuse_flush(uint2* queue, uint32_t* qcount, uint
   }
   const uint32_t idx = atomicAdd(qcount, 1u);
   if (idx < cap) queue[idx] = make_uint2((uint32_t)(start >> 6), (nv << 6) | (uint32_t)(start & 63));
-  st.z = st.y + 1u;
-  st.w = st.x;
-  st.x = kRunNone;
+  else atomicOr(fuse_word, kFuseOverflow);
+  st.z = y + 1u;
+  st.w = x | ((idx >= press_at || (st.w & kRunPressure)) ? kRunPressure : 0u);
   return st;
 }
 // adds the columns [lo, hi] (lo = kRunNone: nothing to add, only queue the pending run)
-__device__ __noinline__ uint4 fuse_add_range(uint2* queue, uint32_t* qcount, uint32_t* fuse_word, uint32_t cap, uint32_t mk,
-                                             int64_t col_base, uint32_t first_col, uint4 st, uint32_t lo, uint32_t hi) {
-  if (lo == kRunNone) return fuse_flush(queue, qcount, fuse_word, cap, mk, col_base, st);
+__device__ __noinline__ rep4 fuse_add_range(uint2* queue, uint32_t* qcount, uint32_t* fuse_word, uint32_t cap, uint32_t press_at,
+                                            uint32_t mk, int64_t col_base, uint32_t first_col, rep4 st, uint32_t lo, uint32_t hi) {
+  if (lo == kRunNone) {
+    if (st.x != kRunNone) {
+      st = fuse_emit(queue, qcount, fuse_word, cap, press_at, mk, col_base, st, st.x, st.y);
+      st.x = kRunNone;
+    }
+    return st;
+  }
   if (lo < first_col) lo = first_col;  // the halo's end positions are not ours
-  if (lo < st.w) {
+  if (lo < (st.w & ~kRunPressure)) {
     // columns in front of a window that is already queued (possible only when an occurrence's marks reach further
     // than a block: long patterns): the classic chain takes the search
     atomicOr(fuse_word, kFuseOverflow);
@@ -1717,9 +1732,14 @@ __device__ __noinline__ uint4 fuse_add_range(uint2* queue, uint32_t* qcount, uin
   if (st.x != kRunNone && lo <= st.y + kRunMergeGap) {
     st.x = min(st.x, lo);
     st.y = max(st.y, hi);
+    if (st.y - st.x >= 64u * kFuseSplitBlocks + 64u) {  // a long run: its first kFuseSplitBlocks blocks leave now
+      const uint32_t e = st.x + 64u * kFuseSplitBlocks - 1u;
+      st = fuse_emit(queue, qcount, fuse_word, cap, press_at, mk, col_base, st, st.x, e);
+      st.x = e + 1u;
+    }
     return st;
   }
-  st = fuse_flush(queue, qcount, fuse_word, cap, mk, col_base, st);
+  if (st.x != kRunNone) st = fuse_emit(queue, qcount, fuse_word, cap, press_at, mk, col_base, st, st.x, st.y);
   st.x = lo;
   st.y = hi;
   return st;

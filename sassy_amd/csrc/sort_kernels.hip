@@ -83,6 +83,42 @@ __global__ __launch_bounds__(256) void flag_reports_kernel(const Candidate* __re
   keep[i] = report ? 1 : 0;
 }
 
+// Does the sorted list of one strand's reports need the host's attention?  bit 1: a report is conditional (kCandCond),
+// bit 2: a report is a copy of its left neighbour (fused filter: two lanes' windows share columns) or lies in front of
+// min_pos (the previous shard's).  With neither (and no failed traceback, bit 0, from the traceback kernels) the rows
+// are final as the traceback writes them: the result takes them where they lie.  The flags gather in a DEVICE word
+// (an atomic on pinned host memory per wave cost this kernel 27 us for 13 000 reports); the host gets a copy.
+__global__ __launch_bounds__(256) void report_flags_kernel(const Candidate* __restrict__ c, const uint32_t* __restrict__ count_ptr,
+                                                           uint64_t min_pos, uint32_t* __restrict__ d_flags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t count = *count_ptr;
+  uint32_t hf = 0;
+  if (i < count) {
+    const Candidate me = c[i];
+    if (me.flags & kCandCond) hf |= 2u;
+    if ((me.flags & kCandDrop) || me.pos < min_pos || (i > 0 && c[i - 1].pos == me.pos)) hf |= 4u;
+  }
+  const unsigned long long b2 = __ballot((hf & 2u) != 0), b4 = __ballot((hf & 4u) != 0);
+  if ((b2 | b4) != 0 && (threadIdx.x & 63u) == 0) atomicOr(d_flags, (b2 ? 2u : 0u) | (b4 ? 4u : 0u));
+}
+
+// The fused filter's windows may overlap: a report can be in the (sorted) list more than once, and windows that begin
+// in the halo report end positions in front of min_pos.  keep[i] = first copy of an owned position.  A copy is
+// unconditional when its window saw what settles the plateau state; then the report is certain whatever the other
+// copies say: the first copy drops its kCandCond when any copy has none.
+__global__ __launch_bounds__(256) void unique_flags_kernel(Candidate* __restrict__ c, uint32_t count, uint64_t min_pos,
+                                                           unsigned char* __restrict__ keep) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint64_t pos = c[i].pos;
+  const bool first = i == 0 || c[i - 1].pos != pos;
+  if (first && (c[i].flags & kCandCond)) {
+    for (uint32_t j = i + 1; j < count && c[j].pos == pos; ++j)
+      if (!(c[j].flags & kCandCond)) { c[i].flags &= ~kCandCond; break; }
+  }
+  keep[i] = (first && pos >= min_pos) ? 1 : 0;
+}
+
 // Reports of many patterns over a multi-text buffer learn their text (the largest t with start[t] <= position).  A
 // report that ends inside the separator behind text t stands for the end-of-text report of text t and is moved
 // there; in search_all mode such positions do not exist in a single-text search and are dropped (as
@@ -117,8 +153,36 @@ size_t sort_scratch_bytes(uint32_t count) {
 }
 
 // sorted[0 .. count) = cand[0 .. count) by ascending end position (by_tag: by (flags >> 8, end position)).
+hipError_t launch_report_flags(const Candidate* d_list, uint32_t max_count, const uint32_t* d_count, uint64_t min_pos,
+                               uint32_t* d_flags, hipStream_t stream) {
+  if (max_count == 0) return hipSuccess;
+  hipLaunchKernelGGL(report_flags_kernel, dim3((max_count + 255) / 256), dim3(256), 0, stream, d_list, d_count, min_pos, d_flags);
+  return hipGetLastError();
+}
+
+// out[0 .. *d_out_count) = sorted[0 .. count) without copies and without the reports in front of min_pos (order kept).
+size_t unique_scratch_bytes(uint32_t count) {
+  size_t temp = 0;
+  (void)rocprim::select(nullptr, temp, static_cast<Candidate*>(nullptr), static_cast<unsigned char*>(nullptr),
+                        static_cast<Candidate*>(nullptr), static_cast<uint32_t*>(nullptr), (size_t)count, hipStream_t(nullptr));
+  return ((size_t)count + 255) / 256 * 256 + temp + 256;
+}
+hipError_t launch_unique_reports(Candidate* d_sorted, uint32_t count, uint64_t min_pos, Candidate* d_out, uint32_t* d_out_count,
+                                 void* d_scratch, size_t scratch_bytes, hipStream_t stream) {
+  if (count == 0) return hipMemsetAsync(d_out_count, 0, 4, stream);
+  const size_t flag_bytes = ((size_t)count + 255) / 256 * 256;
+  if (scratch_bytes < flag_bytes) return hipErrorInvalidValue;
+  unsigned char* keep = static_cast<unsigned char*>(d_scratch);
+  hipLaunchKernelGGL(unique_flags_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_sorted, count, min_pos, keep);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  size_t temp_bytes = scratch_bytes - flag_bytes;
+  return rocprim::select(keep + flag_bytes, temp_bytes, d_sorted, keep, d_out, d_out_count, (size_t)count, stream);
+}
+
+// key_bits: the keys' significant bits (a radix pass per 8 bits: end positions of a 3 GB text need 32, not 64)
 hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, uint32_t count, void* d_scratch,
-                                  size_t scratch_bytes, hipStream_t stream, int by_tag) {
+                                  size_t scratch_bytes, hipStream_t stream, int by_tag, int key_bits) {
   if (count == 0) return hipSuccess;
   const size_t key_bytes = ((size_t)count * 8 + 255) / 256 * 256;
   if (scratch_bytes < 2 * key_bytes) return hipErrorInvalidValue;
@@ -129,7 +193,8 @@ hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, 
   hipLaunchKernelGGL(sort_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_cand, count, keys_in, by_tag);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, d_cand, d_sorted, (size_t)count, 0, 64, stream);
+  const unsigned end_bit = (key_bits > 0 && key_bits < 64) ? (unsigned)key_bits : 64u;
+  return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, d_cand, d_sorted, (size_t)count, 0, end_bit, stream);
 }
 
 // Bytes of scratch launch_select_reports needs: keep flags, plateau heads (marks, scanned), rocPRIM's own for the

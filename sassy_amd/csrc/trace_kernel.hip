@@ -342,6 +342,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
     const uint32_t* ssrc = reinterpret_cast<const uint32_t*>(sbuf);
     for (uint32_t x = 0; x < ndw; ++x) dstr[x] = ssrc[x];
     P.out[c] = r;
+    if (!ok && P.host_flags) __hip_atomic_fetch_or(P.host_flags, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (c < P.host_cap) {
       uint32_t* hstr = reinterpret_cast<uint32_t*>(P.host_str + (uint64_t)c * P.str_stride);
       for (uint32_t x = 0; x < ndw; ++x) hstr[x] = ssrc[x];

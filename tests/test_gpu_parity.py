@@ -2156,8 +2156,10 @@ def test_fused_filter_equals_classic_chain_and_oracle(sassy):
     pat = bytes(oracle.generate_dna(43, 0, 32))
     n = (1 << 21) + 333
     text = bytearray(oracle.generate_dna(42, 0, n).tobytes())
-    bounds = [0, 64 * 1000, 64 * 1001, 1 << 20, n]
+    bounds = [0, 64 * 1000, 64 * 1001, 64 * 5000, 64 * 9000, 1 << 20, n]
     for b in bounds[1:-1]:
+        if b in (64 * 5000, 64 * 9000):
+            continue
         for off in (-40, -3, 10):
             ins = mutate(rng, pat, rng.randrange(3))
             text[b + off:b + off + len(ins)] = ins
@@ -2165,6 +2167,11 @@ def test_fused_filter_equals_classic_chain_and_oracle(sassy):
         ins = mutate(rng, pat, rng.randrange(4))
         at = rng.randrange(0, n - 64)
         text[at:at + len(ins)] = ins
+    # matches that END exactly on a shard border (the border position belongs to the shard on its left), and one
+    # position to either side of it
+    text[64 * 5000 - 32:64 * 5000] = pat
+    text[64 * 9000 - 31:64 * 9000 + 1] = pat
+    text[64 * 9000 - 1000 - 33:64 * 9000 - 1000 - 1] = pat
     text = bytes(text[:n])
     buf = sassy.DeviceBuffer(n + 256)
     buf.upload(text)
@@ -2180,7 +2187,12 @@ def test_fused_filter_equals_classic_chain_and_oracle(sassy):
             assert r.conditional_index == -1 and r.exit_state in (0, 1)
             allm += r.matches
         assert_same(allm, want, "shards")
-    assert fused.stats()["fused"] == 1 or not can_fuse
+        assert s is classic or fused.stats()["fused"] == 1 or not can_fuse
+        allm = []
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            h = 0 if a == 0 else halo
+            allm += s.search_shard(pat, buf.ptr + a - h, h, b - a, a, n, 2, sassy.ALL_MINIMA).matches
+        assert_same(allm, oracle.search("dna", pat, text, 2, all_minima=True), "shards, search_all")
     t1 = fused.search_shard_begin(pat, buf.ptr, 0, n, 0, n, 3)
     t2 = fused.search_shard_begin(pat, buf.ptr, 0, n, 0, n, 2)
     assert_same(fused.search_finish(t2).matches, oracle.search("dna", pat, text, 2), "in flight k=2")
