@@ -25,6 +25,8 @@ from typing import List, Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "lib", "libsassy_hip.so")
+if os.environ.get("SASSY_HIP_LIBRARY"):  # A/B timing of two builds on one box (tools only)
+    _SO = os.environ["SASSY_HIP_LIBRARY"]
 
 ALL_MINIMA = 1
 WITHOUT_TRACE = 2

@@ -256,8 +256,6 @@ struct ScanLane {
   uint32_t table_q = 0, table_k = 0, table_r = 0;   // table_r: 0 = piece bit table, else the counting table's R
   bool table_rc = false;                            // the counting table also holds the Rc strand's q-grams
   uint32_t fuse_backoff = 0;                        // searches this lane still runs unfused after a fused one overflowed
-  const uint8_t* dirty_text = nullptr;              // the text on which the Iupac bit-plane filter last gave up (letters other than
-  uint64_t dirty_len = 0;                           //  A C G T in long runs): not tried again while searches stay on it
   double table_density = 0;
   // pinned host staging area: control block and the first kSpec reports of a scan are written into
   // it by the kernels themselves; one stream synchronisation makes them readable
@@ -998,18 +996,17 @@ int ScanJob::prepare() {
   const bool fuse_ok = !ext_bitmap && !ext_desc && rc_bitmap == nullptr && rev_n == 0 && S->fuse && !no_fuse &&
                        L.fuse_backoff == 0 && env_lin0 <= 0 && env_selfrank0 != 0 && do_trace && trace_wave_ok &&
                        texts.n == 0 && plan.nwords <= 8 && n_blocks < 0x7FFFFFFFull && !S->want_counters;
-  // Iupac searcher, pattern of plain A C G T, <= 4 pieces: the Dna bit-plane filter and chunk DP with a check of the
-  // text (filter_dna_kernel, CHECK) -- as the fused launch only, on a whole text (a shard's halo in front of the first
-  // owned block belongs to no lane's checked range), and not on a text that sent the last such search to the classic
-  // chain (it holds other letters).
+  // Iupac searcher, pattern of plain A C G T, <= 4 pieces: the Dna bit-plane filter with a check of the text
+  // (filter_dna_kernel, CHECK) -- as the fused launch only.  Where the text holds other letters (N runs, ambiguity codes,
+  // anything) the lane that owns the block queues the columns a match touching them can end in, like a piece
+  // occurrence, and the chunk DP of such a launch builds the Iupac profile's masks: exact on any text.
   static const int env_iupac_planes = getenv("SASSY_HIP_IUPAC_PLANES") ? atoi(getenv("SASSY_HIP_IUPAC_PLANES")) : 1;
   bool plain_pattern = S->profile == PROFILE_IUPAC && env_iupac_planes != 0 && !overhang;
   for (uint32_t j = 0; plain_pattern && j < plan.m; ++j) {
     const uint8_t u = pat[j] & 0xDFu;
     plain_pattern = u == 'A' || u == 'C' || u == 'G' || u == 'T';
   }
-  const bool iupac_planes = plain_pattern && fuse_ok && q >= 6 && q <= 12 && pieces <= 4 && plan.nslots <= 4 &&
-                            sh.halo_len == 0 && !(L.dirty_text == sh.d_text && L.dirty_len == sh.text_len);
+  const bool iupac_planes = plain_pattern && fuse_ok && q >= 6 && q <= 12 && pieces <= 4 && plan.nslots <= 4;
   const bool can_planes = q > 0 && pieces <= 8 && (S->profile == PROFILE_DNA || iupac_planes);
   // q-gram counting (count_filter.hip): per (Q, R) variant the threshold t = m + 1 - (k+1) Q, the
   // window W, and how often a window of random text reaches t by chance (the pattern's q-grams,
@@ -1346,8 +1343,11 @@ int ScanJob::prepare() {
       F.fused = 1u | (env_probe == 1 ? 2u : env_probe == 2 ? 6u : 0u);
       F.dp_first_owned = first_owned;
       static const int env_qcap = getenv("SASSY_HIP_FUSED_QCAP") ? atoi(getenv("SASSY_HIP_FUSED_QCAP")) : 0;
-      F.fuse_queue_cap = env_qcap > 0 ? (uint32_t)env_qcap : 160u;  // chunks per wave (config 2: ~22 expected); 4 workgroups per CU still fit the LDS
-      F.lds_per_wave += F.fuse_queue_cap * 8u + 16u;
+      // chunks per wave between two chunk-DP passes: a wave runs a pass when more than cap - 128 are queued (a full
+      // batch of 64 lanes), so the queue never overflows; + the count (16 bytes) + one word per lane for the text check;
+      // 4 workgroups per CU still fit the LDS: 4 x 4 x (8192 + 1536 + 16 + 256) = 160 000 bytes
+      F.fuse_queue_cap = env_qcap > 128 ? (uint32_t)env_qcap : 192u;
+      F.lds_per_wave += F.fuse_queue_cap * 8u + 16u + 256u;
     }
     {
       // Searches in flight on several lanes: the filter's long-lived workgroups would fill every CU (4 waves
@@ -1574,14 +1574,17 @@ int ScanJob::enqueue(int attempt) {
 // classic chain, which resolves all of that.
 int ScanJob::finish(ScanOut& out) {
   bool redo = false;
+  const sassy_hip_Stats before = S->stats;
   if (int rc = finish_once(out, redo)) return rc;
   if (!redo) return 0;
   no_fuse = true;
-  L.fuse_backoff = 16;  // and so do the lane's next searches: a text that overflows the queue once does it again
-  if (S->profile == PROFILE_IUPAC) {  // (the bit-plane filter with its text check: not again on this text)
-    L.dirty_text = sh.d_text;
-    L.dirty_len = sh.text_len;
-  }
+  L.fuse_backoff = 16;  // and so do the lane's next searches: what sends one search to the classic chain sends the next
+  // (only the attempt that produces the result counts: kernel times, bytes and launches of the abandoned one are dropped;
+  // the host's waiting stays)
+  const double waited = S->stats.host_wait_ms - before.host_wait_ms, queued = S->stats.host_enqueue_ms - before.host_enqueue_ms;
+  S->stats = before;
+  S->stats.host_wait_ms += waited;
+  S->stats.host_enqueue_ms += queued;
   if (int rc = prepare()) return rc;
   if (!empty)
     if (int rc = enqueue(0)) return rc;
@@ -1852,7 +1855,8 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
     for (size_t i = 0; i < out.cands.size(); ++i) {
       if (out.cands[i].pos < fused_min_pos) continue;
       if (w > 0 && out.cands[i].pos == out.cands[w - 1].pos) {
-        if (out.cands[i].flags & kCandCond) out.cands[w - 1].flags |= kCandCond;
+        // (a copy without kCandCond saw what settles the plateau state: the report is certain whatever the others say)
+        if (!(out.cands[i].flags & kCandCond)) out.cands[w - 1].flags &= ~kCandCond;
         continue;
       }
       if (w != i) {

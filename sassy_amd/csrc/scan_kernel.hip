@@ -156,6 +156,9 @@ __device__ __forceinline__ rep4 make_rep4(uint32_t x, uint32_t y, uint32_t z, ui
 __device__ __noinline__ rep4 scan_block(const EmitCtx P, uint64_t vp, uint64_t vm, int ds, uint64_t b, bool owned,
                                          bool last_warm, int64_t x0, uint32_t state) {
   bool dec = (state & kStDec) != 0, amb = (state & kStAmb) != 0;
+  // (window chunks: bits 8 .. 23 of `state` = how many exact columns behind x0 are not this chunk's to report -- they
+  // are there to settle the plateau state, their end positions are another window's)
+  const int64_t r0 = x0 + (int64_t)((state >> 8) & 0xFFFFu);
   const int k = (int)P.k;
   const bool all = (P.flags & kScanAllMinima) != 0;
   uint64_t rep = 0;
@@ -182,6 +185,19 @@ __device__ __noinline__ rep4 scan_block(const EmitCtx P, uint64_t vp, uint64_t v
   if (all && owned && cost <= k && base == P.text_begin && P.global_offset == 0 && (P.flags & kScanTextStart))
     report(0, false);
   bool determined = (x0 < 0);
+  // A flat block that lies whole inside the text and behind x0 -- the inside of a run of N, of poly-A against poly-A:
+  // one plateau from its first column to its last.  Nothing rises, nothing falls: no report under the report rule, `dec`
+  // stays; the plateau state is settled when its cost is 0 or > k (as in the loop below).  Such blocks come by the
+  // thousand, one after the other in a lane, and the 64-step walk was twice the cost of their DP rows.
+  if (!all && (vp | vm) == 0 && !ov && base + 64 <= max_pos && (int64_t)base >= x0 &&
+      !((P.flags & kScanTextEnd) && base + 64 == max_pos)) {
+    if (cost > k || cost == 0) {
+      if (owned) amb = false;
+      else determined = true;
+    }
+    if (last_warm) amb = !determined;
+    return make_rep4(0u, 0u, (dec ? kStDec : 0u) | (amb ? kStAmb : 0u), 0u);
+  }
   for (int bit = 1; bit <= 64; ++bit) {
     const uint64_t pos = base + (uint64_t)bit;
     if (pos > max_pos) break;
@@ -192,10 +208,10 @@ __device__ __noinline__ rep4 scan_block(const EmitCtx P, uint64_t vp, uint64_t v
     // whole; a window chunk warms up inside its own first block(s): nothing is reported or concluded there)
     const bool exact = (int64_t)pos > x0;
     if (all) {
-      if (owned && exact && cost <= k) report((uint32_t)bit, false);
+      if (owned && (int64_t)pos > r0 && cost <= k) report((uint32_t)bit, false);
     } else {
       const bool rising = cost > prev_cost, falling = cost < prev_cost;
-      if (dec && rising && prev_cost <= k && owned && (int64_t)prev_pos > x0) report((uint32_t)bit - 1u, amb);
+      if (dec && rising && prev_cost <= k && owned && (int64_t)prev_pos > r0) report((uint32_t)bit - 1u, amb);
       dec = falling || (dec && !rising);
       // An exact cell of cost 0 settles the plateau state as well: costs are >= 0, so the last change in front of it
       // was no increase -- `dec` is true there in the one-pass definition whatever lies left of this chunk (long
@@ -211,7 +227,7 @@ __device__ __noinline__ rep4 scan_block(const EmitCtx P, uint64_t vp, uint64_t v
   }
   if (!all) {
     if (last_warm) amb = !determined;
-    if (owned && (P.flags & kScanTextEnd) && prev_pos == max_pos && dec && prev_cost <= k && (int64_t)prev_pos > x0)
+    if (owned && (P.flags & kScanTextEnd) && prev_pos == max_pos && dec && prev_cost <= k && (int64_t)prev_pos > r0)
       report((uint32_t)(prev_pos - base), amb);
   }
   return make_rep4((uint32_t)rep, (uint32_t)(rep >> 32), (dec ? kStDec : 0u) | (amb ? kStAmb : 0u) | (n_cond << 8) | rep_base, 0u);
@@ -1496,6 +1512,8 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
   const bool at_text_start = whole_text || (blk0 == 0 && shift == 0 && (P.flags & kScanTextStart));
   const bool exact_start = clear_before || at_text_start;
   const int64_t x0 = exact_start ? -1 : (int64_t)(blk0 * 64 + shift + P.m + P.k);
+  // (windows: the chunk reports the end positions behind column start + (pad_ >> 8), scan_block's r0)
+  const uint32_t rskip = WIN ? (uint32_t)std::max<int64_t>(0, (int64_t)(blk0 * 64 + shift + (d.pad_ >> 8)) - x0) & 0xFFFFu : 0u;
   // (windows may begin in the halo: the host drops the end positions in front of the first owned block)
   const uint32_t my_iters = has_chunk ? (uint32_t)(own_hi - blk0) : 0u;
 
@@ -1595,7 +1613,7 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
         if (P.counters) cnt_blocks += 1;
         if (ran_through && row_maybe_live(ds, V, k)) {
           if (P.counters) cnt_live += 1;
-          rr = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
+          rr = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st | (rskip << 8));
           st = rr.z & (kStDec | kStAmb);
         } else if (!WIN || (int64_t)((b + 1) * 64 + shift) > x0) {
           st = kStDec;  // no cell <= k in the block (a window's block that ends inside its warm-up says nothing)
@@ -1676,26 +1694,36 @@ __device__ __noinline__ uint2 piece_end_cols(uint64_t bits, uint64_t b, int64_t 
 }
 // The run of end positions a lane is collecting (columns relative to col_base): x = first (kRunNone: none),
 // y = last, z = one past the last column the lane's queued windows cover, w = first column of the last queued one
-// (bit 31 of w: kRunPressure -- the wave's queue is filling up, see below).
+// (bit 31 of w: kRunPressure -- the wave's queue is filling up; bit 30: kRunCont, see below).
 constexpr uint32_t kRunNone = 0xFFFFFFFFu;
 constexpr uint32_t kRunPressure = 0x80000000u;
 constexpr uint32_t kRunMergeGap = 32;  // runs this close share a window
 // Queues the window chunk for the columns [x, y]: the DP starts fresh at column `start` and is exact from start + mk on
 // (mk = m + k), so the window [start, y] with start <= x - 1 - mk reports every end position of the run, plateau
 // state included (unless the plateau reaches back beyond x - 1 without an exact cell of cost 0: such a report is
-// conditional, scan_block).  Whole 64-column blocks ending at y: {first block, blocks << 6 | byte shift}.
+// conditional, scan_block).  Whole 64-column blocks ending at y: {first block, skip << 14 | blocks << 6 | byte shift},
+// skip = x - 2 - start: the columns whose end positions the window does not report (warm-up, margin, rounding).
 // A long run -- a run of N under Iupac, poly-A against poly-A, a microsatellite -- is no work for one lane: it leaves
 // the lane in windows of kFuseSplitBlocks blocks of end positions each, as it grows (fuse_add_range), every window
 // with its own warm-up; neighbouring windows share up to 63 exact columns, and what both report is dropped where the
 // reports are ranked.
-constexpr uint32_t kFuseSplitBlocks = 32;
-constexpr uint32_t kFuseMaxBlocks = kFuseSplitBlocks + 16;  // (no window is longer: split length + the widest single range + warm-up)
+constexpr uint32_t kFuseSplitBlocks = 8;
+// A window that continues a run -- behind a split, or at the very beginning of the lane's range, where the run may be
+// the neighbour lane's going on -- begins inside cells <= k: how its plateau was entered lies in front of it.  It gets
+// kFuseMargin more columns on the left: whatever rises, falls, reaches 0 or exceeds k in them settles the state before
+// the window's own columns begin (their reports are the previous window's: copies, dropped).  What stays open -- a
+// plateau of one cost > 0 that is flat for more than the margin -- is a conditional report, the classic chain's.
+constexpr uint32_t kFuseMargin = 64;
+constexpr uint32_t kFuseMaxBlocks = kFuseSplitBlocks + 16;  // (no window is longer: split length + the widest single range + warm-up + margin)
+constexpr uint32_t kRunCont = 0x40000000u;  // (bit 30 of w) the pending run continues a window that was split off
 // press_at: a lane whose entry gets this index or a later one raises kRunPressure -- the wave then runs the chunk DP
 // over its queue at the next block pair instead of at the end of its text range (the queue never overflows: between
 // two looks at the flag every lane adds at most two entries).
 __device__ __forceinline__ rep4 fuse_emit(uint2* queue, uint32_t* qcount, uint32_t* fuse_word, uint32_t cap, uint32_t press_at,
                                           uint32_t mk, int64_t col_base, rep4 st, uint32_t x, uint32_t y) {
-  uint32_t nv = (y - x + mk + 2u + 63u) / 64u;
+  // (65536: the lane's first own column, see col_base)
+  const uint32_t margin = ((st.w & kRunCont) || x < 65536u + 2u * 64u) ? kFuseMargin : 0u;
+  uint32_t nv = (y - x + margin + mk + 2u + 63u) / 64u;
   if (nv > kFuseMaxBlocks) atomicOr(fuse_word, kFuseOverflow);  // (cannot happen: runs are split before they get there)
   const int64_t end = col_base + (int64_t)y;
   int64_t start = end - 64 * (int64_t)nv;
@@ -1703,11 +1731,17 @@ __device__ __forceinline__ rep4 fuse_emit(uint2* queue, uint32_t* qcount, uint32
     start = 0;
     nv = (uint32_t)((end + 63) / 64);
   }
+  // the window reports the end positions from x on: the exact columns in front of them (the margin, and what the
+  // rounding to whole blocks adds) only settle the plateau state
+  // (x - 2: the end position x - 1 is decided when column x is seen -- behind a split it is the last one of the window
+  // in front, which could not decide it)
+  const int64_t skip64 = (col_base + (int64_t)x - 2) - start;  // (>= mk - 1, or the window begins the buffer)
+  const uint32_t skip = skip64 > 0 ? (uint32_t)skip64 : 0u;
   const uint32_t idx = atomicAdd(qcount, 1u);
-  if (idx < cap) queue[idx] = make_uint2((uint32_t)(start >> 6), (nv << 6) | (uint32_t)(start & 63));
+  if (idx < cap) queue[idx] = make_uint2((uint32_t)(start >> 6), (skip << 14) | (nv << 6) | (uint32_t)(start & 63));
   else atomicOr(fuse_word, kFuseOverflow);
   st.z = y + 1u;
-  st.w = x | ((idx >= press_at || (st.w & kRunPressure)) ? kRunPressure : 0u);
+  st.w = x | ((idx >= press_at || (st.w & kRunPressure)) ? kRunPressure : 0u);  // (kRunCont: set by the caller that splits)
   return st;
 }
 // adds the columns [lo, hi] (lo = kRunNone: nothing to add, only queue the pending run)
@@ -1721,7 +1755,7 @@ __device__ __noinline__ rep4 fuse_add_range(uint2* queue, uint32_t* qcount, uint
     return st;
   }
   if (lo < first_col) lo = first_col;  // the halo's end positions are not ours
-  if (lo < (st.w & ~kRunPressure)) {
+  if (lo < (st.w & ~(kRunPressure | kRunCont))) {
     // columns in front of a window that is already queued (possible only when an occurrence's marks reach further
     // than a block: long patterns): the classic chain takes the search
     atomicOr(fuse_word, kFuseOverflow);
@@ -1736,6 +1770,7 @@ __device__ __noinline__ rep4 fuse_add_range(uint2* queue, uint32_t* qcount, uint
       const uint32_t e = st.x + 64u * kFuseSplitBlocks - 1u;
       st = fuse_emit(queue, qcount, fuse_word, cap, press_at, mk, col_base, st, st.x, e);
       st.x = e + 1u;
+      st.w |= kRunCont;
     }
     return st;
   }
@@ -1790,6 +1825,17 @@ __device__ __forceinline__ bool other_letters16(const uint4 v) {
   }
   return diff != 0u;
 }
+// (CHECK, rare path) the staging lane found other letters in the 16-byte pieces `dm` (bit i = staging instruction i):
+// it tells the lanes that own those blocks -- dirty[owner] |= 1 << (piece of the owner's staged pair, 0 .. 7).
+__device__ __noinline__ void note_dirty_pieces(uint32_t* dirty, uint32_t lane, uint32_t dm) {
+  while (dm) {
+    const uint32_t i = (uint32_t)__ffs((int)dm) - 1u;
+    dm &= dm - 1u;
+    const uint32_t owner = i * 8u + lane / 8u;
+    const uint32_t j = (lane % 8u) ^ ((owner >> 1) & 7u);  // the piece's place in the owner's 128 bytes
+    atomicOr(&dirty[owner], 1u << j);
+  }
+}
 
 template <int Q, int NPG, bool FUSED, bool CHECK = false>
 // (CHECK: four waves per SIMD are asked for -- left to itself the compiler settles for three, 0.59 instead of 0.52 ms)
@@ -1805,19 +1851,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
   constexpr uint32_t kTile = 64u * kRowBytes;
   typedef const ScanParams __attribute__((address_space(4)))* kparams_ptr;
 
-  // (FUSED: everything is derived from a pointer to the launch parameters that is opaque to the optimiser, so that
-  // nothing of the chunk DP behind the streaming loop is hoisted in front of it and held there.)
-  constexpr uint32_t units = 1u;
-  for (uint32_t unit = 0; unit < units; ++unit) {
+  // FUSED: the wave streams its text range in SEGMENTS.  A segment ends when the range is done or when the wave's chunk
+  // queue is filling up (kRunPressure); then the wave runs the chunk DP over what it queued -- the DP's masks and carries
+  // take the place of the text tile -- and streams on.  What a segment needs from the one before: the next iteration,
+  // the previous block's plane halves, the run the lane is collecting.  Everything else is derived again, inside the
+  // loop, from a pointer to the launch parameters that is opaque to the optimiser, so that nothing of the chunk DP is
+  // hoisted in front of the streaming loop and held there.
+  // (The per-lane part of it waits in LDS while the DP runs -- six words per lane in the 2 KiB of the tile the DP's
+  // masks and carries, at most eight pattern words, leave free -- and the lane index comes from v_mbcnt, the wave index
+  // from a scalar: kept in vector registers across the DP they were spilled to scratch memory, and a kernel that owns a
+  // scratch segment starts its waves slower.)
+  constexpr uint32_t kSegState = 6144u;            // tile offset of the saved state: [6][64] u32
+  uint32_t seg_it = 0;                             // wave-uniform, even
+  bool first_segment = true;
+  const uint32_t wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (;;) {
   kparams_ptr Pk = (kparams_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-  uint32_t tid0 = threadIdx.x;
-  if constexpr (FUSED) asm volatile("" : "+s"(Pk), "+v"(tid0));
-  const uint32_t lane = tid0 & 63u;
-  const uint32_t wave = tid0 >> 6;
+  uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  uint32_t wave = __builtin_amdgcn_readfirstlane(wave_s);
+  if constexpr (FUSED) asm volatile("" : "+s"(Pk), "+v"(lane), "+s"(wave));
   unsigned char* tile = smem + (size_t)wave * Pk->lds_per_wave;
-  // FUSED: the wave's chunk queue behind the tile: fuse_queue_cap entries {first block, blocks << 6 | byte shift}, then the count
+  // FUSED: the wave's chunk queue behind the tile: fuse_queue_cap entries {first block, blocks << 6 | byte shift}, then
+  // the count (16 bytes), then (CHECK) one word per lane: the dirty pieces of the block pair it owns in the tile
   uint2* queue = reinterpret_cast<uint2*>(tile + kTile);
   uint32_t* qcount = reinterpret_cast<uint32_t*>(tile + kTile + (size_t)Pk->fuse_queue_cap * 8u);
+  uint32_t* dirty = qcount + 4;
   const uint64_t group = (uint64_t)blockIdx.x + Pk->group_offset;
   const uint32_t bpl = Pk->bpl;
   const uint64_t first_owned = Pk->first_owned_block;
@@ -1836,20 +1894,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
   uint32_t u_bpl = bpl;
   uint64_t u_first = first_owned + group * 256ull * bpl;
   const uint32_t lc0 = wave * kWave;  // the wave's first lane chunk inside the unit
-  if (u_first + (uint64_t)lc0 * u_bpl >= Pk->n_blocks) break;  // wave-uniform: nothing left for this wave
+  if (u_first + (uint64_t)lc0 * u_bpl >= Pk->n_blocks) break;  // wave-uniform: nothing for this wave
   unsigned long long probe_t0 = 0;
   if constexpr (FUSED) {
-    if (lane == 0) *qcount = 0;
-    if (Pk->fused & 2u) probe_t0 = wall_clock64();
-  }
-  bool other_seen = false;  // (CHECK) this lane staged a byte that is not a plain base
-  if constexpr (CHECK) {
-    if (blockIdx.x == 0 && tid0 == 0) {  // the text's last, partial 16-byte piece (the staging steps check whole pieces)
-      for (uint64_t q2 = Pk->text_len & ~15ull; q2 < Pk->text_len; ++q2) {
-        const uint32_t u = Pk->text[q2] & 0xDFu;
-        other_seen |= !(u == 'A' || u == 'C' || u == 'G' || u == 'T');
-      }
+    if (first_segment) {
+      if (lane == 0) *qcount = 0;
+      if constexpr (CHECK) dirty[lane] = 0u;
     }
+    if (Pk->fused & 2u) probe_t0 = wall_clock64();
   }
   const uint32_t n_iter = Pk->n_iter - bpl + u_bpl;
   const uint64_t own_lo = u_first + (uint64_t)(lc0 + lane) * u_bpl;
@@ -1873,25 +1925,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
   const bool interior = wave_last * 64 <= Pk->text_len;
   uint32_t prev0 = 0, prev1 = 0;  // high halves of the previous block's planes
 
-  // FUSED: the run of match-end blocks this lane is collecting, and the end of the last one it queued
-  uint4 run = make_uint4(kRunNone, 0u, 0u, 0u);  // (columns, see fuse_add_range)
+  // FUSED: the run of match-end columns this lane is collecting, and the end of the last window it queued
+  rep4 run = make_rep4(kRunNone, 0u, 0u, 0u);
+  if constexpr (FUSED) {
+    if (!first_segment) {
+      const uint32_t* sv = reinterpret_cast<const uint32_t*>(tile + kSegState) + lane;
+      prev0 = sv[0]; prev1 = sv[64];
+      run = make_rep4(sv[128], sv[192], sv[256], sv[320]);
+    }
+  }
+  const uint32_t press_at = Pk->fuse_queue_cap > 128u ? Pk->fuse_queue_cap - 128u : 0u;
 
   // software pipeline: the loads of the next staging step are in flight while this one is processed
   uint4 nxt[kStageInstr];
 #pragma unroll
   for (int i = 0; i < kStageInstr; ++i) {
     nxt[i] = make_uint4(0u, 0u, 0u, 0u);
-    if (interior) nxt[i] = stream_load16<SASSY_NT_DNA>(text_base + soff[i]);
+    if (interior && seg_it < n_iter) nxt[i] = stream_load16<SASSY_NT_DNA>(text_base + (uint64_t)seg_it * 64 + soff[i]);
   }
+  uint32_t dmask = 0;  // (CHECK) dirty pieces of the lane's staged pair
 
-  for (uint32_t it = 0; it < n_iter; ++it) {
+  uint32_t it = seg_it;
+  for (; it < n_iter; ++it) {
     const uint32_t sub = it & 1u;
     if (sub == 0) {
+      uint32_t dm = 0;  // (CHECK) the pieces this lane staged that hold other letters, bit i = instruction i
       if (interior) {
 #pragma unroll
         for (int i = 0; i < kStageInstr; ++i) {
           *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = nxt[i];
-          if constexpr (CHECK) other_seen |= other_letters16(nxt[i]);
+          if constexpr (CHECK) dm |= other_letters16(nxt[i]) ? (1u << i) : 0u;
         }
         // (the next loads go into the registers the check has just read: scheduled in front of it they would need
         // 32 more)
@@ -1909,9 +1972,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
           if (off + 16 <= Pk->text_len) v = *reinterpret_cast<const uint4*>(Pk->text + off);
           else v = load_tail16(Pk->text, off, Pk->text_len);
           *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
-          // (the one piece that straddles the end of the text is checked by the launch's first lane, below)
-          if constexpr (CHECK) other_seen |= off + 16 <= Pk->text_len && other_letters16(v);
+          // (bytes behind the end of the text read as 'X': other letters where no match can end)
+          if constexpr (CHECK) dm |= other_letters16(v) ? (1u << i) : 0u;
         }
+      }
+      if constexpr (CHECK) {
+        // Other letters are handled where they lie: the owner of the block treats every such 16-byte piece like a piece
+        // occurrence -- whatever match touches it ends within m + k columns behind it -- and the chunk DP of a CHECK
+        // launch is the Iupac one.  (One word per lane in LDS; same wave: the LDS operations complete in order.)
+        if (dm != 0) note_dirty_pieces(dirty, lane, dm);
+        dmask = dirty[lane];
+        if (dmask != 0) dirty[lane] = 0u;
       }
     }
     uint2 t0, t1;
@@ -1965,6 +2036,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
     uint32_t hit = 0;
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) hit |= al[pp] | ah[pp];
+    if constexpr (CHECK) hit |= (dmask >> (4u * sub)) & 15u;  // (this block's dirty pieces)
     const uint64_t b = blk0 + it;
     const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
     if (evaluate && hit != 0) {
@@ -1979,8 +2051,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
             hi = max(hi, r.y);
           }
         }
+        if constexpr (CHECK) {
+          const uint32_t dp = (dmask >> (4u * sub)) & 15u;
+          if (dp != 0) {
+            // a match that touches text byte t ends in [t + 1, t + m + k] (+ 1 column: the report rule decides about a
+            // position when it sees the next one); t = the pieces' first .. last byte
+            const int64_t t_first = (int64_t)(b * 64) + 16 * (__ffs((int)dp) - 1);
+            const int64_t t_last = (int64_t)(b * 64) + 16 * (31 - __clz((int)dp)) + 15;
+            int64_t c_hi = t_last + (int64_t)Pk->m + (int64_t)Pk->k + 1;
+            if (c_hi > (int64_t)(Pk->n_blocks * 64)) c_hi = (int64_t)(Pk->n_blocks * 64);
+            lo = min(lo, (uint32_t)(t_first + 1 - col_base));
+            hi = max(hi, (uint32_t)(c_hi - col_base));
+          }
+        }
         const int64_t fc = (int64_t)(Pk->dp_first_owned * 64) - col_base;
-        run = fuse_add_range(queue, qcount, Pk->cand_count + kCtlFuseWord, Pk->fuse_queue_cap, Pk->m + Pk->k, col_base,
+        run = fuse_add_range(queue, qcount, Pk->cand_count + kCtlFuseWord, Pk->fuse_queue_cap, press_at, Pk->m + Pk->k, col_base,
                              fc > 0 ? (uint32_t)fc : 0u, run, lo, hi);
       } else {
 #pragma unroll
@@ -1995,30 +2080,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
         }
       }
     }
-  }
-
-  if constexpr (CHECK) {
-    if (__any(other_seen)) {  // not a plain text: the Iupac profile's own chain takes the search
-      if (lane == 0) atomicOr(&Pk->cand_count[kCtlFuseWord], kFuseOverflow);
-      continue;
+    if constexpr (FUSED) {
+      // the queue is filling up: the block pair is done with the tile -- the chunk DP may have it
+      if (sub == 1u && __any((run.w & kRunPressure) != 0u)) { ++it; break; }
     }
   }
+  if constexpr (!FUSED) break;
+
   if constexpr (FUSED) {
-    if (run.x != kRunNone)
-      run = fuse_add_range(queue, qcount, Pk->cand_count + kCtlFuseWord, Pk->fuse_queue_cap, Pk->m + Pk->k, col_base, 0u, run,
-                           kRunNone, 0u);
     // (one wave: its LDS operations complete in order; the fence keeps the compiler from moving the read up)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const uint32_t nq = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(qcount));
+    uint32_t nq = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(qcount));
+    const bool streamed = it >= n_iter;
+    bool last = false;
+    if (streamed && nq + 64u <= Pk->fuse_queue_cap) {  // the runs the lanes still hold (one entry each at most), then the last pass
+      if (run.x != kRunNone)
+        run = fuse_add_range(queue, qcount, Pk->cand_count + kCtlFuseWord, Pk->fuse_queue_cap, 0xFFFFFFFFu, Pk->m + Pk->k, col_base, 0u, run,
+                             kRunNone, 0u);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      nq = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile uint32_t*>(qcount));
+      last = true;
+    }
+    // what the next segment starts from
+    seg_it = it;
+    first_segment = false;
+    if (!last) {
+      uint32_t* sv = reinterpret_cast<uint32_t*>(tile + kSegState) + lane;
+      sv[0] = prev0; sv[64] = prev1;
+      sv[128] = run.x; sv[192] = run.y; sv[256] = run.z; sv[320] = run.w & ~kRunPressure;
+    }
     unsigned long long probe_t1 = 0;
     if (Pk->fused & 2u) probe_t1 = wall_clock64();  // SASSY_HIP_FUSED_PROBE: 100 MHz ticks spent streaming / in the chunk DP
-    if (Pk->fused & 4u) continue;                   // (probe: no chunk DP at all -- timing only, no reports)
-    if (nq == 0) continue;
-    if (nq > Pk->fuse_queue_cap) {  // more chunks than the queue holds: the classic chain takes this search
+    if (nq > Pk->fuse_queue_cap) {  // (cannot happen -- see press_at; the classic chain would take the search)
       if (lane == 0) atomicOr(&Pk->cand_count[kCtlFuseWord], kFuseOverflow);
-      continue;
+      nq = 0;
     }
+    if ((Pk->fused & 4u) == 0u && nq != 0) {  // (probe bit 4: no chunk DP at all -- timing only, no reports)
     // What the DP needs of the launch parameters is read HERE, through a pointer the optimiser cannot see
     // through: read from P they would be loaded at the top of the kernel and held (or spilled to VGPR lanes and
     // read back inside the streaming loop) for the whole life of the wave.
@@ -2049,27 +2148,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
     L.chunk_state = nullptr;
     L.texts_start = nullptr;
     L.texts_len = nullptr;
+    if constexpr (CHECK) {  // (the Iupac masks of a plain pattern: four slots, A C T G)
+      L.nslots = 4;
+#pragma unroll
+      for (int sl = 0; sl < 4; ++sl) L.slot_val[sl] = kp->slot_val[sl];
+    }
     // (the same for everything the DP derives from the thread index -- LDS addresses per lane, word, slot:
     // computed from an opaque copy, they cannot be hoisted in front of the streaming loop and held in VGPRs there)
-    uint32_t tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const uint32_t dlane = tid & 63u;
-    unsigned char* dtile = smem + (size_t)(tid >> 6) * kp->lds_per_wave;
+    uint32_t dlane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    uint32_t dwave = __builtin_amdgcn_readfirstlane(wave_s);
+    asm volatile("" : "+v"(dlane), "+s"(dwave));
+    unsigned char* dtile = smem + (size_t)dwave * kp->lds_per_wave;
     const uint2* dqueue = reinterpret_cast<const uint2*>(dtile + kTile);
-    if (dlane == 0) atomicAdd(&L.cand_count[1], nq);  // statistics: chunks
+    if (dlane == 0) atomicAdd(&L.cand_count[1], last ? nq : (nq & ~63u));  // statistics: chunks
     // the DP's LDS -- slot masks, per-row carries -- takes the place of the text tile
     unsigned char* mask_bytes = dtile;
     uint32_t* carry = reinterpret_cast<uint32_t*>(dtile + 4 * 512);
-    for (uint32_t base = 0; base < nq; base += 64u) {
-      const bool has = base + dlane < nq;
+    // between segments only full batches of 64 chunks run; what is left over waits for the next pass
+    const uint32_t n_run = last ? nq : (nq & ~63u);
+    for (uint32_t base = 0; base < n_run; base += 64u) {
+      const bool has = base + dlane < n_run;
       uint2 e = make_uint2(0u, 0u);
       if (has) e = dqueue[base + dlane];
       ChunkDesc dsc;
       dsc.own_lo = e.x;
-      dsc.own_hi = e.x + (e.y >> 6);
+      dsc.own_hi = e.x + ((e.y >> 6) & 0xFFu);
       dsc.flags = kDescWindow;
-      dsc.pad_ = e.y & 63u;
-      list_lanes<PROFILE_DNA, 4, true>(L, mask_bytes, carry, dlane, has, dsc, kNoStateSlot);
+      dsc.pad_ = (e.y & 63u) | ((e.y >> 14) << 8);  // byte shift | columns not to report << 8
+      list_lanes<CHECK ? (int)PROFILE_IUPAC : (int)PROFILE_DNA, 4, true>(L, mask_bytes, carry, dlane, has, dsc, kNoStateSlot);
     }
     if ((kp->fused & 2u) && dlane == 0) {
       unsigned long long* pc = reinterpret_cast<unsigned long long*>(L.cand_count + 4);  // the control block's counters
@@ -2078,11 +2184,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
       atomicAdd(&pc[2], (unsigned long long)nq);
       atomicAdd(&pc[3], 1ull);
     }
-    // the tile is the next unit's again: the DP's LDS traffic is complete before its first staging store (one wave,
-    // in-order LDS); the fence keeps the compiler from reordering across it
+    }
+    // the queue keeps what did not fill a batch; the tile is the next segment's: the DP's LDS traffic is complete before
+    // its first staging store (one wave, in-order LDS); the fence keeps the compiler from reordering across it
+    {
+      const uint32_t left = (last || (Pk->fused & 4u)) ? 0u : (nq & 63u);
+      uint2 keep_e = make_uint2(0u, 0u);
+      if (lane < left) keep_e = queue[(nq & ~63u) + lane];
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (lane < left) queue[lane] = keep_e;
+      if (lane == 0) *qcount = left;
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (last) break;
   }
-  }  // units
+  }  // segments
 }
 
 // ====================================================================== K1-list, few long chunks

@@ -461,6 +461,15 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
       // rank = reports with a smaller end position + (dedup) earlier copies of this very report: copies of one
       // position then fill consecutive slots, and every copy but the first is a kCandDrop record the host skips
       uint32_t r = 0;
+      // (dedup) a conditional report is certain after all when a copy of it -- another window's view of the same end
+      // position -- is not conditional: that window saw what settles the plateau state
+      const bool want_twin = P.dedup && (cd.flags & kCandCond) != 0;  // wave-uniform, rare
+      bool twin_uncond = false;
+      if (want_twin)
+        for (uint32_t v = lane; v < count; v += 64) {
+          const Candidate o = P.unsorted[v];
+          twin_uncond |= o.pos == cd.pos && v != u && !(o.flags & kCandCond);
+        }
       if (pos_in_lds) {
         for (uint32_t v = lane; v < count; v += 64) {
           const unsigned long long p0 = lpos[v];
@@ -491,6 +500,7 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
       c = (r & 0xFFFFu) + twins;
       const bool drop = twins != 0 || (P.dedup && cd.pos < P.min_pos);
       if (drop) cd.flags |= kCandDrop;
+      if (want_twin && __any(twin_uncond)) cd.flags &= ~kCandCond;
       if (lane == 0) {
         const_cast<Candidate*>(P.cand)[c] = cd;
         if (c < P.host_cap && P.host_cand) P.host_cand[c] = cd;

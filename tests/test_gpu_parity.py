@@ -2200,11 +2200,11 @@ def test_fused_filter_equals_classic_chain_and_oracle(sassy):
     buf.free()
 
 
-def test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_plain_text_only(sassy):
+def test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_any_text(sassy):
     """An Iupac searcher whose pattern holds A C G T only runs the fused Dna launch with a check of the text
-    (filter_dna_kernel<.., CHECK>): exact while the text is plain (either case); ONE other letter anywhere -- inside a
-    match, where N matches every base, in the text's last partial 16-byte piece, in its first block -- sends the
-    search to the Iupac profile's own chain, and the searcher does not try again on that text."""
+    (filter_dna_kernel<.., CHECK>) on ANY text: other letters -- inside a match, where N matches every base, in the
+    text's last partial 16-byte piece, in its first block, whole runs of N -- are handled where they lie (the owning lane
+    queues the columns a match touching them can end in, the chunk DP builds the Iupac masks): same launch, exact."""
     rng = random.Random(123)
     can_fuse = _env_allows_fusing() and os.environ.get("SASSY_HIP_IUPAC_PLANES", "1") != "0"
     pat = rand_seq(rng, 32)
@@ -2228,6 +2228,13 @@ def test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_plain_text_only(sa
         variants["a non-letter as the first byte"] = bytes(t)
         t = bytearray(base); t[n - 40] = ord("U")
         variants["U near the end"] = bytes(t)
+        t = bytearray(base)
+        for a, ln in ((n // 5, 3000), (n // 5 + 3100, 31), (n // 3, 29), (n - 200, 200), (0, 50)):
+            if a + ln <= n:
+                t[a:a + ln] = b"N" * ln
+        for i in range(0, min(n, 50_000), 211):
+            t[i] = ord("RYKMSWBDHVNX-"[i % 13])
+        variants["runs of N (one longer than two windows), ambiguity letters every 211 bytes"] = bytes(t)
         for name, text in variants.items():
             s = sassy.Searcher("iupac", rc=False)
             want = oracle.search("iupac", pat, text, k)
@@ -2236,8 +2243,7 @@ def test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_plain_text_only(sa
                 st = s.stats()
                 assert_same(got, want, (name, n, rep, st["fused"], st["filtered"]))
                 if can_fuse and n > 4096:
-                    # plain: fused every time; else: tried once (rep 0 falls back inside the call), then not again
-                    assert st["fused"] == (1 if name == "plain" else 0), (name, n, rep, st)
+                    assert st["fused"] == 1, (name, n, rep, st)  # every variant, every time
             # a pattern with an ambiguity letter never takes that launch
             pat2 = pat[:7] + b"N" + pat[8:]
             assert_same(s.search(pat2, text, k), oracle.search("iupac", pat2, text, k), (name, n, "N in the pattern"))
@@ -2272,11 +2278,14 @@ def test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_plain_text_only(sa
         assert_same(g, wants[which], ("in flight", which))
 
 
-def test_fused_filter_falls_back_when_a_wave_queue_overflows(sassy):
-    """More candidate runs than a wave's LDS queue holds (a near-match every 192 bytes), and plateaus that cross
-    chunk seams (conditional reports): the fused launch flags it, the classic chain takes the search, the lane backs
-    off for its next searches, and the results are the oracle's."""
+def test_fused_filter_dense_runs_and_its_one_fall_back(sassy):
+    """More candidate runs than a wave's LDS queue holds (a near-match every 192 bytes) and long plateaus of cost 0: the
+    wave runs its chunk DP whenever the queue fills and splits long runs into windows -- one launch, the oracle's
+    results.  What the fused launch still hands to the classic chain: a long FLAT plateau of cost > 0 (no window sees
+    how it was entered, nothing inside settles it) -- the conditional report sends the search there, the lane backs off
+    for its next searches, and the results are the oracle's."""
     rng = random.Random(78)
+    can_fuse = _env_allows_fusing()
     pat = rand_seq(rng, 32)
     n = 400_000
     t = bytearray(rand_seq(rng, n))
@@ -2286,20 +2295,29 @@ def test_fused_filter_falls_back_when_a_wave_queue_overflows(sassy):
     text = bytes(t[:n])
     s = sassy.Searcher("dna", rc=False)
     got = s.search(pat, text, 3)
-    assert s.stats()["fused"] == 0 and s.stats()["filtered"] == 2
+    assert (s.stats()["fused"] == 1 and s.stats()["filtered"] == 2) or not can_fuse
     want = oracle.search("dna", pat, text, 3)
     assert len(want) > 1500
     assert_same(got, want)
-    # the lane stays unfused for a while, then fuses again
+    assert_same(s.search_all(pat, text[:100_000], 2), oracle.search("dna", pat, text[:100_000], 2, all_minima=True), "dense, search_all")
+    # plateaus of cost 0 far longer than a window (poly-A against poly-A), one of them to the end of the text
+    p2 = b"A" * 28
+    for t2 in (b"G" * 5000 + b"A" * 40_000 + b"G" * 5000, b"G" * 777 + b"A" * 300_000, b"A" * 70_000 + b"C" + b"A" * 9000 + b"G" * 40):
+        assert_same(s.search(p2, t2, 3), oracle.search("dna", p2, t2, 3), ("cost-0 plateau", len(t2)))
+        assert s.stats()["fused"] == 1 or not can_fuse
+    # a flat plateau of cost 1, 40 000 columns: conditional report -> classic chain, and the lane backs off
+    p3 = b"A" * 16 + b"C" + b"A" * 15
+    t3 = b"G" * 5000 + b"A" * 40_000 + b"G" * 5000
+    assert_same(s.search(p3, t3, 3), oracle.search("dna", p3, t3, 3), "flat plateau of cost 1")
+    assert s.stats()["fused"] == 0
+    if not can_fuse:
+        return
     sparse = bytes(rand_seq(rng, 100_000))
     seen = []
     for _ in range(20):
         assert s.search(pat, sparse, 3) == []
         seen.append(s.stats()["fused"])
-    assert seen[0] == 0 and seen[-1] == 1, seen
-    # a plateau over a chunk seam: conditional report -> classic chain
-    p2, t2 = b"A" * 28, b"G" * 5000 + b"A" * 40_000 + b"G" * 5000
-    assert_same(s.search(p2, t2, 3), oracle.search("dna", p2, t2, 3))
+    assert (seen[0] == 0 and seen[-1] == 1) or not can_fuse, seen
 
 
 # ------------------------------------------------------------------ fuzz failures, replayed
@@ -2339,7 +2357,7 @@ _CORE = ("test_fuzz_small_texts or test_low_complexity_and_seams or test_long_pa
          "test_traceback_variants or test_dna_profile_text_with_other_letters or test_device_resident_search_and_shards or "
          "test_shard_seam_plateau_chain or test_fused_filter_equals_classic_chain_and_oracle or test_dense_reports or "
          "test_qgram_count_filter_worst_case_edits or test_searches_in_flight_begin_finish or "
-         "test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_plain_text_only")
+         "test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_any_text or test_fused_filter_dense_runs_and_its_one_fall_back")
 _FORCED = [
     {"SASSY_HIP_PREFILTER": "0"},                    # streaming DP over every block (scan_kernel), also multi-word
     {"SASSY_HIP_PREFILTER": "0", "SASSY_HIP_ROW_CUT": "0"},   # ... every row of every block
