@@ -1861,7 +1861,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
   // masks and carries, at most eight pattern words, leave free -- and the lane index comes from v_mbcnt, the wave index
   // from a scalar: kept in vector registers across the DP they were spilled to scratch memory, and a kernel that owns a
   // scratch segment starts its waves slower.)
-  constexpr uint32_t kSegState = 6144u;            // tile offset of the saved state: [6][64] u32
+  constexpr uint32_t kSegState = 6144u;            // tile offset of the saved state: [7][64] u32
   uint32_t seg_it = 0;                             // wave-uniform, even
   bool first_segment = true;
   const uint32_t wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1944,6 +1944,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
     if (interior && seg_it < n_iter) nxt[i] = stream_load16<SASSY_NT_DNA>(text_base + (uint64_t)seg_it * 64 + soff[i]);
   }
   uint32_t dmask = 0;  // (CHECK) dirty pieces of the lane's staged pair
+  uint32_t npure = 0;  // (CHECK) how many blocks of nothing but N the lane has just walked over
+  if constexpr (CHECK) {
+    if (!first_segment) npure = (reinterpret_cast<const uint32_t*>(tile + kSegState) + lane)[384];
+  }
 
   uint32_t it = seg_it;
   for (; it < n_iter; ++it) {
@@ -2036,12 +2040,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
     uint32_t hit = 0;
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) hit |= al[pp] | ah[pp];
-    if constexpr (CHECK) hit |= (dmask >> (4u * sub)) & 15u;  // (this block's dirty pieces)
+    if constexpr (CHECK) {
+      const uint32_t dpc = (dmask >> (4u * sub)) & 15u;  // this block's dirty pieces
+      hit |= dpc | (npure >= Pk->wb ? 16u : 0u);         // (a lane inside a long run of N looks at every block)
+      if (dpc != 15u && npure < Pk->wb) npure = 0;       // (inside one, the rare path below decides)
+    }
     const uint64_t b = blk0 + it;
     const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
     if (evaluate && hit != 0) {
       if constexpr (FUSED) {
+        // (CHECK) The inside of a run of N: a block of 64 N whose last wb blocks were N as well.  Every alignment that
+        // ends in it runs over N only -- cost 0, one plateau, nothing to report under the report rule and nothing to
+        // learn (a cell of cost 0 settles the plateau state wherever the DP begins).  Such blocks are not queued at
+        // all: a run of N costs the windows around its two ends, whatever its length (a genome's centromere gaps are
+        // megabases).  Lists of ALL end positions <= k have every one of them: no short cut there.
+        bool n_inside = false, n_leaving = false;
+        if constexpr (CHECK) {
+          const bool was_long = npure >= Pk->wb;
+          bool pure = false;
+          if (((dmask >> (4u * sub)) & 15u) == 15u && !(Pk->flags & kScanAllMinima) && b + 1 < Pk->n_blocks) {
+            const uint32_t hs2 = (((sub << 2) ^ (fsw & 4u)) << 4);
+            uint32_t acc = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const uint4 v = *reinterpret_cast<const uint4*>(tile + rc[c] + hs2);
+              acc |= ((v.x & 0xDFDFDFDFu) ^ 0x4E4E4E4Eu) | ((v.y & 0xDFDFDFDFu) ^ 0x4E4E4E4Eu) |
+                     ((v.z & 0xDFDFDFDFu) ^ 0x4E4E4E4Eu) | ((v.w & 0xDFDFDFDFu) ^ 0x4E4E4E4Eu);
+            }
+            pure = acc == 0u;
+          }
+          n_inside = pure && was_long;
+          n_leaving = !pure && was_long;
+          npure = pure ? (npure < 0xFFFFu ? npure + 1u : npure) : 0u;
+        }
         uint32_t lo = kRunNone, hi = 0;
+        if ((n_inside && b + 1 == own_hi) || n_leaving) {
+          // leaving: the first block behind the run -- the plateau of cost 0 ends at its first column at the earliest: the
+          // window reports from there on (it begins, with warm-up and margin, inside the run: settled at once).
+          // The lane's range ends inside the run: should the run end there too, the plateau's last position is the next
+          // lane's first, which knows nothing of the run -- the window around that border is queued here.
+          const uint64_t bb = n_leaving ? b : b + 1;
+          int64_t c_hi = (int64_t)(bb * 64) + (int64_t)Pk->m + (int64_t)Pk->k + 1;
+          if (c_hi > (int64_t)(Pk->n_blocks * 64)) c_hi = (int64_t)(Pk->n_blocks * 64);
+          lo = (uint32_t)((int64_t)(bb * 64) - col_base);
+          hi = (uint32_t)(c_hi - col_base);
+        }
+        if (!n_inside) {
 #pragma unroll
         for (int pp = 0; pp < NP; ++pp) {
           const uint64_t bits = ((uint64_t)ah[pp] << 32) | al[pp];
@@ -2064,9 +2108,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
             hi = max(hi, (uint32_t)(c_hi - col_base));
           }
         }
+        }
         const int64_t fc = (int64_t)(Pk->dp_first_owned * 64) - col_base;
-        run = fuse_add_range(queue, qcount, Pk->cand_count + kCtlFuseWord, Pk->fuse_queue_cap, press_at, Pk->m + Pk->k, col_base,
-                             fc > 0 ? (uint32_t)fc : 0u, run, lo, hi);
+        if (lo != kRunNone)
+          run = fuse_add_range(queue, qcount, Pk->cand_count + kCtlFuseWord, Pk->fuse_queue_cap, press_at, Pk->m + Pk->k, col_base,
+                               fc > 0 ? (uint32_t)fc : 0u, run, lo, hi);
       } else {
 #pragma unroll
         for (int pp = 0; pp < NP; ++pp) {
@@ -2110,6 +2156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
       uint32_t* sv = reinterpret_cast<uint32_t*>(tile + kSegState) + lane;
       sv[0] = prev0; sv[64] = prev1;
       sv[128] = run.x; sv[192] = run.y; sv[256] = run.z; sv[320] = run.w & ~kRunPressure;
+      if constexpr (CHECK) sv[384] = npure;
     }
     unsigned long long probe_t1 = 0;
     if (Pk->fused & 2u) probe_t1 = wall_clock64();  // SASSY_HIP_FUSED_PROBE: 100 MHz ticks spent streaming / in the chunk DP

@@ -2229,7 +2229,8 @@ def test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_any_text(sassy):
         t = bytearray(base); t[n - 40] = ord("U")
         variants["U near the end"] = bytes(t)
         t = bytearray(base)
-        for a, ln in ((n // 5, 3000), (n // 5 + 3100, 31), (n // 3, 29), (n - 200, 200), (0, 50)):
+        for a, ln in ((n // 5, 3000), (n // 5 + 3100, 31), (n // 3, 29), (n - 200, 200), (0, 50), (n // 2 + 5000, 150_000),
+                      (n // 2 + 160_000, 64 * 40), (n // 2 + 170_001, 64 * 3 + 5)):
             if a + ln <= n:
                 t[a:a + ln] = b"N" * ln
         for i in range(0, min(n, 50_000), 211):
