@@ -248,6 +248,26 @@ int sassy_hip_multi_plant(sassy_hip_Multi *m, uint64_t seed, const uint8_t *patt
                           uint64_t stride, uint64_t *planted);
 int sassy_hip_multi_search(sassy_hip_Multi *m, const uint8_t *pattern, size_t pattern_len, size_t k, uint32_t flags,
                            sassy_hip_Result **out);
+/* Both strands (reference: Searcher::new_rc; the CLI's default, bin/grep.rs:476-503 fans such searches out over its
+ * threads): sassy_hip_multi_search then appends the Rc strand's matches to the forward ones, as sassy_hip_search does.
+ * The Rc strand is complement(pattern) against the REVERSED text (src/search.rs:813-878): every device keeps a few
+ * bytes of text on BOTH sides of its shard and searches its share of the reversed text as a shard of its own
+ * (reversed with the reverse kernel, never uploaded twice); the shard results are chained in reversed order. */
+int sassy_hip_multi_set_rc(sassy_hip_Multi *m, int rc);
+/* search_encoded_patterns over several devices shards the PATTERNS (bin/crispr.rs:188-196): every device
+ * scans the whole text for its share -- no halo, no seam, the same gather.  That needs the whole text on every device:
+ * call sassy_hip_multi_set_replicated(m, 1) BEFORE the text is set / generated (0 = text shards again).  The result's
+ * pattern_idx refers to the caller's list; order: device by device (the reference's order is an implementation
+ * artefact too -- compare sorted).  Both strands with sassy_hip_multi_set_rc. */
+int sassy_hip_multi_set_replicated(sassy_hip_Multi *m, int on);
+int sassy_hip_multi_search_encoded(sassy_hip_Multi *m, const uint8_t *patterns, size_t n_patterns, size_t pattern_len,
+                                   size_t k, uint32_t flags, sassy_hip_Result **out);
+/* search_many over several devices shards the TEXTS (host pointers; whole texts, contiguous runs of about equal total
+ * length per device; src/search.rs:531-603 does the same over threads): every device searches all patterns in its
+ * texts, text_idx refers to the caller's list.  Needs no resident text. */
+int sassy_hip_multi_search_many(sassy_hip_Multi *m, const uint8_t *const *patterns, const size_t *pattern_lens,
+                                size_t n_patterns, const uint8_t *const *texts, const size_t *text_lens, size_t n_texts,
+                                size_t k, uint32_t flags, sassy_hip_Result **out);
 void sassy_hip_multi_free(sassy_hip_Multi *m);
 
 typedef struct sassy_hip_Ticket sassy_hip_Ticket;

@@ -120,6 +120,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_search_many", "sassy_hip_tsv_header", "sassy_hip_format_tsv",
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
+    "sassy_hip_multi_set_rc", "sassy_hip_multi_set_replicated", "sassy_hip_multi_search_encoded", "sassy_hip_multi_search_many",
     "sassy_hip_generate_dna", "sassy_hip_generate_genome_like", "sassy_hip_plant",
     "sassy_hip_malloc", "sassy_hip_free", "sassy_hip_memcpy_h2d", "sassy_hip_memcpy_d2h",
 ]
@@ -189,6 +190,16 @@ def lib():
     L.sassy_hip_multi_plant.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)]
     L.sassy_hip_multi_search.restype = C.c_int
     L.sassy_hip_multi_search.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(vp)]
+    L.sassy_hip_multi_set_rc.restype = C.c_int
+    L.sassy_hip_multi_set_rc.argtypes = [vp, C.c_int]
+    L.sassy_hip_multi_set_replicated.restype = C.c_int
+    L.sassy_hip_multi_set_replicated.argtypes = [vp, C.c_int]
+    L.sassy_hip_multi_search_encoded.restype = C.c_int
+    L.sassy_hip_multi_search_encoded.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(vp)]
+    L.sassy_hip_multi_search_many.restype = C.c_int
+    L.sassy_hip_multi_search_many.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t,
+                                              C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_uint32,
+                                              C.POINTER(vp)]
     L.sassy_hip_multi_free.restype = None
     L.sassy_hip_multi_free.argtypes = [vp]
     L.sassy_hip_set_only_best_match.restype = C.c_int
@@ -700,6 +711,36 @@ class MultiSearcher:
         out = C.c_void_p()
         pattern = bytes(pattern)
         _check(lib().sassy_hip_multi_search(self._h, pattern, len(pattern), k, flags, C.byref(out)))
+        return Result(out)
+
+    def set_rc(self, rc: bool = True):
+        """Both strands: searches append the Rc strand's matches (Searcher::new_rc)."""
+        _check(lib().sassy_hip_multi_set_rc(self._h, int(bool(rc))))
+        return self
+
+    def set_replicated(self, on: bool = True):
+        """Every device holds the whole text (before set_text / generate_dna): search_encoded shards the patterns."""
+        _check(lib().sassy_hip_multi_set_replicated(self._h, int(bool(on))))
+        return self
+
+    def search_encoded(self, patterns: Sequence[bytes], k: int, flags: int = 0) -> "Result":
+        patterns = [bytes(p) for p in patterns]
+        plen = len(patterns[0])
+        if any(len(p) != plen for p in patterns):
+            raise SassyHipError("All pattern must have the same length")
+        out = C.c_void_p()
+        _check(lib().sassy_hip_multi_search_encoded(self._h, b"".join(patterns), len(patterns), plen, k, flags, C.byref(out)))
+        return Result(out)
+
+    def search_many(self, patterns: Sequence[bytes], texts: Sequence[bytes], k: int, flags: int = 0) -> "Result":
+        patterns = [bytes(p) for p in patterns]
+        texts = [bytes(t) for t in texts]
+        pp = (C.c_char_p * len(patterns))(*patterns)
+        pl = (C.c_size_t * len(patterns))(*[len(p) for p in patterns])
+        tp = (C.c_char_p * len(texts))(*texts)
+        tl = (C.c_size_t * len(texts))(*[len(t) for t in texts])
+        out = C.c_void_p()
+        _check(lib().sassy_hip_multi_search_many(self._h, pp, pl, len(patterns), tp, tl, len(texts), k, flags, C.byref(out)))
         return Result(out)
 
 

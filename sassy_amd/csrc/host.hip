@@ -537,6 +537,9 @@ struct sassy_SearcherType {
   // scan; default), 2 every phase.  Each event record costs a few microseconds of stream idle time.
   int timing = getenv("SASSY_HIP_TIMING") ? atoi(getenv("SASSY_HIP_TIMING")) : 1;
   sassy_hip_Stats stats{};
+  // the drop-in search() over several devices (SASSY_HIP_DEVICES): a multi-device searcher of this searcher's alphabet
+  // and strands, made at the first such call (sassy_hip_Multi is defined further down: owned through its deleter)
+  std::shared_ptr<void> multi;
 
   ~sassy_SearcherType() {
     for (ScanLane& l : lanes)  // searches still in flight (tickets never finished): let their kernels drain
@@ -4286,18 +4289,27 @@ struct sassy_hip_Multi {
   struct Part {
     int device = 0;
     sassy_SearcherType* searcher = nullptr;
+    sassy_SearcherType* searcher_rc = nullptr;  // (both strands in one call: search_encoded / search_many with rc)
     uint8_t* d_text = nullptr;       // halo first
     size_t d_cap = 0;
+    uint8_t* d_rev = nullptr;        // Rc strand: the reversed view of this part's share of the reversed text
+    size_t d_rev_cap = 0;
     uint64_t halo = 0, len = 0, offset = 0;  // bytes in front of the shard, shard length, its global offset
+    uint64_t halo_r = 0;             // bytes of text kept behind the shard (the Rc strand's halo lies on that side)
     std::unique_ptr<MultiWorker> worker;
     int rc = 0;
     std::string err;
     sassy_hip_Result* result = nullptr;
+    sassy_hip_Result* result_rc = nullptr;
   };
   std::vector<Part> parts;
+  std::string alphabet;
+  float alpha = NAN;
   uint64_t total_len = 0;
   uint64_t halo_for = 0;  // the resident shards carry halos good for searches with required_halo(m, k) <= this
   bool have_text = false;
+  bool rc = false;          // sassy_hip_multi_set_rc: searches return both strands
+  bool replicate = false;   // sassy_hip_multi_set_replicated: every device holds the WHOLE text (patterns are sharded)
   ~sassy_hip_Multi() {
     for (Part& p : parts) {
       if (p.worker) p.worker->stop();
@@ -4305,7 +4317,9 @@ struct sassy_hip_Multi {
       (void)hipGetDevice(&prev);
       (void)hipSetDevice(p.device);
       if (p.d_text) (void)hipFree(p.d_text);
+      if (p.d_rev) (void)hipFree(p.d_rev);
       if (p.searcher) delete p.searcher;
+      if (p.searcher_rc) delete p.searcher_rc;
       (void)hipSetDevice(prev);
     }
   }
@@ -4333,18 +4347,33 @@ struct sassy_hip_Multi {
     a = std::min<uint64_t>(i * per, total_len);
     b = std::min<uint64_t>((i + 1) * per, total_len);
   }
+  // The Rc strand is complement(pattern) against the REVERSED text (src/search.rs:813-878), sharded like the forward
+  // one but in reversed coordinates: reversed shard j owns the reversed end positions (A, B] with A = j * per -- the
+  // forward bytes [n - B, n - A), whose borders differ from the forward shards' by up to 64 * parts bytes unless n is a
+  // multiple of 64 * parts.  Part i keeps reversed shard parts - 1 - i: it needs a few bytes more of text on either side.
+  uint64_t slack() const { return 64ull * (parts.size() + 1); }
   int layout(uint64_t len, size_t max_m, size_t max_k) {
     total_len = len;
     halo_for = sassy_hip_required_halo(max_m, max_k);
     for (size_t i = 0; i < parts.size(); ++i) {
       uint64_t a, b;
       bounds(i, a, b);
+      if (replicate) { a = 0; b = len; }
       parts[i].offset = a;
       parts[i].len = b - a;
-      parts[i].halo = (i == 0 || a == 0) ? 0 : std::min<uint64_t>(halo_for, a);
+      parts[i].halo = (i == 0 || a == 0) ? 0 : std::min<uint64_t>(halo_for + slack(), a);
       parts[i].halo = parts[i].halo / 64 * 64;
+      parts[i].halo_r = std::min<uint64_t>(halo_for + slack(), len - b);
     }
     return 0;
+  }
+  // reversed shard `j` in forward coordinates: [fa, fb) and its halo [fb, fb + hrev) (hrev a multiple of 64)
+  void rev_bounds(size_t j, uint64_t& fa, uint64_t& fb, uint64_t& hrev) const {
+    uint64_t A, B;
+    bounds(j, A, B);
+    fa = total_len - B;
+    fb = total_len - A;
+    hrev = std::min<uint64_t>(halo_for, A);  // (A = n - fb bytes lie behind fb; A and halo_for are multiples of 64)
   }
   static int reserve(Part& p, size_t bytes) {
     if (bytes <= p.d_cap) return 0;
@@ -4373,6 +4402,8 @@ sassy_hip_Multi* sassy_hip_multi_new(const char* alphabet, float alpha, const in
   for (int d : devs)
     if (d < 0 || d >= visible) { fail(SASSY_HIP_EINVAL, "no such HIP device"); return nullptr; }
   std::unique_ptr<sassy_hip_Multi> M(new sassy_hip_Multi());
+  M->alphabet = alphabet ? alphabet : "";
+  M->alpha = alpha;
   M->parts.resize(devs.size());
   for (size_t i = 0; i < devs.size(); ++i) {
     sassy_hip_Multi::Part& p = M->parts[i];
@@ -4398,7 +4429,7 @@ int sassy_hip_multi_set_text(sassy_hip_Multi* m, const uint8_t* text, size_t len
   m->have_text = false;
   // every device fetches its own shard (halo included) over its own PCIe link, all at the same time
   const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
-    const size_t bytes = (size_t)(p.halo + p.len);
+    const size_t bytes = (size_t)(p.halo + p.len + p.halo_r);
     if (int r = sassy_hip_Multi::reserve(p, bytes)) return r;
     if (bytes) HIP_TRY(hipMemcpy(p.d_text, text + (p.offset - p.halo), bytes, hipMemcpyHostToDevice));
     return 0;
@@ -4413,7 +4444,7 @@ int sassy_hip_multi_generate_dna(sassy_hip_Multi* m, uint64_t len, uint64_t seed
   m->layout(len, max_pattern_len, max_k);
   m->have_text = false;
   const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
-    const size_t bytes = (size_t)(p.halo + p.len);
+    const size_t bytes = (size_t)(p.halo + p.len + p.halo_r);
     if (int r = sassy_hip_Multi::reserve(p, bytes)) return r;
     if (bytes)
       if (int r = sassy_hip_generate_dna(p.d_text, bytes, seed, p.offset - p.halo, nullptr)) return r;
@@ -4431,7 +4462,7 @@ int sassy_hip_multi_plant(sassy_hip_Multi* m, uint64_t seed, const uint8_t* patt
   std::vector<uint64_t> cnt(m->parts.size(), 0);
   const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
     const size_t i = (size_t)(&p - m->parts.data());
-    const size_t bytes = (size_t)(p.halo + p.len);
+    const size_t bytes = (size_t)(p.halo + p.len + p.halo_r);
     if (!bytes) return 0;
     if (int r = sassy_hip_plant(p.d_text, bytes, p.offset - p.halo, m->total_len, seed, pattern, pattern_len, k, stride, nullptr, &cnt[i]))
       return r;
@@ -4448,24 +4479,234 @@ int sassy_hip_multi_plant(sassy_hip_Multi* m, uint64_t seed, const uint8_t* patt
   return 0;
 }
 
+int sassy_hip_multi_set_rc(sassy_hip_Multi* m, int rc) {
+  if (!m) return fail(SASSY_HIP_EINVAL, "null argument");
+  Profile pr;
+  if (rc && parse_alphabet(m->alphabet.c_str(), pr) && pr == PROFILE_ASCII)
+    return fail(SASSY_HIP_EUNSUPPORTED, "reverse complement is not defined for the ascii alphabet");
+  m->rc = rc != 0;
+  return 0;
+}
+int sassy_hip_multi_set_replicated(sassy_hip_Multi* m, int on) {
+  if (!m) return fail(SASSY_HIP_EINVAL, "null argument");
+  if (m->replicate != (on != 0)) m->have_text = false;  // (the resident buffers were laid out the other way)
+  m->replicate = on != 0;
+  return 0;
+}
+
+// The Rc strand of one part: reversed shard j = parts - 1 - i of the reversed text, read off the part's resident
+// forward bytes by the reverse kernel, searched with complement(pattern) like any shard (reversed coordinates).
+static int multi_rc_shard(sassy_hip_Multi* m, sassy_hip_Multi::Part& p, const uint8_t* cpat, size_t plen, size_t k, uint32_t f) {
+  const size_t i = (size_t)(&p - m->parts.data());
+  const size_t j = m->parts.size() - 1 - i;
+  uint64_t fa, fb, hrev;
+  m->rev_bounds(j, fa, fb, hrev);
+  p.result_rc = nullptr;
+  if (fb <= fa) { p.result_rc = new sassy_hip_Result(); return 0; }
+  const uint64_t buf0 = p.offset - p.halo, buf1 = p.offset + p.len + p.halo_r;  // the resident bytes [buf0, buf1)
+  const uint64_t fa16 = fa / 16 * 16, end = fb + hrev;
+  if (fa16 < buf0 || end > buf1)
+    return fail(SASSY_HIP_EINVAL, "internal: the part's resident text does not cover its share of the reversed text");
+  const size_t nrev = (size_t)(end - fa16);
+  if (nrev + 256 > p.d_rev_cap) {
+    if (p.d_rev) (void)hipFree(p.d_rev);
+    p.d_rev = nullptr;
+    p.d_rev_cap = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p.d_rev), nrev + 512);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc (reversed shard)");
+    p.d_rev_cap = nrev + 256;
+  }
+  // reverse(text[fa16, end)): its first (end - fa) bytes are the reversed shard with its halo in front; the up to 15
+  // bytes behind them (the alignment the reverse kernel wants) are only there
+  hipError_t le = launch_reverse(p.d_text + (fa16 - buf0), p.d_rev, nrev, nullptr);
+  if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
+  HIP_TRY(hipStreamSynchronize(nullptr));
+  uint64_t A, B;
+  m->bounds(j, A, B);
+  return sassy_hip_search_shard(p.searcher, cpat, plen, p.d_rev, hrev, B - A, A, m->total_len, k, f, &p.result_rc);
+}
+
 int sassy_hip_multi_search(sassy_hip_Multi* m, const uint8_t* pattern, size_t pattern_len, size_t k, uint32_t flags,
                            sassy_hip_Result** out) {
   if (!m || !pattern || !out) return fail(SASSY_HIP_EINVAL, "null argument");
   if (!m->have_text) return fail(SASSY_HIP_EINVAL, "no resident text (sassy_hip_multi_set_text)");
+  if (m->replicate) return fail(SASSY_HIP_EINVAL, "the devices hold whole copies of the text (sassy_hip_multi_set_replicated): search_encoded only");
   if (sassy_hip_required_halo(pattern_len, k) > m->halo_for && m->parts.size() > 1)
     return fail(SASSY_HIP_EINVAL, "the resident shards' halos are too short for this pattern length and k");
   const uint32_t f = flags & (SASSY_HIP_ALL_MINIMA | SASSY_HIP_WITHOUT_TRACE);
+  std::vector<uint8_t> cp;  // complement(pattern) for the Rc strand (src/search.rs:813-820)
+  if (m->rc) {
+    Profile pr;
+    if (!parse_alphabet(m->alphabet.c_str(), pr)) return fail(SASSY_HIP_EINVAL, "unknown alphabet");
+    cp.resize(pattern_len);
+    for (size_t i = 0; i < pattern_len; ++i) cp[i] = complement_char(pr, pattern[i]);
+  }
   const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
     p.result = nullptr;
-    if (p.len == 0) { p.result = new sassy_hip_Result(); return 0; }
-    return sassy_hip_search_shard(p.searcher, pattern, pattern_len, p.d_text, p.halo, p.len, p.offset, m->total_len, k, f, &p.result);
+    p.result_rc = nullptr;
+    if (p.len == 0) p.result = new sassy_hip_Result();
+    else if (int r = sassy_hip_search_shard(p.searcher, pattern, pattern_len, p.d_text, p.halo / 64 * 64, p.len, p.offset, m->total_len, k, f, &p.result))
+      return r;
+    if (m->rc) return multi_rc_shard(m, p, cp.data(), pattern_len, k, f);
+    return 0;
   });
-  std::vector<const sassy_hip_Result*> rs;
-  for (sassy_hip_Multi::Part& p : m->parts) rs.push_back(p.result);
   int mrc = rc;
-  if (!mrc) mrc = sassy_hip_merge_shards(rs.data(), rs.size(), kStateDecTrue, out);
+  sassy_hip_Result* fwd = nullptr;
+  sassy_hip_Result* rev = nullptr;
+  if (!mrc) {
+    std::vector<const sassy_hip_Result*> rs;
+    for (sassy_hip_Multi::Part& p : m->parts) rs.push_back(p.result);
+    mrc = sassy_hip_merge_shards(rs.data(), rs.size(), kStateDecTrue, &fwd);
+  }
+  if (!mrc && m->rc) {  // reversed shard j lives on part parts - 1 - j
+    std::vector<const sassy_hip_Result*> rs;
+    for (size_t j = 0; j < m->parts.size(); ++j) rs.push_back(m->parts[m->parts.size() - 1 - j].result_rc);
+    mrc = sassy_hip_merge_shards(rs.data(), rs.size(), kStateDecTrue, &rev);
+  }
+  for (sassy_hip_Multi::Part& p : m->parts) {
+    delete p.result; p.result = nullptr;
+    delete p.result_rc; p.result_rc = nullptr;
+  }
+  if (!mrc && rev) {
+    // the Rc strand's matches behind the forward ones, mapped back to forward coordinates (src/search.rs:868-873)
+    const bool wo = (f & SASSY_HIP_WITHOUT_TRACE) != 0;
+    const size_t base = fwd->pool.size();
+    if (base + rev->pool_size() > 0xFFFFFFFFull) mrc = fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB");
+    else {
+      fwd->pool.append(rev->pool_data(), rev->pool_size());
+      const sassy_hip_Match* rm = rev->data();
+      for (size_t i = 0; i < rev->size(); ++i) {
+        sassy_hip_Match r = rm[i];
+        const uint64_t rs_ = r.text_start, re = r.text_end;
+        r.strand = 1;
+        r.text_start = m->total_len - re;
+        r.text_end = wo ? UINT64_MAX : m->total_len - rs_;
+        r.cigar_off = (uint32_t)(r.cigar_off + base);
+        fwd->matches.push_back(r);
+      }
+    }
+  }
+  delete rev;
+  if (mrc) { delete fwd; return mrc; }
+  *out = fwd;
+  return 0;
+}
+
+// search_encoded_patterns over several devices: the PATTERNS are sharded (every device scans the whole text
+// for its share of the patterns -- no halo, no seam), which needs the whole text on every device
+// (sassy_hip_multi_set_replicated before the text is set).  pattern_idx of the result refers to the caller's list.
+int sassy_hip_multi_search_encoded(sassy_hip_Multi* m, const uint8_t* patterns, size_t n_patterns, size_t pattern_len, size_t k,
+                                   uint32_t flags, sassy_hip_Result** out) {
+  if (!m || !patterns || !out) return fail(SASSY_HIP_EINVAL, "null argument");
+  if (!m->have_text || !m->replicate)
+    return fail(SASSY_HIP_EINVAL, "search_encoded over several devices shards the patterns: every device needs the whole text "
+                                  "(sassy_hip_multi_set_replicated(m, 1), then set the text)");
+  if (n_patterns == 0) return fail(SASSY_HIP_EINVAL, "No queries provided");
+  const size_t G = m->parts.size();
+  const uint32_t f = (flags & (SASSY_HIP_ALL_MINIMA | SASSY_HIP_WITHOUT_TRACE)) | SASSY_HIP_TEXT_ON_DEVICE;
+  const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
+    const size_t i = (size_t)(&p - m->parts.data());
+    const size_t p0 = n_patterns * i / G, p1 = n_patterns * (i + 1) / G;
+    p.result = nullptr;
+    if (p1 == p0) { p.result = new sassy_hip_Result(); return 0; }
+    sassy_SearcherType* s = p.searcher;
+    if (m->rc) {
+      if (!p.searcher_rc) {
+        p.searcher_rc = sassy_hip_searcher_new(m->alphabet.c_str(), true, m->alpha);
+        if (!p.searcher_rc) return SASSY_HIP_EINVAL;
+        p.searcher_rc->device = p.device;
+      }
+      s = p.searcher_rc;
+    }
+    sassy_hip_Encoded* e = sassy_hip_encode_patterns(s, patterns + p0 * pattern_len, p1 - p0, pattern_len);
+    if (!e) return SASSY_HIP_EINVAL;
+    const int r = sassy_hip_search_encoded(s, e, p.d_text, (size_t)m->total_len, k, f, &p.result);
+    sassy_hip_encoded_free(e);
+    return r;
+  });
+  std::unique_ptr<sassy_hip_Result> R(new sassy_hip_Result());
+  int mrc = rc;
+  for (size_t i = 0; i < G && !mrc; ++i) {
+    const sassy_hip_Result* r = m->parts[i].result;
+    const size_t p0 = n_patterns * i / G, base = R->pool.size();
+    if (base + r->pool_size() > 0xFFFFFFFFull) { mrc = fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB"); break; }
+    R->pool.append(r->pool_data(), r->pool_size());
+    const sassy_hip_Match* rm = r->data();
+    for (size_t x = 0; x < r->size(); ++x) {
+      sassy_hip_Match q = rm[x];
+      q.pattern_idx += p0;
+      q.cigar_off = (uint32_t)(q.cigar_off + base);
+      R->matches.push_back(q);
+    }
+  }
   for (sassy_hip_Multi::Part& p : m->parts) { delete p.result; p.result = nullptr; }
-  return mrc;
+  if (mrc) return mrc;
+  if (R->pool.empty()) R->pool.push_back('\0');
+  *out = R.release();
+  return 0;
+}
+
+// search_many over several devices: the TEXTS are sharded (whole texts; contiguous runs of about equal total length),
+// every device searches all patterns in its texts; text_idx of the result refers to the caller's list.  Host texts;
+// nothing resident is needed.  Order: device by device, each in sassy_hip_search_many's order.
+int sassy_hip_multi_search_many(sassy_hip_Multi* m, const uint8_t* const* patterns, const size_t* pattern_lens, size_t n_patterns,
+                                const uint8_t* const* texts, const size_t* text_lens, size_t n_texts, size_t k, uint32_t flags,
+                                sassy_hip_Result** out) {
+  if (!m || !out || (!patterns && n_patterns) || (!texts && n_texts)) return fail(SASSY_HIP_EINVAL, "null argument");
+  const size_t G = m->parts.size();
+  const uint32_t f = flags & (SASSY_HIP_ALL_MINIMA | SASSY_HIP_WITHOUT_TRACE);
+  // cut points: text t goes to part floor(G * (bytes in front of t) / total)
+  std::vector<size_t> first(G + 1, n_texts);
+  {
+    uint64_t total = 0;
+    for (size_t t = 0; t < n_texts; ++t) total += text_lens[t] + 64;
+    uint64_t before = 0;
+    size_t g = 0;
+    first[0] = 0;
+    for (size_t t = 0; t < n_texts; ++t) {
+      const size_t want = total ? (size_t)((unsigned __int128)before * G / total) : 0;
+      while (g < want && g + 1 < G) first[++g] = t;
+      before += text_lens[t] + 64;
+    }
+    while (g + 1 <= G - 1) first[++g] = n_texts;
+    first[G] = n_texts;
+  }
+  const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
+    const size_t i = (size_t)(&p - m->parts.data());
+    const size_t t0 = first[i], t1 = first[i + 1];
+    p.result = nullptr;
+    if (t1 <= t0 || n_patterns == 0) { p.result = new sassy_hip_Result(); return 0; }
+    sassy_SearcherType* s = p.searcher;
+    if (m->rc) {
+      if (!p.searcher_rc) {
+        p.searcher_rc = sassy_hip_searcher_new(m->alphabet.c_str(), true, m->alpha);
+        if (!p.searcher_rc) return SASSY_HIP_EINVAL;
+        p.searcher_rc->device = p.device;
+      }
+      s = p.searcher_rc;
+    }
+    return sassy_hip_search_many(s, patterns, pattern_lens, n_patterns, texts + t0, text_lens + t0, t1 - t0, k, f, &p.result);
+  });
+  std::unique_ptr<sassy_hip_Result> R(new sassy_hip_Result());
+  int mrc = rc;
+  for (size_t i = 0; i < G && !mrc; ++i) {
+    const sassy_hip_Result* r = m->parts[i].result;
+    const size_t base = R->pool.size();
+    if (base + r->pool_size() > 0xFFFFFFFFull) { mrc = fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB"); break; }
+    R->pool.append(r->pool_data(), r->pool_size());
+    const sassy_hip_Match* rm = r->data();
+    for (size_t x = 0; x < r->size(); ++x) {
+      sassy_hip_Match q = rm[x];
+      q.text_idx += first[i];
+      q.cigar_off = (uint32_t)(q.cigar_off + base);
+      R->matches.push_back(q);
+    }
+  }
+  for (sassy_hip_Multi::Part& p : m->parts) { delete p.result; p.result = nullptr; }
+  if (mrc) return mrc;
+  if (R->pool.empty()) R->pool.push_back('\0');
+  *out = R.release();
+  return 0;
 }
 
 void sassy_hip_multi_free(sassy_hip_Multi* m) { delete m; }
@@ -4599,11 +4840,50 @@ int64_t sassy_hip_result_conditional_index(const sassy_hip_Result* r) { return r
 void sassy_hip_result_free(sassy_hip_Result* r) { delete r; }
 
 // ---- drop-in `search` (reference: c/sassy.h:52-58, src/c.rs:89-122) ----
+// SASSY_HIP_DEVICES = "all" | "0,1,2,...": the drop-in search() cuts a host text into one shard per named device (a
+// device may be named more than once), uploads the shards over all PCIe links at once, searches them at once and merges
+// (sassy_hip_multi_*).  Unset, or a text of less than 4 MiB per device: the searcher's own device does it all.
+static std::vector<int> drop_in_devices() {
+  std::vector<int> devs;
+  const char* e = getenv("SASSY_HIP_DEVICES");
+  if (!e || !*e) return devs;
+  int visible = 0;
+  if (hipGetDeviceCount(&visible) != hipSuccess) { (void)hipGetLastError(); return devs; }
+  if (!strcmp(e, "all")) {
+    for (int d = 0; d < visible; ++d) devs.push_back(d);
+    if (devs.size() < 2) devs.clear();
+    return devs;
+  }
+  for (const char* q = e; *q;) {
+    char* end = nullptr;
+    const long d = strtol(q, &end, 10);
+    if (end == q || d < 0 || d >= visible) { devs.clear(); return devs; }
+    devs.push_back((int)d);
+    q = *end == ',' ? end + 1 : end;
+    if (*end && *end != ',') { devs.clear(); return devs; }
+  }
+  return devs;
+}
+
 uintptr_t search(sassy_SearcherType* searcher, const uint8_t* pattern, uintptr_t pattern_len,
                  const uint8_t* text, uintptr_t text_len, uintptr_t k, sassy_Match** out_matches) {
   if (!searcher || !pattern || !text || !out_matches) die("Pointers in search() must not be null");
   sassy_hip_Result* R = nullptr;
-  if (sassy_hip_search(searcher, pattern, pattern_len, text, text_len, k, 0, &R) != 0) die(g_err.c_str());
+  static const std::vector<int> devs = drop_in_devices();
+  const bool plain_modes = std::isnan(searcher->alpha) && std::isnan(searcher->max_n_frac) && !searcher->only_best &&
+                           searcher->ref_lanes == 0 && !(searcher->rc && searcher->profile == PROFILE_ASCII);
+  if (!devs.empty() && plain_modes && text_len >= devs.size() * (size_t)(4u << 20)) {
+    if (!searcher->multi) {
+      const char* names[] = {"ascii", "dna", "iupac"};
+      sassy_hip_Multi* mm = sassy_hip_multi_new(names[(int)searcher->profile], NAN, devs.data(), devs.size());
+      if (!mm) die(g_err.c_str());
+      if (sassy_hip_multi_set_rc(mm, searcher->rc ? 1 : 0) != 0) die(g_err.c_str());
+      searcher->multi = std::shared_ptr<void>(mm, [](void* q) { sassy_hip_multi_free(static_cast<sassy_hip_Multi*>(q)); });
+    }
+    sassy_hip_Multi* mm = static_cast<sassy_hip_Multi*>(searcher->multi.get());
+    if (sassy_hip_multi_set_text(mm, text, text_len, pattern_len, k) != 0) die(g_err.c_str());
+    if (sassy_hip_multi_search(mm, pattern, pattern_len, k, 0, &R) != 0) die(g_err.c_str());
+  } else if (sassy_hip_search(searcher, pattern, pattern_len, text, text_len, k, 0, &R) != 0) die(g_err.c_str());
   const size_t n = R->matches.size();
   // never null, also for zero matches (the reference hands out a dangling non-null pointer and
   // sassy_matches_free asserts non-null: src/c.rs:112-127)

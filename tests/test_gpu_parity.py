@@ -2541,6 +2541,121 @@ def test_multi_searcher_shards_on_one_gpu(sassy):
 
 
 
+def test_multi_searcher_both_strands_encoded_and_many_on_one_gpu(sassy):
+    """The multi-device searcher beyond forward single-pattern searches, with device 0 named several times: both
+    strands (every device searches its share of the REVERSED text as a shard of its own, text lengths that are and are
+    not multiples of the block size), search_encoded with the PATTERNS sharded over devices that hold the whole text,
+    search_many with the TEXTS sharded -- all against the oracle / the single-device searcher."""
+    rng = random.Random(93)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for profile, n, G in (("dna", 300_017, 3), ("iupac", 64 * 3 * 700, 3), ("dna", 200_001, 5), ("dna", 5000, 4)):
+        ms = sassy.MultiSearcher(profile, devices=[0] * G).set_rc(True)
+        pat = rand_seq(rng, 32)
+        rcp = pat.translate(comp)[::-1]
+        t = bytearray(rand_seq(rng, n))
+        per = -(-(-(-n // G)) // 64) * 64
+        for g in range(1, G):
+            for b in (g * per, n - g * per):  # the forward shards' borders and the reversed shards'
+                for off in (-40, -33, -20, -1, 0, 3):
+                    ins = mutate(rng, pat if rng.random() < 0.5 else rcp, rng.randrange(4))
+                    at = max(0, min(n - len(ins), b + off))
+                    t[at:at + len(ins)] = ins
+        for _ in range(60):
+            ins = mutate(rng, pat if rng.random() < 0.5 else rcp, rng.randrange(4))
+            at = rng.randrange(0, n - 64)
+            t[at:at + len(ins)] = ins
+        t[0:32] = rcp
+        t[n - 32:n] = rcp
+        text = bytes(t[:n])
+        ms.set_text(text, 64, 6)
+        assert_same(ms.search(pat, 3).matches, oracle.search(profile, pat, text, 3, rc=True), ("multi rc", profile, n, G))
+        assert_same(ms.search(pat, 2, sassy.ALL_MINIMA).matches, oracle.search(profile, pat, text, 2, rc=True, all_minima=True),
+                    ("multi rc all", profile, n, G))
+        wo = ms.search(pat, 3, sassy.WITHOUT_TRACE).matches
+        want = oracle.search(profile, pat, text, 3, rc=True)
+        assert [(m.text_end if m.strand == "+" else m.text_start, m.cost, m.strand) for m in wo] == \
+               [(m.text_end if m.strand == "+" else m.text_start, m.cost, m.strand) for m in want]
+    # a plateau over the reversed shards' borders
+    ms = sassy.MultiSearcher("dna", devices=[0, 0, 0]).set_rc(True)
+    pa, ta = b"T" * 20, b"G" * 333 + b"A" * 150_000 + b"C" + b"A" * 50_000 + b"G" * 99
+    ms.set_text(ta, 32, 3)
+    assert_same(ms.search(pa, 3).matches, oracle.search("dna", pa, ta, 3, rc=True), "multi rc plateau")
+    # search_encoded: patterns sharded, whole text everywhere
+    n = 150_000
+    text = bytearray(rand_seq(rng, n))
+    pats = [bytes(text[997 * i + 5:997 * i + 25]) for i in range(40)] + [rand_seq(rng, 20) for _ in range(13)]
+    for i in range(0, 40, 3):  # a few of them again, mutated, elsewhere
+        ins = mutate(rng, pats[i], 2)
+        at = 80_000 + 500 * i
+        text[at:at + len(ins)] = ins
+    text = bytes(text)
+    for rc in (False, True):
+        me = sassy.MultiSearcher("iupac", devices=[0, 0, 0]).set_replicated(True).set_rc(rc)
+        me.set_text(text, 32, 3)
+        got = me.search_encoded(pats, 2).matches
+        want = oracle.search_encoded("iupac", pats, text, 2, rc=rc)
+        assert sorted(key(m) for m in got) == sorted(key(m) for m in want), ("multi encoded", rc, len(got), len(want))
+        assert len(want) >= 40
+        with pytest.raises(sassy.SassyHipError, match="whole copies"):
+            me.search(pats[0], 2)
+    with pytest.raises(sassy.SassyHipError, match="whole text"):
+        sassy.MultiSearcher("iupac", devices=[0, 0]).set_text(text, 32, 3).search_encoded(pats, 2)
+    # search_many: texts sharded
+    texts = [rand_seq(rng, rng.choice([0, 1, 50, 300, 2000, 9000])) for _ in range(37)]
+    mpats = [rand_seq(rng, 24) for _ in range(5)]
+    texts = [bytes(bytearray(x[:10]) + mutate(rng, mpats[i % 5], i % 3) + bytearray(x[10:])) if len(x) > 100 else x for i, x in enumerate(texts)]
+    for rc in (False, True):
+        mm = sassy.MultiSearcher("dna", devices=[0, 0, 0, 0]).set_rc(rc)
+        got = mm.search_many(mpats, texts, 2).matches
+        single = sassy.Searcher("dna", rc=rc).search_many(mpats, texts, 2)
+
+        def key_t(m):
+            return (m.pattern_idx, m.text_idx) + key(m)[1:]
+        assert sorted(key_t(m) for m in got) == sorted(key_t(m) for m in single), ("multi many", rc, len(got), len(single))
+        assert len(single) >= 10
+
+
+def test_drop_in_search_over_several_devices(sassy):
+    """SASSY_HIP_DEVICES names the devices the drop-in search() cuts a host text over (read once per process: a process
+    of its own; device 0 three times on the one-GPU box): same matches as the oracle, both strands."""
+    import subprocess
+    code = r'''
+import ctypes as C, random, sys
+sys.path.insert(0, ".")
+import oracle, sassy_amd
+rng = random.Random(5)
+n = (13 << 20) + 77
+text = bytearray(oracle.generate_dna(42, 0, n).tobytes())
+pat = bytes(oracle.generate_dna(43, 0, 32))
+comp = bytes.maketrans(b"ACGT", b"TGCA")
+for i in range(300):
+    ins = bytearray(pat if i % 2 else pat.translate(comp)[::-1])
+    for _ in range(i % 4):
+        ins[rng.randrange(len(ins))] = rng.choice(b"ACGT")
+    at = rng.randrange(0, n - 64)
+    text[at:at + len(ins)] = ins
+text = bytes(text)
+L = sassy_amd.lib()
+for rc in (False, True):
+    s = L.sassy_searcher(b"dna", rc, float("nan"))
+    out = C.POINTER(sassy_amd.CMatch)()
+    cnt = L.search(s, pat, len(pat), text, len(text), 3, C.byref(out))
+    got = [(out[i].text_start, out[i].text_end, out[i].pattern_start, out[i].pattern_end, out[i].cost, out[i].strand) for i in range(cnt)]
+    L.sassy_matches_free(out, cnt)
+    want = [(m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, 1 if m.strand == "-" else 0)
+            for m in oracle.search("dna", pat, text, 3, rc=rc)]
+    assert got == want, (rc, len(got), len(want), got[:3], want[:3])
+    assert len(want) >= (250 if rc else 120)
+    L.sassy_searcher_free(s)
+print("ok")
+'''
+    e = dict(os.environ)
+    e["SASSY_HIP_DEVICES"] = "0,0,0"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=e, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_config5_shape_24gb_in_eight_shards_on_one_gpu(sassy):
     """BASELINE config 5's data path at its own size, on the ONE GPU of the test box: 24e9 bytes of the synthetic text
     in eight shards with halos (the in-process multi-device searcher with device 0 named eight times: generated shard
