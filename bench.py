@@ -147,12 +147,22 @@ def main():
                          "profiles/r02_in_flight.txt)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short runs of BASELINE configs 3 and 4 on the resident text (N = 1, after the timed steps)")
+    ap.add_argument("--mode", choices=["ranks", "inproc"], default="ranks",
+                    help="N > 1: 'ranks' (default) = one process per GPU, torch.distributed over RCCL, match rows gathered to "
+                         "rank 0; 'inproc' = ONE process driving all N devices through the C-ABI's multi-device searcher "
+                         "(sassy_hip_multi_*: a host thread and a resident shard per device, merge in C) -- no "
+                         "torch.distributed, no RCCL: a scaling run that does not depend on the collective path")
+    ap.add_argument("--settle", type=int, default=100,
+                    help="untimed searches in front of the timed region on top of --warmup (clocks, first touches, the "
+                         "pipeline of searches in flight): the first dozens of steps after start-up run a few percent slow")
     ap.add_argument("--allow-shared-gpu", action="store_true",
                     help="debugging the N > 1 path on a box with fewer GPUs than ranks: ranks share devices and "
                          "the match exchange goes over gloo; never a valid scaling measurement")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.mode == "inproc":
+        return main_inproc(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
 
@@ -302,7 +312,7 @@ def main():
     fused_launch = bool(searcher.stats().get("fused", 0))
     searcher.set_timing(1)
 
-    for _ in range(args.warmup):
+    for _ in range(args.warmup + max(0, args.settle)):
         step()
     sync()
     t0 = time.perf_counter()
@@ -407,7 +417,8 @@ def main():
             "parallelism": f"text sharded x{world}, one process per GPU"
                            + ("" if world == 1 else f", {dist.get_backend()} ({'RCCL' if dist.get_backend() == 'nccl' else 'debug: shared GPU'}) world {dist.get_world_size()}"),
             "setup": (f"one cold search (cold_first_search_ms), {args.tune_searches} tuning searches, 50 one-at-a-time searches "
-                      f"(single_search_latency_ms and the roofline object's kernel time), then the W warm-up steps and the K timed steps"),
+                      f"(single_search_latency_ms and the roofline object's kernel time), then the W warm-up steps + {max(0, args.settle)} "
+                      f"more untimed steps (--settle) and the K timed steps"),
         },
         "matches": len(matches),
         "matches_per_s": round(len(matches) * args.steps / elapsed, 1),
@@ -448,11 +459,108 @@ def main():
         out["h2d_inclusive"] = h2d_inclusive(sassy_amd, args.profile, pat, host, k, len(matches))
         if not args.no_other_configs:
             out["other_configs"] = other_configs(sassy_amd, buf[:n_per])
+            out["other_configs"]["2_dense"] = dense_config(sassy_amd, buf[:n_per], pat, k)
     print(json.dumps(out), flush=True)
     if gather_worker is not None:
         gather_worker.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main_inproc(args):
+    """--mode inproc: the same workload and the same JSON line, driven through sassy_hip_multi_* from this one process
+    (a host thread, a bound searcher and a resident shard per device; shard results merged in C).  No torch, no RCCL."""
+    import sassy_amd
+    n_dev = sassy_amd.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a HIP device")
+    world = args.gpus
+    if world > n_dev and not args.allow_shared_gpu:
+        raise SystemExit(f"--gpus {world} but only {n_dev} HIP device(s) visible (one shard per GPU)")
+    devices = [g % n_dev for g in range(world)]
+    n_per = args.text_bytes // 64 * 64
+    total = n_per * world
+    m, k = args.pattern_len, args.k
+    pat = bytes(_dna_bytes(43, 0, m))
+    ms = sassy_amd.MultiSearcher(args.profile, devices=devices)
+    ms.generate_dna(total, 42, m, k)
+    planted = ms.plant(42, pat, k, args.plant_stride)
+    t_cold = time.perf_counter()
+    r = ms.search(pat, k)
+    cold_ms = (time.perf_counter() - t_cold) * 1e3
+    for _ in range(args.warmup + max(0, args.settle)):
+        r = ms.search(pat, k)
+    kern = [0.0] * world
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = ms.search(pat, k)
+        for g in range(world):
+            kern[g] += ms.shard_stats(g)["filter_ms"] or ms.shard_stats(g)["scan_ms"]
+    elapsed = time.perf_counter() - t0
+    st = ms.shard_stats(0)
+    dom_ms = max(kern) / args.steps
+    dom_name = {0: "scan_kernel", 1: "filter_kernel", 2: "filter_dna_kernel", 3: "filter_table_kernel", 4: "filter_count_kernel"}[int(st["filtered"])]
+    achieved = n_per / (dom_ms / 1e3) / 1e9 if dom_ms > 0 else 0.0
+    ms_per_step = elapsed / args.steps * 1e3
+    out = {
+        "metric": METRIC,
+        "value": round(total * args.steps / elapsed / 1e9, 3),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "cold_first_search_ms": round(cold_ms, 3),
+        "config": {
+            "workload": (f"BASELINE config {'2' if world == 1 else '5'}: Searcher::<{args.profile.capitalize()}>::new_fwd().search, "
+                         f"|pattern|={m} (seeded random), k={k}, {n_per} B random-ACGT text per GPU resident in HBM, one planted "
+                         f"near-match per {args.plant_stride} B; step = sassy_hip_multi_search: every device searches its shard at "
+                         f"once (scan + traceback + Match records on the host), the shard results are chained and merged in C"),
+            "text_bytes_per_gpu": n_per, "total_text_bytes": total, "pattern_len": m, "k": k, "profile": args.profile,
+            "searches_in_flight": 1,
+            "parallelism": f"text sharded x{world}, ONE process, a host thread per device (sassy_hip_multi_*), no torch.distributed / RCCL; devices {devices}",
+            "setup": f"one cold search, {args.warmup} warm-up + {max(0, args.settle)} settling searches, then the K timed searches (one at a time)",
+        },
+        "matches": len(r),
+        "matches_per_s": round(len(r) * args.steps / elapsed, 1),
+        "planted": planted,
+        "dominant_kernel_ms": round(dom_ms, 4),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": dom_name,
+                     "algorithmic_bytes_per_launch": n_per, "launch_ms": round(dom_ms, 4),
+                     "measured": "HIP events around the kernel on each shard searcher's stream inside the timed steps; the slowest device's average"},
+        "roofline_search": {"bound": "hbm", "achieved": round(n_per / (ms_per_step / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": round(n_per / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
+                            "what": "text bytes per GPU / ms_per_step, one multi-device search at a time"},
+        "cpu_baseline": None,
+        "cpu_baseline_note": "reported by the default mode at N = 1 (python bench.py)",
+    }
+    print(json.dumps(out), flush=True)
+
+
+def dense_config(sassy_amd, text, pat, k):
+    """SURVEY 8(d)'s dense variant of config 2 on the resident text (N = 1, after everything else: it plants a near-match
+    of the bench pattern every 4 096 bytes): the output path -- matches per second with the records on the host."""
+    n = text.numel()
+    planted = sassy_amd.plant(text.data_ptr(), n, 0, n, 42, pat, k, 4096)
+    s = sassy_amd.Searcher("dna", rc=False)
+    s.set_timing(0)
+    for _ in range(4):
+        r = s.search_shard(pat, text.data_ptr(), 0, n, 0, n, k)
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        r = s.search_shard(pat, text.data_ptr(), 0, n, 0, n, k)
+    dt = (time.perf_counter() - t0) / reps
+    st = s.stats()
+    return {"workload": f"config 2 with a planted near-match every 4 096 B ({planted} plants), {n} B, lone searches",
+            "ms_per_search": round(dt * 1e3, 3), "matches": len(r), "matches_per_s": round(len(r) / dt, 1),
+            "text_GB_per_s": round(n / dt / 1e9, 1), "fused": int(st["fused"]), "path": int(st["filtered"])}
 
 
 def other_configs(sassy_amd, text):

@@ -713,6 +713,15 @@ class MultiSearcher:
         _check(lib().sassy_hip_multi_search(self._h, pattern, len(pattern), k, flags, C.byref(out)))
         return Result(out)
 
+    def shard_stats(self, shard: int) -> dict:
+        """Stats of the last search on one shard's searcher (sassy_hip_multi_searcher)."""
+        st = Stats()
+        h = lib().sassy_hip_multi_searcher(self._h, shard)
+        if not h:
+            raise SassyHipError("no such shard")
+        _check(lib().sassy_hip_get_stats(h, C.byref(st)))
+        return st.as_dict()
+
     def set_rc(self, rc: bool = True):
         """Both strands: searches append the Rc strand's matches (Searcher::new_rc)."""
         _check(lib().sassy_hip_multi_set_rc(self._h, int(bool(rc))))
