@@ -190,16 +190,17 @@ def lib():
     L.sassy_hip_multi_plant.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)]
     L.sassy_hip_multi_search.restype = C.c_int
     L.sassy_hip_multi_search.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(vp)]
-    L.sassy_hip_multi_set_rc.restype = C.c_int
-    L.sassy_hip_multi_set_rc.argtypes = [vp, C.c_int]
-    L.sassy_hip_multi_set_replicated.restype = C.c_int
-    L.sassy_hip_multi_set_replicated.argtypes = [vp, C.c_int]
-    L.sassy_hip_multi_search_encoded.restype = C.c_int
-    L.sassy_hip_multi_search_encoded.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(vp)]
-    L.sassy_hip_multi_search_many.restype = C.c_int
-    L.sassy_hip_multi_search_many.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t,
-                                              C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_uint32,
-                                              C.POINTER(vp)]
+    if not os.environ.get("SASSY_HIP_LIBRARY"):  # (an older build loaded for an A/B timing lacks the newer entry points)
+        L.sassy_hip_multi_set_rc.restype = C.c_int
+        L.sassy_hip_multi_set_rc.argtypes = [vp, C.c_int]
+        L.sassy_hip_multi_set_replicated.restype = C.c_int
+        L.sassy_hip_multi_set_replicated.argtypes = [vp, C.c_int]
+        L.sassy_hip_multi_search_encoded.restype = C.c_int
+        L.sassy_hip_multi_search_encoded.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(vp)]
+        L.sassy_hip_multi_search_many.restype = C.c_int
+        L.sassy_hip_multi_search_many.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t,
+                                                  C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_uint32,
+                                                  C.POINTER(vp)]
     L.sassy_hip_multi_free.restype = None
     L.sassy_hip_multi_free.argtypes = [vp]
     L.sassy_hip_set_only_best_match.restype = C.c_int

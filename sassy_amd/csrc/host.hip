@@ -1347,10 +1347,10 @@ int ScanJob::prepare() {
       F.dp_first_owned = first_owned;
       static const int env_qcap = getenv("SASSY_HIP_FUSED_QCAP") ? atoi(getenv("SASSY_HIP_FUSED_QCAP")) : 0;
       // chunks per wave between two chunk-DP passes: a wave runs a pass when more than cap - 128 are queued (a full
-      // batch of 64 lanes), so the queue never overflows; + the count (16 bytes) + one word per lane for the text check;
-      // 4 workgroups per CU still fit the LDS: 4 x 4 x (8192 + 1536 + 16 + 256) = 160 000 bytes
+      // batch of 64 lanes), so the queue never overflows; + the count (16 bytes);
+      // 4 workgroups per CU still fit the LDS: 4 x 4 x (8192 + 1536 + 16) = 155 904 bytes
       F.fuse_queue_cap = env_qcap > 128 ? (uint32_t)env_qcap : 192u;
-      F.lds_per_wave += F.fuse_queue_cap * 8u + 16u + 256u;
+      F.lds_per_wave += F.fuse_queue_cap * 8u + 16u;
     }
     {
       // Searches in flight on several lanes: the filter's long-lived workgroups would fill every CU (4 waves

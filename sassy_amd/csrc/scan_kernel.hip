@@ -1815,28 +1815,16 @@ __device__ __noinline__ rep4 fuse_add_range(uint2* queue, uint32_t* qcount, uint
 // (the host does not try again on that text).
 // (CHECK) do these 16 text bytes hold anything but plain bases?  The letter a byte's code stands for
 // (v_perm selectors 0 / 2 / 4 / 6 = twice the code -> A C T G) against the byte without its case bit, summed by v_sad_u8.
-__device__ __forceinline__ bool other_letters16(const uint4 v) {
+__device__ __forceinline__ uint32_t other_letters_sum16(const uint4 v, uint32_t diff) {
   const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
-  uint32_t diff = 0;
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
     const uint32_t want = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, w4[d] & 0x06060606u);
     diff = __builtin_amdgcn_sad_u8(w4[d] & 0xDFDFDFDFu, want, diff);
   }
-  return diff != 0u;
+  return diff;  // (sums of absolute differences: 0 stays 0 only while every byte is a plain base)
 }
-// (CHECK, rare path) the staging lane found other letters in the 16-byte pieces `dm` (bit i = staging instruction i):
-// it tells the lanes that own those blocks -- dirty[owner] |= 1 << (piece of the owner's staged pair, 0 .. 7).
-__device__ __noinline__ void note_dirty_pieces(uint32_t* dirty, uint32_t lane, uint32_t dm) {
-  while (dm) {
-    const uint32_t i = (uint32_t)__ffs((int)dm) - 1u;
-    dm &= dm - 1u;
-    const uint32_t owner = i * 8u + lane / 8u;
-    const uint32_t j = (lane % 8u) ^ ((owner >> 1) & 7u);  // the piece's place in the owner's 128 bytes
-    atomicOr(&dirty[owner], 1u << j);
-  }
-}
-
+__device__ __forceinline__ bool other_letters16(const uint4 v) { return other_letters_sum16(v, 0u) != 0u; }
 template <int Q, int NPG, bool FUSED, bool CHECK = false>
 // (CHECK: four waves per SIMD are asked for -- left to itself the compiler settles for three, 0.59 instead of 0.52 ms)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 : 1))) void filter_dna_kernel(const ScanParams P) {
@@ -1872,10 +1860,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
   if constexpr (FUSED) asm volatile("" : "+s"(Pk), "+v"(lane), "+s"(wave));
   unsigned char* tile = smem + (size_t)wave * Pk->lds_per_wave;
   // FUSED: the wave's chunk queue behind the tile: fuse_queue_cap entries {first block, blocks << 6 | byte shift}, then
-  // the count (16 bytes), then (CHECK) one word per lane: the dirty pieces of the block pair it owns in the tile
+  // the count (16 bytes)
   uint2* queue = reinterpret_cast<uint2*>(tile + kTile);
   uint32_t* qcount = reinterpret_cast<uint32_t*>(tile + kTile + (size_t)Pk->fuse_queue_cap * 8u);
-  uint32_t* dirty = qcount + 4;
   const uint64_t group = (uint64_t)blockIdx.x + Pk->group_offset;
   const uint32_t bpl = Pk->bpl;
   const uint64_t first_owned = Pk->first_owned_block;
@@ -1899,7 +1886,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
   if constexpr (FUSED) {
     if (first_segment) {
       if (lane == 0) *qcount = 0;
-      if constexpr (CHECK) dirty[lane] = 0u;
     }
     if (Pk->fused & 2u) probe_t0 = wall_clock64();
   }
@@ -1943,7 +1929,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
     nxt[i] = make_uint4(0u, 0u, 0u, 0u);
     if (interior && seg_it < n_iter) nxt[i] = stream_load16<SASSY_NT_DNA>(text_base + (uint64_t)seg_it * 64 + soff[i]);
   }
-  uint32_t dmask = 0;  // (CHECK) dirty pieces of the lane's staged pair
   uint32_t npure = 0;  // (CHECK) how many blocks of nothing but N the lane has just walked over
   if constexpr (CHECK) {
     if (!first_segment) npure = (reinterpret_cast<const uint32_t*>(tile + kSegState) + lane)[384];
@@ -1953,16 +1938,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
   for (; it < n_iter; ++it) {
     const uint32_t sub = it & 1u;
     if (sub == 0) {
-      uint32_t dm = 0;  // (CHECK) the pieces this lane staged that hold other letters, bit i = instruction i
       if (interior) {
 #pragma unroll
-        for (int i = 0; i < kStageInstr; ++i) {
-          *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = nxt[i];
-          if constexpr (CHECK) dm |= other_letters16(nxt[i]) ? (1u << i) : 0u;
-        }
-        // (the next loads go into the registers the check has just read: scheduled in front of it they would need
-        // 32 more)
-        if constexpr (CHECK) __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < kStageInstr; ++i) *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = nxt[i];
         if (it + SB < n_iter) {
 #pragma unroll
           for (int i = 0; i < kStageInstr; ++i)
@@ -1974,22 +1952,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
           const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
           uint4 v;
           if (off + 16 <= Pk->text_len) v = *reinterpret_cast<const uint4*>(Pk->text + off);
-          else v = load_tail16(Pk->text, off, Pk->text_len);
+          else v = load_tail16(Pk->text, off, Pk->text_len);  // (bytes behind the end of the text read as 'X')
           *reinterpret_cast<uint4*>(tile + i * 1024 + lane * 16) = v;
-          // (bytes behind the end of the text read as 'X': other letters where no match can end)
-          if constexpr (CHECK) dm |= other_letters16(v) ? (1u << i) : 0u;
         }
-      }
-      if constexpr (CHECK) {
-        // Other letters are handled where they lie: the owner of the block treats every such 16-byte piece like a piece
-        // occurrence -- whatever match touches it ends within m + k columns behind it -- and the chunk DP of a CHECK
-        // launch is the Iupac one.  (One word per lane in LDS; same wave: the LDS operations complete in order.)
-        if (dm != 0) note_dirty_pieces(dirty, lane, dm);
-        dmask = dirty[lane];
-        if (dmask != 0) dirty[lane] = 0u;
       }
     }
     uint2 t0, t1;
+    uint32_t dsum = 0;  // (CHECK) != 0: the block holds other letters
     {
       const uint32_t hs = (((sub << 2) ^ (fsw & 4u)) << 4);
       uint32_t x[16];
@@ -2000,6 +1969,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
       }
       t0 = bit_plane<1>(x);  // code bit 0
       t1 = bit_plane<2>(x);  // code bit 1
+      // (CHECK) Other letters are handled where they lie, by the lane that owns the block: does it hold anything but
+      // plain bases?  (four chains of sums of absolute differences against the letter each byte's code stands for; the
+      // rare path below sorts out which 16-byte pieces they are in.)  The staging lanes used to check what they loaded
+      // and tell the owners through LDS: a vote, a call and a word that lives across the block pair -- 0.54 -> 0.65 ms.
+      if constexpr (CHECK) {
+        uint32_t d4[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          const uint32_t want = __builtin_amdgcn_perm(0x00470054u, 0x00430041u, x[c] & 0x06060606u);
+          d4[c & 3] = __builtin_amdgcn_sad_u8(x[c] & 0xDFDFDFDFu, want, d4[c & 3]);
+        }
+        dsum = (d4[0] | d4[1]) | (d4[2] | d4[3]);
+      }
     }
     // the piece rows' bits, opaque to the optimiser inside the loop: what is derived from them below (one scalar
     // per term) is computed here, per iteration, on the scalar unit, instead of living in 2 * Q * pieces registers
@@ -2040,11 +2022,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
     uint32_t hit = 0;
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) hit |= al[pp] | ah[pp];
-    if constexpr (CHECK) {
-      const uint32_t dpc = (dmask >> (4u * sub)) & 15u;  // this block's dirty pieces
-      hit |= dpc | (npure >= Pk->wb ? 16u : 0u);         // (a lane inside a long run of N looks at every block)
-      if (dpc != 15u && npure < Pk->wb) npure = 0;       // (inside one, the rare path below decides)
-    }
+    // (CHECK: this block's dirty pieces; a lane that counts blocks of N looks at every block -- the rare path keeps the count)
+    if constexpr (CHECK) hit |= dsum | npure;
     const uint64_t b = blk0 + it;
     const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
     if (evaluate && hit != 0) {
@@ -2055,19 +2034,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
         // all: a run of N costs the windows around its two ends, whatever its length (a genome's centromere gaps are
         // megabases).  Lists of ALL end positions <= k have every one of them: no short cut there.
         bool n_inside = false, n_leaving = false;
+        uint32_t dp = 0;  // (CHECK) the block's 16-byte pieces that hold other letters
         if constexpr (CHECK) {
           const bool was_long = npure >= Pk->wb;
           bool pure = false;
-          if (((dmask >> (4u * sub)) & 15u) == 15u && !(Pk->flags & kScanAllMinima) && b + 1 < Pk->n_blocks) {
+          if (dsum != 0u) {  // (the block, once more, from the tile: which pieces, and is it nothing but N?)
             const uint32_t hs2 = (((sub << 2) ^ (fsw & 4u)) << 4);
             uint32_t acc = 0;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               const uint4 v = *reinterpret_cast<const uint4*>(tile + rc[c] + hs2);
+              if (other_letters16(v)) dp |= 1u << c;
               acc |= ((v.x & 0xDFDFDFDFu) ^ 0x4E4E4E4Eu) | ((v.y & 0xDFDFDFDFu) ^ 0x4E4E4E4Eu) |
                      ((v.z & 0xDFDFDFDFu) ^ 0x4E4E4E4Eu) | ((v.w & 0xDFDFDFDFu) ^ 0x4E4E4E4Eu);
             }
-            pure = acc == 0u;
+            pure = acc == 0u && !(Pk->flags & kScanAllMinima) && b + 1 < Pk->n_blocks;
           }
           n_inside = pure && was_long;
           n_leaving = !pure && was_long;
@@ -2096,7 +2077,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
           }
         }
         if constexpr (CHECK) {
-          const uint32_t dp = (dmask >> (4u * sub)) & 15u;
           if (dp != 0) {
             // a match that touches text byte t ends in [t + 1, t + m + k] (+ 1 column: the report rule decides about a
             // position when it sees the next one); t = the pieces' first .. last byte
@@ -2222,7 +2202,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
       dsc.own_hi = e.x + ((e.y >> 6) & 0xFFu);
       dsc.flags = kDescWindow;
       dsc.pad_ = (e.y & 63u) | ((e.y >> 14) << 8);  // byte shift | columns not to report << 8
+#if !defined(SASSY_EXP) || !(SASSY_EXP & 1)
       list_lanes<CHECK ? (int)PROFILE_IUPAC : (int)PROFILE_DNA, 4, true>(L, mask_bytes, carry, dlane, has, dsc, kNoStateSlot);
+#else
+      list_lanes<(int)PROFILE_DNA, 4, true>(L, mask_bytes, carry, dlane, has, dsc, kNoStateSlot);
+#endif
     }
     if ((kp->fused & 2u) && dlane == 0) {
       unsigned long long* pc = reinterpret_cast<unsigned long long*>(L.cand_count + 4);  // the control block's counters

@@ -102,10 +102,20 @@ __global__ __launch_bounds__(256) void tiled_scan_kernel(const TiledParams P) {
         for (uint32_t i = 0; i < 8; ++i)
           eq[i] = *reinterpret_cast<const Word*>(lane_lds + (uint32_t)__builtin_amdgcn_readlane((int)off, (int)(g + i)));
         if (owned) {
+          // (one look per eight characters whether any of them ended a match: a compare and a branch per character were
+          // a third of the loop's instructions)
+          int c8[8];
+          int lowest = 0x7FFFFFFF;
 #pragma unroll
           for (uint32_t i = 0; i < 8; ++i) {
             tiled_step(S, eq[i], top_shift);
-            if (S.cost <= kk) tiled_emit(P, pos0 + g + i, S.cost, pat);
+            c8[i] = S.cost;
+            lowest = min(lowest, S.cost);
+          }
+          if (lowest <= kk) {
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i)
+              if (c8[i] <= kk) tiled_emit(P, pos0 + g + i, c8[i], pat);
           }
         } else {  // warm-up: nothing is reported
 #pragma unroll

@@ -16,7 +16,10 @@ def run(profile, p, k, steps=5):
     dt = (time.perf_counter() - t0) / steps
     st = s.stats()
     print(json.dumps({"profile": profile, "m": len(p), "k": k, "ms": round(dt*1e3, 3), "matches": len(r),
-        **{q: (round(st[q], 3) if isinstance(st[q], float) else st[q]) for q in ("filtered", "piece_len", "filter_ms", "scan_ms", "trace_ms", "hit_blocks", "chunks")}}), flush=True)
+        "path": {0: "streaming DP (scan_kernel)", 1: "slot-mask filter + chain", 2: "bit-plane filter" + (", fused launch" if st["fused"] else " + chain"),
+                 3: "q-gram table filter + chain", 4: "q-gram counting filter + chain"}[int(st["filtered"])],
+        "roofline_frac_lone": round(n / dt / 8e12, 4),
+        **{q: (round(st[q], 3) if isinstance(st[q], float) else st[q]) for q in ("filtered", "fused", "piece_len", "filter_ms", "scan_ms", "trace_ms", "hit_blocks", "chunks")}}), flush=True)
 run("dna", pat(32, 43), 3)
 run("iupac", pat(32, 43), 3)
 p = bytearray(pat(200, 44)); p[50], p[100], p[150], p[199] = ord("N"), ord("R"), ord("Y"), ord("W")
@@ -25,3 +28,14 @@ run("iupac", pat(20, 45), 2)
 run("dna", pat(100, 46), 10)
 run("iupac", pat(64, 47), 6)
 run("iupac", pat(1000, 48), 100, steps=2)
+# the reference's own canonical shapes (benches/perf.rs:46-48: CRISPR guide 20 + NGG, k = 3) and the k / m ratios
+# between 1/8 and 1/5, where the choice of path flips
+run("iupac", pat(20, 49) + b"NGG", 3)
+run("dna", pat(23, 49), 3)
+run("dna", pat(32, 43), 4)
+run("dna", pat(32, 43), 5)
+run("dna", pat(32, 43), 6)
+run("dna", pat(64, 47), 8)
+run("dna", pat(64, 47), 12)
+run("dna", pat(50, 50), 10)
+run("iupac", pat(32, 43), 5)
