@@ -141,6 +141,8 @@ struct ScanParams {
   // filter's, which also looks at the last halo blocks); fuse_queue_cap = chunks a wave's LDS queue holds
   uint32_t fused;
   uint32_t fuse_queue_cap;
+  uint32_t fuse_press;        // a wave runs a chunk-DP pass between two block pairs once this many chunks are queued
+                              // (<= fuse_queue_cap - 128: between two looks every lane queues at most two)
   uint64_t dp_first_owned;
   TextStash* stash;           // fused: the text under the reports (stash_cap slots), or null
   uint32_t stash_cap;

@@ -1351,6 +1351,9 @@ int ScanJob::prepare() {
       // 4 workgroups per CU still fit the LDS: 4 x 4 x (8192 + 1536 + 16) = 155 904 bytes
       F.fuse_queue_cap = env_qcap > 128 ? (uint32_t)env_qcap : 192u;
       F.lds_per_wave += F.fuse_queue_cap * 8u + 16u;
+      static const int env_press = getenv("SASSY_HIP_FUSED_PRESS") ? atoi(getenv("SASSY_HIP_FUSED_PRESS")) : 0;
+      F.fuse_press = F.fuse_queue_cap - 128u;
+      if (env_press > 0 && (uint32_t)env_press < F.fuse_press) F.fuse_press = (uint32_t)env_press;
     }
     {
       // Searches in flight on several lanes: the filter's long-lived workgroups would fill every CU (4 waves

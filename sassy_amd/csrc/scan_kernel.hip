@@ -1920,7 +1920,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
       run = make_rep4(sv[128], sv[192], sv[256], sv[320]);
     }
   }
-  const uint32_t press_at = Pk->fuse_queue_cap > 128u ? Pk->fuse_queue_cap - 128u : 0u;
+  const uint32_t press_at = Pk->fuse_press;
 
   // software pipeline: the loads of the next staging step are in flight while this one is processed
   uint4 nxt[kStageInstr];
@@ -2187,12 +2187,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
     asm volatile("" : "+v"(dlane), "+s"(dwave));
     unsigned char* dtile = smem + (size_t)dwave * kp->lds_per_wave;
     const uint2* dqueue = reinterpret_cast<const uint2*>(dtile + kTile);
-    if (dlane == 0) atomicAdd(&L.cand_count[1], last ? nq : (nq & ~63u));  // statistics: chunks
+    const uint32_t n_run = (last || nq < 64u) ? nq : (nq & ~63u);
+    if (dlane == 0) atomicAdd(&L.cand_count[1], n_run);  // statistics: chunks
     // the DP's LDS -- slot masks, per-row carries -- takes the place of the text tile
     unsigned char* mask_bytes = dtile;
     uint32_t* carry = reinterpret_cast<uint32_t*>(dtile + 4 * 512);
     // between segments only full batches of 64 chunks run; what is left over waits for the next pass
-    const uint32_t n_run = last ? nq : (nq & ~63u);
     for (uint32_t base = 0; base < n_run; base += 64u) {
       const bool has = base + dlane < n_run;
       uint2 e = make_uint2(0u, 0u);
@@ -2219,7 +2219,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
     // the queue keeps what did not fill a batch; the tile is the next segment's: the DP's LDS traffic is complete before
     // its first staging store (one wave, in-order LDS); the fence keeps the compiler from reordering across it
     {
-      const uint32_t left = (last || (Pk->fused & 4u)) ? 0u : (nq & 63u);
+      const uint32_t left = (last || (Pk->fused & 4u) || nq < 64u) ? 0u : (nq & 63u);
       uint2 keep_e = make_uint2(0u, 0u);
       if (lane < left) keep_e = queue[(nq & ~63u) + lane];
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -2,7 +2,7 @@
 # tools/refresh_profiles.sh <round-tag> -- ON THE GPU BOX (via gpurun): every measurement profiles/ holds,
 # written under gpurun_out/refresh/ (copy the files into profiles/ afterwards: tools/collect_profiles.sh).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r04}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/refresh
@@ -71,6 +71,17 @@ python tools/bench_encoded.py > $OUT/${TAG}_encoded_paths.txt 2> $OUT/encoded.er
 python tools/bench_crispr.py > $OUT/${TAG}_crispr.json 2> $OUT/crispr.err
 python tools/bench_crispr.py --genome-like >> $OUT/${TAG}_crispr.json 2>> $OUT/crispr.err
 python tools/bench_texts.py > $OUT/${TAG}_texts.json 2> $OUT/texts.err
+# ---- kernel timelines of lone searches on the texts that are not i.i.d. (dense plants, N runs under Iupac, poly-A, microsatellite)
+{ echo "# lone searches of tools/bench_texts.py cases under rocprofv3 --kernel-trace (tools/prof_texts.sh): the last dispatches in time order, then totals";
+  TAIL_N=22 bash tools/prof_texts.sh iid_plant_4KiB repeatsN_iupac_random32 repeats_polyA repeats_family32 repeats_ACx16; } > $OUT/${TAG}_texts_timelines.txt 2>&1
+# ---- this tree against the previous round's library on the same box (sassy_amd/lib/libsassy_hip_r3.so, when it was built)
+if [ -f sassy_amd/lib/libsassy_hip_r3.so ]; then
+  { echo "# tools/ab.sh: lone config-2 search (tools/probe_fused.py), round-3 library / this tree, alternating on one box";
+    echo "## Dna"; bash tools/ab.sh 3; echo "## Iupac searcher, plain pattern (CHECK launch)"; bash tools/ab.sh 3 PROBE_PROFILE=iupac; } > $OUT/${TAG}_ab_vs_r03.txt 2>&1
+fi
+# ---- the multi-device searcher as the bench line's driver (one device here), and the RCCL preflight's script on gloo
+python bench.py --mode inproc --gpus 1 --no-cpu-baseline > $OUT/${TAG}_bench_inproc.json 2>> $OUT/bench.err
+python tools/preflight_multigpu.py --gpus 2 --backend gloo 2>/dev/null | tail -1 > $OUT/${TAG}_preflight_gloo.json
 { python tools/bench_reads.py; python tools/bench_reads.py --reads 330000; python tools/bench_reads.py --overhang 0.5; } > $OUT/${TAG}_reads.json 2> $OUT/reads.err
 { python tools/probe_count.py; python tools/probe_rc.py; } > $OUT/${TAG}_shapes.json 2> $OUT/shapes.err
 python tools/cpu_probe.py > $OUT/${TAG}_host_cpus.txt 2>&1
