@@ -119,9 +119,12 @@ int sassy_hip_set_prefilter(sassy_SearcherType *s, int mode);
  * wavefront runs the chunk DP over the match-end blocks it found itself when it has streamed its text range
  * (no hit bitmap, no chunk-list kernel, no list kernel).  on = 1 (default; process-wide: SASSY_HIP_FUSED=0 turns it
  * off), 0 = always the classic chain.  Same matches either way; stats.fused tells which one ran.
- * An Iupac searcher takes the same launch when its pattern holds plain A C G T only (<= 4 pieces) and the text does
- * too: the launch checks every text byte, and one other letter sends the search to the Iupac chain (and the searcher
- * does not try again on that text; SASSY_HIP_IUPAC_PLANES=0 turns the attempt off). */
+ * An Iupac searcher takes the same launch when its pattern holds plain A C G T only (<= 4 pieces), on ANY text: the lane
+ * that owns a block checks it for other letters and queues the columns a match touching them can end in; the chunk DP of
+ * such a launch builds the Iupac profile's masks; the inside of a run of N is walked over, not searched (cost 0
+ * everywhere: nothing to report under the report rule) -- SASSY_HIP_IUPAC_PLANES=0 turns the launch off.
+ * What the fused launch cannot finish alone (a report on a long FLAT plateau of cost > 0 whose beginning no window
+ * sees, a shard's exit state on such a plateau) sends that one search to the classic chain. */
 int sassy_hip_set_fused(sassy_SearcherType *s, int on);
 /* Which reports a search of ONE text returns on low-complexity text (sassy_hip_search, the drop-in search):
  * 0 (default) = the definition -- one left-to-right pass over the text, independent of any chunking;

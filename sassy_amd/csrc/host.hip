@@ -173,15 +173,27 @@ struct PinPool {
       }
     return false;
   }
+  // newest block in, oldest blocks out: after a few dense searches the pool holds their 100 MB blocks, and a
+  // following stream of small results must still find its own block sizes kept (dropping the NEW block instead
+  // cost every such search a hipHostFree + hipHostMalloc, about 0.9 ms)
   void give(const PinBlock& b) {
     if (!b.h) return;
+    std::vector<PinBlock> drop;
     {
       std::lock_guard<std::mutex> g(mu);
-      size_t kept = 0;
-      for (const PinBlock& x : blocks) kept += x.cap;
-      if (blocks.size() < kKeep && kept + b.cap <= kKeepBytes) { blocks.push_back(b); return; }
+      if (b.cap > kKeepBytes) drop.push_back(b);
+      else {
+        blocks.push_back(b);
+        size_t kept = 0;
+        for (const PinBlock& x : blocks) kept += x.cap;
+        while (blocks.size() > kKeep || kept > kKeepBytes) {
+          kept -= blocks.front().cap;
+          drop.push_back(blocks.front());
+          blocks.erase(blocks.begin());
+        }
+      }
     }
-    (void)hipHostFree(b.h);
+    for (const PinBlock& x : drop) (void)hipHostFree(x.h);
   }
 };
 static PinPool g_pin_pool;
