@@ -266,6 +266,13 @@ struct MatchOut {
   uint32_t cigar_len;
 };
 
+// One strand's pass of search_many over a batch of texts, records still on the device (sort_kernels.hip: assemble).
+struct ManyPart {
+  const MatchOut* rows;
+  const char* strs;   // record i's cigar string at i * str_stride
+  uint32_t n;
+};
+
 // Reports are ranked (sorted by end position) on the device up to this many; beyond it the host sorts.
 constexpr uint32_t kRankLimit = 32768;
 // The trace kernel keeps its 64 per-thread slices (+ the pattern) in LDS up to this many bytes.

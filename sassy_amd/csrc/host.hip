@@ -85,6 +85,10 @@ hipError_t launch_drop_excluded(const Candidate* d_in, uint32_t count, const uns
 hipError_t launch_compact_candidates(const Candidate* d_in, uint32_t count, const unsigned char* d_keep, Candidate* d_out,
                                      uint32_t* d_out_count, void* d_scratch, size_t scratch_bytes, hipStream_t stream);
 hipError_t launch_tiled_scan(const TiledParams& P, hipStream_t stream);
+size_t many_scratch_bytes(uint32_t count);
+hipError_t launch_assemble_many(const ManyPart& a, const ManyPart& b, uint32_t n_texts, const uint64_t* d_text_len,
+                                uint64_t first_text, uint32_t str_stride, MatchOut* d_rows, char* d_strs, uint32_t* d_flags,
+                                void* d_scratch, size_t scratch_bytes, hipStream_t stream);
 hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable& texts, uint32_t* d_report_text,
                                hipStream_t stream);
 
@@ -2672,14 +2676,23 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
 // tt / ht: the buffer holds several texts (device / host tables): a report learns its text from its position,
 // reports inside a separator are moved to their text's end (search_all: dropped), the records carry text-relative
 // coordinates and the text's index in the buffer.
+// defer (search_many over a batch of texts, traced, no report filters, not search_all): the records stay on the
+// device -- in the buffers of lane defer->lane -- for assemble_many, nothing is appended to R.
+struct ManyDefer {
+  int lane = 0;
+  ManyPart part{nullptr, nullptr, 0};
+  uint32_t str_stride = 0;
+};
 static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, const PatternPlan& plan0,
                                const uint8_t* tptr, const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all,
                                bool wo, uint32_t count, bool copies, sassy_hip_Result* R,
-                               const TextTable* tt = nullptr, const HostTexts* ht = nullptr) {
+                               const TextTable* tt = nullptr, const HostTexts* ht = nullptr, ManyDefer* defer = nullptr) {
+  if (defer && (wo || all || !tt)) return fail(SASSY_HIP_EINVAL, "internal: deferred records need a traced, multi-text search");
   ScanLane& L = s->lanes[0];
   hipStream_t st = s->stream;
   const uint32_t m = (uint32_t)e->plen;
   uint32_t counts[2] = {count, 0};
+  g_marks.mark("list: scan");
   // ---- (pattern, position) order, then the report rule ----
   if (int rc = L.d_sorted.reserve(count)) return rc;
   if (int rc = L.d_sort.reserve(std::max(sort_scratch_bytes(count), select_scratch_bytes(count)))) return rc;
@@ -2700,6 +2713,7 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
     HIP_TRY(hipMemcpyAsync(s->d_tiled_cnt.p + 1, &count, 4, hipMemcpyHostToDevice, st));
   }
   if (n_rep == 0) return 0;
+  g_marks.mark("list: sort+rule");
   std::vector<uint32_t> rtext;
   if (tt) {  // several texts: which one a report belongs to; reports inside separators
     if (d_rep == L.d_sorted.p) {  // (search_all without copies: the sorted list itself is the report list)
@@ -2727,8 +2741,9 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
     str_stride = (uint32_t)strb;
     if ((uint64_t)n_rep * strb > 0xFFFFFFFFull)
       return fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB");
-    if (int rc = L.d_trace.reserve(n_rep)) return rc;
-    if (int rc = L.d_str.reserve((size_t)n_rep * strb)) return rc;
+    ScanLane& LT = defer ? s->lanes[defer->lane] : L;  // (the same stream: only the buffers are the other lane's)
+    if (int rc = LT.d_trace.reserve(n_rep)) return rc;
+    if (int rc = LT.d_str.reserve((size_t)n_rep * strb)) return rc;
     TraceParams T{};
     T.text = tptr;
     T.total_len = text_len;
@@ -2743,8 +2758,8 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
     T.scratch_stride = (uint32_t)wstride;
     T.band_bytes = (uint32_t)band;
     T.win_bytes = (uint32_t)win;
-    T.out = L.d_trace.p;
-    T.out_str = L.d_str.p;
+    T.out = LT.d_trace.p;
+    T.out_str = LT.d_str.p;
     T.str_stride = str_stride;
     T.ops_bytes = (uint32_t)opsb;
     T.wave_mode = 1;
@@ -2759,6 +2774,11 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
     le = launch_trace(T, (uint32_t)std::min<uint64_t>(1024, ((uint64_t)n_rep + 3) / 4), st);
     if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
     HIP_TRY(hipEventRecord(s->ev_multi, st));
+    if (defer) {
+      defer->part = ManyPart{LT.d_trace.p, reinterpret_cast<const char*>(LT.d_str.p), n_rep};
+      defer->str_stride = str_stride;
+      return 0;
+    }
     rows.resize(n_rep);
     pool.resize((size_t)n_rep * strb);
     if (int rc = L.download(rows.data(), L.d_trace.p, (size_t)n_rep * sizeof(MatchOut))) return rc;
@@ -2770,6 +2790,7 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
   if (int rc = L.download(reps.data(), d_rep, (size_t)n_rep * sizeof(Candidate))) return rc;
   if (tt)
     if (int rc = L.download(rtext.data(), s->d_tiled_rtext.p, (size_t)n_rep * sizeof(uint32_t))) return rc;
+  g_marks.mark("list: trace+copy");
   if (tt && all) {  // drop the reports that lie in separators (their records were not written)
     size_t w = 0;
     for (size_t i = 0; i < n_rep; ++i) {
@@ -2808,6 +2829,7 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
       r.strand = p >= e->n_original ? 1 : 0;
       r.cigar_off += (uint32_t)base;
     }
+    g_marks.mark("list: adopt rows");
     return 0;
   }
   size_t i0 = 0;
@@ -2929,7 +2951,7 @@ static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, co
 static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
                                 const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
                                 sassy_hip_Result* R, bool* done, const TextTable* tt = nullptr,
-                                const HostTexts* ht = nullptr) {
+                                const HostTexts* ht = nullptr, ManyDefer* defer = nullptr) {
   *done = false;
   const size_t npat = e->patterns.size();
   const uint32_t m = (uint32_t)e->plen;
@@ -2958,7 +2980,7 @@ static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* 
   s->stats.candidates += count;
   *done = true;
   if (count == 0) return 0;
-  return finish_pattern_list(s, e, plan0, tptr, h_text, text_len, k, all, wo, count, false, R, tt, ht);
+  return finish_pattern_list(s, e, plan0, tptr, h_text, text_len, k, all, wo, count, false, R, tt, ht, defer);
 }
 
 // The seeded search on a text with other letters than ACGT (Iupac searcher; seed_kernels.hip, second half).  The
@@ -3118,7 +3140,7 @@ static int seeded_dirty_zones(sassy_SearcherType* s, const sassy_hip_Encoded* e,
 static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
                                  const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
                                  sassy_hip_Result* R, bool* done, const TextTable* tt = nullptr,
-                                 const HostTexts* ht = nullptr, bool dirty_text = false) {
+                                 const HostTexts* ht = nullptr, bool dirty_text = false, ManyDefer* defer = nullptr) {
   *done = false;
   hipStream_t st = s->stream;
   const size_t npat = e->patterns.size();
@@ -3373,7 +3395,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   s->stats.candidates += out_count;
   *done = true;
   if (out_count == 0) return 0;
-  return finish_pattern_list(s, e, plan0, tptr, h_text, text_len, k, all, wo, out_count, true, R, tt, ht);
+  return finish_pattern_list(s, e, plan0, tptr, h_text, text_len, k, all, wo, out_count, true, R, tt, ht, defer);
 }
 
 static void reset_stats(sassy_SearcherType* S) { S->stats = sassy_hip_Stats{}; }
@@ -3651,6 +3673,54 @@ static bool many_tiled_wanted(const sassy_SearcherType* s, const size_t* pattern
   return est_tiled < est_chains;
 }
 
+// Both strands' passes over one batch have left their records on the device (ManyDefer): one sort of (pattern, text,
+// strand) keys, one kernel that writes every record -- final text index, strand, coordinates -- and its cigar string
+// to its place in the result order, two DMA copies into a pinned block that the result keeps.  The host used to take
+// the records through vectors, an append, a loop per strand and a stable sort of 64-byte rows: 35 of the 49 ms of
+// 96 barcodes x 330 000 reads.
+static int assemble_many(sassy_SearcherType* s, const ManyDefer& fwd, const ManyDefer& rcd, uint32_t n_texts,
+                         const uint64_t* d_text_len, uint64_t first_text, sassy_hip_Result* R) {
+  const uint64_t n = (uint64_t)fwd.part.n + rcd.part.n;
+  if (n == 0) return 0;
+  if (n > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "more than 2^32 records in one result");
+  const uint32_t strb = fwd.part.n ? fwd.str_stride : rcd.str_stride;
+  if (n * strb > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB");
+  ScanLane& L = s->lanes[0];
+  ScanLane& LO = s->lanes[2];  // (its record / string buffers take the assembled result)
+  hipStream_t st = s->stream;
+  if (int rc = LO.d_trace.reserve(n)) return rc;
+  if (int rc = LO.d_str.reserve(n * strb)) return rc;
+  if (int rc = L.d_sort.reserve(many_scratch_bytes((uint32_t)n))) return rc;
+  if (int rc = L.d_flags.reserve(4)) return rc;
+  HIP_TRY(hipMemsetAsync(L.d_flags.p, 0, 4, st));
+  hipError_t le = launch_assemble_many(fwd.part, rcd.part, n_texts, d_text_len, first_text, strb, LO.d_trace.p,
+                                       reinterpret_cast<char*>(LO.d_str.p), L.d_flags.p, L.d_sort.p, L.d_sort.cap, st);
+  if (le != hipSuccess) return hip_fail(le, "result assembly launch");
+  const size_t rows_off = 256, strs_off = (rows_off + n * sizeof(MatchOut) + 255) / 256 * 256;
+  const size_t bytes = strs_off + n * strb + 256;
+  if (int rc = L.reserve_pinned(bytes)) return rc;
+  HIP_TRY(hipMemcpyAsync(L.h_pin, L.d_flags.p, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(L.h_pin + rows_off, LO.d_trace.p, n * sizeof(MatchOut), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(L.h_pin + strs_off, LO.d_str.p, n * strb, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  uint32_t flags = 0;
+  memcpy(&flags, L.h_pin, 4);
+  if (flags) return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
+  const sassy_hip_Match* hm = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + rows_off);
+  const char* hs = reinterpret_cast<const char*>(L.h_pin + strs_off);
+  if (g_pin_pool.may_adopt(L.h_pin_cap)) {
+    R->pin = L.take_pin();
+    R->ext_matches = hm;
+    R->ext_n = n;
+    R->ext_pool = hs;
+    R->ext_pool_len = n * strb;
+  } else {
+    R->matches.assign(hm, hm + n);
+    R->pool.assign(hs, n * strb);
+  }
+  return 0;
+}
+
 static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patterns, const size_t* pattern_lens,
                                size_t n_patterns, const uint8_t* const* texts, const size_t* text_lens, size_t n_texts,
                                size_t k, uint32_t flags, sassy_hip_Result* R, bool& handled, bool tiled_only = false) {
@@ -3758,6 +3828,13 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
         if (use) {
           const size_t batch_first = R->matches.size(), pool_first = R->pool.size();
           tiled_done = true;
+          // the whole call is this one batch, traced, every report is a record: the records are put in order on the
+          // device (assemble_many; SASSY_HIP_MANY_ASSEMBLE=0: by the host, as for several batches)
+          const bool env_noasm = getenv("SASSY_HIP_MANY_ASSEMBLE") && atoi(getenv("SASSY_HIP_MANY_ASSEMBLE")) == 0;  // (per call: tests flip it)
+          const bool on_device = !env_noasm && !wo && !all && std::isnan(s->max_n_frac) && !s->only_best && t0 == 0 &&
+                                 t1 == n_texts && batch_first == 0 && pool_first == 0 && !R->pin.h;
+          ManyDefer defer[2];
+          defer[1].lane = 1;
           for (int strand = 0; strand < (s->rc ? 2 : 1) && tiled_done; ++strand) {
             sassy_hip_Encoded tmp;
             tmp.profile = s->profile;
@@ -3774,11 +3851,11 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
             if (seed_batch)
               if (int rc = search_encoded_seeded(s, &tmp, strand ? s->d_rev.p : s->d_text.p, strand ? nullptr : hbuf, total,
                                                  (uint32_t)k, all, wo, R, &done, strand ? &tt_rev : &tt,
-                                                 strand ? &ht_rev : &ht)) return rc;
+                                                 strand ? &ht_rev : &ht, false, on_device ? &defer[strand] : nullptr)) return rc;
             if (!done)
               if (int rc = search_encoded_tiled(s, &tmp, strand ? s->d_rev.p : s->d_text.p, strand ? nullptr : hbuf, total,
                                                 (uint32_t)k, all, wo, R, &done, strand ? &tt_rev : &tt,
-                                                strand ? &ht_rev : &ht)) return rc;
+                                                strand ? &ht_rev : &ht, on_device ? &defer[strand] : nullptr)) return rc;
             if (!done) { tiled_done = false; break; }
             for (size_t i = first; i < R->matches.size(); ++i) {
               sassy_hip_Match& m = R->matches[i];
@@ -3791,6 +3868,11 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
               m.text_start = len - re;
               m.text_end = wo ? UINT64_MAX : len - rs;
             }
+            g_marks.mark("batch: strand rows");
+          }
+          if (tiled_done && on_device) {
+            if (int rc = assemble_many(s, defer[0], defer[1], (uint32_t)nt, d_tab + nt, t0, R)) return rc;
+            g_marks.mark("batch: assemble");
           }
           if (!tiled_done) {  // too many end positions for one list: back to one chain per pattern for this batch
             R->matches.resize(batch_first);
@@ -4083,10 +4165,12 @@ int sassy_hip_search_many(sassy_SearcherType* s, const uint8_t* const* patterns,
       for (size_t i = first; i < R->matches.size(); ++i) R->matches[i].text_idx = ti;
     }
   }
+  g_marks.mark("many: searches");
   std::stable_sort(R->matches.begin(), R->matches.end(), [](const sassy_hip_Match& a, const sassy_hip_Match& b) {
     if (a.pattern_idx != b.pattern_idx) return a.pattern_idx < b.pattern_idx;
     return a.text_idx < b.text_idx;
   });
+  g_marks.mark("many: order");
   if (R->pool.empty()) R->pool.push_back('\0');
   s->stats.total_ms = now_ms() - t0;
   s->stats.host_post_ms = s->stats.total_ms - s->stats.host_enqueue_ms - s->stats.host_wait_ms;

@@ -141,6 +141,56 @@ __global__ __launch_bounds__(256) void assign_texts_kernel(Candidate* __restrict
   }
   report_text[i] = lo;
 }
+
+// ---- search_many over a batch of texts, both strands: the records of the two strands' passes into result order ----
+// (host.hip: assemble_many).  The result order is the one a stable sort by (pattern, text) of [forward records, Rc
+// records] gives; the Rc pass saw the batch reversed: text r of its buffer is text n_texts - 1 - r, and its
+// coordinates count from the text's end (src/search.rs:859-873).
+__global__ __launch_bounds__(256) void many_keys_kernel(const ManyPart a, const ManyPart b, uint32_t n_texts,
+                                                        unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n + b.n) return;
+  const bool rc = i >= a.n;
+  const MatchOut* row = rc ? b.rows + (i - a.n) : a.rows + i;
+  const unsigned long long text = rc ? (unsigned long long)(n_texts - 1) - row->text_idx : row->text_idx;
+  keys[i] = (row->pattern_idx << 33) | (text << 1) | (rc ? 1ull : 0ull);
+  idx[i] = i;
+}
+
+// record j of the result = record idx[j] of the passes, with its final text index, strand and coordinates; its
+// cigar string moves to slot j of the result's pool.  16 lanes per record: the 64 bytes of the row and the string
+// slot travel as 16-byte pieces.
+__global__ __launch_bounds__(256) void many_rows_kernel(const ManyPart a, const ManyPart b, uint32_t n_texts,
+                                                        const uint64_t* __restrict__ text_len, uint64_t first_text,
+                                                        const uint32_t* __restrict__ idx, uint32_t str_stride,
+                                                        MatchOut* __restrict__ out_rows, char* __restrict__ out_strs,
+                                                        uint32_t* __restrict__ flags) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = t >> 4, part = t & 15u;
+  if (j >= a.n + b.n) return;
+  const uint32_t i = idx[j];
+  const bool rc = i >= a.n;
+  const uint32_t li = rc ? i - a.n : i;
+  const MatchOut* src = (rc ? b.rows : a.rows) + li;
+  const char* sstr = (rc ? b.strs : a.strs) + (size_t)li * str_stride;
+  for (uint32_t x = part; x < str_stride / 16; x += 16)
+    reinterpret_cast<uint4*>(out_strs + (size_t)j * str_stride)[x] = reinterpret_cast<const uint4*>(sstr)[x];
+  if (part == 0) {
+    MatchOut r = *src;
+    if (r.pad_[0] == kTraceFailed) atomicOr(flags, 1u);
+    if (rc) {
+      const uint64_t tx = (uint64_t)(n_texts - 1) - r.text_idx;
+      const uint64_t len = text_len[tx], rs = r.text_start, re = r.text_end;
+      r.text_idx = tx;
+      r.text_start = len - re;
+      r.text_end = len - rs;
+      r.strand = 1;
+    }
+    r.text_idx += first_text;
+    r.cigar_off = j * str_stride;
+    out_rows[j] = r;
+  }
+}
 }  // namespace
 
 // Bytes of scratch launch_sort_candidates needs for `count` reports (keys in, keys out, rocPRIM's own).
@@ -248,6 +298,39 @@ hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable
                                hipStream_t stream) {
   if (count == 0) return hipSuccess;
   hipLaunchKernelGGL(assign_texts_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_rep, count, texts, d_report_text);
+  return hipGetLastError();
+}
+
+
+// ---- host.hip: assemble_many ----
+size_t many_scratch_bytes(uint32_t count) {
+  size_t temp = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, temp, static_cast<unsigned long long*>(nullptr),
+                                  static_cast<unsigned long long*>(nullptr), static_cast<uint32_t*>(nullptr),
+                                  static_cast<uint32_t*>(nullptr), (size_t)count, 0, 64, hipStream_t(nullptr));
+  return 2 * (((size_t)count * 8 + 255) / 256 * 256) + 2 * (((size_t)count * 4 + 255) / 256 * 256) + temp + 256;
+}
+hipError_t launch_assemble_many(const ManyPart& a, const ManyPart& b, uint32_t n_texts, const uint64_t* d_text_len,
+                                uint64_t first_text, uint32_t str_stride, MatchOut* d_rows, char* d_strs, uint32_t* d_flags,
+                                void* d_scratch, size_t scratch_bytes, hipStream_t stream) {
+  const uint32_t count = a.n + b.n;
+  if (count == 0) return hipSuccess;
+  const size_t kb = ((size_t)count * 8 + 255) / 256 * 256, ib = ((size_t)count * 4 + 255) / 256 * 256;
+  if (scratch_bytes < 2 * kb + 2 * ib) return hipErrorInvalidValue;
+  unsigned char* base = static_cast<unsigned char*>(d_scratch);
+  unsigned long long* keys_in = reinterpret_cast<unsigned long long*>(base);
+  unsigned long long* keys_out = reinterpret_cast<unsigned long long*>(base + kb);
+  uint32_t* idx_in = reinterpret_cast<uint32_t*>(base + 2 * kb);
+  uint32_t* idx_out = reinterpret_cast<uint32_t*>(base + 2 * kb + ib);
+  void* temp = base + 2 * kb + 2 * ib;
+  size_t temp_bytes = scratch_bytes - (2 * kb + 2 * ib);
+  hipLaunchKernelGGL(many_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, a, b, n_texts, keys_in, idx_in);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (size_t)count, 0, 58, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(many_rows_kernel, dim3((uint32_t)(((uint64_t)count * 16 + 255) / 256)), dim3(256), 0, stream, a, b, n_texts,
+                     d_text_len, first_text, idx_out, str_stride, d_rows, d_strs, d_flags);
   return hipGetLastError();
 }
 

@@ -1745,6 +1745,17 @@ def test_search_many_pattern_tiled(sassy):
                                 wk.append((pi, ti, x.text_start, x.text_end, x.pattern_start, x.pattern_end, x.cost, x.strand, x.cigar))
                     assert gk == sorted(wk), (mode, profile, m, k, npat, allm, rc, len(gk), len(wk))
                     assert len(wk) >= 15
+                    if not allm:
+                        # the records were put in result order on the device (host.hip: assemble_many): the same
+                        # records in the same order as the host's way (per-strand copies, append, stable sort)
+                        os.environ["SASSY_HIP_MANY_ASSEMBLE"] = "0"
+                        try:
+                            host = s.search_many(pats, texts, k, all_minima=allm)
+                        finally:
+                            os.environ.pop("SASSY_HIP_MANY_ASSEMBLE", None)
+                        row = lambda x: (x.pattern_idx, x.text_idx, x.text_start, x.text_end, x.pattern_start,
+                                         x.pattern_end, x.cost, x.strand, x.cigar)
+                        assert [row(x) for x in got] == [row(x) for x in host], (mode, profile, m, k, rc)
     finally:
         os.environ.pop("SASSY_HIP_MANY_TILED", None)
         os.environ.pop("SASSY_HIP_MANY_SEEDED", None)
