@@ -479,17 +479,30 @@ class Searcher:
         """Searcher::search_many in SearchMode::Single order (src/search.rs:531-560): every pattern in
         every text, pattern-major; matches carry pattern_idx and text_idx."""
         patterns = [bytes(p) for p in patterns]
-        infos = [_ptr_len(t) for t in texts]
-        on_dev = [i[3] for i in infos]
-        if any(on_dev) and not all(on_dev):
-            raise SassyHipError("texts must be all on the host or all on the device")
         pp = (C.c_char_p * len(patterns))(*patterns)
         pl = (C.c_size_t * len(patterns))(*[len(p) for p in patterns])
-        tp = (C.c_void_p * len(infos))(*[i[0] for i in infos])
-        tl = (C.c_size_t * len(infos))(*[i[1] for i in infos])
-        flags = (ALL_MINIMA if all_minima else 0) | (TEXT_ON_DEVICE if infos and on_dev[0] else 0)
+        if all(type(t) is bytes for t in texts):
+            # a read set: ctypes fills the pointer array from the list itself (a few hundred thousand _ptr_len calls
+            # cost more than the search)
+            import numpy as np
+            n_texts, on_device = len(texts), False
+            # (CPython: the bytes of a bytes object sit bytes.__basicsize__ - 1 behind its address; `texts` keeps
+            # them alive for the call)
+            addr = np.fromiter(map(id, texts), dtype=np.uint64, count=n_texts) + np.uint64(bytes.__basicsize__ - 1)
+            lens = np.fromiter(map(len, texts), dtype=np.uint64, count=n_texts)
+            tp = addr.ctypes.data_as(C.POINTER(C.c_void_p))
+            tl = lens.ctypes.data_as(C.POINTER(C.c_size_t))
+        else:
+            infos = [_ptr_len(t) for t in texts]
+            on_dev = [i[3] for i in infos]
+            if any(on_dev) and not all(on_dev):
+                raise SassyHipError("texts must be all on the host or all on the device")
+            n_texts, on_device = len(infos), bool(infos and on_dev[0])
+            tp = (C.c_void_p * n_texts)(*[i[0] for i in infos])
+            tl = (C.c_size_t * n_texts)(*[i[1] for i in infos])
+        flags = (ALL_MINIMA if all_minima else 0) | (TEXT_ON_DEVICE if on_device else 0)
         out = C.c_void_p()
-        _check(lib().sassy_hip_search_many(self._h, pp, pl, len(patterns), tp, tl, len(infos), k, flags, C.byref(out)))
+        _check(lib().sassy_hip_search_many(self._h, pp, pl, len(patterns), tp, tl, n_texts, k, flags, C.byref(out)))
         return Result(out).matches
 
     def search_patterns(self, patterns: Sequence[bytes], text, k: int) -> List[Match]:

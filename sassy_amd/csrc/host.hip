@@ -2318,6 +2318,51 @@ static void layout_texts(uint8_t* dst, const uint8_t* const* texts, const size_t
   for (std::thread& th : pool) th.join();
 }
 
+// layout_texts with the upload riding along: the batch is cut into segments of about 32 MB; the threads lay the
+// segments out one after the other (each thread a share of every segment), and as soon as a segment is complete the
+// calling thread queues its host -> device copy -- the PCIe transfer of segment i runs while segment i + 1 is laid
+// out (330 MB of reads: 3.7 ms of layout + 6 ms of upload -> 6.5 ms).
+static int layout_and_upload(uint8_t* dst, uint8_t* d_dst, const uint8_t* const* texts, const size_t* lens,
+                             const uint64_t* start, size_t nt, uint64_t total, uint8_t pad, hipStream_t stream) {
+  const size_t nthreads = (size_t)std::min<uint64_t>(16, std::min<uint64_t>(total >> 22, nt));
+  if (nthreads < 2 || total < (64u << 20)) {
+    layout_texts(dst, texts, lens, start, nt, total, pad);
+    HIP_TRY(hipMemcpyAsync(d_dst, dst, total, hipMemcpyHostToDevice, stream));
+    return 0;
+  }
+  // segment boundaries (text indices): about 32 MB each
+  std::vector<size_t> seg{0};
+  for (size_t i = 1; i < nt; ++i)
+    if (start[i] - start[seg.back()] >= (32u << 20)) seg.push_back(i);
+  seg.push_back(nt);
+  const size_t ns = seg.size() - 1;
+  std::vector<std::atomic<uint32_t>> done(ns);
+  for (auto& d : done) d.store(0, std::memory_order_relaxed);
+  auto work = [&](size_t t) {
+    for (size_t sg = 0; sg < ns; ++sg) {
+      const size_t a0 = seg[sg], n = seg[sg + 1] - a0, per = (n + nthreads - 1) / nthreads;
+      const size_t a = a0 + std::min(n, t * per), b = a0 + std::min(n, (t + 1) * per);
+      for (size_t i = a; i < b; ++i) {
+        if (lens[i]) memcpy(dst + start[i], texts[i], lens[i]);
+        const uint64_t end = i + 1 < nt ? start[i + 1] : total;
+        const uint64_t from = start[i] + lens[i];
+        if (end > from) memset(dst + from, pad, end - from);
+      }
+      done[sg].fetch_add(1, std::memory_order_release);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (size_t t = 0; t < nthreads; ++t) pool.emplace_back(work, t);
+  hipError_t err = hipSuccess;
+  for (size_t sg = 0; sg < ns; ++sg) {
+    while (done[sg].load(std::memory_order_acquire) < nthreads) std::this_thread::yield();
+    const uint64_t from = sg ? start[seg[sg]] : 0, to = sg + 1 < ns ? start[seg[sg + 1]] : total;
+    if (err == hipSuccess && to > from) err = hipMemcpyAsync(d_dst + from, dst + from, to - from, hipMemcpyHostToDevice, stream);
+  }
+  for (std::thread& th : pool) th.join();
+  return err == hipSuccess ? 0 : hip_fail(err, "hipMemcpyAsync");
+}
+
 // Host view of a multi-text buffer (see TextTable in common.h).  Null = the buffer is one text.
 struct HostTexts {
   std::vector<uint64_t> start, len;
@@ -3771,12 +3816,11 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
       if (int rc = s->reserve_stage(total + 64)) return rc;
       hbuf = s->h_stage;
       if (ht.start[0] > 0) memset(hbuf, 'X', ht.start[0]);
-      layout_texts(hbuf, texts + t0, text_lens + t0, ht.start.data(), nt, total, (uint8_t)'X');
-      g_marks.mark("batch layout");
       if (int rc = s->d_text.reserve(total + 64)) return rc;
       if (int rc = s->d_tables.reserve(4 * nt)) return rc;
-      HIP_TRY(hipMemcpyAsync(s->d_text.p, hbuf, total, hipMemcpyHostToDevice, s->stream));
-      g_marks.mark("batch upload");
+      if (int rc = layout_and_upload(hbuf, s->d_text.p, texts + t0, text_lens + t0, ht.start.data(), nt, total, (uint8_t)'X',
+                                     s->stream)) return rc;
+      g_marks.mark("batch layout + upload");
       uint64_t* d_tab = s->d_tables.p;
       HIP_TRY(hipMemcpyAsync(d_tab, ht.start.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
       HIP_TRY(hipMemcpyAsync(d_tab + nt, ht.len.data(), nt * 8, hipMemcpyHostToDevice, s->stream));

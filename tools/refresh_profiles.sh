@@ -82,7 +82,7 @@ fi
 # ---- the multi-device searcher as the bench line's driver (one device here), and the RCCL preflight's script on gloo
 python bench.py --mode inproc --gpus 1 --no-cpu-baseline > $OUT/${TAG}_bench_inproc.json 2>> $OUT/bench.err
 python tools/preflight_multigpu.py --gpus 2 --backend gloo 2>/dev/null | tail -1 > $OUT/${TAG}_preflight_gloo.json
-{ python tools/bench_reads.py; python tools/bench_reads.py --reads 330000; python tools/bench_reads.py --overhang 0.5; } > $OUT/${TAG}_reads.json 2> $OUT/reads.err
+{ python tools/bench_reads.py; python tools/bench_reads.py --reads 330000; python tools/bench_reads.py --reads 330000 --fwd; python tools/bench_reads.py --overhang 0.5; } > $OUT/${TAG}_reads.json 2> $OUT/reads.err
 { python tools/probe_count.py; python tools/probe_rc.py; } > $OUT/${TAG}_shapes.json 2> $OUT/shapes.err
 python tools/cpu_probe.py > $OUT/${TAG}_host_cpus.txt 2>&1
 tail -2 $OUT/*.err
