@@ -2469,6 +2469,9 @@ static hipError_t launch_list_one(const ScanParams& P, uint32_t grid, size_t sme
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&list_kernel<PROFILE, NS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&list_words_kernel<PROFILE, NS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     attr_set.done();
   }
   if (P.list_words_max) {  // few chunks of a multi-word pattern are taken by the word-pipelined kernel
