@@ -141,10 +141,38 @@ def fused_case(rng, searchers):
             a = rng.randrange(m)
             junk += pat[a:a + rng.randrange(q, 2 * q + 1)]
         text[at:at + len(junk)] = junk[:len(text) - at]
+    profile = "dna"
+    if rng.random() < 0.45:
+        # an Iupac searcher with a plain pattern takes the same launch (CHECK): runs of N of every length (inside a
+        # block, over block and lane borders, longer than a window), single other letters, lower case
+        profile = "iupac"
+        for _ in range(rng.randrange(0, 7)):
+            ln = min(n, rng.choice([1, 2, 3, 31, 40, 63, 64, 65, 128, 200, 1000, 5000, 70000]))
+            at = rng.choice([0, n - ln, rng.randrange(0, n - ln + 1), rng.randrange(0, n - ln + 1) // 64 * 64])
+            text[at:at + ln] = b"N" * ln
+        for _ in range(rng.randrange(0, 20)):
+            text[rng.randrange(n)] = rng.choice(b"RYSWKMBDHVNXn-")
+        if rng.random() < 0.2:
+            at = rng.randrange(n)
+            text[at:at + 500] = bytes(text[at:at + 500]).lower()
+        if rng.random() < 0.1:
+            pat = pat[:m // 2] + b"N" + pat[m // 2 + 1:]  # (an ambiguity letter in the pattern: another path)
+    if rng.random() < 0.2:
+        # a stretch of one short unit and a pattern of the same unit: runs of end positions far longer than a window
+        unit = rand_seq(rng, rng.randrange(1, 4), b"ACGT")
+        if rng.random() < 0.7:
+            pat = (unit * (m // len(unit) + 1))[:m]
+        for _ in range(rng.randrange(1, 4)):
+            ln = min(n, rng.choice([100, 700, 5000, 20000]))
+            at = rng.randrange(0, n - ln + 1)
+            st = bytearray((unit * (ln // len(unit) + 1))[:ln])
+            for _ in range(rng.randrange(0, 4)):
+                st[rng.randrange(ln)] = rng.choice(b"ACGT")
+            text[at:at + ln] = st
     text = bytes(text[:n])
-    s = searchers[("dna", False)]
+    s = searchers[(profile, False)]
     allm = rng.random() < 0.2
-    desc = dict(mode="fused", profile="dna", m=m, k=k, n=n, rc=False, all_minima=allm)
+    desc = dict(mode="fused", profile=profile, m=m, k=k, n=n, rc=False, all_minima=allm)
     if rng.random() < 0.3 and n >= 3000 and not allm:  # as shards over a resident text
         buf = sassy_amd.DeviceBuffer(n + 256)
         buf.upload(text)
@@ -165,7 +193,7 @@ def fused_case(rng, searchers):
         buf.free()
     else:
         got = s.search_all(pat, text, k) if allm else s.search(pat, text, k)
-    want = oracle.search("dna", pat, text, k, all_minima=allm)
+    want = oracle.search(profile, pat, text, k, all_minima=allm)
     st = s.stats()
     desc["filtered"] = st["filtered"] * 10 + st["fused"]
     desc["matches"] = len(want)
