@@ -442,8 +442,9 @@ def main():
             "kernel": dom_name,
             "algorithmic_bytes_per_launch": n_per,
             "launch_ms": round(dom_ms, 4),
-            "measured": (f"HIP events around the kernel on the searcher's stream, {n_lat} launches of the one-search-at-a-time "
-                         f"loop of this run" if args.in_flight > 1 else "HIP events around the kernel on the searcher's stream, the timed steps"),
+            "measured": (f"HIP events carried by the kernel's dispatch (hipExtLaunchKernelGGL start / stop events on the searcher's "
+                         f"stream: the launch's own begin and end), {n_lat} launches of the one-search-at-a-time loop of this run"
+                         if args.in_flight > 1 else "HIP events carried by the kernel's dispatch on the searcher's stream, the timed steps"),
         },
     }
     # the whole search against the same roofline: text bytes of one GPU / time per step (the kernel figure above
@@ -533,7 +534,7 @@ def main_inproc(args):
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": dom_name,
                      "algorithmic_bytes_per_launch": n_per, "launch_ms": round(dom_ms, 4),
-                     "measured": "HIP events around the kernel on each shard searcher's stream inside the timed steps; the slowest device's average"},
+                     "measured": "HIP events carried by the kernel's dispatch on each shard searcher's stream inside the timed steps; the slowest device's average"},
         "roofline_search": {"bound": "hbm", "achieved": round(n_per / (ms_per_step / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": round(n_per / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
                             "what": "text bytes per GPU / ms_per_step, one multi-device search at a time"},

@@ -266,6 +266,13 @@ struct MatchOut {
   uint32_t cigar_len;
 };
 
+// Set by the host right in front of a fused filter launch it wants timed; the launcher hands the events to the
+// dispatch (hipExtLaunchKernelGGL) and clears them.
+struct LaunchEvents {
+  hipEvent_t start = nullptr, stop = nullptr;
+};
+extern thread_local LaunchEvents g_launch_events;
+
 // One strand's pass of search_many over a batch of texts, records still on the device (sort_kernels.hip: assemble).
 struct ManyPart {
   const MatchOut* rows;

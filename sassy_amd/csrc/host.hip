@@ -27,6 +27,8 @@
 #include "profiles.h"
 
 namespace sassy_hip {
+thread_local LaunchEvents g_launch_events;
+
 
 // kernel launchers (scan_kernel.hip is compiled once per profile; aux_kernels.hip)
 hipError_t launch_scan_dna(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream);
@@ -1458,7 +1460,10 @@ int ScanJob::enqueue(int attempt) {
   if (wait_for && attempt == 0) HIP_TRY(hipStreamWaitEvent(L.stream, wait_for, 0));
   // (a job that only consumes a bitmap has no filter to time: no events at level 1, each costs ~6 us of stream idle)
   const bool time_head = timing >= 2 || (timing == 1 && !ext_bitmap);
-  if (time_head) HIP_TRY(hipEventRecord(L.ev_a, L.stream));
+  // (the fused launch carries its events itself: LaunchEvents)
+  static const bool env_ext_ev = !(getenv("SASSY_HIP_EXT_EVENTS") && atoi(getenv("SASSY_HIP_EXT_EVENTS")) == 0);
+  const bool ext_events = time_head && filtered && fused && attempt == 0 && env_ext_ev;
+  if (time_head && !ext_events) HIP_TRY(hipEventRecord(L.ev_a, L.stream));
   hipError_t le;
   if (!filtered) {
     le = launch_scan_any(S->profile, P, grid, (size_t)P.waves_per_group * P.lds_per_wave, L.stream);
@@ -1473,7 +1478,9 @@ int ScanJob::enqueue(int attempt) {
       F.stash_cap = (uint32_t)std::min<size_t>(L.d_stash.cap, 0xFFFFFEu);
       F.counters = nullptr;
       F.row_tab = P.row_tab;
+      if (ext_events) g_launch_events = LaunchEvents{L.ev_a, L.ev_f};
       le = launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, L.stream);
+      g_launch_events = LaunchEvents{};
       if (le != hipSuccess) return hip_fail(le, "fused filter kernel launch");
     } else if (attempt == 0 && !ext_bitmap && !ext_desc) {  // the hit bitmap does not depend on buffer sizes: build it once
       if (rc_marked) HIP_TRY(hipMemsetAsync(rc_bitmap, 0, (n_words + 2) * 8, L.stream));
@@ -1487,7 +1494,7 @@ int ScanJob::enqueue(int attempt) {
                : launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, L.stream);
       if (le != hipSuccess) return hip_fail(le, "filter kernel launch");
     }
-    if (time_head && attempt == 0) HIP_TRY(hipEventRecord(L.ev_f, L.stream));
+    if (time_head && attempt == 0 && !ext_events) HIP_TRY(hipEventRecord(L.ev_f, L.stream));
     if (signal_filter_done && attempt == 0) HIP_TRY(hipEventRecord(L.ev_filter_done, L.stream));
     if (!fused) {
     maxlen = 16;
@@ -1729,6 +1736,10 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
           Tall.unsorted = nullptr;
           Tall.count_max = 0xFFFFFFFFu;
         }
+        // (this launch traces whatever the list holds by now: the dedup below may leave fewer than kTraceWaveMax reports,
+        // the count the thread kernel otherwise leaves to the wave kernel -- it returned at once, and the rows of an
+        // earlier search went out: fuzz, search_all over N runs, 7 360 reports out of > 8 192 with copies)
+        Tall.count_min = 0;
         if (big) {
           big_list = L.d_sorted.p;
           if (fused) {

@@ -33,6 +33,7 @@
 //
 // No MFMA: this is integer bit-twiddling bounded by VALU issue and HBM reads.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <type_traits>
@@ -2496,7 +2497,13 @@ hipError_t launch_scan_dna(const ScanParams& P, uint32_t grid, size_t smem, hipS
 template <int Q, int NPG>
 static hipError_t launch_filter_planes_q(const ScanParams& P, uint32_t grid, hipStream_t stream) {
   const size_t smem = (size_t)kWavesPerGroup * P.lds_per_wave;
-  if (P.fused) hipLaunchKernelGGL((filter_dna_kernel<Q, NPG, true>), dim3(grid), dim3(256), smem, stream, P);
+  const LaunchEvents ev = g_launch_events;
+  g_launch_events = LaunchEvents{};
+  // (timed launches: the dispatch itself carries the events -- its own begin and end, what rocprofv3 reports --
+  // instead of two markers around it, which add a few microseconds of queue latency)
+  if (P.fused && ev.start)
+    hipExtLaunchKernelGGL((filter_dna_kernel<Q, NPG, true>), dim3(grid), dim3(256), smem, stream, ev.start, ev.stop, 0, P);
+  else if (P.fused) hipLaunchKernelGGL((filter_dna_kernel<Q, NPG, true>), dim3(grid), dim3(256), smem, stream, P);
   else hipLaunchKernelGGL((filter_dna_kernel<Q, NPG, false>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
 }
@@ -2592,7 +2599,11 @@ template <int Q>
 static hipError_t launch_filter_planes_iupac_q(const ScanParams& P, uint32_t grid, hipStream_t stream) {
   const size_t smem = (size_t)kWavesPerGroup * P.lds_per_wave;
   if (P.piece_groups != 1) return hipErrorInvalidValue;  // (eight pieces + the check do not fit 128 VGPRs: the host asks for <= 4)
-  hipLaunchKernelGGL((filter_dna_kernel<Q, 1, true, true>), dim3(grid), dim3(256), smem, stream, P);
+  const LaunchEvents ev = g_launch_events;
+  g_launch_events = LaunchEvents{};
+  if (ev.start)
+    hipExtLaunchKernelGGL((filter_dna_kernel<Q, 1, true, true>), dim3(grid), dim3(256), smem, stream, ev.start, ev.stop, 0, P);
+  else hipLaunchKernelGGL((filter_dna_kernel<Q, 1, true, true>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
 }
 static hipError_t launch_filter_planes_iupac(const ScanParams& P, uint32_t grid, hipStream_t stream) {
