@@ -2203,11 +2203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
       dsc.own_hi = e.x + ((e.y >> 6) & 0xFFu);
       dsc.flags = kDescWindow;
       dsc.pad_ = (e.y & 63u) | ((e.y >> 14) << 8);  // byte shift | columns not to report << 8
-#if !defined(SASSY_EXP) || !(SASSY_EXP & 1)
       list_lanes<CHECK ? (int)PROFILE_IUPAC : (int)PROFILE_DNA, 4, true>(L, mask_bytes, carry, dlane, has, dsc, kNoStateSlot);
-#else
-      list_lanes<(int)PROFILE_DNA, 4, true>(L, mask_bytes, carry, dlane, has, dsc, kNoStateSlot);
-#endif
     }
     if ((kp->fused & 2u) && dlane == 0) {
       unsigned long long* pc = reinterpret_cast<unsigned long long*>(L.cand_count + 4);  // the control block's counters
