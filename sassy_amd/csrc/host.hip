@@ -1027,6 +1027,14 @@ int ScanJob::prepare() {
     const uint8_t u = pat[j] & 0xDFu;
     plain_pattern = u == 'A' || u == 'C' || u == 'G' || u == 'T';
   }
+  // Pieces of 6 rows, at most four of them (m = 24 .. 27 with k = 3, a 20-mer with k = 2): a window chunk in every
+  // sixteenth block is still less work for the fused launch than the streaming DP over every block (m = 24, k = 3:
+  // 0.85 against 1.03 ms per 3 GB; five pieces: 1.10 against 1.085; 5-row pieces: 2.2 and more -- tools/probe_short_pieces.py).
+  // SASSY_HIP_SHORT_PIECES=0: never.
+  static const bool env_short = !(getenv("SASSY_HIP_SHORT_PIECES") && atoi(getenv("SASSY_HIP_SHORT_PIECES")) == 0);
+  if (q == 0 && env_pre < 0 && env_short && fuse_ok && !overhang && !ext_bitmap && !ext_desc && plan.nslots <= 16 && !plan.bytes &&
+      (S->profile == PROFILE_DNA || plain_pattern) && pieces <= 4 && plan.m / pieces == 6)
+    q = 6;
   const bool iupac_planes = plain_pattern && fuse_ok && q >= 6 && q <= 12 && pieces <= 4 && plan.nslots <= 4;
   const bool can_planes = q > 0 && pieces <= 8 && (S->profile == PROFILE_DNA || iupac_planes);
   // q-gram counting (count_filter.hip): per (Q, R) variant the threshold t = m + 1 - (k+1) Q, the

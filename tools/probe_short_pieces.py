@@ -9,10 +9,12 @@ from bench import _dna_bytes
 n = int(float(os.environ.get("PROBE_N", "3e9"))) // 64 * 64
 buf = sassy_amd.DeviceBuffer(n + 4096)
 sassy_amd.generate_dna(buf.ptr, n, 42, 0)
-shapes = [("dna", 32, 4), ("dna", 24, 3), ("dna", 23, 3), ("dna", 32, 5), ("dna", 28, 3), ("iupac", 32, 4), ("iupac", 23, 3)]
+shapes = [("dna", 24, 3), ("dna", 27, 3), ("dna", 20, 2), ("dna", 18, 2), ("dna", 12, 1), ("iupac", 24, 3), ("iupac", 20, 2), ("dna", 32, 4), ("dna", 23, 3)]
+if os.environ.get("PROBE_SHAPES"):
+    shapes = [(a, int(b), int(c)) for a, b, c in (x.split(":") for x in os.environ["PROBE_SHAPES"].split(","))]
 for profile, m, k in shapes:
     pat = bytes(_dna_bytes(43, 0, m))
-    for mode in (-1, 1):
+    for mode in (-1, 0):
         s = sassy_amd.Searcher(profile, rc=False).set_prefilter(mode)
         for _ in range(6):
             r = s.search_shard(pat, buf.ptr, 0, n, 0, n, k)
