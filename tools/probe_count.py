@@ -39,3 +39,8 @@ run("dna", pat(64, 47), 8)
 run("dna", pat(64, 47), 12)
 run("dna", pat(50, 50), 10)
 run("iupac", pat(32, 43), 5)
+# at most four pieces of six rows: the fused bit-plane launch (round 4)
+run("dna", pat(20, 45), 2)
+run("dna", pat(24, 51), 3)
+run("iupac", pat(24, 51), 3)
+run("dna", pat(27, 52), 3)

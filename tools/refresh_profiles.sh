@@ -84,6 +84,10 @@ python bench.py --mode inproc --gpus 1 --no-cpu-baseline > $OUT/${TAG}_bench_inp
 python tools/preflight_multigpu.py --gpus 2 --backend gloo 2>/dev/null | tail -1 > $OUT/${TAG}_preflight_gloo.json
 { python tools/bench_reads.py; python tools/bench_reads.py --reads 330000; python tools/bench_reads.py --reads 330000 --fwd; python tools/bench_reads.py --overhang 0.5; } > $OUT/${TAG}_reads.json 2> $OUT/reads.err
 { python tools/probe_count.py; python tools/probe_rc.py; } > $OUT/${TAG}_shapes.json 2> $OUT/shapes.err
+{ echo "# tools/probe_short_pieces.py: shapes whose pigeonhole pieces are 5 or 6 rows -- default path against no prefilter (streaming DP), lone searches, 3 GB";
+  python tools/probe_short_pieces.py; } > $OUT/${TAG}_short_pieces.txt 2> $OUT/short.err
+{ echo "# tools/pmc_kernel.sh list_words_kernel: config 3's chunk DP (word-pipelined), counters per dispatch (sums over the waves; cycles in units of 4)";
+  bash tools/pmc_kernel.sh list_words_kernel PROBE_C3=1 PROBE_PROFILE=iupac PROBE_M=200 PROBE_K=20; } > $OUT/${TAG}_list_words_pmc.txt 2>&1
 python tools/cpu_probe.py > $OUT/${TAG}_host_cpus.txt 2>&1
 tail -2 $OUT/*.err
 ls -la $OUT
