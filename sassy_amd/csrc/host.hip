@@ -1027,16 +1027,17 @@ int ScanJob::prepare() {
     const uint8_t u = pat[j] & 0xDFu;
     plain_pattern = u == 'A' || u == 'C' || u == 'G' || u == 'T';
   }
-  // Pieces of 6 rows, at most four of them (m = 24 .. 27 with k = 3, a 20-mer with k = 2): a window chunk in every
-  // sixteenth block is still less work for the fused launch than the streaming DP over every block (m = 24, k = 3:
-  // 0.85 against 1.03 ms per 3 GB; five pieces: 1.10 against 1.085; 5-row pieces: 2.2 and more -- tools/probe_short_pieces.py).
-  // SASSY_HIP_SHORT_PIECES=0: never.
+  bool iupac_planes = plain_pattern && fuse_ok && q >= 6 && q <= 12 && pieces <= 4 && plan.nslots <= 4;
+  bool can_planes = q > 0 && pieces <= 8 && (S->profile == PROFILE_DNA || iupac_planes);
+  // Pieces of 6 rows, at most four of them, where the q-gram counting filter below finds nothing selective (m = 24, k = 3;
+  // m = 18, k = 2; m = 12, k = 1): a window chunk in every sixteenth block is still less work for the fused launch than
+  // the streaming DP over every block -- 0.87 against 1.03 ms per 3 GB (Iupac searcher: 0.95 against 1.29), m = 12, k = 1 with
+  // its 13 764 matches 1.08 against 5.6.  Where the counting filter applies it stays (a 20-mer with k = 2: 0.76 against 0.79;
+  // m = 27, k = 3: 0.72 against 0.87); five pieces, or pieces of 5 rows, lose against the streaming DP
+  // (tools/probe_short_pieces.py).  SASSY_HIP_SHORT_PIECES=0: never.
   static const bool env_short = !(getenv("SASSY_HIP_SHORT_PIECES") && atoi(getenv("SASSY_HIP_SHORT_PIECES")) == 0);
-  if (q == 0 && env_pre < 0 && env_short && fuse_ok && !overhang && !ext_bitmap && !ext_desc && plan.nslots <= 16 && !plan.bytes &&
-      (S->profile == PROFILE_DNA || plain_pattern) && pieces <= 4 && plan.m / pieces == 6)
-    q = 6;
-  const bool iupac_planes = plain_pattern && fuse_ok && q >= 6 && q <= 12 && pieces <= 4 && plan.nslots <= 4;
-  const bool can_planes = q > 0 && pieces <= 8 && (S->profile == PROFILE_DNA || iupac_planes);
+  const bool short_ok = q == 0 && env_pre < 0 && env_short && fuse_ok && !overhang && !ext_bitmap && !ext_desc && plan.nslots <= 16 &&
+                        !plan.bytes && (S->profile == PROFILE_DNA || plain_pattern) && pieces <= 4 && plan.m / pieces == 6;
   // q-gram counting (count_filter.hip): per (Q, R) variant the threshold t = m + 1 - (k+1) Q, the
   // window W, and how often a window of random text reaches t by chance (the pattern's q-grams,
   // ambiguity letters expanded, against 4^Q; Poisson tail).  Taken when that beats the expected
@@ -1105,6 +1106,11 @@ int ScanJob::prepare() {
         count_tail = clumped_tail(64.0 * count_w * L.table_density, count_t);
       }
     }
+  }
+  if (short_ok && fkind != kFilterCount) {
+    q = 6;
+    iupac_planes = plain_pattern && plan.nslots <= 4;
+    can_planes = S->profile == PROFILE_DNA || iupac_planes;
   }
   filtered = q > 0;
   if (filtered && !ext_bitmap && !ext_desc && fkind != kFilterCount) {

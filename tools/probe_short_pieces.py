@@ -14,7 +14,7 @@ if os.environ.get("PROBE_SHAPES"):
     shapes = [(a, int(b), int(c)) for a, b, c in (x.split(":") for x in os.environ["PROBE_SHAPES"].split(","))]
 for profile, m, k in shapes:
     pat = bytes(_dna_bytes(43, 0, m))
-    for mode in (-1, 0):
+    for mode in ((-1,) if os.environ.get("PROBE_DEFAULT_ONLY") else (-1, 0)):
         s = sassy_amd.Searcher(profile, rc=False).set_prefilter(mode)
         for _ in range(6):
             r = s.search_shard(pat, buf.ptr, 0, n, 0, n, k)
