@@ -1037,7 +1037,11 @@ int ScanJob::prepare() {
   // (tools/probe_short_pieces.py).  SASSY_HIP_SHORT_PIECES=0: never.
   static const bool env_short = !(getenv("SASSY_HIP_SHORT_PIECES") && atoi(getenv("SASSY_HIP_SHORT_PIECES")) == 0);
   const bool short_ok = q == 0 && env_pre < 0 && env_short && fuse_ok && !overhang && !ext_bitmap && !ext_desc && plan.nslots <= 16 &&
-                        !plan.bytes && (S->profile == PROFILE_DNA || plain_pattern) && pieces <= 4 && plan.m / pieces == 6;
+                        !plan.bytes && (S->profile == PROFILE_DNA || plain_pattern) && pieces <= 4 &&
+                        (plan.m / pieces == 6 || (plan.m / pieces == 5 && plan.m <= 15));
+  // (5-row pieces only for patterns of at most 15 rows: there the streaming DP is slow -- its test "may this block hold
+  // a cell <= k" is byte-granular and nearly always says yes when m is not much more than 8 + k: 6.1 -> 2.7 ms for
+  // m = 11, k = 1, 3.4 -> 2.3 for m = 15, k = 2; m = 17, k = 2 would lose, 1.05 -> 1.8)
   // q-gram counting (count_filter.hip): per (Q, R) variant the threshold t = m + 1 - (k+1) Q, the
   // window W, and how often a window of random text reaches t by chance (the pattern's q-grams,
   // ambiguity letters expanded, against 4^Q; Poisson tail).  Taken when that beats the expected
@@ -1108,7 +1112,7 @@ int ScanJob::prepare() {
     }
   }
   if (short_ok && fkind != kFilterCount) {
-    q = 6;
+    q = plan.m / pieces;
     iupac_planes = plain_pattern && plan.nslots <= 4;
     can_planes = S->profile == PROFILE_DNA || iupac_planes;
   }

@@ -2604,6 +2604,7 @@ static hipError_t launch_filter_planes_iupac_q(const ScanParams& P, uint32_t gri
 }
 static hipError_t launch_filter_planes_iupac(const ScanParams& P, uint32_t grid, hipStream_t stream) {
   switch (P.piece_len) {
+    case 5: return launch_filter_planes_iupac_q<5>(P, grid, stream);
     case 6: return launch_filter_planes_iupac_q<6>(P, grid, stream);
     case 7: return launch_filter_planes_iupac_q<7>(P, grid, stream);
     case 8: return launch_filter_planes_iupac_q<8>(P, grid, stream);

@@ -2133,7 +2133,7 @@ def _fused_cases(rng):
     cases.append((b"AC" * 16, b"AC" * 9000 + b"G" * 77 + b"CA" * 3000, 2))
     # at most four pieces of six rows (a 20-mer with k = 2, m = 24 .. 27 with k = 3): a window in every sixteenth
     # block of random text -- many passes of the wave over its queue
-    for (m, k) in ((20, 2), (24, 3), (27, 3), (12, 1), (6, 0)):
+    for (m, k) in ((20, 2), (24, 3), (27, 3), (12, 1), (6, 0), (11, 1), (15, 2)):  # (the last two: 5-row pieces, m <= 15)
         p = rand_seq(rng, m)
         t = bytearray(rand_seq(rng, 200_000))
         for _ in range(300):

@@ -9,7 +9,8 @@ from bench import _dna_bytes
 n = int(float(os.environ.get("PROBE_N", "3e9"))) // 64 * 64
 buf = sassy_amd.DeviceBuffer(n + 4096)
 sassy_amd.generate_dna(buf.ptr, n, 42, 0)
-shapes = [("dna", 24, 3), ("dna", 27, 3), ("dna", 20, 2), ("dna", 18, 2), ("dna", 12, 1), ("iupac", 24, 3), ("iupac", 20, 2), ("dna", 32, 4), ("dna", 23, 3)]
+shapes = [("dna", 24, 3), ("dna", 27, 3), ("dna", 20, 2), ("dna", 18, 2), ("dna", 12, 1), ("iupac", 24, 3), ("iupac", 20, 2), ("dna", 32, 4), ("dna", 23, 3),
+          ("dna", 11, 1), ("iupac", 10, 1), ("dna", 15, 2), ("dna", 17, 2)]
 if os.environ.get("PROBE_SHAPES"):
     shapes = [(a, int(b), int(c)) for a, b, c in (x.split(":") for x in os.environ["PROBE_SHAPES"].split(","))]
 for profile, m, k in shapes:
