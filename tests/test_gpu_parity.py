@@ -2172,7 +2172,7 @@ def test_fused_filter_equals_classic_chain_and_oracle(sassy):
         assert_same(got, want, ("classic", i, len(pat), k, len(text)))
         if i % 4 == 0:
             assert_same(fused.search_all(pat, text[:3000], k), oracle.search("dna", pat, text[:3000], k, all_minima=True), ("all", i))
-    assert ran_fused >= 35 or not can_fuse, ran_fused
+    assert ran_fused >= (30 if os.environ.get("SASSY_HIP_SHORT_PIECES") == "0" else 35) or not can_fuse, ran_fused
     # shards with halos over a resident text; plants across the seams; both searchers give the same shard results
     pat = bytes(oracle.generate_dna(43, 0, 32))
     n = (1 << 21) + 333
@@ -2400,6 +2400,8 @@ _FORCED = [
     {"SASSY_HIP_LANES": "3", "SASSY_HIP_SUBSHARD_MIN": "2048"},  # one search cut into sub-shards on several streams
     {"SASSY_HIP_IUPAC_PLANES": "0"},                 # Iupac searches with plain patterns through the Iupac chain only
     {"SASSY_HIP_FILTER_KIND": "4", "SASSY_HIP_COUNT_WPG": "4"},  # the counting filter with four waves per workgroup
+    {"SASSY_HIP_BIG_PIN": "0", "SASSY_HIP_SHORT_PIECES": "0"},   # dense results through the host's vectors; no 5- / 6-row pieces
+    {"SASSY_HIP_FUSED_PRESS": "8", "SASSY_HIP_EXT_EVENTS": "0"},  # a pass of the fused launch's waves every 8 queued windows
 ]
 
 
