@@ -1031,17 +1031,14 @@ int ScanJob::prepare() {
   bool can_planes = q > 0 && pieces <= 8 && (S->profile == PROFILE_DNA || iupac_planes);
   // Pieces of 6 rows, at most four of them, where the q-gram counting filter below finds nothing selective (m = 24, k = 3;
   // m = 18, k = 2; m = 12, k = 1): a window chunk in every sixteenth block is still less work for the fused launch than
-  // the streaming DP over every block -- 0.87 against 1.03 ms per 3 GB (Iupac searcher: 0.95 against 1.29), m = 12, k = 1 with
-  // its 13 764 matches 1.08 against 5.6.  Where the counting filter applies it stays (a 20-mer with k = 2: 0.76 against 0.79;
+  // the streaming DP over every block -- 0.85 against 1.03 ms per 3 GB (Iupac searcher: 0.94 against 1.29), m = 12, k = 1 with
+  // its 13 764 matches 0.99 against 1.21.  Where the counting filter applies it stays (a 20-mer with k = 2: 0.76 against 0.79;
   // m = 27, k = 3: 0.72 against 0.87); five pieces, or pieces of 5 rows, lose against the streaming DP
   // (tools/probe_short_pieces.py).  SASSY_HIP_SHORT_PIECES=0: never.
   static const bool env_short = !(getenv("SASSY_HIP_SHORT_PIECES") && atoi(getenv("SASSY_HIP_SHORT_PIECES")) == 0);
   const bool short_ok = q == 0 && env_pre < 0 && env_short && fuse_ok && !overhang && !ext_bitmap && !ext_desc && plan.nslots <= 16 &&
-                        !plan.bytes && (S->profile == PROFILE_DNA || plain_pattern) && pieces <= 4 &&
-                        (plan.m / pieces == 6 || (plan.m / pieces == 5 && plan.m <= 15));
-  // (5-row pieces only for patterns of at most 15 rows: there the streaming DP is slow -- its test "may this block hold
-  // a cell <= k" is byte-granular and nearly always says yes when m is not much more than 8 + k: 6.1 -> 2.7 ms for
-  // m = 11, k = 1, 3.4 -> 2.3 for m = 15, k = 2; m = 17, k = 2 would lose, 1.05 -> 1.8)
+                        !plan.bytes && (S->profile == PROFILE_DNA || plain_pattern) && pieces <= 4 && plan.m / pieces == 6;
+  // (5-row pieces lose everywhere: m = 11, k = 1 takes 2.6 ms against 1.7 on the streaming DP, m = 15, k = 2 2.2 against 1.2)
   // q-gram counting (count_filter.hip): per (Q, R) variant the threshold t = m + 1 - (k+1) Q, the
   // window W, and how often a window of random text reaches t by chance (the pattern's q-grams,
   // ambiguity letters expanded, against 4^Q; Poisson tail).  Taken when that beats the expected

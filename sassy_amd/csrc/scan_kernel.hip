@@ -115,6 +115,32 @@ __device__ __forceinline__ bool row_maybe_live(int ds, const DpWord& V, int k) {
   return ds + mn <= k;
 }
 
+// The exact answer behind row_maybe_live: does the block's last row hold a cell <= k?  Only the byte groups whose
+// bound passes are walked, column by column.  With few pattern rows (m not much more than 8 + k) the bound passes for
+// some lane of nearly every wave and block, and what used to follow -- scan_block's walk for the whole wave -- made the
+// streaming DP five times slower for m = 12 than for m = 16 (5.5 against 1.0 ms per 3 GB); the same, less pronounced,
+// where k / m is large.  Out of line: the streaming loop keeps its registers.
+__device__ __noinline__ bool row_live_exact(uint32_t pl, uint32_t ph, uint32_t ml, uint32_t mh, int ds, int k) {
+  // (the cell on the block's left edge -- the last column of the block in front -- counts: the report rule decides about
+  // it when it sees this block's first column, and the byte-granular bound has always let such a block through)
+  bool live = ds <= k;
+  int s = ds;  // cost in front of the byte group
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const uint32_t pb = ((q < 4 ? pl : ph) >> (8 * (q & 3))) & 0xFFu, mb = ((q < 4 ? ml : mh) >> (8 * (q & 3))) & 0xFFu;
+    if (__any(s - (int)__popc(mb) <= k)) {  // (wave-uniform branch; the lanes whose bound fails walk along idly)
+      int c = s;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        c += (int)((pb >> t) & 1u) - (int)((mb >> t) & 1u);
+        live |= c <= k;
+      }
+    }
+    s += (int)__popc(pb) - (int)__popc(mb);
+  }
+  return live;
+}
+
 // Lane state, packed in one register: bit 0 = dec ("decreasing" of the report rule, reference:
 // src/search.rs:1349-1359), bit 1 = amb (dec is not yet determined by anything this chunk has
 // seen in its exact region).
@@ -824,9 +850,11 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
     // ---- last row of the block: anything <= k ? ----
     rep4 rr = make_rep4(0u, 0u, 0u, 0u);
     const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
+    bool live = active && ran_through && row_maybe_live(ds, V, k);
+    if (__any(live)) live = row_live_exact(V.vpl, V.vph, V.vml, V.vmh, ds, k) && live;
     if (active) {
       if (P.counters) cnt_blocks += 1;
-      if (ran_through && row_maybe_live(ds, V, k)) {
+      if (live) {
         if (P.counters) cnt_live += 1;
         rr = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
         st = rr.z & (kStDec | kStAmb);
@@ -1610,9 +1638,11 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
                                         !active, first_rows, minus_total, m, P.counters != nullptr && active, cnt_rows);
       rep4 rr = make_rep4(0u, 0u, 0u, 0u);
       const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
+      bool live = active && ran_through && row_maybe_live(ds, V, k);
+      if (__any(live)) live = row_live_exact(V.vpl, V.vph, V.vml, V.vmh, ds, k) && live;
       if (active) {
         if (P.counters) cnt_blocks += 1;
-        if (ran_through && row_maybe_live(ds, V, k)) {
+        if (live) {
           if (P.counters) cnt_live += 1;
           rr = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st | (rskip << 8));
           st = rr.z & (kStDec | kStAmb);

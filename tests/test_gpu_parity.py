@@ -2133,7 +2133,7 @@ def _fused_cases(rng):
     cases.append((b"AC" * 16, b"AC" * 9000 + b"G" * 77 + b"CA" * 3000, 2))
     # at most four pieces of six rows (a 20-mer with k = 2, m = 24 .. 27 with k = 3): a window in every sixteenth
     # block of random text -- many passes of the wave over its queue
-    for (m, k) in ((20, 2), (24, 3), (27, 3), (12, 1), (6, 0), (11, 1), (15, 2)):  # (the last two: 5-row pieces, m <= 15)
+    for (m, k) in ((20, 2), (24, 3), (27, 3), (12, 1), (6, 0), (11, 1), (15, 2)):  # (the last two: 5-row pieces, the streaming DP)
         p = rand_seq(rng, m)
         t = bytearray(rand_seq(rng, 200_000))
         for _ in range(300):
@@ -2172,7 +2172,7 @@ def test_fused_filter_equals_classic_chain_and_oracle(sassy):
         assert_same(got, want, ("classic", i, len(pat), k, len(text)))
         if i % 4 == 0:
             assert_same(fused.search_all(pat, text[:3000], k), oracle.search("dna", pat, text[:3000], k, all_minima=True), ("all", i))
-    assert ran_fused >= (30 if os.environ.get("SASSY_HIP_SHORT_PIECES") == "0" else 35) or not can_fuse, ran_fused
+    assert ran_fused >= (30 if os.environ.get("SASSY_HIP_SHORT_PIECES") == "0" else 33) or not can_fuse, ran_fused
     # shards with halos over a resident text; plants across the seams; both searchers give the same shard results
     pat = bytes(oracle.generate_dna(43, 0, 32))
     n = (1 << 21) + 333
