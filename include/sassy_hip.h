@@ -85,6 +85,9 @@ typedef struct sassy_hip_Stats {
   double host_post_ms;    /* host wall time after it: sort, seams, cigar strings, result records */
   uint64_t live_blocks;   /* blocks whose last row passed the cheap "may hold a cell <= k" test and were
                              walked column by column (0 unless counters are enabled) */
+  uint32_t pair;          /* != 0: the fused launch ran the PAIRED filter with this many super-pieces of 2 * piece_len
+                             rows (one half exact, the other half with <= 1 edit next to it; SASSY_HIP_PAIR=0: never) */
+  uint32_t reserved_;
 } sassy_hip_Stats;
 
 const char *sassy_hip_last_error(void);

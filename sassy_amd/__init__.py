@@ -96,6 +96,8 @@ class Stats(C.Structure):
         ("host_wait_ms", C.c_double),
         ("host_post_ms", C.c_double),
         ("live_blocks", C.c_uint64),
+        ("pair", C.c_uint32),
+        ("reserved_", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -147,7 +147,13 @@ struct ScanParams {
   TextStash* stash;           // fused: the text under the reports (stash_cap slots), or null
   uint32_t stash_cap;
   uint32_t piece_rem[8];      // pattern rows behind piece p: a match that contains the piece exactly, ending
-                              // at text position e, ends in [e + rem - k, e + rem + k]
+                              // at text position e, ends in [e + rem - k, e + rem + k]  (read as int32: the paired
+                              // filter's A-type sub-pieces count from their detection column, piece_len + 1 later)
+  uint32_t pair_y[4];         // paired filter: the sibling sub-piece of piece p in the reading order its test uses (rows
+                              // forwards for the B behind an A, backwards for the A in front of a B), code bit 0 / code
+                              // bit 1 in byte p & 3 of pair_y[2 (p >> 2)] / pair_y[2 (p >> 2) + 1]
+  uint32_t pair;              // != 0: the paired filter (filter_dna_kernel<.., PAIR>) with this many super-pieces of
+                              // 2 * piece_len rows; pieces 2t / 2t+1 = the halves A / B of super-piece t
   // multi-pattern bit-plane filter (filter_dna_multi_kernel): multi_n patterns of equal length and
   // piece geometry; pattern p's piece_bits at multi_bits[16 p + 2 piece + plane], its hit bitmap at
   // hit_bitmap + p * multi_stride (64-bit words)

@@ -914,6 +914,7 @@ struct ScanJob {
   bool filtered = false;
   FilterKind fkind = kFilterGeneric;
   uint32_t count_r = 0, count_w = 0, count_t = 0, count_wpg = 4;  // counting filter: R, window blocks, threshold, waves per workgroup
+  uint32_t pair = 0;                                   // paired filter: super-pieces (0: not taken)
   double count_tail = 0;                           // ... and the expected fraction of candidate blocks
   unsigned long long* d_bitmap = nullptr;
   uint32_t* d_counts = nullptr;
@@ -1039,6 +1040,18 @@ int ScanJob::prepare() {
   const bool short_ok = q == 0 && env_pre < 0 && env_short && fuse_ok && !overhang && !ext_bitmap && !ext_desc && plan.nslots <= 16 &&
                         !plan.bytes && (S->profile == PROFILE_DNA || plain_pattern) && pieces <= 4 && plan.m / pieces == 6;
   // (5-row pieces lose everywhere: m = 11, k = 1 takes 2.6 ms against 1.7 on the streaming DP, m = 15, k = 2 2.2 against 1.2)
+  // The paired filter (filter_dna_kernel<.., PAIR>): S = ceil((k+1)/2) super-pieces of 2 Q rows, each with at most one of
+  // the k edits -- one half exact, the other half with <= 1 edit right next to it, tested on the bit planes the lane
+  // holds.  For the shapes whose k+1 pigeonhole pieces are 5 or 6 rows (m = 23, k = 3; m = 32, k = 4, 5; ...): the fused
+  // launch, and only it (what it cannot finish goes to the paths below, as before).  SASSY_HIP_PAIR=0: never; 2: the
+  // q-gram counting filter keeps the shapes it is selective for.
+  static const int env_pair = getenv("SASSY_HIP_PAIR") ? atoi(getenv("SASSY_HIP_PAIR")) : 1;
+  const uint32_t pair_s = (k + 2) / 2;
+  const uint32_t pair_q = (k >= 1 && pair_s <= 4) ? plan.m / (2 * pair_s) : 0;
+  const bool pair_ok = env_pair != 0 && q == 0 && env_pre < 0 && fuse_ok && !overhang && !ext_bitmap && !ext_desc && !plan.bytes &&
+                       (S->profile == PROFILE_DNA || (plain_pattern && plan.nslots <= 4 && pair_s <= 3)) &&
+                       (pair_q == 5 || pair_q == 6) && (env_kind == 0 || env_kind == kFilterPlanes);
+  pair = 0;
   // q-gram counting (count_filter.hip): per (Q, R) variant the threshold t = m + 1 - (k+1) Q, the
   // window W, and how often a window of random text reaches t by chance (the pattern's q-grams,
   // ambiguity letters expanded, against 4^Q; Poisson tail).  Taken when that beats the expected
@@ -1046,7 +1059,8 @@ int ScanJob::prepare() {
   // strands in one pass cost the bit-plane kernel 8 pieces, 0.85 ms per 3 GB, the counting kernel nothing extra).
   count_r = 0;
   if (!overhang && !ext_bitmap && !ext_desc && S->profile != PROFILE_ASCII && env_pre != 0 &&
-      (env_kind == 0 || env_kind == kFilterCount) && !(can_planes && env_kind == 0 && rc_bitmap == nullptr)) {
+      (env_kind == 0 || env_kind == kFilterCount) && !(can_planes && env_kind == 0 && rc_bitmap == nullptr) &&
+      !(pair_ok && env_pair != 2)) {
     // two positions per lookup first (half the LDS traffic of (7,1)); the 7-gram variant only where
     // the shorter q-grams are not selective enough
     static const uint32_t variants[][2] = {{6, 2}, {5, 2}, {7, 1}};
@@ -1108,7 +1122,12 @@ int ScanJob::prepare() {
       }
     }
   }
-  if (short_ok && fkind != kFilterCount) {
+  if (pair_ok && fkind != kFilterCount) {
+    pair = pair_s;
+    q = pair_q;
+    iupac_planes = plain_pattern;
+    can_planes = true;
+  } else if (short_ok && fkind != kFilterCount) {
     q = plan.m / pieces;
     iupac_planes = plain_pattern && plan.nslots <= 4;
     can_planes = S->profile == PROFILE_DNA || iupac_planes;
@@ -1280,7 +1299,8 @@ int ScanJob::prepare() {
     // owned one is affected.
     const uint64_t look = std::min<uint64_t>(first_owned, (uint64_t)P.wb + 2);
     F.first_owned_block = first_owned - look;
-    F.n_pieces = k + 1;
+    F.n_pieces = pair ? 2 * pair : k + 1;
+    F.pair = pair;
     F.piece_len = q;
     F.piece_groups = F.n_pieces <= 4 ? 1u : F.n_pieces <= 8 ? 2u : 0u;
     if (F.piece_groups) {
@@ -1319,8 +1339,22 @@ int ScanJob::prepare() {
         X.piece_bits[pp][0] = b0;
         X.piece_bits[pp][1] = b1;
         X.piece_rem[pp] = plan.m - (piece + 1) * q;
+        // (paired filter: an A-type sub-piece is detected q + 1 columns behind its end)
+        if (pair && (piece & 1u) == 0) X.piece_rem[pp] = (uint32_t)((int32_t)X.piece_rem[pp] - (int32_t)(q + 1));
         if (mirror) X.piece_mirror |= 1u << pp;
       };
+      if (pair) {
+        for (uint32_t w = 0; w < 4; ++w) F.pair_y[w] = 0;
+        for (uint32_t pp = 0; pp < 2 * pair; ++pp) {
+          const uint32_t sib = pp ^ 1u;
+          for (uint32_t j = 0; j < q; ++j) {
+            // piece pp even (A): its B read forwards; odd (B): its A read backwards
+            const uint32_t code = (pat[sib * q + ((pp & 1u) ? q - 1 - j : j)] >> 1) & 3u;
+            F.pair_y[2 * (pp >> 2)] |= (code & 1u) << (8 * (pp & 3u) + j);
+            F.pair_y[2 * (pp >> 2) + 1] |= (code >> 1) << (8 * (pp & 3u) + j);
+          }
+        }
+      }
       const uint32_t np = k + 1;
       const bool with_rc = rc_bitmap != nullptr && !ext_bitmap && !ext_desc;
       if (with_rc && np <= 4) {  // both strands' pieces in one launch (a repeated piece changes nothing)
@@ -1807,6 +1841,7 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
   S->stats.filtered = filtered ? (uint32_t)fkind : 0u;
   S->stats.piece_len = q;
   S->stats.fused = fused ? 1u : 0u;
+  S->stats.pair = fused ? pair : 0u;
   {
     unsigned long long c[4];
     memcpy(c, L.h_pin + kPinCounters, sizeof c);

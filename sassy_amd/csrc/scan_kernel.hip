@@ -1856,17 +1856,35 @@ __device__ __forceinline__ uint32_t other_letters_sum16(const uint4 v, uint32_t 
   return diff;  // (sums of absolute differences: 0 stays 0 only while every byte is a plain base)
 }
 __device__ __forceinline__ bool other_letters16(const uint4 v) { return other_letters_sum16(v, 0u) != 0u; }
-template <int Q, int NPG, bool FUSED, bool CHECK = false>
+//
+// PAIR (fused only): the PAIRED filter for shapes whose k+1 pigeonhole pieces would be 5 or 6 rows -- the reference's own
+// benchmark shape m = 23, k = 3 (benches/perf.rs:46-48), m = 32 with k = 4, 5 -- where an exact piece ends in every fourth
+// to tenth block and the chunk DP behind the filter costs more than the streaming DP over every block.  The pattern is
+// cut into S = ceil((k+1)/2) SUPER-PIECES of 2 Q rows instead (NPG = S here): of k edits one super-piece holds at most
+// floor(k / S) = 1, so one of its two halves ("sub-pieces" A = first Q rows, B = next Q rows) occurs exactly and the
+// other one with at most one edit RIGHT NEXT TO IT in the text.  Stage 1 is the bit-plane test of the 2 S sub-pieces
+// (A-type pieces are detected Q + 1 columns late, so that the text their B lies in is in the lane's registers); stage 2
+// takes every occurrence, in the lane that found it, from the planes it already holds: the Q + 1 characters behind A /
+// in front of B against the sibling sub-piece with offsets -1, 0, +1 (one substitution, one skipped pattern row, one
+// extra text character -- mismatch masks, first mismatch, what lies beyond it).  An occurrence whose sibling fails is
+// dropped; 4 % of them survive on random text, and a window chunk is queued in every hundredth block instead of every
+// fourth.  Exact: a match with <= k edits always has such a pair (pigeonhole on the super-pieces), and a pair whose
+// detection column lies behind the last block of the buffer (A in the last Q + 1 columns) belongs to a match that ends
+// in the last k + 1 columns: those are always searched.
+template <int Q, int NPG, bool FUSED, bool CHECK = false, bool PAIR = false>
 // (CHECK: four waves per SIMD are asked for -- left to itself the compiler settles for three, 0.59 instead of 0.52 ms)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 : 1))) void filter_dna_kernel(const ScanParams P) {
   static_assert(!CHECK || FUSED, "the text check exists in the fused launch only");
+  static_assert(!PAIR || (FUSED && 2 * Q + 1 <= 31), "the paired filter exists in the fused launch only; its look-back stays inside one plane half");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int SB = 2;
   constexpr uint32_t kRowBytes = 64u * SB;
   constexpr uint32_t kSlots = 4u * SB;
   constexpr uint32_t kOwnersPerInstr = 64u / kSlots;
   constexpr int kStageInstr = 4 * SB;
-  constexpr int NP = 4 * NPG;
+  constexpr int NP = PAIR ? 2 * NPG : 4 * NPG;
+  constexpr int DL = Q + 1;                  // PAIR: A-type sub-pieces (even index) are detected this many columns late
+  constexpr int ND = PAIR ? 2 * Q + 1 : Q;   // shift distances the piece rows are taken at
   constexpr uint32_t kTile = 64u * kRowBytes;
   typedef const ScanParams __attribute__((address_space(4)))* kparams_ptr;
 
@@ -2027,7 +2045,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
 #pragma unroll
     for (int pp = 0; pp < NP; ++pp) { al[pp] = 0xFFFFFFFFu; ah[pp] = 0xFFFFFFFFu; }
 #pragma unroll
-    for (int d = 0; d < Q; ++d) {
+    for (int d = 0; d < ND; ++d) {
+      if (PAIR && d == Q) continue;  // (no sub-piece row sits at this distance)
       uint32_t s0l, s0h, s1l, s1h;
       if (d == 0) {
         s0l = t0.x; s0h = t0.y; s1l = t1.x; s1h = t1.y;
@@ -2037,15 +2056,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
         s1l = __builtin_amdgcn_alignbit(t1.x, prev1, 32 - d);
         s1h = __builtin_amdgcn_alignbit(t1.y, t1.x, 32 - d);
       }
-      const int j = Q - 1 - d;  // the piece row whose char sits d bits left of the end
 #pragma unroll
       for (int pp = 0; pp < NP; ++pp) {
+        // the piece row whose char sits d bits left of the detection column (PAIR: B-type pieces -- odd -- end there,
+        // A-type pieces ended DL columns earlier)
+        int j = Q - 1 - d;
+        if constexpr (PAIR) {
+          if ((pp & 1) == 0) j += DL;
+          if (j < 0 || j >= Q) continue;
+        }
         const uint32_t n0 = (uint32_t)__builtin_amdgcn_sbfe((int)b0[pp], j, 1);  // all ones iff bit j is set
         const uint32_t n1 = (uint32_t)__builtin_amdgcn_sbfe((int)b1[pp], j, 1);
         al[pp] = bitop3<0x60>(al[pp], s0l, n0);  // a & (b ^ c)
         ah[pp] = bitop3<0x60>(ah[pp], s0h, n0);
         al[pp] = bitop3<0x60>(al[pp], s1l, n1);
         ah[pp] = bitop3<0x60>(ah[pp], s1h, n1);
+      }
+    }
+    if constexpr (PAIR) {
+      // Stage 2: the sibling sub-piece of an occurrence, with at most one edit, right next to it -- for the FIRST occurrence
+      // of every sub-piece in the block (a second one of the same sub-piece in the same block stays: a window too many in
+      // one lane and block of five hundred).  No loop, no branch: all sub-pieces are tested at once, one 8-bit field
+      // of a word each.
+      //   w0 / w1: the code planes of the Q + 1 characters that follow an A (read forwards) / precede a B (read
+      //   backwards), bit j of the field = the character at distance j; y0 / y1: the sibling's rows in that reading
+      //   order (the host packs them); x0 / xm / xp: where sibling row j differs from the character at distance j / j - 1
+      //   / j + 1.  With f = the first set bit of x0: one substitution <=> x0 has no other bit; row f skipped <=> xm is
+      //   clear beyond f; an extra character in front of row f <=> xp is clear from f on (an earlier edit position can only
+      //   do better where x0 is clear anyway).  Field arithmetic: bit 7 of every field is the guard the per-field
+      //   negations, decrements and "is it zero" sums carry into.
+      constexpr uint32_t F1 = 0x01010101u, F7 = 0x7F7F7F7Fu, F8 = 0x80808080u;
+      constexpr uint32_t YM4 = ((1u << Q) - 1u) * F1;
+      constexpr int NW = (NP + 3) / 4;
+      uint32_t w0[NW], w1[NW], bitv[NP];
+      bool lowv[NP];
+#pragma unroll
+      for (int wd = 0; wd < NW; ++wd) w0[wd] = w1[wd] = 0u;
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        const bool low = al[pp] != 0u;
+        const uint32_t w = low ? al[pp] : ah[pp];
+        uint32_t sh;  // column inside the half + 1 (no occurrence: 0 -- the field is computed and never used)
+        asm("v_ffbl_b32 %0, %1" : "=v"(sh) : "v"(w));
+        sh += 1u;
+        const uint64_t s0 = low ? pair64(prev0, t0.x) : pair64(t0.x, t0.y);
+        const uint64_t s1 = low ? pair64(prev1, t1.x) : pair64(t1.x, t1.y);
+        uint32_t e0 = (uint32_t)(s0 >> sh), e1 = (uint32_t)(s1 >> sh);  // bit 31 = the detection column
+        if (pp & 1) {
+          e0 = __builtin_amdgcn_ubfe(__builtin_bitreverse32(e0), Q, Q + 1);
+          e1 = __builtin_amdgcn_ubfe(__builtin_bitreverse32(e1), Q, Q + 1);
+        } else {
+          e0 = __builtin_amdgcn_ubfe(e0, 31 - Q, Q + 1);
+          e1 = __builtin_amdgcn_ubfe(e1, 31 - Q, Q + 1);
+        }
+        w0[pp >> 2] |= e0 << (8 * (pp & 3));
+        w1[pp >> 2] |= e1 << (8 * (pp & 3));
+        bitv[pp] = w & (0u - w);
+        lowv[pp] = low;
+      }
+      uint32_t fail[NW];
+#pragma unroll
+      for (int wd = 0; wd < NW; ++wd) {
+        const uint32_t y0 = Pk->pair_y[2 * wd], y1 = Pk->pair_y[2 * wd + 1];
+        const uint32_t x0 = ((w0[wd] ^ y0) | (w1[wd] ^ y1)) & YM4;
+        const uint32_t xp = (((w0[wd] >> 1) ^ y0) | ((w1[wd] >> 1) ^ y1)) & YM4;
+        const uint32_t xm = (((w0[wd] << 1) ^ y0) | ((w1[wd] << 1) ^ y1)) & YM4;
+        const uint32_t first = x0 & ((x0 ^ F7) + F1);
+        const uint32_t below = (first | F8) - F1;       // (x0 == 0: all seven bits)
+        const uint32_t sub_f = x0 ^ first, del_f = xm & ~(below | first), ins_f = xp & ~below;
+        fail[wd] = (sub_f + F7) & (del_f + F7) & (ins_f + F7);  // bit 7 of a field: none of the three ways fits
+      }
+#pragma unroll
+      for (int pp = 0; pp < NP; ++pp) {
+        const uint32_t d = (uint32_t)__builtin_amdgcn_sbfe((int)fail[pp >> 2], 8 * (pp & 3) + 7, 1) & bitv[pp];
+        const uint32_t dl = lowv[pp] ? d : 0u;
+        al[pp] ^= dl;
+        ah[pp] ^= d ^ dl;
       }
     }
     prev0 = t0.y;
@@ -2102,7 +2188,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
         for (int pp = 0; pp < NP; ++pp) {
           const uint64_t bits = ((uint64_t)ah[pp] << 32) | al[pp];
           if (bits != 0) {
-            const uint2 r = piece_end_cols(bits, b, (int64_t)Pk->piece_rem[pp], (int64_t)Pk->k, (int64_t)(Pk->n_blocks * 64), col_base);
+            // (PAIR: an A-type piece's rem counts from its detection column -- it may be -1)
+            const uint2 r = piece_end_cols(bits, b, (int64_t)(int32_t)Pk->piece_rem[pp], (int64_t)Pk->k, (int64_t)(Pk->n_blocks * 64), col_base);
             lo = min(lo, r.x);
             hi = max(hi, r.y);
           }
@@ -2152,6 +2239,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
     const bool streamed = it >= n_iter;
     bool last = false;
     if (streamed && nq + 64u <= Pk->fuse_queue_cap) {  // the runs the lanes still hold (one entry each at most), then the last pass
+      if constexpr (PAIR) {
+        // An A-type sub-piece in the buffer's last Q + 1 columns would be detected behind the last block.  The match
+        // around it ends in the last k + 1 columns (>= Q rows follow the piece): the lane that owns the last block
+        // always has them searched.
+        if (has_chunk && own_hi == Pk->n_blocks && own_lo < own_hi) {
+          int64_t c_lo = (int64_t)Pk->text_len - (int64_t)Pk->k, c_hi = (int64_t)Pk->text_len + 1;
+          if (c_lo < 1) c_lo = 1;
+          if (c_hi > (int64_t)(Pk->n_blocks * 64)) c_hi = (int64_t)(Pk->n_blocks * 64);
+          const int64_t fc = (int64_t)(Pk->dp_first_owned * 64) - col_base;
+          run = fuse_add_range(queue, qcount, Pk->cand_count + kCtlFuseWord, Pk->fuse_queue_cap, 0xFFFFFFFFu, Pk->m + Pk->k, col_base,
+                               fc > 0 ? (uint32_t)fc : 0u, run, (uint32_t)(c_lo - col_base), (uint32_t)(c_hi - col_base));
+        }
+      }
       if (run.x != kRunNone)
         run = fuse_add_range(queue, qcount, Pk->cand_count + kCtlFuseWord, Pk->fuse_queue_cap, 0xFFFFFFFFu, Pk->m + Pk->k, col_base, 0u, run,
                              kRunNone, 0u);
@@ -2533,6 +2633,35 @@ static hipError_t launch_filter_planes_q(const ScanParams& P, uint32_t grid, hip
   else hipLaunchKernelGGL((filter_dna_kernel<Q, NPG, false>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
 }
+// the paired filter (fused launch only): S super-pieces of two Q-row sub-pieces each
+template <int Q, int S>
+static hipError_t launch_filter_pair_q(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  const size_t smem = (size_t)kWavesPerGroup * P.lds_per_wave;
+  const LaunchEvents ev = g_launch_events;
+  g_launch_events = LaunchEvents{};
+  if (!P.fused) return hipErrorInvalidValue;
+  if (ev.start)
+    hipExtLaunchKernelGGL((filter_dna_kernel<Q, S, true, false, true>), dim3(grid), dim3(256), smem, stream, ev.start, ev.stop, 0, P);
+  else hipLaunchKernelGGL((filter_dna_kernel<Q, S, true, false, true>), dim3(grid), dim3(256), smem, stream, P);
+  return hipGetLastError();
+}
+template <int Q>
+static hipError_t launch_filter_pair_s(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  switch (P.pair) {
+    case 1: return launch_filter_pair_q<Q, 1>(P, grid, stream);
+    case 2: return launch_filter_pair_q<Q, 2>(P, grid, stream);
+    case 3: return launch_filter_pair_q<Q, 3>(P, grid, stream);
+    case 4: return launch_filter_pair_q<Q, 4>(P, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
+static hipError_t launch_filter_pair(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  switch (P.piece_len) {
+    case 5: return launch_filter_pair_s<5>(P, grid, stream);
+    case 6: return launch_filter_pair_s<6>(P, grid, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
 template <int NPG>
 static hipError_t launch_filter_planes(const ScanParams& P, uint32_t grid, hipStream_t stream) {
   switch (P.piece_len) {  // 7 .. 12 by default; shorter pieces with SASSY_HIP_PREFILTER=1 / sassy_hip_set_prefilter(s, 1)
@@ -2591,6 +2720,7 @@ hipError_t launch_filter_dna(const ScanParams& P, uint32_t grid, size_t smem, hi
       hipLaunchKernelGGL((filter_dna_linear_kernel<2>), dim3(grid), dim3(256), (size_t)kWavesPerGroup * 8192u, stream, P);
     return hipGetLastError();
   }
+  if (P.piece_planes && P.pair) return launch_filter_pair(P, grid, stream);
   if (P.piece_planes)  // <= 8 pieces: the bit-plane kernel (lds_per_wave = the staging tile, + the chunk queue when fused)
     return P.piece_groups == 1 ? launch_filter_planes<1>(P, grid, stream) : launch_filter_planes<2>(P, grid, stream);
   return launch_filter_one<PROFILE_DNA, 4>(P, grid, smem, stream);
@@ -2632,7 +2762,29 @@ static hipError_t launch_filter_planes_iupac_q(const ScanParams& P, uint32_t gri
   else hipLaunchKernelGGL((filter_dna_kernel<Q, 1, true, true>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
 }
+template <int Q, int S>
+static hipError_t launch_filter_pair_iupac_q(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  const size_t smem = (size_t)kWavesPerGroup * P.lds_per_wave;
+  const LaunchEvents ev = g_launch_events;
+  g_launch_events = LaunchEvents{};
+  if (ev.start)
+    hipExtLaunchKernelGGL((filter_dna_kernel<Q, S, true, true, true>), dim3(grid), dim3(256), smem, stream, ev.start, ev.stop, 0, P);
+  else hipLaunchKernelGGL((filter_dna_kernel<Q, S, true, true, true>), dim3(grid), dim3(256), smem, stream, P);
+  return hipGetLastError();
+}
 static hipError_t launch_filter_planes_iupac(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  if (P.pair) {  // the paired filter with the text check (the host asks for at most three super-pieces here)
+    const uint32_t key = P.piece_len * 8u + P.pair;
+    switch (key) {
+      case 5 * 8 + 1: return launch_filter_pair_iupac_q<5, 1>(P, grid, stream);
+      case 5 * 8 + 2: return launch_filter_pair_iupac_q<5, 2>(P, grid, stream);
+      case 5 * 8 + 3: return launch_filter_pair_iupac_q<5, 3>(P, grid, stream);
+      case 6 * 8 + 1: return launch_filter_pair_iupac_q<6, 1>(P, grid, stream);
+      case 6 * 8 + 2: return launch_filter_pair_iupac_q<6, 2>(P, grid, stream);
+      case 6 * 8 + 3: return launch_filter_pair_iupac_q<6, 3>(P, grid, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (P.piece_len) {
     case 5: return launch_filter_planes_iupac_q<5>(P, grid, stream);
     case 6: return launch_filter_planes_iupac_q<6>(P, grid, stream);

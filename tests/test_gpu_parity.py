@@ -2374,12 +2374,159 @@ def test_fuzz_regressions(sassy, name):
                 os.environ.pop(k_, None)
 
 
+# ------------------------------------------------------------------ the paired filter (round 5)
+_PAIR_SHAPES = [(23, 3), (20, 3), (24, 3), (27, 3), (32, 4), (34, 4), (32, 5), (35, 5), (41, 5), (10, 1), (12, 1), (13, 1), (20, 2),
+                (40, 6), (48, 6), (47, 7), (55, 7)]
+
+
+def _pair_geometry(m, k):
+    """(super-pieces S, rows per sub-piece Q) of the paired filter for a shape (host.hip: pair_s / pair_q)."""
+    s_ = (k + 2) // 2
+    return s_, m // (2 * s_)
+
+
+def _pair_variants(rng, pat, k):
+    """Mutated copies of `pat`, each within k edits, built against the paired filter's pigeonhole: ONE super-piece keeps a
+    single edit -- every row of both of its halves, every kind of edit -- and the other super-pieces take the rest of the
+    budget (two edits each where it reaches), so that the pair the filter must find is the one with the edit in it."""
+    m = len(pat)
+    S, Q = _pair_geometry(m, k)
+    out = []
+    other = lambda c: bytes([rng.choice([x for x in b"ACGT" if x != c])])
+    for t in range(S):
+        for j in range(2 * Q):
+            for kind in range(3):
+                edits = {t * 2 * Q + j: kind}
+                budget = k - 1
+                for u in range(S):  # two edits in every other super-piece while the budget lasts, far from their borders
+                    if u == t:
+                        continue
+                    for off in (1, Q + 1):
+                        if budget > 0:
+                            edits[u * 2 * Q + off] = 0
+                            budget -= 1
+                v = bytearray()
+                for i, c in enumerate(pat):
+                    if i in edits:
+                        if edits[i] == 0:
+                            v += other(c)
+                        elif edits[i] == 1:
+                            v += other(c) + bytes([c])   # an extra text character in front of row i
+                        # kind 2: row i has no text character
+                    else:
+                        v.append(c)
+                out.append(bytes(v))
+    return out
+
+
+def _env_allows_pairing():
+    e = os.environ
+    return _env_allows_fusing() and e.get("SASSY_HIP_PAIR", "1") != "0" and e.get("SASSY_HIP_PREFILTER", "-1") == "-1"
+
+
+@pytest.mark.parametrize("profile", ["dna", "iupac"])
+def test_paired_filter_against_oracle(sassy, profile):
+    """filter_dna_kernel<.., PAIR>: shapes whose pigeonhole pieces are 5 or 6 rows (the reference's benchmark shape m = 23,
+    k = 3, benches/perf.rs:46-48) -- every single-edit placement in every super-piece with the rest of the budget spent
+    elsewhere, plants at the text's first and last columns (the A-type sub-piece that would be detected behind the last
+    block), ragged and block-aligned lengths, search_all, shards, an Iupac searcher on a text with other letters, tiny texts."""
+    rng = random.Random(505 if profile == "dna" else 506)
+    s = sassy.Searcher(profile, rc=False)
+    ran = 0
+    for m, k in _PAIR_SHAPES:
+        S, Q = _pair_geometry(m, k)
+        if profile == "iupac" and S > 3:
+            continue
+        pat = rand_seq(rng, m)
+        variants = _pair_variants(rng, pat, k)
+        rng.shuffle(variants)
+        variants = variants[:60]
+        # over budget: one more edit than k, spread
+        variants += [mutate(rng, pat, k + 1) for _ in range(6)]
+        for tail in (0, 1, 64):  # the text ends inside a block / on a block border
+            text = bytearray()
+            for v in variants:
+                text += rand_seq(rng, rng.randrange(40, 200)) + v
+            text += rand_seq(rng, 100)
+            n = (len(text) + 63) // 64 * 64 + tail
+            text += rand_seq(rng, n - len(text))
+            # the text begins with a copy that lost its first rows, and ends with one that lost its last rows (the pair in
+            # front of them is found behind the last block's columns: the tail the launch always searches)
+            j0, j1 = rng.randrange(0, k + 1), rng.randrange(0, k + 1)
+            text[:m - j0] = pat[j0:]
+            text[n - (m - j1):] = pat[:m - j1]
+            text = bytes(text)
+            want = oracle.search(profile, pat, text, k)
+            got = s.search(pat, text, k)
+            st = s.stats()
+            ran += 1 if st["pair"] else 0
+            assert_same(got, want, ("pair", profile, m, k, tail, st["filtered"], st["fused"], st["pair"]))
+            assert len(want) >= 20
+            if tail == 1:
+                cut = text[:5000]
+                assert_same(s.search_all(pat, cut, k), oracle.search(profile, pat, cut, k, all_minima=True), ("pair all", m, k))
+        # tiny texts: shorter than the pattern, than a block, than the look-back
+        for n in (0, 1, Q, 2 * Q + 1, m - k, m, m + k, 63, 64, 65, 129):
+            text = (pat * 3)[:n] if n % 2 else rand_seq(rng, n)
+            assert_same(s.search(pat, text, k), oracle.search(profile, pat, text, k), ("pair tiny", m, k, n))
+    if _env_allows_pairing():
+        assert ran >= 3 * (len(_PAIR_SHAPES) - (5 if profile == "iupac" else 0)) - 2, ran
+    # a low-complexity pattern on a text of its own units: sub-piece occurrences everywhere, every sibling passes
+    for unit, m, k in ((b"AC", 23, 3), (b"A", 32, 4), (b"ACG", 32, 5), (b"AAC", 23, 3)):
+        pat = (unit * m)[:m]
+        text = bytearray(rand_seq(rng, 30000))
+        for _ in range(4):
+            at, ln = rng.randrange(0, 28000), rng.choice([50, 300, 1500])
+            text[at:at + ln] = (unit * ln)[:ln]
+        for _ in range(30):
+            text[rng.randrange(len(text))] = rng.choice(b"ACGT")
+        text = bytes(text)
+        assert_same(s.search(pat, text, k), oracle.search(profile, pat, text, k), ("pair low complexity", unit, m, k))
+    # shards with halos over a resident text, plants across the seams and at the seams' first / last columns
+    m, k = 23, 3
+    pat = rand_seq(rng, m)
+    n = (1 << 20) + 77
+    text = bytearray(oracle.generate_dna(52, 0, n).tobytes())
+    bounds = [0, 64 * 700, 64 * 701, 64 * 4000, 1 << 19, n]
+    for b in bounds[1:-1]:
+        for off in (-m - 2, -m, -12, -3, 0, 5):
+            ins = mutate(rng, pat, rng.randrange(k + 1))
+            text[b + off:b + off + len(ins)] = ins
+    for v in _pair_variants(rng, pat, k)[::3]:
+        at = rng.randrange(0, n - 64)
+        text[at:at + len(v)] = v
+    if profile == "iupac":
+        for _ in range(300):
+            text[rng.randrange(n)] = rng.choice(b"NRYKMnX-")
+        for _ in range(3):
+            at, ln = rng.randrange(0, n - 3000), rng.choice([70, 900, 2500])
+            text[at:at + ln] = b"N" * ln
+    text = bytes(text[:n])
+    buf = sassy.DeviceBuffer(n + 256)
+    buf.upload(text)
+    want = oracle.search(profile, pat, text, k)
+    halo = sassy.required_halo(m, k)
+    allm = []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        h = 0 if a == 0 else halo
+        allm.append(s.search_shard(pat, buf.ptr + a - h, h, b - a, a, n, k))
+    assert_same(sassy.merge_shards(allm, 1).matches, want, "pair shards")
+    assert s.stats()["pair"] == 2 or not _env_allows_pairing()
+    t1 = s.search_shard_begin(pat, buf.ptr, 0, n, 0, n, k)
+    t2 = s.search_shard_begin(pat, buf.ptr, 0, n, 0, n, k - 1)
+    assert_same(s.search_finish(t2).matches, oracle.search(profile, pat, text, k - 1), "pair in flight k-1")
+    assert_same(s.search_finish(t1).matches, want, "pair in flight")
+    buf.free()
+
+
+
 # ------------------------------------------------------------------ every kernel path, forced
 _CORE = ("test_fuzz_small_texts or test_low_complexity_and_seams or test_long_pattern_iupac_config3_shape or "
          "test_traceback_variants or test_dna_profile_text_with_other_letters or test_device_resident_search_and_shards or "
          "test_shard_seam_plateau_chain or test_fused_filter_equals_classic_chain_and_oracle or test_dense_reports or "
          "test_qgram_count_filter_worst_case_edits or test_searches_in_flight_begin_finish or "
-         "test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_any_text or test_fused_filter_dense_runs_and_its_one_fall_back")
+         "test_iupac_searcher_plain_pattern_takes_the_dna_launch_on_any_text or test_fused_filter_dense_runs_and_its_one_fall_back or "
+         "test_paired_filter_against_oracle")
 _FORCED = [
     {"SASSY_HIP_PREFILTER": "0"},                    # streaming DP over every block (scan_kernel), also multi-word
     {"SASSY_HIP_PREFILTER": "0", "SASSY_HIP_ROW_CUT": "0"},   # ... every row of every block
@@ -2402,6 +2549,7 @@ _FORCED = [
     {"SASSY_HIP_FILTER_KIND": "4", "SASSY_HIP_COUNT_WPG": "4"},  # the counting filter with four waves per workgroup
     {"SASSY_HIP_BIG_PIN": "0", "SASSY_HIP_SHORT_PIECES": "0"},   # dense results through the host's vectors; no 5- / 6-row pieces
     {"SASSY_HIP_FUSED_PRESS": "8", "SASSY_HIP_EXT_EVENTS": "0"},  # a pass of the fused launch's waves every 8 queued windows
+    {"SASSY_HIP_PAIR": "0"},                         # no paired filter: 5- / 6-row shapes through the paths of round 4
 ]
 
 
