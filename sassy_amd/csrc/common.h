@@ -148,7 +148,7 @@ struct ScanParams {
   uint32_t stash_cap;
   uint32_t piece_rem[8];      // pattern rows behind piece p: a match that contains the piece exactly, ending
                               // at text position e, ends in [e + rem - k, e + rem + k]  (read as int32: the paired
-                              // filter's A-type sub-pieces count from their detection column, piece_len + 1 later)
+                              // filter's A-type sub-pieces count from their detection column, piece_len + 2 later)
   uint32_t pair_y[4];         // paired filter: the sibling sub-piece of piece p in the reading order its test uses (rows
                               // forwards for the B behind an A, backwards for the A in front of a B), code bit 0 / code
                               // bit 1 in byte p & 3 of pair_y[2 (p >> 2)] / pair_y[2 (p >> 2) + 1]

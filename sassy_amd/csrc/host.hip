@@ -1339,8 +1339,8 @@ int ScanJob::prepare() {
         X.piece_bits[pp][0] = b0;
         X.piece_bits[pp][1] = b1;
         X.piece_rem[pp] = plan.m - (piece + 1) * q;
-        // (paired filter: an A-type sub-piece is detected q + 1 columns behind its end)
-        if (pair && (piece & 1u) == 0) X.piece_rem[pp] = (uint32_t)((int32_t)X.piece_rem[pp] - (int32_t)(q + 1));
+        // (paired filter: an A-type sub-piece is detected q + 2 columns behind its end)
+        if (pair && (piece & 1u) == 0) X.piece_rem[pp] = (uint32_t)((int32_t)X.piece_rem[pp] - (int32_t)(q + 2));
         if (mirror) X.piece_mirror |= 1u << pp;
       };
       if (pair) {

@@ -1863,19 +1863,19 @@ __device__ __forceinline__ bool other_letters16(const uint4 v) { return other_le
 // cut into S = ceil((k+1)/2) SUPER-PIECES of 2 Q rows instead (NPG = S here): of k edits one super-piece holds at most
 // floor(k / S) = 1, so one of its two halves ("sub-pieces" A = first Q rows, B = next Q rows) occurs exactly and the
 // other one with at most one edit RIGHT NEXT TO IT in the text.  Stage 1 is the bit-plane test of the 2 S sub-pieces
-// (A-type pieces are detected Q + 1 columns late, so that the text their B lies in is in the lane's registers); stage 2
+// (A-type pieces are detected Q + 2 columns late, so that the text their B lies in is in the lane's registers); stage 2
 // takes every occurrence, in the lane that found it, from the planes it already holds: the Q + 1 characters behind A /
 // in front of B against the sibling sub-piece with offsets -1, 0, +1 (one substitution, one skipped pattern row, one
 // extra text character -- mismatch masks, first mismatch, what lies beyond it).  An occurrence whose sibling fails is
 // dropped; 4 % of them survive on random text, and a window chunk is queued in every hundredth block instead of every
 // fourth.  Exact: a match with <= k edits always has such a pair (pigeonhole on the super-pieces), and a pair whose
-// detection column lies behind the last block of the buffer (A in the last Q + 1 columns) belongs to a match that ends
-// in the last k + 1 columns: those are always searched.
+// detection column lies behind the last block of the buffer (A in the last Q + 2 columns) belongs to a match that ends
+// in the last k + 2 columns: those are always searched.
 template <int Q, int NPG, bool FUSED, bool CHECK = false, bool PAIR = false>
 // (CHECK: four waves per SIMD are asked for -- left to itself the compiler settles for three, 0.59 instead of 0.52 ms)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 : 1))) void filter_dna_kernel(const ScanParams P) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CHECK || PAIR) ? 4 : 1))) void filter_dna_kernel(const ScanParams P) {
   static_assert(!CHECK || FUSED, "the text check exists in the fused launch only");
-  static_assert(!PAIR || (FUSED && 2 * Q + 1 <= 31), "the paired filter exists in the fused launch only; its look-back stays inside one plane half");
+  static_assert(!PAIR || (FUSED && 2 * Q + 2 <= 31), "the paired filter exists in the fused launch only; its look-back stays inside one plane half");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int SB = 2;
   constexpr uint32_t kRowBytes = 64u * SB;
@@ -1883,8 +1883,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
   constexpr uint32_t kOwnersPerInstr = 64u / kSlots;
   constexpr int kStageInstr = 4 * SB;
   constexpr int NP = PAIR ? 2 * NPG : 4 * NPG;
-  constexpr int DL = Q + 1;                  // PAIR: A-type sub-pieces (even index) are detected this many columns late
-  constexpr int ND = PAIR ? 2 * Q + 1 : Q;   // shift distances the piece rows are taken at
+  // PAIR: A-type sub-pieces (even index) are detected DL columns late: the Q + 1 characters behind them then lie in front
+  // of the detection column, like the characters in front of a B (one v_alignbit by the column index fetches either)
+  constexpr int DL = Q + 2;
+  constexpr int ND = PAIR ? Q + DL : Q;      // shift distances the piece rows are taken at
   constexpr uint32_t kTile = 64u * kRowBytes;
   typedef const ScanParams __attribute__((address_space(4)))* kparams_ptr;
 
@@ -2046,7 +2048,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
     for (int pp = 0; pp < NP; ++pp) { al[pp] = 0xFFFFFFFFu; ah[pp] = 0xFFFFFFFFu; }
 #pragma unroll
     for (int d = 0; d < ND; ++d) {
-      if (PAIR && d == Q) continue;  // (no sub-piece row sits at this distance)
+      if (PAIR && d >= Q && d < DL) continue;  // (no sub-piece row sits at these distances)
+      if constexpr (PAIR) __builtin_amdgcn_sched_barrier(0);
       uint32_t s0l, s0h, s1l, s1h;
       if (d == 0) {
         s0l = t0.x; s0h = t0.y; s1l = t1.x; s1h = t1.y;
@@ -2088,33 +2091,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
       constexpr uint32_t F1 = 0x01010101u, F7 = 0x7F7F7F7Fu, F8 = 0x80808080u;
       constexpr uint32_t YM4 = ((1u << Q) - 1u) * F1;
       constexpr int NW = (NP + 3) / 4;
-      uint32_t w0[NW], w1[NW], bitv[NP];
-      bool lowv[NP];
+      uint32_t w0[NW], w1[NW];
 #pragma unroll
       for (int wd = 0; wd < NW; ++wd) w0[wd] = w1[wd] = 0u;
+      // (the scheduler is kept from weaving stage 2 into stage 1 and the sub-pieces into one another: left to itself it
+      // holds every shifted plane and every sub-piece's intermediate values at once -- 165 VGPRs, three waves per SIMD)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int pp = 0; pp < NP; ++pp) {
+        if (pp) __builtin_amdgcn_sched_barrier(0);
         const bool low = al[pp] != 0u;
         const uint32_t w = low ? al[pp] : ah[pp];
-        uint32_t sh;  // column inside the half + 1 (no occurrence: 0 -- the field is computed and never used)
+        uint32_t sh;  // column inside the half (no occurrence: -1 -- the field is computed and never used)
         asm("v_ffbl_b32 %0, %1" : "=v"(sh) : "v"(w));
-        sh += 1u;
+        // the 32 columns in front of the detection column: bit 31 = the column right in front of it
         const uint64_t s0 = low ? pair64(prev0, t0.x) : pair64(t0.x, t0.y);
         const uint64_t s1 = low ? pair64(prev1, t1.x) : pair64(t1.x, t1.y);
-        uint32_t e0 = (uint32_t)(s0 >> sh), e1 = (uint32_t)(s1 >> sh);  // bit 31 = the detection column
+        uint32_t e0 = (uint32_t)(s0 >> (sh & 31u)), e1 = (uint32_t)(s1 >> (sh & 31u));
         if (pp & 1) {
-          e0 = __builtin_amdgcn_ubfe(__builtin_bitreverse32(e0), Q, Q + 1);
-          e1 = __builtin_amdgcn_ubfe(__builtin_bitreverse32(e1), Q, Q + 1);
+          e0 = __builtin_amdgcn_ubfe(__builtin_bitreverse32(e0), Q - 1, Q + 1);
+          e1 = __builtin_amdgcn_ubfe(__builtin_bitreverse32(e1), Q - 1, Q + 1);
         } else {
           e0 = __builtin_amdgcn_ubfe(e0, 31 - Q, Q + 1);
           e1 = __builtin_amdgcn_ubfe(e1, 31 - Q, Q + 1);
         }
         w0[pp >> 2] |= e0 << (8 * (pp & 3));
         w1[pp >> 2] |= e1 << (8 * (pp & 3));
-        bitv[pp] = w & (0u - w);
-        lowv[pp] = low;
       }
       uint32_t fail[NW];
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int wd = 0; wd < NW; ++wd) {
         const uint32_t y0 = Pk->pair_y[2 * wd], y1 = Pk->pair_y[2 * wd + 1];
@@ -2126,12 +2131,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
         const uint32_t sub_f = x0 ^ first, del_f = xm & ~(below | first), ins_f = xp & ~below;
         fail[wd] = (sub_f + F7) & (del_f + F7) & (ins_f + F7);  // bit 7 of a field: none of the three ways fits
       }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int pp = 0; pp < NP; ++pp) {
-        const uint32_t d = (uint32_t)__builtin_amdgcn_sbfe((int)fail[pp >> 2], 8 * (pp & 3) + 7, 1) & bitv[pp];
-        const uint32_t dl = lowv[pp] ? d : 0u;
-        al[pp] ^= dl;
-        ah[pp] ^= d ^ dl;
+        // a failed sibling: the sub-piece's first occurrence -- the lowest set bit of its 64 columns -- leaves the mask
+        const uint32_t keep = ~(uint32_t)__builtin_amdgcn_sbfe((int)fail[pp >> 2], 8 * (pp & 3) + 7, 1);
+        const uint64_t less = lshl_add_u64<0>(pair64(al[pp], ah[pp]), ~0ull);  // mask - 1
+        al[pp] &= lo32(less) | keep;
+        ah[pp] &= hi32(less) | keep;
       }
     }
     prev0 = t0.y;
@@ -2240,11 +2247,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CHECK ? 4 :
     bool last = false;
     if (streamed && nq + 64u <= Pk->fuse_queue_cap) {  // the runs the lanes still hold (one entry each at most), then the last pass
       if constexpr (PAIR) {
-        // An A-type sub-piece in the buffer's last Q + 1 columns would be detected behind the last block.  The match
-        // around it ends in the last k + 1 columns (>= Q rows follow the piece): the lane that owns the last block
-        // always has them searched.
+        // An A-type sub-piece in the buffer's last DL columns would be detected behind the last block.  The match
+        // around it ends in the last k + 1 + DL - Q columns (>= Q rows follow the piece): the lane that owns the last
+        // block always has them searched.
         if (has_chunk && own_hi == Pk->n_blocks && own_lo < own_hi) {
-          int64_t c_lo = (int64_t)Pk->text_len - (int64_t)Pk->k, c_hi = (int64_t)Pk->text_len + 1;
+          int64_t c_lo = (int64_t)Pk->text_len - (int64_t)Pk->k - (DL - Q - 1), c_hi = (int64_t)Pk->text_len + 1;
           if (c_lo < 1) c_lo = 1;
           if (c_hi > (int64_t)(Pk->n_blocks * 64)) c_hi = (int64_t)(Pk->n_blocks * 64);
           const int64_t fc = (int64_t)(Pk->dp_first_owned * 64) - col_base;
