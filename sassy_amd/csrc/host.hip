@@ -688,6 +688,31 @@ static uint32_t filter_piece_len(const PatternPlan& plan, uint32_t k, int mode) 
   return (uint32_t)q;
 }
 
+// The paired filter's geometry for a shape (filter_dna_kernel<.., PAIR>): S = ceil((k+1)/2) super-pieces of two sub-pieces
+// of Q = m / (2 S) rows each.  Taken where the k+1 pigeonhole pieces are shorter than 7 rows and Q is 5 or 6 (m = 23, k = 3;
+// m = 32, k = 4, 5; m = 12, k = 1; ...).  False: the shape is not one of them.
+static bool pair_geometry(uint32_t m, uint32_t k, uint32_t* s_out, uint32_t* q_out) {
+  if (k < 1 || m / (k + 1) >= 7) return false;
+  const uint32_t s = (k + 2) / 2;
+  if (s > 4) return false;
+  const uint32_t q = m / (2 * s);
+  if (q != 5 && q != 6) return false;
+  *s_out = s;
+  *q_out = q;
+  return true;
+}
+static int pair_env() {
+  static const int v = getenv("SASSY_HIP_PAIR") ? atoi(getenv("SASSY_HIP_PAIR")) : 1;
+  return v;
+}
+static bool plain_acgt(const uint8_t* pat, size_t m) {
+  for (size_t j = 0; j < m; ++j) {
+    const uint8_t u = pat[j] & 0xDFu;
+    if (u != 'A' && u != 'C' && u != 'G' && u != 'T') return false;
+  }
+  return true;
+}
+
 // The three prefilter kernels (scan_kernel.hip): which one evaluates the pieces.
 enum FilterKind : uint32_t {
   kFilterGeneric = 1,  // filter_kernel: slot masks in LDS, any profile, <= 255 piece rows
@@ -1045,12 +1070,12 @@ int ScanJob::prepare() {
   // holds.  For the shapes whose k+1 pigeonhole pieces are 5 or 6 rows (m = 23, k = 3; m = 32, k = 4, 5; ...): the fused
   // launch, and only it (what it cannot finish goes to the paths below, as before).  SASSY_HIP_PAIR=0: never; 2: the
   // q-gram counting filter keeps the shapes it is selective for.
-  static const int env_pair = getenv("SASSY_HIP_PAIR") ? atoi(getenv("SASSY_HIP_PAIR")) : 1;
-  const uint32_t pair_s = (k + 2) / 2;
-  const uint32_t pair_q = (k >= 1 && pair_s <= 4) ? plan.m / (2 * pair_s) : 0;
+  const int env_pair = pair_env();
+  uint32_t pair_s = 0, pair_q = 0;
   const bool pair_ok = env_pair != 0 && q == 0 && env_pre < 0 && fuse_ok && !overhang && !ext_bitmap && !ext_desc && !plan.bytes &&
+                       pair_geometry(plan.m, k, &pair_s, &pair_q) &&
                        (S->profile == PROFILE_DNA || (plain_pattern && plan.nslots <= 4 && pair_s <= 3)) &&
-                       (pair_q == 5 || pair_q == 6) && (env_kind == 0 || env_kind == kFilterPlanes);
+                       (env_kind == 0 || env_kind == kFilterPlanes);
   pair = 0;
   // q-gram counting (count_filter.hip): per (Q, R) variant the threshold t = m + 1 - (k+1) Q, the
   // window W, and how often a window of random text reaches t by chance (the pattern's q-grams,
@@ -2677,8 +2702,16 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
   static const int env_fuse = getenv("SASSY_HIP_RC_FUSED") ? atoi(getenv("SASSY_HIP_RC_FUSED")) : 1;
   // the reference's lane reports (run_scan_ref_lanes): single texts, no overhang; each strand lane by lane
   const uint32_t ref_lanes = (S->ref_lanes == 4 || S->ref_lanes == 8) && std::isnan(S->alpha) ? S->ref_lanes : 0u;
+  // Shapes of the paired filter: it exists as the fused launch of ONE strand only, and two of them (the Rc strand's on the
+  // reversed copy) beat the forward strand's streaming DP with the Rc marks in it (m = 23, k = 3: 1.4 against 1.8 ms).
+  // SASSY_HIP_PAIR_RC=0: as before.
+  static const int env_pair_rc = getenv("SASSY_HIP_PAIR_RC") ? atoi(getenv("SASSY_HIP_PAIR_RC")) : 1;
+  uint32_t ps_ = 0, pq_ = 0;
+  const bool pair_strands = env_pair_rc != 0 && pair_env() != 0 && prefilter_mode(S->prefilter) < 0 && S->fuse && !wo && k <= 0xFFFFu &&
+                            pair_geometry(plan.m, (uint32_t)k, &ps_, &pq_) &&
+                            (S->profile == PROFILE_DNA || (S->profile == PROFILE_IUPAC && ps_ <= 3 && plain_acgt(pattern, plen)));
   const bool can_fuse = fwd_strand && rc_strand && env_fuse != 0 && !ef.fn && std::isnan(S->max_n_frac) &&
-                        std::isnan(S->alpha) && S->profile != PROFILE_ASCII && ref_lanes == 0;
+                        std::isnan(S->alpha) && S->profile != PROFILE_ASCII && ref_lanes == 0 && !pair_strands;
   bool rc_by_bitmap = false;
 
   if (fwd_strand) {

@@ -118,6 +118,13 @@ def fused_case(rng, searchers):
     k = rng.choice([0, 1, 2, 3, 3, 4, 5, 6, 7])
     q = rng.choice([6, 7, 8, 9, 12])  # (6: the fused launch takes 6-row pieces when there are at most four)
     m = q * (k + 1) + rng.choice([0, 0, 1, 3, 17, 60])
+    if rng.random() < 0.4:
+        # the paired filter's shapes: S = ceil((k+1)/2) super-pieces of two 5- or 6-row halves, k+1 pieces shorter than 7 rows
+        k = rng.choice([1, 2, 3, 3, 3, 4, 5, 6, 7])
+        S = (k + 2) // 2
+        q = rng.choice([5, 6])
+        lo, hi = 2 * S * q, min(2 * S * (q + 1), 7 * (k + 1)) - 1
+        m = rng.randrange(lo, hi + 1) if hi >= lo else lo
     n = rng.choice([200, 3_000, 50_000, 300_000, 1_000_000])
     if m > 120:
         n = min(n, 300_000)

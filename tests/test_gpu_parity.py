@@ -2432,6 +2432,7 @@ def test_paired_filter_against_oracle(sassy, profile):
     block), ragged and block-aligned lengths, search_all, shards, an Iupac searcher on a text with other letters, tiny texts."""
     rng = random.Random(505 if profile == "dna" else 506)
     s = sassy.Searcher(profile, rc=False)
+    both = sassy.Searcher(profile, rc=True)
     ran = 0
     for m, k in _PAIR_SHAPES:
         S, Q = _pair_geometry(m, k)
@@ -2465,6 +2466,9 @@ def test_paired_filter_against_oracle(sassy, profile):
             if tail == 1:
                 cut = text[:5000]
                 assert_same(s.search_all(pat, cut, k), oracle.search(profile, pat, cut, k, all_minima=True), ("pair all", m, k))
+                # both strands (each strand a fused launch of its own, the Rc strand's on the reversed copy)
+                rtext = text[:3000] + oracle.reverse_complement(profile, text[3000:9000]) + text[9000:12000]
+                assert_same(both.search(pat, rtext, k), oracle.search(profile, pat, rtext, k, rc=True), ("pair rc", m, k))
         # tiny texts: shorter than the pattern, than a block, than the look-back
         for n in (0, 1, Q, 2 * Q + 1, m - k, m, m + k, 63, 64, 65, 129):
             text = (pat * 3)[:n] if n % 2 else rand_seq(rng, n)

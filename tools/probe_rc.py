@@ -16,20 +16,22 @@ class DevText:
     def numel(self): return self._n
     def is_contiguous(self): return True
 text = DevText(buf.ptr, n)
-pat = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, 32)])
+import os
+M, K = int(os.environ.get("PROBE_M", "32")), int(os.environ.get("PROBE_K", "3"))
+pat = bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[r.integers(0, 4, M)])
 for profile in ("dna", "iupac"):
     for rc in (False, True):
         s = sassy_amd.Searcher(profile, rc=rc)
-        s.search(pat, text, 3)
+        s.search(pat, text, K)
         t0 = time.perf_counter()
         for _ in range(5):
-            res = s.search(pat, text, 3)
+            res = s.search(pat, text, K)
         dt = (time.perf_counter() - t0) / 5
-        print(json.dumps({"profile": profile, "rc": rc, "ms": round(dt * 1e3, 3), "matches": len(res)}), flush=True)
+        print(json.dumps({"profile": profile, "m": M, "k": K, "rc": rc, "ms": round(dt * 1e3, 3), "matches": len(res)}), flush=True)
         if rc:
             s.text_unchanged(True)
             t0 = time.perf_counter()
             for _ in range(5):
-                res = s.search(pat, text, 3)
+                res = s.search(pat, text, K)
             dt = (time.perf_counter() - t0) / 5
-            print(json.dumps({"profile": profile, "rc": rc, "text_unchanged": True, "ms": round(dt * 1e3, 3)}), flush=True)
+            print(json.dumps({"profile": profile, "m": M, "k": K, "rc": rc, "text_unchanged": True, "ms": round(dt * 1e3, 3)}), flush=True)
