@@ -591,6 +591,24 @@ def other_configs(sassy_amd, text):
     res["3"] = {"workload": f"Iupac new_fwd, |pattern|=200 (N, R, Y, W at 50/100/150/199), k=20, {n} B",
                 "ms_per_search": round(dt * 1e3, 3), "text_GB_per_s": round(n / dt / 1e9, 1), "matches": len(r),
                 "planted": int(planted3), "roofline_frac": round(n / dt / 1e9 / HBM_PEAK_GBPS, 4), "path": path3}
+    # the reference's own benchmark shape (benches/perf.rs:46-48: |pattern| = 23, k = 3 -- every CRISPR guide 20 + PAM) and
+    # m = 32 with k = 4: shapes whose k+1 pigeonhole pieces are 5 / 6 rows -- the paired filter's fused launch
+    for name, profile, m_, k_ in (("m23k3", "dna", 23, 3), ("m23k3_iupac", "iupac", 23, 3), ("m32k4", "dna", 32, 4)):
+        ps = bytes(_dna_bytes(49, 0, m_))
+        ss = sassy_amd.Searcher(profile, rc=False)
+        r = ss.search_shard(ps, text.data_ptr(), 0, n, 0, n, k_)
+        st = ss.stats()
+        ss.set_timing(0)
+        for _ in range(3):
+            r = ss.search_shard(ps, text.data_ptr(), 0, n, 0, n, k_)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            r = ss.search_shard(ps, text.data_ptr(), 0, n, 0, n, k_)
+        dt = (time.perf_counter() - t0) / 20
+        res[name] = {"workload": f"{profile.capitalize()} new_fwd, |pattern|={m_}, k={k_}, {n} B, lone searches",
+                     "ms_per_search": round(dt * 1e3, 3), "text_GB_per_s": round(n / dt / 1e9, 1), "matches": len(r),
+                     "roofline_frac": round(n / dt / 1e9 / HBM_PEAK_GBPS, 4), "path": int(st["filtered"]), "fused": int(st["fused"]),
+                     "pair": int(st.get("pair", 0)), "piece_len": int(st["piece_len"])}
     flat = _dna_bytes(45, 0, 20 * 10_000).tobytes()
     pats = [flat[20 * i:20 * i + 20] for i in range(10_000)]
     s4 = sassy_amd.Searcher("iupac", rc=False)

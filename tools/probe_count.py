@@ -16,10 +16,10 @@ def run(profile, p, k, steps=5):
     dt = (time.perf_counter() - t0) / steps
     st = s.stats()
     print(json.dumps({"profile": profile, "m": len(p), "k": k, "ms": round(dt*1e3, 3), "matches": len(r),
-        "path": {0: "streaming DP (scan_kernel)", 1: "slot-mask filter + chain", 2: "bit-plane filter" + (", fused launch" if st["fused"] else " + chain"),
+        "path": {0: "streaming DP (scan_kernel)", 1: "slot-mask filter + chain", 2: ("paired bit-plane filter" if st["pair"] else "bit-plane filter") + (", fused launch" if st["fused"] else " + chain"),
                  3: "q-gram table filter + chain", 4: "q-gram counting filter + chain"}[int(st["filtered"])],
         "roofline_frac_lone": round(n / dt / 8e12, 4),
-        **{q: (round(st[q], 3) if isinstance(st[q], float) else st[q]) for q in ("filtered", "fused", "piece_len", "filter_ms", "scan_ms", "trace_ms", "hit_blocks", "chunks")}}), flush=True)
+        **{q: (round(st[q], 3) if isinstance(st[q], float) else st[q]) for q in ("filtered", "fused", "pair", "piece_len", "filter_ms", "scan_ms", "trace_ms", "hit_blocks", "chunks")}}), flush=True)
 run("dna", pat(32, 43), 3)
 run("iupac", pat(32, 43), 3)
 p = bytearray(pat(200, 44)); p[50], p[100], p[150], p[199] = ord("N"), ord("R"), ord("Y"), ord("W")
