@@ -21,6 +21,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass
+from collections.abc import Sequence as _SequenceABC
 from typing import List, Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -192,7 +193,7 @@ def lib():
     L.sassy_hip_multi_plant.argtypes = [vp, C.c_uint64, C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint64, C.POINTER(C.c_uint64)]
     L.sassy_hip_multi_search.restype = C.c_int
     L.sassy_hip_multi_search.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(vp)]
-    if not os.environ.get("SASSY_HIP_LIBRARY"):  # (an older build loaded for an A/B timing lacks the newer entry points)
+    if hasattr(L, "sassy_hip_multi_set_rc"):  # (an older build loaded for an A/B timing lacks the newer entry points)
         L.sassy_hip_multi_set_rc.restype = C.c_int
         L.sassy_hip_multi_set_rc.argtypes = [vp, C.c_int]
         L.sassy_hip_multi_set_replicated.restype = C.c_int
@@ -388,10 +389,70 @@ class Result:
         return self._n
 
     @property
-    def matches(self) -> List["Match"]:
+    def matches(self) -> Sequence["Match"]:
+        """The records as reference-style Match objects: a list for small results, a lazy read-only sequence over the
+        numpy array beyond LAZY_MATCHES records (a Python object per match costs 1.4 us -- 0.46 s for the 330 000 matches
+        of a read set whose search takes 0.02 s)."""
         if self._matches is None:
-            self._matches = matches_from_array(self.array, self.pool)
+            if self._n > LAZY_MATCHES:
+                self._matches = MatchList(self.array, self.pool)
+            else:
+                self._matches = matches_from_array(self.array, self.pool)
         return self._matches
+
+
+LAZY_MATCHES = 4096
+
+
+def _bytes_payload_offset():
+    """Where the payload of a bytes object sits behind id(obj) -- CPython's object layout, checked once at import against a
+    known string; None (search_many then takes every text through _ptr_len) on any other interpreter or layout, or where
+    a pointer does not fit the uint64 / size_t arrays the fast path builds."""
+    import sys
+    if sys.implementation.name != "cpython" or C.sizeof(C.c_void_p) != 8 or C.sizeof(C.c_size_t) != 8:
+        return None
+    off = bytes.__basicsize__ - 1
+    probe = b"sassy-layout-probe"
+    try:
+        return off if C.string_at(id(probe) + off, len(probe)) == probe else None
+    except Exception:
+        return None
+
+
+_BYTES_PAYLOAD_OFFSET = _bytes_payload_offset()
+
+
+class MatchList(_SequenceABC):
+    """A read-only sequence of Match objects over a Result's numpy array and cigar pool: len(), indexing, slicing and
+    iteration behave like the list they replace, the objects are made when they are looked at.  `.array` / `.pool`:
+    the columns themselves (match_dtype)."""
+
+    __slots__ = ("array", "pool")
+
+    def __init__(self, array, pool: bytes):
+        self.array = array
+        self.pool = pool
+
+    def __len__(self):
+        return len(self.array)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return matches_from_array(self.array[i], self.pool)
+        return matches_from_array(self.array[i:i + 1] if i >= 0 else self.array[len(self.array) + i:len(self.array) + i + 1],
+                                  self.pool)[0]
+
+    def __iter__(self):
+        for a in range(0, len(self.array), 4096):
+            yield from matches_from_array(self.array[a:a + 4096], self.pool)
+
+    def __eq__(self, other):
+        if isinstance(other, (list, tuple, MatchList)):
+            return len(other) == len(self) and all(x == y for x, y in zip(self, other))
+        return NotImplemented
+
+    def __repr__(self):
+        return f"MatchList({len(self)} matches)"
 
 
 def matches_from_array(array, pool: bytes) -> List["Match"]:
@@ -483,14 +544,14 @@ class Searcher:
         patterns = [bytes(p) for p in patterns]
         pp = (C.c_char_p * len(patterns))(*patterns)
         pl = (C.c_size_t * len(patterns))(*[len(p) for p in patterns])
-        if all(type(t) is bytes for t in texts):
+        if _BYTES_PAYLOAD_OFFSET is not None and all(type(t) is bytes for t in texts):
             # a read set: ctypes fills the pointer array from the list itself (a few hundred thousand _ptr_len calls
             # cost more than the search)
             import numpy as np
             n_texts, on_device = len(texts), False
             # (CPython: the bytes of a bytes object sit bytes.__basicsize__ - 1 behind its address; `texts` keeps
             # them alive for the call)
-            addr = np.fromiter(map(id, texts), dtype=np.uint64, count=n_texts) + np.uint64(bytes.__basicsize__ - 1)
+            addr = np.fromiter(map(id, texts), dtype=np.uint64, count=n_texts) + np.uint64(_BYTES_PAYLOAD_OFFSET)
             lens = np.fromiter(map(len, texts), dtype=np.uint64, count=n_texts)
             tp = addr.ctypes.data_as(C.POINTER(C.c_void_p))
             tl = lens.ctypes.data_as(C.POINTER(C.c_size_t))
@@ -750,6 +811,8 @@ class MultiSearcher:
 
     def search_encoded(self, patterns: Sequence[bytes], k: int, flags: int = 0) -> "Result":
         patterns = [bytes(p) for p in patterns]
+        if not patterns:
+            raise SassyHipError("No queries provided")
         plen = len(patterns[0])
         if any(len(p) != plen for p in patterns):
             raise SassyHipError("All pattern must have the same length")

@@ -3969,8 +3969,10 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
           // the whole call is this one batch, traced, every report is a record: the records are put in order on the
           // device (assemble_many; SASSY_HIP_MANY_ASSEMBLE=0: by the host, as for several batches)
           const bool env_noasm = getenv("SASSY_HIP_MANY_ASSEMBLE") && atoi(getenv("SASSY_HIP_MANY_ASSEMBLE")) == 0;  // (per call: tests flip it)
+          // (the device's sort key packs pattern << 33 | text << 1 | strand into bits 0 .. 58: many_keys_kernel)
           const bool on_device = !env_noasm && !wo && !all && std::isnan(s->max_n_frac) && !s->only_best && t0 == 0 &&
-                                 t1 == n_texts && batch_first == 0 && pool_first == 0 && !R->pin.h;
+                                 t1 == n_texts && batch_first == 0 && pool_first == 0 && !R->pin.h &&
+                                 (uint64_t)n_patterns < (1ull << 25) && (uint64_t)n_texts < (1ull << 31);
           ManyDefer defer[2];
           defer[1].lane = 1;
           for (int strand = 0; strand < (s->rc ? 2 : 1) && tiled_done; ++strand) {
