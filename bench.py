@@ -192,10 +192,18 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if shared_gpu:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=device)  # "nccl" is RCCL on ROCm
+        # The collective path must not be able to sink a scaling run on first contact: the process group is brought up and
+        # one all_reduce + barrier is run under a timeout (multigpu.init_or_fallback); if any of it fails on any rank, rank 0
+        # runs the SAME workload through the in-process multi-device searcher (--mode inproc: a host thread per GPU, no
+        # torch.distributed) and says so in config.parallelism; the other ranks leave quietly.
+        verdict, why = multigpu.init_or_fallback(dist, "gloo" if shared_gpu else "nccl", None if shared_gpu else device,
+                                                 coll_device, torch, timeout_s=float(os.environ.get("SASSY_BENCH_INIT_TIMEOUT", "180")))
+        if verdict != "ranks":
+            if rank != 0:
+                return
+            args.fallback_reason = why
+            args.allow_shared_gpu = args.allow_shared_gpu or shared_gpu
+            return main_inproc(args)
 
     # ---------------------------------------------------------------- workload
     n_per = args.text_bytes // 64 * 64
@@ -489,17 +497,43 @@ def main_inproc(args):
     t_cold = time.perf_counter()
     r = ms.search(pat, k)
     cold_ms = (time.perf_counter() - t_cold) * 1e3
-    for _ in range(args.warmup + max(0, args.settle)):
-        r = ms.search(pat, k)
+    # one search at a time: the dominant kernel's HIP-event duration for the roofline object (with searches in flight two
+    # launches share the HBM) and the latency of a lone multi-device search
+    n_lat = 30
     kern = [0.0] * world
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    lat_t0 = time.perf_counter()
+    for _ in range(n_lat):
         r = ms.search(pat, k)
         for g in range(world):
             kern[g] += ms.shard_stats(g)["filter_ms"] or ms.shard_stats(g)["scan_ms"]
-    elapsed = time.perf_counter() - t0
+    lone_ms = (time.perf_counter() - lat_t0) / n_lat * 1e3
     st = ms.shard_stats(0)
-    dom_ms = max(kern) / args.steps
+    dom_ms = max(kern) / n_lat
+    # the stream of searches: `--in-flight` of them begun and not yet finished on every device
+    # (sassy_hip_multi_search_begin / _finish); every timed search is begun AND finished inside the timed region
+    depth = max(1, min(4, args.in_flight))
+    ms.set_pipe_depth(depth)
+    pending = []
+
+    def step():
+        if depth <= 1:
+            return ms.search(pat, k)
+        pending.append(ms.search_begin(pat, k))
+        return ms.search_finish(pending.pop(0)) if len(pending) >= depth else None
+
+    def drain(last):
+        while pending:
+            last = ms.search_finish(pending.pop(0))
+        return last
+
+    for _ in range(args.warmup + max(0, args.settle)):
+        r = step() or r
+    r = drain(r)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step() or r
+    r = drain(r)
+    elapsed = time.perf_counter() - t0
     dom_name = {0: "scan_kernel", 1: "filter_kernel", 2: "filter_dna_kernel", 3: "filter_table_kernel", 4: "filter_count_kernel"}[int(st["filtered"])]
     achieved = n_per / (dom_ms / 1e3) / 1e9 if dom_ms > 0 else 0.0
     ms_per_step = elapsed / args.steps * 1e3
@@ -520,13 +554,16 @@ def main_inproc(args):
         "config": {
             "workload": (f"BASELINE config {'2' if world == 1 else '5'}: Searcher::<{args.profile.capitalize()}>::new_fwd().search, "
                          f"|pattern|={m} (seeded random), k={k}, {n_per} B random-ACGT text per GPU resident in HBM, one planted "
-                         f"near-match per {args.plant_stride} B; step = sassy_hip_multi_search: every device searches its shard at "
-                         f"once (scan + traceback + Match records on the host), the shard results are chained and merged in C"),
+                         f"near-match per {args.plant_stride} B; step = one sassy_hip_multi_search_begin / _finish pair: every device searches "
+                         f"its shard at once (scan + traceback + Match records on the host), the shard results are chained and merged in C"),
             "text_bytes_per_gpu": n_per, "total_text_bytes": total, "pattern_len": m, "k": k, "profile": args.profile,
-            "searches_in_flight": 1,
-            "parallelism": f"text sharded x{world}, ONE process, a host thread per device (sassy_hip_multi_*), no torch.distributed / RCCL; devices {devices}",
-            "setup": f"one cold search, {args.warmup} warm-up + {max(0, args.settle)} settling searches, then the K timed searches (one at a time)",
+            "searches_in_flight": depth,
+            "parallelism": f"text sharded x{world}, ONE process, a host thread per device (sassy_hip_multi_*), no torch.distributed / RCCL; devices {devices}"
+                           + (f"; FALLBACK from the rank path: {args.fallback_reason}" if getattr(args, "fallback_reason", None) else ""),
+            "setup": f"one cold search, {n_lat} one-at-a-time searches (single_search_latency_ms, the roofline object's kernel time), "
+                     f"{args.warmup} warm-up + {max(0, args.settle)} settling searches, then the K timed searches ({depth} in flight)",
         },
+        "single_search_latency_ms": round(lone_ms, 4),
         "matches": len(r),
         "matches_per_s": round(len(r) * args.steps / elapsed, 1),
         "planted": planted,
@@ -534,10 +571,10 @@ def main_inproc(args):
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "kernel": dom_name,
                      "algorithmic_bytes_per_launch": n_per, "launch_ms": round(dom_ms, 4),
-                     "measured": "HIP events carried by the kernel's dispatch on each shard searcher's stream inside the timed steps; the slowest device's average"},
+                     "measured": f"HIP events carried by the kernel's dispatch on each shard searcher's stream, {n_lat} one-at-a-time multi-device searches of this run; the slowest device's average"},
         "roofline_search": {"bound": "hbm", "achieved": round(n_per / (ms_per_step / 1e3) / 1e9, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": round(n_per / (ms_per_step / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
-                            "what": "text bytes per GPU / ms_per_step, one multi-device search at a time"},
+                            "what": f"text bytes per GPU / ms_per_step, {depth} multi-device search(es) in flight"},
         "cpu_baseline": None,
         "cpu_baseline_note": "reported by the default mode at N = 1 (python bench.py)",
     }

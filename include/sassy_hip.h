@@ -274,6 +274,24 @@ int sassy_hip_multi_search_encoded(sassy_hip_Multi *m, const uint8_t *patterns, 
 int sassy_hip_multi_search_many(sassy_hip_Multi *m, const uint8_t *const *patterns, const size_t *pattern_lens,
                                 size_t n_patterns, const uint8_t *const *texts, const size_t *text_lens, size_t n_texts,
                                 size_t k, uint32_t flags, sassy_hip_Result **out);
+/* Searches in flight over several devices (the reference's worker threads never idle between two tasks,
+ * bin/grep.rs:516-537, src/search.rs:531-603): begin() queues one shard search per device and strand
+ * (sassy_hip_search_shard_begin on every device's host thread) and returns; finish() waits for that search on every
+ * device and merges the shard results -- the tail of search i (chunk DP, tracebacks, the host's merge) runs under the
+ * text stream of search i + 1 on every device.  Up to `depth` searches per multi-searcher (1 .. 4, default 3); tickets
+ * may be finished in any order; the synchronous sassy_hip_multi_search is refused while a ticket is open.  Same
+ * result as sassy_hip_multi_search, both strands included (sassy_hip_multi_set_rc). */
+typedef struct sassy_hip_MultiTicket sassy_hip_MultiTicket;
+int sassy_hip_multi_set_pipe_depth(sassy_hip_Multi *m, int depth);
+int sassy_hip_multi_search_begin(sassy_hip_Multi *m, const uint8_t *pattern, size_t pattern_len, size_t k,
+                                 uint32_t flags, sassy_hip_MultiTicket **out);
+int sassy_hip_multi_search_finish(sassy_hip_Multi *m, sassy_hip_MultiTicket *t, sassy_hip_Result **out);
+/* The layout arithmetic of a multi-searcher without any device: part i's {offset, len, halo in front, bytes kept
+ * behind, first / one-past-last forward byte of its share of the REVERSED text, that share's halo} in
+ * out[7 i .. 7 i + 6] (out may be NULL).  Returns the number of parts that hold a share of the text (a text of less
+ * than 64 n (n + 2) bytes is one device's), or -1 if a part's resident bytes would not cover its share of the
+ * reversed text (never, by construction: what the tests pin). */
+long sassy_hip_multi_layout(uint64_t len, size_t n_parts, size_t max_pattern_len, size_t max_k, uint64_t *out);
 void sassy_hip_multi_free(sassy_hip_Multi *m);
 
 typedef struct sassy_hip_Ticket sassy_hip_Ticket;

@@ -124,6 +124,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
     "sassy_hip_multi_set_rc", "sassy_hip_multi_set_replicated", "sassy_hip_multi_search_encoded", "sassy_hip_multi_search_many",
+    "sassy_hip_multi_set_pipe_depth", "sassy_hip_multi_search_begin", "sassy_hip_multi_search_finish", "sassy_hip_multi_layout",
     "sassy_hip_generate_dna", "sassy_hip_generate_genome_like", "sassy_hip_plant",
     "sassy_hip_malloc", "sassy_hip_free", "sassy_hip_memcpy_h2d", "sassy_hip_memcpy_d2h",
 ]
@@ -204,6 +205,15 @@ def lib():
         L.sassy_hip_multi_search_many.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t,
                                                   C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t, C.c_uint32,
                                                   C.POINTER(vp)]
+    if hasattr(L, "sassy_hip_multi_search_begin"):
+        L.sassy_hip_multi_set_pipe_depth.restype = C.c_int
+        L.sassy_hip_multi_set_pipe_depth.argtypes = [vp, C.c_int]
+        L.sassy_hip_multi_search_begin.restype = C.c_int
+        L.sassy_hip_multi_search_begin.argtypes = [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_uint32, C.POINTER(vp)]
+        L.sassy_hip_multi_search_finish.restype = C.c_int
+        L.sassy_hip_multi_search_finish.argtypes = [vp, vp, C.POINTER(vp)]
+        L.sassy_hip_multi_layout.restype = C.c_long
+        L.sassy_hip_multi_layout.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64)]
     L.sassy_hip_multi_free.restype = None
     L.sassy_hip_multi_free.argtypes = [vp]
     L.sassy_hip_set_only_best_match.restype = C.c_int
@@ -809,6 +819,22 @@ class MultiSearcher:
         _check(lib().sassy_hip_multi_set_replicated(self._h, int(bool(on))))
         return self
 
+    def set_pipe_depth(self, depth: int) -> "MultiSearcher":
+        _check(lib().sassy_hip_multi_set_pipe_depth(self._h, int(depth)))
+        return self
+
+    def search_begin(self, pattern: bytes, k: int, flags: int = 0) -> int:
+        """Queues one search on every device and returns a ticket (sassy_hip_multi_search_begin)."""
+        pattern = bytes(pattern)
+        t = C.c_void_p()
+        _check(lib().sassy_hip_multi_search_begin(self._h, pattern, len(pattern), k, flags, C.byref(t)))
+        return t.value
+
+    def search_finish(self, ticket: int) -> "Result":
+        out = C.c_void_p()
+        _check(lib().sassy_hip_multi_search_finish(self._h, ticket, C.byref(out)))
+        return Result(out)
+
     def search_encoded(self, patterns: Sequence[bytes], k: int, flags: int = 0) -> "Result":
         patterns = [bytes(p) for p in patterns]
         if not patterns:
@@ -830,6 +856,14 @@ class MultiSearcher:
         out = C.c_void_p()
         _check(lib().sassy_hip_multi_search_many(self._h, pp, pl, len(patterns), tp, tl, len(texts), k, flags, C.byref(out)))
         return Result(out)
+
+
+def multi_layout(length: int, n_parts: int, max_pattern_len: int, max_k: int):
+    """(parts that hold a share, [(offset, len, halo, halo_behind, rev_first, rev_end, rev_halo)] per part) -- the layout
+    arithmetic of a MultiSearcher, no device needed (sassy_hip_multi_layout); -1 parts: a share is not covered."""
+    out = (C.c_uint64 * (7 * n_parts))()
+    e = lib().sassy_hip_multi_layout(length, n_parts, max_pattern_len, max_k, out)
+    return e, [tuple(out[7 * i:7 * i + 7]) for i in range(n_parts)]
 
 
 def generate_dna(d_ptr: int, n: int, seed: int, first: int = 0, stream: int = 0):

@@ -4533,9 +4533,12 @@ struct sassy_hip_Multi {
     size_t d_cap = 0;
     uint8_t* d_rev = nullptr;        // Rc strand: the reversed view of this part's share of the reversed text
     size_t d_rev_cap = 0;
+    bool rev_valid = false;          // d_rev holds the reverse of the resident bytes as they are now (built once per text)
+    sassy_SearcherType* searcher_rs = nullptr;  // searches in flight: the Rc strand's shard search has lanes of its own
     uint64_t halo = 0, len = 0, offset = 0;  // bytes in front of the shard, shard length, its global offset
     uint64_t halo_r = 0;             // bytes of text kept behind the shard (the Rc strand's halo lies on that side)
     std::unique_ptr<MultiWorker> worker;
+    int open_tickets = 0;            // searches begun and not yet finished (sassy_hip_multi_search_begin)
     int rc = 0;
     std::string err;
     sassy_hip_Result* result = nullptr;
@@ -4547,6 +4550,7 @@ struct sassy_hip_Multi {
   uint64_t total_len = 0;
   uint64_t halo_for = 0;  // the resident shards carry halos good for searches with required_halo(m, k) <= this
   bool have_text = false;
+  int pipe_depth = 3;       // searches in flight per device (sassy_hip_multi_set_pipe_depth)
   bool rc = false;          // sassy_hip_multi_set_rc: searches return both strands
   bool replicate = false;   // sassy_hip_multi_set_replicated: every device holds the WHOLE text (patterns are sharded)
   ~sassy_hip_Multi() {
@@ -4559,6 +4563,7 @@ struct sassy_hip_Multi {
       if (p.d_rev) (void)hipFree(p.d_rev);
       if (p.searcher) delete p.searcher;
       if (p.searcher_rc) delete p.searcher_rc;
+      if (p.searcher_rs) delete p.searcher_rs;
       (void)hipSetDevice(prev);
     }
   }
@@ -4579,18 +4584,24 @@ struct sassy_hip_Multi {
     return first;
   }
   // [a, b) of shard i: equal shares of whole 64-byte blocks (sassy_amd/multigpu.py: shard_bounds)
-  void bounds(size_t i, uint64_t& a, uint64_t& b) const {
-    const uint64_t n = parts.size();
-    uint64_t per = (total_len + n - 1) / n;
+  void bounds(size_t i, uint64_t& a, uint64_t& b) const { multi_bounds(total_len, eff_parts(), i, a, b); }
+  // how many of the parts get a share: all of them, unless the text is so short that a share would be smaller than the
+  // slack between forward and reversed shard borders (a trailing part without bytes cannot hold its share of the
+  // reversed text) -- such a text is one device's
+  size_t eff_parts() const { return multi_eff_parts(total_len, parts.size()); }
+  static size_t multi_eff_parts(uint64_t len, size_t n) { return (n <= 1 || len < 64ull * n * (n + 2)) ? 1 : n; }
+  static void multi_bounds(uint64_t len, size_t n, size_t i, uint64_t& a, uint64_t& b) {
+    if (i >= n) { a = b = len; return; }
+    uint64_t per = (len + n - 1) / n;
     per = (per + 63) / 64 * 64;
-    a = std::min<uint64_t>(i * per, total_len);
-    b = std::min<uint64_t>((i + 1) * per, total_len);
+    a = std::min<uint64_t>(i * per, len);
+    b = std::min<uint64_t>((i + 1) * per, len);
   }
   // The Rc strand is complement(pattern) against the REVERSED text (src/search.rs:813-878), sharded like the forward
   // one but in reversed coordinates: reversed shard j owns the reversed end positions (A, B] with A = j * per -- the
   // forward bytes [n - B, n - A), whose borders differ from the forward shards' by up to 64 * parts bytes unless n is a
   // multiple of 64 * parts.  Part i keeps reversed shard parts - 1 - i: it needs a few bytes more of text on either side.
-  uint64_t slack() const { return 64ull * (parts.size() + 1); }
+  uint64_t slack() const { return 64ull * (eff_parts() + 1); }
   int layout(uint64_t len, size_t max_m, size_t max_k) {
     total_len = len;
     halo_for = sassy_hip_required_halo(max_m, max_k);
@@ -4603,6 +4614,7 @@ struct sassy_hip_Multi {
       parts[i].halo = (i == 0 || a == 0) ? 0 : std::min<uint64_t>(halo_for + slack(), a);
       parts[i].halo = parts[i].halo / 64 * 64;
       parts[i].halo_r = std::min<uint64_t>(halo_for + slack(), len - b);
+      parts[i].rev_valid = false;
     }
     return 0;
   }
@@ -4703,6 +4715,7 @@ int sassy_hip_multi_plant(sassy_hip_Multi* m, uint64_t seed, const uint8_t* patt
     const size_t i = (size_t)(&p - m->parts.data());
     const size_t bytes = (size_t)(p.halo + p.len + p.halo_r);
     if (!bytes) return 0;
+    p.rev_valid = false;  // (the text changes under the cached reversed copy)
     if (int r = sassy_hip_plant(p.d_text, bytes, p.offset - p.halo, m->total_len, seed, pattern, pattern_len, k, stride, nullptr, &cnt[i]))
       return r;
     HIP_TRY(hipDeviceSynchronize());
@@ -4733,15 +4746,22 @@ int sassy_hip_multi_set_replicated(sassy_hip_Multi* m, int on) {
   return 0;
 }
 
-// The Rc strand of one part: reversed shard j = parts - 1 - i of the reversed text, read off the part's resident
-// forward bytes by the reverse kernel, searched with complement(pattern) like any shard (reversed coordinates).
-static int multi_rc_shard(sassy_hip_Multi* m, sassy_hip_Multi::Part& p, const uint8_t* cpat, size_t plen, size_t k, uint32_t f) {
+// The Rc strand of one part: reversed shard j = E - 1 - i of the reversed text (E = the parts that hold a share), read off
+// the part's resident forward bytes by the reverse kernel ONCE per resident text (rev_valid; the copy is made on the
+// searcher's stream and waited for there -- not on the null stream, which every blocking stream of the device would
+// wait behind), searched with complement(pattern) like any shard (reversed coordinates).
+// Returns 1 when the part has no share of the reversed text.
+static int multi_rc_prepare(sassy_hip_Multi* m, sassy_hip_Multi::Part& p, uint64_t* A_out, uint64_t* B_out, uint64_t* hrev_out) {
   const size_t i = (size_t)(&p - m->parts.data());
-  const size_t j = m->parts.size() - 1 - i;
+  const size_t E = m->eff_parts();
+  if (i >= E) return 1;
+  const size_t j = E - 1 - i;
   uint64_t fa, fb, hrev;
   m->rev_bounds(j, fa, fb, hrev);
-  p.result_rc = nullptr;
-  if (fb <= fa) { p.result_rc = new sassy_hip_Result(); return 0; }
+  if (fb <= fa) return 1;
+  m->bounds(j, *A_out, *B_out);
+  *hrev_out = hrev;
+  if (p.rev_valid) return 0;
   const uint64_t buf0 = p.offset - p.halo, buf1 = p.offset + p.len + p.halo_r;  // the resident bytes [buf0, buf1)
   const uint64_t fa16 = fa / 16 * 16, end = fb + hrev;
   if (fa16 < buf0 || end > buf1)
@@ -4757,38 +4777,24 @@ static int multi_rc_shard(sassy_hip_Multi* m, sassy_hip_Multi::Part& p, const ui
   }
   // reverse(text[fa16, end)): its first (end - fa) bytes are the reversed shard with its halo in front; the up to 15
   // bytes behind them (the alignment the reverse kernel wants) are only there
-  hipError_t le = launch_reverse(p.d_text + (fa16 - buf0), p.d_rev, nrev, nullptr);
+  if (int rc = p.searcher->ensure_device()) return rc;
+  hipError_t le = launch_reverse(p.d_text + (fa16 - buf0), p.d_rev, nrev, p.searcher->stream);
   if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
-  HIP_TRY(hipStreamSynchronize(nullptr));
-  uint64_t A, B;
-  m->bounds(j, A, B);
+  HIP_TRY(hipStreamSynchronize(p.searcher->stream));
+  p.rev_valid = true;
+  return 0;
+}
+static int multi_rc_shard(sassy_hip_Multi* m, sassy_hip_Multi::Part& p, const uint8_t* cpat, size_t plen, size_t k, uint32_t f) {
+  uint64_t A = 0, B = 0, hrev = 0;
+  p.result_rc = nullptr;
+  const int pr = multi_rc_prepare(m, p, &A, &B, &hrev);
+  if (pr == 1) { p.result_rc = new sassy_hip_Result(); return 0; }
+  if (pr) return pr;
   return sassy_hip_search_shard(p.searcher, cpat, plen, p.d_rev, hrev, B - A, A, m->total_len, k, f, &p.result_rc);
 }
 
-int sassy_hip_multi_search(sassy_hip_Multi* m, const uint8_t* pattern, size_t pattern_len, size_t k, uint32_t flags,
-                           sassy_hip_Result** out) {
-  if (!m || !pattern || !out) return fail(SASSY_HIP_EINVAL, "null argument");
-  if (!m->have_text) return fail(SASSY_HIP_EINVAL, "no resident text (sassy_hip_multi_set_text)");
-  if (m->replicate) return fail(SASSY_HIP_EINVAL, "the devices hold whole copies of the text (sassy_hip_multi_set_replicated): search_encoded only");
-  if (sassy_hip_required_halo(pattern_len, k) > m->halo_for && m->parts.size() > 1)
-    return fail(SASSY_HIP_EINVAL, "the resident shards' halos are too short for this pattern length and k");
-  const uint32_t f = flags & (SASSY_HIP_ALL_MINIMA | SASSY_HIP_WITHOUT_TRACE);
-  std::vector<uint8_t> cp;  // complement(pattern) for the Rc strand (src/search.rs:813-820)
-  if (m->rc) {
-    Profile pr;
-    if (!parse_alphabet(m->alphabet.c_str(), pr)) return fail(SASSY_HIP_EINVAL, "unknown alphabet");
-    cp.resize(pattern_len);
-    for (size_t i = 0; i < pattern_len; ++i) cp[i] = complement_char(pr, pattern[i]);
-  }
-  const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
-    p.result = nullptr;
-    p.result_rc = nullptr;
-    if (p.len == 0) p.result = new sassy_hip_Result();
-    else if (int r = sassy_hip_search_shard(p.searcher, pattern, pattern_len, p.d_text, p.halo / 64 * 64, p.len, p.offset, m->total_len, k, f, &p.result))
-      return r;
-    if (m->rc) return multi_rc_shard(m, p, cp.data(), pattern_len, k, f);
-    return 0;
-  });
+// the parts' shard results (p.result, and p.result_rc with both strands) -> one result; the parts' results are freed
+static int multi_merge(sassy_hip_Multi* m, uint32_t f, int rc, sassy_hip_Result** out) {
   int mrc = rc;
   sassy_hip_Result* fwd = nullptr;
   sassy_hip_Result* rev = nullptr;
@@ -4797,9 +4803,10 @@ int sassy_hip_multi_search(sassy_hip_Multi* m, const uint8_t* pattern, size_t pa
     for (sassy_hip_Multi::Part& p : m->parts) rs.push_back(p.result);
     mrc = sassy_hip_merge_shards(rs.data(), rs.size(), kStateDecTrue, &fwd);
   }
-  if (!mrc && m->rc) {  // reversed shard j lives on part parts - 1 - j
+  if (!mrc && m->rc) {  // reversed shard j lives on part E - 1 - j
     std::vector<const sassy_hip_Result*> rs;
-    for (size_t j = 0; j < m->parts.size(); ++j) rs.push_back(m->parts[m->parts.size() - 1 - j].result_rc);
+    const size_t E = m->eff_parts();
+    for (size_t j = 0; j < E; ++j) rs.push_back(m->parts[E - 1 - j].result_rc);
     mrc = sassy_hip_merge_shards(rs.data(), rs.size(), kStateDecTrue, &rev);
   }
   for (sassy_hip_Multi::Part& p : m->parts) {
@@ -4829,6 +4836,174 @@ int sassy_hip_multi_search(sassy_hip_Multi* m, const uint8_t* pattern, size_t pa
   if (mrc) { delete fwd; return mrc; }
   *out = fwd;
   return 0;
+}
+
+static int multi_check_search(sassy_hip_Multi* m, const uint8_t* pattern, size_t pattern_len, size_t k, const void* out,
+                              std::vector<uint8_t>& cp) {
+  if (!m || !pattern || !out) return fail(SASSY_HIP_EINVAL, "null argument");
+  if (!m->have_text) return fail(SASSY_HIP_EINVAL, "no resident text (sassy_hip_multi_set_text)");
+  if (m->replicate) return fail(SASSY_HIP_EINVAL, "the devices hold whole copies of the text (sassy_hip_multi_set_replicated): search_encoded only");
+  if (sassy_hip_required_halo(pattern_len, k) > m->halo_for && m->eff_parts() > 1)
+    return fail(SASSY_HIP_EINVAL, "the resident shards' halos are too short for this pattern length and k");
+  if (m->rc) {  // complement(pattern) for the Rc strand (src/search.rs:813-820)
+    Profile pr;
+    if (!parse_alphabet(m->alphabet.c_str(), pr)) return fail(SASSY_HIP_EINVAL, "unknown alphabet");
+    cp.resize(pattern_len);
+    for (size_t i = 0; i < pattern_len; ++i) cp[i] = complement_char(pr, pattern[i]);
+  }
+  return 0;
+}
+
+int sassy_hip_multi_search(sassy_hip_Multi* m, const uint8_t* pattern, size_t pattern_len, size_t k, uint32_t flags,
+                           sassy_hip_Result** out) {
+  std::vector<uint8_t> cp;
+  if (int rc = multi_check_search(m, pattern, pattern_len, k, out, cp)) return rc;
+  for (sassy_hip_Multi::Part& p : m->parts)
+    if (p.open_tickets) return fail(SASSY_HIP_EINVAL, "searches are in flight on this multi-searcher: finish them first");
+  const uint32_t f = flags & (SASSY_HIP_ALL_MINIMA | SASSY_HIP_WITHOUT_TRACE);
+  const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
+    p.result = nullptr;
+    p.result_rc = nullptr;
+    if (p.len == 0) p.result = new sassy_hip_Result();
+    else if (int r = sassy_hip_search_shard(p.searcher, pattern, pattern_len, p.d_text, p.halo / 64 * 64, p.len, p.offset, m->total_len, k, f, &p.result))
+      return r;
+    if (m->rc) return multi_rc_shard(m, p, cp.data(), pattern_len, k, f);
+    return 0;
+  });
+  return multi_merge(m, f, rc, out);
+}
+
+// ---- searches in flight over several devices (the reference's workers never idle between tasks: bin/grep.rs:516-537) ----
+// begin() queues one shard search per device and strand (sassy_hip_search_shard_begin on the part's worker thread) and
+// returns; finish() waits for them, in any order of tickets, and merges.  Up to depth (sassy_hip_multi_set_pipe_depth,
+// 1 .. 4, default 3) searches per multi-searcher: the tail of search i -- chunk DP, traceback, the host's merge -- runs
+// under the text stream of search i + 1 on every device.
+struct sassy_hip_MultiTicket {
+  sassy_hip_Multi* owner = nullptr;
+  std::vector<uint8_t> pat, cpat;
+  size_t k = 0;
+  uint32_t f = 0;
+  std::vector<sassy_hip_Ticket*> fwd, rcs;  // per part; nullptr: the part has no share
+};
+
+int sassy_hip_multi_set_pipe_depth(sassy_hip_Multi* m, int depth) {
+  if (!m || depth < 1 || depth > kMaxLanes) return fail(SASSY_HIP_EINVAL, "pipe depth must be 1 .. 4");
+  for (sassy_hip_Multi::Part& p : m->parts)
+    if (p.open_tickets) return fail(SASSY_HIP_EINVAL, "searches are in flight");
+  m->pipe_depth = depth;
+  return 0;
+}
+
+int sassy_hip_multi_search_begin(sassy_hip_Multi* m, const uint8_t* pattern, size_t pattern_len, size_t k, uint32_t flags,
+                                 sassy_hip_MultiTicket** out) {
+  std::unique_ptr<sassy_hip_MultiTicket> T(new sassy_hip_MultiTicket());
+  if (int rc = multi_check_search(m, pattern, pattern_len, k, out, T->cpat)) return rc;
+  for (sassy_hip_Multi::Part& p : m->parts)
+    if (p.open_tickets >= m->pipe_depth) return fail(SASSY_HIP_EINVAL, "too many searches in flight: finish one first (sassy_hip_multi_set_pipe_depth)");
+  T->owner = m;
+  T->pat.assign(pattern, pattern + pattern_len);
+  T->k = k;
+  T->f = flags & (SASSY_HIP_ALL_MINIMA | SASSY_HIP_WITHOUT_TRACE);
+  T->fwd.assign(m->parts.size(), nullptr);
+  T->rcs.assign(m->parts.size(), nullptr);
+  sassy_hip_MultiTicket* t = T.get();
+  const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
+    const size_t i = (size_t)(&p - m->parts.data());
+    if (p.searcher->pipe_depth != m->pipe_depth)
+      if (int r = sassy_hip_set_pipe_depth(p.searcher, m->pipe_depth)) return r;
+    if (p.len != 0)
+      if (int r = sassy_hip_search_shard_begin(p.searcher, t->pat.data(), pattern_len, p.d_text, p.halo / 64 * 64, p.len, p.offset,
+                                               m->total_len, k, t->f, &t->fwd[i])) return r;
+    if (m->rc) {
+      uint64_t A = 0, B = 0, hrev = 0;
+      const int pr = multi_rc_prepare(m, p, &A, &B, &hrev);
+      if (pr == 1) return 0;
+      if (pr) return pr;
+      if (!p.searcher_rs) {
+        p.searcher_rs = sassy_hip_searcher_new(m->alphabet.c_str(), false, m->alpha);
+        if (!p.searcher_rs) return SASSY_HIP_EINVAL;
+        p.searcher_rs->device = p.device;
+      }
+      if (p.searcher_rs->pipe_depth != m->pipe_depth)
+        if (int r = sassy_hip_set_pipe_depth(p.searcher_rs, m->pipe_depth)) return r;
+      if (int r = sassy_hip_search_shard_begin(p.searcher_rs, t->cpat.data(), pattern_len, p.d_rev, hrev, B - A, A, m->total_len, k,
+                                               t->f, &t->rcs[i])) return r;
+    }
+    return 0;
+  });
+  if (rc) {  // what was begun on the other devices is waited for and dropped
+    const std::string err = g_err;
+    (void)m->on_all([&](sassy_hip_Multi::Part& p) -> int {
+      const size_t i = (size_t)(&p - m->parts.data());
+      if (t->fwd[i]) (void)sassy_hip_search_finish(p.searcher, t->fwd[i], nullptr);
+      if (t->rcs[i]) (void)sassy_hip_search_finish(p.searcher_rs, t->rcs[i], nullptr);
+      return 0;
+    });
+    g_err = err;
+    return rc;
+  }
+  for (sassy_hip_Multi::Part& p : m->parts) ++p.open_tickets;
+  *out = T.release();
+  return 0;
+}
+
+int sassy_hip_multi_search_finish(sassy_hip_Multi* m, sassy_hip_MultiTicket* t, sassy_hip_Result** out) {
+  if (!m || !t || t->owner != m || !out) return fail(SASSY_HIP_EINVAL, "not a ticket of this multi-searcher");
+  std::unique_ptr<sassy_hip_MultiTicket> guard(t);
+  const int rc = m->on_all([&](sassy_hip_Multi::Part& p) -> int {
+    const size_t i = (size_t)(&p - m->parts.data());
+    p.result = nullptr;
+    p.result_rc = nullptr;
+    int first = 0;
+    if (t->fwd[i]) first = sassy_hip_search_finish(p.searcher, t->fwd[i], &p.result);
+    else p.result = new sassy_hip_Result();
+    if (m->rc) {
+      int r2 = 0;
+      if (t->rcs[i]) r2 = sassy_hip_search_finish(p.searcher_rs, t->rcs[i], &p.result_rc);
+      else p.result_rc = new sassy_hip_Result();
+      if (!first) first = r2;
+    }
+    return first;
+  });
+  for (sassy_hip_Multi::Part& p : m->parts)
+    if (p.open_tickets) --p.open_tickets;
+  if (rc)
+    for (sassy_hip_Multi::Part& p : m->parts) {  // (a part that failed may have left no result at all)
+      if (!p.result) p.result = new sassy_hip_Result();
+      if (m->rc && !p.result_rc) p.result_rc = new sassy_hip_Result();
+    }
+  return multi_merge(m, t->f, rc, out);
+}
+
+// The layout arithmetic of a multi-searcher, without any device (tests; drivers that want to know a shard's bytes before
+// they allocate): for a text of `len` bytes over `n_parts` devices with halos good for (max_pattern_len, max_k), part i's
+// {offset, len, halo in front, bytes kept behind, first forward byte of its share of the REVERSED text, one past its
+// last, that share's halo} go to out[7 i .. 7 i + 6]; returns the number of parts that hold a share, or -1 when some
+// part's resident bytes would not cover its share of the reversed text (never, by construction).
+long sassy_hip_multi_layout(uint64_t len, size_t n_parts, size_t max_pattern_len, size_t max_k, uint64_t* out) {
+  if (n_parts == 0) return -1;
+  const size_t E = sassy_hip_Multi::multi_eff_parts(len, n_parts);
+  const uint64_t halo_for = sassy_hip_required_halo(max_pattern_len, max_k), slack = 64ull * (E + 1);
+  long ok = (long)E;
+  for (size_t i = 0; i < n_parts; ++i) {
+    uint64_t a, b;
+    sassy_hip_Multi::multi_bounds(len, E, i, a, b);
+    uint64_t halo = (i == 0 || a == 0) ? 0 : std::min<uint64_t>(halo_for + slack, a);
+    halo = halo / 64 * 64;
+    const uint64_t halo_r = std::min<uint64_t>(halo_for + slack, len - b);
+    uint64_t fa = 0, fb = 0, hrev = 0;
+    if (i < E) {
+      uint64_t A, B;
+      sassy_hip_Multi::multi_bounds(len, E, E - 1 - i, A, B);
+      fa = len - B; fb = len - A; hrev = std::min<uint64_t>(halo_for, A);
+      if (fb > fa && (fa / 16 * 16 < a - halo || fb + hrev > b + halo_r)) ok = -1;
+    }
+    if (out) {
+      uint64_t* o = out + 7 * i;
+      o[0] = a; o[1] = b - a; o[2] = halo; o[3] = halo_r; o[4] = fa; o[5] = fb; o[6] = hrev;
+    }
+  }
+  return ok;
 }
 
 // search_encoded_patterns over several devices: the PATTERNS are sharded (every device scans the whole text

@@ -382,3 +382,75 @@ class GatherWorker:
     def close(self):
         self.q.put(None)
         self.t.join()
+
+
+
+def init_or_fallback(dist, backend: str, device_id, coll_device, torch, timeout_s: float = 180.0, preflight_cmd=None):
+    """Brings up the process group of a one-rank-per-GPU run so that a broken collective path cannot sink the run.
+
+    1. every rank joins a gloo group (CPU, TCP on the launcher's MASTER_ADDR: failures here are ordinary exceptions);
+    2. backend "nccl" (= RCCL): rank 0 runs `preflight_cmd` (default: tools/preflight_multigpu.py with as many ranks --
+       fresh processes doing an all_reduce, the header all_gather, the row gather and one real search on the same GPUs)
+       and tells the others over gloo whether it passed: an RCCL hang or abort kills the preflight's processes, not this one;
+    3. the gloo group is replaced by the real one and one all_reduce + barrier runs on it.
+    Returns ("ranks", None) with the real group initialised, or ("inproc", reason): the caller's rank 0 then runs the same
+    workload through the in-process multi-device searcher (bench.py --mode inproc), the other ranks return.
+    SASSY_BENCH_PREFLIGHT=0 skips step 2.  SASSY_BENCH_INJECT_INIT_FAILURE = "preflight" | "rank<r>" | "real": tests."""
+    import datetime
+    import os
+    import subprocess
+    import sys
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    inject = os.environ.get("SASSY_BENCH_INJECT_INIT_FAILURE", "")
+    to = datetime.timedelta(seconds=timeout_s)
+
+    def down():
+        try:
+            if dist.is_initialized():
+                dist.destroy_process_group()
+        except Exception:
+            pass
+
+    try:
+        if inject == f"rank{rank}":
+            raise RuntimeError("injected failure on this rank before the rendezvous (SASSY_BENCH_INJECT_INIT_FAILURE)")
+        dist.init_process_group(backend="gloo", timeout=to)
+        verdict = [None]
+        if rank == 0:
+            why = None
+            if inject == "preflight":
+                why = "injected preflight failure (SASSY_BENCH_INJECT_INIT_FAILURE)"
+            elif backend == "nccl" and os.environ.get("SASSY_BENCH_PREFLIGHT", "1") != "0":
+                root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+                cmd = preflight_cmd or [sys.executable, os.path.join(root, "tools", "preflight_multigpu.py"), "--gpus", str(world),
+                                        "--mbytes", "8", "--timeout", str(int(timeout_s))]
+                env = {k_: v for k_, v in os.environ.items()
+                       if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
+                                     "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+                try:
+                    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s + 60)
+                    if r.returncode != 0 or '"ok": true' not in r.stdout:
+                        why = f"RCCL preflight failed (exit {r.returncode}): {(r.stderr or r.stdout)[-300:].strip()}"
+                except Exception as e:  # noqa: BLE001 -- timeout, missing file: all of it means "do not trust the collective path"
+                    why = f"RCCL preflight did not finish: {type(e).__name__}: {str(e)[:200]}"
+            verdict[0] = why
+        dist.broadcast_object_list(verdict, src=0)
+        dist.barrier()
+        down()
+        if verdict[0] is not None:
+            return "inproc", verdict[0]
+        if inject == "real":
+            raise RuntimeError("injected failure of the real process group (SASSY_BENCH_INJECT_INIT_FAILURE)")
+        kw = dict(backend=backend, timeout=to)
+        if device_id is not None:
+            kw["device_id"] = device_id
+        dist.init_process_group(**kw)
+        t = torch.ones(1, dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t)
+        if int(t.item()) != world:
+            raise RuntimeError(f"first all_reduce over {world} ranks summed to {t.item()}")
+        dist.barrier()
+        return "ranks", None
+    except Exception as e:  # noqa: BLE001
+        down()
+        return "inproc", f"{type(e).__name__}: {str(e)[:300]}"

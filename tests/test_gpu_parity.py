@@ -2716,6 +2716,100 @@ def test_multi_searcher_shards_on_one_gpu(sassy):
 
 
 
+def _multi_in_flight_case(sassy, devices, profile, rc, n, rng):
+    """Searches in flight over several devices (sassy_hip_multi_search_begin / _finish): different patterns and k in
+    flight at once, finished out of order, both strands with the cached reversed shards, a text that changes in between
+    (the cache must go), tiny texts on a both-strand multi-searcher (ADVICE of round 4: one device takes them)."""
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    ms = sassy.MultiSearcher(profile, devices=devices).set_rc(rc)
+    G = len(devices)
+    pats = [rand_seq(rng, m) for m in (32, 23, 40, 32)]
+    ks = [3, 3, 4, 2]
+    t = bytearray(rand_seq(rng, n))
+    per = -(-(-(-n // G)) // 64) * 64
+    for g in range(1, G):
+        for b in (g * per, n - g * per):
+            for off in (-40, -20, -1, 3):
+                p_ = rng.choice(pats)
+                ins = mutate(rng, p_ if rng.random() < 0.5 else p_.translate(comp)[::-1], rng.randrange(3))
+                at = max(0, min(n - len(ins), b + off))
+                t[at:at + len(ins)] = ins
+    for _ in range(120):
+        p_ = rng.choice(pats)
+        ins = mutate(rng, p_ if rng.random() < 0.5 else p_.translate(comp)[::-1], rng.randrange(4))
+        at = rng.randrange(0, n - 64)
+        t[at:at + len(ins)] = ins
+    text = bytes(t[:n])
+    ms.set_text(text, 64, 6)
+    ms.set_pipe_depth(3)
+    want = [oracle.search(profile, p_, text, k_, rc=rc) for p_, k_ in zip(pats, ks)]
+    tickets = [ms.search_begin(pats[i], ks[i]) for i in range(3)]
+    with pytest.raises(sassy.SassyHipError, match="in flight"):
+        ms.search_begin(pats[3], ks[3])          # a fourth one: the depth is three
+    with pytest.raises(sassy.SassyHipError, match="in flight"):
+        ms.search(pats[0], 3)                    # the synchronous call is refused while tickets are open
+    assert_same(ms.search_finish(tickets[1]).matches, want[1], ("in flight, second first", devices, rc))
+    tickets.append(ms.search_begin(pats[3], ks[3]))
+    for i in (0, 3, 2):
+        assert_same(ms.search_finish(tickets[i]).matches, want[i], ("in flight", i, devices, rc))
+    assert sum(len(w) for w in want) >= 40
+    # a stream of them
+    pend, got = [], []
+    for i in range(12):
+        pend.append((i % 4, ms.search_begin(pats[i % 4], ks[i % 4])))
+        if len(pend) == 3:
+            j, tk = pend.pop(0)
+            got.append((j, ms.search_finish(tk).matches))
+    while pend:
+        j, tk = pend.pop(0)
+        got.append((j, ms.search_finish(tk).matches))
+    for j, g_ in got:
+        assert_same(g_, want[j], ("stream", j))
+    assert_same(ms.search(pats[0], ks[0]).matches, want[0], "synchronous again")
+    # the text changes: the reversed shards are made again
+    t2 = bytearray(text)
+    t2[n // 2:n // 2 + 32] = pats[0].translate(comp)[::-1]
+    t2[100:132] = pats[0]
+    text2 = bytes(t2)
+    ms.set_text(text2, 64, 6)
+    tk = ms.search_begin(pats[0], 3)
+    assert_same(ms.search_finish(tk).matches, oracle.search(profile, pats[0], text2, 3, rc=rc), "changed text")
+    # tiny texts: fewer blocks than parts
+    for n_t in (0, 1, 31, 63, 64, 65, 130, 64 * G + 1, 64 * G * (G + 2) - 1, 64 * G * (G + 2)):
+        tt = (pats[0] * 40)[:n_t] if n_t % 3 else rand_seq(rng, n_t)
+        ms.set_text(tt, 64, 6)
+        assert_same(ms.search(pats[0], 3).matches, oracle.search(profile, pats[0], tt, 3, rc=rc), ("tiny", n_t, G, rc))
+        tk = ms.search_begin(pats[0], 3)
+        assert_same(ms.search_finish(tk).matches, oracle.search(profile, pats[0], tt, 3, rc=rc), ("tiny in flight", n_t, G, rc))
+
+
+def test_multi_searcher_searches_in_flight_on_one_gpu(sassy):
+    rng = random.Random(95)
+    _multi_in_flight_case(sassy, [0, 0, 0], "dna", False, 300_017, rng)
+    _multi_in_flight_case(sassy, [0, 0, 0, 0], "iupac", True, 260_000, rng)
+    _multi_in_flight_case(sassy, [0], "dna", True, 100_003, rng)
+
+
+def test_two_real_devices(sassy):
+    """Two real GPUs (hipGetDeviceCount() >= 2): the text sharded over them, searches one at a time and in flight, both
+    strands, search_encoded with the patterns sharded, search_many with the texts sharded -- against the oracle.  Skipped,
+    and reported as skipped, on a one-GPU box: nothing in this suite has ever had a second device."""
+    if sassy.device_count() < 2:
+        pytest.skip(f"{sassy.device_count()} HIP device(s) visible: the two-device test needs two")
+    rng = random.Random(96)
+    _multi_in_flight_case(sassy, [0, 1], "dna", False, 400_001, rng)
+    _multi_in_flight_case(sassy, [0, 1], "iupac", True, 300_000, rng)
+    ms = sassy.MultiSearcher("dna", devices=[0, 1])
+    n2 = (1 << 24) + 999
+    ms.generate_dna(n2, 42, 32, 3)
+    p2 = bytes(oracle.generate_dna(43, 0, 32))
+    ms.plant(42, p2, 3, 1 << 18)
+    host = oracle.generate_dna(42, 0, n2)
+    oracle.plant_window(42, n2, 0, host, p2, 3, stride=1 << 18)
+    assert_same(ms.search(p2, 3).matches, oracle.search("dna", p2, host.tobytes(), 3), "two devices, synthetic text")
+    assert ms.devices() == [0, 1]
+
+
 def test_multi_searcher_both_strands_encoded_and_many_on_one_gpu(sassy):
     """The multi-device searcher beyond forward single-pattern searches, with device 0 named several times: both
     strands (every device searches its share of the REVERSED text as a shard of its own, text lengths that are and are

@@ -165,3 +165,76 @@ def test_gather_gloo_world2():
     for p in ps:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_multi_layout_covers_every_share_of_the_reversed_text():
+    """sassy_hip_multi_layout (no device needed): for every text length -- tiny texts above all: fewer blocks than parts,
+    a trailing part without bytes -- and 1 .. 8 parts, each part's resident bytes [offset - halo, offset + len + behind)
+    cover the forward bytes of its share of the REVERSED text with that share's halo (the Rc strand of a both-strand
+    multi-searcher, multi_rc_prepare); texts shorter than 64 n (n + 2) bytes are one part's."""
+    import sassy_amd
+    lens = list(range(0, 700)) + [1023, 1024, 1025, 4095, 4096, 5119, 5120, 5121, 65536 + 7, 10**6 + 3, 3 * 10**9]
+    for parts in range(1, 9):
+        for n in lens:
+            for (m, k) in ((32, 3), (200, 20)):
+                e, rows = sassy_amd.multi_layout(n, parts, m, k)
+                assert e >= 1, (n, parts, m, k, rows)
+                assert e == (1 if parts == 1 or n < 64 * parts * (parts + 2) else parts)
+                halo_need = sassy_amd.required_halo(m, k)
+                assert sum(r[1] for r in rows) == n and all(r[1] == 0 for r in rows[e:])
+                at = 0
+                for i, (off, ln, halo, behind, fa, fb, hrev) in enumerate(rows):
+                    assert off == at or ln == 0
+                    at += ln
+                    assert halo % 64 == 0 and halo <= off and off + ln + behind <= n
+                    if i and ln:
+                        assert halo >= min(halo_need, off) // 64 * 64
+                    if i < e and fb > fa:
+                        assert off - halo <= fa // 16 * 16 and fb + hrev <= off + ln + behind, (n, parts, i, rows[i])
+                # the reversed shares tile the text as well
+                assert sum(r[5] - r[4] for r in rows[:e]) == n
+
+
+def _fallback_worker(rank, world, port, inject, q):
+    import torch
+    import torch.distributed as dist
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": str(rank), "WORLD_SIZE": str(world)})
+    if inject:
+        os.environ["SASSY_BENCH_INJECT_INIT_FAILURE"] = inject
+    try:
+        verdict, why = multigpu.init_or_fallback(dist, "gloo", None, torch.device("cpu"), torch, timeout_s=8.0)
+        extra = None
+        if verdict == "ranks":  # the group it left behind works
+            t = torch.full((4,), float(rank + 1))
+            dist.all_reduce(t)
+            extra = float(t[0])
+            dist.destroy_process_group()
+        q.put((rank, verdict, bool(why), extra, dist.is_initialized()))
+    except Exception as e:  # pragma: no cover
+        q.put((rank, "raised", repr(e), None, None))
+
+
+@pytest.mark.parametrize("inject", ["", "preflight", "real", "rank1"])
+def test_rank_path_falls_back_to_inproc_gloo_world2(inject):
+    """bench.py's rank path must not be able to fail on first contact (multigpu.init_or_fallback, gloo world 2): a sound
+    collective path gives ("ranks", None) and a working group; a failed preflight, a failing real group, a rank that dies
+    before the rendezvous all give ("inproc", reason) on every surviving rank -- rank 0 then runs --mode inproc -- with
+    no process group left behind and nobody hanging."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_fallback_worker, args=(r, 2, port, inject, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    if inject == "":
+        assert res == [(0, "ranks", False, 3.0, False), (1, "ranks", False, 3.0, False)], res
+    else:
+        assert [r[:3] for r in res] == [(0, "inproc", True), (1, "inproc", True)], res
+        assert all(r[4] is False for r in res), res
