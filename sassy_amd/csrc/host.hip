@@ -93,6 +93,10 @@ hipError_t launch_assemble_many(const ManyPart& a, const ManyPart& b, uint32_t n
                                 void* d_scratch, size_t scratch_bytes, hipStream_t stream);
 hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable& texts, uint32_t* d_report_text,
                                hipStream_t stream);
+size_t encoded_scratch_bytes(uint32_t count);
+hipError_t launch_assemble_encoded(const MatchOut* d_rows_in, const char* d_strs_in, uint32_t count, uint64_t n_original, uint32_t str_stride,
+                                   int key_bits, MatchOut* d_rows, char* d_strs, uint32_t* d_flags, void* d_scratch, size_t scratch_bytes,
+                                   hipStream_t stream);
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -149,12 +153,13 @@ struct PinPool {
   std::mutex mu;
   std::vector<PinBlock> blocks;
   static constexpr size_t kKeep = 12;
-  static constexpr size_t kKeepBytes = (size_t)2 << 30;  // idle blocks kept for reuse (dense results hold 100 MB and more each)
+  static constexpr size_t kKeepBytes = (size_t)5 << 30;  // idle blocks kept for reuse (dense results hold 100 MB and more each; a
+                                                         // guide set's 17 M matches 2.2 GB -- pinning that again costs more than the search)
   // blocks that results hold right now: a caller who keeps every result alive must not pin memory without bound (and
   // pay a hipHostMalloc per search) -- beyond kMaxAdopted outstanding blocks (or kMaxAdoptedBytes) results are copied
   // out as before
   static constexpr int kMaxAdopted = 16;
-  static constexpr size_t kMaxAdoptedBytes = (size_t)4 << 30;
+  static constexpr size_t kMaxAdoptedBytes = (size_t)8 << 30;
   int adopted = 0;
   size_t adopted_bytes = 0;
   bool may_adopt(size_t bytes) {
@@ -2917,6 +2922,58 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
       defer->part = ManyPart{LT.d_trace.p, reinterpret_cast<const char*>(LT.d_str.p), n_rep};
       defer->str_stride = str_stride;
       return 0;
+    }
+    // Dense results (a CRISPR guide set on a genome: 10^7 matches): every report is a record, nothing is filtered or
+    // dropped, the result is empty so far -- the rows get their final pattern index and strand on the device and leave,
+    // with the cigar strings, by two DMA copies into ONE pinned block that the result keeps (as assemble_many and the
+    // dense single-pattern searches do).  The host used to take 128 bytes per match through zero-filled vectors, pageable
+    // copies and three loops: 0.9 of the 1.13 s of 312 guides x both strands on the genome-like text (17 M matches).
+    // SASSY_HIP_ENCODED_PIN=0: the host's way (tests compare the two record by record).
+    const bool env_nopin = getenv("SASSY_HIP_ENCODED_PIN") && atoi(getenv("SASSY_HIP_ENCODED_PIN")) == 0;  // (per call: tests flip it)
+    const bool no_filters = std::isnan(s->max_n_frac) && !s->only_best;
+    if (!env_nopin && no_filters && !tt && R->matches.empty() && R->pool.empty() && !R->pin.h && n_rep >= 1024 &&
+        text_len < (1ull << 39) && m + k < 0xFFFFu && k < 0x7FFFu && strb % 16 == 0) {
+      const size_t n = n_rep;
+      ScanLane& LO = s->lanes[2];  // (its record / string buffers take the ordered result)
+      if (int rc = LO.d_trace.reserve(n)) return rc;
+      if (int rc = LO.d_str.reserve(n * strb)) return rc;
+      if (int rc = L.d_sort.reserve(encoded_scratch_bytes(n_rep))) return rc;
+      int key_bits = 40;
+      while (key_bits < 64 && ((uint64_t)e->n_original >> (key_bits - 39)) != 0) ++key_bits;
+      const size_t rows_off = 256, strs_off = (rows_off + n * sizeof(MatchOut) + 255) / 256 * 256;
+      const size_t bytes = strs_off + n * strb + 256;
+      if (L.reserve_pinned(bytes) == 0) {
+        if (int rc = L.d_flags.reserve(4)) return rc;
+        HIP_TRY(hipMemsetAsync(L.d_flags.p, 0, 4, st));
+        le = launch_assemble_encoded(L.d_trace.p, reinterpret_cast<const char*>(L.d_str.p), n_rep, e->n_original, (uint32_t)strb, key_bits,
+                                     LO.d_trace.p, reinterpret_cast<char*>(LO.d_str.p), L.d_flags.p, L.d_sort.p, L.d_sort.cap, st);
+        if (le != hipSuccess) return hip_fail(le, "result ordering launch");
+        HIP_TRY(hipMemcpyAsync(L.h_pin, L.d_flags.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(L.h_pin + rows_off, LO.d_trace.p, n * sizeof(MatchOut), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(L.h_pin + strs_off, LO.d_str.p, n * strb, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
+        s->stats.trace_ms += ms;
+        uint32_t flags = 0;
+        memcpy(&flags, L.h_pin, 4);
+        if (flags) return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
+        const sassy_hip_Match* hm = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + rows_off);
+        const char* hs = reinterpret_cast<const char*>(L.h_pin + strs_off);
+        if (g_pin_pool.may_adopt(L.h_pin_cap)) {
+          R->pin = L.take_pin();
+          R->ext_matches = hm;
+          R->ext_n = n;
+          R->ext_pool = hs;
+          R->ext_pool_len = n * strb;
+        } else {
+          R->matches.assign(hm, hm + n);
+          R->pool.assign(hs, n * strb);
+        }
+        g_marks.mark("list: pinned rows");
+        return 0;
+      }
+      (void)hipGetLastError();  // (no pinned block of that size: the host's way)
     }
     rows.resize(n_rep);
     pool.resize((size_t)n_rep * strb);

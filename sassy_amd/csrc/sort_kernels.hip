@@ -302,6 +302,93 @@ hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable
 }
 
 
+// ---- host.hip: finish_pattern_list, dense results of search_encoded ----
+// The rows of a one-pass search of many patterns as the traceback left them (pattern_idx = the rc-expanded pattern, in
+// (pattern, end position) order) -> the records of the result in the order sassy_hip_search_encoded documents and its host
+// path sorts into: (pattern_idx mod P, text_start, text_end, cost, strand) -- the key the reference's own differential
+// test sorts by (pattern_tiling/search.rs:748-757); the reference reports pattern_idx mod P with strand = Rc for the
+// appended reverse complements (tqueries.rs:74-80, trace.rs:444-449).  Two stable radix sorts of (key, index) pairs --
+// the minor key (length, cost, strand) first --, then one kernel writes every record and its cigar string to its place.
+namespace {
+__global__ __launch_bounds__(256) void encoded_minor_keys_kernel(const MatchOut* __restrict__ rows, uint32_t n, uint64_t n_original,
+                                                                 uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  const MatchOut r = rows[i];
+  const uint32_t len = (uint32_t)(r.text_end - r.text_start) & 0xFFFFu, cost = (uint32_t)r.cost & 0x7FFFu;
+  keys[i] = (len << 16) | (cost << 1) | (r.pattern_idx >= n_original ? 1u : 0u);
+  idx[i] = i;
+}
+__global__ __launch_bounds__(256) void encoded_major_keys_kernel(const MatchOut* __restrict__ rows, uint32_t n, uint64_t n_original,
+                                                                 const uint32_t* __restrict__ idx, unsigned long long* __restrict__ keys) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j >= n) return;
+  const MatchOut* r = rows + idx[j];
+  keys[j] = ((r->pattern_idx % n_original) << 39) | (r->text_start & ((1ull << 39) - 1ull));
+}
+// record j of the result = row idx[j]; 16 lanes per record (the row and the string slot travel as 16-byte pieces)
+__global__ __launch_bounds__(256) void encoded_rows_kernel(const MatchOut* __restrict__ rows, const char* __restrict__ strs, uint32_t n,
+                                                           uint64_t n_original, const uint32_t* __restrict__ idx, uint32_t str_stride,
+                                                           MatchOut* __restrict__ out_rows, char* __restrict__ out_strs,
+                                                           uint32_t* __restrict__ flags) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t j = t >> 4, part = t & 15u;
+  if (j >= n) return;
+  const uint32_t i = idx[j];
+  const char* sstr = strs + (size_t)i * str_stride;
+  for (uint32_t x = part; x < str_stride / 16; x += 16)
+    reinterpret_cast<uint4*>(out_strs + (size_t)j * str_stride)[x] = reinterpret_cast<const uint4*>(sstr)[x];
+  if (part == 0) {
+    MatchOut r = rows[i];
+    if (r.pad_[0] == kTraceFailed) atomicOr(flags, 1u);
+    const uint64_t p = r.pattern_idx;
+    r.pattern_idx = p % n_original;
+    r.strand = p >= n_original ? 1 : 0;
+    r.cigar_off = j * str_stride;
+    out_rows[j] = r;
+  }
+}
+}  // namespace
+size_t encoded_scratch_bytes(uint32_t count) {
+  size_t t1 = 0, t2 = 0;
+  (void)rocprim::radix_sort_pairs(nullptr, t1, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
+                                  static_cast<uint32_t*>(nullptr), (size_t)count, 0, 32, hipStream_t(nullptr));
+  (void)rocprim::radix_sort_pairs(nullptr, t2, static_cast<unsigned long long*>(nullptr), static_cast<unsigned long long*>(nullptr),
+                                  static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), (size_t)count, 0, 64, hipStream_t(nullptr));
+  return 2 * (((size_t)count * 8 + 255) / 256 * 256) + 2 * (((size_t)count * 4 + 255) / 256 * 256) + std::max(t1, t2) + 256;
+}
+// key_bits: significant bits of (pattern_idx mod P) << 39 | text_start
+hipError_t launch_assemble_encoded(const MatchOut* d_rows_in, const char* d_strs_in, uint32_t count, uint64_t n_original, uint32_t str_stride,
+                                   int key_bits, MatchOut* d_rows, char* d_strs, uint32_t* d_flags, void* d_scratch, size_t scratch_bytes,
+                                   hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  const size_t kb = ((size_t)count * 8 + 255) / 256 * 256, ib = ((size_t)count * 4 + 255) / 256 * 256;
+  if (scratch_bytes < 2 * kb + 2 * ib) return hipErrorInvalidValue;
+  unsigned char* base = static_cast<unsigned char*>(d_scratch);
+  unsigned long long* k64_in = reinterpret_cast<unsigned long long*>(base);
+  unsigned long long* k64_out = reinterpret_cast<unsigned long long*>(base + kb);
+  uint32_t* k32_in = reinterpret_cast<uint32_t*>(base);        // (the minor keys use the same space, before the major ones)
+  uint32_t* k32_out = reinterpret_cast<uint32_t*>(base + kb);
+  uint32_t* idx_a = reinterpret_cast<uint32_t*>(base + 2 * kb);
+  uint32_t* idx_b = reinterpret_cast<uint32_t*>(base + 2 * kb + ib);
+  void* temp = base + 2 * kb + 2 * ib;
+  size_t temp_bytes = scratch_bytes - (2 * kb + 2 * ib);
+  const uint32_t grid = (count + 255) / 256;
+  hipLaunchKernelGGL(encoded_minor_keys_kernel, dim3(grid), dim3(256), 0, stream, d_rows_in, count, n_original, k32_in, idx_a);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = rocprim::radix_sort_pairs(temp, temp_bytes, k32_in, k32_out, idx_a, idx_b, (size_t)count, 0, 32, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(encoded_major_keys_kernel, dim3(grid), dim3(256), 0, stream, d_rows_in, count, n_original, idx_b, k64_in);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = rocprim::radix_sort_pairs(temp, temp_bytes, k64_in, k64_out, idx_b, idx_a, (size_t)count, 0, (unsigned)std::min(64, std::max(8, key_bits)), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(encoded_rows_kernel, dim3((uint32_t)(((uint64_t)count * 16 + 255) / 256)), dim3(256), 0, stream, d_rows_in, d_strs_in, count,
+                     n_original, idx_a, str_stride, d_rows, d_strs, d_flags);
+  return hipGetLastError();
+}
+
 // ---- host.hip: assemble_many ----
 size_t many_scratch_bytes(uint32_t count) {
   size_t temp = 0;
