@@ -2940,24 +2940,25 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
       if (int rc = L.d_sort.reserve(encoded_scratch_bytes(n_rep))) return rc;
       int key_bits = 40;
       while (key_bits < 64 && ((uint64_t)e->n_original >> (key_bits - 39)) != 0) ++key_bits;
+      if (int rc = L.d_flags.reserve(4)) return rc;
+      HIP_TRY(hipMemsetAsync(L.d_flags.p, 0, 8, st));
+      le = launch_assemble_encoded(L.d_trace.p, reinterpret_cast<const char*>(L.d_str.p), n_rep, e->n_original, (uint32_t)strb, key_bits,
+                                   LO.d_trace.p, reinterpret_cast<char*>(LO.d_str.p), L.d_flags.p, L.d_sort.p, L.d_sort.cap, st);
+      if (le != hipSuccess) return hip_fail(le, "result ordering launch");
+      uint32_t flags2[2] = {0, 0};
+      HIP_TRY(hipMemcpyAsync(flags2, L.d_flags.p, 8, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      if (flags2[0]) return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
+      const size_t pool_bytes = flags2[1];  // (the strings without their slots' padding)
       const size_t rows_off = 256, strs_off = (rows_off + n * sizeof(MatchOut) + 255) / 256 * 256;
-      const size_t bytes = strs_off + n * strb + 256;
+      const size_t bytes = strs_off + pool_bytes + 256;
       if (L.reserve_pinned(bytes) == 0) {
-        if (int rc = L.d_flags.reserve(4)) return rc;
-        HIP_TRY(hipMemsetAsync(L.d_flags.p, 0, 4, st));
-        le = launch_assemble_encoded(L.d_trace.p, reinterpret_cast<const char*>(L.d_str.p), n_rep, e->n_original, (uint32_t)strb, key_bits,
-                                     LO.d_trace.p, reinterpret_cast<char*>(LO.d_str.p), L.d_flags.p, L.d_sort.p, L.d_sort.cap, st);
-        if (le != hipSuccess) return hip_fail(le, "result ordering launch");
-        HIP_TRY(hipMemcpyAsync(L.h_pin, L.d_flags.p, 4, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(L.h_pin + rows_off, LO.d_trace.p, n * sizeof(MatchOut), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(L.h_pin + strs_off, LO.d_str.p, n * strb, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(L.h_pin + strs_off, LO.d_str.p, pool_bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, s->ev_a_multi(), s->ev_multi));
         s->stats.trace_ms += ms;
-        uint32_t flags = 0;
-        memcpy(&flags, L.h_pin, 4);
-        if (flags) return fail(SASSY_HIP_EINVAL, "traceback failed for a reported end position (internal error)");
         const sassy_hip_Match* hm = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + rows_off);
         const char* hs = reinterpret_cast<const char*>(L.h_pin + strs_off);
         if (g_pin_pool.may_adopt(L.h_pin_cap)) {
@@ -2965,10 +2966,10 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
           R->ext_matches = hm;
           R->ext_n = n;
           R->ext_pool = hs;
-          R->ext_pool_len = n * strb;
+          R->ext_pool_len = pool_bytes;
         } else {
           R->matches.assign(hm, hm + n);
-          R->pool.assign(hs, n * strb);
+          R->pool.assign(hs, pool_bytes);
         }
         g_marks.mark("list: pinned rows");
         return 0;

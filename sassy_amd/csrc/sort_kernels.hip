@@ -326,26 +326,38 @@ __global__ __launch_bounds__(256) void encoded_major_keys_kernel(const MatchOut*
   const MatchOut* r = rows + idx[j];
   keys[j] = ((r->pattern_idx % n_original) << 39) | (r->text_start & ((1ull << 39) - 1ull));
 }
-// record j of the result = row idx[j]; 16 lanes per record (the row and the string slot travel as 16-byte pieces)
+// bytes of record j's cigar string in the result's pool: the text and its NUL
+__global__ __launch_bounds__(256) void encoded_lens_kernel(const MatchOut* __restrict__ rows, uint32_t n, const uint32_t* __restrict__ idx,
+                                                           uint32_t* __restrict__ lens) {
+  const uint32_t j = blockIdx.x * 256u + threadIdx.x;
+  if (j < n) lens[j] = rows[idx[j]].cigar_len + 1u;
+}
+// record j of the result = row idx[j]; its cigar string goes to offs[j] of a pool WITHOUT the slots' padding (a slot is
+// 2 (m + k + 1) + 2 bytes rounded up, a cigar of a 23-mer a dozen: 1.1 GB of the 2.2 GB a guide set's 17 M matches took
+// over the PCIe link were NULs).  8 lanes per record, 8 string bytes each; flags[1] = the pool's size.
 __global__ __launch_bounds__(256) void encoded_rows_kernel(const MatchOut* __restrict__ rows, const char* __restrict__ strs, uint32_t n,
                                                            uint64_t n_original, const uint32_t* __restrict__ idx, uint32_t str_stride,
-                                                           MatchOut* __restrict__ out_rows, char* __restrict__ out_strs,
-                                                           uint32_t* __restrict__ flags) {
+                                                           const uint32_t* __restrict__ offs, MatchOut* __restrict__ out_rows,
+                                                           char* __restrict__ out_strs, uint32_t* __restrict__ flags) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t j = t >> 4, part = t & 15u;
+  const uint32_t j = t >> 3, part = t & 7u;
   if (j >= n) return;
   const uint32_t i = idx[j];
+  const uint32_t len = rows[i].cigar_len + 1u, off = offs[j];
   const char* sstr = strs + (size_t)i * str_stride;
-  for (uint32_t x = part; x < str_stride / 16; x += 16)
-    reinterpret_cast<uint4*>(out_strs + (size_t)j * str_stride)[x] = reinterpret_cast<const uint4*>(sstr)[x];
+  for (uint32_t x = part * 8u; x < len; x += 64u) {
+    const uint32_t e = min(x + 8u, len);
+    for (uint32_t y = x; y < e; ++y) out_strs[(size_t)off + y] = y + 1u < len ? sstr[y] : '\0';
+  }
   if (part == 0) {
     MatchOut r = rows[i];
     if (r.pad_[0] == kTraceFailed) atomicOr(flags, 1u);
     const uint64_t p = r.pattern_idx;
     r.pattern_idx = p % n_original;
     r.strand = p >= n_original ? 1 : 0;
-    r.cigar_off = j * str_stride;
+    r.cigar_off = off;
     out_rows[j] = r;
+    if (j + 1 == n) flags[1] = off + len;
   }
 }
 }  // namespace
@@ -355,9 +367,13 @@ size_t encoded_scratch_bytes(uint32_t count) {
                                   static_cast<uint32_t*>(nullptr), (size_t)count, 0, 32, hipStream_t(nullptr));
   (void)rocprim::radix_sort_pairs(nullptr, t2, static_cast<unsigned long long*>(nullptr), static_cast<unsigned long long*>(nullptr),
                                   static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), (size_t)count, 0, 64, hipStream_t(nullptr));
-  return 2 * (((size_t)count * 8 + 255) / 256 * 256) + 2 * (((size_t)count * 4 + 255) / 256 * 256) + std::max(t1, t2) + 256;
+  size_t t3 = 0;
+  (void)rocprim::exclusive_scan(nullptr, t3, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), 0u, (size_t)count,
+                                rocprim::plus<uint32_t>(), hipStream_t(nullptr));
+  return 2 * (((size_t)count * 8 + 255) / 256 * 256) + 2 * (((size_t)count * 4 + 255) / 256 * 256) + std::max(std::max(t1, t2), t3) + 256;
 }
-// key_bits: significant bits of (pattern_idx mod P) << 39 | text_start
+// key_bits: significant bits of (pattern_idx mod P) << 39 | text_start.  d_flags: two words -- [0] a traceback failed,
+// [1] bytes of the compacted cigar pool (<= count * str_stride, which d_strs must hold).
 hipError_t launch_assemble_encoded(const MatchOut* d_rows_in, const char* d_strs_in, uint32_t count, uint64_t n_original, uint32_t str_stride,
                                    int key_bits, MatchOut* d_rows, char* d_strs, uint32_t* d_flags, void* d_scratch, size_t scratch_bytes,
                                    hipStream_t stream) {
@@ -384,8 +400,16 @@ hipError_t launch_assemble_encoded(const MatchOut* d_rows_in, const char* d_strs
   if (e != hipSuccess) return e;
   e = rocprim::radix_sort_pairs(temp, temp_bytes, k64_in, k64_out, idx_b, idx_a, (size_t)count, 0, (unsigned)std::min(64, std::max(8, key_bits)), stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(encoded_rows_kernel, dim3((uint32_t)(((uint64_t)count * 16 + 255) / 256)), dim3(256), 0, stream, d_rows_in, d_strs_in, count,
-                     n_original, idx_a, str_stride, d_rows, d_strs, d_flags);
+  // (the key areas are free again: string lengths and their offsets)
+  uint32_t* lens = reinterpret_cast<uint32_t*>(base);
+  uint32_t* offs = reinterpret_cast<uint32_t*>(base + kb);
+  hipLaunchKernelGGL(encoded_lens_kernel, dim3(grid), dim3(256), 0, stream, d_rows_in, count, idx_a, lens);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = rocprim::exclusive_scan(temp, temp_bytes, lens, offs, 0u, (size_t)count, rocprim::plus<uint32_t>(), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(encoded_rows_kernel, dim3((uint32_t)(((uint64_t)count * 8 + 255) / 256)), dim3(256), 0, stream, d_rows_in, d_strs_in, count,
+                     n_original, idx_a, str_stride, offs, d_rows, d_strs, d_flags);
   return hipGetLastError();
 }
 

@@ -40,6 +40,45 @@ __device__ __forceinline__ void tiled_emit(const TiledParams& P, uint64_t pos, i
   if (idx < P.cand_cap) P.cand[idx] = Candidate{pos, cost, pat << kCandTextShift};
 }
 
+// The same for eight consecutive end positions of every lane of the wave at once (called in wave-uniform control flow):
+// bit i of `mask` = position pos + i of this lane's pattern is listed, with cost c8[i].  ONE counter update per call: in
+// the inside of a run of N every pattern matches at every position -- 512 records per wave and step, and an atomic each
+// (plus the saturation test's read of the counter) made the zones around the N runs of a genome the longest kernel of a
+// guide-set search (119 of 210 ms).
+__device__ __forceinline__ void tiled_emit8(const TiledParams& P, uint64_t pos, uint32_t mask, const int (&c8)[8], uint32_t pat) {
+  if (P.keep_bits) {  // (a gathered buffer: context, separators)
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+      const uint64_t q = pos + i;
+      if (((mask >> i) & 1u) && !((P.keep_bits[q >> 5] >> (q & 31u)) & 1u)) mask &= ~(1u << i);
+    }
+  }
+  const uint32_t n = (uint32_t)__popc(mask), lane = __lane_id();
+  uint32_t inc = n;  // inclusive prefix sum over the wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d, 64);
+    if (lane >= (uint32_t)d) inc += t;
+  }
+  const uint32_t total = __shfl(inc, 63, 64);
+  if (total == 0) return;
+  uint32_t first = 0xFFFFFFFFu;
+  if (lane == 0) {
+    // (saturating: far beyond any capacity the host would retry with, the waves stop counting -- the counter never wraps)
+    if (*reinterpret_cast<volatile const uint32_t*>(P.cand_count) <= P.cand_stop) first = atomicAdd(P.cand_count, total);
+  }
+  first = __shfl(first, 0, 64);
+  if (first == 0xFFFFFFFFu) return;
+  uint32_t idx = first + inc - n;
+#pragma unroll
+  for (uint32_t i = 0; i < 8; ++i) {
+    if ((mask >> i) & 1u) {
+      if (idx < P.cand_cap) P.cand[idx] = Candidate{pos + i, c8[i], pat << kCandTextShift};
+      ++idx;
+    }
+  }
+}
+
 // WORDS = 1: patterns of <= 32 rows (one 32-bit word), 2: 33 .. 64 rows.
 //
 // Coordinates: y = text position + skew indexes the 64-byte-aligned array text_aligned = text - skew, so that
@@ -112,10 +151,11 @@ __global__ __launch_bounds__(256) void tiled_scan_kernel(const TiledParams P) {
             c8[i] = S.cost;
             lowest = min(lowest, S.cost);
           }
-          if (lowest <= kk) {
+          if (__any(lowest <= kk)) {  // (wave-uniform: the records of all lanes leave with one counter update)
+            uint32_t mask = 0;
 #pragma unroll
-            for (uint32_t i = 0; i < 8; ++i)
-              if (c8[i] <= kk) tiled_emit(P, pos0 + g + i, c8[i], pat);
+            for (uint32_t i = 0; i < 8; ++i) mask |= (c8[i] <= kk ? 1u : 0u) << i;
+            tiled_emit8(P, pos0 + g, mask, c8, pat);
           }
         } else {  // warm-up: nothing is reported
 #pragma unroll
