@@ -46,6 +46,8 @@ struct TextTable {
   uint32_t all_minima;    // search_all: reports inside a separator are dropped (else: moved to the text end)
   uint32_t per_text;      // 1: block-aligned texts scanned one lane per text -- the reports already carry
                           // their text index and lie where they belong (nothing to look up or move)
+  uint32_t ov_steps;      // overhang: end positions up to len + ov_steps behind a text's start are the text's own (virtual
+                          // 'N' columns), not positions inside a separator
 };
 // chunk exit states
 constexpr uint8_t kStateDecFalse = 0, kStateDecTrue = 1, kStatePass = 2;
@@ -221,6 +223,21 @@ struct TiledParams {
                                   // the host would retry with): a 32-bit counter that kept counting could wrap on a
                                   // dense shape and pass for a complete list
   const uint32_t* keep_bits;      // optional: bit p = end position p is wanted (others are computed, not listed)
+  // ---- overhang in one pass (tiled_pertext_kernel; reference: the v2 scan takes overhang in its tiled loop,
+  // src/pattern_tiling/search.rs:222-323, alpha_pattern :462-472) ----
+  // n_texts != 0: text_aligned is a buffer of n_texts texts, text t in whole 64-byte blocks from texts_start[t] on,
+  // texts_len[t] characters followed by >= ov_steps + 2 'N' (the virtual columns behind the text are real there, and the
+  // end positions of two texts never touch).  Every text starts from the overhang column (ov_vp = the vertical deltas
+  // floor((j+1) alpha) - floor(j alpha), ov_cost0 their sum); an end position i > len costs floor(alpha (i - len)) more;
+  // positions texts_start[t] + 0 .. len + ov_steps are listed.
+  const uint64_t* texts_start;
+  const uint64_t* texts_len;
+  uint32_t n_texts;
+  uint32_t texts_per_wave;
+  uint32_t ov_steps;
+  float alpha;
+  unsigned long long ov_vp;
+  int32_t ov_cost0;
 };
 
 // The seeded search of many patterns over a long text (seed_kernels.hip).

@@ -710,13 +710,16 @@ static int pair_env() {
   static const int v = getenv("SASSY_HIP_PAIR") ? atoi(getenv("SASSY_HIP_PAIR")) : 1;
   return v;
 }
-static bool plain_acgt(const uint8_t* pat, size_t m) {
-  for (size_t j = 0; j < m; ++j) {
+// rows of the pattern, from row 0 on, that are plain bases
+static size_t plain_prefix(const uint8_t* pat, size_t m) {
+  size_t j = 0;
+  for (; j < m; ++j) {
     const uint8_t u = pat[j] & 0xDFu;
-    if (u != 'A' && u != 'C' && u != 'G' && u != 'T') return false;
+    if (u != 'A' && u != 'C' && u != 'G' && u != 'T') break;
   }
-  return true;
+  return j;
 }
+static bool plain_acgt(const uint8_t* pat, size_t m) { return plain_prefix(pat, m) == m; }
 
 // The three prefilter kernels (scan_kernel.hip): which one evaluates the pieces.
 enum FilterKind : uint32_t {
@@ -1079,7 +1082,12 @@ int ScanJob::prepare() {
   uint32_t pair_s = 0, pair_q = 0;
   const bool pair_ok = env_pair != 0 && q == 0 && env_pre < 0 && fuse_ok && !overhang && !ext_bitmap && !ext_desc && !plan.bytes &&
                        pair_geometry(plan.m, k, &pair_s, &pair_q) &&
-                       (S->profile == PROFILE_DNA || (plain_pattern && plan.nslots <= 4 && pair_s <= 3)) &&
+                       // (an Iupac searcher: the filter's 2 S Q rows are plain bases -- the rows behind them may hold
+                       // ambiguity letters, a guide's NGG: the chunk DP then builds up to eight slot masks)
+                       (S->profile == PROFILE_DNA ||
+                        (S->profile == PROFILE_IUPAC && env_iupac_planes != 0 && pair_s <= 3 &&
+                         plain_prefix(pat, plan.m) >= (size_t)2 * pair_s * pair_q &&
+                         (plan.nslots <= 4 || (plan.nslots <= 8 && plan.nwords <= 4)))) &&
                        (env_kind == 0 || env_kind == kFilterPlanes);
   pair = 0;
   // q-gram counting (count_filter.hip): per (Q, R) variant the threshold t = m + 1 - (k+1) Q, the
@@ -1155,7 +1163,7 @@ int ScanJob::prepare() {
   if (pair_ok && fkind != kFilterCount) {
     pair = pair_s;
     q = pair_q;
-    iupac_planes = plain_pattern;
+    iupac_planes = S->profile == PROFILE_IUPAC;
     can_planes = true;
   } else if (short_ok && fkind != kFilterCount) {
     q = plan.m / pieces;
@@ -2714,7 +2722,9 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
   uint32_t ps_ = 0, pq_ = 0;
   const bool pair_strands = env_pair_rc != 0 && pair_env() != 0 && prefilter_mode(S->prefilter) < 0 && S->fuse && !wo && k <= 0xFFFFu &&
                             pair_geometry(plan.m, (uint32_t)k, &ps_, &pq_) &&
-                            (S->profile == PROFILE_DNA || (S->profile == PROFILE_IUPAC && ps_ <= 3 && plain_acgt(pattern, plen)));
+                            (S->profile == PROFILE_DNA ||
+                             (S->profile == PROFILE_IUPAC && ps_ <= 3 && pair_geometry(plan.m, (uint32_t)k, &ps_, &pq_) &&
+                              plain_prefix(pattern, plen) >= (size_t)2 * ps_ * pq_));
   const bool can_fuse = fwd_strand && rc_strand && env_fuse != 0 && !ef.fn && std::isnan(S->max_n_frac) &&
                         std::isnan(S->alpha) && S->profile != PROFILE_ASCII && ref_lanes == 0 && !pair_strands;
   bool rc_by_bitmap = false;

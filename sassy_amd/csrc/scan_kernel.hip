@@ -1871,7 +1871,10 @@ __device__ __forceinline__ bool other_letters16(const uint4 v) { return other_le
 // fourth.  Exact: a match with <= k edits always has such a pair (pigeonhole on the super-pieces), and a pair whose
 // detection column lies behind the last block of the buffer (A in the last Q + 2 columns) belongs to a match that ends
 // in the last k + 2 columns: those are always searched.
-template <int Q, int NPG, bool FUSED, bool CHECK = false, bool PAIR = false>
+// DPNS (CHECK only): slot masks the chunk DP builds -- 4 for a pattern of plain bases, 8 when the rows BEHIND the filter's
+// pieces hold ambiguity letters (a CRISPR guide: 20 bases + NGG; the pieces themselves are plain, so the filter is the
+// same): masks 8 x 512 B + carries of at most four pattern words fill the tile up to the saved segment state.
+template <int Q, int NPG, bool FUSED, bool CHECK = false, bool PAIR = false, int DPNS = 4>
 // (CHECK: four waves per SIMD are asked for -- left to itself the compiler settles for three, 0.59 instead of 0.52 ms)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CHECK || PAIR) ? 4 : 1))) void filter_dna_kernel(const ScanParams P) {
   static_assert(!CHECK || FUSED, "the text check exists in the fused launch only");
@@ -2313,10 +2316,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CHECK || P
     L.chunk_state = nullptr;
     L.texts_start = nullptr;
     L.texts_len = nullptr;
-    if constexpr (CHECK) {  // (the Iupac masks of a plain pattern: four slots, A C T G)
-      L.nslots = 4;
+    if constexpr (CHECK) {  // (the Iupac masks of the pattern's letters: four slots -- A C T G -- or up to eight)
+      L.nslots = DPNS == 4 ? 4u : kp->nslots;
 #pragma unroll
-      for (int sl = 0; sl < 4; ++sl) L.slot_val[sl] = kp->slot_val[sl];
+      for (int sl = 0; sl < DPNS; ++sl) L.slot_val[sl] = kp->slot_val[sl];
     }
     // (the same for everything the DP derives from the thread index -- LDS addresses per lane, word, slot:
     // computed from an opaque copy, they cannot be hoisted in front of the streaming loop and held in VGPRs there)
@@ -2329,7 +2332,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CHECK || P
     if (dlane == 0) atomicAdd(&L.cand_count[1], n_run);  // statistics: chunks
     // the DP's LDS -- slot masks, per-row carries -- takes the place of the text tile
     unsigned char* mask_bytes = dtile;
-    uint32_t* carry = reinterpret_cast<uint32_t*>(dtile + 4 * 512);
+    uint32_t* carry = reinterpret_cast<uint32_t*>(dtile + DPNS * 512);
     // between segments only full batches of 64 chunks run; what is left over waits for the next pass
     for (uint32_t base = 0; base < n_run; base += 64u) {
       const bool has = base + dlane < n_run;
@@ -2340,7 +2343,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((CHECK || P
       dsc.own_hi = e.x + ((e.y >> 6) & 0xFFu);
       dsc.flags = kDescWindow;
       dsc.pad_ = (e.y & 63u) | ((e.y >> 14) << 8);  // byte shift | columns not to report << 8
-      list_lanes<CHECK ? (int)PROFILE_IUPAC : (int)PROFILE_DNA, 4, true>(L, mask_bytes, carry, dlane, has, dsc, kNoStateSlot);
+      list_lanes<CHECK ? (int)PROFILE_IUPAC : (int)PROFILE_DNA, DPNS, true>(L, mask_bytes, carry, dlane, has, dsc, kNoStateSlot);
     }
     if ((kp->fused & 2u) && dlane == 0) {
       unsigned long long* pc = reinterpret_cast<unsigned long long*>(L.cand_count + 4);  // the control block's counters
@@ -2769,15 +2772,20 @@ static hipError_t launch_filter_planes_iupac_q(const ScanParams& P, uint32_t gri
   else hipLaunchKernelGGL((filter_dna_kernel<Q, 1, true, true>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
 }
-template <int Q, int S>
-static hipError_t launch_filter_pair_iupac_q(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+template <int Q, int S, int DPNS>
+static hipError_t launch_filter_pair_iupac_ns(const ScanParams& P, uint32_t grid, hipStream_t stream) {
   const size_t smem = (size_t)kWavesPerGroup * P.lds_per_wave;
   const LaunchEvents ev = g_launch_events;
   g_launch_events = LaunchEvents{};
   if (ev.start)
-    hipExtLaunchKernelGGL((filter_dna_kernel<Q, S, true, true, true>), dim3(grid), dim3(256), smem, stream, ev.start, ev.stop, 0, P);
-  else hipLaunchKernelGGL((filter_dna_kernel<Q, S, true, true, true>), dim3(grid), dim3(256), smem, stream, P);
+    hipExtLaunchKernelGGL((filter_dna_kernel<Q, S, true, true, true, DPNS>), dim3(grid), dim3(256), smem, stream, ev.start, ev.stop, 0, P);
+  else hipLaunchKernelGGL((filter_dna_kernel<Q, S, true, true, true, DPNS>), dim3(grid), dim3(256), smem, stream, P);
   return hipGetLastError();
+}
+template <int Q, int S>
+static hipError_t launch_filter_pair_iupac_q(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  if (P.nslots > 8 || (P.nslots > 4 && P.nwords > 4)) return hipErrorInvalidValue;  // (the host asks for what fits the tile)
+  return P.nslots <= 4 ? launch_filter_pair_iupac_ns<Q, S, 4>(P, grid, stream) : launch_filter_pair_iupac_ns<Q, S, 8>(P, grid, stream);
 }
 static hipError_t launch_filter_planes_iupac(const ScanParams& P, uint32_t grid, hipStream_t stream) {
   if (P.pair) {  // the paired filter with the text check (the host asks for at most three super-pieces here)

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void assign_texts_kernel(Candidate* __restrict
     if (T.start[mid] <= v.pos) lo = mid; else hi = mid;
   }
   const uint64_t te = T.start[lo] + T.len[lo];
-  if (v.pos > te) {
+  if (v.pos > te + T.ov_steps) {  // (overhang: the virtual columns behind a text are end positions of its own)
     if (T.all_minima) v.flags |= kCandDrop;
     else v.pos = te;
     rep[i] = v;

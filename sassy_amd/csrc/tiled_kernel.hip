@@ -172,6 +172,101 @@ __global__ __launch_bounds__(256) void tiled_scan_kernel(const TiledParams P) {
   }
 }
 
+// Overhang in one pass over a batch of texts (TiledParams::n_texts != 0): a wave = 64 patterns x a run of
+// texts_per_wave texts, each text from its own overhang column to its last virtual 'N' column.
+template <int WORDS>
+__global__ __launch_bounds__(256) void tiled_pertext_kernel(const TiledParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tsmem[];
+  typedef typename std::conditional<WORDS == 1, uint32_t, unsigned long long>::type Word;
+  constexpr uint32_t kShift = WORDS == 1 ? 8u : 9u;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint64_t w = (uint64_t)blockIdx.x * kWavesPerGroup + wave;
+  const uint64_t range = w / P.n_groups;
+  const uint32_t group = (uint32_t)(w % P.n_groups);
+  const uint64_t t_lo = range * P.texts_per_wave;
+  if (t_lo >= P.n_texts) return;  // wave-uniform
+  const uint64_t t_hi = t_lo + P.texts_per_wave < P.n_texts ? t_lo + P.texts_per_wave : P.n_texts;
+  const uint32_t pat = group * 64u + lane;
+  const bool valid = pat < P.npat;
+  unsigned char* wave_lds = tsmem + ((size_t)wave * P.classes << kShift);
+  Word* peq = reinterpret_cast<Word*>(wave_lds);
+  for (uint32_t c = 0; c < P.classes; ++c) {
+    const unsigned long long v = valid ? P.peq[(size_t)c * P.npat_padded + pat] : 0ull;
+    peq[c * 64u + lane] = (Word)v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const unsigned char* lane_lds = wave_lds + lane * sizeof(Word);
+  const int kk = valid ? (int)P.k : (int)0x80000000;  // lanes without a pattern never report
+  const uint32_t top_shift = (P.m - 1u) & 31u;
+  for (uint64_t t = t_lo; t < t_hi; ++t) {
+    const uint64_t start = P.texts_start[t], len = P.texts_len[t];
+    if (len == 0) continue;  // no reports for an empty text (src/search.rs:1314-1316)
+    const uint64_t end = len + P.ov_steps;
+    TiledState<Word> S;
+    S.vp = (Word)P.ov_vp;
+    S.vn = 0;
+    S.cost = P.ov_cost0;
+    if (S.cost <= kk) tiled_emit(P, start, S.cost, pat);  // end position 0: the whole pattern hangs over the text's start
+    for (uint64_t yb = 0; yb < end; yb += 64) {
+      const uint32_t ch = P.text_aligned[start + yb + lane];
+      uint32_t off;
+      if (P.classes == 4) off = ((ch >> 1) & 3u) << kShift;
+      else off = (uint32_t)kTiledIupacNib[ch & 31u] << kShift;
+      const uint64_t pos0 = start + yb + 1;  // end position behind character u = 0 of this block
+      if (yb + 64 <= len) {  // a whole block inside the text
+#pragma unroll
+        for (uint32_t g = 0; g < 64; g += 8) {
+          Word eq[8];
+#pragma unroll
+          for (uint32_t i = 0; i < 8; ++i)
+            eq[i] = *reinterpret_cast<const Word*>(lane_lds + (uint32_t)__builtin_amdgcn_readlane((int)off, (int)(g + i)));
+          int c8[8];
+          int lowest = 0x7FFFFFFF;
+#pragma unroll
+          for (uint32_t i = 0; i < 8; ++i) {
+            tiled_step(S, eq[i], top_shift);
+            c8[i] = S.cost;
+            lowest = min(lowest, S.cost);
+          }
+          if (__any(lowest <= kk)) {
+            uint32_t mask = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 8; ++i) mask |= (c8[i] <= kk ? 1u : 0u) << i;
+            tiled_emit8(P, pos0 + g, mask, c8, pat);
+          }
+        }
+      } else {  // the block the text ends in, and the virtual columns behind it ('N' in the buffer)
+        const uint32_t u1 = end - yb < 64 ? (uint32_t)(end - yb) : 64u;
+        for (uint32_t u = 0; u < u1; ++u) {
+          const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)u);
+          tiled_step(S, *reinterpret_cast<const Word*>(lane_lds + o), top_shift);
+          const uint64_t i = yb + u + 1;
+          // (f32 arithmetic, as the reference's add_overshoot_cost: src/search.rs:1274-1282)
+          const int tot = S.cost + (i > len ? __float2int_rd(P.alpha * (float)(i - len)) : 0);
+          if (tot <= kk) tiled_emit(P, start + i, tot, pat);
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_tiled_pertext(const TiledParams& P, hipStream_t stream) {
+  if (P.n_texts == 0 || P.texts_per_wave == 0) return hipErrorInvalidValue;
+  const uint64_t ranges = ((uint64_t)P.n_texts + P.texts_per_wave - 1) / P.texts_per_wave;
+  const uint64_t waves = ranges * (uint64_t)P.n_groups;
+  const uint64_t groups = (waves + kWavesPerGroup - 1) / kWavesPerGroup;
+  if (groups > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  if (P.m <= 32) {
+    const size_t lds = (size_t)kWavesPerGroup * P.classes * 64u * 4u;
+    hipLaunchKernelGGL((tiled_pertext_kernel<1>), dim3((uint32_t)groups), dim3(256), lds, stream, P);
+  } else {
+    const size_t lds = (size_t)kWavesPerGroup * P.classes * 64u * 8u;
+    hipLaunchKernelGGL((tiled_pertext_kernel<2>), dim3((uint32_t)groups), dim3(256), lds, stream, P);
+  }
+  return hipGetLastError();
+}
+
 hipError_t launch_tiled_scan(const TiledParams& P, hipStream_t stream) {
   const uint64_t waves = P.n_chunks * (uint64_t)P.n_groups;
   const uint64_t groups = (waves + kWavesPerGroup - 1) / kWavesPerGroup;

@@ -11,6 +11,6 @@ for line in sys.stdin:
         m=re.search(r'remark: +'+key+r': (\d+)',line)
         if m and cur: d[short]=int(m.group(1))
     if 'LDS Size' in line and cur:
-        if 'filter_dna_kernel' in cur and 'Lb1EEEv' in cur: print(cur[24:50], d)
+        if 'filter_dna_kernel' in cur and 'Lb1ELi' in cur: print(cur[24:56], d)
         cur=None
 "; done; rm -f /tmp/kr_$$.o

@@ -2,7 +2,7 @@
 # tools/refresh_profiles.sh <round-tag> -- ON THE GPU BOX (via gpurun): every measurement profiles/ holds,
 # written under gpurun_out/refresh/ (copy the files into profiles/ afterwards: tools/collect_profiles.sh).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/refresh
@@ -83,7 +83,13 @@ fi
 python bench.py --mode inproc --gpus 1 --no-cpu-baseline > $OUT/${TAG}_bench_inproc.json 2>> $OUT/bench.err
 python tools/preflight_multigpu.py --gpus 2 --backend gloo 2>/dev/null | tail -1 > $OUT/${TAG}_preflight_gloo.json
 { python tools/bench_reads.py; python tools/bench_reads.py --reads 330000; python tools/bench_reads.py --reads 330000 --fwd; python tools/bench_reads.py --overhang 0.5; } > $OUT/${TAG}_reads.json 2> $OUT/reads.err
-{ python tools/probe_count.py; python tools/probe_rc.py; } > $OUT/${TAG}_shapes.json 2> $OUT/shapes.err
+{ python tools/probe_count.py; python tools/probe_rc.py; PROBE_M=23 PROBE_K=3 python tools/probe_rc.py; } > $OUT/${TAG}_shapes.json 2> $OUT/shapes.err
+{ echo "# the paired filter (round 5) against the paths of round 4 (SASSY_HIP_PAIR=0): lone searches, 3 GB, tools/probe_short_pieces.py";
+  export PROBE_SHAPES="dna:32:3,dna:23:3,iupac:23:3,dna:32:4,dna:32:5,iupac:32:5,dna:24:3,dna:27:3,dna:20:2,dna:12:1,dna:40:6,dna:48:7";
+  echo "## default"; PROBE_DEFAULT_ONLY=1 python tools/probe_short_pieces.py; echo "## SASSY_HIP_PAIR=0"; SASSY_HIP_PAIR=0 PROBE_DEFAULT_ONLY=1 python tools/probe_short_pieces.py;
+  echo "## counters of the fused launch, m = 23, k = 3 (tools/pmc_kernel.sh) and where its waves spend their time (SASSY_HIP_FUSED_PROBE=1 / 2: no chunk DP)";
+  bash tools/pmc_kernel.sh filter_dna_kernel PROBE_M=23 PROBE_K=3; SASSY_HIP_FUSED_PROBE=1 PROBE_M=23 PROBE_K=3 python tools/probe_fused.py 2>/dev/null | tail -1; SASSY_HIP_FUSED_PROBE=2 PROBE_M=23 PROBE_K=3 python tools/probe_fused.py 2>/dev/null | tail -1;
+  unset PROBE_SHAPES; } > $OUT/${TAG}_paired_filter.txt 2> $OUT/pair.err
 { echo "# tools/probe_short_pieces.py: shapes whose pigeonhole pieces are 5 or 6 rows -- default path against no prefilter (streaming DP), lone searches, 3 GB";
   python tools/probe_short_pieces.py; } > $OUT/${TAG}_short_pieces.txt 2> $OUT/short.err
 { echo "# tools/pmc_kernel.sh list_words_kernel: config 3's chunk DP (word-pipelined), counters per dispatch (sums over the waves; cycles in units of 4)";
