@@ -87,10 +87,11 @@ hipError_t launch_drop_excluded(const Candidate* d_in, uint32_t count, const uns
 hipError_t launch_compact_candidates(const Candidate* d_in, uint32_t count, const unsigned char* d_keep, Candidate* d_out,
                                      uint32_t* d_out_count, void* d_scratch, size_t scratch_bytes, hipStream_t stream);
 hipError_t launch_tiled_scan(const TiledParams& P, hipStream_t stream);
+hipError_t launch_tiled_pertext(const TiledParams& P, hipStream_t stream);
 size_t many_scratch_bytes(uint32_t count);
 hipError_t launch_assemble_many(const ManyPart& a, const ManyPart& b, uint32_t n_texts, const uint64_t* d_text_len,
                                 uint64_t first_text, uint32_t str_stride, MatchOut* d_rows, char* d_strs, uint32_t* d_flags,
-                                void* d_scratch, size_t scratch_bytes, hipStream_t stream);
+                                void* d_scratch, size_t scratch_bytes, hipStream_t stream, int flip = 1);
 hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable& texts, uint32_t* d_report_text,
                                hipStream_t stream);
 size_t encoded_scratch_bytes(uint32_t count);
@@ -2920,6 +2921,11 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
     T.count_min = 0;
     T.count_max = 0xFFFFFFFFu;
     T.max_overhang = 0xFFFFFFFFu;
+    if (!std::isnan(s->alpha)) {  // overhang (the one-pass search of a batch: search_many_pertext)
+      T.use_alpha = 1u;
+      T.alpha = s->alpha;
+      T.max_overhang = s->max_overhang >= 0 ? (uint32_t)std::min<long>(s->max_overhang, 0x7FFFFFFF) : 0xFFFFFFFFu;
+    }
     if (tt) {
       T.texts = *tt;
       T.report_text = s->d_tiled_rtext.p;
@@ -3067,12 +3073,24 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
   return 0;
 }
 
+// Overhang in one pass over a batch of texts in whole blocks (tiled_pertext_kernel): where the texts lie, the virtual
+// columns behind each, the overhang column every text starts from.
+struct TiledPerText {
+  const uint64_t* d_start;
+  const uint64_t* d_len;
+  uint32_t n;
+  uint32_t steps;
+  float alpha;
+  unsigned long long vp;
+  int32_t cost0;
+};
 // The pattern-tiled kernel over one device buffer: every (pattern, end position, cost <= k) into `list` (grown on
 // demand; the counter is the device word d_count).  *ok = false: more than 2^26 of them.  classes: 4 (Dna codes) or
 // 16 (Iupac base sets; 'X' matches nothing).
 static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* buf, uint64_t len, uint32_t k,
                            uint32_t classes, DevBuf<unsigned long long>& d_peq, DevBuf<Candidate>& list, uint32_t* d_count,
-                           uint32_t* count, bool* ok, uint64_t* n_waves, const uint32_t* d_keep_bits = nullptr) {
+                           uint32_t* count, bool* ok, uint64_t* n_waves, const uint32_t* d_keep_bits = nullptr,
+                           const TiledPerText* pt = nullptr) {
   *ok = false;
   *count = 0;
   const size_t npat = e->patterns.size();
@@ -3119,6 +3137,20 @@ static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, co
     P.n_chunks = (span + chunk - 1) / chunk;
   }
   *n_waves = P.n_chunks * P.n_groups;
+  if (pt) {  // a batch of texts, each from its own overhang column to its last virtual column
+    P.skew = 0;
+    P.text_aligned = buf;
+    P.texts_start = pt->d_start;
+    P.texts_len = pt->d_len;
+    P.n_texts = pt->n;
+    P.ov_steps = pt->steps;
+    P.alpha = pt->alpha;
+    P.ov_vp = pt->vp;
+    P.ov_cost0 = pt->cost0;
+    const uint64_t waves_wanted = 32768;
+    P.texts_per_wave = (uint32_t)std::max<uint64_t>(1, ((uint64_t)pt->n * P.n_groups + waves_wanted - 1) / waves_wanted);
+    *n_waves = (((uint64_t)pt->n + P.texts_per_wave - 1) / P.texts_per_wave) * P.n_groups;
+  }
   const uint64_t kMaxList = 1ull << 28;  // 4 GiB of (pattern, position, cost) records: beyond that, per-pattern scans
   uint32_t got = 0;
   for (int attempt = 0;; ++attempt) {
@@ -3129,7 +3161,7 @@ static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, co
     P.cand_count = d_count;
     HIP_TRY(hipMemsetAsync(d_count, 0, 4, st));
     HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
-    hipError_t le = launch_tiled_scan(P, st);
+    hipError_t le = pt ? launch_tiled_pertext(P, st) : launch_tiled_scan(P, st);
     if (le != hipSuccess) return hip_fail(le, "pattern-tiled scan launch");
     HIP_TRY(hipEventRecord(s->ev_multi, st));
     HIP_TRY(hipMemcpyAsync(&got, d_count, 4, hipMemcpyDeviceToHost, st));
@@ -3158,7 +3190,7 @@ static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, co
 static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
                                 const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
                                 sassy_hip_Result* R, bool* done, const TextTable* tt = nullptr,
-                                const HostTexts* ht = nullptr, ManyDefer* defer = nullptr) {
+                                const HostTexts* ht = nullptr, ManyDefer* defer = nullptr, const TiledPerText* pt = nullptr) {
   *done = false;
   const size_t npat = e->patterns.size();
   const uint32_t m = (uint32_t)e->plen;
@@ -3179,7 +3211,7 @@ static int search_encoded_tiled(sassy_SearcherType* s, const sassy_hip_Encoded* 
   uint64_t n_waves = 0;
   bool ok = false;
   if (int rc = tiled_scan_list(s, e, tptr, text_len, k, s->profile == PROFILE_DNA ? 4u : 16u, s->d_tiled_peq, s->d_tiled_list,
-                               s->d_tiled_cnt.p, &count, &ok, &n_waves)) return rc;
+                               s->d_tiled_cnt.p, &count, &ok, &n_waves, nullptr, pt)) return rc;
   if (!ok) return 0;  // *done stays false
   s->stats.text_bytes += text_len;
   s->stats.chunks += n_waves;
@@ -3886,7 +3918,7 @@ static bool many_tiled_wanted(const sassy_SearcherType* s, const size_t* pattern
 // the records through vectors, an append, a loop per strand and a stable sort of 64-byte rows: 35 of the 49 ms of
 // 96 barcodes x 330 000 reads.
 static int assemble_many(sassy_SearcherType* s, const ManyDefer& fwd, const ManyDefer& rcd, uint32_t n_texts,
-                         const uint64_t* d_text_len, uint64_t first_text, sassy_hip_Result* R) {
+                         const uint64_t* d_text_len, uint64_t first_text, sassy_hip_Result* R, bool flip = true) {
   const uint64_t n = (uint64_t)fwd.part.n + rcd.part.n;
   if (n == 0) return 0;
   if (n > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "more than 2^32 records in one result");
@@ -3901,7 +3933,7 @@ static int assemble_many(sassy_SearcherType* s, const ManyDefer& fwd, const Many
   if (int rc = L.d_flags.reserve(4)) return rc;
   HIP_TRY(hipMemsetAsync(L.d_flags.p, 0, 4, st));
   hipError_t le = launch_assemble_many(fwd.part, rcd.part, n_texts, d_text_len, first_text, strb, LO.d_trace.p,
-                                       reinterpret_cast<char*>(LO.d_str.p), L.d_flags.p, L.d_sort.p, L.d_sort.cap, st);
+                                       reinterpret_cast<char*>(LO.d_str.p), L.d_flags.p, L.d_sort.p, L.d_sort.cap, st, flip ? 1 : 0);
   if (le != hipSuccess) return hip_fail(le, "result assembly launch");
   const size_t rows_off = 256, strs_off = (rows_off + n * sizeof(MatchOut) + 255) / 256 * 256;
   const size_t bytes = strs_off + n * strb + 256;
@@ -4145,6 +4177,30 @@ static int search_many_batched(sassy_SearcherType* s, const uint8_t* const* patt
 // its reports with the text index.  There is no prefilter in this mode, so it is used where the
 // separator layout (search_many_batched) cannot be: overhang searches, the Ascii profile, Dna text
 // with other letters, and patterns whose pieces are too short to filter anyway.
+// The overhang column and the virtual columns of a pattern of m rows (reference: src/search.rs:347-356, 1695-1748;
+// f32 arithmetic as there): *steps = 'N' columns behind the text, *vp = the vertical deltas at the text's start (bit j =
+// floor((j+1) alpha) - floor(j alpha) for j < max_overhang, else 1), *cost0 = their sum.
+static void overhang_column(const sassy_SearcherType* s, uint32_t m, uint32_t k, uint32_t* steps, unsigned long long* vp, int32_t* cost0) {
+  uint64_t st = m;
+  if (s->alpha > 0.0f) {
+    const float qf = std::ceil(((float)k + s->alpha) / s->alpha);
+    if (qf < (float)st) st = (uint64_t)qf;
+  }
+  if (s->max_overhang >= 0) st = std::min<uint64_t>(st, (uint64_t)s->max_overhang);
+  *steps = (uint32_t)st;
+  const uint64_t mo = s->max_overhang >= 0 ? (uint64_t)s->max_overhang : UINT64_MAX;
+  unsigned long long bits = 0;
+  int32_t sum = 0;
+  for (uint32_t i = 0; i < m && i < 64; ++i) {
+    uint32_t d = 1;
+    if (i < mo) d = (uint32_t)((uint64_t)std::floor((float)(i + 1) * s->alpha) - (uint64_t)std::floor((float)i * s->alpha));
+    bits |= (unsigned long long)(d & 1u) << i;
+    sum += (int32_t)(d & 1u);
+  }
+  *vp = bits;
+  *cost0 = sum;
+}
+
 static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patterns, const size_t* pattern_lens,
                                size_t n_patterns, const uint8_t* const* texts, const size_t* text_lens, size_t n_texts,
                                size_t k, uint32_t flags, sassy_hip_Result* R, bool& handled) {
@@ -4173,8 +4229,24 @@ static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patt
   const bool wo = (flags & SASSY_HIP_WITHOUT_TRACE) != 0;
   // virtual columns behind a text's end (overhang): at most max_m; padded with 'N' (any other profile
   // never looks at the padding: no end position lies beyond the text)
-  const uint64_t steps = overhang ? max_m : 0;
+  // (+ 2 with overhang: the end positions of two texts -- the last virtual column of one, column 0 of the next -- must not
+  // be neighbours in the one-pass search's list)
+  const uint64_t steps = overhang ? max_m + 2 : 0;
   const uint8_t pad = overhang ? (uint8_t)'N' : (uint8_t)'X';
+  // Overhang, several patterns of one length: ONE pass per strand over the batch (tiled_pertext_kernel: a pattern per
+  // lane, every text from its own overhang column to its last virtual column; reference: the v2 scan takes overhang in
+  // its tiled loop, src/pattern_tiling/search.rs:222-323) instead of one launch per pattern and strand -- 96 barcodes x
+  // both strands were 192 launches.  SASSY_HIP_OVERHANG_TILED=0: as before.
+  bool tiled_ov = false;
+  uint32_t ov_exact = 0;
+  unsigned long long ov_vp = 0;
+  int32_t ov_cost0 = 0;
+  if (overhang && s->profile == PROFILE_IUPAC && n_patterns >= 4 && n_patterns < (1u << 24) && max_m <= 64 && 2 * k + 3 <= 64) {
+    const bool env_off = getenv("SASSY_HIP_OVERHANG_TILED") && atoi(getenv("SASSY_HIP_OVERHANG_TILED")) == 0;  // (per call: tests flip it)
+    tiled_ov = !env_off;
+    for (size_t pi = 0; pi < n_patterns && tiled_ov; ++pi) tiled_ov = pattern_lens[pi] == max_m;
+    if (tiled_ov) overhang_column(s, (uint32_t)max_m, (uint32_t)k, &ov_exact, &ov_vp, &ov_cost0);
+  }
   const uint64_t batch_cap = 1ull << 30;
   uint8_t* hbuf = nullptr;  // the batch in pinned host memory (s->h_stage)
   HostTexts ht;
@@ -4247,6 +4319,58 @@ static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patt
       }
       std::string err;
       g_marks.mark("pertext upload");
+      if (tiled_ov) {
+        const size_t batch_first = R->matches.size(), pool_first = R->pool.size();
+        TextTable tto = tt;
+        tto.per_text = 0;
+        tto.ov_steps = ov_exact;
+        TiledPerText pt{d_tab, d_tab + nt, (uint32_t)nt, ov_exact, s->alpha, ov_vp, ov_cost0};
+        bool ok_all = true;
+        // the whole call is this one batch, traced, every report a record: both strands' records stay on the device and are
+        // put in order there (assemble_many: every text was reversed in its own slot -- no index flip)
+        const bool env_noasm = getenv("SASSY_HIP_MANY_ASSEMBLE") && atoi(getenv("SASSY_HIP_MANY_ASSEMBLE")) == 0;
+        const bool on_device = !env_noasm && !wo && !all && std::isnan(s->max_n_frac) && !s->only_best && t0 == 0 && t1 == n_texts &&
+                               batch_first == 0 && pool_first == 0 && !R->pin.h && (uint64_t)n_patterns < (1ull << 25) &&
+                               (uint64_t)n_texts < (1ull << 31);
+        ManyDefer defer[2];
+        defer[1].lane = 1;
+        for (int strand = 0; strand < (s->rc ? 2 : 1) && ok_all; ++strand) {
+          sassy_hip_Encoded tmp;
+          tmp.profile = s->profile;
+          tmp.rc = false;
+          tmp.plen = max_m;
+          tmp.n_original = n_patterns;
+          for (size_t pi = 0; pi < n_patterns; ++pi) {
+            tmp.patterns.emplace_back(patterns[pi], patterns[pi] + pattern_lens[pi]);
+            if (strand)
+              for (uint8_t& c : tmp.patterns.back()) c = complement_char(s->profile, c);
+          }
+          const size_t first = R->matches.size();
+          bool done = false;
+          if (int rc = search_encoded_tiled(s, &tmp, strand ? s->d_rev.p : s->d_text.p, strand ? nullptr : hbuf, total, (uint32_t)k, all,
+                                            wo, R, &done, &tto, &ht, on_device ? &defer[strand] : nullptr, &pt)) return rc;
+          if (!done) { ok_all = false; break; }
+          for (size_t i = first; i < R->matches.size(); ++i) {
+            sassy_hip_Match& m = R->matches[i];
+            if (strand) {  // reference: src/search.rs:859-873 (each text was reversed in its own slot)
+              const uint64_t len = ht.len[m.text_idx], rs = m.text_start, re = m.text_end;
+              m.strand = 1;
+              m.text_start = len - re;
+              m.text_end = wo ? UINT64_MAX : len - rs;
+            }
+            m.text_idx += t0;
+          }
+        }
+        if (ok_all && on_device)
+          if (int rc = assemble_many(s, defer[0], defer[1], (uint32_t)nt, d_tab + nt, t0, R, false)) return rc;
+        if (ok_all) {
+          g_marks.mark("pertext one pass");
+          t0 = t1;
+          continue;
+        }
+        R->matches.resize(batch_first);  // (more end positions than the list holds: the patterns one by one)
+        R->pool.resize(pool_first);
+      }
       ScanQueue queue(s, [&](uint64_t tag, ScanOut& so, const PatternPlan& plan, const uint8_t* pat) -> int {
         const size_t pi = (size_t)(tag >> 1);
         const bool is_rc = (tag & 1) != 0;

@@ -146,13 +146,15 @@ __global__ __launch_bounds__(256) void assign_texts_kernel(Candidate* __restrict
 // (host.hip: assemble_many).  The result order is the one a stable sort by (pattern, text) of [forward records, Rc
 // records] gives; the Rc pass saw the batch reversed: text r of its buffer is text n_texts - 1 - r, and its
 // coordinates count from the text's end (src/search.rs:859-873).
-__global__ __launch_bounds__(256) void many_keys_kernel(const ManyPart a, const ManyPart b, uint32_t n_texts,
+// (flip: the Rc pass saw the batch reversed AS A WHOLE -- its text r is text n_texts - 1 - r; else every text was reversed
+// in its own slot: the per-text layout of the overhang searches)
+__global__ __launch_bounds__(256) void many_keys_kernel(const ManyPart a, const ManyPart b, uint32_t n_texts, int flip,
                                                         unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n + b.n) return;
   const bool rc = i >= a.n;
   const MatchOut* row = rc ? b.rows + (i - a.n) : a.rows + i;
-  const unsigned long long text = rc ? (unsigned long long)(n_texts - 1) - row->text_idx : row->text_idx;
+  const unsigned long long text = (rc && flip) ? (unsigned long long)(n_texts - 1) - row->text_idx : row->text_idx;
   keys[i] = (row->pattern_idx << 33) | (text << 1) | (rc ? 1ull : 0ull);
   idx[i] = i;
 }
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void many_keys_kernel(const ManyPart a, const 
 // record j of the result = record idx[j] of the passes, with its final text index, strand and coordinates; its
 // cigar string moves to slot j of the result's pool.  16 lanes per record: the 64 bytes of the row and the string
 // slot travel as 16-byte pieces.
-__global__ __launch_bounds__(256) void many_rows_kernel(const ManyPart a, const ManyPart b, uint32_t n_texts,
+__global__ __launch_bounds__(256) void many_rows_kernel(const ManyPart a, const ManyPart b, uint32_t n_texts, int flip,
                                                         const uint64_t* __restrict__ text_len, uint64_t first_text,
                                                         const uint32_t* __restrict__ idx, uint32_t str_stride,
                                                         MatchOut* __restrict__ out_rows, char* __restrict__ out_strs,
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(256) void many_rows_kernel(const ManyPart a, const 
     MatchOut r = *src;
     if (r.pad_[0] == kTraceFailed) atomicOr(flags, 1u);
     if (rc) {
-      const uint64_t tx = (uint64_t)(n_texts - 1) - r.text_idx;
+      const uint64_t tx = flip ? (uint64_t)(n_texts - 1) - r.text_idx : r.text_idx;
       const uint64_t len = text_len[tx], rs = r.text_start, re = r.text_end;
       r.text_idx = tx;
       r.text_start = len - re;
@@ -423,7 +425,7 @@ size_t many_scratch_bytes(uint32_t count) {
 }
 hipError_t launch_assemble_many(const ManyPart& a, const ManyPart& b, uint32_t n_texts, const uint64_t* d_text_len,
                                 uint64_t first_text, uint32_t str_stride, MatchOut* d_rows, char* d_strs, uint32_t* d_flags,
-                                void* d_scratch, size_t scratch_bytes, hipStream_t stream) {
+                                void* d_scratch, size_t scratch_bytes, hipStream_t stream, int flip) {
   const uint32_t count = a.n + b.n;
   if (count == 0) return hipSuccess;
   const size_t kb = ((size_t)count * 8 + 255) / 256 * 256, ib = ((size_t)count * 4 + 255) / 256 * 256;
@@ -435,12 +437,12 @@ hipError_t launch_assemble_many(const ManyPart& a, const ManyPart& b, uint32_t n
   uint32_t* idx_out = reinterpret_cast<uint32_t*>(base + 2 * kb + ib);
   void* temp = base + 2 * kb + 2 * ib;
   size_t temp_bytes = scratch_bytes - (2 * kb + 2 * ib);
-  hipLaunchKernelGGL(many_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, a, b, n_texts, keys_in, idx_in);
+  hipLaunchKernelGGL(many_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, a, b, n_texts, flip, keys_in, idx_in);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, idx_in, idx_out, (size_t)count, 0, 58, stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(many_rows_kernel, dim3((uint32_t)(((uint64_t)count * 16 + 255) / 256)), dim3(256), 0, stream, a, b, n_texts,
+  hipLaunchKernelGGL(many_rows_kernel, dim3((uint32_t)(((uint64_t)count * 16 + 255) / 256)), dim3(256), 0, stream, a, b, n_texts, flip,
                      d_text_len, first_text, idx_out, str_stride, d_rows, d_strs, d_flags);
   return hipGetLastError();
 }

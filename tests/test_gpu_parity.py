@@ -712,6 +712,90 @@ def test_overhang(sassy, kats):
         assert_same(got, want), (it, m, k, alpha, mo, n)
 
 
+def test_overhang_many_patterns_in_one_pass(sassy):
+    """search_many with an overhang searcher and several patterns of one length: one pass per strand over the batch
+    (tiled_pertext_kernel: every text from its own overhang column to its last virtual column; the reference's v2 scan takes
+    overhang in its tiled loop, src/pattern_tiling/search.rs:222-323) -- against oracle.search_overhang pair by pair and
+    against the launch-per-pattern path (SASSY_HIP_OVERHANG_TILED=0): barcodes hanging over read starts and ends, texts
+    shorter than a pattern, empty texts, lengths around the block size, alpha in {0, 0.25, 0.5, 1}, max_overhang, both
+    strands, search_all, without_trace; then the reference's own overhang vectors, each as a batch of texts."""
+    import os
+    rng = random.Random(616)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for it in range(14):
+        m = rng.choice([8, 16, 24, 24, 32, 40, 64])
+        k = rng.randrange(0, min(5, m // 3) + 1)
+        alpha = rng.choice([0.0, 0.25, 0.5, 0.5, 1.0])
+        mo = rng.choice([None, None, 0, 3, m // 2])
+        npat = rng.choice([4, 7, 70])
+        pats = []
+        for _ in range(npat):
+            p_ = bytearray(rand_seq(rng, m))
+            if rng.random() < 0.3:
+                p_[rng.randrange(m)] = rng.choice(b"NRYW")
+            pats.append(bytes(p_))
+        texts = []
+        for _ in range(rng.choice([3, 40, 300])):
+            n = rng.choice([0, 1, 5, m - 1, m, 62, 63, 64, 65, 127, 128, 129, 300, 1000])
+            t = bytearray(rng.choice(b"ACGTN") if rng.random() < 0.03 else rng.choice(b"ACGT") for _ in range(n))
+            if n:
+                plain = bytes(c if c in b"ACGT" else 65 for c in rng.choice(pats))
+                if rng.random() < 0.5:
+                    plain = plain.translate(comp)[::-1]
+                cut = rng.randrange(1, m)
+                head = mutate(rng, plain, rng.randrange(0, 2))[cut:][:n]
+                if rng.random() < 0.6:
+                    t[:len(head)] = head
+                cut = rng.randrange(1, m)
+                tail = mutate(rng, plain, rng.randrange(0, 2))[:cut][-n:]
+                if rng.random() < 0.6:
+                    t[n - len(tail):] = tail
+                if n > 3 * m and rng.random() < 0.7:
+                    mid = mutate(rng, plain, rng.randrange(0, k + 1))
+                    at = rng.randrange(m, n - 2 * m)
+                    t[at:at + len(mid)] = mid
+            texts.append(bytes(t))
+        rc, allm = bool(it & 1), it % 5 == 4
+        want = []
+        for pi, p_ in enumerate(pats):
+            for ti, t in enumerate(texts):
+                for x in oracle.search_overhang("iupac", p_, t, k, alpha, rc=rc, all_minima=allm, max_overhang=mo):
+                    want.append((pi, ti) + key(x)[1:])
+        keyf = lambda x: (x.pattern_idx, x.text_idx) + key(x)[1:]
+        res = {}
+        for env in ("1", "0"):
+            os.environ["SASSY_HIP_OVERHANG_TILED"] = env
+            s = sassy.Searcher("iupac", rc=rc, alpha=alpha).with_max_overhang(mo)
+            got = s.search_many(pats, texts, k, all_minima=allm)
+            res[env] = [keyf(x) for x in got]
+            assert sorted(res[env]) == sorted(want), (it, env, m, k, alpha, mo, npat, len(texts), rc, allm, len(got), len(want))
+            if env == "1" and len(texts) >= 2:
+                assert s.stats()["filtered"] == 5, s.stats()   # the pattern-tiled scan took the batch
+        os.environ.pop("SASSY_HIP_OVERHANG_TILED")
+        # pattern-major, text by text, the forward strand's records in front of the Rc strand's -- as the other path orders them
+        assert [x[:2] for x in res["1"]] == [x[:2] for x in res["0"]], (it,)
+    # the reference's overhang vectors: each text between decoys, four copies of the pattern (a batch the one pass takes)
+    for e in kats_overhang():
+        pat, text = e["pattern"].encode(), e["text"].encode()
+        if len(pat) > 64:
+            continue
+        s = sassy.Searcher(e["profile"], rc=e["rc"], alpha=e["alpha"])
+        texts = [b"ACGTACGTAC", text, b"", text[::-1], text]
+        got = s.search_many([pat] * 4, texts, e["k"], all_minima=e["mode"] == "search_all")
+        want = []
+        for pi in range(4):
+            for ti, t in enumerate(texts):
+                for x in oracle.search_overhang(e["profile"], pat, t, e["k"], e["alpha"], rc=e["rc"], all_minima=e["mode"] == "search_all"):
+                    want.append((pi, ti) + key(x)[1:])
+        assert sorted((x.pattern_idx, x.text_idx) + key(x)[1:] for x in got) == sorted(want), e["id"]
+
+
+def kats_overhang():
+    import json
+    root = os.path.dirname(os.path.abspath(__file__))
+    return [e for e in json.load(open(os.path.join(root, "golden", "kats.json")))["overhang"] if "max_n_frac" not in e]
+
+
 def test_encoded_many_patterns(sassy):
     """search_encoded_patterns with many plain-ACGT patterns on an Iupac searcher (BASELINE config 4
     shape): on plain-ACGT text the scans run with the Dna kernels, on text with other letters with the
