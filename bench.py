@@ -683,9 +683,28 @@ def h2d_inclusive(sassy_amd, profile, pat, host_text, k, want_matches):
             times.append(dt)
     L.sassy_searcher_free(s)
     best = min(times)
+    # the link's own ceiling on this box, measured the same minute: one hipMemcpy of 1 GiB from PINNED host memory
+    link = None
+    try:
+        import torch
+        nb = min(n, 1 << 30)
+        src = torch.empty(nb, dtype=torch.uint8, pin_memory=True)
+        dst = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize()
+        link = round(3 * nb / (time.perf_counter() - t0) / 1e9, 2)
+        del src, dst
+    except Exception:  # noqa: BLE001 -- the ceiling is context, never a reason to lose the bench line
+        link = None
     return {"value": round(n / best / 1e9, 2), "unit": "GB/s", "ms_per_search": round(best * 1e3, 2),
             "what": "drop-in search() of include/sassy.h on a host text (pageable numpy memory): upload over PCIe + "
                     "scan + matches, best of 2 calls after one untimed call; never the headline value",
+            "link_ceiling_GB_per_s": link,
+            "link_ceiling_what": "hipMemcpy host -> device of 1 GiB from pinned memory on this box (one PCIe link), three copies back to back",
             "matches": int(cnt), "matches_equal_resident": int(cnt) == int(want_matches)}
 
 

@@ -316,6 +316,16 @@ def many_case(rng, searchers):
         os.environ.pop("SASSY_HIP_MANY_SEEDED", None)
     else:
         os.environ["SASSY_HIP_MANY_SEEDED"] = seed
+    # overhang (Iupac): every text gets its own overhang column and virtual columns -- several patterns of one length go
+    # through one pass per strand (tiled_pertext_kernel), else a launch per pattern
+    alpha = None
+    if profile == "iupac" and rng.random() < 0.35:
+        alpha = rng.choice([0.0, 0.25, 0.5, 0.5, 1.0])
+        mo = rng.choice([None, None, 0, 3])
+        if same and rng.random() < 0.7:
+            pats = pats + [rand_seq(rng, m_same, b"ACGT") for _ in range(rng.choice([3, 5, 66]))]
+            npat = len(pats)
+        s = sassy_amd.Searcher(profile, rc=rc, alpha=alpha).with_max_overhang(mo)
     got = s.search_many(pats, texts, k, all_minima=allm)
     os.environ.pop("SASSY_HIP_MANY_TILED", None)
     os.environ.pop("SASSY_HIP_MANY_SEEDED", None)
@@ -324,9 +334,11 @@ def many_case(rng, searchers):
     wk = []
     for pi, p in enumerate(pats):
         for ti, t in enumerate(texts):
-            for m in oracle.search(profile, p, t, k, rc=rc, all_minima=allm):
+            ms_ = oracle.search(profile, p, t, k, rc=rc, all_minima=allm) if alpha is None else \
+                oracle.search_overhang(profile, p, t, k, alpha, rc=rc, all_minima=allm, max_overhang=mo)
+            for m in ms_:
                 wk.append((pi, ti, m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, m.strand, m.cigar))
-    desc = dict(mode="many", profile=profile, k=k, rc=rc, all_minima=allm, npat=npat, ntext=len(texts), tiled=force,
+    desc = dict(mode="many", profile=profile, k=k, rc=rc, all_minima=allm, npat=npat, ntext=len(texts), tiled=force, alpha=alpha,
                 filtered=s.stats()["filtered"], matches=len(wk))
     return sorted(gk) == sorted(wk), desc, b"|".join(pats), b"|".join(texts), gk, wk
 

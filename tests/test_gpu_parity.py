@@ -2551,9 +2551,10 @@ def _pair_variants(rng, pat, k):
     return out
 
 
-def _env_allows_pairing():
+def _env_allows_pairing(profile="dna"):
     e = os.environ
-    return _env_allows_fusing() and e.get("SASSY_HIP_PAIR", "1") != "0" and e.get("SASSY_HIP_PREFILTER", "-1") == "-1"
+    return _env_allows_fusing() and e.get("SASSY_HIP_PAIR", "1") != "0" and e.get("SASSY_HIP_PREFILTER", "-1") == "-1" and \
+        not (profile == "iupac" and e.get("SASSY_HIP_IUPAC_PLANES", "1") == "0")
 
 
 @pytest.mark.parametrize("profile", ["dna", "iupac"])
@@ -2610,7 +2611,7 @@ def test_paired_filter_against_oracle(sassy, profile):
         for n in (0, 1, Q, 2 * Q + 1, m - k, m, m + k, 63, 64, 65, 129):
             text = (pat * 3)[:n] if n % 2 else rand_seq(rng, n)
             assert_same(s.search(pat, text, k), oracle.search(profile, pat, text, k), ("pair tiny", m, k, n))
-    if _env_allows_pairing():
+    if _env_allows_pairing(profile):
         assert ran >= 3 * (len(_PAIR_SHAPES) - (5 if profile == "iupac" else 0)) - 2, ran
     # a low-complexity pattern on a text of its own units: sub-piece occurrences everywhere, every sibling passes
     for unit, m, k in ((b"AC", 23, 3), (b"A", 32, 4), (b"ACG", 32, 5), (b"AAC", 23, 3)):
@@ -2652,7 +2653,7 @@ def test_paired_filter_against_oracle(sassy, profile):
         h = 0 if a == 0 else halo
         allm.append(s.search_shard(pat, buf.ptr + a - h, h, b - a, a, n, k))
     assert_same(sassy.merge_shards(allm, 1).matches, want, "pair shards")
-    assert s.stats()["pair"] == 2 or not _env_allows_pairing()
+    assert s.stats()["pair"] == 2 or not _env_allows_pairing(profile)
     t1 = s.search_shard_begin(pat, buf.ptr, 0, n, 0, n, k)
     t2 = s.search_shard_begin(pat, buf.ptr, 0, n, 0, n, k - 1)
     assert_same(s.search_finish(t2).matches, oracle.search(profile, pat, text, k - 1), "pair in flight k-1")
