@@ -28,6 +28,10 @@ struct RawSearcher {
     _p: [u8; 0],
 }
 #[repr(C)]
+struct RawMultiTicket {
+    _p: [u8; 0],
+}
+#[repr(C)]
 struct RawResult {
     _p: [u8; 0],
 }
@@ -72,6 +76,11 @@ extern "C" {
     fn sassy_hip_multi_search(m: *mut RawMulti, pattern: *const u8, pattern_len: usize, k: usize, flags: u32,
                               out: *mut *mut RawResult) -> c_int;
     fn sassy_hip_multi_free(m: *mut RawMulti);
+    // searches in flight over several devices (include/sassy_hip.h)
+    fn sassy_hip_multi_set_pipe_depth(m: *mut RawMulti, depth: c_int) -> c_int;
+    fn sassy_hip_multi_search_begin(m: *mut RawMulti, pattern: *const u8, pattern_len: usize, k: usize, flags: u32,
+                                    out: *mut *mut RawMultiTicket) -> c_int;
+    fn sassy_hip_multi_search_finish(m: *mut RawMulti, ticket: *mut RawMultiTicket, out: *mut *mut RawResult) -> c_int;
 }
 
 #[repr(C)]
