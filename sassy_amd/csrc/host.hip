@@ -94,6 +94,9 @@ hipError_t launch_assemble_many(const ManyPart& a, const ManyPart& b, uint32_t n
                                 void* d_scratch, size_t scratch_bytes, hipStream_t stream, int flip = 1);
 hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable& texts, uint32_t* d_report_text,
                                hipStream_t stream);
+size_t compact_scratch_bytes(uint32_t max_count, uint32_t str_stride);
+hipError_t launch_compact_cigars(MatchOut* d_rows, const char* d_strs, uint32_t max_count, const uint32_t* d_count, uint32_t str_stride,
+                                 uint32_t* d_total, void* d_scratch, size_t scratch_bytes, const char** d_out_strs, hipStream_t stream);
 size_t encoded_scratch_bytes(uint32_t count);
 hipError_t launch_assemble_encoded(const MatchOut* d_rows_in, const char* d_strs_in, uint32_t count, uint64_t n_original, uint32_t str_stride,
                                    int key_bits, MatchOut* d_rows, char* d_strs, uint32_t* d_flags, void* d_scratch, size_t scratch_bytes,
@@ -262,7 +265,7 @@ struct ScanLane {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_f = nullptr, ev_filter_done = nullptr;
-  DevBuf<uint8_t> d_state, d_scratch, d_str, d_ctl, d_sort;
+  DevBuf<uint8_t> d_state, d_scratch, d_str, d_ctl, d_sort, d_scratch2;
   DevBuf<uint32_t> d_flags;     // dense results: "does any record need the host's attention" (report_flags_kernel)
   DevBuf<Candidate> d_cand, d_sorted;
   DevBuf<MatchOut> d_trace;
@@ -406,7 +409,7 @@ struct ScanLane {
   void destroy() {
     if (h_up) (void)hipHostFree(h_up);
     h_up = nullptr; h_up_cap = h_up_used = 0;
-    d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release(); d_sort.release(); d_flags.release();
+    d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release(); d_sort.release(); d_scratch2.release(); d_flags.release();
     for (unsigned char*& b : h_bulk) { if (b) (void)hipHostFree(b); b = nullptr; }
     d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release();
     d_pattern.release(); d_table.release(); d_rowoff.release(); d_ovtab.release(); d_stash.release();
@@ -1273,8 +1276,16 @@ int ScanJob::prepare() {
     if ((stride / 4) % 2 == 0) stride += 4;  // odd number of LDS words: conflict-free slices
     if (stride > 0xFFFFFFFFull) return fail(SASSY_HIP_EUNSUPPORTED, "pattern/k too large for the traceback band");
     if (use_thread) {
+      // Threads of the thread-per-report launch.  With the slices in LDS (64 per workgroup) as many workgroups as the chip
+      // holds at once -- a dense result (10^5 .. 10^6 reports) is bound by how many reports are in flight: 16 384 threads
+      // were one wave on a quarter of the SIMDs, 2.3 ms for 743 000 reports.  Slices in global memory: 256 MB of them.
+      static const int env_tt = getenv("SASSY_HIP_TRACE_THREADS") ? atoi(getenv("SASSY_HIP_TRACE_THREADS")) : 0;
+      const bool slices_in_lds = 64 * stride + pat_bytes <= kTraceLdsLimit;
       uint64_t nthreads = (256ull << 20) / stride;
-      nthreads = std::max<uint64_t>(64, std::min<uint64_t>(16384, nthreads)) / 64 * 64;
+      uint64_t cap_threads = 16384;
+      if (slices_in_lds) cap_threads = std::min<uint64_t>(256ull * 64ull * std::max<uint64_t>(1, (160ull * 1024) / (64 * stride + pat_bytes)), 131072);
+      if (env_tt >= 64) cap_threads = (uint64_t)env_tt;
+      nthreads = std::max<uint64_t>(64, std::min<uint64_t>(cap_threads, slices_in_lds ? cap_threads : nthreads)) / 64 * 64;
       trace_blocks = (uint32_t)(nthreads / 64);
       if (64 * stride + pat_bytes > kTraceLdsLimit)  // slices in global memory
         if (int rc = L.d_scratch.reserve(nthreads * stride)) return rc;
@@ -1714,7 +1725,7 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
   if (empty) return 0;
   bool sorted_on_device = false;
   bool big = false;  // the result's rows and strings lie in the lane's pinned block at these offsets (dense results)
-  size_t big_rows_off = 0, big_strs_off = 0, big_cands_off = 0;
+  size_t big_rows_off = 0, big_strs_off = 0, big_cands_off = 0, big_pool_bytes = 0;
   const Candidate* big_list = nullptr;  // ... and the (sorted, deduplicated) reports they belong to on the device
   for (int attempt = 0;; ++attempt) {
     // the only synchronisation of the call; the kernels have written the results into h_pin
@@ -1850,10 +1861,25 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
         le = launch_trace(Tall, use_thread ? trace_blocks : wave_blocks, L.stream);
         if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
         if (big) {
+          // the strings without their slots' padding (SASSY_HIP_COMPACT_CIGARS=0: the slots as they are)
+          static const bool env_nocompact = getenv("SASSY_HIP_COMPACT_CIGARS") && atoi(getenv("SASSY_HIP_COMPACT_CIGARS")) == 0;
+          const char* d_pool = reinterpret_cast<const char*>(L.d_str.p);
+          big_pool_bytes = (size_t)counts[0] * T.str_stride;
+          if (!env_nocompact) {
+            if (int rc = L.d_scratch2.reserve(compact_scratch_bytes(counts[0], T.str_stride))) return rc;
+            HIP_TRY(hipMemsetAsync(L.d_flags.p + 1, 0, 4, L.stream));
+            le = launch_compact_cigars(L.d_trace.p, reinterpret_cast<const char*>(L.d_str.p), counts[0], d_counts, T.str_stride, L.d_flags.p + 1,
+                                       L.d_scratch2.p, L.d_scratch2.cap, &d_pool, L.stream);
+            if (le != hipSuccess) return hip_fail(le, "cigar compaction launch");
+            uint32_t total = 0;
+            HIP_TRY(hipMemcpyAsync(&total, L.d_flags.p + 1, 4, hipMemcpyDeviceToHost, L.stream));
+            HIP_TRY(hipStreamSynchronize(L.stream));
+            big_pool_bytes = total;
+          }
           HIP_TRY(hipMemcpyAsync(L.h_pin + kPinFlags2, L.d_flags.p, 4, hipMemcpyDeviceToHost, L.stream));
           HIP_TRY(hipMemcpyAsync(L.h_pin + kPinCount2, d_counts, 4, hipMemcpyDeviceToHost, L.stream));
           HIP_TRY(hipMemcpyAsync(L.h_pin + big_rows_off, L.d_trace.p, (size_t)counts[0] * sizeof(MatchOut), hipMemcpyDeviceToHost, L.stream));
-          HIP_TRY(hipMemcpyAsync(L.h_pin + big_strs_off, L.d_str.p, (size_t)counts[0] * T.str_stride, hipMemcpyDeviceToHost, L.stream));
+          if (big_pool_bytes) HIP_TRY(hipMemcpyAsync(L.h_pin + big_strs_off, d_pool, big_pool_bytes, hipMemcpyDeviceToHost, L.stream));
           if (!sh.adopt_ok)  // (a caller that edits the list wants the reports themselves as well)
             HIP_TRY(hipMemcpyAsync(L.h_pin + big_cands_off, big_list, (size_t)counts[0] * sizeof(Candidate), hipMemcpyDeviceToHost, L.stream));
         }
@@ -1914,7 +1940,7 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
     out.ext_matches = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + (big ? big_rows_off : pin_recs));
     out.ext_n = count;
     out.ext_pool = reinterpret_cast<const char*>(L.h_pin + (big ? big_strs_off : pin_ops));
-    out.ext_pool_len = (size_t)count * T.str_stride;
+    out.ext_pool_len = big ? big_pool_bytes : (size_t)count * T.str_stride;
   } else if (big) {
     // (host -> host copies out of the pinned block; the reports themselves came along unless the caller was expected to adopt)
     out.cands.resize(count);
@@ -1922,7 +1948,7 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
     else if (int rc = L.download(out.cands.data(), big_list, (size_t)count * sizeof(Candidate))) return rc;
     const sassy_hip_Match* hm = reinterpret_cast<const sassy_hip_Match*>(L.h_pin + big_rows_off);
     out.matches.assign(hm, hm + count);
-    out.pool.assign(reinterpret_cast<const char*>(L.h_pin + big_strs_off), (size_t)count * T.str_stride);
+    out.pool.assign(reinterpret_cast<const char*>(L.h_pin + big_strs_off), big_pool_bytes);
   } else if (count) {
     // (after a device sort the staging area's head holds the unsorted list's records: take everything from the device)
     const uint32_t have = sorted_on_device ? 0u : std::min<uint32_t>(count, kSpec);

@@ -415,6 +415,64 @@ hipError_t launch_assemble_encoded(const MatchOut* d_rows_in, const char* d_strs
   return hipGetLastError();
 }
 
+// ---- host.hip: ScanJob::finish, dense results of one pattern ----
+// The cigar strings of rows[0 .. *count_ptr) out of their slots (str_stride bytes each: 2 (m + k + 1) + 2 rounded up, a
+// dozen of them used) into one pool without the padding; the rows learn their new offsets; total[0] = the pool's bytes.
+// A dense result's strings were 60 of the 108 MB that crossed the PCIe link for 743 000 matches.
+namespace {
+__global__ __launch_bounds__(256) void cigar_lens_kernel(const MatchOut* __restrict__ rows, uint32_t max_count,
+                                                         const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ lens) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= max_count) return;
+  lens[i] = i < *count_ptr ? rows[i].cigar_len + 1u : 0u;
+}
+__global__ __launch_bounds__(256) void cigar_compact_kernel(MatchOut* __restrict__ rows, const char* __restrict__ strs, uint32_t max_count,
+                                                            const uint32_t* __restrict__ count_ptr, uint32_t str_stride,
+                                                            const uint32_t* __restrict__ offs, char* __restrict__ out_strs,
+                                                            uint32_t* __restrict__ total) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t i = t >> 2, part = t & 3u;
+  const uint32_t n = *count_ptr < max_count ? *count_ptr : max_count;
+  if (i >= n) return;
+  const uint32_t len = rows[i].cigar_len + 1u, off = offs[i];
+  const char* sstr = strs + (size_t)i * str_stride;
+  for (uint32_t y = part; y < len; y += 4u) out_strs[(size_t)off + y] = y + 1u < len ? sstr[y] : '\0';
+  if (part == 0) {
+    // (the other lanes of the record read cigar_len only: the offset is the row's last word to change)
+    rows[i].cigar_off = off;
+    if (i + 1 == n) total[0] = off + len;
+  }
+}
+}  // namespace
+size_t compact_scratch_bytes(uint32_t max_count, uint32_t str_stride) {
+  size_t t = 0;
+  (void)rocprim::exclusive_scan(nullptr, t, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), 0u, (size_t)max_count,
+                                rocprim::plus<uint32_t>(), hipStream_t(nullptr));
+  return 2 * (((size_t)max_count * 4 + 255) / 256 * 256) + ((size_t)max_count * str_stride + 255) / 256 * 256 + t + 256;
+}
+// *d_out_strs = where the compacted pool lies inside the scratch area
+hipError_t launch_compact_cigars(MatchOut* d_rows, const char* d_strs, uint32_t max_count, const uint32_t* d_count, uint32_t str_stride,
+                                 uint32_t* d_total, void* d_scratch, size_t scratch_bytes, const char** d_out_strs, hipStream_t stream) {
+  if (max_count == 0) return hipSuccess;
+  const size_t ib = ((size_t)max_count * 4 + 255) / 256 * 256, sb = ((size_t)max_count * str_stride + 255) / 256 * 256;
+  if (scratch_bytes < 2 * ib + sb) return hipErrorInvalidValue;
+  unsigned char* base = static_cast<unsigned char*>(d_scratch);
+  uint32_t* lens = reinterpret_cast<uint32_t*>(base);
+  uint32_t* offs = reinterpret_cast<uint32_t*>(base + ib);
+  char* out = reinterpret_cast<char*>(base + 2 * ib);
+  void* temp = base + 2 * ib + sb;
+  size_t temp_bytes = scratch_bytes - (2 * ib + sb);
+  hipLaunchKernelGGL(cigar_lens_kernel, dim3((max_count + 255) / 256), dim3(256), 0, stream, d_rows, max_count, d_count, lens);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = rocprim::exclusive_scan(temp, temp_bytes, lens, offs, 0u, (size_t)max_count, rocprim::plus<uint32_t>(), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(cigar_compact_kernel, dim3((uint32_t)(((uint64_t)max_count * 4 + 255) / 256)), dim3(256), 0, stream, d_rows, d_strs,
+                     max_count, d_count, str_stride, offs, out, d_total);
+  *d_out_strs = out;
+  return hipGetLastError();
+}
+
 // ---- host.hip: assemble_many ----
 size_t many_scratch_bytes(uint32_t count) {
   size_t temp = 0;
