@@ -2957,7 +2957,26 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
       T.report_text = s->d_tiled_rtext.p;
     }
     HIP_TRY(hipEventRecord(s->ev_a_multi(), st));
-    le = launch_trace(T, (uint32_t)std::min<uint64_t>(1024, ((uint64_t)n_rep + 3) / 4), st);
+    uint32_t trace_grid = (uint32_t)std::min<uint64_t>(1024, ((uint64_t)n_rep + 3) / 4);
+    {
+      // Dense lists (a guide set on a genome: 10^7 reports) with a narrow band (k <= 6: the band row in registers): a
+      // thread per report, as many workgroups as the chip holds -- 0.7 ns per report against the wavefront shape's 2.3.
+      // (SASSY_HIP_ENCODED_TRACE_THREADS=0: never; =<n>: from n reports on -- read per call: tests flip it)
+      const int env_tt = getenv("SASSY_HIP_ENCODED_TRACE_THREADS") ? atoi(getenv("SASSY_HIP_ENCODED_TRACE_THREADS")) : -1;
+      const bool env_off = env_tt == 0;
+      const uint32_t from = env_tt > 0 ? (uint32_t)env_tt : 65536u;
+      uint64_t stride_t = band + win + opsb + strb;
+      if ((stride_t / 4) % 2 == 0) stride_t += 4;  // odd number of LDS words: conflict-free slices
+      const uint64_t pat_bytes = ((uint64_t)m + 15) / 16 * 16;
+      if (!env_off && k <= 6 && !T.use_alpha && n_rep >= from && 64 * stride_t + pat_bytes <= kTraceLdsLimit) {
+        T.wave_mode = 0;
+        T.scratch = nullptr;
+        T.scratch_stride = (uint32_t)stride_t;
+        const uint64_t nthreads = std::min<uint64_t>(256ull * 64ull * std::max<uint64_t>(1, (160ull * 1024) / (64 * stride_t + pat_bytes)), 131072);
+        trace_grid = (uint32_t)(nthreads / 64);
+      }
+    }
+    le = launch_trace(T, trace_grid, st);
     if (le != hipSuccess) return hip_fail(le, "trace kernel launch");
     HIP_TRY(hipEventRecord(s->ev_multi, st));
     if (defer) {

@@ -169,16 +169,20 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
   // block-shared pattern copy behind the 64 slices (LDS mode)
   unsigned char* spat = trace_smem + (size_t)64 * P.scratch_stride;
   const CharRule rule = char_rule(P.profile);
-  if (IN_LDS) {
+  // (pattern_stride != 0: many patterns -- a report brings its own, named in its flags' upper bits; the threads of a
+  // workgroup then read their rows from the patterns' array, a few KB that stay in L1 / L2)
+  const bool many = P.pattern_stride != 0;
+  if (IN_LDS && !many) {
     for (uint32_t x = tid; x < P.m; x += 64) {
       const uint32_t ch = P.pattern[x];
       spat[x] = (unsigned char)(rule.iupac ? kIupacCode[ch & 31u] : ch);
     }
     __syncthreads();
   }
+  const uint8_t* my_pat = P.pattern;
   auto pat_at = [&](int j) -> uint32_t {
-    if (IN_LDS) return spat[j];
-    const uint32_t ch = P.pattern[j];
+    if (IN_LDS && !many) return spat[j];
+    const uint32_t ch = my_pat[j];
     return rule.iupac ? kIupacCode[ch & 31u] : ch;
   };
   unsigned char* slice = IN_LDS ? trace_smem + (size_t)tid * P.scratch_stride
@@ -189,8 +193,13 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
 
   for (uint32_t c = blockIdx.x * 64 + tid; c < count; c += gridDim.x * 64) {
     const Candidate cd = P.cand[c];
-    const Window W = report_window(P, cd);
+    const Window W = report_window(P, cd, c);
     if (W.skip) continue;
+    uint32_t pattern_idx = 0;
+    if (many) {
+      pattern_idx = cd.flags >> kCandTextShift;
+      my_pat = P.pattern + (size_t)pattern_idx * P.pattern_stride;
+    }
     const uint64_t o = W.o, we = W.we;                     // global window bounds
     const int wl = (int)(we - o);
     // Rc strand without a reversed copy: the window [o, o + wl) of the reversed text is the forward
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(64) void trace_kernel(const TraceParams P) {
     // ---- cigar text and the finished row, to the device arrays and (head of the list) the host ----
     unsigned char* sbuf = ops + P.ops_bytes;
     const uint32_t w = rle_text(ops, nops, ok, sbuf);
-    const MatchOut r = make_row(P, c, W, o + (uint64_t)i, cost, w, ok, pattern_start, pattern_end);
+    const MatchOut r = make_row(P, c, W, o + (uint64_t)i, cost, w, ok, pattern_start, pattern_end, pattern_idx);
     const uint32_t ndw = w / 4 + 1;
     uint32_t* dstr = reinterpret_cast<uint32_t*>(P.out_str + (uint64_t)c * P.str_stride);
     const uint32_t* ssrc = reinterpret_cast<const uint32_t*>(sbuf);

@@ -1130,15 +1130,18 @@ def test_encoded_dense_results_leave_in_a_pinned_block(sassy):
             assert len(want) >= 1100, len(want)
             for env in ({"SASSY_HIP_SEEDED": "1"}, {"SASSY_HIP_SEEDED": "0", "SASSY_HIP_TILED": "1"}):
                 res = []
-                for pin in ("1", "0"):
+                for pin in ("1", "0", "threads"):
                     os.environ.update(env)
-                    os.environ["SASSY_HIP_ENCODED_PIN"] = pin
+                    os.environ["SASSY_HIP_ENCODED_PIN"] = "1" if pin == "threads" else pin
+                    if pin == "threads":  # the thread-per-report traceback (dense lists: from 65 536 reports on) with a pattern per report
+                        os.environ["SASSY_HIP_ENCODED_TRACE_THREADS"] = "512"
                     s = sassy.Searcher(profile, rc=rc)
                     r = s.search_encoded_patterns(s.encode_patterns(pats), tb, k, as_result=True)
-                    for k_ in list(env) + ["SASSY_HIP_ENCODED_PIN"]:
-                        os.environ.pop(k_)
+                    for k_ in list(env) + ["SASSY_HIP_ENCODED_PIN", "SASSY_HIP_ENCODED_TRACE_THREADS"]:
+                        os.environ.pop(k_, None)
                     res.append(r)
-                a, b = res
+                a, b, c = res
+                assert canon(a) == canon(c), (profile, rc, env, "thread-per-report traceback")
                 assert len(a) == len(b) == len(want), (profile, rc, env, len(a), len(b), len(want))
                 # the same records in the same order (the strings' places in the two pools differ: compared per record)
                 for f in a.array.dtype.names:
