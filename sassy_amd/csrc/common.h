@@ -238,6 +238,7 @@ struct TiledParams {
   float alpha;
   unsigned long long ov_vp;
   int32_t ov_cost0;
+  uint32_t edge_cols;             // != 0: only the end positions overhang changes (see tiled_pertext_kernel)
 };
 
 // The seeded search of many patterns over a long text (seed_kernels.hip).

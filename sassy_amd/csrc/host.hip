@@ -94,6 +94,8 @@ hipError_t launch_assemble_many(const ManyPart& a, const ManyPart& b, uint32_t n
                                 void* d_scratch, size_t scratch_bytes, hipStream_t stream, int flip = 1);
 hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable& texts, uint32_t* d_report_text,
                                hipStream_t stream);
+hipError_t launch_keep_interior(const Candidate* d_rec, uint32_t count, const TextTable& texts, uint32_t edge, unsigned char* d_keep,
+                                hipStream_t stream);
 size_t compact_scratch_bytes(uint32_t max_count, uint32_t str_stride);
 hipError_t launch_compact_cigars(MatchOut* d_rows, const char* d_strs, uint32_t max_count, const uint32_t* d_count, uint32_t str_stride,
                                  uint32_t* d_total, void* d_scratch, size_t scratch_bytes, const char** d_out_strs, hipStream_t stream);
@@ -3128,6 +3130,7 @@ struct TiledPerText {
   float alpha;
   unsigned long long vp;
   int32_t cost0;
+  uint32_t edge_cols;  // != 0: only the end positions overhang changes (the seeded search lists the inside of the texts)
 };
 // The pattern-tiled kernel over one device buffer: every (pattern, end position, cost <= k) into `list` (grown on
 // demand; the counter is the device word d_count).  *ok = false: more than 2^26 of them.  classes: 4 (Dna codes) or
@@ -3192,6 +3195,7 @@ static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, co
     P.alpha = pt->alpha;
     P.ov_vp = pt->vp;
     P.ov_cost0 = pt->cost0;
+    P.edge_cols = pt->edge_cols;
     const uint64_t waves_wanted = 32768;
     P.texts_per_wave = (uint32_t)std::max<uint64_t>(1, ((uint64_t)pt->n * P.n_groups + waves_wanted - 1) / waves_wanted);
     *n_waves = (((uint64_t)pt->n + P.texts_per_wave - 1) / P.texts_per_wave) * P.n_groups;
@@ -3417,6 +3421,46 @@ static int seeded_dirty_zones(sassy_SearcherType* s, const sassy_hip_Encoded* e,
   return 0;
 }
 
+// An overhang batch through the seeded search (search_many_pertext): the seeded pass has listed every end position with
+// cost <= k of the buffer as if there were no overhang.  Kept: the INSIDE of the texts -- end positions (m + k, len], which
+// no alignment that reaches a text's first column can end in, and behind which the virtual columns lie.  Added: what
+// overhang changes -- [0, m + k] from the overhang column, (len, len + steps] -- from tiled_pertext_kernel's edge segments.
+static int seeded_overhang_edges(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* buf, uint64_t total, uint32_t k,
+                                 const TextTable& tt, const TiledPerText& ov, uint32_t* list_count, bool* ok) {
+  *ok = false;
+  ScanLane& L = s->lanes[0];
+  hipStream_t st = s->stream;
+  uint32_t* d_cnt = s->d_tiled_cnt.p;
+  const uint32_t have = *list_count;
+  uint32_t kept = 0;
+  if (have) {
+    if (int rc = L.d_sorted.reserve(have)) return rc;
+    if (int rc = L.d_sort.reserve(select_scratch_bytes(have))) return rc;
+    const size_t flag_bytes = ((size_t)have + 255) / 256 * 256;
+    unsigned char* d_keep = L.d_sort.p;
+    hipError_t le = launch_keep_interior(s->d_tiled_list.p, have, tt, ov.edge_cols, d_keep, st);
+    if (le != hipSuccess) return hip_fail(le, "record filter launch");
+    le = launch_compact_candidates(s->d_tiled_list.p, have, d_keep, L.d_sorted.p, d_cnt + 5, L.d_sort.p + flag_bytes,
+                                   L.d_sort.cap - flag_bytes, st);
+    if (le != hipSuccess) return hip_fail(le, "record compaction launch");
+    HIP_TRY(hipMemcpyAsync(&kept, d_cnt + 5, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  uint32_t zc = 0;
+  uint64_t waves = 0;
+  bool zok = false;
+  if (int rc = tiled_scan_list(s, e, buf, total, k, 16u, s->d_zone_peq, s->d_zone_list, d_cnt + 4, &zc, &zok, &waves, nullptr, &ov)) return rc;
+  if (!zok) return 0;
+  if ((uint64_t)kept + zc > (1ull << 28)) return 0;
+  if (int rc = s->d_tiled_list.reserve((size_t)kept + zc + 1024)) return rc;  // (may move the buffer: its records are in d_sorted)
+  if (kept) HIP_TRY(hipMemcpyAsync(s->d_tiled_list.p, L.d_sorted.p, (size_t)kept * sizeof(Candidate), hipMemcpyDeviceToDevice, st));
+  if (zc) HIP_TRY(hipMemcpyAsync(s->d_tiled_list.p + kept, s->d_zone_list.p, (size_t)zc * sizeof(Candidate), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *list_count = kept + zc;
+  *ok = true;
+  return 0;
+}
+
 // search_encoded_patterns for many patterns over a long text: seed -> verify -> report (seed_kernels.hip).  One
 // pass over the text -- one launch -- looks every L-gram up in a table of all patterns' pigeonhole pieces; one lane
 // per hit runs the pattern over the few dozen characters around it.  Dna codes only (the caller has checked the text is plain ACGT
@@ -3424,7 +3468,8 @@ static int seeded_dirty_zones(sassy_SearcherType* s, const sassy_hip_Encoded* e,
 static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr,
                                  const uint8_t* h_text, uint64_t text_len, uint32_t k, bool all, bool wo,
                                  sassy_hip_Result* R, bool* done, const TextTable* tt = nullptr,
-                                 const HostTexts* ht = nullptr, bool dirty_text = false, ManyDefer* defer = nullptr) {
+                                 const HostTexts* ht = nullptr, bool dirty_text = false, ManyDefer* defer = nullptr,
+                                 const TiledPerText* ov = nullptr) {
   *done = false;
   hipStream_t st = s->stream;
   const size_t npat = e->patterns.size();
@@ -3669,6 +3714,12 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     bool zones_ok = false;
     if (int rc = seeded_dirty_zones(s, e, tptr, text_len, k, all, &out_count, &zones_ok)) return rc;
     if (!zones_ok) return 0;  // *done stays false
+  }
+  if (ov) {  // an overhang batch: the texts' edges come from the per-text tiled scan
+    if (!tt) return fail(SASSY_HIP_EINVAL, "internal: overhang edges need the batch's text table");
+    bool edges_ok = false;
+    if (int rc = seeded_overhang_edges(s, e, tptr, text_len, k, *tt, *ov, &out_count, &edges_ok)) return rc;
+    if (!edges_ok) return 0;  // *done stays false
   }
   s->stats.text_bytes += text_len;
   s->stats.chunks += waves;
@@ -4292,6 +4343,15 @@ static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patt
     for (size_t pi = 0; pi < n_patterns && tiled_ov; ++pi) tiled_ov = pattern_lens[pi] == max_m;
     if (tiled_ov) overhang_column(s, (uint32_t)max_m, (uint32_t)k, &ov_exact, &ov_vp, &ov_cost0);
   }
+  // ... and where the seeded search applies (plain ACGT batch, seeds long enough), IT lists the inside of the texts -- the
+  // end positions (m + k, len], which overhang cannot change -- at 1.4-1.9 TB/s, and the per-text tiled scan only the two
+  // edges of every text (6 % of a 1 kb read).  The batch is then padded with 'X' (the seeded search's separator: matches
+  // nothing); the virtual 'N' columns are made by the kernel.  SASSY_HIP_OVERHANG_SEEDED=0: the tiled scan over everything.
+  bool seed_ov = false;
+  if (tiled_ov && seeded_hit_rate(max_m, k) > 0) {
+    const bool env_off = getenv("SASSY_HIP_OVERHANG_SEEDED") && atoi(getenv("SASSY_HIP_OVERHANG_SEEDED")) == 0;  // (per call)
+    seed_ov = !env_off;
+  }
   const uint64_t batch_cap = 1ull << 30;
   uint8_t* hbuf = nullptr;  // the batch in pinned host memory (s->h_stage)
   HostTexts ht;
@@ -4317,7 +4377,8 @@ static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patt
     if (total > 0) {
       if (int rc = s->reserve_stage(total + 64)) return rc;
       hbuf = s->h_stage;
-      layout_texts(hbuf, texts + t0, text_lens + t0, ht.start.data(), nt, total, pad);
+      uint8_t pad_b = seed_ov ? (uint8_t)'X' : pad;
+      layout_texts(hbuf, texts + t0, text_lens + t0, ht.start.data(), nt, total, pad_b);
       blk2text.assign(total / 64, 0u);
       for (size_t i = 0; i < nt; ++i) {
         const uint64_t b0 = ht.start[i] / 64, b1 = (i + 1 < nt ? ht.start[i + 1] : total) / 64;
@@ -4359,17 +4420,30 @@ static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patt
         HIP_TRY(hipMemcpyAsync(d_b2t, blk2text.data(), blk2text.size() * 4, hipMemcpyHostToDevice, s->stream));
         s->rev_src = nullptr;
         if (int rc = s->d_rev.reserve(total + 64)) return rc;
-        hipError_t le = launch_reverse_texts(s->d_text.p, s->d_rev.p, total, d_b2t, d_tab, d_tab + nt, pad, s->stream);
+        hipError_t le = launch_reverse_texts(s->d_text.p, s->d_rev.p, total, d_b2t, d_tab, d_tab + nt, pad_b, s->stream);
         if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
       }
       std::string err;
       g_marks.mark("pertext upload");
       if (tiled_ov) {
+        bool seed_this = seed_ov;
+        if (seed_this) {  // the seeded search reads Dna codes: the batch must hold plain bases (and the padding) only
+          if (int rc = s->d_ncount.reserve(4)) return rc;
+          HIP_TRY(hipMemsetAsync(s->d_ncount.p, 0, 4, s->stream));
+          hipError_t le = launch_acgt_check(s->d_text.p, total, s->d_ncount.p, s->stream, 1);
+          if (le != hipSuccess) return hip_fail(le, "text check kernel launch");
+          uint32_t bad = 1;
+          HIP_TRY(hipMemcpyAsync(&bad, s->d_ncount.p, 4, hipMemcpyDeviceToHost, s->stream));
+          HIP_TRY(hipStreamSynchronize(s->stream));
+          seed_this = !bad;
+        }
         const size_t batch_first = R->matches.size(), pool_first = R->pool.size();
         TextTable tto = tt;
         tto.per_text = 0;
         tto.ov_steps = ov_exact;
-        TiledPerText pt{d_tab, d_tab + nt, (uint32_t)nt, ov_exact, s->alpha, ov_vp, ov_cost0};
+        TiledPerText pt{d_tab, d_tab + nt, (uint32_t)nt, ov_exact, s->alpha, ov_vp, ov_cost0, 0u};
+        TiledPerText pt_edges = pt;
+        pt_edges.edge_cols = (uint32_t)(max_m + k);
         bool ok_all = true;
         // the whole call is this one batch, traced, every report a record: both strands' records stay on the device and are
         // put in order there (assemble_many: every text was reversed in its own slot -- no index flip)
@@ -4392,8 +4466,12 @@ static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patt
           }
           const size_t first = R->matches.size();
           bool done = false;
-          if (int rc = search_encoded_tiled(s, &tmp, strand ? s->d_rev.p : s->d_text.p, strand ? nullptr : hbuf, total, (uint32_t)k, all,
-                                            wo, R, &done, &tto, &ht, on_device ? &defer[strand] : nullptr, &pt)) return rc;
+          if (seed_this)
+            if (int rc = search_encoded_seeded(s, &tmp, strand ? s->d_rev.p : s->d_text.p, strand ? nullptr : hbuf, total, (uint32_t)k, all,
+                                               wo, R, &done, &tto, &ht, false, on_device ? &defer[strand] : nullptr, &pt_edges)) return rc;
+          if (!done)
+            if (int rc = search_encoded_tiled(s, &tmp, strand ? s->d_rev.p : s->d_text.p, strand ? nullptr : hbuf, total, (uint32_t)k, all,
+                                              wo, R, &done, &tto, &ht, on_device ? &defer[strand] : nullptr, &pt)) return rc;
           if (!done) { ok_all = false; break; }
           for (size_t i = first; i < R->matches.size(); ++i) {
             sassy_hip_Match& m = R->matches[i];
@@ -4415,6 +4493,15 @@ static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patt
         }
         R->matches.resize(batch_first);  // (more end positions than the list holds: the patterns one by one)
         R->pool.resize(pool_first);
+        if (pad_b != pad) {  // ... whose DP reads the virtual columns from the buffer: pad it with 'N' after all
+          pad_b = pad;
+          layout_texts(hbuf, texts + t0, text_lens + t0, ht.start.data(), nt, total, pad_b);
+          HIP_TRY(hipMemcpyAsync(s->d_text.p, hbuf, total, hipMemcpyHostToDevice, s->stream));
+          if (s->rc) {
+            hipError_t le = launch_reverse_texts(s->d_text.p, s->d_rev.p, total, d_b2t, d_tab, d_tab + nt, pad_b, s->stream);
+            if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
+          }
+        }
       }
       ScanQueue queue(s, [&](uint64_t tag, ScanOut& so, const PatternPlan& plan, const uint8_t* pat) -> int {
         const size_t pi = (size_t)(tag >> 1);

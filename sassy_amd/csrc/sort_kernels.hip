@@ -296,6 +296,30 @@ hipError_t launch_compact_candidates(const Candidate* d_in, uint32_t count, cons
   return rocprim::select(d_scratch, scratch_bytes, d_in, d_keep, d_out, d_out_count, (size_t)count, stream);
 }
 
+// keep[i] = record i ends in the INSIDE of its text: behind the first `edge` columns and not behind the text's end (the
+// seeded search of an overhang batch: what overhang changes comes from tiled_pertext_kernel's edge segments)
+__global__ __launch_bounds__(256) void keep_interior_kernel(const Candidate* __restrict__ rec, uint32_t count, const TextTable T,
+                                                            uint32_t edge, unsigned char* __restrict__ keep) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  const uint64_t pos = rec[i].pos;
+  uint32_t lo = 0, hi = T.n;  // invariant: start[lo] <= pos < start[hi]
+  while (lo + 1 < hi) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (T.start[mid] <= pos) lo = mid; else hi = mid;
+  }
+  const uint64_t rel = pos - T.start[lo];
+  const uint64_t len = T.len[lo];
+  // (a text of at most `edge` characters is the edge segments' as a whole)
+  keep[i] = (len > edge && rel > edge && rel <= len) ? 1 : 0;
+}
+hipError_t launch_keep_interior(const Candidate* d_rec, uint32_t count, const TextTable& texts, uint32_t edge, unsigned char* d_keep,
+                                hipStream_t stream) {
+  if (count == 0) return hipSuccess;
+  hipLaunchKernelGGL(keep_interior_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_rec, count, texts, edge, d_keep);
+  return hipGetLastError();
+}
+
 hipError_t launch_assign_texts(Candidate* d_rep, uint32_t count, const TextTable& texts, uint32_t* d_report_text,
                                hipStream_t stream) {
   if (count == 0) return hipSuccess;

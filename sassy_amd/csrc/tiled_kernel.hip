@@ -173,7 +173,12 @@ __global__ __launch_bounds__(256) void tiled_scan_kernel(const TiledParams P) {
 }
 
 // Overhang in one pass over a batch of texts (TiledParams::n_texts != 0): a wave = 64 patterns x a run of
-// texts_per_wave texts, each text from its own overhang column to its last virtual 'N' column.
+// texts_per_wave texts, each text from its own overhang column to its last virtual 'N' column (the virtual columns are
+// made here -- class 15 -- whatever the buffer holds behind a text).
+// edge_cols != 0: ONLY what overhang changes -- the seeded search lists the end positions (edge_cols, len] of a text
+// longer than edge_cols = m + k (no alignment with <= k edits that ends there reaches the text's first column, and the
+// virtual columns lie behind them): this kernel adds [0, edge_cols] from the overhang column and (len, len + ov_steps]
+// from a fresh column m + k characters in front of the text's end.
 template <int WORDS>
 __global__ __launch_bounds__(256) void tiled_pertext_kernel(const TiledParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tsmem[];
@@ -199,52 +204,69 @@ __global__ __launch_bounds__(256) void tiled_pertext_kernel(const TiledParams P)
   const unsigned char* lane_lds = wave_lds + lane * sizeof(Word);
   const int kk = valid ? (int)P.k : (int)0x80000000;  // lanes without a pattern never report
   const uint32_t top_shift = (P.m - 1u) & 31u;
+  const uint32_t n_class = (P.classes == 4 ? 3u : 15u) << kShift;  // 'N' (overhang is Iupac's: 16 classes)
   for (uint64_t t = t_lo; t < t_hi; ++t) {
     const uint64_t start = P.texts_start[t], len = P.texts_len[t];
     if (len == 0) continue;  // no reports for an empty text (src/search.rs:1314-1316)
     const uint64_t end = len + P.ov_steps;
-    TiledState<Word> S;
-    S.vp = (Word)P.ov_vp;
-    S.vn = 0;
-    S.cost = P.ov_cost0;
-    if (S.cost <= kk) tiled_emit(P, start, S.cost, pat);  // end position 0: the whole pattern hangs over the text's start
-    for (uint64_t yb = 0; yb < end; yb += 64) {
-      const uint32_t ch = P.text_aligned[start + yb + lane];
-      uint32_t off;
-      if (P.classes == 4) off = ((ch >> 1) & 3u) << kShift;
-      else off = (uint32_t)kTiledIupacNib[ch & 31u] << kShift;
-      const uint64_t pos0 = start + yb + 1;  // end position behind character u = 0 of this block
-      if (yb + 64 <= len) {  // a whole block inside the text
+    const bool edges = P.edge_cols != 0 && len > P.edge_cols;
+    // the segments of this text: characters [c0, c1) (virtual ones included), end positions from emit_from on
+    for (int seg = 0; seg < (edges ? 2 : 1); ++seg) {
+      const uint64_t c0 = seg == 0 ? 0 : len - P.edge_cols;
+      const uint64_t c1 = edges && seg == 0 ? P.edge_cols : end;
+      const uint64_t emit_from = seg == 0 ? 0 : len + 1;
+      TiledState<Word> S;
+      if (c0 == 0) {  // the overhang column
+        S.vp = (Word)P.ov_vp;
+        S.cost = P.ov_cost0;
+        if (S.cost <= kk) tiled_emit(P, start, S.cost, pat);  // end position 0: the whole pattern hangs over the text's start
+      } else {        // a fresh column inside the text
+        S.vp = P.m >= 8 * sizeof(Word) ? (Word)~(Word)0 : (Word)(((Word)1 << P.m) - 1);
+        S.cost = (int)P.m;
+      }
+      S.vn = 0;
+      for (uint64_t yb = c0 & ~63ull; yb < c1; yb += 64) {
+        // (the slot is a whole number of blocks that covers len + ov_steps + 2 characters: the load stays inside it)
+        const uint32_t ch = P.text_aligned[start + yb + lane];
+        uint32_t off;
+        if (P.classes == 4) off = ((ch >> 1) & 3u) << kShift;
+        else off = (uint32_t)kTiledIupacNib[ch & 31u] << kShift;
+        const uint64_t pos0 = start + yb + 1;  // end position behind character u = 0 of this block
+        if (yb >= c0 && yb + 64 <= c1 && yb + 64 <= len && yb + 1 >= emit_from) {  // a whole block inside the text, all of it listed
 #pragma unroll
-        for (uint32_t g = 0; g < 64; g += 8) {
-          Word eq[8];
+          for (uint32_t g = 0; g < 64; g += 8) {
+            Word eq[8];
 #pragma unroll
-          for (uint32_t i = 0; i < 8; ++i)
-            eq[i] = *reinterpret_cast<const Word*>(lane_lds + (uint32_t)__builtin_amdgcn_readlane((int)off, (int)(g + i)));
-          int c8[8];
-          int lowest = 0x7FFFFFFF;
+            for (uint32_t i = 0; i < 8; ++i)
+              eq[i] = *reinterpret_cast<const Word*>(lane_lds + (uint32_t)__builtin_amdgcn_readlane((int)off, (int)(g + i)));
+            int c8[8];
+            int lowest = 0x7FFFFFFF;
 #pragma unroll
-          for (uint32_t i = 0; i < 8; ++i) {
-            tiled_step(S, eq[i], top_shift);
-            c8[i] = S.cost;
-            lowest = min(lowest, S.cost);
+            for (uint32_t i = 0; i < 8; ++i) {
+              tiled_step(S, eq[i], top_shift);
+              c8[i] = S.cost;
+              lowest = min(lowest, S.cost);
+            }
+            if (__any(lowest <= kk)) {
+              uint32_t mask = 0;
+#pragma unroll
+              for (uint32_t i = 0; i < 8; ++i) mask |= (c8[i] <= kk ? 1u : 0u) << i;
+              tiled_emit8(P, pos0 + g, mask, c8, pat);
+            }
           }
-          if (__any(lowest <= kk)) {
-            uint32_t mask = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < 8; ++i) mask |= (c8[i] <= kk ? 1u : 0u) << i;
-            tiled_emit8(P, pos0 + g, mask, c8, pat);
+        } else {  // a segment's first or last block, the block the text ends in, the virtual columns
+          const uint32_t u0 = c0 > yb ? (uint32_t)(c0 - yb) : 0u;
+          const uint32_t u1 = c1 - yb < 64 ? (uint32_t)(c1 - yb) : 64u;
+          for (uint32_t u = u0; u < u1; ++u) {
+            const uint64_t i = yb + u + 1;  // the end position behind this character
+            const uint32_t o = i <= len ? (uint32_t)__builtin_amdgcn_readlane((int)off, (int)u) : n_class;
+            tiled_step(S, *reinterpret_cast<const Word*>(lane_lds + o), top_shift);
+            if (i >= emit_from) {
+              // (f32 arithmetic, as the reference's add_overshoot_cost: src/search.rs:1274-1282)
+              const int tot = S.cost + (i > len ? __float2int_rd(P.alpha * (float)(i - len)) : 0);
+              if (tot <= kk) tiled_emit(P, start + i, tot, pat);
+            }
           }
-        }
-      } else {  // the block the text ends in, and the virtual columns behind it ('N' in the buffer)
-        const uint32_t u1 = end - yb < 64 ? (uint32_t)(end - yb) : 64u;
-        for (uint32_t u = 0; u < u1; ++u) {
-          const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)u);
-          tiled_step(S, *reinterpret_cast<const Word*>(lane_lds + o), top_shift);
-          const uint64_t i = yb + u + 1;
-          // (f32 arithmetic, as the reference's add_overshoot_cost: src/search.rs:1274-1282)
-          const int tot = S.cost + (i > len ? __float2int_rd(P.alpha * (float)(i - len)) : 0);
-          if (tot <= kk) tiled_emit(P, start + i, tot, pat);
         }
       }
     }

@@ -722,6 +722,7 @@ def test_overhang_many_patterns_in_one_pass(sassy):
     import os
     rng = random.Random(616)
     comp = bytes.maketrans(b"ACGT", b"TGCA")
+    seeded_cases = 0
     for it in range(14):
         m = rng.choice([8, 16, 24, 24, 32, 40, 64])
         k = rng.randrange(0, min(5, m // 3) + 1)
@@ -737,7 +738,9 @@ def test_overhang_many_patterns_in_one_pass(sassy):
         texts = []
         for _ in range(rng.choice([3, 40, 300])):
             n = rng.choice([0, 1, 5, m - 1, m, 62, 63, 64, 65, 127, 128, 129, 300, 1000])
-            t = bytearray(rng.choice(b"ACGTN") if rng.random() < 0.03 else rng.choice(b"ACGT") for _ in range(n))
+            # (every other case a batch of plain bases: the seeded search then lists the inside of the texts, the per-text
+            # tiled scan their two edges)
+            t = bytearray(rng.choice(b"ACGTN") if (it % 2 and rng.random() < 0.03) else rng.choice(b"ACGT") for _ in range(n))
             if n:
                 plain = bytes(c if c in b"ACGT" else 65 for c in rng.choice(pats))
                 if rng.random() < 0.5:
@@ -763,17 +766,24 @@ def test_overhang_many_patterns_in_one_pass(sassy):
                     want.append((pi, ti) + key(x)[1:])
         keyf = lambda x: (x.pattern_idx, x.text_idx) + key(x)[1:]
         res = {}
-        for env in ("1", "0"):
-            os.environ["SASSY_HIP_OVERHANG_TILED"] = env
+        paths = set()
+        for env in ("1", "tiled", "0"):
+            os.environ["SASSY_HIP_OVERHANG_TILED"] = "0" if env == "0" else "1"
+            if env == "tiled":
+                os.environ["SASSY_HIP_OVERHANG_SEEDED"] = "0"
             s = sassy.Searcher("iupac", rc=rc, alpha=alpha).with_max_overhang(mo)
             got = s.search_many(pats, texts, k, all_minima=allm)
+            os.environ.pop("SASSY_HIP_OVERHANG_SEEDED", None)
             res[env] = [keyf(x) for x in got]
             assert sorted(res[env]) == sorted(want), (it, env, m, k, alpha, mo, npat, len(texts), rc, allm, len(got), len(want))
-            if env == "1" and len(texts) >= 2:
-                assert s.stats()["filtered"] == 5, s.stats()   # the pattern-tiled scan took the batch
+            if env != "0" and len(texts) >= 2:
+                assert s.stats()["filtered"] in ((5, 6) if env == "1" else (5,)), s.stats()   # one pass took the batch
+                paths.add(s.stats()["filtered"])
         os.environ.pop("SASSY_HIP_OVERHANG_TILED")
+        seeded_cases = seeded_cases + (1 if 6 in paths else 0)
         # pattern-major, text by text, the forward strand's records in front of the Rc strand's -- as the other path orders them
         assert [x[:2] for x in res["1"]] == [x[:2] for x in res["0"]], (it,)
+    assert seeded_cases >= 2, seeded_cases   # (the seeded search + edge segments took some of the plain batches)
     # the reference's overhang vectors: each text between decoys, four copies of the pattern (a batch the one pass takes)
     for e in kats_overhang():
         pat, text = e["pattern"].encode(), e["text"].encode()
