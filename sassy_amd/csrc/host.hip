@@ -3679,9 +3679,10 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   SP.bits_off[0] = seed_bits_off[0];
   SP.bits_off[1] = seed_bits_off[1];
   SP.separators = tt ? 1u : 0u;  // several texts in the buffer: 'X' between them
-  // 2 KiB of text per wave and step; enough waves for two rounds of the chip, contiguous runs per wave
+  // 2 KiB of text per wave and step; contiguous runs per wave
   static const uint64_t env_waves = getenv("SASSY_HIP_SEED_WAVES") ? (uint64_t)atoll(getenv("SASSY_HIP_SEED_WAVES")) : 0ull;
-  const uint64_t waves = std::min<uint64_t>(env_waves ? env_waves : 16384, std::max<uint64_t>(1, (text_len + 2047) / 2048));
+  // (65 536 waves: 13 rounds of the chip's 5 120 resident waves -- the last round's ragged end is 4 % of config 4 with 16 384)
+  const uint64_t waves = std::min<uint64_t>(env_waves ? env_waves : 65536, std::max<uint64_t>(1, (text_len + 2047) / 2048));
   const uint32_t grid = (uint32_t)((waves + kWavesPerGroup - 1) / kWavesPerGroup);
 
   const uint64_t kMaxList = 1ull << 26;
