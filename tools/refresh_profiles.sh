@@ -82,7 +82,7 @@ fi
 # ---- the multi-device searcher as the bench line's driver (one device here), and the RCCL preflight's script on gloo
 python bench.py --mode inproc --gpus 1 --no-cpu-baseline > $OUT/${TAG}_bench_inproc.json 2>> $OUT/bench.err
 python tools/preflight_multigpu.py --gpus 2 --backend gloo 2>/dev/null | tail -1 > $OUT/${TAG}_preflight_gloo.json
-{ python tools/bench_reads.py; python tools/bench_reads.py --reads 330000; python tools/bench_reads.py --reads 330000 --fwd; python tools/bench_reads.py --overhang 0.5; } > $OUT/${TAG}_reads.json 2> $OUT/reads.err
+{ python tools/bench_reads.py; python tools/bench_reads.py --reads 330000; python tools/bench_reads.py --reads 330000 --fwd; python tools/bench_reads.py --overhang 0.5; python tools/bench_reads.py --reads 330000 --overhang 0.5; SASSY_HIP_OVERHANG_SEEDED=0 python tools/bench_reads.py --reads 330000 --overhang 0.5; SASSY_HIP_OVERHANG_TILED=0 python tools/bench_reads.py --overhang 0.5; } > $OUT/${TAG}_reads.json 2> $OUT/reads.err
 { python tools/probe_count.py; python tools/probe_rc.py; PROBE_M=23 PROBE_K=3 python tools/probe_rc.py; } > $OUT/${TAG}_shapes.json 2> $OUT/shapes.err
 { echo "# the paired filter (round 5) against the paths of round 4 (SASSY_HIP_PAIR=0): lone searches, 3 GB, tools/probe_short_pieces.py";
   export PROBE_SHAPES="dna:32:3,dna:23:3,iupac:23:3,dna:32:4,dna:32:5,iupac:32:5,dna:24:3,dna:27:3,dna:20:2,dna:12:1,dna:40:6,dna:48:7";
