@@ -276,6 +276,10 @@ struct SeedParams {
                                   // min(len, 8) characters c -- staged in LDS, tested before the tables are read
   uint32_t bits_off[2];
   uint32_t separators;            // 1: a multi-text buffer -- text bytes with bit 3 set ('X', the separator) match no row
+  // ---- the narrow layout of the sub-piece test (seed_kernels.hip: sub_piece_test_narrow; nullptr: not in use) ----
+  const uint4* entries16;         // both tables' entries, table 1 behind table 0: (pattern << 3 | piece, packed rows lo, hi, 0)
+  uint32_t entries16_off1;        // index of table 1's first entry
+  uint32_t win_left;              // the text window starts this many characters in front of the seed's end
 };
 
 // A finished match record as the trace kernel writes it; same layout as sassy_hip_Match

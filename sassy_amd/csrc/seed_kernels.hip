@@ -52,6 +52,9 @@ __global__ __launch_bounds__(256) void pack_text_kernel(const uint4* __restrict_
     packed[i] = pack_codes16(text16[i]);
 }
 
+// two neighbouring table offsets, one load (one line access of the vector cache instead of two)
+struct __attribute__((packed, aligned(4))) StartPair { uint32_t a, b; };
+
 // 64 bits = 32 characters of the packed text from character c on (c >= 0, the dwords exist)
 __device__ __forceinline__ unsigned long long packed_window(const uint32_t* packed, int64_t c) {
   const uint32_t* src = packed + (c >> 4);
@@ -63,20 +66,47 @@ __device__ __forceinline__ unsigned long long packed_window(const uint32_t* pack
 
 // The sub-piece test (SeedParams::sub): false = no alignment with <= k edits keeps this hit's piece intact.
 // KT >= 0: k is the compile-time constant KT (the loops over sub-pieces and shifts unroll), KT < 0: any k.
-template <int KT>
-__device__ __forceinline__ bool sub_piece_test(const SeedParams& P, unsigned long long cand) {
+// rows: SeedParams::sub staged in LDS (8 dwords per piece) -- the row decides whether the hit is tested at all, and
+// from global memory that answer was a round trip in front of the text loads.
+// MODE 1 (fast): every position fits 32 bits, the patterns hold no letters the test must not compare (no care words)
+// and k <= 3 (four pieces: their seed lengths in the low half of seed_len_packed): 32-bit arithmetic and offsets.
+template <int KT, int MODE>
+__device__ __forceinline__ bool sub_piece_test(const SeedParams& P, const uint32_t* rows, unsigned long long cand) {
+  constexpr bool FAST = MODE == 1;
   const uint32_t entry = (uint32_t)cand & ((1u << kSeedPosShift) - 1u);
   const uint32_t pat = entry >> 3, piece = entry & 7u;
-  const int64_t i = (int64_t)(cand >> kSeedPosShift);
-  // everything the test reads, requested at once: the piece's sub-piece row, the pattern, the two text windows
-  const uint4* row = reinterpret_cast<const uint4*>(P.sub + 8u * piece);
-  const uint4 r0 = row[0], r1 = row[1];
-  const unsigned long long pp = P.packed_pat[P.pat_care ? 2u * pat : pat];
-  const unsigned long long care = P.pat_care ? P.packed_pat[2u * pat + 1u] : ~0ull;  // (wave-uniform branch)
-  const int64_t cl = i - (int64_t)((P.seed_len_packed >> (8u * piece)) & 0xFFu) - 24, ch = i - 8;
-  const bool inside = cl >= 0 && ch + 32 <= (int64_t)P.text_len;
-  const unsigned long long lo = packed_window(P.packed_text, inside ? cl : 0),
-                           hi = packed_window(P.packed_text, inside ? ch : 0);
+  const uint4 r0 = *reinterpret_cast<const uint4*>(rows + 8u * piece);
+  uint4 r1 = make_uint4(0, 0, 0, 0);
+  if (KT < 0 || KT > 3) r1 = *reinterpret_cast<const uint4*>(rows + 8u * piece + 4u);
+  unsigned long long pp, care = ~0ull, lo, hi;
+  bool inside;
+  if (FAST) {
+    const char* pats = reinterpret_cast<const char*>(P.packed_pat);
+    const char* text = reinterpret_cast<const char*>(P.packed_text);
+    pp = *reinterpret_cast<const unsigned long long*>(pats + (entry & ~7u));  // 8 pat
+    const uint32_t i = (uint32_t)(cand >> kSeedPosShift);
+    const uint32_t len = ((uint32_t)P.seed_len_packed >> (8u * piece)) & 0xFFu;
+    inside = i >= len + 24u && i + 24u <= (uint32_t)P.text_len;
+    const uint32_t cl = inside ? i - len - 24u : 0u, ch = inside ? i - 8u : 0u;
+    // 64 bits = 32 characters of the packed text from character c on
+    auto window = [&](uint32_t c) __attribute__((always_inline)) {
+      const uint32_t* src = reinterpret_cast<const uint32_t*>(text + ((c >> 4) << 2));
+      const uint32_t sh = 2u * (c & 15u);
+      const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
+      return ((unsigned long long)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);
+    };
+    lo = window(cl);
+    hi = window(ch);
+  } else {
+    // everything the test reads, requested at once: the pattern, the two text windows
+    pp = P.packed_pat[P.pat_care ? 2u * pat : pat];
+    if (P.pat_care) care = P.packed_pat[2u * pat + 1u];  // (wave-uniform branch)
+    const int64_t i = (int64_t)(cand >> kSeedPosShift);
+    const int64_t cl = i - (int64_t)((P.seed_len_packed >> (8u * piece)) & 0xFFu) - 24, ch = i - 8;
+    inside = cl >= 0 && ch + 32 <= (int64_t)P.text_len;
+    lo = packed_window(P.packed_text, inside ? cl : 0);
+    hi = packed_window(P.packed_text, inside ? ch : 0);
+  }
   if ((r0.x & 0xFFu) == 0xFFu || !inside) return true;  // untested
   const uint32_t ent[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
   const uint32_t k = KT >= 0 ? (uint32_t)KT : P.k;
@@ -86,7 +116,8 @@ __device__ __forceinline__ bool sub_piece_test(const SeedParams& P, unsigned lon
     if (u <= k) {
       // row fields (host.hip): 2a | (32 - 2 len) << 8 | 2 (c0 - k) << 16 | side << 24
       const uint32_t want = (uint32_t)(pp >> (ent[u] & 0xFFu));
-      const uint32_t mask = (0xFFFFFFFFu >> ((ent[u] >> 8) & 0xFFu)) & (uint32_t)(care >> (ent[u] & 0xFFu));
+      uint32_t mask = 0xFFFFFFFFu >> ((ent[u] >> 8) & 0xFFu);
+      if (!FAST) mask &= (uint32_t)(care >> (ent[u] & 0xFFu));
       // the window from the leftmost shift on; every further shift is two bits down
       const unsigned long long w = ((ent[u] >> 24) ? hi : lo) >> ((ent[u] >> 16) & 0xFFu);
       const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
@@ -99,6 +130,63 @@ __device__ __forceinline__ bool sub_piece_test(const SeedParams& P, unsigned lon
       } else {
         for (uint32_t d = 0; d <= 2u * k; ++d) miss = min(miss, (__builtin_amdgcn_alignbit(wh, wl, 2u * d) ^ want) & mask);
       }
+    }
+  }
+  return miss == 0u;
+}
+
+// MODE 2 (narrow; the conditions of MODE 1, and every sub-piece of every piece within 48 characters -- 10 000 20-mers):
+// the kernel is bound by the vector cache's rate of line accesses (one per lane and load: entry, pattern, two text
+// windows, table rows -- 4.2 per hit measured, ~1 per cycle and CU), so this path makes two per hit and has them in
+// flight together.  The queue holds the INDEX of the hit's table entry; the test reads entry16[index] = (pattern << 3 |
+// piece, the pattern's packed rows) and ONE window of 4 dwords of the packed text that starts win_left characters in
+// front of the seed's end, whatever the piece.  Row fields: 2a | (32 - 2 len) << 8 | 2 (off & 15) << 16 |
+// (off >> 4) << 24, off = the sub-piece's leftmost shift in characters from the window's start (< 32).
+// cand comes back as (position << kSeedPosShift) | pattern << 3 | piece, what the verification reads.
+// The test comes in two halves so that the kernel can have the loads of the next 64 hits in flight while it compares
+// this batch (a wave spent 60 % of its time waiting for these two loads).
+struct NarrowLoads {
+  unsigned long long cand;
+  uint4 entry;            // entries16[index]
+  uint32_t d0, d1, d2, d3;  // the text window's dwords
+};
+__device__ __forceinline__ NarrowLoads narrow_issue(const SeedParams& P, unsigned long long cand) {
+  NarrowLoads L;
+  L.cand = cand;
+  const uint32_t idx = (uint32_t)cand & ((1u << kSeedPosShift) - 1u);
+  const uint32_t i = (uint32_t)(cand >> kSeedPosShift);
+  const uint32_t cl = i >= P.win_left ? i - P.win_left : 0u;
+  L.entry = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.entries16) + (idx << 4));
+  const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(P.packed_text) + ((cl >> 4) << 2));
+  L.d0 = src[0]; L.d1 = src[1]; L.d2 = src[2]; L.d3 = src[3];
+  return L;
+}
+template <int KT>
+__device__ __forceinline__ bool narrow_finish(const SeedParams& P, const uint32_t* rows, const NarrowLoads& L, unsigned long long& cand) {
+  static_assert(KT >= 0 && KT <= 3, "narrow test: k <= 3");
+  const uint32_t i = (uint32_t)(L.cand >> kSeedPosShift);
+  const bool inside = i >= P.win_left;  // (beyond the text's end the packed copy holds zeros: a test that passes too often)
+  const uint32_t sh = 2u * ((i - P.win_left) & 15u);
+  const uint32_t x0 = __builtin_amdgcn_alignbit(L.d1, L.d0, sh), x1 = __builtin_amdgcn_alignbit(L.d2, L.d1, sh),
+                 x2 = __builtin_amdgcn_alignbit(L.d3, L.d2, sh);  // 48 characters from the window's start on
+  const uint4 E = L.entry;
+  cand = (L.cand & ~(unsigned long long)((1u << kSeedPosShift) - 1u)) | E.x;
+  const uint4 r0 = *reinterpret_cast<const uint4*>(rows + 8u * (E.x & 7u));
+  if ((r0.x & 0xFFu) == 0xFFu || !inside) return true;  // untested
+  const unsigned long long pp = ((unsigned long long)E.z << 32) | E.y;
+  const uint32_t ent[4] = {r0.x, r0.y, r0.z, r0.w};
+  uint32_t miss = 0xFFFFFFFFu;
+#pragma unroll
+  for (uint32_t u = 0; u <= (uint32_t)KT; ++u) {
+    const uint32_t want = (uint32_t)(pp >> (ent[u] & 0xFFu));
+    const uint32_t mask = 0xFFFFFFFFu >> ((ent[u] >> 8) & 0xFFu);
+    const bool far = (ent[u] >> 24) != 0u;
+    const unsigned long long w = (((unsigned long long)(far ? x2 : x1) << 32) | (far ? x1 : x0)) >> ((ent[u] >> 16) & 0xFFu);
+    const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+#pragma unroll
+    for (uint32_t d = 0; d <= 2u * (uint32_t)KT; ++d) {
+      const uint32_t got = d == 0 ? wl : __builtin_amdgcn_alignbit(wh, wl, 2u * d);
+      miss = min(miss, (got ^ want) & mask);
     }
   }
   return miss == 0u;
@@ -236,8 +324,9 @@ __device__ __noinline__ void verify_candidate(const VerifyArgs P, unsigned long 
 // One wave walks a contiguous range of the text, 2 KiB per step: lane l takes the 32 characters [g, g + 32),
 // g = step base + 32 l, plus the 16 in front of them (seeds that end in its characters start there).
 // KT: the sub-piece test's k (>= 0: compile-time, -1: run-time, -2: no test).
-template <int WORDS, int KT>
+template <int WORDS, int KT, int MODE>
 __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
+  constexpr bool NARROW = MODE == 2;
   constexpr uint32_t kTurn = 4;
   __shared__ unsigned long long queue_mem[kWavesPerGroup][128], pass_mem[kWavesPerGroup][128];
   // "does any pattern have a seed that ends like this?" -- one bit per min(len, 8)-gram and table (<= 2 x 8 KiB): with
@@ -245,6 +334,8 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
   __shared__ uint32_t bits_lds[2 * 2048];
   for (uint32_t x = threadIdx.x; x < P.bits_off[1] + (P.len[1] ? (1u << (2 * (P.len[1] < 8 ? P.len[1] : 8))) / 32 : 0); x += blockDim.x)
     bits_lds[x] = P.seed_bits[x];
+  __shared__ __attribute__((aligned(16))) uint32_t sub_rows[64];
+  if (KT >= -1 && threadIdx.x < 64) sub_rows[threadIdx.x] = P.sub[threadIdx.x];
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave_in_group = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -257,16 +348,17 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
   if (s_lo >= s_hi) return;
   unsigned long long* queue = queue_mem[wave_in_group];
   unsigned long long* passed = pass_mem[wave_in_group];
-  uint32_t queued = 0, n_passed = 0;  // wave-uniform
+  // both queues are rings of 128 entries: [head, head + count) modulo 128
+  uint32_t queued = 0, n_passed = 0, q_head = 0, p_head = 0;  // wave-uniform
   uint64_t n_hits = 0, n_pass = 0;
 
   // verify the first `count` hits of `from`, one per lane (the window of a hit near the text's ends needs range checks)
-  auto verify_from = [&](const unsigned long long* from, uint32_t count) __attribute__((always_inline)) {
+  auto verify_from = [&](const unsigned long long* from, uint32_t head, uint32_t count) __attribute__((always_inline)) {
     const bool have = lane < count;
     unsigned long long cand = 0;
     bool edge = false;
     if (have) {
-      cand = from[lane];
+      cand = from[(head + lane) & 127u];
       const int64_t i = (int64_t)(cand >> kSeedPosShift);
       const int64_t e_hi = i + (int64_t)((P.rem_packed >> (8u * ((uint32_t)cand & 7u))) & 0xFFu) + (int64_t)P.k;
       const int64_t s0 = e_hi - ((int64_t)P.m + 3 * (int64_t)P.k + 1);
@@ -282,34 +374,56 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
       if (have) verify_candidate<WORDS, false>(va, cand);
     }
   };
-  // drop the first 64 entries of a queue of `have` (< 128) entries
-  auto pop64 = [&](unsigned long long* q, uint32_t have) __attribute__((always_inline)) {
-    const uint32_t rest = have - 64;
-    unsigned long long moved = 0;
-    if (lane < rest) moved = q[64 + lane];
-    __builtin_amdgcn_wave_barrier();
-    if (lane < rest) q[lane] = moved;
-    __builtin_amdgcn_wave_barrier();
-  };
   // The first `count` queued hits, one per lane: with the sub-piece test (WORDS == 1, P.sub) the few that pass it
   // collect in a second queue and are verified 64 at a time, else they are verified at once.
-  auto verify = [&](uint32_t count) __attribute__((always_inline)) {
-    if (KT < -1) { verify_from(queue, count); return; }
-    bool ok = false;
-    unsigned long long cand = 0;
-    if (lane < count) {
-      cand = queue[lane];
-      ok = sub_piece_test<KT>(P, cand);
-    }
+  // (narrow layout: the batch whose loads are in flight -- narrow_issue -- and its size; compared when the next one's
+  // loads have been issued)
+  NarrowLoads pend{};
+  uint32_t pend_n = 0;  // wave-uniform
+  auto passed_push = [&](bool ok, unsigned long long cand) __attribute__((always_inline)) {
     const unsigned long long m = __ballot(ok);
-    if (ok) passed[n_passed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = cand;
+    if (ok)
+      passed[(p_head + n_passed + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))) & 127u] = cand;
     n_passed += (uint32_t)__popcll(m);
     n_pass += (uint32_t)__popcll(m);
     __builtin_amdgcn_wave_barrier();
     if (n_passed >= 64) {
-      verify_from(passed, 64);
-      pop64(passed, n_passed);
+      verify_from(passed, p_head, 64);
+      p_head = (p_head + 64u) & 127u;
       n_passed -= 64;
+    }
+  };
+  auto verify = [&](uint32_t count) __attribute__((always_inline)) {
+    if (KT < -1) { verify_from(queue, q_head, count); return; }
+    if constexpr (NARROW) {
+      const NarrowLoads next = narrow_issue(P, lane < count ? queue[(q_head + lane) & 127u] : 0ull);
+      if (pend_n) {
+        unsigned long long cand = 0;
+        bool ok = false;
+        if (lane < pend_n) ok = narrow_finish<KT>(P, sub_rows, pend, cand);
+        passed_push(ok, cand);
+      }
+      pend = next;
+      pend_n = count;
+    } else {
+      bool ok = false;
+      unsigned long long cand = 0;
+      if (lane < count) {
+        cand = queue[(q_head + lane) & 127u];
+        ok = sub_piece_test<KT, MODE>(P, sub_rows, cand);
+      }
+      passed_push(ok, cand);
+    }
+  };
+  auto verify_drain = [&]() __attribute__((always_inline)) {
+    if constexpr (NARROW) {
+      if (pend_n) {
+        unsigned long long cand = 0;
+        bool ok = false;
+        if (lane < pend_n) ok = narrow_finish<KT>(P, sub_rows, pend, cand);
+        passed_push(ok, cand);
+        pend_n = 0;
+      }
     }
   };
 
@@ -338,16 +452,18 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
         const uint32_t code = (uint32_t)(q >> (2u * (17u + (j & 15u) - P.len[0]))) & mask0;
         const uint32_t c8 = code >> cut0;  // the seed's last min(len, 8) characters
         if ((bits_lds[c8 >> 5] >> (c8 & 31u)) & 1u) {
-          a0 = P.start[0][code];
-          b0 = P.start[0][code + 1];
+          const StartPair ab = *reinterpret_cast<const StartPair*>(P.start[0] + code);
+          a0 = ab.a;
+          b0 = ab.b;
         }
       }
       if (P.len[1] && in_text && end >= P.len[1]) {
         const uint32_t code = (uint32_t)(q >> (2u * (17u + (j & 15u) - P.len[1]))) & mask1;
         const uint32_t c8 = code >> cut1;
         if ((bits_lds[P.bits_off[1] + (c8 >> 5)] >> (c8 & 31u)) & 1u) {
-          a1 = P.start[1][code];
-          b1 = P.start[1][code + 1];
+          const StartPair ab = *reinterpret_cast<const StartPair*>(P.start[1] + code);
+          a1 = ab.a;
+          b1 = ab.b;
         }
       }
     };
@@ -366,7 +482,8 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
         for (uint32_t x = 0; x < kTurn; ++x) {
           const uint32_t r = r0 + x;
           ent[x] = 0;
-          if (r < n) ent[x] = r < n0 ? P.entries[0][a0 + r] : P.entries[1][a1 + (r - n0)];
+          if (NARROW) ent[x] = r < n0 ? a0 + r : P.entries16_off1 + a1 + (r - n0);  // the entry's index: read by the test
+          else if (r < n) ent[x] = r < n0 ? P.entries[0][a0 + r] : P.entries[1][a1 + (r - n0)];
         }
 #pragma unroll
         for (uint32_t x = 0; x < kTurn; ++x) {
@@ -374,14 +491,14 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
           const unsigned long long m = __ballot(active);
           if (m == 0) break;
           if (active) {
-            const uint32_t slot = queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            queue[slot] = ((unsigned long long)end << kSeedPosShift) | ent[x];
+            const uint32_t slot = q_head + queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            queue[slot & 127u] = ((unsigned long long)end << kSeedPosShift) | ent[x];
           }
           queued += (uint32_t)__popcll(m);
           __builtin_amdgcn_wave_barrier();
           if (queued >= 64) {
             verify(64);
-            pop64(queue, queued);
+            q_head = (q_head + 64u) & 127u;
             queued -= 64;
             n_hits += 64;
           }
@@ -391,8 +508,9 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
     }
   }
   if (queued) verify(queued);
+  verify_drain();
   n_hits += queued;
-  if (n_passed) verify_from(passed, n_passed);
+  if (n_passed) verify_from(passed, p_head, n_passed);
   if (P.hit_count && lane == 0 && n_hits) {
     atomicAdd(P.hit_count, (unsigned long long)n_hits);
     atomicAdd(P.hit_count + 1, (unsigned long long)n_pass);
@@ -566,13 +684,27 @@ hipError_t launch_pack_text(const uint8_t* d_text, uint64_t n, uint32_t* d_packe
 hipError_t launch_seed_search(const SeedParams& P, uint32_t grid, hipStream_t stream) {
   if (P.text_len == 0 || grid == 0) return hipSuccess;
   const dim3 g(grid), b(256);
-  if (P.m > 32) hipLaunchKernelGGL((seed_search_kernel<2, -2>), g, b, 0, stream, P);
-  else if (P.sub == nullptr) hipLaunchKernelGGL((seed_search_kernel<1, -2>), g, b, 0, stream, P);
-  else if (P.k == 0) hipLaunchKernelGGL((seed_search_kernel<1, 0>), g, b, 0, stream, P);
-  else if (P.k == 1) hipLaunchKernelGGL((seed_search_kernel<1, 1>), g, b, 0, stream, P);
-  else if (P.k == 2) hipLaunchKernelGGL((seed_search_kernel<1, 2>), g, b, 0, stream, P);
-  else if (P.k == 3) hipLaunchKernelGGL((seed_search_kernel<1, 3>), g, b, 0, stream, P);
-  else hipLaunchKernelGGL((seed_search_kernel<1, -1>), g, b, 0, stream, P);
+  // (modes: see sub_piece_test, sub_piece_test_narrow)
+  const bool fast = P.sub != nullptr && !P.pat_care && P.k <= 3 && P.text_len < 0xFFFF0000ull;
+  const int mode = fast && P.entries16 ? 2 : fast ? 1 : 0;
+  if (P.m > 32) hipLaunchKernelGGL((seed_search_kernel<2, -2, 0>), g, b, 0, stream, P);
+  else if (P.sub == nullptr) hipLaunchKernelGGL((seed_search_kernel<1, -2, 0>), g, b, 0, stream, P);
+  else if (P.k > 3) hipLaunchKernelGGL((seed_search_kernel<1, -1, 0>), g, b, 0, stream, P);
+  else {
+#define SASSY_SEED_LAUNCH(K, M) hipLaunchKernelGGL((seed_search_kernel<1, K, M>), g, b, 0, stream, P)
+#define SASSY_SEED_MODES(K)                       \
+  do {                                            \
+    if (mode == 2) SASSY_SEED_LAUNCH(K, 2);       \
+    else if (mode == 1) SASSY_SEED_LAUNCH(K, 1);  \
+    else SASSY_SEED_LAUNCH(K, 0);                 \
+  } while (0)
+    if (P.k == 0) SASSY_SEED_MODES(0);
+    else if (P.k == 1) SASSY_SEED_MODES(1);
+    else if (P.k == 2) SASSY_SEED_MODES(2);
+    else SASSY_SEED_MODES(3);
+#undef SASSY_SEED_MODES
+#undef SASSY_SEED_LAUNCH
+  }
   return hipGetLastError();
 }
 
