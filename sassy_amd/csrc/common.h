@@ -261,25 +261,26 @@ struct SeedParams {
   unsigned long long* hit_count;  // optional: [0] table hits, [1] hits that passed the sub-piece test
   // ---- the sub-piece test in front of the verification (m <= 32; sub == nullptr: off) ----
   // A hit says piece p is intact at i.  The other rows of the pattern hold at most k edits, so of any k+1 disjoint
-  // sub-pieces of them one is intact too, at most k characters off the seed's diagonal.  Sub-piece u of piece p =
-  // rows [a, a + len), len <= 16; side 0: left of the seed, compared in the window of 32 characters that ends 8
-  // behind the seed's start, side 1: right of it, window of 32 characters that starts 8 in front of the seed's end;
-  // c0 = its character offset in that window on the seed's diagonal.  sub[8 p + u] = 2a | (32 - 2 len) << 8 |
-  // 2 (c0 - k) << 16 | side << 24 (the shift amounts the test uses); sub[8 p] = 0xFF in its low byte: no test for piece p.
+  // sub-pieces of them one is intact too, at most k characters off the seed's diagonal.  The test reads one window
+  // of the 2-bit text, win_dwords dwords from the dword that holds character i - win_left.  Sub-piece u of piece p =
+  // rows [a, a + len), off = the characters from the window's start to where it lies at its leftmost shift (k left
+  // of the seed's diagonal): sub[8 p + u] = 2a | (32 - 2 len) << 8 | 2 (off & 15) << 16 | (off >> 4) << 24 (the shift
+  // amounts the test uses; (off & 15) + 2k + len <= 32, off < 16 (win_dwords - 2)); sub[8 p] = 0xFF in its low byte:
+  // no test for piece p.
   const uint32_t* sub;
   const uint32_t* packed_text;    // 2-bit Dna codes of the text, 16 characters per dword
-  const unsigned long long* packed_pat;  // per pattern: row r at bits 2r; pat_care: two words per pattern, the second
-                                         // one = 11 at the rows the test may compare (concrete bases), 00 elsewhere
+  // both tables' entries, table 1 behind table 0: (pattern << 3 | piece, the pattern's packed rows -- row r at bits
+  // 2r --, 0); pat_care: 32 bytes per entry, the second half = 11 at the rows the test may compare (concrete
+  // bases), 00 elsewhere
+  const uint4* entries16;
+  uint32_t entries16_off1;        // index of table 1's first entry
+  uint32_t win_left, win_dwords;  // (4: the narrow layout, 5: the wide one -- seed_kernels.hip: test_issue)
   uint32_t pat_care;
   uint64_t seed_len_packed;       // byte p = rows of the seed of piece p
   const uint32_t* seed_bits;      // bit c of table t's part (offset bits_off[t] words): some seed of table t ends with the
                                   // min(len, 8) characters c -- staged in LDS, tested before the tables are read
   uint32_t bits_off[2];
   uint32_t separators;            // 1: a multi-text buffer -- text bytes with bit 3 set ('X', the separator) match no row
-  // ---- the narrow layout of the sub-piece test (seed_kernels.hip: sub_piece_test_narrow; nullptr: not in use) ----
-  const uint4* entries16;         // both tables' entries, table 1 behind table 0: (pattern << 3 | piece, packed rows lo, hi, 0)
-  uint32_t entries16_off1;        // index of table 1's first entry
-  uint32_t win_left;              // the text window starts this many characters in front of the seed's end
 };
 
 // A finished match record as the trace kernel writes it; same layout as sassy_hip_Match

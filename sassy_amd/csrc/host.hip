@@ -553,7 +553,6 @@ struct sassy_SearcherType {
   DevBuf<Candidate> d_tiled_sel, d_tiled_list;  // (the list is not a lane's d_cand: its size must not leak into single searches)
   // seeded search (search_encoded_seeded): the piece tables; sub-piece table, packed text and patterns
   DevBuf<uint32_t> d_seed_start[2], d_seed_entries[2], d_seed_sub, d_seed_packed, d_seed_bits, d_seed_e16;
-  DevBuf<unsigned long long> d_seed_ppk;
   // ... on texts with other letters (seeded_dirty_zones): run lists / tables, the gathered neighbourhoods, their scan
   DevBuf<unsigned long long> d_zone_u64, d_zone_tab, d_zone_peq;
   DevBuf<uint8_t> d_zone_text;
@@ -579,7 +578,7 @@ struct sassy_SearcherType {
     d_range.release(); d_ncount.release(); d_tables.release(); d_multi_bitmap.release(); d_multi_bits.release();
     d_tiled_peq.release(); d_tiled_pat.release(); d_tiled_cnt.release(); d_tiled_sel.release(); d_tiled_list.release(); d_tiled_rtext.release();
     for (int t = 0; t < 2; ++t) { d_seed_start[t].release(); d_seed_entries[t].release(); }
-    d_seed_sub.release(); d_seed_packed.release(); d_seed_ppk.release(); d_seed_bits.release(); d_seed_e16.release();
+    d_seed_sub.release(); d_seed_packed.release(); d_seed_bits.release(); d_seed_e16.release();
     d_zone_u64.release(); d_zone_tab.release(); d_zone_peq.release(); d_zone_text.release(); d_zone_list.release();
     if (ev_multi) (void)hipEventDestroy(ev_multi);
     if (ev_multi_a) (void)hipEventDestroy(ev_multi_a);
@@ -3613,113 +3612,107 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     SP.seed_len_packed |= (uint64_t)p_len[pc] << (8 * pc);
   }
   // ---- the sub-piece test in front of the verification (common.h: SeedParams::sub; patterns of <= 32 rows) ----
-  // For a hit of piece p: k+1 disjoint sub-pieces of the rows within 24 - k of the seed, shared out between the two
+  // For a hit of piece p: k+1 disjoint sub-pieces of the rows within `reach` of the seed, shared out between the two
   // sides in proportion to the rows there; one of them must be intact within k characters of the seed's diagonal.
+  // The test reads ONE window of the 2-bit text for all pieces (seed_kernels.hip: test_issue): it starts win_left =
+  // (longest seed) + (most rows used left of a seed) + k characters in front of the seed's end, and every sub-piece
+  // must start, at its leftmost shift, within 48 characters of that -- the largest reach <= 24 - k that allows it.
   static const bool env_sub = !(getenv("SASSY_HIP_SEED_SUBTEST") && atoi(getenv("SASSY_HIP_SEED_SUBTEST")) == 0);
+  static const bool env_narrow = !(getenv("SASSY_HIP_SEED_NARROW") && atoi(getenv("SASSY_HIP_SEED_NARROW")) == 0);
   if (!wide && env_sub) {
-    // (an Iupac searcher whose patterns are all plain bases -- 10 000 random 20-mers -- needs no second word)
-    bool care_words = false;
+    struct SubPiece { uint32_t pc, u, a, len, off; };
+    std::vector<SubPiece> subs;
+    uint32_t win_left = 0, max_off = 0;
+    for (uint32_t reach = 24 - k; reach >= 4; --reach) {  // (k <= 7)
+      subs.clear();
+      uint32_t max_nl = 0, max_len = 0;
+      for (uint32_t pc = 0; pc < pieces; ++pc) {
+        const uint32_t sp = p_end[pc] - p_len[pc], pe = p_end[pc];
+        const uint32_t nl = std::min(sp, reach), nr = std::min(m - pe, reach);
+        max_len = std::max(max_len, p_len[pc]);
+        if (nl + nr < pieces) continue;  // fewer rows than sub-pieces: no test for this piece
+        max_nl = std::max(max_nl, nl);
+        uint32_t cl = (uint32_t)(((uint64_t)pieces * nl + (nl + nr) / 2) / (nl + nr));
+        cl = std::min(cl, nl);
+        uint32_t cr = pieces - cl;
+        if (cr > nr) { cr = nr; cl = pieces - cr; }
+        uint32_t u = 0;
+        for (uint32_t x = 0; x < cl; ++x) {  // left of the seed: rows [sp - nl, sp) in cl parts
+          const uint32_t a = sp - nl + (uint32_t)((uint64_t)nl * x / cl), b = sp - nl + (uint32_t)((uint64_t)nl * (x + 1) / cl);
+          subs.push_back({pc, u++, a, b - a, sp - a});  // (off: for now the rows from a to the seed's start)
+        }
+        for (uint32_t x = 0; x < cr; ++x) {  // right of it: rows [pe, pe + nr) in cr parts
+          const uint32_t a = pe + (uint32_t)((uint64_t)nr * x / cr), b = pe + (uint32_t)((uint64_t)nr * (x + 1) / cr);
+          subs.push_back({pc, u++, a, b - a, 0x80000000u | (a - pe)});  // (rows from the seed's end to a)
+        }
+      }
+      win_left = max_len + max_nl + k;
+      max_off = 0;
+      for (SubPiece& q : subs) {
+        q.off = (q.off & 0x80000000u) ? win_left + (q.off & 0x7FFFFFFFu) - k : win_left - p_len[q.pc] - q.off - k;
+        max_off = std::max(max_off, q.off);
+      }
+      if (max_off <= 47) break;
+      subs.clear();
+    }
+    // (an Iupac searcher whose patterns are all plain bases -- 10 000 random 20-mers -- needs no care words; the
+    // kernel for positions beyond 32 bits always reads them)
+    bool care_words = text_len >= 0xFFFF0000ull;
     if (iupac_pats)
       for (size_t p = 0; p < npat && !care_words; ++p)
         for (uint32_t j = 0; j < m; ++j) {
           const uint32_t set = base_set(e->patterns[p][j]);
           if (!set || (set & (set - 1))) { care_words = true; break; }
         }
+    const bool narrow = env_narrow && !care_words && max_off <= 31;
     std::vector<uint32_t> sub(64, 0xFFu);  // (low byte 0xFF in a piece's first entry: no test for that piece)
-    const uint32_t reach = 24 - k;  // (k <= 7)
-    struct SubPiece { uint32_t pc, u, a, len; bool right; };
-    std::vector<SubPiece> subs;
-    uint32_t max_nl = 0, max_len = 0;
-    for (uint32_t pc = 0; pc < pieces; ++pc) {
-      const uint32_t sp = p_end[pc] - p_len[pc], pe = p_end[pc];
-      const uint32_t nl = std::min(sp, reach), nr = std::min(m - pe, reach);
-      max_len = std::max(max_len, p_len[pc]);
-      if (nl + nr < pieces) continue;  // fewer rows than sub-pieces: no test for this piece
-      max_nl = std::max(max_nl, nl);
-      uint32_t cl = (uint32_t)(((uint64_t)pieces * nl + (nl + nr) / 2) / (nl + nr));
-      cl = std::min(cl, nl);
-      uint32_t cr = pieces - cl;
-      if (cr > nr) { cr = nr; cl = pieces - cr; }
-      uint32_t u = 0;
-      for (uint32_t x = 0; x < cl; ++x) {  // left of the seed: rows [sp - nl, sp) in cl parts
-        const uint32_t a = sp - nl + (uint32_t)((uint64_t)nl * x / cl), b = sp - nl + (uint32_t)((uint64_t)nl * (x + 1) / cl);
-        subs.push_back({pc, u++, a, std::min(b - a, 16u), false});
-      }
-      for (uint32_t x = 0; x < cr; ++x) {  // right of it: rows [pe, pe + nr) in cr parts
-        const uint32_t a = pe + (uint32_t)((uint64_t)nr * x / cr), b = pe + (uint32_t)((uint64_t)nr * (x + 1) / cr);
-        subs.push_back({pc, u++, a, std::min(b - a, 16u), true});
-      }
-    }
-    // The narrow layout (seed_kernels.hip: sub_piece_test_narrow): one text window for all pieces, win_left characters
-    // in front of the seed's end; usable when every sub-piece's leftmost shift starts within 32 characters of it.
-    static const bool env_narrow = !(getenv("SASSY_HIP_SEED_NARROW") && atoi(getenv("SASSY_HIP_SEED_NARROW")) == 0);
-    const uint32_t win_left = max_len + max_nl + k;
-    bool narrow = env_narrow && !care_words && k <= 3 && text_len < 0xFFFF0000ull && !subs.empty();
     for (const SubPiece& q : subs) {
-      const uint32_t sp = p_end[q.pc] - p_len[q.pc], pe = p_end[q.pc];
-      const uint32_t off = q.right ? win_left + (q.a - pe) - k : win_left - p_len[q.pc] - (sp - q.a) - k;
-      if (off > 31) narrow = false;
+      // (off & 15) + 2k + len <= 32: the compared bits lie in the 64 the test takes from the window
+      const uint32_t len = std::min(q.len, std::min(16u, 17u - 2u * k));
+      sub[8 * q.pc + q.u] = (2 * q.a) | ((32 - 2 * len) << 8) | ((2 * (q.off & 15u)) << 16) | ((q.off >> 4) << 24);
     }
-    for (const SubPiece& q : subs) {
-      const uint32_t sp = p_end[q.pc] - p_len[q.pc], pe = p_end[q.pc];
-      if (narrow) {
-        const uint32_t off = q.right ? win_left + (q.a - pe) - k : win_left - p_len[q.pc] - (sp - q.a) - k;
-        const uint32_t len = std::min(q.len, 17u - 2u * k);  // (off & 15) + 2k + len <= 32: the compared bits are the window's
-        sub[8 * q.pc + q.u] = (2 * q.a) | ((32 - 2 * len) << 8) | ((2 * (off & 15u)) << 16) | ((off >> 4) << 24);
-      } else if (!q.right) {
-        sub[8 * q.pc + q.u] = (2 * q.a) | ((32 - 2 * q.len) << 8) | ((2 * (24u - (sp - q.a) - k)) << 16) | (0u << 24);
-      } else {
-        sub[8 * q.pc + q.u] = (2 * q.a) | ((32 - 2 * q.len) << 8) | ((2 * (8u + (q.a - pe) - k)) << 16) | (1u << 24);
-      }
-    }
-    // packed patterns: row j at bits 2j; with ambiguity letters a second word per pattern says which rows the test
-    // may compare (11: a concrete base, 00: a letter that stands for several -- such a row matches any character here)
-    std::vector<unsigned long long> ppk(npat * (care_words ? 2 : 1), 0ull);
+    // the table entries with their patterns' packed rows: row j at bits 2j; with care words a second pair says which
+    // rows the test may compare (11: a concrete base, 00: a letter that stands for several -- such a row matches
+    // any character here)
+    std::vector<unsigned long long> ppk(npat * 2, 0ull);
     for (size_t p = 0; p < npat; ++p)
       for (uint32_t j = 0; j < m; ++j) {
         if (!iupac_pats) {
-          ppk[p] |= (unsigned long long)((e->patterns[p][j] >> 1) & 3u) << (2 * j);
+          ppk[2 * p] |= (unsigned long long)((e->patterns[p][j] >> 1) & 3u) << (2 * j);
+          ppk[2 * p + 1] |= 3ull << (2 * j);
           continue;
         }
         const uint32_t set = base_set(e->patterns[p][j]);
         const bool one = set && !(set & (set - 1));
         const uint32_t code = one ? (set == 1 ? 0u : set == 2 ? 1u : set == 4 ? 2u : 3u) : 0u;
-        if (care_words) {
-          ppk[2 * p] |= (unsigned long long)code << (2 * j);
-          if (one) ppk[2 * p + 1] |= 3ull << (2 * j);
-        } else {
-          ppk[p] |= (unsigned long long)code << (2 * j);
-        }
+        ppk[2 * p] |= (unsigned long long)code << (2 * j);
+        if (one) ppk[2 * p + 1] |= 3ull << (2 * j);
+      }
+    std::vector<uint32_t> e16;
+    e16.reserve((care_words ? 8 : 4) * (entries[0].size() + entries[1].size()));
+    for (int t = 0; t < 2; ++t)
+      for (uint32_t en : entries[t]) {
+        const unsigned long long rows = ppk[2 * (en >> 3)], care = ppk[2 * (en >> 3) + 1];
+        e16.push_back(en); e16.push_back((uint32_t)rows); e16.push_back((uint32_t)(rows >> 32)); e16.push_back(0u);
+        if (care_words) { e16.push_back((uint32_t)care); e16.push_back((uint32_t)(care >> 32)); e16.push_back(0u); e16.push_back(0u); }
       }
     const uint64_t n16 = (text_len + 15) / 16;
     if (int rc = s->d_seed_sub.reserve(64)) return rc;
-    if (int rc = s->d_seed_ppk.reserve(ppk.size())) return rc;
+    if (int rc = s->d_seed_e16.reserve(e16.size() + 8)) return rc;
     if (int rc = s->d_seed_packed.reserve(n16 + 8)) return rc;
     HIP_TRY(hipMemcpyAsync(s->d_seed_sub.p, sub.data(), 64 * 4, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(s->d_seed_ppk.p, ppk.data(), ppk.size() * 8, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_seed_e16.p, e16.data(), e16.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->d_seed_packed.p + n16, 0, 8 * 4, st));
     hipError_t pe_ = launch_pack_text(tptr, text_len, s->d_seed_packed.p, st);
     if (pe_ != hipSuccess) return hip_fail(pe_, "text packing launch");
-    HIP_TRY(hipStreamSynchronize(st));  // (`sub`, `ppk` go out of scope)
+    HIP_TRY(hipStreamSynchronize(st));  // (`sub`, `e16` go out of scope)
     SP.sub = s->d_seed_sub.p;
     SP.packed_text = s->d_seed_packed.p;
-    SP.packed_pat = s->d_seed_ppk.p;
     SP.pat_care = care_words ? 1u : 0u;
-    if (narrow) {
-      std::vector<uint32_t> e16;
-      e16.reserve(4 * (entries[0].size() + entries[1].size()));
-      for (int t = 0; t < 2; ++t)
-        for (uint32_t en : entries[t]) {
-          const unsigned long long rows = ppk[en >> 3];
-          e16.push_back(en); e16.push_back((uint32_t)rows); e16.push_back((uint32_t)(rows >> 32)); e16.push_back(0u);
-        }
-      if (int rc = s->d_seed_e16.reserve(e16.size() + 4)) return rc;
-      HIP_TRY(hipMemcpyAsync(s->d_seed_e16.p, e16.data(), e16.size() * 4, hipMemcpyHostToDevice, st));
-      HIP_TRY(hipStreamSynchronize(st));  // (`e16` goes out of scope)
-      SP.entries16 = reinterpret_cast<const uint4*>(s->d_seed_e16.p);
-      SP.entries16_off1 = (uint32_t)entries[0].size();
-      SP.win_left = win_left;
-    }
+    SP.entries16 = reinterpret_cast<const uint4*>(s->d_seed_e16.p);
+    SP.entries16_off1 = (uint32_t)entries[0].size();
+    SP.win_left = win_left;
+    SP.win_dwords = narrow ? 4u : 5u;
   }
   SP.out_count = s->d_tiled_cnt.p;
   SP.hit_count = reinterpret_cast<unsigned long long*>(s->d_tiled_cnt.p + 4);

@@ -55,71 +55,102 @@ __global__ __launch_bounds__(256) void pack_text_kernel(const uint4* __restrict_
 // two neighbouring table offsets, one load (one line access of the vector cache instead of two)
 struct __attribute__((packed, aligned(4))) StartPair { uint32_t a, b; };
 
-// 64 bits = 32 characters of the packed text from character c on (c >= 0, the dwords exist)
-__device__ __forceinline__ unsigned long long packed_window(const uint32_t* packed, int64_t c) {
-  const uint32_t* src = packed + (c >> 4);
-  const uint32_t sh = 2u * ((uint32_t)c & 15u);
-  const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
-  const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-  return ((unsigned long long)hi << 32) | lo;
-}
-
-// The sub-piece test (SeedParams::sub): false = no alignment with <= k edits keeps this hit's piece intact.
+// The sub-piece test (common.h: SeedParams::sub): false = no alignment with <= k edits keeps this hit's piece intact.
 // KT >= 0: k is the compile-time constant KT (the loops over sub-pieces and shifts unroll), KT < 0: any k.
-// rows: SeedParams::sub staged in LDS (8 dwords per piece) -- the row decides whether the hit is tested at all, and
-// from global memory that answer was a round trip in front of the text loads.
-// MODE 1 (fast): every position fits 32 bits, the patterns hold no letters the test must not compare (no care words)
-// and k <= 3 (four pieces: their seed lengths in the low half of seed_len_packed): 32-bit arithmetic and offsets.
-template <int KT, int MODE>
-__device__ __forceinline__ bool sub_piece_test(const SeedParams& P, const uint32_t* rows, unsigned long long cand) {
-  constexpr bool FAST = MODE == 1;
-  const uint32_t entry = (uint32_t)cand & ((1u << kSeedPosShift) - 1u);
-  const uint32_t pat = entry >> 3, piece = entry & 7u;
-  const uint4 r0 = *reinterpret_cast<const uint4*>(rows + 8u * piece);
-  uint4 r1 = make_uint4(0, 0, 0, 0);
-  if (KT < 0 || KT > 3) r1 = *reinterpret_cast<const uint4*>(rows + 8u * piece + 4u);
-  unsigned long long pp, care = ~0ull, lo, hi;
-  bool inside;
-  if (FAST) {
-    const char* pats = reinterpret_cast<const char*>(P.packed_pat);
-    const char* text = reinterpret_cast<const char*>(P.packed_text);
-    pp = *reinterpret_cast<const unsigned long long*>(pats + (entry & ~7u));  // 8 pat
-    const uint32_t i = (uint32_t)(cand >> kSeedPosShift);
-    const uint32_t len = ((uint32_t)P.seed_len_packed >> (8u * piece)) & 0xFFu;
-    inside = i >= len + 24u && i + 24u <= (uint32_t)P.text_len;
-    const uint32_t cl = inside ? i - len - 24u : 0u, ch = inside ? i - 8u : 0u;
-    // 64 bits = 32 characters of the packed text from character c on
-    auto window = [&](uint32_t c) __attribute__((always_inline)) {
-      const uint32_t* src = reinterpret_cast<const uint32_t*>(text + ((c >> 4) << 2));
-      const uint32_t sh = 2u * (c & 15u);
-      const uint32_t d0 = src[0], d1 = src[1], d2 = src[2];
-      return ((unsigned long long)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);
-    };
-    lo = window(cl);
-    hi = window(ch);
+//
+// What bounds the seeded search is the latency and the number of the test's loads (a wave spent 60 % of its time
+// waiting for them; the vector cache takes one line access per lane and load), so:
+//   * the hit queue holds the INDEX of the hit's table entry (the pass over the text loads no entries);
+//   * entries16[index] = (pattern << 3 | piece, the pattern's packed rows) in one 16-byte record (with care words: 32
+//     bytes, the second half = 11 at the rows the test may compare), and ONE window of the packed text that starts
+//     win_left characters in front of the seed's end, whatever the piece: two loads per hit (three with care words),
+//     none of them waiting for another one;
+//   * the test comes in two halves: test_issue requests the loads of the next 64 hits, test_finish compares the
+//     batch before -- its loads were in flight while the batch before it was compared;
+//   * rows: SeedParams::sub staged in LDS (8 dwords per piece).
+// MODE 1 (narrow): every sub-piece starts within 32 characters of the window's start -- four dwords of text, the
+// 64 bits a sub-piece is compared in start in dword 0 or 1; no care words; positions fit 32 bits.
+// MODE 2 (wide): within 48 characters -- five dwords, 64 bits from dword 0, 1 or 2.  MODE 3: with care words.
+// MODE 4: with care words, positions of any size.
+// cand comes back as (position << kSeedPosShift) | pattern << 3 | piece, what the verification reads.
+struct TestLoads {
+  unsigned long long cand;
+  uint4 entry;         // (pattern << 3 | piece, packed rows lo, hi, -)
+  uint32_t care[2];
+  uint32_t d[5];       // the text window's dwords
+};
+template <int MODE>
+__device__ __forceinline__ TestLoads test_issue(const SeedParams& P, unsigned long long cand) {
+  TestLoads L;
+  L.cand = cand;
+  const uint32_t idx = (uint32_t)cand & ((1u << kSeedPosShift) - 1u);
+  const char* table = reinterpret_cast<const char*>(P.entries16);
+  const uint32_t* src;
+  if (MODE == 4) {
+    const uint64_t i = cand >> kSeedPosShift;
+    const uint64_t cl = i >= P.win_left ? i - P.win_left : 0u;
+    src = P.packed_text + (cl >> 4);
   } else {
-    // everything the test reads, requested at once: the pattern, the two text windows
-    pp = P.packed_pat[P.pat_care ? 2u * pat : pat];
-    if (P.pat_care) care = P.packed_pat[2u * pat + 1u];  // (wave-uniform branch)
-    const int64_t i = (int64_t)(cand >> kSeedPosShift);
-    const int64_t cl = i - (int64_t)((P.seed_len_packed >> (8u * piece)) & 0xFFu) - 24, ch = i - 8;
-    inside = cl >= 0 && ch + 32 <= (int64_t)P.text_len;
-    lo = packed_window(P.packed_text, inside ? cl : 0);
-    hi = packed_window(P.packed_text, inside ? ch : 0);
+    const uint32_t i = (uint32_t)(cand >> kSeedPosShift);
+    const uint32_t cl = i >= P.win_left ? i - P.win_left : 0u;
+    src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(P.packed_text) + ((cl >> 4) << 2));
   }
+  if (MODE >= 3) {
+    const uint4* e = reinterpret_cast<const uint4*>(table + ((uint64_t)idx << 5));
+    L.entry = e[0];
+    const uint2 c = *reinterpret_cast<const uint2*>(e + 1);
+    L.care[0] = c.x; L.care[1] = c.y;
+  } else {
+    L.entry = *reinterpret_cast<const uint4*>(table + (idx << 4));
+    L.care[0] = L.care[1] = 0xFFFFFFFFu;
+  }
+  L.d[0] = src[0]; L.d[1] = src[1]; L.d[2] = src[2]; L.d[3] = src[3];
+  L.d[4] = MODE >= 2 ? src[4] : 0u;
+  return L;
+}
+template <int KT, int MODE>
+__device__ __forceinline__ bool test_finish(const SeedParams& P, const uint32_t* rows, const TestLoads& L, unsigned long long& cand) {
+  bool inside;
+  uint32_t sh;  // bits of the window's first character in d[0]
+  if (MODE == 4) {
+    const uint64_t i = L.cand >> kSeedPosShift;
+    inside = i >= P.win_left;  // (beyond the text's end the packed copy holds zeros: a test that passes too often)
+    sh = 2u * ((uint32_t)(i - P.win_left) & 15u);
+  } else {
+    const uint32_t i = (uint32_t)(L.cand >> kSeedPosShift);
+    inside = i >= P.win_left;
+    sh = 2u * ((i - P.win_left) & 15u);
+  }
+  const uint4 E = L.entry;
+  cand = (L.cand & ~(unsigned long long)((1u << kSeedPosShift) - 1u)) | E.x;
+  const uint4 r0 = *reinterpret_cast<const uint4*>(rows + 8u * (E.x & 7u));
+  uint4 r1 = make_uint4(0, 0, 0, 0);
+  if (KT < 0 || KT > 3) r1 = *reinterpret_cast<const uint4*>(rows + 8u * (E.x & 7u) + 4u);
   if ((r0.x & 0xFFu) == 0xFFu || !inside) return true;  // untested
+  // the window's characters from its start on, 16 per dword
+  uint32_t x[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) x[j] = (j < 3 || MODE >= 2) ? __builtin_amdgcn_alignbit(L.d[j + 1], L.d[j], sh) : 0u;
+  const unsigned long long pp = ((unsigned long long)E.z << 32) | E.y;
+  const unsigned long long care = ((unsigned long long)L.care[1] << 32) | L.care[0];
   const uint32_t ent[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
   const uint32_t k = KT >= 0 ? (uint32_t)KT : P.k;
   uint32_t miss = 0xFFFFFFFFu;  // minimum over all (sub-piece, shift) of the differing bits: 0 = one of them is intact
 #pragma unroll
   for (uint32_t u = 0; u < 8; ++u) {
     if (u <= k) {
-      // row fields (host.hip): 2a | (32 - 2 len) << 8 | 2 (c0 - k) << 16 | side << 24
+      // row fields (host.hip): 2a | (32 - 2 len) << 8 | 2 (off & 15) << 16 | (off >> 4) << 24
       const uint32_t want = (uint32_t)(pp >> (ent[u] & 0xFFu));
       uint32_t mask = 0xFFFFFFFFu >> ((ent[u] >> 8) & 0xFFu);
-      if (!FAST) mask &= (uint32_t)(care >> (ent[u] & 0xFFu));
+      if (MODE >= 3) mask &= (uint32_t)(care >> (ent[u] & 0xFFu));
       // the window from the leftmost shift on; every further shift is two bits down
-      const unsigned long long w = ((ent[u] >> 24) ? hi : lo) >> ((ent[u] >> 16) & 0xFFu);
+      const uint32_t which = ent[u] >> 24;
+      uint32_t w0 = which ? x[1] : x[0], w1 = which ? x[2] : x[1];
+      if (MODE >= 2) {
+        w0 = which > 1u ? x[2] : w0;
+        w1 = which > 1u ? x[3] : w1;
+      }
+      const unsigned long long w = (((unsigned long long)w1 << 32) | w0) >> ((ent[u] >> 16) & 0xFFu);
       const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
       if (KT >= 0) {
 #pragma unroll
@@ -130,63 +161,6 @@ __device__ __forceinline__ bool sub_piece_test(const SeedParams& P, const uint32
       } else {
         for (uint32_t d = 0; d <= 2u * k; ++d) miss = min(miss, (__builtin_amdgcn_alignbit(wh, wl, 2u * d) ^ want) & mask);
       }
-    }
-  }
-  return miss == 0u;
-}
-
-// MODE 2 (narrow; the conditions of MODE 1, and every sub-piece of every piece within 48 characters -- 10 000 20-mers):
-// the kernel is bound by the vector cache's rate of line accesses (one per lane and load: entry, pattern, two text
-// windows, table rows -- 4.2 per hit measured, ~1 per cycle and CU), so this path makes two per hit and has them in
-// flight together.  The queue holds the INDEX of the hit's table entry; the test reads entry16[index] = (pattern << 3 |
-// piece, the pattern's packed rows) and ONE window of 4 dwords of the packed text that starts win_left characters in
-// front of the seed's end, whatever the piece.  Row fields: 2a | (32 - 2 len) << 8 | 2 (off & 15) << 16 |
-// (off >> 4) << 24, off = the sub-piece's leftmost shift in characters from the window's start (< 32).
-// cand comes back as (position << kSeedPosShift) | pattern << 3 | piece, what the verification reads.
-// The test comes in two halves so that the kernel can have the loads of the next 64 hits in flight while it compares
-// this batch (a wave spent 60 % of its time waiting for these two loads).
-struct NarrowLoads {
-  unsigned long long cand;
-  uint4 entry;            // entries16[index]
-  uint32_t d0, d1, d2, d3;  // the text window's dwords
-};
-__device__ __forceinline__ NarrowLoads narrow_issue(const SeedParams& P, unsigned long long cand) {
-  NarrowLoads L;
-  L.cand = cand;
-  const uint32_t idx = (uint32_t)cand & ((1u << kSeedPosShift) - 1u);
-  const uint32_t i = (uint32_t)(cand >> kSeedPosShift);
-  const uint32_t cl = i >= P.win_left ? i - P.win_left : 0u;
-  L.entry = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(P.entries16) + (idx << 4));
-  const uint32_t* src = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(P.packed_text) + ((cl >> 4) << 2));
-  L.d0 = src[0]; L.d1 = src[1]; L.d2 = src[2]; L.d3 = src[3];
-  return L;
-}
-template <int KT>
-__device__ __forceinline__ bool narrow_finish(const SeedParams& P, const uint32_t* rows, const NarrowLoads& L, unsigned long long& cand) {
-  static_assert(KT >= 0 && KT <= 3, "narrow test: k <= 3");
-  const uint32_t i = (uint32_t)(L.cand >> kSeedPosShift);
-  const bool inside = i >= P.win_left;  // (beyond the text's end the packed copy holds zeros: a test that passes too often)
-  const uint32_t sh = 2u * ((i - P.win_left) & 15u);
-  const uint32_t x0 = __builtin_amdgcn_alignbit(L.d1, L.d0, sh), x1 = __builtin_amdgcn_alignbit(L.d2, L.d1, sh),
-                 x2 = __builtin_amdgcn_alignbit(L.d3, L.d2, sh);  // 48 characters from the window's start on
-  const uint4 E = L.entry;
-  cand = (L.cand & ~(unsigned long long)((1u << kSeedPosShift) - 1u)) | E.x;
-  const uint4 r0 = *reinterpret_cast<const uint4*>(rows + 8u * (E.x & 7u));
-  if ((r0.x & 0xFFu) == 0xFFu || !inside) return true;  // untested
-  const unsigned long long pp = ((unsigned long long)E.z << 32) | E.y;
-  const uint32_t ent[4] = {r0.x, r0.y, r0.z, r0.w};
-  uint32_t miss = 0xFFFFFFFFu;
-#pragma unroll
-  for (uint32_t u = 0; u <= (uint32_t)KT; ++u) {
-    const uint32_t want = (uint32_t)(pp >> (ent[u] & 0xFFu));
-    const uint32_t mask = 0xFFFFFFFFu >> ((ent[u] >> 8) & 0xFFu);
-    const bool far = (ent[u] >> 24) != 0u;
-    const unsigned long long w = (((unsigned long long)(far ? x2 : x1) << 32) | (far ? x1 : x0)) >> ((ent[u] >> 16) & 0xFFu);
-    const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
-#pragma unroll
-    for (uint32_t d = 0; d <= 2u * (uint32_t)KT; ++d) {
-      const uint32_t got = d == 0 ? wl : __builtin_amdgcn_alignbit(wh, wl, 2u * d);
-      miss = min(miss, (got ^ want) & mask);
     }
   }
   return miss == 0u;
@@ -323,19 +297,22 @@ __device__ __noinline__ void verify_candidate(const VerifyArgs P, unsigned long 
 
 // One wave walks a contiguous range of the text, 2 KiB per step: lane l takes the 32 characters [g, g + 32),
 // g = step base + 32 l, plus the 16 in front of them (seeds that end in its characters start there).
-// KT: the sub-piece test's k (>= 0: compile-time, -1: run-time, -2: no test).
+// KT: the sub-piece test's k (>= 0: compile-time, -1: run-time, -2: no test); MODE: the test's layout (0: no test).
 template <int WORDS, int KT, int MODE>
 __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
-  constexpr bool NARROW = MODE == 2;
+  static_assert((KT < -1) == (MODE == 0), "a test needs a layout");
+  constexpr bool TEST = MODE != 0;
   constexpr uint32_t kTurn = 4;
-  __shared__ unsigned long long queue_mem[kWavesPerGroup][128], pass_mem[kWavesPerGroup][128];
+  // with a test the hit queue takes a position's hits of all lanes before any of them is tested
+  constexpr uint32_t kRing = TEST ? 256 : 128;
+  __shared__ unsigned long long queue_mem[kWavesPerGroup][kRing], pass_mem[kWavesPerGroup][128];
   // "does any pattern have a seed that ends like this?" -- one bit per min(len, 8)-gram and table (<= 2 x 8 KiB): with
   // few patterns nearly every position fails it and never reads the tables in global memory
   __shared__ uint32_t bits_lds[2 * 2048];
   for (uint32_t x = threadIdx.x; x < P.bits_off[1] + (P.len[1] ? (1u << (2 * (P.len[1] < 8 ? P.len[1] : 8))) / 32 : 0); x += blockDim.x)
     bits_lds[x] = P.seed_bits[x];
   __shared__ __attribute__((aligned(16))) uint32_t sub_rows[64];
-  if (KT >= -1 && threadIdx.x < 64) sub_rows[threadIdx.x] = P.sub[threadIdx.x];
+  if (TEST && threadIdx.x < 64) sub_rows[threadIdx.x] = P.sub[threadIdx.x];
   __syncthreads();
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave_in_group = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -348,17 +325,17 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
   if (s_lo >= s_hi) return;
   unsigned long long* queue = queue_mem[wave_in_group];
   unsigned long long* passed = pass_mem[wave_in_group];
-  // both queues are rings of 128 entries: [head, head + count) modulo 128
+  // both queues are rings (of kRing and 128 entries): [head, head + count) modulo their size
   uint32_t queued = 0, n_passed = 0, q_head = 0, p_head = 0;  // wave-uniform
   uint64_t n_hits = 0, n_pass = 0;
 
   // verify the first `count` hits of `from`, one per lane (the window of a hit near the text's ends needs range checks)
-  auto verify_from = [&](const unsigned long long* from, uint32_t head, uint32_t count) __attribute__((always_inline)) {
+  auto verify_from = [&](const unsigned long long* from, uint32_t head, uint32_t count, uint32_t ring = 128) __attribute__((always_inline)) {
     const bool have = lane < count;
     unsigned long long cand = 0;
     bool edge = false;
     if (have) {
-      cand = from[(head + lane) & 127u];
+      cand = from[(head + lane) & (ring - 1u)];
       const int64_t i = (int64_t)(cand >> kSeedPosShift);
       const int64_t e_hi = i + (int64_t)((P.rem_packed >> (8u * ((uint32_t)cand & 7u))) & 0xFFu) + (int64_t)P.k;
       const int64_t s0 = e_hi - ((int64_t)P.m + 3 * (int64_t)P.k + 1);
@@ -376,9 +353,8 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
   };
   // The first `count` queued hits, one per lane: with the sub-piece test (WORDS == 1, P.sub) the few that pass it
   // collect in a second queue and are verified 64 at a time, else they are verified at once.
-  // (narrow layout: the batch whose loads are in flight -- narrow_issue -- and its size; compared when the next one's
-  // loads have been issued)
-  NarrowLoads pend{};
+  // the batch whose loads are in flight (test_issue) and its size; compared when the next one's loads have been issued
+  TestLoads pend{};
   uint32_t pend_n = 0;  // wave-uniform
   auto passed_push = [&](bool ok, unsigned long long cand) __attribute__((always_inline)) {
     const unsigned long long m = __ballot(ok);
@@ -393,37 +369,27 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
       n_passed -= 64;
     }
   };
-  auto verify = [&](uint32_t count) __attribute__((always_inline)) {
-    if (KT < -1) { verify_from(queue, q_head, count); return; }
-    if constexpr (NARROW) {
-      const NarrowLoads next = narrow_issue(P, lane < count ? queue[(q_head + lane) & 127u] : 0ull);
-      if (pend_n) {
-        unsigned long long cand = 0;
-        bool ok = false;
-        if (lane < pend_n) ok = narrow_finish<KT>(P, sub_rows, pend, cand);
-        passed_push(ok, cand);
-      }
-      pend = next;
-      pend_n = count;
-    } else {
-      bool ok = false;
+  auto verify_pending = [&]() __attribute__((always_inline)) {
+    if (pend_n) {
       unsigned long long cand = 0;
-      if (lane < count) {
-        cand = queue[(q_head + lane) & 127u];
-        ok = sub_piece_test<KT, MODE>(P, sub_rows, cand);
-      }
+      bool ok = false;
+      if (lane < pend_n) ok = test_finish<KT, MODE>(P, sub_rows, pend, cand);
       passed_push(ok, cand);
     }
   };
+  auto verify = [&](uint32_t count) __attribute__((always_inline)) {
+    if constexpr (!TEST) verify_from(queue, q_head, count, kRing);
+    else {
+      const TestLoads next = test_issue<MODE>(P, lane < count ? queue[(q_head + lane) & (kRing - 1u)] : 0ull);
+      verify_pending();
+      pend = next;
+      pend_n = count;
+    }
+  };
   auto verify_drain = [&]() __attribute__((always_inline)) {
-    if constexpr (NARROW) {
-      if (pend_n) {
-        unsigned long long cand = 0;
-        bool ok = false;
-        if (lane < pend_n) ok = narrow_finish<KT>(P, sub_rows, pend, cand);
-        passed_push(ok, cand);
-        pend_n = 0;
-      }
+    if constexpr (TEST) {
+      verify_pending();
+      pend_n = 0;
     }
   };
 
@@ -475,32 +441,60 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
       look_up(j + 1, xa0, xb0, xa1, xb1);
       const uint64_t end = g + j + 1;
       const uint32_t n0 = b0 - a0, n = n0 + (b1 - a1);
-      // the hits of this position, kTurn per lane and turn: their entry loads are in flight together
-      for (uint32_t r0 = 0; __ballot(r0 < n) != 0; r0 += kTurn) {
-        uint32_t ent[kTurn];
-#pragma unroll
-        for (uint32_t x = 0; x < kTurn; ++x) {
-          const uint32_t r = r0 + x;
-          ent[x] = 0;
-          if (NARROW) ent[x] = r < n0 ? a0 + r : P.entries16_off1 + a1 + (r - n0);  // the entry's index: read by the test
-          else if (r < n) ent[x] = r < n0 ? P.entries[0][a0 + r] : P.entries[1][a1 + (r - n0)];
-        }
-#pragma unroll
-        for (uint32_t x = 0; x < kTurn; ++x) {
-          const bool active = r0 + x < n;
-          const unsigned long long m = __ballot(active);
-          if (m == 0) break;
-          if (active) {
-            const uint32_t slot = q_head + queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            queue[slot & 127u] = ((unsigned long long)end << kSeedPosShift) | ent[x];
+      if constexpr (TEST) {
+        // The hits of this position: first all of them into the queue (one per lane and turn: the index of its table
+        // entry, nothing to load), then the full batches out of it -- a tight loop in front of the one that carries
+        // the batch in flight.
+        const uint32_t rest = P.entries16_off1 + a1 - n0;  // hit r >= n0 is entry rest + r
+        uint32_t r = 0;
+        bool more = true;
+        while (more) {
+          for (;; ++r) {
+            const bool active = r < n;
+            const unsigned long long m = __ballot(active);
+            more = m != 0;
+            if (!more || queued > kRing - 64u) break;
+            if (active) {
+              const uint32_t slot = q_head + queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+              queue[slot & (kRing - 1u)] = ((unsigned long long)end << kSeedPosShift) | (r + (r < n0 ? a0 : rest));
+            }
+            queued += (uint32_t)__popcll(m);
           }
-          queued += (uint32_t)__popcll(m);
           __builtin_amdgcn_wave_barrier();
-          if (queued >= 64) {
+          while (queued >= 64) {
             verify(64);
-            q_head = (q_head + 64u) & 127u;
+            q_head = (q_head + 64u) & (kRing - 1u);
             queued -= 64;
             n_hits += 64;
+          }
+        }
+      } else {
+        // the hits of this position, kTurn per lane and turn: their entry loads are in flight together
+        for (uint32_t r0 = 0; __ballot(r0 < n) != 0; r0 += kTurn) {
+          uint32_t ent[kTurn];
+#pragma unroll
+          for (uint32_t x = 0; x < kTurn; ++x) {
+            const uint32_t r = r0 + x;
+            ent[x] = 0;
+            if (r < n) ent[x] = r < n0 ? P.entries[0][a0 + r] : P.entries[1][a1 + (r - n0)];
+          }
+#pragma unroll
+          for (uint32_t x = 0; x < kTurn; ++x) {
+            const bool active = r0 + x < n;
+            const unsigned long long m = __ballot(active);
+            if (m == 0) break;
+            if (active) {
+              const uint32_t slot = q_head + queued + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+              queue[slot & (kRing - 1u)] = ((unsigned long long)end << kSeedPosShift) | ent[x];
+            }
+            queued += (uint32_t)__popcll(m);
+            __builtin_amdgcn_wave_barrier();
+            if (queued >= 64) {
+              verify(64);
+              q_head = (q_head + 64u) & (kRing - 1u);
+              queued -= 64;
+              n_hits += 64;
+            }
           }
         }
       }
@@ -684,24 +678,24 @@ hipError_t launch_pack_text(const uint8_t* d_text, uint64_t n, uint32_t* d_packe
 hipError_t launch_seed_search(const SeedParams& P, uint32_t grid, hipStream_t stream) {
   if (P.text_len == 0 || grid == 0) return hipSuccess;
   const dim3 g(grid), b(256);
-  // (modes: see sub_piece_test, sub_piece_test_narrow)
-  const bool fast = P.sub != nullptr && !P.pat_care && P.k <= 3 && P.text_len < 0xFFFF0000ull;
-  const int mode = fast && P.entries16 ? 2 : fast ? 1 : 0;
+  // (modes: see test_issue)
+  const int mode = P.sub == nullptr ? 0 : P.text_len >= 0xFFFF0000ull ? 4 : P.pat_care ? 3 : P.win_dwords == 4 ? 1 : 2;
   if (P.m > 32) hipLaunchKernelGGL((seed_search_kernel<2, -2, 0>), g, b, 0, stream, P);
-  else if (P.sub == nullptr) hipLaunchKernelGGL((seed_search_kernel<1, -2, 0>), g, b, 0, stream, P);
-  else if (P.k > 3) hipLaunchKernelGGL((seed_search_kernel<1, -1, 0>), g, b, 0, stream, P);
+  else if (mode == 0) hipLaunchKernelGGL((seed_search_kernel<1, -2, 0>), g, b, 0, stream, P);
   else {
 #define SASSY_SEED_LAUNCH(K, M) hipLaunchKernelGGL((seed_search_kernel<1, K, M>), g, b, 0, stream, P)
 #define SASSY_SEED_MODES(K)                       \
   do {                                            \
-    if (mode == 2) SASSY_SEED_LAUNCH(K, 2);       \
-    else if (mode == 1) SASSY_SEED_LAUNCH(K, 1);  \
-    else SASSY_SEED_LAUNCH(K, 0);                 \
+    if (mode == 1) SASSY_SEED_LAUNCH(K, 1);       \
+    else if (mode == 2) SASSY_SEED_LAUNCH(K, 2);  \
+    else if (mode == 3) SASSY_SEED_LAUNCH(K, 3);  \
+    else SASSY_SEED_LAUNCH(K, 4);                 \
   } while (0)
     if (P.k == 0) SASSY_SEED_MODES(0);
     else if (P.k == 1) SASSY_SEED_MODES(1);
     else if (P.k == 2) SASSY_SEED_MODES(2);
-    else SASSY_SEED_MODES(3);
+    else if (P.k == 3) SASSY_SEED_MODES(3);
+    else SASSY_SEED_MODES(-1);
 #undef SASSY_SEED_MODES
 #undef SASSY_SEED_LAUNCH
   }

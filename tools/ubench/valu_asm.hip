@@ -58,6 +58,15 @@ DEFK(k_fma, "v_fma_f32 v100, v101, v102, v103\n v_fma_f32 v104, v105, v106, v107
 DEFK(k_lshl2, "v_lshlrev_b32 v100, 1, v101\n v_lshrrev_b32 v104, 31, v105\n v_lshlrev_b32 v108, 1, v109\n v_lshrrev_b32 v112, 31, v113\n"
               "v_lshlrev_b32 v116, 1, v117\n v_lshrrev_b32 v120, 31, v121\n v_lshlrev_b32 v102, 1, v103\n v_lshrrev_b32 v106, 31, v107\n")
 
+DEFK(k_shr64, "v_lshrrev_b64 v[100:101], v102, v[104:105]\n v_lshrrev_b64 v[106:107], v108, v[110:111]\n v_lshrrev_b64 v[112:113], v114, v[116:117]\n v_lshrrev_b64 v[118:119], v120, v[122:123]\n"
+              "v_lshrrev_b64 v[102:103], v104, v[106:107]\n v_lshrrev_b64 v[108:109], v110, v[112:113]\n v_lshrrev_b64 v[114:115], v116, v[118:119]\n v_lshrrev_b64 v[120:121], v122, v[100:101]\n")
+DEFK(k_min3, "v_min3_u32 v100, v101, v102, v103\n v_min3_u32 v104, v105, v106, v107\n v_min3_u32 v108, v109, v110, v111\n v_min3_u32 v112, v113, v114, v115\n"
+             "v_min3_u32 v116, v117, v118, v119\n v_min3_u32 v120, v121, v122, v123\n v_min3_u32 v101, v102, v103, v104\n v_min3_u32 v105, v106, v107, v108\n")
+DEFK(k_alignbit_v, "v_alignbit_b32 v100, v101, v102, v103\n v_alignbit_b32 v104, v105, v106, v107\n v_alignbit_b32 v108, v109, v110, v111\n v_alignbit_b32 v112, v113, v114, v115\n"
+                   "v_alignbit_b32 v116, v117, v118, v119\n v_alignbit_b32 v120, v121, v122, v123\n v_alignbit_b32 v101, v102, v103, v104\n v_alignbit_b32 v105, v106, v107, v108\n")
+DEFK(k_mov64, "v_mov_b64 v[100:101], v[102:103]\n v_mov_b64 v[104:105], v[106:107]\n v_mov_b64 v[108:109], v[110:111]\n v_mov_b64 v[112:113], v[114:115]\n"
+              "v_mov_b64 v[116:117], v[118:119]\n v_mov_b64 v[120:121], v[122:123]\n v_mov_b64 v[102:103], v[104:105]\n v_mov_b64 v[106:107], v[108:109]\n")
+
 template <typename K> void run(const char* name, K kern, unsigned* d, int waves_per_simd) {
   const int iters = 2048, grid = 256 * waves_per_simd;  // blocks of 256 = 4 waves = 1 per SIMD
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
@@ -78,6 +87,10 @@ int main() {
     run("v_bitop3 (same bank)", k_bitop3_conf, d, w);
     run("v_bitop3 (2 distinct src)", k_bitop3_2src, d, w);
     run("v_alignbit", k_alignbit, d, w);
+    run("v_alignbit (shift in a VGPR)", k_alignbit_v, d, w);
+    run("v_lshrrev_b64", k_shr64, d, w);
+    run("v_min3_u32", k_min3, d, w);
+    run("v_mov_b64", k_mov64, d, w);
     run("v_lshl_or", k_lshl_or, d, w);
     run("v_lshl_add_u64", k_add64, d, w);
     run("v_add_co+v_addc_co (per instr)", k_addc, d, w);
