@@ -3619,6 +3619,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   // must start, at its leftmost shift, within 48 characters of that -- the largest reach <= 24 - k that allows it.
   static const bool env_sub = !(getenv("SASSY_HIP_SEED_SUBTEST") && atoi(getenv("SASSY_HIP_SEED_SUBTEST")) == 0);
   static const bool env_narrow = !(getenv("SASSY_HIP_SEED_NARROW") && atoi(getenv("SASSY_HIP_SEED_NARROW")) == 0);
+  static const bool env_pos64 = getenv("SASSY_HIP_SEED_POS64") && atoi(getenv("SASSY_HIP_SEED_POS64")) != 0;  // (tests)
   if (!wide && env_sub) {
     struct SubPiece { uint32_t pc, u, a, len, off; };
     std::vector<SubPiece> subs;
@@ -3657,7 +3658,8 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     }
     // (an Iupac searcher whose patterns are all plain bases -- 10 000 random 20-mers -- needs no care words; the
     // kernel for positions beyond 32 bits always reads them)
-    bool care_words = text_len >= 0xFFFF0000ull;
+    const bool pos64 = env_pos64 || text_len >= 0xFFFF0000ull;
+    bool care_words = pos64;
     if (iupac_pats)
       for (size_t p = 0; p < npat && !care_words; ++p)
         for (uint32_t j = 0; j < m; ++j) {
@@ -3713,6 +3715,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     SP.entries16_off1 = (uint32_t)entries[0].size();
     SP.win_left = win_left;
     SP.win_dwords = narrow ? 4u : 5u;
+    SP.pos64 = pos64 ? 1u : 0u;
   }
   SP.out_count = s->d_tiled_cnt.p;
   SP.hit_count = reinterpret_cast<unsigned long long*>(s->d_tiled_cnt.p + 4);

@@ -679,7 +679,7 @@ hipError_t launch_seed_search(const SeedParams& P, uint32_t grid, hipStream_t st
   if (P.text_len == 0 || grid == 0) return hipSuccess;
   const dim3 g(grid), b(256);
   // (modes: see test_issue)
-  const int mode = P.sub == nullptr ? 0 : P.text_len >= 0xFFFF0000ull ? 4 : P.pat_care ? 3 : P.win_dwords == 4 ? 1 : 2;
+  const int mode = P.sub == nullptr ? 0 : P.pos64 ? 4 : P.pat_care ? 3 : P.win_dwords == 4 ? 1 : 2;
   if (P.m > 32) hipLaunchKernelGGL((seed_search_kernel<2, -2, 0>), g, b, 0, stream, P);
   else if (mode == 0) hipLaunchKernelGGL((seed_search_kernel<1, -2, 0>), g, b, 0, stream, P);
   else {

@@ -2728,6 +2728,24 @@ def test_forced_kernel_paths(sassy, env):
     print(env, r.stdout.strip().splitlines()[-1])
 
 
+@pytest.mark.parametrize("env", [{"SASSY_HIP_SEED_NARROW": "0"}, {"SASSY_HIP_SEED_POS64": "1"}, {"SASSY_HIP_SEED_SUBTEST": "0"}],
+                         ids=lambda e: ",".join(f"{k[10:]}={v}" for k, v in e.items()))
+def test_seeded_search_forced_test_layouts(sassy, env):
+    """The seeded search's sub-piece test picks its layout by shape and text (seed_kernels.hip: test_issue -- narrow,
+    wide, with care words, positions beyond 32 bits) or is off; the switches are read once per process, so the seeded
+    tests run once more under each forced layout in a process of their own."""
+    import subprocess
+    e = {k_: v for k_, v in os.environ.items() if not k_.startswith("SASSY_HIP_")}
+    e.update(env)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
+                        "-p", "no:cacheprovider", "-k", "test_encoded_seeded or test_encoded_kats_through_hip or "
+                        "test_overhang_many_patterns_in_one_pass"], env=e, cwd=root, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout[-3000:] + r.stderr[-1500:])
+    assert r.returncode == 0, (env, tail)
+    assert " passed" in r.stdout and "failed" not in r.stdout, (env, tail)
+
+
 def test_synchronous_calls_are_refused_while_a_ticket_is_open(sassy):
     """A search begun with search_shard_begin owns a lane's stream and result buffers until it is finished: the
     synchronous entry points of the same searcher must not run in between (they would overwrite what finish() reads)."""
