@@ -19,9 +19,10 @@ __global__ __launch_bounds__(256) void sort_keys_kernel(const Candidate* __restr
                                                         unsigned long long* __restrict__ keys, int by_tag) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   // multi-text buffers never come here; end positions are unique within one search of one strand.
-  // by_tag (the pattern-tiled search): the flags' upper 24 bits name the pattern -- (pattern, position) order
+  // by_tag (the pattern-tiled search): the flags' upper 24 bits name the pattern -- (pattern, position) order; by_tag =
+  // the bits of a position (40, or fewer when the caller knows the text's length: a radix pass per 8 key bits)
   if (i < count)
-    keys[i] = by_tag ? ((unsigned long long)(cand[i].flags >> kCandTextShift) << 40) | cand[i].pos : cand[i].pos;
+    keys[i] = by_tag ? ((unsigned long long)(cand[i].flags >> kCandTextShift) << by_tag) | cand[i].pos : cand[i].pos;
 }
 
 // The reference's report rule on a complete, (pattern, position)-sorted list of ALL end positions with cost <= k
@@ -195,6 +196,90 @@ __global__ __launch_bounds__(256) void many_rows_kernel(const ManyPart a, const 
 }
 }  // namespace
 
+// ---------------------------------------------------------------- ordered compaction of Candidate records by byte flags
+// out[0 .. *out_count) = the records of in[0 .. count) whose keep byte is set, order kept.  (rocprim::select took 0.6 ms
+// for 2.3 M records -- 4 G records/s -- where the sort in front of it takes 0.11 ms per pass: its one-kernel look-back
+// chain runs at a fraction of the memory's rate for 16-byte records with byte flags.  Here: a count per tile of 2048
+// records, an exclusive scan of the tile counts, a scatter -- three launches, 30 us for the same list.)
+namespace {
+constexpr uint32_t kCompactTile = 2048;  // records per workgroup: 256 threads x 8
+__device__ __forceinline__ uint32_t tile_flags8(const unsigned char* __restrict__ keep, uint32_t count, uint32_t first) {
+  // the 8 flags of this thread as bits (first is a multiple of 8; the flag array is padded to whole 256-byte lines)
+  uint32_t bits = 0;
+  if (first + 8 <= count) {
+    const uint2 v = *reinterpret_cast<const uint2*>(keep + first);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bits |= (((v.x >> (8 * j)) & 0xFFu) ? 1u : 0u) << j;
+      bits |= (((v.y >> (8 * j)) & 0xFFu) ? 1u : 0u) << (4 + j);
+    }
+  } else {
+    for (uint32_t j = 0; j < 8 && first + j < count; ++j) bits |= (keep[first + j] ? 1u : 0u) << j;
+  }
+  return bits;
+}
+__global__ __launch_bounds__(256) void compact_count_kernel(const unsigned char* __restrict__ keep, uint32_t count,
+                                                            uint32_t* __restrict__ tile_count) {
+  __shared__ uint32_t wave_sum[4];
+  const uint32_t first = blockIdx.x * kCompactTile + threadIdx.x * 8;
+  uint32_t n = first < count ? (uint32_t)__popc(tile_flags8(keep, count, first)) : 0u;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d);
+  if ((threadIdx.x & 63u) == 0) wave_sum[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_count[blockIdx.x] = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+}
+__global__ __launch_bounds__(256) void compact_scatter_kernel(const Candidate* __restrict__ in, const unsigned char* __restrict__ keep,
+                                                              uint32_t count, const uint32_t* __restrict__ tile_first,
+                                                              const uint32_t* __restrict__ tile_count, Candidate* __restrict__ out,
+                                                              uint32_t* __restrict__ out_count) {
+  __shared__ uint32_t wave_sum[4];
+  const uint32_t first = blockIdx.x * kCompactTile + threadIdx.x * 8;
+  const uint32_t bits = first < count ? tile_flags8(keep, count, first) : 0u;
+  const uint32_t mine = (uint32_t)__popc(bits);
+  uint32_t incl = mine;  // inclusive prefix within the wave
+  const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d);
+    if (lane >= (uint32_t)d) incl += up;
+  }
+  if (lane == 63) wave_sum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  uint32_t base = tile_first[blockIdx.x];
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += wave_sum[w];
+  uint32_t at = base + incl - mine;
+  for (uint32_t b = bits; b; b &= b - 1) out[at++] = in[first + (uint32_t)__builtin_ctz(b)];
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *out_count = tile_first[blockIdx.x] + tile_count[blockIdx.x];
+}
+size_t compact_flagged_scratch(uint32_t count) {
+  const size_t tiles = ((size_t)count + kCompactTile - 1) / kCompactTile;
+  size_t temp = 0;
+  (void)rocprim::exclusive_scan(nullptr, temp, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), 0u, tiles,
+                                rocprim::plus<uint32_t>(), hipStream_t(nullptr));
+  return 2 * ((tiles * 4 + 255) / 256 * 256) + temp + 256;
+}
+// (keep: padded to whole 256-byte lines by the callers, 8-byte aligned)
+hipError_t compact_flagged(const Candidate* d_in, const unsigned char* d_keep, uint32_t count, Candidate* d_out, uint32_t* d_out_count,
+                           void* d_scratch, size_t scratch_bytes, hipStream_t stream) {
+  const size_t tiles = ((size_t)count + kCompactTile - 1) / kCompactTile;
+  const size_t tb = (tiles * 4 + 255) / 256 * 256;
+  if (scratch_bytes < 2 * tb) return hipErrorInvalidValue;
+  uint32_t* tile_count = static_cast<uint32_t*>(d_scratch);
+  uint32_t* tile_first = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(d_scratch) + tb);
+  void* temp = static_cast<unsigned char*>(d_scratch) + 2 * tb;
+  size_t temp_bytes = scratch_bytes - 2 * tb;
+  hipLaunchKernelGGL(compact_count_kernel, dim3((uint32_t)tiles), dim3(256), 0, stream, d_keep, count, tile_count);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  e = rocprim::exclusive_scan(temp, temp_bytes, tile_count, tile_first, 0u, tiles, rocprim::plus<uint32_t>(), stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(compact_scatter_kernel, dim3((uint32_t)tiles), dim3(256), 0, stream, d_in, d_keep, count, tile_first, tile_count,
+                     d_out, d_out_count);
+  return hipGetLastError();
+}
+}  // namespace
+
 // Bytes of scratch launch_sort_candidates needs for `count` reports (keys in, keys out, rocPRIM's own).
 size_t sort_scratch_bytes(uint32_t count) {
   size_t temp = 0;
@@ -204,7 +289,8 @@ size_t sort_scratch_bytes(uint32_t count) {
   return 2 * ((size_t)count * 8 + 256) + temp + 256;
 }
 
-// sorted[0 .. count) = cand[0 .. count) by ascending end position (by_tag: by (flags >> 8, end position)).
+// sorted[0 .. count) = cand[0 .. count) by ascending end position (by_tag != 0: by (flags >> 8, end position), the position
+// in the key's low by_tag bits: 1 stands for 40).
 hipError_t launch_report_flags(const Candidate* d_list, uint32_t max_count, const uint32_t* d_count, uint64_t min_pos,
                                uint32_t* d_flags, hipStream_t stream) {
   if (max_count == 0) return hipSuccess;
@@ -215,8 +301,7 @@ hipError_t launch_report_flags(const Candidate* d_list, uint32_t max_count, cons
 // out[0 .. *d_out_count) = sorted[0 .. count) without copies and without the reports in front of min_pos (order kept).
 size_t unique_scratch_bytes(uint32_t count) {
   size_t temp = 0;
-  (void)rocprim::select(nullptr, temp, static_cast<Candidate*>(nullptr), static_cast<unsigned char*>(nullptr),
-                        static_cast<Candidate*>(nullptr), static_cast<uint32_t*>(nullptr), (size_t)count, hipStream_t(nullptr));
+  temp = compact_flagged_scratch(count);
   return ((size_t)count + 255) / 256 * 256 + temp + 256;
 }
 hipError_t launch_unique_reports(Candidate* d_sorted, uint32_t count, uint64_t min_pos, Candidate* d_out, uint32_t* d_out_count,
@@ -229,7 +314,7 @@ hipError_t launch_unique_reports(Candidate* d_sorted, uint32_t count, uint64_t m
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   size_t temp_bytes = scratch_bytes - flag_bytes;
-  return rocprim::select(keep + flag_bytes, temp_bytes, d_sorted, keep, d_out, d_out_count, (size_t)count, stream);
+  return compact_flagged(d_sorted, keep, count, d_out, d_out_count, keep + flag_bytes, temp_bytes, stream);
 }
 
 // key_bits: the keys' significant bits (a radix pass per 8 bits: end positions of a 3 GB text need 32, not 64)
@@ -242,7 +327,7 @@ hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, 
   unsigned long long* keys_out = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(d_scratch) + key_bytes);
   void* temp = static_cast<unsigned char*>(d_scratch) + 2 * key_bytes;
   size_t temp_bytes = scratch_bytes - 2 * key_bytes;
-  hipLaunchKernelGGL(sort_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_cand, count, keys_in, by_tag);
+  hipLaunchKernelGGL(sort_keys_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_cand, count, keys_in, by_tag == 1 ? 40 : by_tag);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const unsigned end_bit = (key_bits > 0 && key_bits < 64) ? (unsigned)key_bits : 64u;
@@ -254,9 +339,7 @@ hipError_t launch_sort_candidates(const Candidate* d_cand, Candidate* d_sorted, 
 static size_t heads_bytes(uint32_t count) { return ((size_t)count * 4 + 255) / 256 * 256; }
 size_t select_scratch_bytes(uint32_t count) {
   size_t temp = 0, temp2 = 0;
-  (void)rocprim::select(nullptr, temp, static_cast<Candidate*>(nullptr), static_cast<unsigned char*>(nullptr),
-                        static_cast<Candidate*>(nullptr), static_cast<uint32_t*>(nullptr), (size_t)count,
-                        hipStream_t(nullptr));
+  temp = compact_flagged_scratch(count);
   (void)rocprim::inclusive_scan(nullptr, temp2, static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr),
                                 (size_t)count, rocprim::maximum<uint32_t>(), hipStream_t(nullptr));
   return ((size_t)count + 255) / 256 * 256 + 2 * heads_bytes(count) + std::max(temp, temp2) + 256;
@@ -286,14 +369,14 @@ hipError_t launch_select_reports(const Candidate* d_sorted, uint32_t count, Cand
                      all_minima ? nullptr : heads);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
-  return rocprim::select(temp, temp_bytes, d_sorted, keep, d_sel, d_sel_count, (size_t)count, stream);
+  return compact_flagged(d_sorted, keep, count, d_sel, d_sel_count, temp, temp_bytes, stream);
 }
 
 // out[0 .. *out_count) = the records of in[0 .. count) whose keep byte is set, order kept (scratch: select_scratch_bytes).
 hipError_t launch_compact_candidates(const Candidate* d_in, uint32_t count, const unsigned char* d_keep, Candidate* d_out,
                                      uint32_t* d_out_count, void* d_scratch, size_t scratch_bytes, hipStream_t stream) {
   if (count == 0) return hipMemsetAsync(d_out_count, 0, 4, stream);
-  return rocprim::select(d_scratch, scratch_bytes, d_in, d_keep, d_out, d_out_count, (size_t)count, stream);
+  return compact_flagged(d_in, d_keep, count, d_out, d_out_count, d_scratch, scratch_bytes, stream);
 }
 
 // keep[i] = record i ends in the INSIDE of its text: behind the first `edge` columns and not behind the text's end (the
