@@ -219,6 +219,8 @@ struct TiledParams {
   Candidate* cand;                // {pos, cost, flags = pattern << kCandTextShift}
   uint32_t* cand_count;
   uint32_t cand_cap;
+  uint32_t cand_chunk;            // != 0: a wave takes its list slots this many at a time (holes: records with position 0;
+                                  // tiled_kernel.hip: EmitCursor) -- the caller's list reader skips them
   uint32_t cand_stop;             // lanes stop counting once the counter is beyond this (> cand_cap and > the largest list
                                   // the host would retry with): a 32-bit counter that kept counting could wrap on a
                                   // dense shape and pass for a complete list

@@ -3179,6 +3179,8 @@ static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, co
   P.classes = classes;
   P.warm_blocks = (m + k + 63) / 64;
   P.keep_bits = d_keep_bits;
+  // (the zones' list -- the one caller with keep bits -- is read by map_zone_list_kernel, which skips empty records)
+  P.cand_chunk = (d_keep_bits && !pt) ? 1024u : 0u;
   {
     const uint64_t span = (uint64_t)P.skew + len;
     const uint64_t waves_wanted = 16384;

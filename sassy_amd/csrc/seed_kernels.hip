@@ -583,39 +583,87 @@ __global__ __launch_bounds__(256) void gather_zones_kernel(const uint8_t* __rest
 // zone[6 z .. 6 z + 5] = first byte of the zone in the zone buffer, text position of that byte, first and last end
 // position (in the text) the zone is responsible for, 1 if a cut-out stretch follows the last one, unused.  Sorted by
 // the first field.
+constexpr uint32_t kMapTile = 2048;  // records per workgroup of map_zone_list_kernel
 __global__ __launch_bounds__(256) void map_zone_list_kernel(const Candidate* __restrict__ in, uint32_t count,
                                                             const unsigned long long* __restrict__ zone, uint32_t n_zones,
                                                             Candidate* __restrict__ out, uint32_t* __restrict__ out_count,
                                                             uint32_t out_cap) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  bool keep = false;
-  Candidate c{0, 0, 0};
-  unsigned long long p = 0;
-  uint32_t lo = 0;
-  if (i < count) {
-    c = in[i];
-    if (c.pos != 0) {
-      uint32_t hi = n_zones;  // the zone whose bytes hold character c.pos - 1: largest z with dst[z] <= c.pos - 1
+  // A workgroup takes kMapTile records, 8 per thread, and updates the one counter ONCE (an update per wave -- 2 M of
+  // them on one address -- was all of this kernel's 22 ms for the 10^8 records of a guide set on a text with N runs).
+  // The list may have holes (position 0: the tiled scan took its slots in ranges).
+  __shared__ uint32_t wave_sum[4];
+  __shared__ uint32_t block_first;
+  const uint32_t lane = threadIdx.x & 63u;
+  unsigned long long p8[8];
+  uint32_t cf8[8];  // flags
+  int cost8[8];
+  uint32_t keep_bits = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j) {
+    const uint32_t i = blockIdx.x * kMapTile + j * 256u + threadIdx.x;
+    Candidate c{0, 0, 0};
+    if (i < count) c = in[i];
+    const bool have = i < count && c.pos != 0;
+    // The zone whose bytes hold character c.pos - 1: the largest z with dst[z] <= c.pos - 1.  The records of a wave come
+    // from one or two waves of the tiled scan -- one or two zones --, so the wave searches once, for its first record,
+    // and a lane searches by itself only when its record lies elsewhere.
+    uint32_t lo = 0;
+    const unsigned long long active = __ballot(have);
+    if (active) {
+      const unsigned long long pos0 = __shfl(c.pos, __ffsll((long long)active) - 1, 64) - 1;
+      uint32_t hi = n_zones;
       while (lo + 1 < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (zone[6 * mid] <= c.pos - 1) lo = mid; else hi = mid;
-      }
-      if (zone[6 * lo] <= c.pos - 1) {  // (else: in the separator in front of the first zone)
-        p = zone[6 * lo + 1] + (c.pos - zone[6 * lo]);  // end position in the text
-        keep = p >= zone[6 * lo + 2] && p <= zone[6 * lo + 3];  // (else: context, or the separator behind the zone)
+        if (zone[6 * mid] <= pos0) lo = mid; else hi = mid;
       }
     }
+    bool keep = false;
+    unsigned long long p = 0;
+    uint32_t flags = c.flags;
+    if (have) {
+      const unsigned long long at = c.pos - 1;
+      const bool here = zone[6 * lo] <= at && (lo + 1 >= n_zones || at < zone[6 * (lo + 1)]);
+      if (!here) {
+        lo = 0;
+        uint32_t hi = n_zones;
+        while (lo + 1 < hi) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (zone[6 * mid] <= at) lo = mid; else hi = mid;
+        }
+      }
+      if (zone[6 * lo] <= at) {  // (else: in the separator in front of the first zone)
+        p = zone[6 * lo + 1] + (c.pos - zone[6 * lo]);  // end position in the text
+        keep = p >= zone[6 * lo + 2] && p <= zone[6 * lo + 3];  // (else: context, or the separator behind the zone)
+        if (keep && p == zone[6 * lo + 3] && zone[6 * lo + 4]) flags |= kCandCont;
+      }
+    }
+    p8[j] = p;
+    cost8[j] = c.cost;
+    cf8[j] = flags;
+    keep_bits |= (keep ? 1u : 0u) << j;
   }
-  // one counter update per wave (a dense text keeps 10^7 records: an atomic each on the one address took 17 ms)
-  const unsigned long long who = __ballot(keep);
-  if (who == 0) return;
-  const uint32_t lane = __lane_id();
-  uint32_t first = 0;
-  if (lane == (uint32_t)__ffsll((long long)who) - 1u) first = atomicAdd(out_count, (uint32_t)__popcll(who));
-  first = __shfl(first, __ffsll((long long)who) - 1, 64);
-  if (!keep) return;
-  const uint32_t k = first + (uint32_t)__popcll(who & ((1ull << lane) - 1ull));
-  if (k < out_cap) out[k] = Candidate{p, c.cost, c.flags | ((p == zone[6 * lo + 3] && zone[6 * lo + 4]) ? kCandCont : 0u)};
+  const uint32_t mine = (uint32_t)__popc(keep_bits);
+  uint32_t incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = __shfl_up(incl, d, 64);
+    if (lane >= (uint32_t)d) incl += up;
+  }
+  if (lane == 63) wave_sum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+    block_first = total ? atomicAdd(out_count, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t at = block_first + incl - mine;
+  for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) at += wave_sum[w];
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j)
+    if ((keep_bits >> j) & 1u) {
+      if (at < out_cap) out[at] = Candidate{p8[j], cost8[j], cf8[j]};
+      ++at;
+    }
 }
 
 // excl[2 x], excl[2 x + 1]: first and last end position of an interval where the zones are responsible (sorted,
@@ -655,7 +703,7 @@ hipError_t launch_gather_zones(const uint8_t* d_text, uint8_t* d_dst, const unsi
 hipError_t launch_map_zone_list(const Candidate* d_in, uint32_t count, const unsigned long long* d_zone, uint32_t n_zones,
                                 Candidate* d_out, uint32_t* d_out_count, uint32_t out_cap, hipStream_t stream) {
   if (count == 0 || n_zones == 0) return hipSuccess;
-  hipLaunchKernelGGL(map_zone_list_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, d_in, count, d_zone, n_zones, d_out,
+  hipLaunchKernelGGL(map_zone_list_kernel, dim3((count + kMapTile - 1) / kMapTile), dim3(256), 0, stream, d_in, count, d_zone, n_zones, d_out,
                      d_out_count, out_cap);
   return hipGetLastError();
 }

@@ -45,7 +45,17 @@ __device__ __forceinline__ void tiled_emit(const TiledParams& P, uint64_t pos, i
 // the inside of a run of N every pattern matches at every position -- 512 records per wave and step, and an atomic each
 // (plus the saturation test's read of the counter) made the zones around the N runs of a genome the longest kernel of a
 // guide-set search (119 of 210 ms).
-__device__ __forceinline__ void tiled_emit8(const TiledParams& P, uint64_t pos, uint32_t mask, const int (&c8)[8], uint32_t pat) {
+// cand_chunk != 0 (the zones around the N runs of a genome: 10^8 records from a few MB of text): the wave takes its list
+// slots cand_chunk at a time and keeps the range in `cur` -- one update of the one counter per cand_chunk records
+// instead of one per call (2.7 M updates of one address were 20 of the scan's 34 ms).  What a wave has left of its
+// last range when it ends it fills with empty records (position 0: tiled_release), so the list has holes and
+// *cand_count counts slots.
+struct EmitCursor {
+  uint32_t cur = 0, end = 0;  // wave-uniform
+  bool dead = false;          // the list is far beyond any capacity: stop
+};
+__device__ __forceinline__ void tiled_emit8(const TiledParams& P, uint64_t pos, uint32_t mask, const int (&c8)[8], uint32_t pat,
+                                            EmitCursor& C) {
   if (P.keep_bits) {  // (a gathered buffer: context, separators)
 #pragma unroll
     for (uint32_t i = 0; i < 8; ++i) {
@@ -62,21 +72,44 @@ __device__ __forceinline__ void tiled_emit8(const TiledParams& P, uint64_t pos, 
   }
   const uint32_t total = __shfl(inc, 63, 64);
   if (total == 0) return;
-  uint32_t first = 0xFFFFFFFFu;
-  if (lane == 0) {
-    // (saturating: far beyond any capacity the host would retry with, the waves stop counting -- the counter never wraps)
-    if (*reinterpret_cast<volatile const uint32_t*>(P.cand_count) <= P.cand_stop) first = atomicAdd(P.cand_count, total);
+  uint32_t idx, wrap_at = 0xFFFFFFFFu, wrap_to = 0;  // slots from wrap_at on continue at wrap_to
+  if (P.cand_chunk) {
+    if (C.dead) return;
+    idx = C.cur + inc - n;
+    if (C.cur + total > C.end) {  // (wave-uniform) the next range; total <= 512 <= cand_chunk
+      uint32_t nf = 0;
+      if (lane == 0) nf = atomicAdd(P.cand_count, P.cand_chunk);
+      nf = __shfl(nf, 0, 64);
+      if (nf > P.cand_stop) { C.dead = true; return; }
+      wrap_at = C.end;
+      wrap_to = nf;
+      C.cur = nf + (C.cur + total - C.end);
+      C.end = nf + P.cand_chunk;
+    } else {
+      C.cur += total;
+    }
+  } else {
+    uint32_t first = 0xFFFFFFFFu;
+    if (lane == 0) {
+      // (saturating: far beyond any capacity the host would retry with, the waves stop counting -- the counter never wraps)
+      if (*reinterpret_cast<volatile const uint32_t*>(P.cand_count) <= P.cand_stop) first = atomicAdd(P.cand_count, total);
+    }
+    first = __shfl(first, 0, 64);
+    if (first == 0xFFFFFFFFu) return;
+    idx = first + inc - n;
   }
-  first = __shfl(first, 0, 64);
-  if (first == 0xFFFFFFFFu) return;
-  uint32_t idx = first + inc - n;
 #pragma unroll
   for (uint32_t i = 0; i < 8; ++i) {
     if ((mask >> i) & 1u) {
-      if (idx < P.cand_cap) P.cand[idx] = Candidate{pos + i, c8[i], pat << kCandTextShift};
+      const uint32_t slot = idx >= wrap_at ? wrap_to + (idx - wrap_at) : idx;
+      if (slot < P.cand_cap) P.cand[slot] = Candidate{pos + i, c8[i], pat << kCandTextShift};
       ++idx;
     }
   }
+}
+// the end of a wave that took its slots in ranges: empty records in what is left of the last one
+__device__ __forceinline__ void tiled_release(const TiledParams& P, const EmitCursor& C) {
+  for (uint32_t i = C.cur + __lane_id(); i < C.end && i < P.cand_cap; i += 64u) P.cand[i] = Candidate{0ull, 0, 0u};
 }
 
 // WORDS = 1: patterns of <= 32 rows (one 32-bit word), 2: 33 .. 64 rows.
@@ -121,6 +154,7 @@ __global__ __launch_bounds__(256) void tiled_scan_kernel(const TiledParams P) {
   S.vn = 0;
   S.cost = (int)m;
   if (chunk == 0 && S.cost <= kk) tiled_emit(P, 0ull, S.cost, pat);  // end position 0 (only when m <= k)
+  EmitCursor cursor;
 
   for (uint64_t yb = first; yb < own_hi; yb += 64) {
     // 64 text bytes, one per lane -> LDS offsets of their character classes
@@ -155,7 +189,7 @@ __global__ __launch_bounds__(256) void tiled_scan_kernel(const TiledParams P) {
             uint32_t mask = 0;
 #pragma unroll
             for (uint32_t i = 0; i < 8; ++i) mask |= (c8[i] <= kk ? 1u : 0u) << i;
-            tiled_emit8(P, pos0 + g, mask, c8, pat);
+            tiled_emit8(P, pos0 + g, mask, c8, pat, cursor);
           }
         } else {  // warm-up: nothing is reported
 #pragma unroll
@@ -170,6 +204,7 @@ __global__ __launch_bounds__(256) void tiled_scan_kernel(const TiledParams P) {
       }
     }
   }
+  if (P.cand_chunk) tiled_release(P, cursor);
 }
 
 // Overhang in one pass over a batch of texts (TiledParams::n_texts != 0): a wave = 64 patterns x a run of
@@ -205,6 +240,7 @@ __global__ __launch_bounds__(256) void tiled_pertext_kernel(const TiledParams P)
   const int kk = valid ? (int)P.k : (int)0x80000000;  // lanes without a pattern never report
   const uint32_t top_shift = (P.m - 1u) & 31u;
   const uint32_t n_class = (P.classes == 4 ? 3u : 15u) << kShift;  // 'N' (overhang is Iupac's: 16 classes)
+  EmitCursor cursor;  // (cand_chunk is 0 here: a counter update per call)
   for (uint64_t t = t_lo; t < t_hi; ++t) {
     const uint64_t start = P.texts_start[t], len = P.texts_len[t];
     if (len == 0) continue;  // no reports for an empty text (src/search.rs:1314-1316)
@@ -251,7 +287,7 @@ __global__ __launch_bounds__(256) void tiled_pertext_kernel(const TiledParams P)
               uint32_t mask = 0;
 #pragma unroll
               for (uint32_t i = 0; i < 8; ++i) mask |= (c8[i] <= kk ? 1u : 0u) << i;
-              tiled_emit8(P, pos0 + g, mask, c8, pat);
+              tiled_emit8(P, pos0 + g, mask, c8, pat, cursor);
             }
           }
         } else {  // a segment's first or last block, the block the text ends in, the virtual columns
