@@ -189,8 +189,11 @@ __device__ __noinline__ void verify_candidate(const VerifyArgs P, unsigned long 
   const uint32_t entry = (uint32_t)cand & ((1u << kSeedPosShift) - 1u);
   const uint32_t pat = entry >> 3, piece = entry & 7u;
   const int64_t i = (int64_t)(cand >> kSeedPosShift);
-  const int m = (int)(P.mks & 0xFFu), k = (int)((P.mks >> 8) & 0xFFu);
-  const bool separators = (P.mks >> 16) != 0;
+  // (the arguments arrive in vector registers: m, k and what follows from them are the same in every lane -- as scalars
+  // the per-step tests "does this step report?" are scalar branches, not compares and exec masks)
+  const uint32_t mks = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.mks);
+  const int m = (int)(mks & 0xFFu), k = (int)((mks >> 8) & 0xFFu);
+  const bool separators = (mks >> 16) != 0;
   const int T = m + 3 * k + 1;
   const int64_t e_hi = i + (int64_t)((P.rem_packed >> (8u * piece)) & 0xFFu) + k;  // last end position the seed allows
   const int64_t s0 = e_hi - T;                          // first character of the window
@@ -246,9 +249,17 @@ __device__ __noinline__ void verify_candidate(const VerifyArgs P, unsigned long 
           const int t = 4 * x + y;
           if (t < T) {
             // eq = e[code of the character]: two mux levels on the code's bits
-            const Word b0 = (Word)(long long)(int)__builtin_amdgcn_sbfe((int)win[x], 8 * y + 1, 1);  // (the builtin's type is unsigned)
-            const Word b1 = (Word)(long long)(int)__builtin_amdgcn_sbfe((int)win[x], 8 * y + 2, 1);
-            Word eq = (((e[0] & ~b0) | (e[1] & b0)) & ~b1) | (((e[2] & ~b0) | (e[3] & b0)) & b1);
+            Word eq;
+            if (WORDS == 1) {  // three v_bitop3 (s ? x1 : x0)
+              const uint32_t s0 = __builtin_amdgcn_sbfe((int)win[x], 8 * y + 1, 1), s1 = __builtin_amdgcn_sbfe((int)win[x], 8 * y + 2, 1);
+              const uint32_t lo = __builtin_amdgcn_bitop3_b32(s0, (uint32_t)e[0], (uint32_t)e[1], 0xAC);
+              const uint32_t hi = __builtin_amdgcn_bitop3_b32(s0, (uint32_t)e[2], (uint32_t)e[3], 0xAC);
+              eq = (Word)__builtin_amdgcn_bitop3_b32(s1, lo, hi, 0xAC);
+            } else {
+              const Word b0 = (Word)(long long)(int)__builtin_amdgcn_sbfe((int)win[x], 8 * y + 1, 1);  // (the builtin's type is unsigned)
+              const Word b1 = (Word)(long long)(int)__builtin_amdgcn_sbfe((int)win[x], 8 * y + 2, 1);
+              eq = (((e[0] & ~b0) | (e[1] & b0)) & ~b1) | (((e[2] & ~b0) | (e[3] & b0)) & b1);
+            }
             if (EDGE) {
               const int64_t c = s0 + t;
               if (c < 0 || c >= (int64_t)P.text_len) eq = 0;  // outside the text: the fresh column stays fresh
