@@ -940,6 +940,54 @@ def test_encoded_pattern_tiled(sassy):
     os.environ.pop("SASSY_HIP_SEEDED", None)
 
 
+def test_seeded_test_geometry_sweep(sassy):
+    """The sub-piece test in front of the seeded search's verification reads ONE text window for all pieces, laid out from
+    the pattern's shape (host.hip: reach, win_left, offsets within 48 characters, lengths capped by the shifts;
+    seed_kernels.hip: test_issue / test_finish).  A wrong offset shows as a LOST match, so: every pattern length 8 .. 32
+    with every k the path takes, matches planted with exactly k edits (substitutions, insertions and deletions at random
+    rows: next to the seed, at sub-piece borders, at the pattern's ends), plain patterns and patterns with ambiguity
+    letters (care words), against the oracle."""
+    import os
+    rng = random.Random(4242)
+    os.environ["SASSY_HIP_SEEDED"] = "1"
+    os.environ.pop("SASSY_HIP_TILED", None)
+    seeded = 0
+    try:
+        for m in range(8, 33):
+            for k in range(0, 8):
+                if m // (k + 1) < 4 or k * 4 > m:
+                    continue
+                for profile in ("dna", "iupac"):
+                    npat, n = 24, 24_000
+                    pats = []
+                    for _ in range(npat):
+                        p = bytearray(rng.choice(b"ACGT") for _ in range(m))
+                        if profile == "iupac" and rng.random() < 0.5:
+                            for _ in range(rng.randrange(1, 3)):
+                                p[rng.randrange(m)] = rng.choice(b"NRYKMSW")
+                        pats.append(bytes(p))
+                    text = bytearray(rng.choice(b"ACGT") for _ in range(n))
+                    at = 64
+                    for p in pats:
+                        conc = bytes(c if c in b"ACGT" else rng.choice(b"ACGT") for c in p)
+                        for e_ in (k, k, max(0, k - 1), k):
+                            ins = mutate(rng, conc, e_)
+                            text[at:at + len(ins)] = ins
+                            at += len(ins) + rng.randrange(m + 2 * k + 2, 3 * m + 40)
+                    assert at < n
+                    tb = bytes(text)
+                    s = sassy.Searcher(profile, rc=False)
+                    enc = s.encode_patterns(pats)
+                    got = s.search_encoded_patterns(enc, tb, k)
+                    seeded += s.stats()["filtered"] == 6
+                    want = oracle.search_encoded(profile, pats, tb, k, rc=False)
+                    assert sorted(key(x) for x in got) == sorted(key(x) for x in want), (profile, m, k, len(got), len(want))
+                    assert len(want) >= 2 * npat
+    finally:
+        os.environ.pop("SASSY_HIP_SEEDED", None)
+    assert seeded >= 60, seeded
+
+
 def _encoded_filters_agree(sassy, rng, env, kind):
     import os
     pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(30)]
@@ -2740,7 +2788,7 @@ def test_seeded_search_forced_test_layouts(sassy, env):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-m", "gpu", "-x", "-q",
                         "-p", "no:cacheprovider", "-k", "test_encoded_seeded or test_encoded_kats_through_hip or "
-                        "test_overhang_many_patterns_in_one_pass"], env=e, cwd=root, capture_output=True, text=True, timeout=900)
+                        "test_overhang_many_patterns_in_one_pass or test_seeded_test_geometry_sweep"], env=e, cwd=root, capture_output=True, text=True, timeout=900)
     tail = (r.stdout[-3000:] + r.stderr[-1500:])
     assert r.returncode == 0, (env, tail)
     assert " passed" in r.stdout and "failed" not in r.stdout, (env, tail)
