@@ -3496,6 +3496,69 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     if (tab_len[0] == 0 || tab_len[0] == p_len[pc]) { tab_len[0] = p_len[pc]; tab_of[pc] = 0; }
     else { tab_len[1] = p_len[pc]; tab_of[pc] = 1; }
   }
+  // Patterns with ambiguity letters (an Iupac searcher): a seed over such a letter stands for several strings -- the NGG
+  // of a CRISPR guide makes the last of the four pieces of a 23-mer hit four times as often as the others.  The
+  // pigeonhole argument needs k+1 DISJOINT pieces, not a cover: choose their places (seeds of at most two lengths, the
+  // tables') so that the expected number of table hits per text position is smallest -- a small dynamic programme over
+  // the rows -- and take that layout when it beats the even cut by 5 % (plain patterns keep the even cut).
+  if (s->profile == PROFILE_IUPAC && getenv("SASSY_HIP_SEED_LAYOUT") == nullptr) {
+    const size_t sample = std::min<size_t>(npat, 512);
+    // rate[a][L] = mean over the sampled patterns of the probability that a random L-gram matches rows [a, a + L)
+    std::vector<std::vector<double>> rate(m + 1, std::vector<double>(kSeedMaxLen + 1, 0.0));
+    for (size_t p = 0; p < sample; ++p) {
+      const uint8_t* pt = e->patterns[p * (npat / sample)].data();
+      for (uint32_t a = 0; a < m; ++a) {
+        double pr = 1.0;
+        for (uint32_t L = 1; L <= kSeedMaxLen && a + L <= m; ++L) {
+          pr *= (double)__builtin_popcount(iupac_code(pt[a + L - 1]) & 0x0Fu) / 4.0;
+          rate[a][L] += pr / (double)sample;
+        }
+      }
+    }
+    double even = 0;
+    for (uint32_t pc = 0; pc < pieces; ++pc) even += rate[p_end[pc] - p_len[pc]][p_len[pc]];
+    double best = even * 0.95;
+    uint32_t best_end[8], best_len[8];
+    bool found = false;
+    for (uint32_t La = 3; La <= kSeedMaxLen; ++La)
+      for (uint32_t Lb = La; Lb <= std::min<uint32_t>(kSeedMaxLen, La + 2); ++Lb) {
+        if ((uint64_t)La * pieces > m) continue;
+        // f[j][i] = least total rate of j pieces within rows [0, i); from[j][i] = the length of the piece that ends at i (0: none)
+        const double inf = 1e300;
+        std::vector<std::vector<double>> f(pieces + 1, std::vector<double>(m + 1, inf));
+        std::vector<std::vector<uint32_t>> from(pieces + 1, std::vector<uint32_t>(m + 1, 0u));
+        for (uint32_t i = 0; i <= m; ++i) f[0][i] = 0;
+        for (uint32_t j = 1; j <= pieces; ++j)
+          for (uint32_t i = 1; i <= m; ++i) {
+            f[j][i] = f[j][i - 1];
+            from[j][i] = 0;
+            for (uint32_t L : {La, Lb})
+              if (i >= L && f[j - 1][i - L] < inf && f[j - 1][i - L] + rate[i - L][L] < f[j][i]) {
+                f[j][i] = f[j - 1][i - L] + rate[i - L][L];
+                from[j][i] = L;
+              }
+          }
+        if (f[pieces][m] >= best) continue;
+        best = f[pieces][m];
+        found = true;
+        uint32_t i = m;
+        for (uint32_t j = pieces; j >= 1; --j) {
+          while (from[j][i] == 0) --i;
+          best_end[j - 1] = i;
+          best_len[j - 1] = from[j][i];
+          i -= from[j][i];
+        }
+      }
+    if (found) {
+      tab_len[0] = tab_len[1] = 0;
+      for (uint32_t pc = 0; pc < pieces; ++pc) {
+        p_end[pc] = best_end[pc];
+        p_len[pc] = best_len[pc];
+        if (tab_len[0] == 0 || tab_len[0] == p_len[pc]) { tab_len[0] = p_len[pc]; tab_of[pc] = 0; }
+        else { tab_len[1] = p_len[pc]; tab_of[pc] = 1; }
+      }
+    }
+  }
   uint32_t seed_bits_off[2] = {0, 0};
   // ---- direct-address tables: code of a seed = sum of its characters' Dna codes, first character lowest ----
   // Iupac searcher (plain-ACGT text, patterns with ambiguity letters -- a CRISPR guide with its NGG): a seed with such
