@@ -68,6 +68,13 @@ PATTERNS=10000 CONFIGS=4 bash tools/prof_configs.sh cfg10k > /dev/null 2>&1
 cp gpurun_out/prof_cfg10k/summary.txt $OUT/${TAG}_config4_seeded_prof.txt
 cp $(ls gpurun_out/prof_cfg10k/trace/*kernel_stats.csv gpurun_out/prof_cfg10k/trace/*/*kernel_stats.csv 2>/dev/null | head -1) $OUT/${TAG}_config4_seeded_kernel_stats.csv
 python tools/bench_encoded.py > $OUT/${TAG}_encoded_paths.txt 2> $OUT/encoded.err
+{ echo "# tools/pmc_cmd.sh seed_search_kernel: counters per dispatch (sums over the waves; SQ cycle counters in units of 4 cycles), config 4 and the CRISPR guide set";
+  echo "## python tools/bench_configs.py --configs 4 --patterns 10000 --steps 2"; bash tools/pmc_cmd.sh seed_search_kernel python tools/bench_configs.py --configs 4 --patterns 10000 --steps 2;
+  echo "## python tools/bench_crispr.py (forward and both strands: the mean of the two)"; bash tools/pmc_cmd.sh seed_search_kernel python tools/bench_crispr.py; } > $OUT/${TAG}_seeded_pmc.txt 2>&1
+{ echo "# tools/timeline_all.py: the last call of tools/bench_crispr.py --genome-like (both strands) and of tools/bench_reads.py --reads 330000: kernels and copies longer than 0.3 ms";
+  for what in "bench_crispr.py --genome-like" "bench_reads.py --reads 330000"; do
+    ( cd /tmp && rocprofv3 --kernel-trace --memory-copy-trace -f csv -d $OLDPWD/gpurun_out/tl_$$ -o t -- python $OLDPWD/tools/$what > /dev/null 2>&1 )
+    echo "## $what"; python tools/timeline_all.py gpurun_out/tl_$$ --gap-ms 15 | awk '{d=$5+0; if (NR==1 || d > 300) print}' | cut -c1-150; rm -rf gpurun_out/tl_$$; done; } > $OUT/${TAG}_many_pattern_timelines.txt 2>&1
 python tools/bench_crispr.py > $OUT/${TAG}_crispr.json 2> $OUT/crispr.err
 python tools/bench_crispr.py --genome-like >> $OUT/${TAG}_crispr.json 2>> $OUT/crispr.err
 python tools/bench_texts.py > $OUT/${TAG}_texts.json 2> $OUT/texts.err
