@@ -554,14 +554,16 @@ class Searcher:
         patterns = [bytes(p) for p in patterns]
         pp = (C.c_char_p * len(patterns))(*patterns)
         pl = (C.c_size_t * len(patterns))(*[len(p) for p in patterns])
-        if _BYTES_PAYLOAD_OFFSET is not None and all(type(t) is bytes for t in texts):
+        if _BYTES_PAYLOAD_OFFSET is not None and len(texts) and set(map(type, texts)) == {bytes}:
             # a read set: ctypes fills the pointer array from the list itself (a few hundred thousand _ptr_len calls
             # cost more than the search)
             import numpy as np
             n_texts, on_device = len(texts), False
-            # (CPython: the bytes of a bytes object sit bytes.__basicsize__ - 1 behind its address; `texts` keeps
-            # them alive for the call)
-            addr = np.fromiter(map(id, texts), dtype=np.uint64, count=n_texts) + np.uint64(_BYTES_PAYLOAD_OFFSET)
+            # (CPython: the bytes of a bytes object sit bytes.__basicsize__ - 1 behind its address, and an object
+            # array IS the array of these addresses; `held` keeps the objects alive for the call)
+            held = np.empty(n_texts, dtype=object)
+            held[:] = texts
+            addr = np.frombuffer((C.c_uint64 * n_texts).from_address(held.ctypes.data), dtype=np.uint64) + np.uint64(_BYTES_PAYLOAD_OFFSET)
             lens = np.fromiter(map(len, texts), dtype=np.uint64, count=n_texts)
             tp = addr.ctypes.data_as(C.POINTER(C.c_void_p))
             tl = lens.ctypes.data_as(C.POINTER(C.c_size_t))
