@@ -3795,8 +3795,11 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   SP.separators = tt ? 1u : 0u;  // several texts in the buffer: 'X' between them
   // 2 KiB of text per wave and step; contiguous runs per wave
   static const uint64_t env_waves = getenv("SASSY_HIP_SEED_WAVES") ? (uint64_t)atoll(getenv("SASSY_HIP_SEED_WAVES")) : 0ull;
-  // (65 536 waves: 13 rounds of the chip's 5 120 resident waves -- the last round's ragged end is 4 % of config 4 with 16 384)
-  const uint64_t waves = std::min<uint64_t>(env_waves ? env_waves : 65536, std::max<uint64_t>(1, (text_len + 2047) / 2048));
+  // (65 536 waves: 13 rounds of the chip's 5 120 resident waves -- the last round's ragged end is 4 % of config 4 with 16 384;
+  // a smaller text: ten steps per wave, at least 4 096 waves -- a workgroup stages 16 KiB of seed bits before its first step:
+  // 330 MB of reads in 65 536 waves of 2.5 steps were 3.9 ms for both strands, 2.3 in 16 384)
+  const uint64_t steps_total = std::max<uint64_t>(1, (text_len + 2047) / 2048);
+  const uint64_t waves = std::min<uint64_t>(env_waves ? env_waves : std::max<uint64_t>(4096, std::min<uint64_t>(65536, steps_total / 10)), steps_total);
   const uint32_t grid = (uint32_t)((waves + kWavesPerGroup - 1) / kWavesPerGroup);
 
   const uint64_t kMaxList = 1ull << 26;
