@@ -988,6 +988,33 @@ def test_seeded_test_geometry_sweep(sassy):
     assert seeded >= 60, seeded
 
 
+def test_search_many_takes_a_text_batch(sassy):
+    """search_many with the texts as ONE buffer + offsets (sassy_amd.TextBatch: what a FASTA / FASTQ reader holds) returns
+    what the list of bytes returns -- empty texts, texts shorter than the patterns, an unused gap in the buffer."""
+    rng = random.Random(77)
+    pats = [bytes(rng.choice(b"ACGT") for _ in range(24)) for _ in range(8)]
+    texts = []
+    for i in range(300):
+        t = bytearray(rng.choice(b"ACGT") for _ in range(rng.choice([0, 5, 200, 700])))
+        if len(t) > 100:
+            ins = mutate(rng, pats[i % len(pats)], rng.randrange(0, 4))
+            at = rng.randrange(0, len(t) - len(ins))
+            t[at:at + len(ins)] = ins
+        texts.append(bytes(t))
+    s = sassy.Searcher("iupac", rc=True)
+    want = s.search_many(pats, texts, 3)
+    got = s.search_many(pats, sassy.TextBatch.from_list(texts), 3)
+    assert [key(x) + (x.text_idx,) for x in got] == [key(x) + (x.text_idx,) for x in want] and len(want) >= 100
+    import numpy as np
+    buf = b"#" * 17 + b"".join(texts)  # (a header in front: starts need not begin at 0)
+    lens = np.array([len(t) for t in texts], dtype=np.uint64)
+    starts = 17 + np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.uint64)
+    got2 = s.search_many(pats, sassy.TextBatch(buf, starts, lens), 3)
+    assert [key(x) + (x.text_idx,) for x in got2] == [key(x) + (x.text_idx,) for x in want]
+    with pytest.raises(sassy.SassyHipError):
+        sassy.TextBatch(b"ACGT", [2], [5])
+
+
 def _encoded_filters_agree(sassy, rng, env, kind):
     import os
     pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) for _ in range(30)]

@@ -50,11 +50,16 @@ def main():
     ms = s.search_many(pats, texts, args.k)         # steady state
     dt = time.perf_counter() - t0
     st = s.stats()
+    batch = sassy_amd.TextBatch.from_list(texts)  # the same read set as one buffer + offsets: nothing per text in Python
+    t0 = time.perf_counter()
+    ms_b = s.search_many(pats, batch, args.k)
+    dt_batch = time.perf_counter() - t0
+    assert len(ms_b) == len(ms)
     print(json.dumps({
         "workload": f"{args.patterns} x {args.pattern_len} bp patterns, {args.reads} reads x {args.read_len} bp "
                     f"({total / 1e6:.0f} MB), k={args.k}, {args.profile}, {'forward strand' if args.fwd else 'both strands'}"
                     + (f", overhang {args.overhang}" if args.overhang is not None else ""),
-        "seconds_python_call": round(dt, 3), "seconds_c_abi": round(st["total_ms"] / 1e3, 3),
+        "seconds_python_call": round(dt, 3), "seconds_python_call_text_batch": round(dt_batch, 3), "seconds_c_abi": round(st["total_ms"] / 1e3, 3),
         "seconds_c_abi_first_call": round(first_ms / 1e3, 3),
         "pattern_text_GB_per_s": round(total * args.patterns / (st["total_ms"] / 1e3) / 1e9, 1),
         "matches": len(ms), "scan_launches": st["scan_launches"], "scan_kernel_ms": round(st["scan_ms"], 2),
