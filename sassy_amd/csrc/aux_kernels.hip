@@ -457,14 +457,31 @@ __global__ __launch_bounds__(256) void rank_scatter_kernel(const Candidate* __re
 // ------------------------------------------------------------------ per-text reversal
 // Block-aligned multi-text buffer (per-text mode): every text reversed inside its own slot, the
 // padding behind it kept in place.  blk2text maps each 64-byte block to the text it belongs to.
+// A thread writes 16 bytes (the slots are whole 64-byte blocks: the 16 belong to one text): where they all lie inside the
+// text they are 16 consecutive source bytes, byte-swapped (a byte per thread was 0.84 ms for 330 MB of reads).
 __global__ __launch_bounds__(256) void reverse_texts_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
                                                             uint64_t n, const uint32_t* __restrict__ blk2text,
                                                             const uint64_t* __restrict__ start,
                                                             const uint64_t* __restrict__ len, uint32_t pad) {
-  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+  const uint64_t n16 = n / 16;  // (n is a multiple of 64)
+  for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < n16; g += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = g * 16;
     const uint32_t t = blk2text[i >> 6];
-    const uint64_t off = i - start[t];
-    dst[i] = off < len[t] ? src[start[t] + len[t] - 1 - off] : (uint8_t)pad;
+    const uint64_t s0 = start[t], l = len[t], off = i - s0;
+    uint4 out;
+    if (off + 16 <= l) {
+      uint32_t w[4];
+      __builtin_memcpy(w, src + s0 + l - 16 - off, 16);  // (unaligned: four dword loads)
+      out = make_uint4(__builtin_bswap32(w[3]), __builtin_bswap32(w[2]), __builtin_bswap32(w[1]), __builtin_bswap32(w[0]));
+    } else {
+      uint32_t w[4] = {0, 0, 0, 0};
+      for (uint32_t j = 0; j < 16; ++j) {
+        const uint32_t c = off + j < l ? src[s0 + l - 1 - (off + j)] : (pad & 0xFFu);
+        w[j >> 2] |= c << (8 * (j & 3));
+      }
+      out = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    *reinterpret_cast<uint4*>(dst + i) = out;
   }
 }
 

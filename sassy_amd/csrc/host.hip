@@ -4496,7 +4496,10 @@ static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patt
       if (int rc = s->reserve_stage(total + 64)) return rc;
       hbuf = s->h_stage;
       uint8_t pad_b = seed_ov ? (uint8_t)'X' : pad;
-      layout_texts(hbuf, texts + t0, text_lens + t0, ht.start.data(), nt, total, pad_b);
+      // (the upload rides along: the copy of a 32 MB segment runs while the next one is laid out, and the tables below
+      // are built while the last copies are in flight)
+      if (int rc = s->d_text.reserve(total + 64)) return rc;
+      if (int rc = layout_and_upload(hbuf, s->d_text.p, texts + t0, text_lens + t0, ht.start.data(), nt, total, pad_b, s->stream)) return rc;
       blk2text.assign(total / 64, 0u);
       for (size_t i = 0; i < nt; ++i) {
         const uint64_t b0 = ht.start[i] / 64, b1 = (i + 1 < nt ? ht.start[i + 1] : total) / 64;
@@ -4524,12 +4527,10 @@ static int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patt
       }
       if (desc.empty()) { t0 = t1; continue; }
       g_marks.mark("pertext layout");
-      if (int rc = s->d_text.reserve(total + 64)) return rc;
       if (int rc = s->d_tables.reserve(2 * nt + 2 * desc.size() + total / 64 / 2 + 8)) return rc;
       uint64_t* d_tab = s->d_tables.p;
       ChunkDesc* d_desc = reinterpret_cast<ChunkDesc*>(d_tab + 2 * nt);
       uint32_t* d_b2t = reinterpret_cast<uint32_t*>(d_tab + 2 * nt + 2 * desc.size());
-      HIP_TRY(hipMemcpyAsync(s->d_text.p, hbuf, total, hipMemcpyHostToDevice, s->stream));
       HIP_TRY(hipMemcpyAsync(d_tab, ht.start.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
       HIP_TRY(hipMemcpyAsync(d_tab + nt, ht.len.data(), nt * 8, hipMemcpyHostToDevice, s->stream));
       HIP_TRY(hipMemcpyAsync(d_desc, desc.data(), desc.size() * sizeof(ChunkDesc), hipMemcpyHostToDevice, s->stream));

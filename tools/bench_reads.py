@@ -46,10 +46,14 @@ def main():
     s.search_many(pats[:2], texts[:100], args.k)  # warm-up (kernels loaded)
     s.search_many(pats, texts, args.k)             # first full-size call: grows the staging / device buffers
     first_ms = s.stats()["total_ms"]
-    t0 = time.perf_counter()
-    ms = s.search_many(pats, texts, args.k)         # steady state
-    dt = time.perf_counter() - t0
-    st = s.stats()
+    dts, sts = [], []
+    for _ in range(3):                              # steady state: the best of three calls (each one's C-ABI time is listed)
+        t0 = time.perf_counter()
+        ms = s.search_many(pats, texts, args.k)
+        dts.append(time.perf_counter() - t0)
+        sts.append(s.stats())
+    best = min(range(3), key=lambda i: sts[i]["total_ms"])
+    dt, st = dts[best], sts[best]
     batch = sassy_amd.TextBatch.from_list(texts)  # the same read set as one buffer + offsets: nothing per text in Python
     t0 = time.perf_counter()
     ms_b = s.search_many(pats, batch, args.k)
@@ -59,7 +63,7 @@ def main():
         "workload": f"{args.patterns} x {args.pattern_len} bp patterns, {args.reads} reads x {args.read_len} bp "
                     f"({total / 1e6:.0f} MB), k={args.k}, {args.profile}, {'forward strand' if args.fwd else 'both strands'}"
                     + (f", overhang {args.overhang}" if args.overhang is not None else ""),
-        "seconds_python_call": round(dt, 3), "seconds_python_call_text_batch": round(dt_batch, 3), "seconds_c_abi": round(st["total_ms"] / 1e3, 3),
+        "seconds_python_call": round(dt, 3), "seconds_python_call_text_batch": round(dt_batch, 3), "seconds_c_abi": round(st["total_ms"] / 1e3, 4), "seconds_c_abi_each_call": [round(x["total_ms"] / 1e3, 4) for x in sts],
         "seconds_c_abi_first_call": round(first_ms / 1e3, 3),
         "pattern_text_GB_per_s": round(total * args.patterns / (st["total_ms"] / 1e3) / 1e9, 1),
         "matches": len(ms), "scan_launches": st["scan_launches"], "scan_kernel_ms": round(st["scan_ms"], 2),
