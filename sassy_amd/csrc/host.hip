@@ -2757,6 +2757,47 @@ static int search_text(sassy_SearcherType* S, const uint8_t* pattern, size_t ple
                         std::isnan(S->alpha) && S->profile != PROFILE_ASCII && ref_lanes == 0 && !pair_strands;
   bool rc_by_bitmap = false;
 
+  // Two searches, one per strand (the Rc strand's on the reversed copy) -- the paired filter's shapes, searchers with an
+  // N filter: both IN FLIGHT, each on a lane of its own, as two tickets of a stream of searches are -- the forward
+  // strand's chunk DP tail and traceback run under the Rc strand's filter (m = 23, k = 3: 1.32 -> 1.1x ms).
+  // SASSY_HIP_STRANDS_IN_FLIGHT=0: one after the other.
+  static const bool env_two = !(getenv("SASSY_HIP_STRANDS_IN_FLIGHT") && atoi(getenv("SASSY_HIP_STRANDS_IN_FLIGHT")) == 0);
+  static const bool env_one_lane = !getenv("SASSY_HIP_LANES") || atoi(getenv("SASSY_HIP_LANES")) <= 1;
+  if (fwd_strand && rc_strand && !can_fuse && env_two && env_one_lane && ref_lanes == 0 && !ef.fn && std::isnan(S->alpha) &&
+      S->profile != PROFILE_ASCII) {
+    const bool reuse = on_dev && (flags & SASSY_HIP_TEXT_UNCHANGED) && S->rev_src == d_fwd && S->rev_len == tlen &&
+                       S->d_rev.p != nullptr;
+    if (!reuse) {
+      S->rev_src = nullptr;
+      if (int rc = S->d_rev.reserve(tlen + 64)) return rc;
+      hipError_t le = launch_reverse(d_fwd, S->d_rev.p, tlen, S->stream);
+      if (le != hipSuccess) return hip_fail(le, "reverse kernel launch");
+      if (on_dev) { S->rev_src = d_fwd; S->rev_len = tlen; }
+    }
+    ScanQueue queue(S, [&](uint64_t strand, ScanOut& so, const PatternPlan& pl, const uint8_t* pat) -> int {
+      if (int rc = post_filter(S, so, pl, pat, (uint32_t)k, (int)strand, strand == 0 && !on_dev ? text : nullptr,
+                               strand ? S->d_rev.p : d_fwd, tlen, !wo, ef)) return rc;
+      size_t first = 0;
+      if (int rc = append_matches(so, tlen, pl, wo, pattern_idx, R, first)) return rc;
+      if (strand)
+        for (size_t i = first; i < R->matches.size(); ++i) {
+          sassy_hip_Match& r = R->matches[i];
+          const uint64_t rs = r.text_start, re = r.text_end;
+          r.strand = 1;
+          r.text_start = tlen - re;
+          r.text_end = wo ? UINT64_MAX : tlen - rs;  // reference: src/search.rs:868-873
+        }
+      return 0;
+    });
+    const TextTable no_texts{};
+    if (int rc = queue.submit(plan, pattern, ShardView{d_fwd, tlen, 0, 0, true, true}, no_texts, (uint32_t)k, all, !wo, tlen, 0)) return rc;
+    if (int rc = queue.submit(cplan, cp.data(), ShardView{S->d_rev.p, tlen, 0, 0, true, true}, no_texts, (uint32_t)k, all, !wo, tlen, 1)) {
+      (void)queue.drain_all();
+      return rc;
+    }
+    return queue.drain_all();
+  }
+
   if (fwd_strand) {
     ShardView sh{d_fwd, tlen, 0, 0, true, true};
     ScanOut so;

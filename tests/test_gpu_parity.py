@@ -2780,6 +2780,7 @@ _FORCED = [
     {"SASSY_HIP_BIG_PIN": "0", "SASSY_HIP_SHORT_PIECES": "0"},   # dense results through the host's vectors; no 5- / 6-row pieces
     {"SASSY_HIP_FUSED_PRESS": "8", "SASSY_HIP_EXT_EVENTS": "0"},  # a pass of the fused launch's waves every 8 queued windows
     {"SASSY_HIP_PAIR": "0"},                         # no paired filter: 5- / 6-row shapes through the paths of round 4
+    {"SASSY_HIP_STRANDS_IN_FLIGHT": "0"},            # two strands that are two searches: one after the other
 ]
 
 
