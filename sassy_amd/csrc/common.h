@@ -279,7 +279,6 @@ struct SeedParams {
   uint32_t win_left, win_dwords;  // (4: the narrow layout, 5: the wide one -- seed_kernels.hip: test_issue)
   uint32_t pat_care;
   uint32_t pos64;                 // positions beyond 32 bits (entries with care words)
-  uint64_t seed_len_packed;       // byte p = rows of the seed of piece p
   const uint32_t* seed_bits;      // bit c of table t's part (offset bits_off[t] words): some seed of table t ends with the
                                   // min(len, 8) characters c -- staged in LDS, tested before the tables are read
   uint32_t bits_off[2];

@@ -3720,7 +3720,6 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   SP.k = k;
   for (uint32_t pc = 0; pc < pieces; ++pc) {
     SP.rem_packed |= (uint64_t)(m - p_end[pc]) << (8 * pc);
-    SP.seed_len_packed |= (uint64_t)p_len[pc] << (8 * pc);
   }
   // ---- the sub-piece test in front of the verification (common.h: SeedParams::sub; patterns of <= 32 rows) ----
   // For a hit of piece p: k+1 disjoint sub-pieces of the rows within `reach` of the seed, shared out between the two

@@ -6,11 +6,15 @@
 // edits leaves one of k+1 disjoint pattern pieces intact): cut every pattern into k+1 pieces; an end position e
 // with cost <= k has an alignment in which some piece p matches the text exactly, ending at a text position i with
 // e in [i + rem_p - k, i + rem_p + k] (rem_p = pattern rows behind the piece).  So
-//   seed     (seed_search_kernel, first half of its loop): ONE pass over the text.  Every lane packs its characters
-//            to 2-bit Dna codes, forms the L-gram ending at each position and looks it up in a direct-address table
-//            of all pieces of all patterns (4^L entries -> list of (pattern, piece)); every hit goes into the wave's
-//            queue in LDS as (position, pattern, piece);
-//   verify   (same kernel, whenever 64 hits are queued): one lane per hit runs the pattern's Myers column steps (bits
+//   seed     (seed_search_kernel, the pass over the text): ONE pass.  Every lane packs its characters to 2-bit Dna codes,
+//            forms the L-gram ending at each position and looks it up in a direct-address table of all pieces of all
+//            patterns (4^L entries -> list of (pattern, piece)); every hit goes into the wave's queue in LDS as
+//            (position, index of the table entry) -- a tight loop that loads nothing;
+//   test     (same kernel, whenever 64 hits are queued): the sub-piece test (test_issue / test_finish below): one of
+//            k+1 disjoint sub-pieces of the pattern's other rows must be intact within k characters of the seed's
+//            diagonal, or the hit is a chance hit (96 % of them).  Two independent loads per hit, requested a batch
+//            ahead of the comparison;
+//   verify   (same kernel, whenever 64 hits have passed): one lane per hit runs the pattern's Myers column steps (bits
 //            along the pattern, tiled_step.h) over the m + 3k + 1 characters in front of the last end position the
 //            hit allows, from the fresh column -- exact after m + k characters -- and appends every end position
 //            with cost <= k in its range to the (pattern, position, cost) list.  (A first version wrote the hits to
@@ -20,9 +24,10 @@
 //   report rule needs: sort, drop duplicates, flag the reports per run (sort_kernels.hip), trace them
 //   (trace_wave_kernel) -- the tail of the pattern-tiled search (host.hip: finish_pattern_list).
 //
-// Cost at config 4: 3.7e-4 hits per (position, pattern) x 27 characters x ~24 VALU operations against the
-// 17 operations per (position, pattern) of the pattern-tiled scan and the ~100 per (row, pattern, two blocks) of
-// the multi-pattern bit-plane filter.  Integer VALU and L2-resident tables; the text is read once.
+// Cost at config 4: 3.7 table hits per text position, 162 VALU per 64 hits -- the test 84, queueing 30,
+// verification 26 (4 % of the hits pass), table look-ups 11, the passed queue 8 -- at 0.83 of the VALU issue rate; never
+// to be priced against the 17 operations per (position, pattern) of the pattern-tiled scan: the kernel does not do
+// that work.  The text is read once.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
