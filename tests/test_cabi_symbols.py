@@ -73,6 +73,25 @@ def test_required_halo(sassy):
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful on a box without a GPU")
+def test_text_batch_marshalling(sassy):
+    """sassy_amd.TextBatch (one buffer + offsets for search_many): the addresses and lengths the C call would get point at
+    the texts -- from a list, from a buffer with a header in front; a text behind the buffer's end is refused (host logic,
+    no device)."""
+    import numpy as np
+    texts = [b"ACGT", b"", b"TTTTTGGG", b"N" * 100]
+    tb = sassy.TextBatch.from_list(texts)
+    assert len(tb) == 4 and [C.string_at(int(a), int(l)) for a, l in zip(tb._addr, tb.lens)] == texts
+    lens = np.array([len(t) for t in texts])
+    starts = 5 + np.concatenate([[0], np.cumsum(lens)[:-1]])
+    tb2 = sassy.TextBatch(b"#####" + b"".join(texts), starts, lens)
+    assert [C.string_at(int(a), int(l)) for a, l in zip(tb2._addr, tb2.lens)] == texts
+    assert len(sassy.TextBatch.from_list([])) == 0
+    with pytest.raises(sassy.SassyHipError):
+        sassy.TextBatch(b"ACGT", [2], [5])
+    with pytest.raises(sassy.SassyHipError):
+        sassy.TextBatch(b"ACGT", [0, 1], [1])
+
+
 def test_no_device_fails_loudly(sassy):
     assert sassy.device_count() == 0
     s = sassy.Searcher("dna", rc=False)
