@@ -367,8 +367,6 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
       if (have) verify_candidate<WORDS, false>(va, cand);
     }
   };
-  // The first `count` queued hits, one per lane: with the sub-piece test (WORDS == 1, P.sub) the few that pass it
-  // collect in a second queue and are verified 64 at a time, else they are verified at once.
   // the batch whose loads are in flight (test_issue) and its size; compared when the next one's loads have been issued
   TestLoads pend{};
   uint32_t pend_n = 0;  // wave-uniform
@@ -393,6 +391,9 @@ __global__ __launch_bounds__(256) void seed_search_kernel(const SeedParams P) {
       passed_push(ok, cand);
     }
   };
+  // The first `count` queued hits, one per lane: with the sub-piece test (WORDS == 1, P.sub) their loads are requested
+  // and the batch before them is compared -- the few that pass collect in a second queue and are verified 64 at a
+  // time --, else they are verified at once.
   auto verify = [&](uint32_t count) __attribute__((always_inline)) {
     if constexpr (!TEST) verify_from(queue, q_head, count, kRing);
     else {
