@@ -292,6 +292,13 @@ int sassy_hip_multi_search_finish(sassy_hip_Multi *m, sassy_hip_MultiTicket *t, 
  * than 64 n (n + 2) bytes is one device's), or -1 if a part's resident bytes would not cover its share of the
  * reversed text (never, by construction: what the tests pin). */
 long sassy_hip_multi_layout(uint64_t len, size_t n_parts, size_t max_pattern_len, size_t max_k, uint64_t *out);
+/* Where the seeded search of sassy_hip_search_encoded (many patterns, a long text) puts its seeds: k + 1 disjoint
+ * pieces of the pattern's rows -- out_end[i] = one past the last row, out_len[i] = rows (<= 10) -- of at most two
+ * lengths; with ambiguity letters in the patterns (alphabet "iupac") placed where the expected number of table
+ * hits is smallest.  Host arithmetic, no device (tests).  Returns k + 1, or -1 for arguments out of range
+ * (pattern_len 1 .. 64, k <= 7, k + 1 <= pattern_len). */
+long sassy_hip_seed_layout(const char *alphabet, const uint8_t *const *patterns, size_t n_patterns, size_t pattern_len,
+                           size_t k, uint32_t *out_end, uint32_t *out_len);
 void sassy_hip_multi_free(sassy_hip_Multi *m);
 
 typedef struct sassy_hip_Ticket sassy_hip_Ticket;

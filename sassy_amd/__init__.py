@@ -124,7 +124,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
     "sassy_hip_multi_set_rc", "sassy_hip_multi_set_replicated", "sassy_hip_multi_search_encoded", "sassy_hip_multi_search_many",
-    "sassy_hip_multi_set_pipe_depth", "sassy_hip_multi_search_begin", "sassy_hip_multi_search_finish", "sassy_hip_multi_layout",
+    "sassy_hip_multi_set_pipe_depth", "sassy_hip_multi_search_begin", "sassy_hip_multi_search_finish", "sassy_hip_multi_layout", "sassy_hip_seed_layout",
     "sassy_hip_generate_dna", "sassy_hip_generate_genome_like", "sassy_hip_plant",
     "sassy_hip_malloc", "sassy_hip_free", "sassy_hip_memcpy_h2d", "sassy_hip_memcpy_d2h",
 ]
@@ -214,6 +214,10 @@ def lib():
         L.sassy_hip_multi_search_finish.argtypes = [vp, vp, C.POINTER(vp)]
         L.sassy_hip_multi_layout.restype = C.c_long
         L.sassy_hip_multi_layout.argtypes = [C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64)]
+    if hasattr(L, "sassy_hip_seed_layout"):
+        L.sassy_hip_seed_layout.restype = C.c_long
+        L.sassy_hip_seed_layout.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_size_t, C.c_size_t, C.c_size_t,
+                                            C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.sassy_hip_multi_free.restype = None
     L.sassy_hip_multi_free.argtypes = [vp]
     L.sassy_hip_set_only_best_match.restype = C.c_int
@@ -901,6 +905,20 @@ def multi_layout(length: int, n_parts: int, max_pattern_len: int, max_k: int):
     out = (C.c_uint64 * (7 * n_parts))()
     e = lib().sassy_hip_multi_layout(length, n_parts, max_pattern_len, max_k, out)
     return e, [tuple(out[7 * i:7 * i + 7]) for i in range(n_parts)]
+
+
+def seed_layout(alphabet: str, patterns: Sequence[bytes], k: int):
+    """[(first row, rows)] of the k + 1 seeds the seeded search of search_encoded_patterns would use for these patterns
+    (sassy_hip_seed_layout: host arithmetic, no device needed)."""
+    patterns = [bytes(p) for p in patterns]
+    if not patterns or any(len(p) != len(patterns[0]) for p in patterns):
+        raise SassyHipError("seed_layout: patterns of one length, at least one")
+    pp = (C.c_char_p * len(patterns))(*patterns)
+    ends, lens = (C.c_uint32 * 8)(), (C.c_uint32 * 8)()
+    n = lib().sassy_hip_seed_layout(alphabet.encode(), pp, len(patterns), len(patterns[0]), k, ends, lens)
+    if n < 0:
+        raise SassyHipError("seed_layout: arguments out of range")
+    return [(ends[i] - lens[i], lens[i]) for i in range(n)]
 
 
 def generate_dna(d_ptr: int, n: int, seed: int, first: int = 0, stream: int = 0):

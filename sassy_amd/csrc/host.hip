@@ -3508,6 +3508,78 @@ static int seeded_overhang_edges(sassy_SearcherType* s, const sassy_hip_Encoded*
   return 0;
 }
 
+// The seeds of the seeded search (search_encoded_seeded): k+1 DISJOINT pieces of the pattern's rows -- all the pigeonhole
+// argument needs, not a cover -- as (end row, length <= kSeedMaxLen), of at most two lengths (the two tables').
+// The even cut: k+1 pieces, the first m mod (k+1) one row longer; a seed is the last <= kSeedMaxLen rows of a piece.
+// Patterns with ambiguity letters (an Iupac searcher): a seed over such a letter stands for several strings -- the NGG
+// of a CRISPR guide makes the last of the four pieces of a 23-mer hit four times as often as the others.  So the
+// places are chosen so that the expected number of table hits per text position is smallest -- a small dynamic
+// programme over the rows, the mean over up to 512 patterns -- and that layout is taken when it beats the even cut by
+// 5 % (plain patterns keep the even cut).  SASSY_HIP_SEED_LAYOUT=0: the even cut.  Pure host arithmetic
+// (sassy_hip_seed_layout; tests/test_cabi_symbols.py).
+static void seed_layout(int profile, const uint8_t* const* patterns, size_t npat, uint32_t m, uint32_t k, uint32_t* p_end,
+                        uint32_t* p_len) {
+  const uint32_t pieces = k + 1, q = m / pieces, spare = m - q * pieces;
+  for (uint32_t pc = 0; pc < pieces; ++pc) {
+    const uint32_t len = q + (pc < spare ? 1u : 0u);
+    p_end[pc] = pc * q + std::min(pc, spare) + len;
+    p_len[pc] = std::min(len, kSeedMaxLen);
+  }
+  if (profile != PROFILE_IUPAC || getenv("SASSY_HIP_SEED_LAYOUT") != nullptr || npat == 0) return;
+  const size_t sample = std::min<size_t>(npat, 512);
+  // rate[a][L] = mean over the sampled patterns of the probability that a random L-gram matches rows [a, a + L)
+  std::vector<std::vector<double>> rate(m + 1, std::vector<double>(kSeedMaxLen + 1, 0.0));
+  for (size_t p = 0; p < sample; ++p) {
+    const uint8_t* pt = patterns[p * (npat / sample)];
+    for (uint32_t a = 0; a < m; ++a) {
+      double pr = 1.0;
+      for (uint32_t L = 1; L <= kSeedMaxLen && a + L <= m; ++L) {
+        pr *= (double)__builtin_popcount(iupac_code(pt[a + L - 1]) & 0x0Fu) / 4.0;
+        rate[a][L] += pr / (double)sample;
+      }
+    }
+  }
+  double even = 0;
+  for (uint32_t pc = 0; pc < pieces; ++pc) even += rate[p_end[pc] - p_len[pc]][p_len[pc]];
+  double best = even * 0.95;
+  uint32_t best_end[8], best_len[8];
+  bool found = false;
+  for (uint32_t La = 3; La <= kSeedMaxLen; ++La)
+    for (uint32_t Lb = La; Lb <= std::min<uint32_t>(kSeedMaxLen, La + 2); ++Lb) {
+      if ((uint64_t)La * pieces > m) continue;
+      // f[j][i] = least total rate of j pieces within rows [0, i); from[j][i] = the length of the piece that ends at i (0: none)
+      const double inf = 1e300;
+      std::vector<std::vector<double>> f(pieces + 1, std::vector<double>(m + 1, inf));
+      std::vector<std::vector<uint32_t>> from(pieces + 1, std::vector<uint32_t>(m + 1, 0u));
+      for (uint32_t i = 0; i <= m; ++i) f[0][i] = 0;
+      for (uint32_t j = 1; j <= pieces; ++j)
+        for (uint32_t i = 1; i <= m; ++i) {
+          f[j][i] = f[j][i - 1];
+          from[j][i] = 0;
+          for (uint32_t L : {La, Lb})
+            if (i >= L && f[j - 1][i - L] < inf && f[j - 1][i - L] + rate[i - L][L] < f[j][i]) {
+              f[j][i] = f[j - 1][i - L] + rate[i - L][L];
+              from[j][i] = L;
+            }
+        }
+      if (f[pieces][m] >= best) continue;
+      best = f[pieces][m];
+      found = true;
+      uint32_t i = m;
+      for (uint32_t j = pieces; j >= 1; --j) {
+        while (from[j][i] == 0) --i;
+        best_end[j - 1] = i;
+        best_len[j - 1] = from[j][i];
+        i -= from[j][i];
+      }
+    }
+  if (found)
+    for (uint32_t pc = 0; pc < pieces; ++pc) {
+      p_end[pc] = best_end[pc];
+      p_len[pc] = best_len[pc];
+    }
+}
+
 // search_encoded_patterns for many patterns over a long text: seed -> verify -> report (seed_kernels.hip).  One
 // pass over the text -- one launch -- looks every L-gram up in a table of all patterns' pigeonhole pieces; one lane
 // per hit runs the pattern over the few dozen characters around it.  Dna codes only (the caller has checked the text is plain ACGT
@@ -3527,78 +3599,17 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     PatternPlan pl;
     if (!make_plan(s->profile, e->patterns[p].data(), m, p == 0 ? plan0 : pl, err)) return fail(SASSY_HIP_EINVAL, err);
   }
-  // ---- pieces: k+1 of them, the first m mod (k+1) one row longer; a seed is the last <= kSeedMaxLen rows of a piece ----
-  const uint32_t pieces = k + 1, q = m / pieces, spare = m - q * pieces;
+  // ---- the seeds: k+1 disjoint pieces, at most two lengths (seed_layout) ----
+  const uint32_t pieces = k + 1;
   uint32_t p_end[8], p_len[8], tab_of[8], tab_len[2] = {0, 0};
+  {
+    std::vector<const uint8_t*> rows(npat);
+    for (size_t p = 0; p < npat; ++p) rows[p] = e->patterns[p].data();
+    seed_layout(s->profile, rows.data(), npat, m, k, p_end, p_len);
+  }
   for (uint32_t pc = 0; pc < pieces; ++pc) {
-    const uint32_t len = q + (pc < spare ? 1u : 0u);
-    p_end[pc] = pc * q + std::min(pc, spare) + len;
-    p_len[pc] = std::min(len, kSeedMaxLen);
     if (tab_len[0] == 0 || tab_len[0] == p_len[pc]) { tab_len[0] = p_len[pc]; tab_of[pc] = 0; }
     else { tab_len[1] = p_len[pc]; tab_of[pc] = 1; }
-  }
-  // Patterns with ambiguity letters (an Iupac searcher): a seed over such a letter stands for several strings -- the NGG
-  // of a CRISPR guide makes the last of the four pieces of a 23-mer hit four times as often as the others.  The
-  // pigeonhole argument needs k+1 DISJOINT pieces, not a cover: choose their places (seeds of at most two lengths, the
-  // tables') so that the expected number of table hits per text position is smallest -- a small dynamic programme over
-  // the rows -- and take that layout when it beats the even cut by 5 % (plain patterns keep the even cut).
-  if (s->profile == PROFILE_IUPAC && getenv("SASSY_HIP_SEED_LAYOUT") == nullptr) {
-    const size_t sample = std::min<size_t>(npat, 512);
-    // rate[a][L] = mean over the sampled patterns of the probability that a random L-gram matches rows [a, a + L)
-    std::vector<std::vector<double>> rate(m + 1, std::vector<double>(kSeedMaxLen + 1, 0.0));
-    for (size_t p = 0; p < sample; ++p) {
-      const uint8_t* pt = e->patterns[p * (npat / sample)].data();
-      for (uint32_t a = 0; a < m; ++a) {
-        double pr = 1.0;
-        for (uint32_t L = 1; L <= kSeedMaxLen && a + L <= m; ++L) {
-          pr *= (double)__builtin_popcount(iupac_code(pt[a + L - 1]) & 0x0Fu) / 4.0;
-          rate[a][L] += pr / (double)sample;
-        }
-      }
-    }
-    double even = 0;
-    for (uint32_t pc = 0; pc < pieces; ++pc) even += rate[p_end[pc] - p_len[pc]][p_len[pc]];
-    double best = even * 0.95;
-    uint32_t best_end[8], best_len[8];
-    bool found = false;
-    for (uint32_t La = 3; La <= kSeedMaxLen; ++La)
-      for (uint32_t Lb = La; Lb <= std::min<uint32_t>(kSeedMaxLen, La + 2); ++Lb) {
-        if ((uint64_t)La * pieces > m) continue;
-        // f[j][i] = least total rate of j pieces within rows [0, i); from[j][i] = the length of the piece that ends at i (0: none)
-        const double inf = 1e300;
-        std::vector<std::vector<double>> f(pieces + 1, std::vector<double>(m + 1, inf));
-        std::vector<std::vector<uint32_t>> from(pieces + 1, std::vector<uint32_t>(m + 1, 0u));
-        for (uint32_t i = 0; i <= m; ++i) f[0][i] = 0;
-        for (uint32_t j = 1; j <= pieces; ++j)
-          for (uint32_t i = 1; i <= m; ++i) {
-            f[j][i] = f[j][i - 1];
-            from[j][i] = 0;
-            for (uint32_t L : {La, Lb})
-              if (i >= L && f[j - 1][i - L] < inf && f[j - 1][i - L] + rate[i - L][L] < f[j][i]) {
-                f[j][i] = f[j - 1][i - L] + rate[i - L][L];
-                from[j][i] = L;
-              }
-          }
-        if (f[pieces][m] >= best) continue;
-        best = f[pieces][m];
-        found = true;
-        uint32_t i = m;
-        for (uint32_t j = pieces; j >= 1; --j) {
-          while (from[j][i] == 0) --i;
-          best_end[j - 1] = i;
-          best_len[j - 1] = from[j][i];
-          i -= from[j][i];
-        }
-      }
-    if (found) {
-      tab_len[0] = tab_len[1] = 0;
-      for (uint32_t pc = 0; pc < pieces; ++pc) {
-        p_end[pc] = best_end[pc];
-        p_len[pc] = best_len[pc];
-        if (tab_len[0] == 0 || tab_len[0] == p_len[pc]) { tab_len[0] = p_len[pc]; tab_of[pc] = 0; }
-        else { tab_len[1] = p_len[pc]; tab_of[pc] = 1; }
-      }
-    }
   }
   uint32_t seed_bits_off[2] = {0, 0};
   // ---- direct-address tables: code of a seed = sum of its characters' Dna codes, first character lowest ----
@@ -5463,6 +5474,17 @@ int sassy_hip_multi_search_finish(sassy_hip_Multi* m, sassy_hip_MultiTicket* t, 
 // {offset, len, halo in front, bytes kept behind, first forward byte of its share of the REVERSED text, one past its
 // last, that share's halo} go to out[7 i .. 7 i + 6]; returns the number of parts that hold a share, or -1 when some
 // part's resident bytes would not cover its share of the reversed text (never, by construction).
+long sassy_hip_seed_layout(const char* alphabet, const uint8_t* const* patterns, size_t n_patterns, size_t pattern_len, size_t k,
+                           uint32_t* out_end, uint32_t* out_len) {
+  if (!alphabet || !patterns || !out_end || !out_len || pattern_len == 0 || pattern_len > 64 || k > 7 || pattern_len / (k + 1) < 1)
+    return -1;
+  const std::string a(alphabet);
+  const int profile = a == "dna" ? PROFILE_DNA : a == "iupac" ? PROFILE_IUPAC : a == "ascii" ? PROFILE_ASCII : -1;
+  if (profile < 0) return -1;
+  seed_layout(profile, patterns, n_patterns, (uint32_t)pattern_len, (uint32_t)k, out_end, out_len);
+  return (long)(k + 1);
+}
+
 long sassy_hip_multi_layout(uint64_t len, size_t n_parts, size_t max_pattern_len, size_t max_k, uint64_t* out) {
   if (n_parts == 0) return -1;
   const size_t E = sassy_hip_Multi::multi_eff_parts(len, n_parts);

@@ -92,6 +92,39 @@ def test_text_batch_marshalling(sassy):
         sassy.TextBatch(b"ACGT", [0, 1], [1])
 
 
+def test_seed_layout_of_the_seeded_search(sassy):
+    """sassy_hip_seed_layout (host arithmetic of search_encoded_patterns' seeded search, no device): k + 1 disjoint seeds of
+    at most two lengths and at most 10 rows inside the pattern, for every shape the path takes; plain patterns keep the
+    even cut; CRISPR guides (20 bases + NGG) get their N into a 6-row seed instead of the even cut's 5-row one (expected
+    table hits per position and guide 4.6e-3 -> 2.4e-3); a row that matches nothing ('X') may sit in a seed."""
+    import random
+    rng = random.Random(5)
+    for m in range(8, 33):
+        for k in range(0, 8):
+            if m // (k + 1) < 3:
+                continue
+            for alphabet in ("dna", "iupac"):
+                pats = [bytes(rng.choice(b"ACGT") for _ in range(m)) for _ in range(5)]
+                if alphabet == "iupac":
+                    pats = [bytes(rng.choice(b"ACGTNRYX") if rng.random() < 0.15 else c for c in p) for p in pats]
+                lay = sassy.seed_layout(alphabet, pats, k)
+                assert len(lay) == k + 1 and len({ln for _, ln in lay}) <= 2, (m, k, lay)
+                last = 0
+                for a, ln in sorted(lay):
+                    assert a >= last and 1 <= ln <= 10 and a + ln <= m, (m, k, lay)
+                    last = a + ln
+    plain = [bytes(rng.choice(b"ACGT") for _ in range(23)) for _ in range(50)]
+    assert sassy.seed_layout("iupac", plain, 3) == sassy.seed_layout("dna", plain, 3) == [(0, 6), (6, 6), (12, 6), (18, 5)]
+    guides = [p[:20] + b"NGG" for p in plain]
+    lay = sorted(sassy.seed_layout("iupac", guides, 3))
+
+    def rate(layout):
+        return sum(4.0 ** -(ln - (1 if a <= 20 < a + ln else 0)) for a, ln in layout)
+    assert rate(lay) < 0.6 * rate([(0, 6), (6, 6), (12, 6), (18, 5)]) and abs(rate(lay) - 2.44e-3) < 1e-4, (lay, rate(lay))
+    with pytest.raises(sassy.SassyHipError):
+        sassy.seed_layout("dna", [b"ACGT"], 5)
+
+
 def test_no_device_fails_loudly(sassy):
     assert sassy.device_count() == 0
     s = sassy.Searcher("dna", rc=False)
