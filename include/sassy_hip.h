@@ -299,6 +299,14 @@ long sassy_hip_multi_layout(uint64_t len, size_t n_parts, size_t max_pattern_len
  * (pattern_len 1 .. 64, k <= 7, k + 1 <= pattern_len). */
 long sassy_hip_seed_layout(const char *alphabet, const uint8_t *const *patterns, size_t n_patterns, size_t pattern_len,
                            size_t k, uint32_t *out_end, uint32_t *out_len);
+/* The 64 table rows of the sub-piece test that runs in front of the seeded search's verification, for seeds
+ * (seed_end[i], seed_len[i]), i <= k, of a pattern of pattern_len <= 32 rows: out_rows[8 p + u] = 2a | (32 - 2 len) << 8 |
+ * 2 (off & 15) << 16 | (off >> 4) << 24 for sub-piece u (rows [a, a + len)) of piece p, off = its leftmost shift in
+ * characters from the start of the one text window the test reads (*out_win_left characters in front of the seed's
+ * end); low byte 0xFF in out_rows[8 p]: no test for piece p.  Returns the largest off (<= 47), -1 for arguments out
+ * of range.  Host arithmetic, no device (tests). */
+long sassy_hip_seed_test_rows(size_t pattern_len, size_t k, const uint32_t *seed_end, const uint32_t *seed_len,
+                              uint32_t *out_rows, uint32_t *out_win_left);
 void sassy_hip_multi_free(sassy_hip_Multi *m);
 
 typedef struct sassy_hip_Ticket sassy_hip_Ticket;

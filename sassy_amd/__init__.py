@@ -124,7 +124,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_result_exit_state", "sassy_hip_result_conditional_index", "sassy_hip_result_free",
     "sassy_hip_encode_patterns", "sassy_hip_encoded_free", "sassy_hip_search_encoded",
     "sassy_hip_multi_set_rc", "sassy_hip_multi_set_replicated", "sassy_hip_multi_search_encoded", "sassy_hip_multi_search_many",
-    "sassy_hip_multi_set_pipe_depth", "sassy_hip_multi_search_begin", "sassy_hip_multi_search_finish", "sassy_hip_multi_layout", "sassy_hip_seed_layout",
+    "sassy_hip_multi_set_pipe_depth", "sassy_hip_multi_search_begin", "sassy_hip_multi_search_finish", "sassy_hip_multi_layout", "sassy_hip_seed_layout", "sassy_hip_seed_test_rows",
     "sassy_hip_generate_dna", "sassy_hip_generate_genome_like", "sassy_hip_plant",
     "sassy_hip_malloc", "sassy_hip_free", "sassy_hip_memcpy_h2d", "sassy_hip_memcpy_d2h",
 ]
@@ -218,6 +218,10 @@ def lib():
         L.sassy_hip_seed_layout.restype = C.c_long
         L.sassy_hip_seed_layout.argtypes = [C.c_char_p, C.POINTER(C.c_char_p), C.c_size_t, C.c_size_t, C.c_size_t,
                                             C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    if hasattr(L, "sassy_hip_seed_test_rows"):
+        L.sassy_hip_seed_test_rows.restype = C.c_long
+        L.sassy_hip_seed_test_rows.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                               C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.sassy_hip_multi_free.restype = None
     L.sassy_hip_multi_free.argtypes = [vp]
     L.sassy_hip_set_only_best_match.restype = C.c_int
@@ -919,6 +923,24 @@ def seed_layout(alphabet: str, patterns: Sequence[bytes], k: int):
     if n < 0:
         raise SassyHipError("seed_layout: arguments out of range")
     return [(ends[i] - lens[i], lens[i]) for i in range(n)]
+
+
+def seed_test_rows(pattern_len: int, k: int, seeds):
+    """(win_left, largest offset, {piece: [(first row, rows, offset)]}) -- the sub-piece test's layout for the seeds
+    [(first row, rows)] (sassy_hip_seed_test_rows: host arithmetic, no device needed); a piece without a test is left out."""
+    ends = (C.c_uint32 * 8)(*[a + ln for a, ln in seeds])
+    lens = (C.c_uint32 * 8)(*[ln for _, ln in seeds])
+    rows, win = (C.c_uint32 * 64)(), C.c_uint32()
+    mx = lib().sassy_hip_seed_test_rows(pattern_len, k, ends, lens, rows, C.byref(win))
+    if mx < 0:
+        raise SassyHipError("seed_test_rows: arguments out of range")
+    out = {}
+    for p in range(k + 1):
+        if (rows[8 * p] & 0xFF) == 0xFF:
+            continue
+        out[p] = [((r & 0xFF) // 2, (32 - ((r >> 8) & 0xFF)) // 2, ((r >> 16) & 0xFF) // 2 + 16 * (r >> 24))
+                  for r in (rows[8 * p + u] for u in range(k + 1))]
+    return win.value, mx, out
 
 
 def generate_dna(d_ptr: int, n: int, seed: int, first: int = 0, stream: int = 0):

@@ -3580,6 +3580,63 @@ static void seed_layout(int profile, const uint8_t* const* patterns, size_t npat
     }
 }
 
+// The rows of the sub-piece test in front of the seeded search's verification (common.h: SeedParams::sub) for the seeds
+// (p_end, p_len).  For a hit of piece p: k+1 disjoint sub-pieces of the rows within `reach` of the seed, shared out between
+// the two sides in proportion to the rows there; one of them must be intact within k characters of the seed's diagonal.
+// The test reads ONE window of the 2-bit text for all pieces (seed_kernels.hip: test_issue): it starts *win_left =
+// (longest seed) + (most rows used left of a seed) + k characters in front of the seed's end, and every sub-piece must
+// start, at its leftmost shift, within 48 characters of that -- the largest reach <= 24 - k that allows it.
+// sub[8 p + u] = 2a | (32 - 2 len) << 8 | 2 (off & 15) << 16 | (off >> 4) << 24 for sub-piece u = rows [a, a + len) of
+// piece p, off = characters from the window's start to where it lies at its leftmost shift; len is capped so that
+// (off & 15) + 2k + len <= 32: the compared bits lie in the 64 the test takes from the window.  sub[8 p] = 0xFF: no
+// test for piece p (fewer rows around it than sub-pieces).  *max_off <= 31: four dwords of text suffice (the narrow
+// layout).  Pure host arithmetic (sassy_hip_seed_test_rows; tests/test_cabi_symbols.py).
+static void seed_test_rows(uint32_t m, uint32_t k, const uint32_t* p_end, const uint32_t* p_len, uint32_t* sub, uint32_t* win_left,
+                           uint32_t* max_off) {
+  const uint32_t pieces = k + 1;
+  struct SubPiece { uint32_t pc, u, a, len, off; };
+  std::vector<SubPiece> subs;
+  *win_left = 0;
+  *max_off = 0;
+  for (uint32_t reach = 24 - k; reach >= 4; --reach) {  // (k <= 7)
+    subs.clear();
+    uint32_t max_nl = 0, max_len = 0;
+    for (uint32_t pc = 0; pc < pieces; ++pc) {
+      const uint32_t sp = p_end[pc] - p_len[pc], pe = p_end[pc];
+      const uint32_t nl = std::min(sp, reach), nr = std::min(m - pe, reach);
+      max_len = std::max(max_len, p_len[pc]);
+      if (nl + nr < pieces) continue;  // fewer rows than sub-pieces: no test for this piece
+      max_nl = std::max(max_nl, nl);
+      uint32_t cl = (uint32_t)(((uint64_t)pieces * nl + (nl + nr) / 2) / (nl + nr));
+      cl = std::min(cl, nl);
+      uint32_t cr = pieces - cl;
+      if (cr > nr) { cr = nr; cl = pieces - cr; }
+      uint32_t u = 0;
+      for (uint32_t x = 0; x < cl; ++x) {  // left of the seed: rows [sp - nl, sp) in cl parts
+        const uint32_t a = sp - nl + (uint32_t)((uint64_t)nl * x / cl), b = sp - nl + (uint32_t)((uint64_t)nl * (x + 1) / cl);
+        subs.push_back({pc, u++, a, b - a, sp - a});  // (off: for now the rows from a to the seed's start)
+      }
+      for (uint32_t x = 0; x < cr; ++x) {  // right of it: rows [pe, pe + nr) in cr parts
+        const uint32_t a = pe + (uint32_t)((uint64_t)nr * x / cr), b = pe + (uint32_t)((uint64_t)nr * (x + 1) / cr);
+        subs.push_back({pc, u++, a, b - a, 0x80000000u | (a - pe)});  // (rows from the seed's end to a)
+      }
+    }
+    *win_left = max_len + max_nl + k;
+    *max_off = 0;
+    for (SubPiece& q : subs) {
+      q.off = (q.off & 0x80000000u) ? *win_left + (q.off & 0x7FFFFFFFu) - k : *win_left - p_len[q.pc] - q.off - k;
+      *max_off = std::max(*max_off, q.off);
+    }
+    if (*max_off <= 47) break;
+    subs.clear();
+  }
+  for (int i = 0; i < 64; ++i) sub[i] = 0xFFu;  // (low byte 0xFF in a piece's first entry: no test for that piece)
+  for (const SubPiece& q : subs) {
+    const uint32_t len = std::min(q.len, std::min(16u, 17u - 2u * k));
+    sub[8 * q.pc + q.u] = (2 * q.a) | ((32 - 2 * len) << 8) | ((2 * (q.off & 15u)) << 16) | ((q.off >> 4) << 24);
+  }
+}
+
 // search_encoded_patterns for many patterns over a long text: seed -> verify -> report (seed_kernels.hip).  One
 // pass over the text -- one launch -- looks every L-gram up in a table of all patterns' pigeonhole pieces; one lane
 // per hit runs the pattern over the few dozen characters around it.  Dna codes only (the caller has checked the text is plain ACGT
@@ -3732,51 +3789,13 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
   for (uint32_t pc = 0; pc < pieces; ++pc) {
     SP.rem_packed |= (uint64_t)(m - p_end[pc]) << (8 * pc);
   }
-  // ---- the sub-piece test in front of the verification (common.h: SeedParams::sub; patterns of <= 32 rows) ----
-  // For a hit of piece p: k+1 disjoint sub-pieces of the rows within `reach` of the seed, shared out between the two
-  // sides in proportion to the rows there; one of them must be intact within k characters of the seed's diagonal.
-  // The test reads ONE window of the 2-bit text for all pieces (seed_kernels.hip: test_issue): it starts win_left =
-  // (longest seed) + (most rows used left of a seed) + k characters in front of the seed's end, and every sub-piece
-  // must start, at its leftmost shift, within 48 characters of that -- the largest reach <= 24 - k that allows it.
+  // ---- the sub-piece test in front of the verification (seed_test_rows; patterns of <= 32 rows) ----
   static const bool env_sub = !(getenv("SASSY_HIP_SEED_SUBTEST") && atoi(getenv("SASSY_HIP_SEED_SUBTEST")) == 0);
   static const bool env_narrow = !(getenv("SASSY_HIP_SEED_NARROW") && atoi(getenv("SASSY_HIP_SEED_NARROW")) == 0);
   static const bool env_pos64 = getenv("SASSY_HIP_SEED_POS64") && atoi(getenv("SASSY_HIP_SEED_POS64")) != 0;  // (tests)
   if (!wide && env_sub) {
-    struct SubPiece { uint32_t pc, u, a, len, off; };
-    std::vector<SubPiece> subs;
-    uint32_t win_left = 0, max_off = 0;
-    for (uint32_t reach = 24 - k; reach >= 4; --reach) {  // (k <= 7)
-      subs.clear();
-      uint32_t max_nl = 0, max_len = 0;
-      for (uint32_t pc = 0; pc < pieces; ++pc) {
-        const uint32_t sp = p_end[pc] - p_len[pc], pe = p_end[pc];
-        const uint32_t nl = std::min(sp, reach), nr = std::min(m - pe, reach);
-        max_len = std::max(max_len, p_len[pc]);
-        if (nl + nr < pieces) continue;  // fewer rows than sub-pieces: no test for this piece
-        max_nl = std::max(max_nl, nl);
-        uint32_t cl = (uint32_t)(((uint64_t)pieces * nl + (nl + nr) / 2) / (nl + nr));
-        cl = std::min(cl, nl);
-        uint32_t cr = pieces - cl;
-        if (cr > nr) { cr = nr; cl = pieces - cr; }
-        uint32_t u = 0;
-        for (uint32_t x = 0; x < cl; ++x) {  // left of the seed: rows [sp - nl, sp) in cl parts
-          const uint32_t a = sp - nl + (uint32_t)((uint64_t)nl * x / cl), b = sp - nl + (uint32_t)((uint64_t)nl * (x + 1) / cl);
-          subs.push_back({pc, u++, a, b - a, sp - a});  // (off: for now the rows from a to the seed's start)
-        }
-        for (uint32_t x = 0; x < cr; ++x) {  // right of it: rows [pe, pe + nr) in cr parts
-          const uint32_t a = pe + (uint32_t)((uint64_t)nr * x / cr), b = pe + (uint32_t)((uint64_t)nr * (x + 1) / cr);
-          subs.push_back({pc, u++, a, b - a, 0x80000000u | (a - pe)});  // (rows from the seed's end to a)
-        }
-      }
-      win_left = max_len + max_nl + k;
-      max_off = 0;
-      for (SubPiece& q : subs) {
-        q.off = (q.off & 0x80000000u) ? win_left + (q.off & 0x7FFFFFFFu) - k : win_left - p_len[q.pc] - q.off - k;
-        max_off = std::max(max_off, q.off);
-      }
-      if (max_off <= 47) break;
-      subs.clear();
-    }
+    uint32_t sub[64], win_left = 0, max_off = 0;
+    seed_test_rows(m, k, p_end, p_len, sub, &win_left, &max_off);
     // (an Iupac searcher whose patterns are all plain bases -- 10 000 random 20-mers -- needs no care words; the
     // kernel for positions beyond 32 bits always reads them)
     const bool pos64 = env_pos64 || text_len >= 0xFFFF0000ull;
@@ -3788,12 +3807,6 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
           if (!set || (set & (set - 1))) { care_words = true; break; }
         }
     const bool narrow = env_narrow && !care_words && max_off <= 31;
-    std::vector<uint32_t> sub(64, 0xFFu);  // (low byte 0xFF in a piece's first entry: no test for that piece)
-    for (const SubPiece& q : subs) {
-      // (off & 15) + 2k + len <= 32: the compared bits lie in the 64 the test takes from the window
-      const uint32_t len = std::min(q.len, std::min(16u, 17u - 2u * k));
-      sub[8 * q.pc + q.u] = (2 * q.a) | ((32 - 2 * len) << 8) | ((2 * (q.off & 15u)) << 16) | ((q.off >> 4) << 24);
-    }
     // the table entries with their patterns' packed rows: row j at bits 2j; with care words a second pair says which
     // rows the test may compare (11: a concrete base, 00: a letter that stands for several -- such a row matches
     // any character here)
@@ -3823,7 +3836,7 @@ static int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded*
     if (int rc = s->d_seed_sub.reserve(64)) return rc;
     if (int rc = s->d_seed_e16.reserve(e16.size() + 8)) return rc;
     if (int rc = s->d_seed_packed.reserve(n16 + 8)) return rc;
-    HIP_TRY(hipMemcpyAsync(s->d_seed_sub.p, sub.data(), 64 * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(s->d_seed_sub.p, sub, 64 * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(s->d_seed_e16.p, e16.data(), e16.size() * 4, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(s->d_seed_packed.p + n16, 0, 8 * 4, st));
     hipError_t pe_ = launch_pack_text(tptr, text_len, s->d_seed_packed.p, st);
@@ -5483,6 +5496,16 @@ long sassy_hip_seed_layout(const char* alphabet, const uint8_t* const* patterns,
   if (profile < 0) return -1;
   seed_layout(profile, patterns, n_patterns, (uint32_t)pattern_len, (uint32_t)k, out_end, out_len);
   return (long)(k + 1);
+}
+
+long sassy_hip_seed_test_rows(size_t pattern_len, size_t k, const uint32_t* seed_end, const uint32_t* seed_len, uint32_t* out_rows,
+                              uint32_t* out_win_left) {
+  if (!seed_end || !seed_len || !out_rows || !out_win_left || pattern_len == 0 || pattern_len > 32 || k > 7) return -1;
+  for (size_t i = 0; i <= k; ++i)
+    if (seed_len[i] == 0 || seed_len[i] > kSeedMaxLen || seed_end[i] > pattern_len || seed_end[i] < seed_len[i]) return -1;
+  uint32_t max_off = 0;
+  seed_test_rows((uint32_t)pattern_len, (uint32_t)k, seed_end, seed_len, out_rows, out_win_left, &max_off);
+  return (long)max_off;
 }
 
 long sassy_hip_multi_layout(uint64_t len, size_t n_parts, size_t max_pattern_len, size_t max_k, uint64_t* out) {

@@ -125,6 +125,39 @@ def test_seed_layout_of_the_seeded_search(sassy):
         sassy.seed_layout("dna", [b"ACGT"], 5)
 
 
+def test_sub_piece_test_rows_of_the_seeded_search(sassy):
+    """sassy_hip_seed_test_rows (host arithmetic, no device): for every shape and both seed layouts -- the even cut and a
+    layout with gaps -- the k + 1 sub-pieces of a tested piece are disjoint, lie in the pattern outside the seed, start
+    within 48 characters of the window (within 32: the narrow layout), keep their compared bits inside the 64 the kernel
+    takes ((off & 15) + 2k + len <= 32), and sit on the seed's diagonal: off = win_left - (seed end - row) - k."""
+    for m in range(8, 33):
+        for k in range(0, 8):
+            if m // (k + 1) < 3:
+                continue
+            even = sassy.seed_layout("dna", [b"A" * m], k)
+            q = m // (k + 1)
+            gaps = [(i * q + (1 if q > 3 else 0), min(q, 10) - (1 if q > 3 else 0)) for i in range(k + 1)]  # (a row left out in front of every seed)
+            for seeds in (even, gaps):
+                win, mx, rows = sassy.seed_test_rows(m, k, seeds)
+                assert mx <= 47 and win <= 10 + 24, (m, k, seeds)
+                tested = 0
+                for p, subs in rows.items():
+                    a0, l0 = seeds[p]
+                    assert len(subs) == k + 1
+                    tested += 1
+                    last = 0
+                    for a, ln, off in sorted(subs):
+                        assert a >= last and ln >= 1 and a + ln <= m and (a + ln <= a0 or a >= a0 + l0), (m, k, seeds, p, subs)
+                        assert (off & 15) + 2 * k + ln <= 32 and off <= mx, (m, k, seeds, p, subs)
+                        assert off == win - (a0 + l0 - a) - k, (m, k, seeds, p, (a, ln, off), win)
+                        last = a + ln
+                # a piece goes untested only when fewer than k + 1 rows lie around it
+                for p, (a0, l0) in enumerate(seeds):
+                    assert (p in rows) or (a0 + (m - a0 - l0) < k + 1) or win == 0, (m, k, seeds, p)
+    with pytest.raises(sassy.SassyHipError):
+        sassy.seed_test_rows(40, 2, [(0, 6), (6, 7), (13, 7)])
+
+
 def test_no_device_fails_loudly(sassy):
     assert sassy.device_count() == 0
     s = sassy.Searcher("dna", rc=False)
