@@ -158,6 +158,50 @@ def test_sub_piece_test_rows_of_the_seeded_search(sassy):
         sassy.seed_test_rows(40, 2, [(0, 6), (6, 7), (13, 7)])
 
 
+def test_sub_piece_test_never_rejects_a_match(sassy):
+    """Soundness of the sub-piece test's layout, on the CPU: a text that holds the pattern with at most k edits, none of
+    them in seed p, is a hit of seed p that the test must pass -- replay the kernel's comparison (seed_kernels.hip:
+    test_finish: window from win_left in front of the seed's end, sub-piece u at offset off + 0 .. 2k) on the exported rows
+    for every shape, every tested piece, random edits (next to the seed, at sub-piece borders, insertions and deletions that
+    shift what lies beyond them)."""
+    import random
+    rng = random.Random(20260929)
+    for m in range(8, 33):
+        for k in range(0, 8):
+            if m // (k + 1) < 3:
+                continue
+            seeds = sassy.seed_layout("dna", [b"A" * m], k)
+            win, mx, rows = sassy.seed_test_rows(m, k, seeds)
+            for p, subs in rows.items():
+                a0, l0 = seeds[p]
+                for _ in range(40):
+                    pat = [rng.choice("ACGT") for _ in range(m)]
+                    # up to k edits at rows outside the seed; the text is built row by row
+                    edits = {}
+                    for _e in range(rng.randrange(0, k + 1)):
+                        r = rng.choice([x for x in range(m) if not (a0 <= x < a0 + l0)])
+                        edits[r] = rng.choice("sid")
+                    left = [rng.choice("ACGT") for _ in range(80)]
+                    text, seed_end = list(left), None
+                    for r in range(m):
+                        e = edits.get(r)
+                        if e == "d":
+                            pass
+                        elif e == "s":
+                            text.append(rng.choice([c for c in "ACGT" if c != pat[r]]))
+                        elif e == "i":
+                            text.append(rng.choice("ACGT")); text.append(pat[r])
+                        else:
+                            text.append(pat[r])
+                        if r == a0 + l0 - 1:
+                            seed_end = len(text)
+                    text += [rng.choice("ACGT") for _ in range(80)]
+                    cl = seed_end - win
+                    ok = any(text[cl + off + d: cl + off + d + ln] == pat[a:a + ln]
+                             for a, ln, off in subs for d in range(2 * k + 1))
+                    assert ok, (m, k, p, seeds, subs, "".join(pat), edits)
+
+
 def test_no_device_fails_loudly(sassy):
     assert sassy.device_count() == 0
     s = sassy.Searcher("dna", rc=False)
