@@ -659,6 +659,38 @@ def other_configs(sassy_amd, text):
                 "seconds": round(min(secs), 4), "seconds_first_call": round(secs[0], 4),
                 "pattern_text_TB_per_s": round(n * 10_000 / min(secs) / 1e12, 1), "matches": len(r),
                 "path": s4.stats()["filtered"]}
+    # a CRISPR guide set (the reference's off-target workflow): 312 guides of 20 bases with their PAM "NGG", k = 3, both
+    # strands, through search_encoded_patterns -- the seeded search with ambiguity letters in its seeds
+    import numpy as np
+    rng = np.random.default_rng(11)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    guides = [bytes(acgt[rng.integers(0, 4, 20)]) + b"NGG" for _ in range(312)]
+    sg = sassy_amd.Searcher("iupac", rc=True)
+    encg = sg.encode_patterns(guides)
+    secs = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        r = sg.search_encoded_patterns(encg, text, 3, as_result=True)
+        secs.append(time.perf_counter() - t0)
+    res["crispr_guides"] = {"workload": f"Iupac searcher, both strands, search_encoded_patterns, 312 guides (20 + NGG), k=3, {n} B",
+                            "seconds": round(min(secs), 4), "seconds_first_call": round(secs[0], 4),
+                            "pattern_text_TB_per_s": round(n * 624 / min(secs) / 1e12, 1), "matches": len(r),
+                            "path": sg.stats()["filtered"]}
+    # the reference's default for DNA is both strands (c/example.c:14, python default): the benchmark shape with rc = true,
+    # the searcher told that the text did not change (the reversed copy is kept)
+    ps = bytes(_dna_bytes(49, 0, 23))
+    sb = sassy_amd.Searcher("dna", rc=True)
+    sb.search(ps, text, 3)  # (makes the reversed copy)
+    sb.text_unchanged(True)
+    sb.set_timing(0)
+    for _ in range(3):
+        r = sb.search(ps, text, 3)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        r = sb.search(ps, text, 3)
+    dt = (time.perf_counter() - t0) / 20
+    res["m23k3_both_strands"] = {"workload": f"Dna, both strands, |pattern|=23, k=3, {n} B, lone searches, text unchanged",
+                                 "ms_per_search": round(dt * 1e3, 3), "matches": len(r)}
     return res
 
 
