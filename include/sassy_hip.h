@@ -113,6 +113,16 @@ int sassy_hip_get_stats(const sassy_SearcherType *s, sassy_hip_Stats *out);
  * streaming scan when unfiltered; default), 2 = every phase (scan_ms, filter_ms, trace_ms).  Each
  * recorded event costs a few microseconds of stream idle time. */
 int sassy_hip_set_timing(sassy_SearcherType *s, int level);
+/* The switch table (sassy_amd/csrc/switches.h): every switch that forces a kernel path or sets a tuning
+ * value.  A searcher fills its copy ONCE, when it is made: the defaults, then the environment variables
+ * SASSY_HIP_<NAME> that are set -- no search entry point reads the environment.  sassy_hip_set_option changes one entry
+ * of an existing searcher (name: lower case, without the prefix -- "fused", "filter_kind", "pair", ...; refused while
+ * searches are in flight), sassy_hip_get_option reads one, sassy_hip_option_table returns "name<TAB>default<TAB>what it
+ * does" lines for all of them.  All settings give the same matches: the switches exist so that every path can be
+ * checked against the oracle (tests/test_gpu_parity.py) and timed apart (tools/). */
+int sassy_hip_set_option(sassy_SearcherType *s, const char *name, long value);
+int sassy_hip_get_option(const sassy_SearcherType *s, const char *name, long *value);
+const char *sassy_hip_option_table(void);
 /* Which scan path a searcher takes: -1 = the library's choice (exact prefilter where the pattern's pieces are
  * selective, the streaming DP otherwise; process-wide override: SASSY_HIP_PREFILTER), 0 = always the streaming
  * DP over every block, 1 = prefilter also with short pieces.  All give the same matches; the setting exists so
@@ -279,8 +289,10 @@ int sassy_hip_multi_search_many(sassy_hip_Multi *m, const uint8_t *const *patter
  * (sassy_hip_search_shard_begin on every device's host thread) and returns; finish() waits for that search on every
  * device and merges the shard results -- the tail of search i (chunk DP, tracebacks, the host's merge) runs under the
  * text stream of search i + 1 on every device.  Up to `depth` searches per multi-searcher (1 .. 4, default 3); tickets
- * may be finished in any order; the synchronous sassy_hip_multi_search is refused while a ticket is open.  Same
- * result as sassy_hip_multi_search, both strands included (sassy_hip_multi_set_rc). */
+ * may be finished in any order.  While a ticket is open every entry point that rewrites, re-lays-out or reallocates the
+ * resident shards or uses the devices' searchers is refused with SASSY_HIP_EINVAL: sassy_hip_multi_set_text,
+ * _generate_dna, _plant, _set_rc, _set_replicated, _search, _search_encoded and _search_many (the searches in flight
+ * read those buffers).  Same result as sassy_hip_multi_search, both strands included (sassy_hip_multi_set_rc). */
 typedef struct sassy_hip_MultiTicket sassy_hip_MultiTicket;
 int sassy_hip_multi_set_pipe_depth(sassy_hip_Multi *m, int depth);
 int sassy_hip_multi_search_begin(sassy_hip_Multi *m, const uint8_t *pattern, size_t pattern_len, size_t k,

@@ -105,6 +105,15 @@ class Stats(C.Structure):
         return {f: getattr(self, f) for f, _ in self._fields_ if f != "pad_"}
 
 
+def option_table():
+    """[(name, default, what it does)] of every switch of the library (csrc/switches.h)."""
+    rows = []
+    for line in lib().sassy_hip_option_table().decode().splitlines():
+        name, dflt, doc = line.split("\t", 2)
+        rows.append((name, dflt, doc))
+    return rows
+
+
 # every symbol include/sassy.h and include/sassy_hip.h declare
 EXPORTED_SYMBOLS = [
     "sassy_searcher", "sassy_searcher_free", "search", "sassy_matches_free",
@@ -116,6 +125,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_result_cigars_len", "sassy_hip_pack_rows", "sassy_hip_enable_counters", "sassy_hip_set_timing",
     "sassy_hip_set_only_best_match", "sassy_hip_set_max_n_frac", "sassy_hip_search_with_fn",
     "sassy_hip_set_max_overhang", "sassy_hip_set_prefilter", "sassy_hip_set_fused",
+    "sassy_hip_set_option", "sassy_hip_get_option", "sassy_hip_option_table",
     "sassy_hip_set_device", "sassy_hip_get_device", "sassy_hip_merge_shards",
     "sassy_hip_multi_new", "sassy_hip_multi_shards", "sassy_hip_multi_device", "sassy_hip_multi_searcher",
     "sassy_hip_multi_set_text", "sassy_hip_multi_generate_dna", "sassy_hip_multi_plant", "sassy_hip_multi_search",
@@ -172,6 +182,12 @@ def lib():
     L.sassy_hip_set_prefilter.argtypes = [vp, C.c_int]
     L.sassy_hip_set_fused.restype = C.c_int
     L.sassy_hip_set_fused.argtypes = [vp, C.c_int]
+    L.sassy_hip_set_option.restype = C.c_int
+    L.sassy_hip_set_option.argtypes = [vp, C.c_char_p, C.c_long]
+    L.sassy_hip_get_option.restype = C.c_int
+    L.sassy_hip_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_long)]
+    L.sassy_hip_option_table.restype = C.c_char_p
+    L.sassy_hip_option_table.argtypes = []
     L.sassy_hip_set_device.restype = C.c_int
     L.sassy_hip_set_device.argtypes = [vp, C.c_int]
     L.sassy_hip_get_device.restype = C.c_int
@@ -407,19 +423,17 @@ class Result:
         return self._n
 
     @property
-    def matches(self) -> Sequence["Match"]:
-        """The records as reference-style Match objects: a list for small results, a lazy read-only sequence over the
-        numpy array beyond LAZY_MATCHES records (a Python object per match costs 1.4 us -- 0.46 s for the 330 000 matches
-        of a read set whose search takes 0.02 s)."""
+    def matches(self) -> List["Match"]:
+        """The records as reference-style Match objects -- always a real list, whatever the size of the result (a Python
+        object per match costs 1.4 us: for results of 10^5 records and more use `.lazy_matches` or the numpy `.array`)."""
         if self._matches is None:
-            if self._n > LAZY_MATCHES:
-                self._matches = MatchList(self.array, self.pool)
-            else:
-                self._matches = matches_from_array(self.array, self.pool)
+            self._matches = matches_from_array(self.array, self.pool)
         return self._matches
 
-
-LAZY_MATCHES = 4096
+    @property
+    def lazy_matches(self) -> "MatchList":
+        """A read-only sequence over the numpy array and the cigar pool: Match objects are made when they are looked at."""
+        return MatchList(self.array, self.pool)
 
 
 def _bytes_payload_offset():
@@ -587,9 +601,10 @@ class Searcher:
                                               ALL_MINIMA if all_minima else 0, cb, None, C.byref(out)))
         return Result(out).matches
 
-    def search_many(self, patterns: Sequence[bytes], texts: Sequence, k: int, all_minima: bool = False) -> List[Match]:
+    def search_many(self, patterns: Sequence[bytes], texts: Sequence, k: int, all_minima: bool = False, as_result: bool = False):
         """Searcher::search_many in SearchMode::Single order (src/search.rs:531-560): every pattern in
-        every text, pattern-major; matches carry pattern_idx and text_idx."""
+        every text, pattern-major; matches carry pattern_idx and text_idx.  as_result: the Result itself (numpy `.array`,
+        `.lazy_matches`) instead of a list of Match objects."""
         patterns = [bytes(p) for p in patterns]
         pp = (C.c_char_p * len(patterns))(*patterns)
         pl = (C.c_size_t * len(patterns))(*[len(p) for p in patterns])
@@ -621,7 +636,8 @@ class Searcher:
         flags = (ALL_MINIMA if all_minima else 0) | (TEXT_ON_DEVICE if on_device else 0)
         out = C.c_void_p()
         _check(lib().sassy_hip_search_many(self._h, pp, pl, len(patterns), tp, tl, n_texts, k, flags, C.byref(out)))
-        return Result(out).matches
+        r = Result(out)
+        return r if as_result else r.matches
 
     def search_patterns(self, patterns: Sequence[bytes], text, k: int) -> List[Match]:
         """Searcher::search_patterns (src/search.rs:648-678): equal-length patterns in one text."""
@@ -755,6 +771,16 @@ class Searcher:
         """The bit-plane prefilter finishes the scan in its own launch (default) / always the classic kernel chain."""
         _check(lib().sassy_hip_set_fused(self._h, int(bool(on))))
         return self
+
+    def set_option(self, name: str, value: int):
+        """One entry of the searcher's switch table (csrc/switches.h): name in lower case without the SASSY_HIP_ prefix."""
+        _check(lib().sassy_hip_set_option(self._h, name.encode(), int(value)))
+        return self
+
+    def get_option(self, name: str) -> int:
+        v = C.c_long(0)
+        _check(lib().sassy_hip_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def enable_counters(self, on: bool = True):
         _check(lib().sassy_hip_enable_counters(self._h, int(on)))

@@ -33,9 +33,12 @@ UNITS = [
     ("tiled_kernel.hip", "tiled_kernel.o", []),
     ("seed_kernels.hip", "seed_kernels.o", []),
     ("trace_kernel.hip", "trace_kernel.o", []),
-    ("host.hip", "host.o", []),
+    ("scan_driver.hip", "scan_driver.o", []),
+    ("many_patterns.hip", "many_patterns.o", []),
+    ("multi_device.hip", "multi_device.o", []),
+    ("c_abi.hip", "c_abi.o", []),
 ]
-HEADERS = ["common.h", "profiles.h", "tiled_step.h", os.path.join("..", "..", "include", "sassy.h"),
+HEADERS = ["common.h", "profiles.h", "tiled_step.h", "switches.h", "host_internal.h", os.path.join("..", "..", "include", "sassy.h"),
            os.path.join("..", "..", "include", "sassy_hip.h")]
 
 

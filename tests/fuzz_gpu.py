@@ -307,15 +307,7 @@ def many_case(rng, searchers):
         texts.append(bytes(t))
     s = searchers[(profile, rc)]
     force = rng.choice([None, "0", "1"])
-    if force is None:
-        os.environ.pop("SASSY_HIP_MANY_TILED", None)
-    else:
-        os.environ["SASSY_HIP_MANY_TILED"] = force
     seed = rng.choice([None, "0", "1"])
-    if seed is None:
-        os.environ.pop("SASSY_HIP_MANY_SEEDED", None)
-    else:
-        os.environ["SASSY_HIP_MANY_SEEDED"] = seed
     # overhang (Iupac): every text gets its own overhang column and virtual columns -- several patterns of one length go
     # through one pass per strand (tiled_pertext_kernel), else a launch per pattern
     alpha = None
@@ -326,9 +318,14 @@ def many_case(rng, searchers):
             pats = pats + [rand_seq(rng, m_same, b"ACGT") for _ in range(rng.choice([3, 5, 66]))]
             npat = len(pats)
         s = sassy_amd.Searcher(profile, rc=rc, alpha=alpha).with_max_overhang(mo)
-    got = s.search_many(pats, texts, k, all_minima=allm)
-    os.environ.pop("SASSY_HIP_MANY_TILED", None)
-    os.environ.pop("SASSY_HIP_MANY_SEEDED", None)
+    # (the switches are per searcher, read from the environment when it is made: set_option on the one that searches)
+    s.set_option("many_tiled", -1 if force is None else int(force))
+    s.set_option("many_seeded", -1 if seed is None else int(seed))
+    try:
+        got = s.search_many(pats, texts, k, all_minima=allm)
+    finally:
+        s.set_option("many_tiled", -1)
+        s.set_option("many_seeded", -1)
     gk = [(m.pattern_idx, m.text_idx, m.text_start, m.text_end, m.pattern_start, m.pattern_end, m.cost, m.strand, m.cigar)
           for m in got]
     wk = []
@@ -385,13 +382,13 @@ def encoded_case(rng, searchers):
     t = bytes(t)
     allm = wide and rng.random() < 0.3
     force = rng.choice([None, None, "0", "1", "seed", "seed"])
-    os.environ.pop("SASSY_HIP_TILED", None)
-    os.environ.pop("SASSY_HIP_SEEDED", None)
-    if force == "seed":  # seed -> verify -> report wherever the shape allows it
-        os.environ["SASSY_HIP_SEEDED"] = "1"
-    elif force is not None:
-        os.environ["SASSY_HIP_TILED"] = force
     s = searchers[(profile, rc)]
+    s.set_option("tiled", -1)
+    s.set_option("seeded", -1)
+    if force == "seed":  # seed -> verify -> report wherever the shape allows it
+        s.set_option("seeded", 1)
+    elif force is not None:
+        s.set_option("tiled", int(force))
     enc = s.encode_patterns(pats)
     # (Dna text with other letters: the scan's 2-bit equality and the traceback's letter equality can disagree;
     # the reference panics in get_trace, the oracle raises, and so must the library)
@@ -408,8 +405,8 @@ def encoded_case(rng, searchers):
             with open(os.path.join(ROOT, "gpurun_out", "fuzz_fail.bin"), "wb") as fh:
                 fh.write(b"|".join(pats) + b"\n" + t)
             raise
-    os.environ.pop("SASSY_HIP_TILED", None)
-    os.environ.pop("SASSY_HIP_SEEDED", None)
+    s.set_option("tiled", -1)
+    s.set_option("seeded", -1)
     if want is None or got is None:
         desc = dict(mode="encoded", profile=profile, m=m, k=k, rc=rc, npat=npat, n=n, all_minima=allm, tiled=force,
                     filtered=s.stats()["filtered"], matches=0)
@@ -554,7 +551,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--focus", default="", help="'count': larger texts through the q-gram counting filter, both strands")
+    families = {"one": one_case, "fused": fused_case, "bytes_long": bytes_long_case, "count": count_case, "many": many_case,
+                "encoded": encoded_case, "shard": shard_case, "inflight": inflight_case, "reflanes": reflanes_case}
+    ap.add_argument("--focus", default="", choices=[""] + sorted(families),
+                    help="one case family only (default: the mix); 'count': larger texts through the q-gram counting filter, both strands")
     args = ap.parse_args()
     rng = random.Random(args.seed)
     searchers = {(p, rc): sassy_amd.Searcher(p, rc=rc) for p in ("dna", "iupac", "ascii") for rc in (False, True)
@@ -568,20 +568,8 @@ def main():
         fn = (one_case if mode < 0.4 else fused_case if mode < 0.52 else bytes_long_case if mode < 0.56 else many_case
               if mode < 0.66 else encoded_case if mode < 0.76 else shard_case if mode < 0.85 else inflight_case
               if mode < 0.93 else reflanes_case)
-        if args.focus == "count":
-            fn = count_case
-        if args.focus == "inflight":
-            fn = inflight_case
-        if args.focus == "reflanes":
-            fn = reflanes_case
-        if args.focus == "encoded":
-            fn = encoded_case
-        if args.focus == "many":
-            fn = many_case
-        if args.focus == "fused":
-            fn = fused_case
-        if args.focus == "bytes_long":
-            fn = bytes_long_case
+        if args.focus:
+            fn = families[args.focus]
         ok, desc, pat, text, got, want = fn(rng, searchers)
         cases += 1
         kinds[desc["filtered"]] = kinds.get(desc["filtered"], 0) + 1

@@ -289,3 +289,39 @@ def test_rust_shim_declares_only_exported_symbols(sassy):
     for n in names:
         assert hasattr(L, n), n
         assert re.search(r"\b" + n + r"\s*\(", hdr), n
+
+
+def test_switch_table_is_the_only_reader_of_the_environment(sassy):
+    """csrc/switches.h: one table of switches, read once when a searcher is made (defaults, then SASSY_HIP_<NAME>), changed
+    per searcher by sassy_hip_set_option -- no getenv on any search entry point.  Every switch is forced by some GPU test
+    (its environment name or a set_option call appears in tests/), and DESIGN.md lists it."""
+    rows = sassy.option_table()
+    names = [r[0] for r in rows]
+    assert len(names) == len(set(names)) >= 40 and "fused" in names and "devices" in names
+    # one reader of the environment in the whole library
+    n_getenv = 0
+    for f in os.listdir(os.path.join(ROOT, "sassy_amd", "csrc")):
+        if f.endswith((".hip", ".h")):
+            n_getenv += open(os.path.join(ROOT, "sassy_amd", "csrc", f)).read().count("getenv(")
+    assert n_getenv <= 2, n_getenv   # (load_switches: one call; one mention in a comment)
+    # the environment is read when the searcher is made; set_option / get_option work per searcher (no device needed)
+    code = ("import os, sassy_amd\n"
+            "os.environ['SASSY_HIP_FILTER_KIND'] = '4'\n"
+            "a = sassy_amd.Searcher('dna', rc=False)\n"
+            "os.environ['SASSY_HIP_FILTER_KIND'] = '3'\n"
+            "b = sassy_amd.Searcher('dna', rc=False)\n"
+            "assert (a.get_option('filter_kind'), b.get_option('filter_kind')) == (4, 3)\n"
+            "a.set_option('filter_kind', 1); a.set_fused(False)\n"
+            "assert (a.get_option('filter_kind'), a.get_option('fused'), b.get_option('fused')) == (1, 0, 1)\n"
+            "try:\n    a.set_option('no_such_switch', 1)\nexcept sassy_amd.SassyHipError as e:\n    assert 'no such option' in str(e)\nelse:\n    raise SystemExit(2)\n"
+            "print('ok')\n")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("SASSY_HIP_")}
+    p = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stdout + p.stderr
+    # every switch has a forced test and a line in DESIGN.md
+    tests_src = "".join(open(os.path.join(ROOT, "tests", f)).read() for f in os.listdir(os.path.join(ROOT, "tests")) if f.endswith(".py"))
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    for n in names:
+        forced = ("SASSY_HIP_" + n.upper()) in tests_src or f'set_option("{n}"' in tests_src
+        assert forced, f"switch {n} is forced by no test"
+        assert f"`{n}`" in design, f"switch {n} is missing from DESIGN.md's table"

@@ -1968,11 +1968,11 @@ def test_search_many_pattern_tiled(sassy):
                     if not allm:
                         # the records were put in result order on the device (host.hip: assemble_many): the same
                         # records in the same order as the host's way (per-strand copies, append, stable sort)
-                        os.environ["SASSY_HIP_MANY_ASSEMBLE"] = "0"
+                        s.set_option("many_assemble", 0)
                         try:
                             host = s.search_many(pats, texts, k, all_minima=allm)
                         finally:
-                            os.environ.pop("SASSY_HIP_MANY_ASSEMBLE", None)
+                            s.set_option("many_assemble", 1)
                         row = lambda x: (x.pattern_idx, x.text_idx, x.text_start, x.text_end, x.pattern_start,
                                          x.pattern_end, x.cost, x.strand, x.cigar)
                         assert [row(x) for x in got] == [row(x) for x in host], (mode, profile, m, k, rc)
@@ -2781,6 +2781,10 @@ _FORCED = [
     {"SASSY_HIP_FUSED_PRESS": "8", "SASSY_HIP_EXT_EVENTS": "0"},  # a pass of the fused launch's waves every 8 queued windows
     {"SASSY_HIP_PAIR": "0"},                         # no paired filter: 5- / 6-row shapes through the paths of round 4
     {"SASSY_HIP_STRANDS_IN_FLIGHT": "0"},            # two strands that are two searches: one after the other
+    # (round 6: the switches of csrc/switches.h that had no forced run)
+    {"SASSY_HIP_PAIR_RC": "0", "SASSY_HIP_COMPACT_CIGARS": "0", "SASSY_HIP_ADOPT": "0", "SASSY_HIP_TRACE_THREADS": "256"},
+    {"SASSY_HIP_FUSED_PROBE": "1", "SASSY_HIP_TRACE_PROBE": "1", "SASSY_HIP_TIMING": "2", "SASSY_HIP_TUNE": "1", "SASSY_HIP_PIPE_DEPTH": "3"},
+    {"SASSY_HIP_COUNT_FUSED": "0", "SASSY_HIP_HOST_POLL": "0"},  # the counting filter's classic chain; the host waits on the stream only
 ]
 
 
@@ -2804,7 +2808,8 @@ def test_forced_kernel_paths(sassy, env):
     print(env, r.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("env", [{"SASSY_HIP_SEED_NARROW": "0"}, {"SASSY_HIP_SEED_POS64": "1"}, {"SASSY_HIP_SEED_SUBTEST": "0"}],
+@pytest.mark.parametrize("env", [{"SASSY_HIP_SEED_NARROW": "0"}, {"SASSY_HIP_SEED_POS64": "1"}, {"SASSY_HIP_SEED_SUBTEST": "0"},
+                                 {"SASSY_HIP_SEED_LAYOUT": "0"}],
                          ids=lambda e: ",".join(f"{k[10:]}={v}" for k, v in e.items()))
 def test_seeded_search_forced_test_layouts(sassy, env):
     """The seeded search's sub-piece test picks its layout by shape and text (seed_kernels.hip: test_issue -- narrow,
@@ -3021,6 +3026,16 @@ def _multi_in_flight_case(sassy, devices, profile, rc, n, rng):
     ms.set_text(text2, 64, 6)
     tk = ms.search_begin(pats[0], 3)
     assert_same(ms.search_finish(tk).matches, oracle.search(profile, pats[0], text2, 3, rc=rc), "changed text")
+    # a ticket is open: nothing may rewrite, re-lay-out or reallocate the resident shards (or their reversed copies) the
+    # search in flight reads, and no synchronous search may use the parts' searchers (round 5's advice: only
+    # multi_search itself was refused)
+    tk = ms.search_begin(pats[0], 3)
+    for call in (lambda: ms.set_text(text, 64, 6), lambda: ms.generate_dna(n, 7, 64, 6), lambda: ms.plant(1, pats[0], 3),
+                 lambda: ms.set_rc(rc), lambda: ms.set_replicated(False), lambda: ms.search(pats[0], 3),
+                 lambda: ms.search_encoded([pats[0][:20]], 2), lambda: ms.search_many([pats[0]], [text[:1000]], 3)):
+        with pytest.raises(sassy.SassyHipError, match="in flight"):
+            call()
+    assert_same(ms.search_finish(tk).matches, oracle.search(profile, pats[0], text2, 3, rc=rc), "after the refused calls")
     # tiny texts: fewer blocks than parts
     for n_t in (0, 1, 31, 63, 64, 65, 130, 64 * G + 1, 64 * G * (G + 2) - 1, 64 * G * (G + 2)):
         tt = (pats[0] * 40)[:n_t] if n_t % 3 else rand_seq(rng, n_t)
