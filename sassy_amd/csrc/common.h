@@ -192,6 +192,9 @@ struct ScanParams {
   // launch when there are at most list_words_max chunks (0: never), list_kernel otherwise
   uint32_t list_words_max;
   uint32_t list_group_log;
+  uint32_t list_rows;         // 1: list_rows_kernel (a lane per BLOCK of a chunk, groups of list_group lanes) takes those
+                              // launches instead of list_words_kernel
+  uint32_t list_group;        // 4 .. 64 lanes per chunk (list_rows_kernel)
   uint8_t slot_val[kMaxSlots]; // per slot: Dna 2-bit code, Iupac base-set nibble, Ascii byte
   // ---- overhang (kScanOverhang; reference: src/search.rs:347-356, 1274-1282, 1695-1748) ----
   const uint32_t* ov_tab;     // device, nwords words: left-edge vertical deltas at the text start

@@ -319,10 +319,9 @@ static int tiled_scan_list(sassy_SearcherType* s, const sassy_hip_Encoded* e, co
   P.warm_blocks = (m + k + 63) / 64;
   P.keep_bits = d_keep_bits;
   // (the zones' list -- the one caller with keep bits -- is read by map_zone_list_kernel, which skips empty records)
-  // Every wave that lists anything takes a whole range, and the counter counts slots: 1 024-slot ranges pay where the
-  // list is dense (a guide set over a genome's N-run borders: 10^8 records), a small zone text would only fill the list
-  // with holes -- 64-slot ranges there, and the first attempt holds a range per wave either way.
-  P.cand_chunk = (d_keep_bits && !pt) ? ((uint64_t)len * ((npat + 63) / 64) >= (1ull << 24) ? 1024u : 64u) : 0u;
+  // Every wave that lists anything takes a whole range of 1 024 slots (a range holds at least one emit call's 512
+  // records: tiled_kernel.hip, EmitCursor), and the counter counts slots: the first attempt reserves a range per wave.
+  P.cand_chunk = (d_keep_bits && !pt) ? 1024u : 0u;
   {
     const uint64_t span = (uint64_t)P.skew + len;
     const uint64_t waves_wanted = 16384;

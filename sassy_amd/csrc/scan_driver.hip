@@ -832,14 +832,28 @@ int ScanJob::enqueue(int attempt) {
     P.desc_cap = desc_cap;
     // multi-word patterns with few chunks: one lane per pattern word instead of one lane per chunk
     // (up to 8192 waves' worth of chunks; beyond that the lane-per-chunk kernel fills the chip anyway)
+    // Round 6: one lane per BLOCK of a chunk (list_rows_kernel: m + blocks - 1 dependent rows per chunk instead of
+    // (blocks + words - 1) x 32; switch list_words = 2: the word-pipelined kernel, 0: the lane-per-chunk kernel only).
     P.list_words_max = 0;
     P.list_group_log = 0;
+    P.list_rows = 0;
     const int env_words = (int)S->sw.list_words;
     if (env_words && !ext_desc && plan.nwords >= 2 && plan.nwords <= 64 && !(P.flags & kScanOverhang)) {
-      uint32_t glog = 1;
-      while ((1u << glog) < plan.nwords) ++glog;
-      P.list_group_log = glog;
-      P.list_words_max = (8192u * 64u) >> glog;
+      // groups of G lanes: a chunk's warm-up blocks and six blocks of end positions in one pass (longer chunks take more)
+      // (list_words >= 4: that many lanes per chunk -- timing experiments)
+      const uint32_t G = env_words >= 4 ? std::min<uint32_t>(64u, (uint32_t)env_words) : std::min<uint32_t>(64u, std::max<uint32_t>(4u, P.wb + 6u));
+      const size_t m16 = ((size_t)plan.m + 15u) & ~(size_t)15;
+      const size_t rows_lds = 128 + m16 + 16 + (size_t)kWavesPerGroup * ((size_t)bucket * 512u + (64u / G) * m16);
+      if (env_words != 2 && !plan.bytes && !S->want_counters && rows_lds <= 150 * 1024) {
+        P.list_rows = 1;
+        P.list_group = G;
+        P.list_words_max = 8192u * (64u / G);
+      } else {
+        uint32_t glog = 1;
+        while ((1u << glog) < plan.nwords) ++glog;
+        P.list_group_log = glog;
+        P.list_words_max = (8192u * 64u) >> glog;
+      }
     }
     // the descriptor count lives on the device: launch for the capacity, idle waves exit at once
     const uint32_t lgrid = (desc_cap + 64u * P.waves_per_group - 1) / (64u * P.waves_per_group);

@@ -260,6 +260,102 @@ __device__ __noinline__ rep4 scan_block(const EmitCtx P, uint64_t vp, uint64_t v
   return make_rep4((uint32_t)rep, (uint32_t)(rep >> 32), (dec ? kStDec : 0u) | (amb ? kStAmb : 0u) | (n_cond << 8) | rep_base, 0u);
 }
 
+// The same decisions, by the WHOLE WAVE for one block: lane c looks at column c + 1.  scan_block is a chain of 64
+// dependent, branchy steps -- ~20 us for one call, whatever the number of lanes that are in it -- and on sparse results
+// (a few live blocks per wave: every search of the benchmarks) those calls were most of the chunk DP's time: 40 of the 75 us
+// of config 3's list kernel, most of the 30 us a wave of the fused launch spends behind its stream.  Here the 64 costs come
+// from two masked popcounts per lane, the comparisons leave as ballots, and the two sequential pieces of the rule become
+// bit arithmetic on those 64-bit masks: `dec` after column c = "the last rise or fall at or before c was a fall" (a fill of
+// the falls through the columns without either, in six doubling steps; dec_in in front of the first), `amb` is cleared by
+// the first exact event, and the reports made up to that column are the conditional ones.  All arguments wave-uniform.
+__device__ __forceinline__ rep4 scan_block_cols(const EmitCtx& P, uint32_t flags, uint64_t text_len, uint64_t text_begin, uint64_t vp,
+                                                uint64_t vm, int ds, uint64_t b, bool owned, bool last_warm, int64_t x0, uint32_t state) {
+  const uint32_t lane = __lane_id();
+  const int k = (int)P.k;
+  const bool all = (flags & kScanAllMinima) != 0;
+  const bool dec_in = (state & kStDec) != 0, amb_in = (state & kStAmb) != 0;
+  const int64_t r0 = x0 + (int64_t)((state >> 8) & 0xFFFFu);
+  const uint64_t base = b * 64 + (flags >> kEmitShiftBit);
+  const uint64_t max_pos = text_len + P.ov_steps;
+  if (base >= max_pos) return make_rep4(0u, 0u, state & 0xFFu, 0u);
+  const uint32_t nbits = max_pos - base < 64 ? (uint32_t)(max_pos - base) : 64u;  // columns that exist (>= 1)
+  const bool ov = P.ov_steps != 0;
+  auto total_of = [&](int c, uint64_t pos) -> int {
+    return (ov && pos > text_len) ? c + __float2int_rd(P.alpha * (float)(pos - text_len)) : c;
+  };
+  const int cost0 = total_of(ds, base);
+  const uint64_t low = lane == 63u ? ~0ull : ((2ull << lane) - 1ull);
+  const uint64_t pos = base + lane + 1u;
+  const int cost = total_of(ds + (int)__popcll(vp & low) - (int)__popcll(vm & low), pos);
+  const bool valid = lane < nbits;
+  const int prevc = __builtin_amdgcn_update_dpp(cost0, cost, 0x138, 0xF, 0xF, false);  // wave_shr:1 (lane 0: the block's left edge)
+  const uint64_t LEK = __ballot(valid && cost <= k);
+  uint64_t rep = 0;
+  uint32_t rep_base = 0, ncond = 0;
+  bool dec = dec_in, amb = amb_in;
+  if (all) {
+    if (owned && cost0 <= k && base == text_begin && P.global_offset == 0 && (flags & kScanTextStart)) rep_base = kRepBase;
+    rep = __ballot(valid && owned && (int64_t)pos > r0 && cost <= k);
+  } else {
+    const uint64_t VAL = nbits == 64u ? ~0ull : ((1ull << nbits) - 1ull);
+    const uint64_t R = __ballot(valid && cost > prevc), F = __ballot(valid && cost < prevc);
+    const uint64_t ZERO = __ballot(valid && cost == 0);
+    const uint64_t EX = __ballot(valid && (int64_t)pos > x0);
+    const uint64_t OWNP = __ballot(valid && owned && (int64_t)(pos - 1u) > r0);  // (the report is for the column in front)
+    const uint64_t E = R | F;
+    uint64_t D = F, Pr = ~E;  // D: dec behind column c -- a fall at j <= c and neither rise nor fall in (j, c]
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) {
+      D |= Pr & (D << sft);
+      Pr &= Pr << sft;
+    }
+    if (dec_in) D |= E ? ((E & (0ull - E)) - 1ull) : ~0ull;  // ... or dec_in and neither in [0, c]
+    const uint64_t LEKp = (LEK << 1) | (cost0 <= k ? 1ull : 0ull);
+    const uint64_t Dp = (D << 1) | (dec_in ? 1ull : 0ull);
+    const uint64_t REP = R & Dp & LEKp & OWNP;  // bit c: a report for end position base + c
+    const uint64_t GTK = ~LEK & VAL, GTKp = ((~LEK << 1) | (cost0 > k ? 1ull : 0ull)) & VAL;
+    const uint64_t EVX = (E | GTK | GTKp | ZERO) & EX;  // exact columns that settle the plateau state
+    bool determined = x0 < 0;
+    if (owned) {
+      // (the column of the first exact event still reports with the old `amb`: the reports up to it are the conditional ones)
+      if (amb_in) ncond = (uint32_t)__popcll(REP & (EVX ? (((EVX & (0ull - EVX)) << 1) - 1ull) : ~0ull));
+      if (EVX) amb = false;
+    } else if (EVX) {
+      determined = true;
+    }
+    dec = ((D >> (nbits - 1u)) & 1ull) != 0;
+    if (last_warm) amb = !determined;
+    rep_base = (REP & 1ull) ? kRepBase : 0u;
+    rep = REP >> 1;
+    if (owned && (flags & kScanTextEnd) && base + nbits == max_pos && dec && ((LEK >> (nbits - 1u)) & 1ull) &&
+        (int64_t)(base + nbits) > r0) {  // the end of the text ends a plateau (src/search.rs:1352-1366)
+      rep |= 1ull << (nbits - 1u);
+      if (amb) ncond = (uint32_t)__popcll(rep) + (rep_base ? 1u : 0u);
+    }
+  }
+  return make_rep4((uint32_t)rep, (uint32_t)(rep >> 32), (dec ? kStDec : 0u) | (amb ? kStAmb : 0u) | (ncond << 8) | rep_base, 0u);
+}
+// scan_block for every lane with `live` set, one block after the other, each by the whole wave.  Called in wave-uniform
+// control flow by all lanes; a lane without a live block gets {0, 0, its state, 0}.
+__device__ __noinline__ rep4 scan_blocks(const EmitCtx P, bool live, uint64_t vp, uint64_t vm, int ds, uint64_t b, bool owned,
+                                          bool last_warm, int64_t x0, uint32_t state) {
+  rep4 out = make_rep4(0u, 0u, state & 0xFFu, 0u);
+  unsigned long long todo = __ballot(live);
+  const uint32_t lane = __lane_id();
+  auto bc32 = [](uint32_t v, int L) -> uint32_t { return (uint32_t)__builtin_amdgcn_readlane((int)v, L); };
+  auto bc64 = [&](uint64_t v, int L) -> uint64_t { return pair64(bc32(lo32(v), L), bc32(hi32(v), L)); };
+  while (todo) {
+    const int L = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    const uint32_t fl = bc32(P.flags, L);
+    const uint32_t bits = bc32((owned ? 1u : 0u) | (last_warm ? 2u : 0u), L);
+    const rep4 r = scan_block_cols(P, fl, bc64(P.text_len, L), bc64(P.text_begin, L), bc64(vp, L), bc64(vm, L), (int)bc32((uint32_t)ds, L),
+                                   bc64(b, L), (bits & 1u) != 0, (bits & 2u) != 0, (int64_t)bc64((uint64_t)x0, L), bc32(state, L));
+    if (lane == (uint32_t)L) out = r;
+  }
+  return out;
+}
+
 // Appends the reports scan_block() decided on, for all lanes of the wave at once: called in wave-uniform control
 // flow (every lane of the wave, lanes without a report pass r = 0), one atomic on the report counter per call
 // (and one on the TextStash counter with kScanStash: a slot per reporting block).  vp / vm / ds / b: the block's last
@@ -852,11 +948,11 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
     const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
     bool live = active && ran_through && row_maybe_live(ds, V, k);
     if (__any(live)) live = row_live_exact(V.vpl, V.vph, V.vml, V.vmh, ds, k) && live;
+    if (__any(live)) rr = scan_blocks(ctx, live, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);  // (the wave, block by block)
     if (active) {
       if (P.counters) cnt_blocks += 1;
       if (live) {
         if (P.counters) cnt_live += 1;
-        rr = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
         st = rr.z & (kStDec | kStAmb);
       } else {
         st = kStDec;  // dec = true: a later <=k run can only be entered by a decrease; amb = false
@@ -1640,11 +1736,11 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
       const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
       bool live = active && ran_through && row_maybe_live(ds, V, k);
       if (__any(live)) live = row_live_exact(V.vpl, V.vph, V.vml, V.vmh, ds, k) && live;
+      if (__any(live)) rr = scan_blocks(ctx, live, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st | (rskip << 8));
       if (active) {
         if (P.counters) cnt_blocks += 1;
         if (live) {
           if (P.counters) cnt_live += 1;
-          rr = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st | (rskip << 8));
           st = rr.z & (kStDec | kStAmb);
         } else if (!WIN || (int64_t)((b + 1) * 64 + shift) > x0) {
           st = kStDec;  // no cell <= k in the block (a window's block that ends inside its warm-up says nothing)
@@ -2531,24 +2627,232 @@ __global__ __launch_bounds__(256) void list_words_kernel(const ScanParams P) {
     dp_word<false, false, PROFILE == (int)PROFILE_ASCII_BYTES>(V, my_masks, ohp, ohm, pkw, rows, nhp, nhm);
     rep4 rr = make_rep4(0u, 0u, 0u, 0u);
     const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
+    const bool live = active && last_word && row_maybe_live(ds, V, k);
+    if (__any(live)) rr = scan_blocks(ctx, live, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
     if (active) {
       ohp = nhp;
       ohm = nhm;
       Vout = V;
       ds_out = ds;
-      if (last_word) {
-        if (row_maybe_live(ds, V, k)) {
-          rr = scan_block(ctx, vp, vm, ds, b, b >= own_lo, b + 1 == own_lo, x0, st);
-          st = rr.z & (kStDec | kStAmb);
-        } else {
-          st = kStDec;
-        }
-      }
+      if (last_word) st = live ? (rr.z & (kStDec | kStAmb)) : kStDec;
     }
     if (__any((rr.x | rr.y | (rr.z & kRepBase)) != 0u)) (void)emit_reports(ctx, rr, vp, vm, ds, b);
   }
   if (has_chunk && last_word) {
     const uint32_t fin = (st & kStAmb) ? kStatePass : ((st & kStDec) ? kStateDecTrue : kStateDecFalse);
+    P.chunk_state[di] = (uint8_t)fin;
+    if (own_hi == P.n_blocks) {
+      uint32_t* tail = P.cand_count + kCtlTailWord;
+      tail[0] = (uint32_t)own_lo; tail[1] = fin; tail[2] = d.flags; tail[3] = 1u;
+    }
+  }
+}
+
+// ====================================================================== K1-list, one lane per BLOCK
+// list_words_kernel pipelines a chunk over its pattern words: (blocks + words - 1) steps of 32 dependent rows each -- for
+// config 3 (m = 200, k = 20: ten blocks x seven words) a chain of ~500 rows x 30 instructions on one wave per SIMD, 89 us
+// for a few thousand chunks that are 5 us of arithmetic.  The dependencies of the text-tiled recurrence allow a finer
+// wavefront: cell (block b, row r) needs (b, r - 1) -- the lane's own registers -- and the two carry bits of (b - 1, r).
+// Here lane i of a group of G lanes owns BLOCK i of a chunk and computes row t - i in step t: the carry bits of its row
+// arrive from lane i - 1 by DPP (computed one step earlier), the horizontal deltas V stay in the lane, the Eq word of
+// (its block, its row) comes from the block's slot masks, which the lane built once.  A chunk of n blocks takes
+// m + n - 1 row steps (209 instead of ~500), every lane is busy m of them, and the 64 / G chunks of a wave fill it.
+// Chunks longer than G blocks run in passes of G blocks; the carries between two passes -- a byte per row -- wait in
+// LDS (read at step r by the pass's first lane, written at step r + G - 1 by its last: in place).
+// The lane that finishes a block (row m - 1) decides about its reports exactly as list_kernel does (scan_block with the
+// plateau state handed on from the block to its left, one step earlier), the wave appends them with one atomic.
+// Row slots per row: bytes in LDS (row_tab is a byte array indexed by the row), padded on both sides so that the
+// prefetches of lanes that have not started / are done read slot 0.
+constexpr uint32_t kRowsPad = 64;
+template <int PROFILE, int NS>
+__global__ __launch_bounds__(256) void list_rows_kernel(const ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = threadIdx.x >> 6;
+  uint32_t n_desc = *P.desc_count;
+  if (n_desc > P.desc_cap) n_desc = P.desc_cap;
+  if (n_desc > P.list_words_max) return;  // many chunks: list_kernel (one lane each) runs them
+  // groups of G lanes (any G from 4 to 64: the carries travel by wave_shr:1, which knows no rows), 64 / G chunks per wave
+  const uint32_t G = P.list_group;
+  const uint32_t per_wave = 64u / G;
+  if (blockIdx.x * kWavesPerGroup * per_wave >= n_desc) return;  // (the whole workgroup)
+  const uint32_t m = P.m;
+  const uint32_t slots_bytes = (kRowsPad + m + kRowsPad + 15u) & ~15u;
+  unsigned char* rowslot = smem + kRowsPad;  // rowslot[r] = 2 * slot of row r, r in [-kRowsPad, m + kRowsPad)
+  {
+    const uint8_t* rt = reinterpret_cast<const uint8_t*>(P.row_tab);
+    for (uint32_t x = threadIdx.x; x < slots_bytes; x += blockDim.x) {
+      const int r = (int)x - (int)kRowsPad;
+      smem[x] = (r >= 0 && r < (int)m) ? rt[r] : (unsigned char)0;
+    }
+  }
+  __syncthreads();
+  const uint32_t carry_bytes = (m + 15u) & ~15u;
+  unsigned char* wbase = smem + slots_bytes + (size_t)wave * (NS * 512u + per_wave * carry_bytes);
+  unsigned char* mask_bytes = wbase;  // [NS][64] u64
+  const uint32_t gi = lane / G, li = lane - gi * G;
+  const bool in_group = gi < per_wave;  // (64 mod G lanes at the wave's end have no group)
+  unsigned char* carry = wbase + NS * 512u + (in_group ? gi : 0u) * carry_bytes;  // the group's carries between two passes
+  const uint32_t wave_first = (blockIdx.x * kWavesPerGroup + wave) * per_wave;
+  if (wave_first >= n_desc) return;  // wave-uniform (no workgroup barrier below)
+  const uint32_t di = wave_first + gi;
+  const bool chunk_here = in_group && di < n_desc;
+  ChunkDesc d;
+  d.own_lo = d.own_hi = d.flags = d.pad_ = 0;
+  if (chunk_here) d = P.desc[di];
+  const uint64_t own_lo = d.own_lo, own_hi = d.own_hi;
+  const bool clear_before = (d.flags & kDescClearBefore) != 0;
+  uint64_t blk0 = own_lo;
+  if (!clear_before) blk0 = own_lo > P.wb ? own_lo - P.wb : 0;
+  const bool at_text_start = blk0 == 0 && (P.flags & kScanTextStart);
+  const bool exact_start = clear_before || at_text_start;
+  const int64_t x0 = exact_start ? -1 : (int64_t)(blk0 * 64 + P.m + P.k);
+  const uint32_t nb = chunk_here ? (uint32_t)(own_hi - blk0) : 0u;
+  const int k = (int)P.k;
+  EmitCtx ctx;
+  ctx.cand = P.cand;
+  ctx.cand_count = P.cand_count;
+  ctx.text_len = P.text_len;
+  ctx.global_offset = P.global_offset;
+  ctx.cand_cap = P.cand_cap;
+  ctx.k = P.k;
+  ctx.flags = P.flags;
+  ctx.alpha = 0.0f;
+  ctx.ov_steps = 0u;
+  ctx.text_begin = 0;
+  ctx.tag = 0;
+  const unsigned char* my_masks = mask_bytes + lane * 8;
+  const uint32_t first_lane = li == 0u ? 1u : 0u;
+  const uint32_t keep_dpp = li == 0u ? 0u : 0xFFFFFFFFu;  // a group's first lane takes nothing from the lane on its left
+  uint32_t st_pass = kStDec;   // plateau state in front of the pass's first block (a chunk starts with dec = true)
+  int ds_pass = (int)m;        // cost on the pass's left edge in the last row (a fresh start: D[m][start] = m)
+  uint32_t st_last = kStDec;   // ... behind the chunk's last block (the lane that owns it)
+  for (uint32_t pass = 0; __any(pass * G < nb); ++pass) {
+    const uint32_t bi = pass * G + li;  // the lane's block inside its chunk
+    const bool has_blk = bi < nb;
+    const uint64_t b = blk0 + bi;
+    {
+      uint32_t x[16];
+#if defined(ROWS_EXP) && ROWS_EXP == 3
+      for (int q = 0; q < 16; ++q) x[q] = 0x41414141u + (uint32_t)b;
+#else
+      fetch_block(P, has_blk, b, x);
+#endif
+      uint2 msk[NS];
+      build_masks<PROFILE, NS>(x, P, msk);
+#pragma unroll
+      for (int q = 0; q < NS; ++q) *reinterpret_cast<uint2*>(mask_bytes + q * 512 + lane * 8) = msk[q];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // blocks of this pass in the wave's longest group (wave-uniform): m + that - 1 steps
+    uint32_t span = has_blk ? li + 1u : 0u;
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) span = max(span, (uint32_t)__shfl_xor((int)span, dd, 64));
+    span = (uint32_t)__builtin_amdgcn_readfirstlane((int)span);
+    const uint32_t nsteps = m + span - 1u;
+    const bool more = (pass + 1u) * G < nb;  // the chunk goes on behind this pass: its last lane leaves the carries
+    const bool any_more = __any(more);
+    const bool later_pass = pass != 0u;      // wave-uniform
+    DpWord V;
+    V.vpl = V.vph = V.vml = V.vmh = 0;
+    uint32_t cout = 0;           // carry bits of the row the lane computed last: bit 0 = +1, bit 1 = -1
+    uint32_t stv = st_pass;      // plateau state behind the lane's block (valid once the block is done)
+    int dsr = ds_pass;           // last-row cost on the lane's RIGHT edge (valid once the block is done)
+    int ds_blk = 0;              // ... on its left edge
+    bool live = false;           // the block's last row may hold a cell <= k
+    uint2 zz = make_uint2(0u, 0u);
+    asm volatile("" : "+v"(zz.x), "+v"(zz.y));
+    // Eq word of (my block, row r), two steps ahead: the row's slot byte, then the mask
+    const unsigned char* rp = rowslot - (int)li;  // rp[0] = slot byte of row t - li
+    uint32_t slot_n = rp[1];                       // row 1 - li (for step 1)
+    uint2 eq_n = *reinterpret_cast<const uint2*>(my_masks + ((uint32_t)rp[0] << 8));  // row -li (step 0)
+    // one row step.  CHECK: the lane may be outside its rows (ramp-up / tail); TAIL: blocks are being finished
+    auto step = [&](uint32_t t, auto check_tag, auto tail_tag) {
+      constexpr bool CHECK = decltype(check_tag)::value, TAIL = decltype(tail_tag)::value;
+      // the carry bits the lane on the left produced one step ago (a group's first lane: a fresh start -- every
+      // left-edge delta is +1 -- or, in a later pass, what the previous pass's last lane left for this row)
+      uint32_t cin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cout, 0x138, 0xF, 0xF, false);  // wave_shr:1
+      cin = (cin & keep_dpp) | (later_pass ? 0u : first_lane);
+      const int r = (int)t - (int)li;
+      bool active = has_blk;
+      if constexpr (CHECK) active = has_blk && (uint32_t)r < m;
+      if (later_pass) {  // wave-uniform
+        if (li == 0u && active) cin = carry[r];
+      }
+      const uint2 eq = eq_n;
+      eq_n = *reinterpret_cast<const uint2*>(my_masks + (slot_n << 8));
+      slot_n = rp[2];
+      ++rp;
+      if (active) {
+        uint32_t nhp = 0, nhm = 0;
+        dp_row(V, eq, cin & 1u, cin >> 1, nhp, nhm, zz);
+        cout = nhp | (nhm << 1);
+        if (any_more) {  // wave-uniform
+          if (more && li == G - 1u) carry[r] = (unsigned char)cout;
+        }
+      }
+      if constexpr (TAIL) {
+        // a block is done: its last row's cost on the left edge comes from the block on its left (done one step ago)
+        const int ds_left = __builtin_amdgcn_update_dpp(0, dsr, 0x138, 0xF, 0xF, false);
+        if (has_blk && r == (int)m - 1) {
+          ds_blk = li == 0u ? ds_pass : ds_left;
+          dsr = ds_blk + (int)__popc(V.vpl) + (int)__popc(V.vph) - (int)__popc(V.vml) - (int)__popc(V.vmh);
+          live = row_maybe_live(ds_blk, V, k);
+#if defined(ROWS_EXP) && ROWS_EXP == 2
+          live = false;
+#endif
+        }
+      }
+    };
+    uint32_t t = 0;
+    // ramp-up until every lane with a block is inside its rows (t = span - 1) or the first block is done (t = m - 1)
+    const uint32_t t_steady = min(span > 0u ? span - 1u : 0u, m - 1u), t_tail = m - 1u;
+    for (; t < t_steady; ++t) step(t, std::true_type{}, std::false_type{});   // ramp-up
+    if (has_blk) {                                                             // every lane with a block is inside its rows
+#if !defined(ROWS_EXP) || ROWS_EXP != 1
+      for (uint32_t t2 = t; t2 < t_tail; ++t2) step(t2, std::false_type{}, std::false_type{});
+#endif
+    } else {
+      rp += t_tail - t;
+    }
+    for (t = t_tail; t < nsteps; ++t) step(t, std::true_type{}, std::true_type{});  // blocks are finished, one per step
+    // ---- the pass's reports.  Every lane still holds its block's last row (V, ds_blk).  The report rule of a block
+    // needs the plateau state behind the block on its left; that block is usually not live (state: dec = true, settled), so
+    // all live lanes decide at once on that assumption, and a lane whose left neighbour turned out otherwise decides again
+    // (a plateau that runs across a block border: a second round, rarely more) -- two calls of scan_block per pass
+    // instead of one per live block and step, and ONE atomic for the pass's reports.
+    rep4 rr = make_rep4(0u, 0u, 0u, 0u);
+    const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
+    uint32_t st_used = 0xFFFFFFFFu;  // the state the lane's decision stands on (none yet)
+    stv = kStDec;
+    for (;;) {
+      const uint32_t st_dpp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)stv, 0x138, 0xF, 0xF, false);
+      const uint32_t st_in = li == 0u ? st_pass : st_dpp;
+      const bool again = live && st_in != st_used;
+      if (!__any(again)) break;
+      const rep4 r2 = scan_blocks(ctx, again, vp, vm, ds_blk, b, b >= own_lo, b + 1 == own_lo, x0, st_in);
+      if (again) {
+        rr = r2;
+        stv = rr.z & (kStDec | kStAmb);
+        st_used = st_in;
+      }
+    }
+    if (has_blk && bi + 1u == nb) st_last = stv;
+#if !defined(ROWS_EXP) || ROWS_EXP != 5
+    if (__any((rr.x | rr.y | (rr.z & kRepBase)) != 0u)) (void)emit_reports(ctx, rr, vp, vm, ds_blk, b);
+#else
+    if (rr.x == 0x12345u) P.chunk_state[0] = 1;
+#endif
+    // the next pass's first lane continues behind this pass's last one
+    const int last_lane = (int)((in_group ? gi : 0u) * G + G - 1u);
+    st_pass = (uint32_t)__shfl((int)stv, last_lane, 64);
+    ds_pass = __shfl(dsr, last_lane, 64);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (chunk_here && nb != 0u && (nb - 1u) % G == li) {  // the lane that owned the chunk's last block
+    const uint32_t fin = (st_last & kStAmb) ? kStatePass : ((st_last & kStDec) ? kStateDecTrue : kStateDecFalse);
     P.chunk_state[di] = (uint8_t)fin;
     if (own_hi == P.n_blocks) {
       uint32_t* tail = P.cand_count + kCtlTailWord;
@@ -2609,13 +2913,23 @@ static hipError_t launch_list_one(const ScanParams& P, uint32_t grid, size_t sme
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&list_words_kernel<PROFILE, NS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&list_rows_kernel<PROFILE, NS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     attr_set.done();
   }
-  if (P.list_words_max) {  // few chunks of a multi-word pattern are taken by the word-pipelined kernel
-    const uint32_t per_group = 256u >> P.list_group_log;
+  if (P.list_words_max) {  // few chunks of a multi-word pattern: a lane per block (list_rows) or per pattern word (list_words)
+    const uint32_t per_group = P.list_rows ? 4u * (64u / P.list_group) : 256u >> P.list_group_log;
     const uint32_t wgrid = (std::min(P.list_words_max, P.desc_cap) + per_group - 1) / per_group;
-    hipLaunchKernelGGL((list_words_kernel<PROFILE, NS>), dim3(wgrid), dim3(256), (size_t)kWavesPerGroup * NS * 512u,
-                       stream, P);
+    if (P.list_rows) {
+      const uint32_t per_wave = 64u / P.list_group;
+      const size_t lds = ((size_t)(2 * kRowsPad + P.m + 15u) & ~(size_t)15) +
+                         (size_t)kWavesPerGroup * (NS * 512u + per_wave * (size_t)((P.m + 15u) & ~15u));
+      hipLaunchKernelGGL((list_rows_kernel<PROFILE, NS>), dim3(wgrid), dim3(256), lds, stream, P);
+    } else {
+      hipLaunchKernelGGL((list_words_kernel<PROFILE, NS>), dim3(wgrid), dim3(256), (size_t)kWavesPerGroup * NS * 512u,
+                         stream, P);
+    }
   }
   hipLaunchKernelGGL((list_kernel<PROFILE, NS>), dim3(grid), dim3(64u * (P.waves_per_group ? P.waves_per_group : 4u)), smem, stream, P);
   return hipGetLastError();

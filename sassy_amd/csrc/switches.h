@@ -35,7 +35,7 @@ namespace sassy_hip {
   X(fused_probe, 0, "1: the fused launch reports where its waves spend their time; 2: no chunk DP at all (timing only, no reports)") \
   X(fused_press, 0, "> 0: a wave of the fused launch runs a chunk-DP pass once this many windows are queued")              \
   X(ext_events, 1, "0: timing events around the fused launch instead of carried by the dispatch")                           \
-  X(list_words, 1, "0: multi-word chunk DP by the lane-per-chunk kernel only")                                              \
+  X(list_words, 1, "multi-word chunk DP of few chunks: 1 a lane per block (list_rows_kernel), 2 a lane per pattern word, 0 the lane-per-chunk kernel only")                                              \
   X(trace_threads, 0, ">= 64: threads of the thread-per-report traceback launch")                                           \
   X(trace_probe, 0, "1: the traceback waves report microseconds per phase to stderr")                                       \
   X(big_pin, 1, "0: dense results through the host's vectors instead of one pinned block")                                  \
