@@ -372,6 +372,50 @@ __global__ __launch_bounds__(1024) void build_chunks_kernel(const BuildParams P)
   }
 }
 
+// ------------------------------------------------------------------ the counting filter's own chunk list
+// filter_count_kernel<.., DIRECT> leaves its chunk descriptors in one region of kRegionSlots slots per wave and the
+// number of each region's entries in region_count (count_filter.hip).  This packs them into the dense list the list
+// kernels read: a workgroup per 1024 regions -- the entries in front of its regions it counts itself (a few thousand
+// numbers), a scan inside the workgroup gives every region its place.  A region that holds more runs than slots has
+// lost some: the fuse word tells the host, which runs that search with the bitmap and the chunk builder instead.
+__global__ __launch_bounds__(1024) void compact_chunks_kernel(const ChunkDesc* __restrict__ regions, const uint32_t* __restrict__ region_count,
+                                                              uint32_t n_regions, ChunkDesc* __restrict__ desc, uint32_t* desc_count,
+                                                              uint32_t desc_cap, uint32_t* fuse_word) {
+  __shared__ uint32_t part[16];
+  __shared__ uint32_t wave_tot[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  const uint32_t r0 = blockIdx.x * 1024u;
+  // entries of the regions in front of this workgroup's
+  uint32_t before = 0;
+  bool over = false;
+  for (uint32_t r = tid; r < r0; r += 1024u) {
+    const uint32_t c = region_count[r];
+    before += c < kRegionSlots ? c : kRegionSlots;
+  }
+  const uint32_t r = r0 + tid;
+  uint32_t c = r < n_regions ? region_count[r] : 0u;
+  if (c > kRegionSlots) { over = true; c = kRegionSlots; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) before += __shfl_xor(before, d);
+  uint32_t inc = c;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t t = __shfl_up(inc, d);
+    if (lane >= (uint32_t)d) inc += t;
+  }
+  if (lane == 63) { part[wv] = before; wave_tot[wv] = inc; }
+  __syncthreads();
+  uint32_t off = 0;
+  for (uint32_t v = 0; v < 16; ++v) off += part[v] + (v < wv ? wave_tot[v] : 0u);
+  off += inc - c;
+  const ChunkDesc* src = regions + (size_t)r * kRegionSlots;
+  for (uint32_t i = 0; i < c; ++i)
+    if (off + i < desc_cap) desc[off + i] = src[i];
+  if (over) atomicOr(fuse_word, kFuseOverflow);
+  // the last region's thread knows the total (the count keeps counting past the capacity, as the builder's does)
+  if (r + 1 == n_regions) *desc_count = off + c;
+}
+
 // ------------------------------------------------------------------ report ranking
 // The scan kernels append reports with an atomic counter, i.e. in arbitrary order; the result
 // order is by end position (reference: matches of one strand come out by increasing end,
@@ -600,6 +644,14 @@ hipError_t launch_reverse(const uint8_t* d_in, uint8_t* d_out, uint64_t n, hipSt
   uint64_t blocks = ((n + 15) / 16 + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(reverse_kernel, dim3((uint32_t)blocks), dim3(256), 0, stream, d_in, d_out, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_compact_chunks(const ChunkDesc* d_regions, const uint32_t* d_region_count, uint32_t n_regions, ChunkDesc* d_desc,
+                                 uint32_t* d_desc_count, uint32_t desc_cap, uint32_t* d_fuse_word, hipStream_t stream) {
+  if (n_regions == 0) return hipSuccess;
+  hipLaunchKernelGGL(compact_chunks_kernel, dim3((n_regions + 1023u) / 1024u), dim3(1024), 0, stream, d_regions, d_region_count, n_regions,
+                     d_desc, d_desc_count, desc_cap, d_fuse_word);
   return hipGetLastError();
 }
 

@@ -15,6 +15,7 @@ constexpr int kWave = 64;              // gfx950 wavefront
 constexpr int kWavesPerGroup = 4;      // 256-thread workgroups, every wave works alone
 constexpr int kTileBytes = 64 * 128;   // text tile of one wave: 64 lane chunks x 2 blocks x 64 B,
                                        // 16-byte slots XOR-swizzled by (owner>>1)&7
+constexpr uint32_t kRegionSlots = 16;  // chunk descriptors a wave of the counting filter can file (count_direct)
 constexpr int kMaxSlots = 64;          // profile slots (distinct pattern letters) per search: Dna 4, Iupac <= 16,
                                        // Ascii <= 64 distinct pattern bytes
 
@@ -172,6 +173,12 @@ struct ScanParams {
   uint32_t count_r;           // positions per table lookup (1, 2 or 4)
   uint32_t count_window;      // W = ceil((m + k - Q) / 64) + 1 blocks
   uint32_t count_thresh;      // t = m + 1 - (k+1) Q
+  uint32_t count_direct;      // 1: the filter files chunk descriptors itself -- wave w of the launch into desc[w * kRegionSlots ..],
+                              // its count into region_count[w]; chunks begin at dp_first_owned or later, long runs leave in
+                              // pieces of count_maxlen blocks: no bitmap, no chunk builder (compact_chunks_kernel packs the
+                              // regions) -- one strand only (count_rc == 0), whole lines per staging step
+  uint32_t count_maxlen;
+  const uint32_t* region_count;
   unsigned long long* hit_bitmap;  // one bit per text block: an exact piece occurrence ends in it
   // ---- both strands from one pass over the forward text (reference: the Rc strand is complement(pattern)
   // against the REVERSED text, src/search.rs:813-878) ----

@@ -48,9 +48,19 @@ __device__ __noinline__ uint4 tail16(const uint8_t* text, uint64_t off, uint64_t
   return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// DIRECT: the lanes file the runs of candidate blocks they find as chunk descriptors themselves (no hit bitmap with its
+// 6 MB memset per 3 GB, no chunk builder over it: 27 + 5 us of a lone config-3 search).  Without a single atomic: a
+// returning atomic on the list's counter from inside the stream cost the kernel 55 us (3 000 of them: the wave waits for
+// the atomic behind its own prefetch in the memory pipeline).  Every WAVE owns kRegionSlots slots of the list (region =
+// its index in the launch): the lanes that file in one step rank themselves by ballot, the stores need no reply, and the
+// wave leaves its count in region_count when it is done (every wave does: nothing to clear).  compact_chunks_kernel
+// (aux_kernels.hip) then packs the regions into the dense list the list kernels read; a wave with more runs than slots
+// leaves its true count and the packer raises the fuse word: the host runs the classic chain for that search.
+// A chunk = [lo, hi), a run of candidate blocks, never with kDescClearBefore: the list kernel warms up on the wb blocks in
+// front of it (the chunk builder makes them part of the chunk instead -- the same blocks, the same start).
 // WPG: waves per workgroup.  The q-gram table is per workgroup: sixteen waves around one copy leave room for sixteen
 // waves per CU (four around each of three copies: twelve).
-template <int Q, int R, int SB, int WPG>
+template <int Q, int R, int SB, int WPG, bool DIRECT = false>
 __global__ __launch_bounds__(64 * WPG) void filter_count_kernel(const ScanParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr uint32_t kTableBytes = 1u << (2 * (Q + R - 1));
@@ -111,6 +121,14 @@ __global__ __launch_bounds__(64 * WPG) void filter_count_kernel(const ScanParams
   uint32_t sum = 0;      // hits in the last W blocks
   uint32_t pos = 0;      // ring slot of the oldest block (wave-uniform)
   uint32_t forced = 0;   // blocks (this one included) whose window still holds a block with such a byte
+  // DIRECT: the run of candidate blocks the lane is collecting -- run_lo = its first block (kNoRun: none); run_st bit 0 /
+  // bit 1 = the window sum of the last block / the block in front of it reached the threshold
+  constexpr uint32_t kNoRun = 0xFFFFFFFFu;
+  uint32_t run_lo = kNoRun, run_st = 0;
+  // (DIRECT) the wave's slots in the descriptor list (scalars: the wave index comes from the thread index, which the compiler
+  // does not know to be wave-uniform)
+  const uint32_t region = blockIdx.x * WPG + (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+  uint32_t region_n = 0;                                       // ... and how many it has used (wave-uniform)
   uint4 nxt[kStageInstr];
 #pragma unroll
   for (int i = 0; i < kStageInstr; ++i) {
@@ -118,7 +136,53 @@ __global__ __launch_bounds__(64 * WPG) void filter_count_kernel(const ScanParams
     if (interior) nxt[i] = stream_load16<SASSY_NT_COUNT>(text_base + soff[i]);
   }
 
+  // DIRECT: the run logic for block bp, whose window sum is bit 0 of run_st (bit 1: the block in front of it).  Run at the
+  // top of the NEXT iteration, where the block's sixteen text words are no longer in registers (behind the look-ups the
+  // descriptor store pushed the sixteen-wave kernel over its 128 registers: a scratch segment), and only when some lane
+  // has anything to decide -- nearly every block of nearly every wave: one vote, and on with the stream.
+  // (block indices as 32-bit words here: the host asks for this variant below 2^31 blocks; a lane without blocks files
+  // nothing: an empty range)
+  const uint32_t blk0_32 = (uint32_t)blk0;
+  const uint32_t f_hi = has_chunk ? (uint32_t)min(own_hi + 1, P.n_blocks) : 0u;
+  const uint32_t f_lo = has_chunk ? (uint32_t)own_lo + (chunk == 0 ? 0u : 1u) : 1u;
+  auto direct_step = [&](uint32_t bp) {  // bp: the block's iteration
+    if (__any(run_st != 0u || run_lo != kNoRun)) {
+      // Block bp is a candidate by its own window sum or by that of the block in front (the report rule looks one column
+      // ahead).  A lane files the blocks (own_lo, own_hi] -- its last block's successor, the next lane's first block,
+      // included (it looks at that block's window too: one iteration more), its own first block left to the lane in front,
+      // whose window sums decide about it.  (The launch's first lane also files its first block: nothing lies in front.)
+      const uint32_t b32 = blk0_32 + bp;
+      const bool own = b32 >= f_lo && b32 < f_hi;
+      const bool cand = own && (run_st & 3u) != 0u && b32 >= (uint32_t)P.dp_first_owned;
+      if (cand && run_lo == kNoRun) run_lo = b32;
+      uint32_t file_hi = 0;
+      if (own && run_lo != kNoRun) {
+        // the run ends in front of this block, or with the lane's last block, or is cut (a long run leaves in pieces)
+        if (!cand) file_hi = b32;
+        else if (b32 + 1u == f_hi || b32 + 1u - run_lo >= P.count_maxlen) file_hi = b32 + 1u;
+      }
+      // (wave-uniform here: the lanes that file rank themselves by ballot -- no counter in memory)
+      const unsigned long long filing = __ballot(file_hi != 0u);
+      if (file_hi != 0u) {
+        const uint32_t idx = region_n + (uint32_t)__popcll(filing & ((1ull << lane) - 1ull));
+        if (idx < kRegionSlots) {
+          ChunkDesc d;
+          d.own_lo = run_lo;
+          d.own_hi = file_hi;
+          d.flags = 0u;
+          d.pad_ = 0;
+          const_cast<ChunkDesc*>(P.desc)[(size_t)region * kRegionSlots + idx] = d;
+        }
+        run_lo = kNoRun;
+      }
+      region_n += (uint32_t)__popcll(filing);
+      run_st = (run_st << 1) & 2u;
+    }
+  };
   for (uint32_t it = 0; it < P.n_iter; ++it) {
+    if constexpr (DIRECT) {
+      if (it) direct_step(it - 1u);
+    }
     const uint32_t sub = SB == 2 ? (it & 1u) : 0u;
     if (sub == 0) {
       if (interior) {
@@ -132,7 +196,11 @@ __global__ __launch_bounds__(64 * WPG) void filter_count_kernel(const ScanParams
       } else {
 #pragma unroll
         for (int i = 0; i < kStageInstr; ++i) {
-          const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + soff[i];
+          // (the wave at the buffer's end: the offset through an opaque copy -- hoisted out of the loop these eight 64-bit
+          // addresses cost the sixteen-wave kernel more registers than it has)
+          uint32_t so = soff[i];
+          asm volatile("" : "+v"(so));
+          const uint64_t off = wave_blk0 * 64 + (uint64_t)it * 64 + so;
           uint4 v;
           if (off + 16 <= P.text_len) v = *reinterpret_cast<const uint4*>(P.text + off);
           else v = tail16(P.text, off, P.text_len);
@@ -182,7 +250,9 @@ __global__ __launch_bounds__(64 * WPG) void filter_count_kernel(const ScanParams
     const bool evaluate = has_chunk && b >= own_lo && b < own_hi;
     const bool reach = sum >= thresh || forced != 0;
     if (forced != 0) --forced;
-    if (evaluate && reach) {
+    if constexpr (DIRECT) {
+      run_st |= reach ? 1u : 0u;  // (filed at the top of the next iteration: direct_step)
+    } else if (evaluate && reach) {
       atomicOr(&P.hit_bitmap[b >> 6], 1ull << (b & 63));
       if (b + 1 < P.n_blocks) atomicOr(&P.hit_bitmap[(b + 1) >> 6], 1ull << ((b + 1) & 63));
       if (P.count_rc) {
@@ -204,23 +274,29 @@ __global__ __launch_bounds__(64 * WPG) void filter_count_kernel(const ScanParams
       }
     }
   }
+  if constexpr (DIRECT) {
+    direct_step(P.n_iter - 1u);
+    if (lane == 0) const_cast<uint32_t*>(P.region_count)[region] = region_n;
+  }
 }
 
-template <int Q, int R, int SB, int WPG>
+template <int Q, int R, int SB, int WPG, bool DIRECT = false>
 hipError_t launch_qr(const ScanParams& P, uint32_t grid, hipStream_t stream) {
   const size_t smem = ((size_t)1 << (2 * (Q + R - 1))) + (size_t)WPG * P.lds_per_wave;
   static DeviceOnce attr_set;  // LDS beyond the 64 KiB default needs an explicit opt-in
   if (attr_set.need()) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_count_kernel<Q, R, SB, WPG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&filter_count_kernel<Q, R, SB, WPG, DIRECT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     attr_set.done();
   }
-  hipLaunchKernelGGL((filter_count_kernel<Q, R, SB, WPG>), dim3(grid), dim3(64 * WPG), smem, stream, P);
+  hipLaunchKernelGGL((filter_count_kernel<Q, R, SB, WPG, DIRECT>), dim3(grid), dim3(64 * WPG), smem, stream, P);
   return hipGetLastError();
 }
 template <int Q, int R>
 hipError_t launch_sb(const ScanParams& P, uint32_t grid, hipStream_t stream) {
+  if (P.count_direct)  // (whole lines, sixteen or four waves per workgroup; one strand)
+    return P.waves_per_group == 16 ? launch_qr<Q, R, 2, 16, true>(P, grid, stream) : launch_qr<Q, R, 2, 4, true>(P, grid, stream);
   if (P.waves_per_group == 16) return P.stage_blocks == 2 ? launch_qr<Q, R, 2, 16>(P, grid, stream) : launch_qr<Q, R, 1, 16>(P, grid, stream);
   return P.stage_blocks == 2 ? launch_qr<Q, R, 2, 4>(P, grid, stream) : launch_qr<Q, R, 1, 4>(P, grid, stream);
 }

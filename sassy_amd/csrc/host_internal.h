@@ -53,6 +53,8 @@ hipError_t launch_build_chunks(const unsigned long long* d_hit, uint64_t n_words
                                uint64_t first_owned, uint32_t wb, uint32_t L, uint32_t maxlen,
                                ChunkDesc* d_desc, uint32_t* d_desc_count, uint32_t desc_cap,
                                unsigned long long* d_hit_count, hipStream_t stream);
+hipError_t launch_compact_chunks(const ChunkDesc* d_regions, const uint32_t* d_region_count, uint32_t n_regions, ChunkDesc* d_desc,
+                                 uint32_t* d_desc_count, uint32_t desc_cap, uint32_t* d_fuse_word, hipStream_t stream);
 hipError_t launch_generate_dna(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first, hipStream_t stream);
 hipError_t launch_generate_genome_like(uint8_t* d_text, uint64_t n, uint64_t seed, uint64_t first, int with_n,
                                        hipStream_t stream);
@@ -273,7 +275,8 @@ struct ScanLane {
   DevBuf<uint32_t> d_flags;     // dense results: "does any record need the host's attention" (report_flags_kernel)
   DevBuf<Candidate> d_cand, d_sorted;
   DevBuf<MatchOut> d_trace;
-  DevBuf<ChunkDesc> d_desc;
+  DevBuf<ChunkDesc> d_desc, d_regions;   // (d_regions / d_region_count: the counting filter's own chunk list, one region per wave)
+  DevBuf<uint32_t> d_region_count;
   // pattern-dependent device data of the scan that runs on this lane, and what it currently holds
   // (uploads are skipped when the pattern repeats); per lane, so that scans of different patterns
   // can be in flight on different lanes
@@ -415,7 +418,7 @@ struct ScanLane {
     h_up = nullptr; h_up_cap = h_up_used = 0;
     d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release(); d_sort.release(); d_scratch2.release(); d_flags.release();
     for (unsigned char*& b : h_bulk) { if (b) (void)hipHostFree(b); b = nullptr; }
-    d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release();
+    d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release(); d_regions.release(); d_region_count.release();
     d_pattern.release(); d_table.release(); d_rowoff.release(); d_ovtab.release(); d_stash.release();
     if (h_pin) g_pin_pool.give(PinBlock{h_pin, h_pin_dev, h_pin_cap, h_pin_device});
     h_pin = nullptr;
@@ -752,6 +755,8 @@ struct ScanJob {
   FilterKind fkind = kFilterGeneric;
   uint32_t count_r = 0, count_w = 0, count_t = 0, count_wpg = 4;  // counting filter: R, window blocks, threshold, waves per workgroup
   uint32_t pair = 0;                                   // paired filter: super-pieces (0: not taken)
+  bool rows_declined = false;                          // the few-chunks list kernel found more chunks than it takes: the lane-per-chunk kernel runs them
+  bool count_direct = false;                           // counting filter: it files the chunk descriptors itself (no bitmap, no chunk-list launch)
   double count_tail = 0;                           // ... and the expected fraction of candidate blocks
   unsigned long long* d_bitmap = nullptr;
   uint32_t* d_counts = nullptr;

@@ -459,8 +459,12 @@ int ScanJob::prepare() {
   //             [0] word rows, [1] blocks, [2] hit blocks
   //   [64, ..)  rank counters of the first kRankLimit reports
   //   [kCtlHead, ..)  the prefilter's hit bitmap (one bit per text block)
-  n_words = filtered ? (n_blocks + 63) / 64 : 0;
-  if (int rc = L.d_ctl.reserve(kCtlHead + (filtered && !ext_bitmap && !ext_desc ? (n_words + 2) * 8 : 0))) return rc;
+  // The counting filter of ONE strand files its chunk descriptors itself (count_filter.hip, DIRECT): no hit bitmap (and no
+  // 6 MB memset per 3 GB), no chunk-list launch.  Switch count_fused = 0: bitmap + build_chunks_kernel as before.
+  count_direct = filtered && fkind == kFilterCount && !rc_marked && !ext_bitmap && !ext_desc && sw.count_fused != 0 &&
+                 sw.count_stage_blocks != 1 && n_blocks < 0xFFFFFFFFull && !no_fuse && L.fuse_backoff == 0;
+  n_words = filtered && !count_direct ? (n_blocks + 63) / 64 : 0;
+  if (int rc = L.d_ctl.reserve(kCtlHead + (filtered && !ext_bitmap && !ext_desc && !count_direct ? (n_words + 2) * 8 : 0))) return rc;
   d_bitmap = ext_bitmap ? ext_bitmap : reinterpret_cast<unsigned long long*>(L.d_ctl.p + kCtlHead);
   if (L.d_cand.cap == 0)
     if (int rc = L.d_cand.reserve(1u << 16)) return rc;
@@ -769,7 +773,7 @@ int ScanJob::enqueue(int attempt) {
   }
   // control block, rank counters and (first attempt: the filter runs once) the hit bitmap
   // (fused: no bitmap -- and the rank counters behind the control block are not used either)
-  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, fused ? 64 : kCtlHead + (filtered && !ext_bitmap && !ext_desc && attempt == 0 ? (n_words + 2) * 8 : 0), L.stream));
+  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, fused ? 64 : kCtlHead + (filtered && !ext_bitmap && !ext_desc && !count_direct && attempt == 0 ? (n_words + 2) * 8 : 0), L.stream));
   if (ext_wait && attempt == 0) HIP_TRY(hipStreamWaitEvent(L.stream, ext_wait, 0));
   // pipelined sub-shards: this lane's filter starts when the previous sub-shard's filter is done,
   // so that the previous lane's DP / rank / traceback kernels overlap this bandwidth-bound one
@@ -798,7 +802,21 @@ int ScanJob::enqueue(int attempt) {
       le = launch_filter_any(S->profile, F, fgrid, 1024 + (size_t)kWavesPerGroup * F.lds_per_wave, L.stream);
       g_launch_events = LaunchEvents{};
       if (le != hipSuccess) return hip_fail(le, "fused filter kernel launch");
-    } else if (attempt == 0 && !ext_bitmap && !ext_desc) {  // the hit bitmap does not depend on buffer sizes: build it once
+    } else if ((attempt == 0 || count_direct) && !ext_bitmap && !ext_desc) {  // the hit bitmap does not depend on buffer sizes: build it once
+      // (count_direct: the filter files the descriptors itself -- into a list that may have grown: every attempt runs it)
+      if (count_direct) {
+        F.count_direct = 1;
+        uint32_t ml = 16;
+        while (ml < 8u * P.wb && ml < 128u) ml <<= 1;
+        F.count_maxlen = ml;
+        F.dp_first_owned = first_owned;
+        const uint32_t n_regions = (uint32_t)((F.n_chunks + 63) / 64);  // a region of the list per wave of the launch
+        if (int rc = L.d_regions.reserve((size_t)n_regions * kRegionSlots)) return rc;
+        if (int rc = L.d_region_count.reserve(n_regions)) return rc;
+        F.desc = L.d_regions.p;
+        F.region_count = L.d_region_count.p;
+        F.hit_count = nullptr;
+      }
       if (rc_marked) HIP_TRY(hipMemsetAsync(rc_bitmap, 0, (n_words + 2) * 8, L.stream));
       if (rc_second_pass) {
         le = launch_filter_any(S->profile, F2, fgrid, 1024 + (size_t)kWavesPerGroup * F2.lds_per_wave, L.stream);
@@ -822,7 +840,12 @@ int ScanJob::enqueue(int attempt) {
       if (int rc = L.upload(d_counts + 1, &ext_ndesc, sizeof(uint32_t))) return rc;
     // right dilation: blocks a match END can reach from a piece occurrence; the bit-plane filter
     // marks those blocks itself (it knows the piece), the other filters mark the occurrence's block
-    if (!ext_desc) {
+    if (count_direct) {  // the regions the filter's waves filled -> the dense list (and its count) the list kernels read
+      le = launch_compact_chunks(L.d_regions.p, L.d_region_count.p, (uint32_t)((F.n_chunks + 63) / 64), L.d_desc.p, d_counts + 1, desc_cap,
+                                 d_counts + kCtlFuseWord, L.stream);
+      if (le != hipSuccess) return hip_fail(le, "chunk list packer launch");
+    }
+    if (!ext_desc && !count_direct) {
       le = launch_build_chunks(d_bitmap, n_words, n_blocks, first_owned, P.wb, fkind == kFilterPlanes || fkind == kFilterCount ? 0u : P.wb, maxlen, L.d_desc.p,
                                d_counts + 1, desc_cap, d_counters + 2, L.stream);
       if (le != hipSuccess) return hip_fail(le, "chunk builder launch");
@@ -838,7 +861,7 @@ int ScanJob::enqueue(int attempt) {
     P.list_group_log = 0;
     P.list_rows = 0;
     const int env_words = (int)S->sw.list_words;
-    if (env_words && !ext_desc && plan.nwords >= 2 && plan.nwords <= 64 && !(P.flags & kScanOverhang)) {
+    if (env_words && !rows_declined && !ext_desc && plan.nwords >= 2 && plan.nwords <= 64 && !(P.flags & kScanOverhang)) {
       // groups of G lanes: a chunk's warm-up blocks and six blocks of end positions in one pass (longer chunks take more)
       // (list_words >= 4: that many lanes per chunk -- timing experiments)
       const uint32_t G = env_words >= 4 ? std::min<uint32_t>(64u, (uint32_t)env_words) : std::min<uint32_t>(64u, std::max<uint32_t>(4u, P.wb + 6u));
@@ -856,7 +879,9 @@ int ScanJob::enqueue(int attempt) {
       }
     }
     // the descriptor count lives on the device: launch for the capacity, idle waves exit at once
-    const uint32_t lgrid = (desc_cap + 64u * P.waves_per_group - 1) / (64u * P.waves_per_group);
+    // (with the few-chunks kernel in front the lane-per-chunk kernel would only start 1 000 workgroups that look at the
+    // count and leave -- 4.7 us of stream time: left out; finish_once() sends a longer list through here again)
+    const uint32_t lgrid = P.list_words_max ? 0u : (desc_cap + 64u * P.waves_per_group - 1) / (64u * P.waves_per_group);
     le = launch_list_any(S->profile, P, lgrid, (size_t)P.waves_per_group * P.lds_per_wave, L.stream);
     if (le != hipSuccess) return hip_fail(le, "list kernel launch");
     }
@@ -992,7 +1017,7 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
       fprintf(stderr, "[sassy-hip] trace waves (us per report): rank %.2f window %.2f fill %.2f walk %.2f out %.2f (%llu reports)\n",
               pr[0] / nrep / 100, pr[1] / nrep / 100, pr[2] / nrep / 100, pr[3] / nrep / 100, pr[4] / nrep / 100, pr[7]);
     }
-    if (fused) {
+    if (fused || count_direct) {
       uint32_t fw = 0;
       memcpy(&fw, L.h_pin + kPinCounts + 4 * kCtlFuseWord, sizeof fw);
       if (fw != 0) {
@@ -1003,6 +1028,10 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
     bool again = false;
     if (filtered && !fused && counts[1] > desc_cap) {  // more chunks than descriptors fit: grow, rebuild
       if (int rc = L.d_desc.reserve((size_t)counts[1] + 1024)) return rc;
+      again = true;
+    }
+    if (filtered && !fused && P.list_words_max && counts[1] > P.list_words_max && counts[1] <= desc_cap) {
+      rows_declined = true;  // more chunks than the few-chunks kernel takes: it left them all to the lane-per-chunk kernel
       again = true;
     }
     if (counts[0] > P.cand_cap) {  // more reports than the buffer holds (dense matches)

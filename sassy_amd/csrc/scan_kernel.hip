@@ -2931,7 +2931,9 @@ static hipError_t launch_list_one(const ScanParams& P, uint32_t grid, size_t sme
                          stream, P);
     }
   }
-  hipLaunchKernelGGL((list_kernel<PROFILE, NS>), dim3(grid), dim3(64u * (P.waves_per_group ? P.waves_per_group : 4u)), smem, stream, P);
+  // (grid = 0: the host leaves the lane-per-chunk kernel out -- the launch above takes every chunk list it expects, and a
+  // list beyond list_words_max sends the search through here once more with list_words_max = 0)
+  if (grid) hipLaunchKernelGGL((list_kernel<PROFILE, NS>), dim3(grid), dim3(64u * (P.waves_per_group ? P.waves_per_group : 4u)), smem, stream, P);
   return hipGetLastError();
 }
 
