@@ -30,6 +30,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+PATTERN_SEEDS = (43, 46, 47, 48)  # the rotation of the searches in flight (one more than the default three in flight)
 METRIC = "GB text/sec (+ matches/sec) |P|=32 k=3 DNA, 1/2/4/8 MI355X vs CPU"
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -209,20 +210,33 @@ def main():
     n_per = args.text_bytes // 64 * 64
     total = n_per * world
     m, k = args.pattern_len, args.k
-    seed_text, seed_pat = 42, 43
-    # the pattern: seeded random ACGT m-mer -- a tiny host-side use of the same
-    # counter-based generator; computed with numpy to keep the oracle out of the product path
-    pat = bytes(_dna_bytes(seed_pat, 0, m))
-    if args.profile == "iupac" and m >= 200:
-        p = bytearray(pat)
-        p[50], p[100], p[150], p[199] = ord("N"), ord("R"), ord("Y"), ord("W")
-        pat = bytes(p)
+    seed_text = 42
+    # The patterns: seeded random ACGT m-mers (a tiny host-side use of the same counter-based generator,
+    # computed with numpy to keep the oracle out of the product path).  The stream of searches ROTATES through
+    # PATTERN_SEEDS -- one pattern more than searches are in flight, so that no lane ever meets the pattern it searched
+    # last (its row table and pattern are uploaded for every search, as for a stream of unrelated queries: the
+    # reference's workers take whatever task comes next, bin/grep.rs:516-537) --, each planted once per
+    # `plant_stride` bytes at its own phase of the stride.  pats[0] (seed 43) is the pattern of the lone-search and
+    # roofline measurements, of the CPU baseline and of the earlier rounds' lines.
+    pats = []
+    for sd in PATTERN_SEEDS:
+        pt = bytes(_dna_bytes(sd, 0, m))
+        if args.profile == "iupac" and m >= 200:
+            p = bytearray(pt)
+            p[50], p[100], p[150], p[199] = ord("N"), ord("R"), ord("Y"), ord("W")
+            pt = bytes(p)
+        pats.append(pt)
+    pat = pats[0]
     halo = 0 if rank == 0 else sassy_amd.required_halo(m, k)
     a = rank * n_per
     buf = torch.empty(halo + n_per + 4096, dtype=torch.uint8, device=device)
     sassy_amd.generate_dna(buf.data_ptr(), halo + n_per, seed_text, a - halo)
-    planted = sassy_amd.plant(buf.data_ptr(), halo + n_per, a - halo, total, seed_text,
-                              bytes({ord("Y"): 67}.get(c, c if c in b"ACGT" else 65) for c in pat), k, args.plant_stride)
+    planted = 0
+    for j, pt in enumerate(pats):
+        cnt = sassy_amd.plant(buf.data_ptr(), halo + n_per, a - halo, total, seed_text + j,
+                              bytes({ord("Y"): 67}.get(c, c if c in b"ACGT" else 65) for c in pt), k, args.plant_stride,
+                              phase=(args.plant_stride // (len(pats) + 1)) * j // 64 * 64)  # (clear of other_configs' plants a quarter stride on)
+        planted = cnt if j == 0 else planted
     torch.cuda.synchronize()
     searcher = sassy_amd.Searcher(args.profile, rc=False)
     searcher.set_pipe_depth(max(1, min(4, args.in_flight)))
@@ -243,6 +257,7 @@ def main():
     # prefilter.  Every step is one complete search with its Match records on the host; all K searches of
     # the timed region are begun AND finished inside it (drain() before the closing barrier).
     pending = []
+    step_no = [0]
 
     def finish_oldest():
         r = searcher.search_finish(pending.pop(0))
@@ -258,15 +273,17 @@ def main():
         # one full search of the resident shard; Match records arrive on the host as one packed
         # array (include/sassy_hip.h: sassy_hip_Match + cigar pool), for N > 1 gathered to rank 0
         try:
+            pt = pats[step_no[0] % len(pats)]
+            step_no[0] += 1
             if args.in_flight <= 1:
-                r = searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
+                r = searcher.search_shard(pt, buf.data_ptr(), halo, n_per, a, total, k)
                 st_ = searcher.stats()
                 if world > 1:
                     gather_worker.submit(r)
                     r = gather_worker.last
                 last[0], last[1] = r, st_
                 return r, st_
-            pending.append(searcher.search_shard_begin(pat, buf.data_ptr(), halo, n_per, a, total, k))
+            pending.append(searcher.search_shard_begin(pt, buf.data_ptr(), halo, n_per, a, total, k))
             if len(pending) >= args.in_flight:
                 last[0], last[1] = finish_oldest()
             return last[0], last[1]
@@ -323,6 +340,7 @@ def main():
     for _ in range(args.warmup + max(0, args.settle)):
         step()
     sync()
+    gather_busy0 = gather_worker.busy_s if gather_worker is not None else 0.0
     t0 = time.perf_counter()
     scan_ms, trace_ms, filter_ms, call_ms, matches, st = 0.0, 0.0, 0.0, 0.0, None, None
     host = [0.0, 0.0, 0.0]
@@ -337,8 +355,14 @@ def main():
         trace_ms += st["trace_ms"]
         filter_ms += st["filter_ms"]
         call_ms += st["total_ms"]
+    # (this rank's own clock: its searches begun and finished, its exchanges done -- before the closing barrier)
+    drain()
+    if gather_worker is not None:
+        gather_worker.flush()
+    own_elapsed = time.perf_counter() - t0
     sync()
     elapsed = time.perf_counter() - t0
+    gather_busy = (gather_worker.busy_s - gather_busy0) if gather_worker is not None else 0.0
     matches, st = last[0], last[1]
     if gather_worker is not None:
         matches = gather_worker.last  # rank 0: the merged rows of the last search; None elsewhere
@@ -347,6 +371,19 @@ def main():
     if dist is not None:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed, scan_avg_ms, filter_avg_ms = float(el[0]), float(el[1]), float(el[2])
+    # per rank: ms per step by the rank's own clock and the exchange worker's busy time per step (N > 1: what a first
+    # SCALE line needs beside BENCH N = 1 -- is a rank slow, or is it the gather?)
+    per_rank = torch.tensor([own_elapsed / args.steps * 1e3, gather_busy / args.steps * 1e3], dtype=torch.float64, device=coll_device)
+    if dist is not None:
+        allr = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(allr, per_rank)
+    else:
+        allr = [per_rank]
+    per_rank_ms = [round(float(x[0]), 4) for x in allr]
+    per_rank_gather_ms = [round(float(x[1]), 4) for x in allr]
+    # every pattern of the rotation once more, alone: its matches on this rank's shard
+    pattern_matches = [len(searcher.search_shard(pt, buf.data_ptr(), halo, n_per, a, total, k)) for pt in pats]
+    matches0 = searcher.search_shard(pat, buf.data_ptr(), halo, n_per, a, total, k)
     filtered = bool(st["filtered"])
     # the dominant kernel: the prefilter scan when the pattern splits into selective pieces
     # (every text byte is read once by it), else the streaming DP kernel.  Its HIP events are the
@@ -401,6 +438,9 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
+        "per_rank_ms_per_step": per_rank_ms,
+        "per_rank_gather_ms_per_step": per_rank_gather_ms,
+        "gather_share_of_step": round(max(per_rank_gather_ms) / ms_per_step, 4) if ms_per_step > 0 else 0.0,
         "single_search_latency_ms": round(latency_ms, 4),
         "single_search_latency_with_kernel_events_ms": round(latency_events_ms, 4),
         "single_search_roofline_frac": round(n_per / (latency_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4),
@@ -413,8 +453,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": (f"BASELINE config {'2' if world == 1 else '5'}: Searcher::<{args.profile.capitalize()}>::new_fwd()"
-                         f".search, |pattern|={m} (seeded random), k={k}, {n_per} B random-ACGT text per GPU "
-                         f"resident in HBM, one planted near-match per {args.plant_stride} B; step = scan + "
+                         f".search, |pattern|={m}, k={k}, {n_per} B random-ACGT text per GPU resident in HBM; the stream "
+                         f"of searches rotates through {len(pats)} DIFFERENT seeded random patterns (seeds {list(PATTERN_SEEDS)}: "
+                         f"never the pattern a lane searched last), each planted once per {args.plant_stride} B; step = scan + "
                          f"traceback + Match records on host, {max(1, args.in_flight)} search(es) in flight" + (" + RCCL gather to rank 0 (one collective per search, overlapped with the next search)" if world > 1 else "")),
             "text_bytes_per_gpu": n_per,
             "total_text_bytes": total,
@@ -429,7 +470,8 @@ def main():
                       f"more untimed steps (--settle) and the K timed steps"),
         },
         "matches": len(matches),
-        "matches_per_s": round(len(matches) * args.steps / elapsed, 1),
+        "matches_per_pattern_rank0": dict(zip([str(sd) for sd in PATTERN_SEEDS], pattern_matches)),
+        "matches_per_s": round(sum(pattern_matches) / len(pattern_matches) * (world if world > 1 else 1) * args.steps / elapsed, 1),
         "planted_rank0": planted,
         "dominant_kernel_ms": round(dom_ms, 4),
         "dominant_kernel_ms_in_flight": round(dom_inflight_ms, 4),
@@ -463,9 +505,9 @@ def main():
                               "frac_single_search": round(n_per / (latency_ms / 1e3) / 1e9 / HBM_PEAK_GBPS, 4)}
     if world == 1 and not args.no_cpu_baseline:
         host = buf[:n_per].cpu().numpy()
-        gpu_ends = [(int(e), int(c)) for e, c in zip(matches.array["text_end"], matches.array["cost"])]
+        gpu_ends = [(int(e), int(c)) for e, c in zip(matches0.array["text_end"], matches0.array["cost"])]
         out["cpu_baseline"] = cpu_baseline(host, pat, k, args.profile, gpu_ends, args.cpu_seconds)
-        out["h2d_inclusive"] = h2d_inclusive(sassy_amd, args.profile, pat, host, k, len(matches))
+        out["h2d_inclusive"] = h2d_inclusive(sassy_amd, args.profile, pat, host, k, len(matches0))
         if not args.no_other_configs:
             out["other_configs"] = other_configs(sassy_amd, buf[:n_per])
             out["other_configs"]["2_dense"] = dense_config(sassy_amd, buf[:n_per], pat, k)

@@ -377,6 +377,10 @@ int sassy_hip_generate_genome_like(uint8_t *d_text, uint64_t n, uint64_t seed, u
 int sassy_hip_plant(uint8_t *d_text, uint64_t n, uint64_t first, uint64_t total_n, uint64_t seed,
                     const uint8_t *pattern, size_t pattern_len, size_t k, uint64_t stride,
                     void *hip_stream, uint64_t *planted);
+/* ... with the plants `phase` bytes further on (q * stride + stride / 2 + phase): several patterns in one text. */
+int sassy_hip_plant_phase(uint8_t *d_text, uint64_t n, uint64_t first, uint64_t total_n, uint64_t seed,
+                          const uint8_t *pattern, size_t pattern_len, size_t k, uint64_t stride, uint64_t phase,
+                          void *hip_stream, uint64_t *planted);
 
 /* Plain device memory helpers so that non-torch callers (C, tests) can use the device paths. */
 void *sassy_hip_malloc(size_t bytes);

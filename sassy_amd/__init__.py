@@ -125,7 +125,7 @@ EXPORTED_SYMBOLS = [
     "sassy_hip_result_cigars_len", "sassy_hip_pack_rows", "sassy_hip_enable_counters", "sassy_hip_set_timing",
     "sassy_hip_set_only_best_match", "sassy_hip_set_max_n_frac", "sassy_hip_search_with_fn",
     "sassy_hip_set_max_overhang", "sassy_hip_set_prefilter", "sassy_hip_set_fused",
-    "sassy_hip_set_option", "sassy_hip_get_option", "sassy_hip_option_table",
+    "sassy_hip_set_option", "sassy_hip_get_option", "sassy_hip_option_table", "sassy_hip_plant_phase",
     "sassy_hip_set_device", "sassy_hip_get_device", "sassy_hip_merge_shards",
     "sassy_hip_multi_new", "sassy_hip_multi_shards", "sassy_hip_multi_device", "sassy_hip_multi_searcher",
     "sassy_hip_multi_set_text", "sassy_hip_multi_generate_dna", "sassy_hip_multi_plant", "sassy_hip_multi_search",
@@ -305,6 +305,9 @@ def lib():
     L.sassy_hip_plant.restype = C.c_int
     L.sassy_hip_plant.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, u8p, sz, sz,
                                   C.c_uint64, vp, C.POINTER(C.c_uint64)]
+    L.sassy_hip_plant_phase.restype = C.c_int
+    L.sassy_hip_plant_phase.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, u8p, sz, sz,
+                                        C.c_uint64, C.c_uint64, vp, C.POINTER(C.c_uint64)]
     L.sassy_hip_malloc.restype = vp
     L.sassy_hip_malloc.argtypes = [sz]
     L.sassy_hip_free.restype = None
@@ -657,9 +660,12 @@ class Searcher:
         cm.text_start, cm.text_end = m.text_start, m.text_end
         cm.pattern_start, cm.pattern_end = m.pattern_start, m.pattern_end
         cm.cost, cm.strand = m.cost, 1 if m.strand == "-" else 0
-        text = bytes(text)
-        addr = C.cast(C.c_char_p(text), C.c_void_p).value or 0
-        args = (self._h, C.byref(cm), m.cigar.encode(), pat_id.encode(), text_id.encode(), addr, len(text), int(sam))
+        if isinstance(text, tuple):  # (address, length) of a text that lives in somebody's buffer (fastx.RecordBatch): no copy
+            addr, tlen = int(text[0]), int(text[1])
+        else:
+            text = bytes(text)
+            addr, tlen = C.cast(C.c_char_p(text), C.c_void_p).value or 0, len(text)
+        args = (self._h, C.byref(cm), m.cigar.encode(), pat_id.encode(), text_id.encode(), addr, tlen, int(sam))
         need = lib().sassy_hip_format_tsv(*args, None, 0)
         if need < 0:
             raise SassyHipError(lib().sassy_hip_last_error().decode())
@@ -980,11 +986,11 @@ def generate_genome_like(d_ptr: int, n: int, seed: int, first: int = 0, with_n: 
 
 
 def plant(d_ptr: int, n: int, first: int, total_n: int, seed: int, pattern: bytes, k: int,
-          stride: int = 1 << 20, stream: int = 0) -> int:
+          stride: int = 1 << 20, stream: int = 0, phase: int = 0) -> int:
     cnt = C.c_uint64()
     pattern = bytes(pattern)
-    _check(lib().sassy_hip_plant(d_ptr, n, first, total_n, seed, pattern, len(pattern), k, stride,
-                                 stream or None, C.byref(cnt)))
+    _check(lib().sassy_hip_plant_phase(d_ptr, n, first, total_n, seed, pattern, len(pattern), k, stride, phase,
+                                       stream or None, C.byref(cnt)))
     return cnt.value
 
 

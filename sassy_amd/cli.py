@@ -13,46 +13,16 @@ scheduling).  Not mirrored: grep / filter output modes, --v2, threads.
 from __future__ import annotations
 
 import argparse
-import gzip
 import sys
-from typing import Iterator, List, Tuple
+from typing import List, Tuple
 
 from . import Searcher
 
-BATCH_BYTES = 64 << 20  # text bytes per search_many call
+BATCH_BYTES = 64 << 20  # input bytes per search_many call (a longer record is a batch of its own; the reader reuses its buffers)
 
 
-def read_fastx(path: str) -> Iterator[Tuple[str, bytes]]:
-    """(id, sequence) of every FASTA / FASTQ record; id = the header line without its marker, as
-    needletail's `id()` returns it (bin/input_iterator.rs:128)."""
-    if path in ("", "-"):
-        fh = sys.stdin.buffer
-    else:
-        fh = open(path, "rb")
-        if fh.read(2) == b"\x1f\x8b":
-            fh.close()
-            fh = gzip.open(path, "rb")
-        else:
-            fh.seek(0)
-    with fh:
-        rid, chunks = None, []
-        it = iter(fh)
-        for line in it:
-            line = line.rstrip(b"\r\n")
-            if line.startswith(b">"):
-                if rid is not None:
-                    yield rid, b"".join(chunks)
-                rid, chunks = line[1:].decode(), []
-            elif line.startswith(b"@") and rid is None:
-                # FASTQ: @id / sequence / + / quality (single-line records)
-                seq = next(it).rstrip(b"\r\n")
-                next(it)
-                next(it)
-                yield line[1:].decode(), seq
-            elif rid is not None:
-                chunks.append(line)
-        if rid is not None:
-            yield rid, b"".join(chunks)
+# (the reader: sassy_amd/fastx.py -- batches of whole records as one buffer + offsets, numpy over an mmap)
+from .fastx import read_fastx, read_fastx_batches  # noqa: E402,F401
 
 
 def load_patterns(args) -> List[Tuple[str, bytes]]:
@@ -90,24 +60,23 @@ def main(argv=None) -> int:
     out.write("pat_id\ttext_id\tcost\tstrand\tstart\tend\tmatch_region\tcigar\n")
     pats = [p for _, p in patterns]
 
-    def flush(batch):
-        # every pattern against every record of the batch in one call (many short records -- reads --
-        # share one device buffer); rows record by record, patterns in input order
-        if not batch:
-            return
-        ms = searcher.search_many(pats, [seq for _, seq in batch], args.k)
-        ms.sort(key=lambda m: (m.text_idx, m.pattern_idx))  # stable: keeps each pair's match order
-        for m in ms:
-            text_id, seq = batch[m.text_idx]
-            out.write(searcher.format_tsv(m, patterns[m.pattern_idx][0], text_id, seq, sam=args.sam))
+    import numpy as np
 
-    batch, batch_bytes = [], 0
+    # every pattern against every record of a batch in one call (the records of a batch are one buffer + offsets:
+    # fastx.RecordBatch -- nothing is copied per record, nothing is split but the stream of records into batches);
+    # rows record by record, patterns in input order
     for path in args.paths:
-        for rec in read_fastx(path):
-            batch.append(rec)
-            batch_bytes += len(rec[1])
-            if batch_bytes >= BATCH_BYTES:  # the reference batches ~1 MB of records per task (bin/input_iterator.rs:6)
-                flush(batch)
-                batch, batch_bytes = [], 0
-    flush(batch)
+        for batch in read_fastx_batches(path, BATCH_BYTES):
+            if not len(batch):
+                continue
+            res = searcher.search_many(pats, batch.texts, args.k, as_result=True)
+            arr = res.array
+            order = np.lexsort((np.arange(len(arr)), arr["pattern_idx"], arr["text_idx"]))  # stable: keeps each pair's match order
+            ms = res.lazy_matches
+            base = int(batch.texts.buffer.ctypes.data)
+            for i in order.tolist():
+                m = ms[i]
+                ti = m.text_idx
+                where = (base + int(batch.texts.starts[ti]), int(batch.texts.lens[ti]))
+                out.write(searcher.format_tsv(m, patterns[m.pattern_idx][0], batch.id(ti), where, sam=args.sam))
     return 0

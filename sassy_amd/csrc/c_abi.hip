@@ -1003,13 +1003,20 @@ static std::vector<uint8_t> make_plant(uint64_t seed, uint64_t q, const uint8_t*
 int sassy_hip_plant(uint8_t* d_text, uint64_t n, uint64_t first, uint64_t total_n, uint64_t seed,
                     const uint8_t* pattern, size_t pattern_len, size_t k, uint64_t stride,
                     void* hip_stream, uint64_t* planted) {
+  return sassy_hip_plant_phase(d_text, n, first, total_n, seed, pattern, pattern_len, k, stride, 0, hip_stream, planted);
+}
+// the same with the plants `phase` bytes further on (q * stride + stride / 2 + phase): several patterns planted into one text
+// (bench.py: the searches in flight look for different patterns)
+int sassy_hip_plant_phase(uint8_t* d_text, uint64_t n, uint64_t first, uint64_t total_n, uint64_t seed,
+                          const uint8_t* pattern, size_t pattern_len, size_t k, uint64_t stride, uint64_t phase,
+                          void* hip_stream, uint64_t* planted) {
   if (!d_text || !pattern || stride == 0) return fail(SASSY_HIP_EINVAL, "bad argument");
   hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
   std::vector<uint64_t> pos;
   std::vector<uint8_t> val;
   uint64_t cnt = 0;
   for (uint64_t q = 0;; ++q) {
-    const uint64_t p = q * stride + stride / 2;
+    const uint64_t p = q * stride + stride / 2 + phase;
     if (p + pattern_len + k > total_n) break;
     if (p >= first + n) break;
     std::vector<uint8_t> s = make_plant(seed, q, pattern, pattern_len, (int)(q % (k + 1)));

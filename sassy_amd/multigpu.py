@@ -345,6 +345,8 @@ class GatherWorker:
         self.q = queue.Queue()
         self.last = None
         self.error = None
+        self.busy_s = 0.0   # seconds the worker spent in gather + merge (the exchange's share of a step, per rank)
+        self.gathers = 0
         self.t = threading.Thread(target=self._run, daemon=True)
         self.t.start()
 
@@ -357,10 +359,14 @@ class GatherWorker:
                 if item is None:
                     return
                 if self.error is None:
+                    import time
                     local, failed = item
+                    t0 = time.perf_counter()
                     shards = self.g.gather(local, error=failed)
                     if shards is not None:
                         self.last = merge_shard_results(shards).copy()
+                    self.busy_s += time.perf_counter() - t0
+                    self.gathers += 1
             except BaseException as e:  # surfaced by flush()
                 self.error = e
             finally:

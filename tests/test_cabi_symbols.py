@@ -325,3 +325,61 @@ def test_switch_table_is_the_only_reader_of_the_environment(sassy):
         forced = ("SASSY_HIP_" + n.upper()) in tests_src or f'set_option("{n}"' in tests_src
         assert forced, f"switch {n} is forced by no test"
         assert f"`{n}`" in design, f"switch {n} is missing from DESIGN.md's table"
+
+
+def test_fastx_batches_equal_a_line_by_line_parse(tmp_path):
+    """sassy_amd/fastx.py (numpy over an mmap: single-line records without a copy, wrapped FASTA by strided copies, .gz by a
+    zlib stream) against a plain line-by-line parse: wrapped / unwrapped / ragged FASTA, CRLF, empty records, FASTQ, gzip,
+    batches smaller than a record, a file without a final newline."""
+    import gzip
+    import random
+    from sassy_amd.fastx import read_fastx_batches
+
+    def slow(path):
+        data = gzip.open(path, "rb").read() if open(path, "rb").read(2) == b"\x1f\x8b" else open(path, "rb").read()
+        lines = data.split(b"\n")
+        if lines and lines[-1] == b"":
+            lines.pop()
+        lines = [ln.rstrip(b"\r") for ln in lines]
+        out = []
+        if lines and lines[0].startswith(b"@"):
+            for i in range(0, len(lines), 4):
+                out.append((lines[i][1:].decode(), lines[i + 1]))
+            return out
+        rid, seq = None, []
+        for ln in lines:
+            if ln.startswith(b">"):
+                if rid is not None:
+                    out.append((rid, b"".join(seq)))
+                rid, seq = ln[1:].decode(), []
+            else:
+                seq.append(ln)
+        if rid is not None:
+            out.append((rid, b"".join(seq)))
+        return out
+
+    rng = random.Random(5)
+    seq = lambda n: bytes(rng.choice(b"ACGTN") for _ in range(n))
+    files = {}
+    wrap = lambda s, w, eol: eol.join(s[i:i + w] for i in range(0, len(s), w))
+    files["wrapped.fa"] = b"".join(b">chr%d some text\n" % i + wrap(seq(n), 60, b"\n") + b"\n" for i, n in enumerate([1000, 60, 61, 0, 5, 7000, 120]))
+    files["crlf.fa"] = b"".join(b">r%d\r\n" % i + wrap(seq(n), 70, b"\r\n") + b"\r\n" for i, n in enumerate([300, 70, 1]))
+    files["ragged.fa"] = b">a\nACGT\nAC\nACGTAC\n>b\nAAAA\nCCCC\nGG\n>c\n>d\nT\n"
+    files["unwrapped.fa"] = b"".join(b">read%d\n" % i + seq(rng.randrange(1, 200)) + b"\n" for i in range(500))
+    files["no_final_newline.fa"] = b">x\nACGT\nAC"
+    files["reads.fq"] = b"".join(b"@q%d extra\n" % i + s + b"\n+\n" + b"I" * len(s) + b"\n" for i, s in enumerate(seq(rng.randrange(1, 150)) for _ in range(400)))
+    files["at_quality.fq"] = b"@r1\nACGT\n+\n@@@@\n@r2\nGG\n+\n@I\n"
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+    with gzip.open(tmp_path / "wrapped.fa.gz", "wb") as fh:
+        fh.write(files["wrapped.fa"])
+    with gzip.open(tmp_path / "reads.fq.gz", "wb") as fh:
+        fh.write(files["reads.fq"])
+    for name in list(files) + ["wrapped.fa.gz", "reads.fq.gz"]:
+        want = slow(str(tmp_path / name))
+        for bb in (64, 1000, 1 << 20):
+            got = []
+            for rb in read_fastx_batches(str(tmp_path / name), bb):
+                assert int(rb.texts.lens.sum()) == rb.text_bytes
+                got += [(rb.id(i), rb.sequence(i)) for i in range(len(rb))]
+            assert got == want, (name, bb, len(got), len(want))
