@@ -862,9 +862,13 @@ int ScanJob::enqueue(int attempt) {
     P.list_rows = 0;
     const int env_words = (int)S->sw.list_words;
     if (env_words && !rows_declined && !ext_desc && plan.nwords >= 2 && plan.nwords <= 64 && !(P.flags & kScanOverhang)) {
-      // groups of G lanes: a chunk's warm-up blocks and six blocks of end positions in one pass (longer chunks take more)
-      // (list_words >= 4: that many lanes per chunk -- timing experiments)
-      const uint32_t G = env_words >= 4 ? std::min<uint32_t>(64u, (uint32_t)env_words) : std::min<uint32_t>(64u, std::max<uint32_t>(4u, P.wb + 6u));
+      // groups of G lanes: a chunk's warm-up blocks and ten blocks of end positions in one pass (longer chunks take more
+      // passes: with G = wb + 6 half the waves of config 3 ran two -- 92 us instead of 46); list_words >= 4: that many lanes
+      // (the sizes that leave no lane of the wave over; a run of candidate blocks behind the counting filter is 5 .. 10 blocks)
+      uint32_t G = 64;
+      for (uint32_t g : {8u, 9u, 10u, 12u, 16u, 21u, 32u, 64u})
+        if (g >= P.wb + 10u) { G = g; break; }
+      if (env_words >= 4) G = std::min<uint32_t>(64u, (uint32_t)env_words);
       const size_t m16 = ((size_t)plan.m + 15u) & ~(size_t)15;
       const size_t rows_lds = 128 + m16 + 16 + (size_t)kWavesPerGroup * ((size_t)bucket * 512u + (64u / G) * m16);
       if (env_words != 2 && !plan.bytes && !S->want_counters && rows_lds <= 150 * 1024) {

@@ -2198,6 +2198,7 @@ def test_searches_in_flight_begin_finish(sassy):
     want = [ref.search_shard(p, buf.ptr, 0, n, 0, n, k).matches for p, k in zip(pats, ks)]
     assert all(len(w) > 20 for w in want[:3])
     # a stream of searches, two in flight, finished oldest first
+    s.set_option("pipe_depth", 2)  # (the default; a forced-switch run may have set another)
     got, pending = [], []
     for p, k in zip(pats, ks):
         pending.append(s.search_shard_begin(p, buf.ptr, 0, n, 0, n, k))
