@@ -41,7 +41,6 @@ namespace sassy_hip {
   X(big_pin, 1, "0: dense results through the host's vectors instead of one pinned block")                                  \
   X(compact_cigars, 1, "0: dense results keep their cigar slots' padding")                                                  \
   X(adopt, 1, "0: results are copied out of the pinned block the kernels wrote them into")                                  \
-  X(host_poll, 1, "the host waits for a lone search on a flag word its last kernel writes into pinned memory (0: hipStreamSynchronize only)") \
   X(lanes, 1, "2 .. 4: one search cut into sub-shards on that many streams")                                                \
   X(subshard_min, 128 << 20, "smallest sub-shard in bytes for lanes > 1")                                                   \
   X(rc_fused, 1, "0: the Rc strand from a reversed copy instead of Rc marks made by the forward pass")                      \
