@@ -180,94 +180,21 @@ constexpr int kEmitShiftBit = 24;
 constexpr uint32_t kRepBase = 1u << 16;
 typedef uint32_t rep4 __attribute__((ext_vector_type(4)));  // (a native vector travels in registers; HIP's uint4 struct went through scratch)
 __device__ __forceinline__ rep4 make_rep4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { rep4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
-__device__ __noinline__ rep4 scan_block(const EmitCtx P, uint64_t vp, uint64_t vm, int ds, uint64_t b, bool owned,
-                                         bool last_warm, int64_t x0, uint32_t state) {
-  bool dec = (state & kStDec) != 0, amb = (state & kStAmb) != 0;
-  // (window chunks: bits 8 .. 23 of `state` = how many exact columns behind x0 are not this chunk's to report -- they
-  // are there to settle the plateau state, their end positions are another window's)
-  const int64_t r0 = x0 + (int64_t)((state >> 8) & 0xFFFFu);
-  const int k = (int)P.k;
-  const bool all = (P.flags & kScanAllMinima) != 0;
-  uint64_t rep = 0;
-  uint32_t n_rep = 0, n_cond = 0, rep_base = 0;
-  const uint64_t base = b * 64 + (P.flags >> kEmitShiftBit);
-  // with overhang the end positions run on into the virtual 'N' columns behind the text, at an
-  // extra cost (reference: add_overshoot_cost, src/search.rs:1274-1282)
-  const uint64_t max_pos = P.text_len + P.ov_steps;
-  if (base >= max_pos) return make_rep4(0u, 0u, state & 0xFFu, 0u);
-  const bool ov = P.ov_steps != 0;
-  auto total_of = [&](int c, uint64_t pos) -> int {
-    return (ov && pos > P.text_len) ? c + __float2int_rd(P.alpha * (float)(pos - P.text_len)) : c;
-  };
-  // report at base + i (i = 0 .. 64); reports are made in position order
-  auto report = [&](uint32_t i, bool cond) {
-    if (i == 0) rep_base = kRepBase;
-    else rep |= 1ull << (i - 1);
-    if (cond) n_cond = n_rep + 1;  // (conditional reports come first)
-    ++n_rep;
-  };
-  int raw = ds;                        // cost without the overshoot part
-  int cost = total_of(raw, base), prev_cost = cost;
-  uint64_t prev_pos = base;
-  if (all && owned && cost <= k && base == P.text_begin && P.global_offset == 0 && (P.flags & kScanTextStart))
-    report(0, false);
-  bool determined = (x0 < 0);
-  // A flat block that lies whole inside the text and behind x0 -- the inside of a run of N, of poly-A against poly-A:
-  // one plateau from its first column to its last.  Nothing rises, nothing falls: no report under the report rule, `dec`
-  // stays; the plateau state is settled when its cost is 0 or > k (as in the loop below).  Such blocks come by the
-  // thousand, one after the other in a lane, and the 64-step walk was twice the cost of their DP rows.
-  if (!all && (vp | vm) == 0 && !ov && base + 64 <= max_pos && (int64_t)base >= x0 &&
-      !((P.flags & kScanTextEnd) && base + 64 == max_pos)) {
-    if (cost > k || cost == 0) {
-      if (owned) amb = false;
-      else determined = true;
-    }
-    if (last_warm) amb = !determined;
-    return make_rep4(0u, 0u, (dec ? kStDec : 0u) | (amb ? kStAmb : 0u), 0u);
-  }
-  for (int bit = 1; bit <= 64; ++bit) {
-    const uint64_t pos = base + (uint64_t)bit;
-    if (pos > max_pos) break;
-    raw += (int)((vp >> (bit - 1)) & 1);
-    raw -= (int)((vm >> (bit - 1)) & 1);
-    cost = total_of(raw, pos);
-    // (x0: columns up to it are not exact yet.  The owned blocks of a chunk with warm-up BLOCKS lie behind x0 as a
-    // whole; a window chunk warms up inside its own first block(s): nothing is reported or concluded there)
-    const bool exact = (int64_t)pos > x0;
-    if (all) {
-      if (owned && (int64_t)pos > r0 && cost <= k) report((uint32_t)bit, false);
-    } else {
-      const bool rising = cost > prev_cost, falling = cost < prev_cost;
-      if (dec && rising && prev_cost <= k && owned && (int64_t)prev_pos > r0) report((uint32_t)bit - 1u, amb);
-      dec = falling || (dec && !rising);
-      // An exact cell of cost 0 settles the plateau state as well: costs are >= 0, so the last change in front of it
-      // was no increase -- `dec` is true there in the one-pass definition whatever lies left of this chunk (long
-      // runs of N under Iupac, poly-A against poly-A: plateaus of cost 0 that no window sees the beginning of).
-      const bool event = rising || falling || cost > k || prev_cost > k || cost == 0;
-      if (event && exact) {
-        if (owned) amb = false;
-        else determined = true;
-      }
-    }
-    prev_cost = cost;
-    prev_pos = pos;
-  }
-  if (!all) {
-    if (last_warm) amb = !determined;
-    if (owned && (P.flags & kScanTextEnd) && prev_pos == max_pos && dec && prev_cost <= k && (int64_t)prev_pos > r0)
-      report((uint32_t)(prev_pos - base), amb);
-  }
-  return make_rep4((uint32_t)rep, (uint32_t)(rep >> 32), (dec ? kStDec : 0u) | (amb ? kStAmb : 0u) | (n_cond << 8) | rep_base, 0u);
-}
-
-// The same decisions, by the WHOLE WAVE for one block: lane c looks at column c + 1.  scan_block is a chain of 64
-// dependent, branchy steps -- ~20 us for one call, whatever the number of lanes that are in it -- and on sparse results
+// By the WHOLE WAVE for one block: lane c looks at column c + 1.  (Until round 6 every lane walked its own block: a chain
+// of 64 dependent, branchy steps -- ~20 us for one call, whatever the number of lanes that were in it -- and on sparse results
 // (a few live blocks per wave: every search of the benchmarks) those calls were most of the chunk DP's time: 40 of the 75 us
 // of config 3's list kernel, most of the 30 us a wave of the fused launch spends behind its stream.  Here the 64 costs come
 // from two masked popcounts per lane, the comparisons leave as ballots, and the two sequential pieces of the rule become
 // bit arithmetic on those 64-bit masks: `dec` after column c = "the last rise or fall at or before c was a fall" (a fill of
 // the falls through the columns without either, in six doubling steps; dec_in in front of the first), `amb` is cleared by
-// the first exact event, and the reports made up to that column are the conditional ones.  All arguments wave-uniform.
+// the first exact event, and the reports made up to that column are the conditional ones.)  All arguments wave-uniform.
+// The rule itself, column by column (pos = base + bit, bit = 1 .. 64, while pos <= text end + overhang steps):
+//   cost = ds + (+1 deltas) - (-1 deltas) up to the column (+ the overshoot cost behind the text end);
+//   search_all: report pos when owned, pos > r0 and cost <= k;
+//   else: rising / falling = cost above / below the previous column's; report the PREVIOUS position when dec, rising,
+//   its cost <= k, owned and behind r0 (conditional while `amb`); dec = falling || (dec && !rising); an exact column
+//   (pos > x0) that rises, falls, exceeds k (itself or the one before) or costs 0 settles the state: amb = false (owned)
+//   / determined (warm-up); behind the last warm-up block amb = !determined; the end of the text ends a plateau.
 __device__ __forceinline__ rep4 scan_block_cols(const EmitCtx& P, uint32_t flags, uint64_t text_len, uint64_t text_begin, uint64_t vp,
                                                 uint64_t vm, int ds, uint64_t b, bool owned, bool last_warm, int64_t x0, uint32_t state) {
   const uint32_t lane = __lane_id();
@@ -2733,11 +2660,7 @@ __global__ __launch_bounds__(256) void list_rows_kernel(const ScanParams P) {
     const uint64_t b = blk0 + bi;
     {
       uint32_t x[16];
-#if defined(ROWS_EXP) && ROWS_EXP == 3
-      for (int q = 0; q < 16; ++q) x[q] = 0x41414141u + (uint32_t)b;
-#else
       fetch_block(P, has_blk, b, x);
-#endif
       uint2 msk[NS];
       build_masks<PROFILE, NS>(x, P, msk);
 #pragma unroll
@@ -2799,9 +2722,6 @@ __global__ __launch_bounds__(256) void list_rows_kernel(const ScanParams P) {
           ds_blk = li == 0u ? ds_pass : ds_left;
           dsr = ds_blk + (int)__popc(V.vpl) + (int)__popc(V.vph) - (int)__popc(V.vml) - (int)__popc(V.vmh);
           live = row_maybe_live(ds_blk, V, k);
-#if defined(ROWS_EXP) && ROWS_EXP == 2
-          live = false;
-#endif
         }
       }
     };
@@ -2810,9 +2730,7 @@ __global__ __launch_bounds__(256) void list_rows_kernel(const ScanParams P) {
     const uint32_t t_steady = min(span > 0u ? span - 1u : 0u, m - 1u), t_tail = m - 1u;
     for (; t < t_steady; ++t) step(t, std::true_type{}, std::false_type{});   // ramp-up
     if (has_blk) {                                                             // every lane with a block is inside its rows
-#if !defined(ROWS_EXP) || ROWS_EXP != 1
       for (uint32_t t2 = t; t2 < t_tail; ++t2) step(t2, std::false_type{}, std::false_type{});
-#endif
     } else {
       rp += t_tail - t;
     }
@@ -2839,11 +2757,7 @@ __global__ __launch_bounds__(256) void list_rows_kernel(const ScanParams P) {
       }
     }
     if (has_blk && bi + 1u == nb) st_last = stv;
-#if !defined(ROWS_EXP) || ROWS_EXP != 5
     if (__any((rr.x | rr.y | (rr.z & kRepBase)) != 0u)) (void)emit_reports(ctx, rr, vp, vm, ds_blk, b);
-#else
-    if (rr.x == 0x12345u) P.chunk_state[0] = 1;
-#endif
     // the next pass's first lane continues behind this pass's last one
     const int last_lane = (int)((in_group ? gi : 0u) * G + G - 1u);
     st_pass = (uint32_t)__shfl((int)stv, last_lane, 64);
