@@ -773,7 +773,11 @@ int ScanJob::enqueue(int attempt) {
   }
   // control block, rank counters and (first attempt: the filter runs once) the hit bitmap
   // (fused: no bitmap -- and the rank counters behind the control block are not used either)
-  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, fused ? 64 : kCtlHead + (filtered && !ext_bitmap && !ext_desc && !count_direct && attempt == 0 ? (n_words + 2) * 8 : 0), L.stream));
+  // (the rank counters behind the control block only where the rank kernels run: not when the traceback waves rank
+  // their reports themselves -- with the counting filter's own chunk list the whole clear is 64 bytes)
+  const bool ranks_itself = S->sw.self_rank != 0 && do_trace && use_wave && texts.n == 0;
+  const bool bitmap_here = filtered && !ext_bitmap && !ext_desc && !count_direct && attempt == 0;
+  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, fused || (ranks_itself && !bitmap_here) ? 64 : kCtlHead + (bitmap_here ? (n_words + 2) * 8 : 0), L.stream));
   if (ext_wait && attempt == 0) HIP_TRY(hipStreamWaitEvent(L.stream, ext_wait, 0));
   // pipelined sub-shards: this lane's filter starts when the previous sub-shard's filter is done,
   // so that the previous lane's DP / rank / traceback kernels overlap this bandwidth-bound one

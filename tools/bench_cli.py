@@ -4,8 +4,8 @@
 
 Writes a synthetic wrapped FASTA (seeded random ACGT, `records` records, `width` bases per line) with one near-match of the
 pattern planted per MiB, then times (1) sassy_amd.fastx.read_fastx_batches over it (unwrap to one buffer + offsets),
-(2) `python -m sassy_amd search` in this process (stdout to a file), (3) the plain upload of as many bytes from pinned
-memory (the ceiling any host-text path has).  One JSON line.
+(2) `python -m sassy_amd search` in this process (stdout to a file), beside the time the PCIe link needs for as many bytes at its
+measured ceiling (bench.py: h2d_inclusive).  One JSON line.
 """
 import argparse
 import io
@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--width", type=int, default=60)
     ap.add_argument("--dir", default="/tmp")
     ap.add_argument("-k", type=int, default=3)
+    ap.add_argument("--link-gb-per-s", type=float, default=57.5, help="the PCIe link's measured ceiling (bench.py: h2d_inclusive)")
     args = ap.parse_args()
     n = int(args.bytes) // (args.records * args.width) * (args.records * args.width)
     pat = bytes(_dna_bytes(43, 0, 32))
@@ -75,22 +76,15 @@ def main():
             finally:
                 sys.stdout = real
     rows = sum(1 for _ in open(tsv)) - 1
-    # (3) the link: the same number of bytes from pinned memory
-    import torch
-    pinned = torch.empty(min(n, 1 << 30), dtype=torch.uint8).pin_memory()
-    dev = torch.empty_like(pinned, device="cuda")
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(max(1, n // pinned.numel())):
-        dev.copy_(pinned, non_blocking=True)
-    torch.cuda.synchronize()
-    t_link = (time.perf_counter() - t0) * (n / (max(1, n // pinned.numel()) * pinned.numel()))
+    # (3) the link's ceiling for as many bytes: bench.py measures it on every run (h2d_inclusive.link_ceiling_GB_per_s, 1 GiB
+    # from pinned memory: 57.5 GB/s on these boxes); quoted here, not measured again
+    t_link = n / (args.link_gb_per_s * 1e9)
     print(json.dumps({
         "workload": f"{fsize} B FASTA ({args.records} records, {args.width} bases per line), Dna, |pattern|=32, k={args.k}, forward",
         "reader_seconds": round(t_read, 3), "reader_GB_per_s": round(fsize / t_read / 1e9, 2),
         "fasta_to_tsv_seconds": round(min(times), 3), "fasta_to_tsv_first_call_seconds": round(times[0], 3),
         "fasta_to_tsv_GB_per_s": round(fsize / min(times) / 1e9, 2), "tsv_rows": rows,
-        "link_seconds_same_bytes_from_pinned_memory": round(t_link, 3),
+        "link_seconds_same_bytes_at_the_measured_ceiling": round(t_link, 3),
         "ratio_to_link": round(min(times) / t_link, 1),
     }))
     os.remove(path)
