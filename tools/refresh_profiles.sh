@@ -2,7 +2,7 @@
 # tools/refresh_profiles.sh <round-tag> -- ON THE GPU BOX (via gpurun): every measurement profiles/ holds,
 # written under gpurun_out/refresh/ (copy the files into profiles/ afterwards: tools/collect_profiles.sh).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 OUT=gpurun_out/refresh
@@ -42,7 +42,7 @@ print('   ms_per_search', d['ms_per_step'], 'scan_kernel_ms', d['dominant_kernel
 # ---- searches in flight: depth, filter occupancy, chaining
 { echo "# python bench.py --steps 400 --warmup 50 (3 GB, config 2): ms per search by searches in flight and switches";
   for v in "--in-flight 1" "--in-flight 2" "--in-flight 3" "--in-flight 4"; do echo "$v: $(python bench.py --steps 400 --warmup 50 --no-cpu-baseline $v 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')"; done;
-  for e in "SASSY_HIP_FILTER_LDS_PAD=0" "SASSY_HIP_FILTER_LDS_PAD=16384" "SASSY_HIP_FILTER_LDS_PAD=40000" "SASSY_HIP_PIPE_CHAIN=1" "SASSY_HIP_FILTER_LINEAR=8192"; do echo "--in-flight 2 $e: $(env $e python bench.py --steps 400 --warmup 50 --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')"; done; } > $OUT/${TAG}_in_flight.txt 2>&1
+  for e in "SASSY_HIP_FILTER_LINEAR=8192" "SASSY_HIP_PIPE_DEPTH=3"; do echo "--in-flight 2 $e: $(env $e python bench.py --steps 400 --warmup 50 --no-cpu-baseline 2>/dev/null | grep -o '"ms_per_step": [0-9.]*')"; done; } > $OUT/${TAG}_in_flight.txt 2>&1
 # ---- lane-chunk geometry: default vs the opt-in tuner, lone searches and searches in flight, several text sizes
 { echo "# bench.py --steps 300 --warmup 60 --tune-searches 40: ms per search (in flight 2) | latency of a lone search; SASSY_HIP_TUNE=1 = opt-in tuner";
   for n in 1000000000 2000000000 2700000000 3000000000 3700000000 5000000000; do for t in 0 1; do
@@ -52,10 +52,13 @@ print('   ms_per_search', d['ms_per_step'], 'scan_kernel_ms', d['dominant_kernel
   echo "# (one-off builds, round 3: half the look-ups 0.578-0.592 ms, no look-ups 0.537 ms, no look-ups + Iupac text check 0.562 ms; WPG=4: 0.593-0.600)";
   for shape in "iupac 200 20" "iupac 32 3" "dna 100 10"; do set -- $shape; for w in 4 16; do
     echo "profile $1 m $2 k $3 SASSY_HIP_COUNT_WPG=$w: $(PROBE_PROFILE=$1 PROBE_M=$2 PROBE_K=$3 SASSY_HIP_FILTER_KIND=4 SASSY_HIP_COUNT_WPG=$w python tools/probe_fused.py 2>/dev/null | tail -1 | cut -c1-200)"; done; done;
-  echo "## the config-3 shape (Iupac, m=200, k=20) as a lone search: kernel timeline";
-  PROBE_PROFILE=iupac PROBE_M=200 PROBE_K=20 rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof_${TAG}_c3 -o t -- python tools/probe_fused.py 2>/dev/null | tail -1 | cut -c1-200;
-  python tools/timeline.py gpurun_out/prof_${TAG}_c3 filter_count;
-  echo "## its traceback waves, microseconds per report and phase"; PROBE_PROFILE=iupac PROBE_M=200 PROBE_K=20 SASSY_HIP_TRACE_PROBE=1 python tools/probe_fused.py 2>&1 | grep "trace waves" | tail -1; } > $OUT/${TAG}_count_filter.txt 2>&1
+  echo "## the config-3 shape (Iupac, m=200, k=20, N R Y W in the pattern) as a lone search: kernel timelines (tools/c3_timeline.sh)";
+  echo "## default: the filter files its chunk descriptors itself, compact_chunks_kernel, list_rows_kernel (a lane per block)"; } > $OUT/${TAG}_count_filter.txt 2>&1
+bash tools/c3_timeline.sh $OUT/${TAG}_count_filter.txt
+bash tools/c3_timeline.sh $OUT/${TAG}_count_filter.txt SASSY_HIP_LIST_WORDS=2
+bash tools/c3_timeline.sh $OUT/${TAG}_count_filter.txt SASSY_HIP_COUNT_FUSED=0
+bash tools/c3_timeline.sh $OUT/${TAG}_count_filter.txt SASSY_HIP_COUNT_FUSED=0 SASSY_HIP_LIST_WORDS=2
+{ echo "## its traceback waves, microseconds per report and phase"; PROBE_C3=1 PROBE_PROFILE=iupac PROBE_M=200 PROBE_K=20 SASSY_HIP_TRACE_PROBE=1 python tools/probe_fused.py 2>&1 | grep "trace waves" | tail -1; } >> $OUT/${TAG}_count_filter.txt 2>&1
 # ---- does gfx950 skip masked 16-lane quarters of a VALU instruction?  (sub-wave groups for the streaming DP: no)
 { echo "# tools/ubench/exec_skip.hip: 4096 x 128 dependent v_bitop3_b32 per wave, 8 waves per SIMD, by EXEC mask";
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/exec_skip tools/ubench/exec_skip.hip 2>/dev/null && /tmp/exec_skip; } > $OUT/${TAG}_exec_mask_ubench.txt 2>&1
@@ -99,8 +102,9 @@ python tools/preflight_multigpu.py --gpus 2 --backend gloo 2>/dev/null | tail -1
   unset PROBE_SHAPES; } > $OUT/${TAG}_paired_filter.txt 2> $OUT/pair.err
 { echo "# tools/probe_short_pieces.py: shapes whose pigeonhole pieces are 5 or 6 rows -- default path against no prefilter (streaming DP), lone searches, 3 GB";
   python tools/probe_short_pieces.py; } > $OUT/${TAG}_short_pieces.txt 2> $OUT/short.err
-{ echo "# tools/pmc_kernel.sh list_words_kernel: config 3's chunk DP (word-pipelined), counters per dispatch (sums over the waves; cycles in units of 4)";
-  bash tools/pmc_kernel.sh list_words_kernel PROBE_C3=1 PROBE_PROFILE=iupac PROBE_M=200 PROBE_K=20; } > $OUT/${TAG}_list_words_pmc.txt 2>&1
+{ echo "# tools/pmc_kernel.sh list_rows_kernel: config 3's chunk DP (a lane per block), counters per dispatch (sums over the waves; cycles in units of 4)";
+  bash tools/pmc_kernel.sh list_rows_kernel PROBE_C3=1 PROBE_PROFILE=iupac PROBE_M=200 PROBE_K=20; } > $OUT/${TAG}_list_rows_pmc.txt 2>&1
+python tools/bench_cli.py > $OUT/${TAG}_bench_cli.json 2> $OUT/bench_cli.err
 python tools/cpu_probe.py > $OUT/${TAG}_host_cpus.txt 2>&1
 tail -2 $OUT/*.err
 ls -la $OUT
