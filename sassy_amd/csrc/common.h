@@ -13,6 +13,7 @@ constexpr uint32_t PROFILE_ASCII_BYTES = 3;
 
 constexpr int kWave = 64;              // gfx950 wavefront
 constexpr int kWavesPerGroup = 4;      // 256-thread workgroups, every wave works alone
+constexpr uint32_t kCarryListGroups = 1024;  // list_kernel<.., GC>: workgroups that share a long pattern's chunk list
 constexpr int kTileBytes = 64 * 128;   // text tile of one wave: 64 lane chunks x 2 blocks x 64 B,
                                        // 16-byte slots XOR-swizzled by (owner>>1)&7
 constexpr uint32_t kRegionSlots = 16;  // chunk descriptors a wave of the counting filter can file (count_direct)
@@ -116,6 +117,8 @@ struct ScanParams {
   uint32_t lds_per_wave;      // bytes
   uint32_t waves_per_group;   // scan_kernel / list_kernel: wavefronts per workgroup (4; fewer when a long pattern's
                               // per-row carries -- 64 bytes per 32 rows and lane -- would not fit four waves' LDS)
+  uint32_t* carry_global;     // != nullptr: the per-row carries of every wave live here (128 * nwords words per wave), not in
+                              // LDS -- patterns beyond ~9 800 rows (scan_kernel<.., GC> / list_kernel<.., GC>)
   uint32_t cand_cap;
   uint32_t n_iter;            // iterations of the block loop
   uint32_t stage_blocks;      // 1 or 2: text blocks per lane chunk fetched per staging step

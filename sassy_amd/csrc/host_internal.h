@@ -277,6 +277,7 @@ struct ScanLane {
   DevBuf<MatchOut> d_trace;
   DevBuf<ChunkDesc> d_desc, d_regions;   // (d_regions / d_region_count: the counting filter's own chunk list, one region per wave)
   DevBuf<uint32_t> d_region_count;
+  DevBuf<uint32_t> d_carry;     // per-row carries of patterns too long for LDS (ScanParams::carry_global)
   // pattern-dependent device data of the scan that runs on this lane, and what it currently holds
   // (uploads are skipped when the pattern repeats); per lane, so that scans of different patterns
   // can be in flight on different lanes
@@ -418,7 +419,7 @@ struct ScanLane {
     h_up = nullptr; h_up_cap = h_up_used = 0;
     d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release(); d_sort.release(); d_scratch2.release(); d_flags.release();
     for (unsigned char*& b : h_bulk) { if (b) (void)hipHostFree(b); b = nullptr; }
-    d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release(); d_regions.release(); d_region_count.release();
+    d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release(); d_regions.release(); d_region_count.release(); d_carry.release();
     d_pattern.release(); d_table.release(); d_rowoff.release(); d_ovtab.release(); d_stash.release();
     if (h_pin) g_pin_pool.give(PinBlock{h_pin, h_pin_dev, h_pin_cap, h_pin_device});
     h_pin = nullptr;

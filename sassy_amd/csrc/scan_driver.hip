@@ -557,15 +557,20 @@ int ScanJob::prepare() {
   fgrid = 0;
   if (!filtered) {
     tuned = S->tune && S->timing >= 1 && !ext_desc;  // (level 1 times the streaming DP when there is no filter)
+    // long patterns: the per-row carries (64 bytes per 32 rows and lane) of four waves no longer fit a workgroup's
+    // 160 KiB of LDS -- fewer waves per workgroup then; beyond ~9 800 rows not even one wave's: the carries go to global
+    // memory (scan_kernel<.., GC>: 512 bytes per pattern word and wave)
+    const bool gc = 4096u * P.stage_blocks + bucket * 512u + (size_t)plan.nwords * 512u > 160 * 1024;
+    if (gc) P.stage_blocks = 1;
     if (int rc = stream_geometry(P, owned, P.wb, &grid, 16, tuned ? &S->tuner_scan : nullptr, sh.d_text, sh.text_len,
                                  1000u + plan.nwords)) return rc;
-    P.lds_per_wave = 4096u * P.stage_blocks + bucket * 512u + plan.nwords * 512u;
-    // long patterns: the per-row carries (64 bytes per 32 rows and lane) of four waves no longer fit a workgroup's
-    // 160 KiB of LDS -- fewer waves per workgroup then (m <= ~9 800 with one)
+    P.lds_per_wave = 4096u * P.stage_blocks + bucket * 512u + (gc ? 0u : plan.nwords * 512u);
     P.waves_per_group = (uint32_t)std::min<size_t>(kWavesPerGroup, (160 * 1024) / P.lds_per_wave);
-    if (P.waves_per_group == 0)
-      return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store (about 9 800 rows)");
     grid = (uint32_t)((P.n_chunks + 64ull * P.waves_per_group - 1) / (64ull * P.waves_per_group));
+    if (gc) {
+      if (int rc = L.d_carry.reserve((size_t)grid * P.waves_per_group * plan.nwords * 128u)) return rc;
+      P.carry_global = L.d_carry.p;
+    }
     if (int rc = L.d_state.reserve(P.n_chunks)) return rc;
     P.chunk_state = L.d_state.p;
   } else {
@@ -743,10 +748,15 @@ int ScanJob::prepare() {
         F2.piece_mirror |= 1u << pp;
       }
     }
-    P.lds_per_wave = bucket * 512u + plan.nwords * 512u;
+    // (the chunk DP's carries: in LDS, fewer waves per workgroup for long patterns; beyond ~10 000 rows in global memory and
+    // a fixed number of waves -- list_kernel<.., GC>)
+    const bool gc = bucket * 512u + (size_t)plan.nwords * 512u > 160 * 1024;
+    P.lds_per_wave = bucket * 512u + (gc ? 0u : plan.nwords * 512u);
     P.waves_per_group = (uint32_t)std::min<size_t>(kWavesPerGroup, (160 * 1024) / P.lds_per_wave);
-    if (P.waves_per_group == 0)
-      return fail(SASSY_HIP_EUNSUPPORTED, "pattern too long for the LDS carry store (about 10 000 rows)");
+    if (gc) {
+      if (int rc = L.d_carry.reserve((size_t)kCarryListGroups * P.waves_per_group * plan.nwords * 128u)) return rc;
+      P.carry_global = L.d_carry.p;
+    }
   }
 
   t_mark = t_enter;
@@ -889,7 +899,8 @@ int ScanJob::enqueue(int attempt) {
     // the descriptor count lives on the device: launch for the capacity, idle waves exit at once
     // (with the few-chunks kernel in front the lane-per-chunk kernel would only start 1 000 workgroups that look at the
     // count and leave -- 4.7 us of stream time: left out; finish_once() sends a longer list through here again)
-    const uint32_t lgrid = P.list_words_max ? 0u : (desc_cap + 64u * P.waves_per_group - 1) / (64u * P.waves_per_group);
+    uint32_t lgrid = P.list_words_max ? 0u : (desc_cap + 64u * P.waves_per_group - 1) / (64u * P.waves_per_group);
+    if (P.carry_global) lgrid = std::min(lgrid, kCarryListGroups);
     le = launch_list_any(S->profile, P, lgrid, (size_t)P.waves_per_group * P.lds_per_wave, L.stream);
     if (le != hipSuccess) return hip_fail(le, "list kernel launch");
     }

@@ -670,7 +670,9 @@ __device__ __forceinline__ uint32_t dp_word(DpWord& V, const unsigned char* my_m
 // first_rows (wave-uniform, in/out): the row count from which this wave tests; it follows the text --
 // down to four rows before the last stop, up by four after a block that ran through.
 // minus_total (per lane, in/out): -1 vertical deltas on the block's left edge over all words.
-template <bool BYTES = false>
+// AHEAD: the next word's carries are fetched while this word's rows run (carries in global memory: a load per word
+// would otherwise be waited for 375 times per block at m = 12 000).
+template <bool BYTES = false, bool AHEAD = false>
 __device__ __forceinline__ bool dp_block(DpWord& V, int& ds, const unsigned char* my_masks, uint32_t* carry, uint32_t lane,
                                          const_u32_ptr row_tab, const uint32_t (&pkw0)[8], uint32_t nwords, uint32_t last_rows,
                                          uint32_t last_word_init, int k, bool idle, uint32_t& first_rows, int& minus_total,
@@ -679,6 +681,8 @@ __device__ __forceinline__ bool dp_block(DpWord& V, int& ds, const unsigned char
   ds = 0;                             // cost at the block's left edge, rows above the current word
   int seen_minus = 0, next_minus = 0;
   uint32_t stop_at = 0;               // != 0: the wave stopped after this many rows of the block
+  uint32_t ahp = 0, ahm = 0;
+  if constexpr (AHEAD) { ahp = carry[lane]; ahm = carry[64 + lane]; }
   for (uint32_t w = 0; w < nwords; ++w) {
     const bool last = w == nwords - 1;
     if (stop_at) {  // wave-uniform: the rows of this word are skipped, right-edge carry (+1, 0)
@@ -686,8 +690,14 @@ __device__ __forceinline__ bool dp_block(DpWord& V, int& ds, const unsigned char
       carry[(w * 2 + 1) * 64 + lane] = 0;
       continue;
     }
-    const uint32_t ohp = carry[(w * 2 + 0) * 64 + lane];
-    const uint32_t ohm = carry[(w * 2 + 1) * 64 + lane];
+    uint32_t ohp, ohm;
+    if constexpr (AHEAD) {
+      ohp = ahp; ohm = ahm;
+      if (!last) { ahp = carry[(w * 2 + 2) * 64 + lane]; ahm = carry[(w * 2 + 3) * 64 + lane]; }
+    } else {
+      ohp = carry[(w * 2 + 0) * 64 + lane];
+      ohm = carry[(w * 2 + 1) * 64 + lane];
+    }
     seen_minus += (int)__popc(ohm);
     const uint32_t rows = last ? last_rows : 32u;
     uint32_t pkw[8];
@@ -725,7 +735,8 @@ __device__ __forceinline__ bool dp_block(DpWord& V, int& ds, const unsigned char
 
 // SB = text blocks per lane chunk fetched by one staging step: 2 = one full 128-byte line per
 // chunk (8 KiB tile), 1 = half lines (4 KiB tile, more waves fit in the LDS).
-template <int PROFILE, int NS, int SB>
+// GC: the per-row carries in global memory (P.carry_global; patterns whose carries do not fit one wave's LDS).
+template <int PROFILE, int NS, int SB, bool GC = false>
 __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr uint32_t kRowBytes = 64u * SB;          // tile row = the staged bytes of one lane chunk
@@ -739,6 +750,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
   unsigned char* tile = wbase;
   unsigned char* mask_bytes = wbase + kTile;                                 // [NS][64] u64
   uint32_t* carry = reinterpret_cast<uint32_t*>(wbase + kTile + NS * 512);  // [word][hp|hm][lane]
+  if constexpr (GC) carry = P.carry_global + ((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * P.nwords * 128u;
 
   const uint64_t wave_chunk0 = ((uint64_t)blockIdx.x * (blockDim.x >> 6) + wave) * kWave;  // (1 .. 4 waves per workgroup)
   if (wave_chunk0 >= P.n_chunks) return;  // wave-uniform
@@ -867,7 +879,7 @@ __global__ __launch_bounds__(256) void scan_kernel(const ScanParams P) {
     if ((it & 7u) == 7u && first_rows > 8u && first_rows <= m) first_rows -= 4u;  // now and then try an earlier row again
     DpWord V;
     int ds;  // cost at the block's left edge in the last row
-    const bool ran_through = dp_block<PROFILE == (int)PROFILE_ASCII_BYTES>(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
+    const bool ran_through = dp_block<PROFILE == (int)PROFILE_ASCII_BYTES, GC>(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
                                       !active, first_rows, minus_total, m, P.counters != nullptr && active, cnt_rows);
 
     // ---- last row of the block: anything <= k ? ----
@@ -1549,7 +1561,7 @@ __global__ __launch_bounds__(256) void filter_table_kernel(const ScanParams P) {
 // di: index of the lane's chunk in P.chunk_state (kNoStateSlot: the exit state is not recorded).
 constexpr uint32_t kNoStateSlot = 0xFFFFFFFFu;
 // WIN: the chunks are windows (kDescWindow): blocks at any byte offset, warm-up inside the owned blocks.
-template <int PROFILE, int NS, bool WIN = false>
+template <int PROFILE, int NS, bool WIN = false, bool GC = false>
 __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* mask_bytes, uint32_t* carry, uint32_t lane,
                                            bool has_chunk, const ChunkDesc d, uint32_t di) {
   const uint64_t own_lo = d.own_lo, own_hi = d.own_hi;
@@ -1657,7 +1669,7 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
       if ((it & 7u) == 7u && first_rows > 8u && first_rows <= m) first_rows -= 4u;
       DpWord V;
       int ds;
-      const bool ran_through = dp_block<PROFILE == (int)PROFILE_ASCII_BYTES>(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
+      const bool ran_through = dp_block<PROFILE == (int)PROFILE_ASCII_BYTES, GC>(V, ds, my_masks, carry, lane, row_tab, pkw0, nwords, last_rows, last_word_init, k,
                                         !active, first_rows, minus_total, m, P.counters != nullptr && active, cnt_rows);
       rep4 rr = make_rep4(0u, 0u, 0u, 0u);
       const uint64_t vp = ((uint64_t)V.vph << 32) | V.vpl, vm = ((uint64_t)V.vmh << 32) | V.vml;
@@ -1708,7 +1720,8 @@ __device__ __forceinline__ void list_lanes(const ScanParams& P, unsigned char* m
   }
 }
 
-template <int PROFILE, int NS>
+// GC: the per-row carries in global memory (P.carry_global), and a fixed number of waves that take the chunk list 64 at a time.
+template <int PROFILE, int NS, bool GC = false>
 __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const uint32_t lane = threadIdx.x & 63u;
@@ -1716,18 +1729,22 @@ __global__ __launch_bounds__(256) void list_kernel(const ScanParams P) {
   unsigned char* wbase = smem + (size_t)wave * P.lds_per_wave;
   unsigned char* mask_bytes = wbase;                                        // [NS][64] u64
   uint32_t* carry = reinterpret_cast<uint32_t*>(wbase + NS * 512);          // [word][hp|hm][lane]
+  const uint32_t gwave = blockIdx.x * (blockDim.x >> 6) + wave;            // (1 .. 4 waves per workgroup)
+  if constexpr (GC) carry = P.carry_global + (size_t)gwave * P.nwords * 128u;
 
   uint32_t n_desc = *P.desc_count;
   if (n_desc > P.desc_cap) n_desc = P.desc_cap;
-  const uint32_t wave_first = (blockIdx.x * (blockDim.x >> 6) + wave) * kWave;  // (1 .. 4 waves per workgroup)
-  if (wave_first >= n_desc) return;  // wave-uniform
   if (n_desc <= P.list_words_max) return;  // few chunks of a multi-word pattern: list_words_kernel runs them
-  const uint32_t di = wave_first + lane;
-  const bool has_chunk = di < n_desc;
-  ChunkDesc d;
-  d.own_lo = d.own_hi = d.flags = d.pad_ = 0;
-  if (has_chunk) d = P.desc[di];
-  list_lanes<PROFILE, NS>(P, mask_bytes, carry, lane, has_chunk, d, di);
+  const uint32_t wave_stride = GC ? gridDim.x * (blockDim.x >> 6) * kWave : 0u;
+  for (uint32_t wave_first = gwave * kWave; wave_first < n_desc; wave_first += wave_stride) {  // (wave-uniform)
+    const uint32_t di = wave_first + lane;
+    const bool has_chunk = di < n_desc;
+    ChunkDesc d;
+    d.own_lo = d.own_hi = d.flags = d.pad_ = 0;
+    if (has_chunk) d = P.desc[di];
+    list_lanes<PROFILE, NS, false, GC>(P, mask_bytes, carry, lane, has_chunk, d, di);
+    if constexpr (!GC) break;
+  }
 }
 
 // Rare paths of the fused filter_dna_kernel, out of line like mark_piece_ends (inlined they cost the streaming
@@ -2790,6 +2807,10 @@ static hipError_t launch_sb(const ScanParams& P, uint32_t grid, size_t smem, hip
 }
 template <int PROFILE, int NS>
 static hipError_t launch_one(const ScanParams& P, uint32_t grid, size_t smem, hipStream_t stream) {
+  if (P.carry_global) {  // (long patterns: half-line staging, the carries in global memory)
+    hipLaunchKernelGGL((scan_kernel<PROFILE, NS, 1, true>), dim3(grid), dim3(64u * (P.waves_per_group ? P.waves_per_group : 4u)), smem, stream, P);
+    return hipGetLastError();
+  }
   return P.stage_blocks == 1 ? launch_sb<PROFILE, NS, 1>(P, grid, smem, stream)
                              : launch_sb<PROFILE, NS, 2>(P, grid, smem, stream);
 }
@@ -2847,7 +2868,10 @@ static hipError_t launch_list_one(const ScanParams& P, uint32_t grid, size_t sme
   }
   // (grid = 0: the host leaves the lane-per-chunk kernel out -- the launch above takes every chunk list it expects, and a
   // list beyond list_words_max sends the search through here once more with list_words_max = 0)
-  if (grid) hipLaunchKernelGGL((list_kernel<PROFILE, NS>), dim3(grid), dim3(64u * (P.waves_per_group ? P.waves_per_group : 4u)), smem, stream, P);
+  if (grid && P.carry_global)
+    hipLaunchKernelGGL((list_kernel<PROFILE, NS, true>), dim3(grid), dim3(64u * (P.waves_per_group ? P.waves_per_group : 4u)), smem, stream, P);
+  else if (grid)
+    hipLaunchKernelGGL((list_kernel<PROFILE, NS>), dim3(grid), dim3(64u * (P.waves_per_group ? P.waves_per_group : 4u)), smem, stream, P);
   return hipGetLastError();
 }
 

@@ -1495,6 +1495,37 @@ def test_ascii_binary_patterns_and_very_long_patterns(sassy):
         assert_same(sl.search(pat, t, k), want, ("long", profile, m, k, pre))
 
 
+@pytest.mark.gpu
+def test_patterns_beyond_the_lds_carry_store(sassy):
+    """The reference's row loop has no cap (src/search.rs:1060-1061, 1100-1163).  Here the per-row carries of a lane live in
+    its wave's LDS -- 512 bytes per 32 rows -- which ends near 9 800 rows; longer patterns keep them in global memory
+    (scan_kernel / list_kernel <.., GC>).  With and without a prefilter, Dna / Iupac / Ascii, against the oracle."""
+    rng = random.Random(61)
+    for profile, m, k, pre in (("dna", 9_900, 40, -1), ("dna", 12_000, 60, 0), ("iupac", 12_500, 100, -1), ("iupac", 10_100, 30, 0),
+                               ("ascii", 11_000, 25, -1), ("dna", 20_000, 150, -1)):
+        abc = b"abcdefghijklmnopqrstuvwxyz " if profile == "ascii" else b"ACGT"
+        pat = rand_seq(rng, m, abc)
+        if profile == "iupac":
+            pb = bytearray(pat)
+            for at in rng.sample(range(m), 12):
+                pb[at] = rng.choice(b"NRYWSKM")
+            pat = bytes(pb)
+        nt = 3 * m + 30_000
+        t = bytearray(rand_seq(rng, nt, abc))
+        plain = bytes(rng.choice(b"ACGT") if c not in abc else c for c in pat) if profile == "iupac" else pat
+        for at, e in ((50, 0), (m + 10_000, k // 2), (2 * m + 20_000, k)):
+            ins = bytearray(mutate(rng, plain, e)) if profile != "ascii" else bytearray(plain)
+            if profile == "ascii":
+                for _ in range(e):
+                    ins[rng.randrange(len(ins))] = rng.choice(abc)
+            t[at:at + len(ins)] = ins
+        t = bytes(t[:nt])
+        sl = sassy.Searcher(profile, rc=False).set_prefilter(pre)
+        want = oracle.search(profile, pat, t, k)
+        assert len(want) >= 2, (profile, m, k)
+        assert_same(sl.search(pat, t, k), want, ("beyond LDS", profile, m, k, pre))
+
+
 # ------------------------------------------------------------------ device-resident text
 def test_device_generator_matches_cpu_twin(sassy):
     n = 1 << 20
