@@ -839,6 +839,9 @@ int sassy_hip_search_encoded(sassy_SearcherType* s, const sassy_hip_Encoded* e, 
       if (env_seeded >= 0) seeded = env_seeded != 0;
     }
     bool tiled_done = false;
+    // an overhang searcher: one pass where the batch path's kernels apply to this text as a batch of one
+    if (!std::isnan(s->alpha))
+      if (int rc = search_encoded_overhang(s, e, tptr, h_text, text_len, (uint32_t)k, all, wo, R, &tiled_done)) return rc;
     if (seeded) {
       if (int rc = search_encoded_seeded(s, e, tptr, h_text, text_len, (uint32_t)k, all, wo, R, &tiled_done, nullptr, nullptr,
                                          dirty_text)) return rc;

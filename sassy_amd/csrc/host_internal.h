@@ -966,6 +966,8 @@ int search_encoded_seeded(sassy_SearcherType* s, const sassy_hip_Encoded* e, con
                                  sassy_hip_Result* R, bool* done, const TextTable* tt = nullptr,
                                  const HostTexts* ht = nullptr, bool dirty_text = false, ManyDefer* defer = nullptr,
                                  const TiledPerText* ov = nullptr);
+int search_encoded_overhang(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr, const uint8_t* h_text,
+                            uint64_t text_len, uint32_t k, bool all, bool wo, sassy_hip_Result* R, bool* done);
 bool many_tiled_wanted(const sassy_SearcherType* s, const size_t* pattern_lens, size_t n_patterns, uint64_t total, size_t k);
 bool acgt_only(const uint8_t* p, size_t n);
 // scan_driver.hip

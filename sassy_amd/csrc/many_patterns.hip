@@ -1352,6 +1352,51 @@ static void overhang_column(const sassy_SearcherType* s, uint32_t m, uint32_t k,
   *cost0 = sum;
 }
 
+// search_encoded_patterns of an overhang searcher on ONE long text in one pass (the reference's v2 scan takes overhang in its
+// tiled loop: src/pattern_tiling/search.rs:222-323; here it used to be a kernel chain per pattern).  The text is a batch of one:
+// the seeded search lists the end positions (m + k, len] -- overhang cannot change them --, tiled_pertext_kernel's two edge
+// segments add [0, m + k] from the overhang column and (len, len + steps], the common tail applies the report rule and traces.
+// Needs what the batch path needs: an Iupac searcher, >= 4 patterns of <= 64 rows with seeds, a text of plain bases (the
+// seeded search reads Dna codes).  *done = false: not this shape -- the caller runs the patterns one by one.
+int search_encoded_overhang(sassy_SearcherType* s, const sassy_hip_Encoded* e, const uint8_t* tptr, const uint8_t* h_text,
+                            uint64_t text_len, uint32_t k, bool all, bool wo, sassy_hip_Result* R, bool* done) {
+  *done = false;
+  const size_t m = e->plen;
+  if (std::isnan(s->alpha) || s->profile != PROFILE_IUPAC || e->patterns.size() < 4 || e->patterns.size() >= (1u << 24) || m > 64 ||
+      2 * k + 3 > 64 || k >= m)
+    return 0;
+  if (s->sw.overhang_tiled == 0 || s->sw.overhang_seeded == 0 || !(seeded_hit_rate(m, k) > 0)) return 0;
+  if (text_len <= m + k + 64 || text_len >= (1ull << 36) || ((uintptr_t)tptr & 15) != 0) return 0;
+  if (int rc = s->d_ncount.reserve(4)) return rc;
+  if (int rc = s->d_tables.reserve(2)) return rc;
+  const uint64_t tab[2] = {0, text_len};
+  HIP_TRY(hipMemsetAsync(s->d_ncount.p, 0, 4, s->stream));
+  HIP_TRY(hipMemcpyAsync(s->d_tables.p, tab, sizeof tab, hipMemcpyHostToDevice, s->stream));
+  hipError_t le = launch_acgt_check(tptr, text_len, s->d_ncount.p, s->stream);
+  if (le != hipSuccess) return hip_fail(le, "text check kernel launch");
+  uint32_t bad = 1;
+  HIP_TRY(hipMemcpyAsync(&bad, s->d_ncount.p, 4, hipMemcpyDeviceToHost, s->stream));
+  HIP_TRY(hipStreamSynchronize(s->stream));
+  if (bad) return 0;
+  uint32_t ov_exact = 0;
+  unsigned long long ov_vp = 0;
+  int32_t ov_cost0 = 0;
+  overhang_column(s, (uint32_t)m, k, &ov_exact, &ov_vp, &ov_cost0);
+  const uint64_t* d_tab = s->d_tables.p;
+  TextTable tt{d_tab, d_tab + 1, 1u, all ? 1u : 0u, 0u, ov_exact};
+  HostTexts ht;
+  ht.start.push_back(0);
+  ht.len.push_back(text_len);
+  const TiledPerText edges{d_tab, d_tab + 1, 1u, ov_exact, s->alpha, ov_vp, ov_cost0, (uint32_t)(m + k)};
+  const size_t first = R->matches.size(), pool_first = R->pool.size();
+  if (int rc = search_encoded_seeded(s, e, tptr, h_text, text_len, k, all, wo, R, done, &tt, &ht, false, nullptr, &edges)) return rc;
+  if (!*done) {
+    R->matches.resize(first);
+    R->pool.resize(pool_first);
+  }
+  return 0;
+}
+
 int search_many_pertext(sassy_SearcherType* s, const uint8_t* const* patterns, const size_t* pattern_lens,
                                size_t n_patterns, const uint8_t* const* texts, const size_t* text_lens, size_t n_texts,
                                size_t k, uint32_t flags, sassy_hip_Result* R, bool& handled) {

@@ -262,8 +262,10 @@ __global__ __launch_bounds__(256) void tiled_pertext_kernel(const TiledParams P)
       }
       S.vn = 0;
       for (uint64_t yb = c0 & ~63ull; yb < c1; yb += 64) {
-        // (the slot is a whole number of blocks that covers len + ov_steps + 2 characters: the load stays inside it)
-        const uint32_t ch = P.text_aligned[start + yb + lane];
+        // (a batch slot is a whole number of blocks that covers len + ov_steps + 2 characters; a single text -- search_encoded
+        // with overhang -- ends where its buffer ends: nothing is read behind text_len, the virtual columns are made below)
+        const uint64_t at = start + yb + lane;
+        const uint32_t ch = at < P.text_len ? P.text_aligned[at] : (uint32_t)'N';
         uint32_t off;
         if (P.classes == 4) off = ((ch >> 1) & 3u) << kShift;
         else off = (uint32_t)kTiledIupacNib[ch & 31u] << kShift;

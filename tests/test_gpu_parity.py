@@ -800,6 +800,70 @@ def test_overhang_many_patterns_in_one_pass(sassy):
         assert sorted((x.pattern_idx, x.text_idx) + key(x)[1:] for x in got) == sorted(want), e["id"]
 
 
+@pytest.mark.gpu
+def test_overhang_encoded_patterns_on_one_long_text(sassy):
+    """search_encoded_patterns of an overhang searcher on ONE long text: one pass (the text as a batch of one: the seeded search
+    for the inside, tiled_pertext_kernel's edge segments for [0, m + k] and the virtual columns; the reference's v2 scan takes
+    overhang in its tiled loop, src/pattern_tiling/search.rs:222-323) -- against oracle.search_overhang pattern by pattern
+    (forward searchers) and against the chain-per-pattern path (switch overhang_seeded = 0; both strands too).  Patterns
+    hanging over the text's start and end, planted inside, host and device-resident texts of odd lengths."""
+    rng = random.Random(717)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for it in range(8):
+        m = rng.choice([20, 24, 32])
+        k = rng.randrange(1, 4)
+        alpha = rng.choice([0.25, 0.5, 0.5, 1.0])
+        mo = rng.choice([None, None, 5])
+        npat = rng.choice([4, 9, 70])
+        pats = []
+        for _ in range(npat):
+            p_ = bytearray(rand_seq(rng, m))
+            if rng.random() < 0.2:
+                p_[rng.randrange(m)] = rng.choice(b"NRYW")
+            pats.append(bytes(p_))
+        n = rng.choice([3_001, 70_001, 200_003])
+        text = bytearray(rand_seq(rng, n))
+        for _ in range(12):
+            plain = bytes(c if c in b"ACGT" else 65 for c in rng.choice(pats))
+            if rng.random() < 0.4:
+                plain = plain.translate(comp)[::-1]
+            ins = mutate(rng, plain, rng.randrange(0, k + 1))
+            at = rng.randrange(2 * m, n - 3 * m)
+            text[at:at + len(ins)] = ins
+        for side in (0, 1):  # a pattern hanging over the text's start / end
+            plain = bytes(c if c in b"ACGT" else 65 for c in rng.choice(pats))
+            cut = rng.randrange(2, m - 2)
+            if side == 0:
+                head = mutate(rng, plain, rng.randrange(0, 2))[cut:]
+                text[:len(head)] = head
+            else:
+                tail = mutate(rng, plain, rng.randrange(0, 2))[:cut]
+                text[n - len(tail):] = tail
+        text = bytes(text[:n])
+        rc, allm = bool(it & 1), it % 4 == 3
+        keyp = lambda x: (x.pattern_idx,) + key(x)[1:]
+        s = sassy.Searcher("iupac", rc=rc, alpha=alpha).with_max_overhang(mo)
+        enc = s.encode_patterns(pats)
+        if it % 3 == 2:  # device-resident, the buffer as long as the text
+            buf = sassy.DeviceBuffer(n)
+            buf.upload(text)
+            got = s.search_encoded_patterns(enc, _DevText(buf.ptr, n), k, all_minima=allm)
+        else:
+            got = s.search_encoded_patterns(enc, text, k, all_minima=allm)
+        assert s.stats()["filtered"] == 6, s.stats()  # the one pass took it
+        s0 = sassy.Searcher("iupac", rc=rc, alpha=alpha).with_max_overhang(mo)
+        s0.set_option("overhang_seeded", 0)
+        got0 = s0.search_encoded_patterns(s0.encode_patterns(pats), text, k, all_minima=allm)
+        assert s0.stats()["filtered"] != 6
+        assert sorted(keyp(x) for x in got) == sorted(keyp(x) for x in got0), (it, m, k, alpha, mo, npat, n, rc, allm, len(got), len(got0))
+        if not rc:
+            want = []
+            for pi, p_ in enumerate(pats):
+                for x in oracle.search_overhang("iupac", p_, text, k, alpha, all_minima=allm, max_overhang=mo):
+                    want.append((pi,) + key(x)[1:])
+            assert sorted(keyp(x) for x in got) == sorted(want), (it, m, k, alpha, mo, npat, n, allm, len(got), len(want))
+
+
 def kats_overhang():
     import json
     root = os.path.dirname(os.path.abspath(__file__))

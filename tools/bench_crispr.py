@@ -25,6 +25,10 @@ def main():
     ap.add_argument("--genome-like", action="store_true",
                     help="repeat-rich text with runs of N and scattered IUPAC letters (generate_genome_like) instead of "
                          "i.i.d. ACGT: the seeded search runs with the pattern-tiled scan around the other letters")
+    ap.add_argument("--overhang", type=float, default=None,
+                    help="an overhang searcher (alpha): the one pass over the text as a batch of one, beside the chain per pattern "
+                         "(switch overhang_seeded = 0) on the first --chain-guides guides")
+    ap.add_argument("--chain-guides", type=int, default=16)
     args = ap.parse_args()
     rng = random.Random(11)
     n = args.text_bytes
@@ -34,6 +38,25 @@ def main():
     else:
         sassy_amd.generate_dna(buf.ptr, n, 42, 0)
     pats = [bytes(rng.choice(b"ACGT") for _ in range(20)) + b"NGG" for _ in range(args.guides)]
+    if args.overhang is not None:
+        for rc in (False, True):
+            for one_pass in (True, False):
+                sub = pats if one_pass else pats[:args.chain_guides]
+                s = sassy_amd.Searcher("iupac", rc=rc, alpha=args.overhang)
+                if not one_pass:
+                    s.set_option("overhang_seeded", 0)
+                enc = s.encode_patterns(sub)
+                secs = []
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    r = s.search_encoded_patterns(enc, DevText(buf.ptr, n), args.k, as_result=True)
+                    secs.append(time.perf_counter() - t0)
+                print(json.dumps({"workload": f"{len(sub)} guides (20 bases + NGG), k={args.k}, Iupac searcher with overhang {args.overhang}, "
+                                              f"{'both strands' if rc else 'forward strand'}, {n} B random ACGT resident in HBM",
+                                  "path": "one pass (seeded search + edge segments)" if one_pass else "a kernel chain per pattern",
+                                  "seconds": round(min(secs), 4), "seconds_per_guide": round(min(secs) / len(sub), 6), "matches": len(r),
+                                  "filtered": s.stats()["filtered"]}), flush=True)
+        return
     for rc in (False, True):
         s = sassy_amd.Searcher("iupac", rc=rc)
         enc = s.encode_patterns(pats)

@@ -80,6 +80,7 @@ python tools/bench_encoded.py > $OUT/${TAG}_encoded_paths.txt 2> $OUT/encoded.er
     echo "## $what"; python tools/timeline_all.py gpurun_out/tl_$$ --gap-ms 15 | awk '{d=$5+0; if (NR==1 || d > 300) print}' | cut -c1-150; rm -rf gpurun_out/tl_$$; done; } > $OUT/${TAG}_many_pattern_timelines.txt 2>&1
 python tools/bench_crispr.py > $OUT/${TAG}_crispr.json 2> $OUT/crispr.err
 python tools/bench_crispr.py --genome-like >> $OUT/${TAG}_crispr.json 2>> $OUT/crispr.err
+python tools/bench_crispr.py --overhang 0.5 > $OUT/${TAG}_overhang_one_text.json 2>> $OUT/crispr.err
 python tools/bench_texts.py > $OUT/${TAG}_texts.json 2> $OUT/texts.err
 # ---- kernel timelines of lone searches on the texts that are not i.i.d. (dense plants, N runs under Iupac, poly-A, microsatellite)
 { echo "# lone searches of tools/bench_texts.py cases under rocprofv3 --kernel-trace (tools/prof_texts.sh): the last dispatches in time order, then totals";
