@@ -615,7 +615,7 @@ void orc_generate_dna(uint64_t seed, uint64_t first, uint64_t n, uint8_t *out) {
  *   r = orc_hash(seed ^ "plant", 64*q + t); type = r % 3 (0 sub, 1 ins, 2 del);
  *   pos = (r >> 8) % len; base = (r >> 40) & 3.
  * The product library restates this on the host side of its device generator
- * (sassy_amd/csrc/synth.cpp); tests compare the two byte for byte. */
+ * (sassy_amd/csrc/c_abi.hip: sassy_hip_generate_dna / sassy_hip_plant); tests compare the two byte for byte. */
 #define ORC_PLANT_SALT 0x706c616e74ULL
 size_t orc_make_plant(uint64_t seed, uint64_t q, const uint8_t *pat, size_t m, int edits,
                       uint8_t *out) {

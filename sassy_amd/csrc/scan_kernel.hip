@@ -72,7 +72,12 @@ __device__ __forceinline__ uint64_t lshl_add_u64(uint64_t a, uint64_t b) {
   asm("v_lshl_add_u64 %0, %1, %3, %2" : "=&v"(r) : "v"(a), "v"(b), "n"(SH));
   return r;
 }
-__device__ __forceinline__ uint64_t pair64(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
+// (a register pair, not arithmetic: `(hi << 32) | lo` left a v_and_or x, 1, 0 behind every carry bit)
+typedef uint32_t u32pair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint64_t pair64(uint32_t lo, uint32_t hi) {
+  const u32pair v = {lo, hi};
+  return __builtin_bit_cast(uint64_t, v);
+}
 
 // zz: two registers holding 0, one per carry (each sits behind its carry bit in a 64-bit register pair; two, so
 // that neither has to be copied into place row after row).
@@ -620,7 +625,7 @@ __device__ __forceinline__ uint32_t dp_word(DpWord& V, const unsigned char* my_m
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
-      dp_row(V, eqc[u], (ohp >> (31 - (4 * g + u))) & 1u, (ohm >> (31 - (4 * g + u))) & 1u, nhp, nhm, zz);
+      dp_row(V, eqc[u], __builtin_amdgcn_ubfe(ohp, 31u - (4 * g + u), 1u), __builtin_amdgcn_ubfe(ohm, 31u - (4 * g + u), 1u), nhp, nhm, zz);
     done = 4u * g + 4u;
     if constexpr (CUT) {
       if (done >= cut->first_test && (done < rows || cut->more_words)) {  // wave-uniform
