@@ -385,6 +385,7 @@ struct TraceParams {
   // text of report c is report_text[c]
   const uint32_t* report_text;
 };
+constexpr uint32_t kTraceWaveDummy = 128;  // trace_wave_kernel: bytes at the end of a wave's slice that nothing reads
 // MatchOut::pad_[0] of a record whose traceback found no ancestor / exceeded the scanned cost
 constexpr uint8_t kTraceFailed = 1;
 

@@ -61,7 +61,7 @@ static int finish_pattern_list(sassy_SearcherType* s, const sassy_hip_Encoded* e
     const uint64_t win = ((uint64_t)m + k + 15 + 15) / 16 * 16;
     const uint64_t opsb = ((uint64_t)m + k + 1 + 3) / 4 * 4;
     const uint64_t strb = ((2ull * (m + k + 1) + 2 + 15) / 16 * 16);
-    const uint64_t wstride = (band + win + opsb + strb + 15) / 16 * 16;
+    const uint64_t wstride = (band + win + opsb + strb + kTraceWaveDummy + 15) / 16 * 16;
     str_stride = (uint32_t)strb;
     if ((uint64_t)n_rep * strb > 0xFFFFFFFFull)
       return fail(SASSY_HIP_EUNSUPPORTED, "cigar pool of one result exceeds 4 GiB");

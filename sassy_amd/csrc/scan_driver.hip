@@ -494,7 +494,8 @@ int ScanJob::prepare() {
     const uint64_t raw = band + win + opsb + strb;
     const uint64_t pat_bytes = ((uint64_t)plan.m + 15) / 16 * 16;
     const int env_wave = (int)sw.trace_wave;
-    const uint64_t wstride = (raw + 15) / 16 * 16;
+    // (+ 128: a byte pair per lane behind the slice -- the band rows' lanes outside the band store there, unmasked)
+    const uint64_t wstride = (raw + kTraceWaveDummy + 15) / 16 * 16;
     use_wave = env_wave != 0 && 2ull * k + 3 <= 64 && 4 * pat_bytes + 4 * wstride <= 160 * 1024;
     use_thread = !use_wave || (k <= 6 && !overhang);  // overhang: wave shape or the generic thread shape
     uint64_t stride = raw;

@@ -78,22 +78,27 @@ __device__ __forceinline__ uint64_t pair64(uint32_t lo, uint32_t hi) {
   const u32pair v = {lo, hi};
   return __builtin_bit_cast(uint64_t, v);
 }
+// (the arithmetic form: list_rows_kernel, whose carry bits come out of one DPP register, is 5 us faster with it -- one wave per
+// SIMD, every instruction of the chain counts, and the register pair costs it two copies per row)
+__device__ __forceinline__ uint64_t pair64_or(uint32_t lo, uint32_t hi) { return ((uint64_t)hi << 32) | lo; }
 
 // zz: two registers holding 0, one per carry (each sits behind its carry bit in a 64-bit register pair; two, so
 // that neither has to be copied into place row after row).
+template <bool CARRY_PAIRS = true>
 __device__ __forceinline__ void dp_row(DpWord& V, uint2 eq, uint32_t hp0, uint32_t hm0,
                                        uint32_t& nhp, uint32_t& nhm, uint2 zz = make_uint2(0u, 0u)) {
+  auto mk = [](uint32_t lo, uint32_t hi) -> uint64_t { return CARRY_PAIRS ? pair64(lo, hi) : pair64_or(lo, hi); };
   const uint32_t vxl = eq.x | V.vml, vxh = eq.y | V.vmh;
   const uint32_t e2l = eq.x | hm0, e2h = eq.y;
-  const uint64_t sum = lshl_add_u64<0>(pair64(e2l & V.vpl, e2h & V.vph), pair64(V.vpl, V.vph));
+  const uint64_t sum = lshl_add_u64<0>(mk(e2l & V.vpl, e2h & V.vph), mk(V.vpl, V.vph));
   const uint32_t hxl = bitop3<0xBE>(lo32(sum), V.vpl, e2l);  // (a ^ b) | c
   const uint32_t hxh = bitop3<0xBE>(hi32(sum), V.vph, e2h);
   const uint32_t Hpl = bitop3<0xF1>(V.vml, hxl, V.vpl), Hph = bitop3<0xF1>(V.vmh, hxh, V.vph);  // a | ~(b | c)
   const uint32_t Hml = V.vpl & hxl, Hmh = V.vph & hxh;
   nhp = __builtin_amdgcn_alignbit(nhp, Hph, 31);  // (nhp << 1) | (Hph >> 31)
   nhm = __builtin_amdgcn_alignbit(nhm, Hmh, 31);
-  const uint64_t Hp2 = lshl_add_u64<1>(pair64(Hpl, Hph), pair64(hp0, zz.x));
-  const uint64_t Hm2 = lshl_add_u64<1>(pair64(Hml, Hmh), pair64(hm0, zz.y));
+  const uint64_t Hp2 = lshl_add_u64<1>(mk(Hpl, Hph), mk(hp0, zz.x));
+  const uint64_t Hm2 = lshl_add_u64<1>(mk(Hml, Hmh), mk(hm0, zz.y));
   V.vpl = bitop3<0xF1>(lo32(Hm2), vxl, lo32(Hp2));
   V.vph = bitop3<0xF1>(hi32(Hm2), vxh, hi32(Hp2));
   V.vml = lo32(Hp2) & vxl;
@@ -2731,7 +2736,7 @@ __global__ __launch_bounds__(256) void list_rows_kernel(const ScanParams P) {
       ++rp;
       if (active) {
         uint32_t nhp = 0, nhm = 0;
-        dp_row(V, eq, cin & 1u, cin >> 1, nhp, nhm, zz);
+        dp_row<false>(V, eq, cin & 1u, cin >> 1, nhp, nhm, zz);
         cout = nhp | (nhm << 1);
         if (any_more) {  // wave-uniform
           if (more && li == G - 1u) carry[r] = (unsigned char)cout;

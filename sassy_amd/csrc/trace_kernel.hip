@@ -580,36 +580,100 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
         prev = v;
       }
     } else {
-      // Branch-free rows.  The reports of a call run side by side (about three waves per SIMD), so a row costs what
-      // it issues: its two LDS reads are requested one row ahead, the band column's first / last row inside the
-      // window are per-lane constants, and a band of <= 16 columns (k <= 6) scans within one 16-lane row.
-      const int lo_j = -(dlo + b);      // the row in which this band column is window column 0
-      const int hi_j = iend - dlo - b;  // the last row in which it lies inside the window
-      const bool narrow = bw <= 16;     // wave-uniform
+      // The reports of a call run side by side (three or four waves per SIMD), so a row costs what it issues.  Round 6:
+      // the row in the "minus b" domain (q = value - b: what the prefix minimum works on anyway, so nothing is subtracted
+      // before the scan or added after it), the compare of the profile and the width of the scan chosen once per report
+      // (wave-uniform; four copies of the loop) instead of per row, one unsigned compare for "inside the window", the
+      // window's first column a scalar: 33 -> 24 VALU per row and no branches.
+      const int lo_j = -(dlo + b);                                     // the row in which this band column is window column 0
+      const int n_valid = in_band ? iend - dlo - b - lo_j + 1 : 0;     // rows lo_j .. lo_j + n_valid - 1 lie inside the window
+      const uint32_t cnt = n_valid > 0 ? (uint32_t)n_valid : 0u;
+      constexpr int kBig = 0x3FFFFFFF;
+      constexpr int kId = 0x7FFFFFFF;  // (the scan's identity must be INT_MAX: only then is a step ONE v_min_i32_dpp)
+      const int infq = inf - b;
       // the text byte under cell (j, i) is win[i - 1] = wp[j - 1].  No clamping: a cell outside the window reads some
       // other byte of the wave's own slice (the band lies in front of the window, ops and text behind it, and
       // |dlo + b| stays below either size) and is overwritten.
       const unsigned char* wp = win + (dlo + b);
-      uint32_t pcn = spat[0], tcn = wp[0];
-#pragma unroll 2
-      for (int j = 1; j <= m; ++j) {
-        const uint32_t pc = pcn, tc = tcn;
-        if (j < m) {
-          pcn = spat[j];
-          tcn = wp[j];
+      const int dlo_u = __builtin_amdgcn_readfirstlane(dlo);  // (the report is the wave's: the compiler cannot know)
+      auto rows = [&](auto iupac_tag, auto width_tag) {
+        constexpr bool IUPAC = decltype(iupac_tag)::value;
+        constexpr int WIDTH = decltype(width_tag)::value;  // lanes the band may reach: 16 / 32 / 64
+        int prevq = prev - b;
+        // lanes outside the band store into a cell of their own at the end of the slice (kTraceWaveDummy bytes nothing
+        // reads) with stride 0: the store needs no exec mask, the row no scalar branch (29.8 -> 24.2 us of fill per report
+        // at m = 200)
+        Cell* Lrow = in_band ? L + bw + b : reinterpret_cast<Cell*>(slice + P.scratch_stride - kTraceWaveDummy) + lane;
+        const int Lstride = in_band ? bw : 0;
+        // MID: a row in which every band column lies inside the window and behind its first column -- no "inside the
+        // window" test, no first-column value; the lanes outside the band are held at infq by the clamp's lower bound
+        const int loq = in_band ? -kBig : infq;
+        auto row = [&](int j, uint32_t pc, uint32_t tc, auto mid_tag) {
+          constexpr bool MID = decltype(mid_tag)::value;
+          // upper neighbour (j-1, i) = band column b+1 of the previous row: prevq of lane b+1, + 1 for the column, + 1 for the step
+          // (lane 63 has no lane 64 to read: it gets 0 -- the band is 2k + 3 <= 63 columns, lane 63 is never inside it)
+          const int uq = __builtin_amdgcn_update_dpp(0, prevq, 0x130, 0xF, 0xF, true) + 2;  // wave_shl:1
+          int dgq;
+          if constexpr (IUPAC) dgq = prevq + ((pc & tc) == 0u ? 1 : 0);  // (pattern letters are base sets <= 15: no mask)
+          else dgq = prevq + (((pc ^ tc) & rule.emask) != 0u ? 1 : 0);
+          int xq = dgq < uq ? dgq : uq;
+          bool valid = true;
+          if constexpr (!MID) {
+            const uint32_t d = (uint32_t)(j - lo_j);
+            const int firstq = (j < inf ? j : inf) + dlo_u + j;  // D[j][0] = j (capped) minus the band column that holds it: a scalar
+            xq = d == 0u ? firstq : xq;
+            valid = d < cnt;
+            xq = valid ? xq : kBig;
+          }
+          xq = min(xq, __builtin_amdgcn_update_dpp(kId, xq, 0x111, 0xF, 0xF, false));  // row_shr:1
+          xq = min(xq, __builtin_amdgcn_update_dpp(kId, xq, 0x112, 0xF, 0xF, false));  // row_shr:2
+          xq = min(xq, __builtin_amdgcn_update_dpp(kId, xq, 0x114, 0xF, 0xF, false));  // row_shr:4
+          xq = min(xq, __builtin_amdgcn_update_dpp(kId, xq, 0x118, 0xF, 0xF, false));  // row_shr:8
+          if constexpr (WIDTH > 16) xq = min(xq, __builtin_amdgcn_update_dpp(kId, xq, 0x142, 0xA, 0xF, false));  // row_bcast:15
+          if constexpr (WIDTH > 32) xq = min(xq, __builtin_amdgcn_update_dpp(kId, xq, 0x143, 0xC, 0xF, false));  // row_bcast:31
+          int vq;
+          if constexpr (MID) {
+            vq = max(min(xq, infq), loq);  // (one v_med3_i32) min(xq, infq) inside the band, infq outside
+          } else {
+            xq = xq < infq ? xq : infq;
+            vq = valid ? xq : infq;
+          }
+          *Lrow = (Cell)(vq + b);
+          Lrow += Lstride;
+          prevq = vq;
+        };
+        // rows j0 .. j1, two per iteration, each with its own pair of prefetch registers (loaded a row ahead; a read behind
+        // the pattern's last row or the window stays inside the wave's slices and is not used)
+        auto run = [&](int j0, int j1, auto mid_tag) {
+          if (j0 > j1) return;
+          uint32_t pa = spat[j0 - 1], ta = wp[j0 - 1];
+          int j = j0;
+          for (; j < j1; j += 2) {
+            const uint32_t pb = spat[j], tb = wp[j];
+            row(j, pa, ta, mid_tag);
+            pa = spat[j + 1];
+            ta = wp[j + 1];
+            row(j + 1, pb, tb, mid_tag);
+          }
+          if (j == j1) row(j, pa, ta, mid_tag);
+        };
+        // middle rows: 1 <= j + dlo (every band column behind the window's first column) and j + dlo + bw - 1 <= iend
+        const int iend_u = __builtin_amdgcn_readfirstlane(iend);
+        int mid0 = 1 - dlo_u, mid1 = iend_u - dlo_u - bw + 1;
+        mid0 = mid0 < 1 ? 1 : mid0;
+        mid1 = mid1 > m ? m : mid1;
+        if (mid0 > mid1) {  // (a window shorter than the band is wide)
+          run(1, m, std::false_type{});
+        } else {
+          run(1, mid0 - 1, std::false_type{});
+          run(mid0, mid1, std::true_type{});
+          run(mid1 + 1, m, std::false_type{});
         }
-        const int up = __builtin_amdgcn_update_dpp(inf, prev, 0x130, 0xF, 0xF, false);  // wave_shl:1
-        const bool valid = in_band && j >= lo_j && j <= hi_j;
-        const int dg = prev + (rule_hit(rule, pc, tc, rule.emask) ? 0 : 1);
-        const int u = up + 1;
-        int t = dg < u ? dg : u;
-        t = j == lo_j ? (j < inf ? j : inf) : t;
-        const int x = valid ? t - b : 0x3FFFFFFF;
-        int v = (narrow ? dpp_min_scan16(x) : dpp_min_scan(x)) + b;
-        v = (valid && v < inf) ? v : inf;
-        if (in_band) L[(size_t)j * bw + b] = (Cell)v;
-        prev = v;
-      }
+      };
+      const bool iu = rule.iupac != 0u;  // wave-uniform, like bw
+      if (bw <= 16) { if (iu) rows(std::true_type{}, std::integral_constant<int, 16>{}); else rows(std::false_type{}, std::integral_constant<int, 16>{}); }
+      else if (bw <= 32) { if (iu) rows(std::true_type{}, std::integral_constant<int, 32>{}); else rows(std::false_type{}, std::integral_constant<int, 32>{}); }
+      else { if (iu) rows(std::true_type{}, std::integral_constant<int, 64>{}); else rows(std::false_type{}, std::integral_constant<int, 64>{}); }
     }
     // make the band and the window visible to every lane (same wave: LDS ops are in order, this
     // only keeps the compiler from reordering)
