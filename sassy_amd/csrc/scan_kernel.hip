@@ -2718,28 +2718,34 @@ __global__ __launch_bounds__(256) void list_rows_kernel(const ScanParams P) {
     uint32_t slot_n = rp[1];                       // row 1 - li (for step 1)
     uint2 eq_n = *reinterpret_cast<const uint2*>(my_masks + ((uint32_t)rp[0] << 8));  // row -li (step 0)
     // one row step.  CHECK: the lane may be outside its rows (ramp-up / tail); TAIL: blocks are being finished
-    auto step = [&](uint32_t t, auto check_tag, auto tail_tag) {
-      constexpr bool CHECK = decltype(check_tag)::value, TAIL = decltype(tail_tag)::value;
+    // PLAIN: a chunk's only pass, no carries through LDS (the steady rows of nearly every chunk); eq_use / eq_load: the two
+    // Eq registers change roles step by step (two steps per iteration of the steady loop: no copies)
+    auto step = [&](uint32_t t, auto check_tag, auto tail_tag, auto plain_tag, uint2& eq_use, uint2& eq_load) {
+      constexpr bool CHECK = decltype(check_tag)::value, TAIL = decltype(tail_tag)::value, PLAIN = decltype(plain_tag)::value;
       // the carry bits the lane on the left produced one step ago (a group's first lane: a fresh start -- every
       // left-edge delta is +1 -- or, in a later pass, what the previous pass's last lane left for this row)
       uint32_t cin = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cout, 0x138, 0xF, 0xF, false);  // wave_shr:1
-      cin = (cin & keep_dpp) | (later_pass ? 0u : first_lane);
+      cin = (cin & keep_dpp) | ((!PLAIN && later_pass) ? 0u : first_lane);
       const int r = (int)t - (int)li;
       bool active = has_blk;
       if constexpr (CHECK) active = has_blk && (uint32_t)r < m;
-      if (later_pass) {  // wave-uniform
-        if (li == 0u && active) cin = carry[r];
+      if constexpr (!PLAIN) {
+        if (later_pass) {  // wave-uniform
+          if (li == 0u && active) cin = carry[r];
+        }
       }
-      const uint2 eq = eq_n;
-      eq_n = *reinterpret_cast<const uint2*>(my_masks + (slot_n << 8));
+      const uint2 eq = eq_use;
+      eq_load = *reinterpret_cast<const uint2*>(my_masks + (slot_n << 8));
       slot_n = rp[2];
       ++rp;
       if (active) {
         uint32_t nhp = 0, nhm = 0;
         dp_row<false>(V, eq, cin & 1u, cin >> 1, nhp, nhm, zz);
         cout = nhp | (nhm << 1);
-        if (any_more) {  // wave-uniform
-          if (more && li == G - 1u) carry[r] = (unsigned char)cout;
+        if constexpr (!PLAIN) {
+          if (any_more) {  // wave-uniform
+            if (more && li == G - 1u) carry[r] = (unsigned char)cout;
+          }
         }
       }
       if constexpr (TAIL) {
@@ -2755,13 +2761,31 @@ __global__ __launch_bounds__(256) void list_rows_kernel(const ScanParams P) {
     uint32_t t = 0;
     // ramp-up until every lane with a block is inside its rows (t = span - 1) or the first block is done (t = m - 1)
     const uint32_t t_steady = min(span > 0u ? span - 1u : 0u, m - 1u), t_tail = m - 1u;
-    for (; t < t_steady; ++t) step(t, std::true_type{}, std::false_type{});   // ramp-up
+    uint2 eq_o = make_uint2(0u, 0u);  // (the other Eq register: even steps use eq_n and load eq_o, odd steps the other way)
+    auto step1 = [&](uint32_t tt, auto check_tag, auto tail_tag, auto plain_tag) {  // (tt is wave-uniform)
+      if (tt & 1u) step(tt, check_tag, tail_tag, plain_tag, eq_o, eq_n);
+      else step(tt, check_tag, tail_tag, plain_tag, eq_n, eq_o);
+    };
+    for (; t < t_steady; ++t) step1(t, std::true_type{}, std::false_type{}, std::false_type{});   // ramp-up
     if (has_blk) {                                                             // every lane with a block is inside its rows
-      for (uint32_t t2 = t; t2 < t_tail; ++t2) step(t2, std::false_type{}, std::false_type{});
+      uint32_t t2 = t;
+      if ((t2 & 1u) && t2 < t_tail) { step1(t2, std::false_type{}, std::false_type{}, std::false_type{}); ++t2; }  // (t2 even from here)
+      if (!later_pass && !any_more) {
+        for (; t2 + 1u < t_tail; t2 += 2u) {
+          step(t2, std::false_type{}, std::false_type{}, std::true_type{}, eq_n, eq_o);
+          step(t2 + 1u, std::false_type{}, std::false_type{}, std::true_type{}, eq_o, eq_n);
+        }
+      } else {
+        for (; t2 + 1u < t_tail; t2 += 2u) {
+          step(t2, std::false_type{}, std::false_type{}, std::false_type{}, eq_n, eq_o);
+          step(t2 + 1u, std::false_type{}, std::false_type{}, std::false_type{}, eq_o, eq_n);
+        }
+      }
+      for (; t2 < t_tail; ++t2) step1(t2, std::false_type{}, std::false_type{}, std::false_type{});
     } else {
       rp += t_tail - t;
     }
-    for (t = t_tail; t < nsteps; ++t) step(t, std::true_type{}, std::true_type{});  // blocks are finished, one per step
+    for (t = t_tail; t < nsteps; ++t) step1(t, std::true_type{}, std::true_type{}, std::false_type{});  // blocks are finished, one per step
     // ---- the pass's reports.  Every lane still holds its block's last row (V, ds_blk).  The report rule of a block
     // needs the plateau state behind the block on its left; that block is usually not live (state: dec = true, settled), so
     // all live lanes decide at once on that assumption, and a lane whose left neighbour turned out otherwise decides again

@@ -427,7 +427,14 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
   unsigned long long* lpos = reinterpret_cast<unsigned long long*>(trace_smem + 4u * pat_bytes + 4u * (size_t)P.scratch_stride);
   const bool pos_in_lds = P.unsorted != nullptr && P.rank_lds != 0 && count <= P.rank_lds;
   if (pos_in_lds) {
-    for (uint32_t x = threadIdx.x; x < count; x += 256u) lpos[x] = P.unsorted[x].pos;
+    // (four loads in flight per thread: a dozen dependent round trips to L2 were 2 us of every report's prologue)
+    uint32_t x = threadIdx.x;
+    for (; x + 768u < count; x += 1024u) {
+      const unsigned long long p0 = P.unsorted[x].pos, p1 = P.unsorted[x + 256u].pos, p2 = P.unsorted[x + 512u].pos,
+                               p3 = P.unsorted[x + 768u].pos;
+      lpos[x] = p0; lpos[x + 256u] = p1; lpos[x + 512u] = p2; lpos[x + 768u] = p3;
+    }
+    for (; x < count; x += 256u) lpos[x] = P.unsorted[x].pos;
     __syncthreads();
   }
 
@@ -480,7 +487,15 @@ __global__ __launch_bounds__(256) void trace_wave_kernel(const TraceParams P) {
           twin_uncond |= o.pos == cd.pos && v != u && !(o.flags & kCandCond);
         }
       if (pos_in_lds) {
-        for (uint32_t v = lane; v < count; v += 64) {
+        uint32_t v = lane;
+        for (; v + 192 < count; v += 256) {  // (four LDS reads in flight)
+          const unsigned long long p0 = lpos[v], p1 = lpos[v + 64], p2 = lpos[v + 128], p3 = lpos[v + 192];
+          r += (p0 < cd.pos ? 1u : 0u) + (p1 < cd.pos ? 1u : 0u) + (p2 < cd.pos ? 1u : 0u) + (p3 < cd.pos ? 1u : 0u);
+          if (P.dedup)
+            r += ((p0 == cd.pos && v < u) ? 0x10000u : 0u) + ((p1 == cd.pos && v + 64 < u) ? 0x10000u : 0u) +
+                 ((p2 == cd.pos && v + 128 < u) ? 0x10000u : 0u) + ((p3 == cd.pos && v + 192 < u) ? 0x10000u : 0u);
+        }
+        for (; v < count; v += 64) {
           const unsigned long long p0 = lpos[v];
           r += p0 < cd.pos ? 1u : 0u;
           if (P.dedup) r += (p0 == cd.pos && v < u) ? 0x10000u : 0u;
