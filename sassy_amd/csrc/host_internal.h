@@ -272,6 +272,12 @@ struct ScanLane {
   bool own_stream = false;
   hipEvent_t ev_a = nullptr, ev_b = nullptr, ev_c = nullptr, ev_f = nullptr, ev_filter_done = nullptr;
   DevBuf<uint8_t> d_state, d_scratch, d_str, d_ctl, d_sort, d_scratch2;
+  // The control block has a twin: a search clears the OTHER one behind its last kernel (64 bytes, while the host is busy
+  // with this search's result), so the next search on this lane starts with its filter instead of a memset launch.
+  DevBuf<uint8_t> d_ctl_twin;
+  int ctl_cur = 0;                         // 0: d_ctl, 1: d_ctl_twin holds the running search's control block
+  bool ctl_clean[2] = {false, false};      // the block's first 64 bytes are zero (cleared behind the previous search)
+  hipEvent_t ev_done = nullptr;            // recorded behind a search's last kernel, in front of the twin's clear
   DevBuf<uint32_t> d_flags;     // dense results: "does any record need the host's attention" (report_flags_kernel)
   DevBuf<Candidate> d_cand, d_sorted;
   DevBuf<MatchOut> d_trace;
@@ -411,19 +417,20 @@ struct ScanLane {
     HIP_TRY(hipEventCreate(&ev_c));
     HIP_TRY(hipEventCreate(&ev_f));
     HIP_TRY(hipEventCreateWithFlags(&ev_filter_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&ev_done, hipEventDisableTiming));
     ready = true;
     return 0;
   }
   void destroy() {
     if (h_up) (void)hipHostFree(h_up);
     h_up = nullptr; h_up_cap = h_up_used = 0;
-    d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release(); d_sort.release(); d_scratch2.release(); d_flags.release();
+    d_state.release(); d_scratch.release(); d_str.release(); d_ctl.release(); d_ctl_twin.release(); d_sort.release(); d_scratch2.release(); d_flags.release();
     for (unsigned char*& b : h_bulk) { if (b) (void)hipHostFree(b); b = nullptr; }
     d_cand.release(); d_sorted.release(); d_trace.release(); d_desc.release(); d_regions.release(); d_region_count.release(); d_carry.release();
     d_pattern.release(); d_table.release(); d_rowoff.release(); d_ovtab.release(); d_stash.release();
     if (h_pin) g_pin_pool.give(PinBlock{h_pin, h_pin_dev, h_pin_cap, h_pin_device});
     h_pin = nullptr;
-    for (hipEvent_t e : {ev_a, ev_b, ev_c, ev_f, ev_filter_done})
+    for (hipEvent_t e : {ev_a, ev_b, ev_c, ev_f, ev_filter_done, ev_done})
       if (e) (void)hipEventDestroy(e);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
   }
@@ -729,6 +736,9 @@ struct ScanJob {
   uint64_t rev_n = 0;
   hipEvent_t wait_for = nullptr;     // pipelining: the previous sub-shard's "filter done"
   bool signal_filter_done = false;   // pipelining: record L.ev_filter_done behind this filter
+  uint8_t* ctl_base = nullptr;       // this search's control block (the lane's d_ctl or its twin)
+  bool ctl_pre_cleared = false;      // ... whose first 64 bytes the previous search cleared
+  bool wait_ev_done = false;         // the host waits for L.ev_done (the twin's clear follows it in the stream)
   bool pipelined = false;            // one of several searches in flight (sassy_hip_search_shard_begin): the
                                      // bit-plane filter takes only half of a CU's wave slots, so that the previous
                                      // search's small tail kernels find room next to it

@@ -464,12 +464,22 @@ int ScanJob::prepare() {
   count_direct = filtered && fkind == kFilterCount && !rc_marked && !ext_bitmap && !ext_desc && sw.count_fused != 0 &&
                  sw.count_stage_blocks != 1 && n_blocks < 0xFFFFFFFFull && !no_fuse && L.fuse_backoff == 0;
   n_words = filtered && !count_direct ? (n_blocks + 63) / 64 : 0;
-  if (int rc = L.d_ctl.reserve(kCtlHead + (filtered && !ext_bitmap && !ext_desc && !count_direct ? (n_words + 2) * 8 : 0))) return rc;
-  d_bitmap = ext_bitmap ? ext_bitmap : reinterpret_cast<unsigned long long*>(L.d_ctl.p + kCtlHead);
+  {
+    // this search takes the lane's other control block (see ScanLane::d_ctl_twin)
+    L.ctl_cur ^= 1;
+    DevBuf<uint8_t>& C = L.ctl_cur ? L.d_ctl_twin : L.d_ctl;
+    const size_t cap0 = C.cap;
+    if (int rc = C.reserve(kCtlHead + (filtered && !ext_bitmap && !ext_desc && !count_direct ? (n_words + 2) * 8 : 0))) return rc;
+    if (C.cap != cap0) L.ctl_clean[L.ctl_cur] = false;  // (a new allocation)
+    ctl_base = C.p;
+    ctl_pre_cleared = L.ctl_clean[L.ctl_cur];
+    L.ctl_clean[L.ctl_cur] = false;  // (in use from here on)
+  }
+  d_bitmap = ext_bitmap ? ext_bitmap : reinterpret_cast<unsigned long long*>(ctl_base + kCtlHead);
   if (L.d_cand.cap == 0)
     if (int rc = L.d_cand.reserve(1u << 16)) return rc;
-  d_counts = reinterpret_cast<uint32_t*>(L.d_ctl.p);
-  d_counters = reinterpret_cast<unsigned long long*>(L.d_ctl.p + 16);
+  d_counts = reinterpret_cast<uint32_t*>(ctl_base);
+  d_counters = reinterpret_cast<unsigned long long*>(ctl_base + 16);
   P.row_tab = L.d_rowoff.p;
   P.cand_count = d_counts;
   P.counters = S->want_counters ? d_counters : nullptr;
@@ -788,7 +798,11 @@ int ScanJob::enqueue(int attempt) {
   // their reports themselves -- with the counting filter's own chunk list the whole clear is 64 bytes)
   const bool ranks_itself = S->sw.self_rank != 0 && do_trace && use_wave && texts.n == 0;
   const bool bitmap_here = filtered && !ext_bitmap && !ext_desc && !count_direct && attempt == 0;
-  HIP_TRY(hipMemsetAsync(L.d_ctl.p, 0, fused || (ranks_itself && !bitmap_here) ? 64 : kCtlHead + (bitmap_here ? (n_words + 2) * 8 : 0), L.stream));
+  const size_t clear_bytes = fused || (ranks_itself && !bitmap_here) ? 64 : kCtlHead + (bitmap_here ? (n_words + 2) * 8 : 0);
+  // (the previous search on this lane cleared the 64 bytes behind its last kernel: no memset launch in front of the filter)
+  if (!(ctl_pre_cleared && attempt == 0 && clear_bytes == 64)) HIP_TRY(hipMemsetAsync(ctl_base, 0, clear_bytes, L.stream));
+  ctl_pre_cleared = false;
+  wait_ev_done = false;
   if (ext_wait && attempt == 0) HIP_TRY(hipStreamWaitEvent(L.stream, ext_wait, 0));
   // pipelined sub-shards: this lane's filter starts when the previous sub-shard's filter is done,
   // so that the previous lane's DP / rank / traceback kernels overlap this bandwidth-bound one
@@ -916,7 +930,7 @@ int ScanJob::enqueue(int attempt) {
   const int env_selfrank = (int)S->sw.self_rank;
   self_rank = env_selfrank != 0 && do_trace && use_wave && texts.n == 0;
   if (!self_rank) {
-    le = launch_rank(L.d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(L.d_ctl.p + 64),
+    le = launch_rank(L.d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(ctl_base + 64),
                      L.d_sorted.p, reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands), host_cap,
                      L.h_pin_dev + kPinCounts, texts, L.stream);
     if (le != hipSuccess) return hip_fail(le, "rank kernel launch");
@@ -970,6 +984,18 @@ int ScanJob::enqueue(int attempt) {
     }
     if (timing >= 2) HIP_TRY(hipEventRecord(L.ev_c, L.stream));
   }
+  // the lane's other control block, for the next search: cleared behind this search's kernels; the host waits for the event
+  // in front of the clear
+  {
+    const int other = L.ctl_cur ^ 1;
+    DevBuf<uint8_t>& O = other ? L.d_ctl_twin : L.d_ctl;
+    if (S->sw.ctl_twin != 0 && !L.ctl_clean[other] && O.p != nullptr && O.cap >= 64) {
+      HIP_TRY(hipEventRecord(L.ev_done, L.stream));
+      HIP_TRY(hipMemsetAsync(O.p, 0, 64, L.stream));
+      L.ctl_clean[other] = true;
+      wait_ev_done = true;
+    }
+  }
   return 0;
 }
 
@@ -1006,7 +1032,8 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
   for (int attempt = 0;; ++attempt) {
     // the only synchronisation of the call; the kernels have written the results into h_pin
     const double t_sync0 = now_ms();
-    HIP_TRY(hipStreamSynchronize(L.stream));
+    if (wait_ev_done) HIP_TRY(hipEventSynchronize(L.ev_done));  // (the twin's clear may still run)
+    else HIP_TRY(hipStreamSynchronize(L.stream));
     const double t_sync1 = now_ms();
     S->stats.host_enqueue_ms += t_sync0 - t_mark;
     S->stats.host_wait_ms += t_sync1 - t_sync0;
@@ -1102,7 +1129,7 @@ int ScanJob::finish_once(ScanOut& out, bool& redo) {
             }
           }
         } else if (self_rank) {
-          le = launch_rank(L.d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(L.d_ctl.p + 64), L.d_sorted.p,
+          le = launch_rank(L.d_cand.p, d_counts, P.cand_cap, reinterpret_cast<uint32_t*>(ctl_base + 64), L.d_sorted.p,
                            reinterpret_cast<Candidate*>(L.h_pin_dev + pin_cands), std::min<uint32_t>(kSpec, P.cand_cap),
                            L.h_pin_dev + kPinCounts, texts, L.stream);
           if (le != hipSuccess) return hip_fail(le, "rank kernel launch");

@@ -19,6 +19,7 @@ namespace sassy_hip {
   X(pipe_depth, 2, "searches in flight per searcher (1 .. 4) for search_shard_begin / _finish")                          \
   X(tune, 0, "1: the on-line geometry tuner tries neighbouring lane-chunk lengths during a resident text's first searches") \
   X(timing, 1, "HIP-event timing: 0 none, 1 the dominant kernel, 2 every phase")                                            \
+  X(ctl_twin, 1, "a search clears the lane's other control block behind its last kernel, the next search starts without a memset launch (0: a memset in front of every search)") \
   X(row_cut, 1, "0: the DP kernels compute every pattern row of every block (no wave-voted stop)")                         \
   X(stage_blocks, 0, "streaming DP: text blocks per lane and staging step (1 / 2; 0 = default 1)")                         \
   X(filter_kind, 0, "force a prefilter kernel where it applies: 1 slot masks, 2 bit planes, 3 q-gram table, 4 q-gram counting") \

@@ -2880,7 +2880,7 @@ _FORCED = [
     # (round 6: the switches of csrc/switches.h that had no forced run)
     {"SASSY_HIP_PAIR_RC": "0", "SASSY_HIP_COMPACT_CIGARS": "0", "SASSY_HIP_ADOPT": "0", "SASSY_HIP_TRACE_THREADS": "256"},
     {"SASSY_HIP_FUSED_PROBE": "1", "SASSY_HIP_TRACE_PROBE": "1", "SASSY_HIP_TIMING": "2", "SASSY_HIP_TUNE": "1", "SASSY_HIP_PIPE_DEPTH": "3"},
-    {"SASSY_HIP_COUNT_FUSED": "0"},                  # the counting filter's classic chain: bitmap + build_chunks_kernel
+    {"SASSY_HIP_COUNT_FUSED": "0", "SASSY_HIP_CTL_TWIN": "0"},  # the counting filter's classic chain: bitmap + build_chunks_kernel; a memset in front of every search
 ]
 
 
