@@ -645,7 +645,7 @@ def dense_config(sassy_amd, text, pat, k):
 
 # lone searches of a fresh searcher settle over their first ~20 calls (0.79 -> 0.65 ms for config 3 on an MI355X that has just
 # run the planting kernels: clocks, not the library's state); the 20 timed calls follow that many untimed ones
-LONE_WARMUP = 25
+LONE_WARMUP = int(os.environ.get("BENCH_LONE_WARMUP", "25"))
 
 
 def other_configs(sassy_amd, text):
