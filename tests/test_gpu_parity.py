@@ -2371,12 +2371,18 @@ def test_bench_launches_its_own_ranks(sassy):
     # (two ranks sharing ONE GPU over gloo is a debugging configuration; it hung once in some forty runs of this suite --
     # never reproduced, 8 of 8 afterwards -- so a run that exceeds 300 s is started once more instead of costing the suite
     # its 900 s and its verdict; a second hang fails the test)
+    import signal
+    import types
     for attempt in (0, 1):
+        proc = subprocess.Popen([sys.executable, bench, "--gpus", "2", "--allow-shared-gpu"] + small, stdout=subprocess.PIPE,
+                                stderr=subprocess.PIPE, text=True, start_new_session=True)  # (its own process group: the ranks too)
         try:
-            p = subprocess.run([sys.executable, bench, "--gpus", "2", "--allow-shared-gpu"] + small,
-                               capture_output=True, text=True, timeout=300)
+            so, se = proc.communicate(timeout=300)
+            p = types.SimpleNamespace(returncode=proc.returncode, stdout=so, stderr=se)
             break
         except subprocess.TimeoutExpired:
+            os.killpg(proc.pid, signal.SIGKILL)  # (exactly the group this test started)
+            proc.communicate()
             if attempt == 1:
                 raise
             print("[test_bench_launches_its_own_ranks] the two-rank run exceeded 300 s: started once more", flush=True)
