@@ -675,6 +675,33 @@ def other_configs(sassy_amd, text):
     res["3"] = {"workload": f"Iupac new_fwd, |pattern|=200 (N, R, Y, W at 50/100/150/199), k=20, {n} B",
                 "ms_per_search": round(dt * 1e3, 3), "text_GB_per_s": round(n / dt / 1e9, 1), "matches": len(r),
                 "planted": int(planted3), "roofline_frac": round(n / dt / 1e9 / HBM_PEAK_GBPS, 4), "path": path3}
+    # ... and as a stream of searches, three in flight (what a pool of workers sees: bin/grep.rs:516-537), alternating between
+    # this pattern and a second one of the same shape with plants of its own -- a lane never meets the pattern it searched last
+    pb = bytearray(_dna_bytes(54, 0, 200))
+    pb[50], pb[100], pb[150], pb[199] = ord("N"), ord("R"), ord("Y"), ord("W")
+    plain_b = bytes({ord("N"): 65, ord("R"): 65, ord("Y"): 67, ord("W"): 65}.get(c, c) for c in pb)
+    shift_b = 3 << 18
+    planted3b = sassy_amd.plant(text.data_ptr() + shift_b, n - shift_b, 0, n - shift_b, 54, plain_b, 20, 1 << 20)
+    s3.set_pipe_depth(3)
+    pats3 = (bytes(p), bytes(pb))
+    pend, got = [], {}
+    def flight_step(i):
+        pend.append((i & 1, s3.search_shard_begin(pats3[i & 1], text.data_ptr(), 0, n, 0, n, 20)))
+        if len(pend) >= 3:
+            which, t = pend.pop(0)
+            got[which] = len(s3.search_finish(t))
+    for i in range(40):
+        flight_step(i)
+    t0 = time.perf_counter()
+    for i in range(40, 140):
+        flight_step(i)
+    while pend:
+        which, t = pend.pop(0)
+        got[which] = len(s3.search_finish(t))
+    dtf = (time.perf_counter() - t0) / 100
+    res["3"]["in_flight_3"] = {"what": "100 searches, three in flight, two patterns of this shape alternating (each with its own plants)",
+                               "ms_per_search": round(dtf * 1e3, 3), "roofline_frac": round(n / dtf / 1e9 / HBM_PEAK_GBPS, 4),
+                               "matches_per_pattern": [got.get(0), got.get(1)], "planted_second_pattern": int(planted3b)}
     # the reference's own benchmark shape (benches/perf.rs:46-48: |pattern| = 23, k = 3 -- every CRISPR guide 20 + PAM) and
     # m = 32 with k = 4: shapes whose k+1 pigeonhole pieces are 5 / 6 rows -- the paired filter's fused launch
     for name, profile, m_, k_ in (("m23k3", "dna", 23, 3), ("m23k3_iupac", "iupac", 23, 3), ("m32k4", "dna", 32, 4)):
