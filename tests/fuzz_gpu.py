@@ -219,10 +219,15 @@ def bytes_long_case(rng, searchers):
         profile = "ascii"
     else:
         m = rng.choice([1800, 2048, 2500, 3333, 4096, 5000])
+        beyond_lds = rng.random() < 0.06  # (round 6: per-row carries in global memory, beyond ~9 800 rows)
+        if beyond_lds:
+            m = rng.choice([9_900, 10_500, 12_000])
         profile = rng.choice(["dna", "iupac"])
         pat = rand_seq(rng, m, b"ACGT")
         k = rng.choice([0, 3, 10, 25, 40])
         n = rng.choice([m + 50, 20_000, 50_000])
+        if beyond_lds:
+            n = rng.choice([m + 50, 2 * m])
         text = bytearray(rand_seq(rng, n, b"ACGT"))
     for _ in range(rng.randrange(0, 4)):
         ins = mutate(rng, pat, rng.randrange(0, k + 2))
@@ -236,6 +241,49 @@ def bytes_long_case(rng, searchers):
     desc = dict(mode="bytes_long", profile=profile, m=m, k=k, n=n, rc=False, all_minima=False, filtered=s.stats()["filtered"],
                 matches=len(want))
     return key(got) == key(want), desc, pat, text, got, want
+
+
+def ovenc_case(rng, searchers):
+    """search_encoded_patterns of an OVERHANG searcher on one text (round 6: one pass -- the seeded search for the inside, edge
+    segments for the text's two ends; or a kernel chain per pattern where that does not apply): forward searchers against
+    oracle.search_overhang pattern by pattern, patterns hanging over both ends."""
+    m = rng.choice([12, 16, 20, 23, 24, 32, 40, 64])
+    k = min(rng.choice([0, 1, 2, 3, 4]), m // 5)
+    alpha = rng.choice([0.0, 0.25, 0.5, 0.5, 1.0])
+    mo = rng.choice([None, None, 0, 3, m // 2])
+    npat = rng.choice([1, 3, 4, 5, 9, 12])
+    pal = b"ACGT" if rng.random() < 0.7 else b"ACGTNRYW"
+    pats = [rand_seq(rng, m, pal) for _ in range(npat)]
+    n = rng.choice([m + k + 60, m + k + 65, 200, 3_000, 20_000, 60_000])
+    t = bytearray(rand_seq(rng, n, b"ACGT"))
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    for p in pats:
+        plain = bytes(c if c in b"ACGT" else 65 for c in p)
+        if rng.random() < 0.5:
+            cut = rng.randrange(1, m)
+            head = mutate(rng, plain, rng.randrange(0, 2))[cut:][:n]
+            t[:len(head)] = head
+        if rng.random() < 0.5:
+            cut = rng.randrange(1, m)
+            tail = mutate(rng, plain, rng.randrange(0, 2))[:cut][-n:]
+            t[n - len(tail):] = tail
+        if n > 4 * m:
+            ins = mutate(rng, plain, rng.randrange(0, k + 2))
+            at = rng.randrange(m, n - 2 * m)
+            t[at:at + len(ins)] = ins
+    if rng.random() < 0.15:  # a stray letter: the one pass declines, the chains run
+        t[rng.randrange(n)] = ord("N")
+    t = bytes(t[:n])
+    allm = rng.random() < 0.25
+    s = sassy_amd.Searcher("iupac", rc=False, alpha=alpha).with_max_overhang(mo)
+    got = s.search_encoded_patterns(s.encode_patterns(pats), t, k, all_minima=allm)
+    kk = lambda pi, x: (pi, x.text_start, x.text_end, x.pattern_start, x.pattern_end, x.cost, x.strand, x.cigar)
+    gk = sorted(kk(x.pattern_idx, x) for x in got)
+    wk = sorted(kk(pi, x) for pi, p in enumerate(pats)
+                for x in oracle.search_overhang("iupac", p, t, k, alpha, all_minima=allm, max_overhang=mo))
+    desc = dict(mode="ovenc", m=m, k=k, alpha=alpha, max_overhang=mo, npat=npat, n=n, all_minima=allm,
+                filtered=s.stats()["filtered"], matches=len(wk))
+    return gk == wk, desc, b"|".join(pats), t, gk, wk
 
 
 def count_case(rng, searchers):
@@ -552,7 +600,8 @@ def main():
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
     families = {"one": one_case, "fused": fused_case, "bytes_long": bytes_long_case, "count": count_case, "many": many_case,
-                "encoded": encoded_case, "shard": shard_case, "inflight": inflight_case, "reflanes": reflanes_case}
+                "encoded": encoded_case, "shard": shard_case, "inflight": inflight_case, "reflanes": reflanes_case,
+                "ovenc": ovenc_case}
     ap.add_argument("--focus", default="", choices=[""] + sorted(families),
                     help="one case family only (default: the mix); 'count': larger texts through the q-gram counting filter, both strands")
     args = ap.parse_args()
@@ -565,7 +614,7 @@ def main():
     total_matches = 0
     while time.time() - t0 < args.seconds:
         mode = rng.random()
-        fn = (one_case if mode < 0.4 else fused_case if mode < 0.52 else bytes_long_case if mode < 0.56 else many_case
+        fn = (one_case if mode < 0.37 else ovenc_case if mode < 0.4 else fused_case if mode < 0.52 else bytes_long_case if mode < 0.56 else many_case
               if mode < 0.66 else encoded_case if mode < 0.76 else shard_case if mode < 0.85 else inflight_case
               if mode < 0.93 else reflanes_case)
         if args.focus:

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:-.}"
 OUT=$1; PER=${2:-150}; MIX=${3:-600}
 { echo "# tests/fuzz_gpu.py against the oracle, $(git rev-parse --short HEAD 2>/dev/null || echo tree) -- family / seed: cases, matches compared, prefilter kinds";
   seed=60
-  for fam in one fused bytes_long count many encoded shard inflight reflanes; do
+  for fam in one fused bytes_long count many encoded shard inflight reflanes ovenc; do
     seed=$((seed + 1))
     echo "--focus $fam --seed $seed --seconds $PER: $(python tests/fuzz_gpu.py --focus $fam --seed $seed --seconds $PER 2>&1 | tail -1)"
   done
