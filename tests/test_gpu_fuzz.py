@@ -12,7 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAMILIES = ["one", "fused", "bytes_long", "count", "many", "encoded", "shard", "inflight", "reflanes", "ovenc"]
-SECONDS = 20  # per family: 10 families, ~3.5 minutes in all
+SECONDS = 15  # per family: 10 families, ~3 minutes in all (the driver gives the whole GPU suite 20 minutes)
 
 
 @pytest.mark.gpu
